@@ -1,0 +1,323 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures by importing the REAL reference from /root/reference (build container only).
+
+Nothing of the reference travels: the outputs are plain .npz files (inputs + expected outputs) under tests/golden/.
+Run:  python tests/golden/make_golden.py          (needs /root/reference; CPU only; ~1 min)
+
+Import-time stubs (never called on the path): cv2, yamlenv.  torchvision is absent from this image, so a *shim*
+module supplies ``torchvision.models.vgg19/vgg16`` with the standard cfg 'E'/'D' layout but channel widths divided by
+WIDTH_DIV (the real weight files are external downloads that do not exist here).  The reference's own
+PerceptualLoss code (normalisation, AvgPool substitution, 30-layer truncation, 13 L1 taps) runs unmodified on it.
+"""
+import os
+import sys
+import types
+import copy
+import argparse
+
+import numpy as np
+import torch
+from torch import nn
+
+REF = '/root/reference'
+OUT = os.path.dirname(os.path.abspath(__file__))
+WIDTH_DIV = 16
+
+# ---- import-time stubs -------------------------------------------------------------------------------------------
+for name in ('cv2', 'yamlenv'):
+    sys.modules.setdefault(name, types.ModuleType(name))
+sys.modules['cv2'].setNumThreads = lambda *_: None
+sys.modules['cv2'].ocl = types.SimpleNamespace(setUseOpenCL=lambda *_: None)
+
+tv = types.ModuleType('torchvision')
+tv.models = types.ModuleType('torchvision.models')
+
+
+def _vgg(cfg):
+    layers, cin = [], 3
+    for v in cfg:
+        if v == 'M':
+            layers.append(nn.MaxPool2d(2, 2))
+        else:
+            v = v // WIDTH_DIV
+            layers += [nn.Conv2d(cin, v, 3, padding=1), nn.ReLU(inplace=True)]
+            cin = v
+
+    class VGG(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.features = nn.Sequential(*layers)
+            self.classifier = nn.Sequential(nn.Linear(8, 8), nn.ReLU(True), nn.Dropout(), nn.Linear(8, 8), nn.ReLU(True),
+                                            nn.Dropout(), nn.Linear(8, 4))
+    return VGG()
+
+
+CFG_E = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512, 512, 'M', 512, 512, 512, 512, 'M']
+CFG_D = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512, 'M']
+tv.models.vgg19 = lambda *a, **k: _vgg(CFG_E)
+tv.models.vgg16 = lambda *a, **k: _vgg(CFG_D)
+sys.modules['torchvision'] = tv
+sys.modules['torchvision.models'] = tv.models
+
+sys.path.insert(0, REF)
+os.chdir(REF)
+
+from generators.common import blocks as ref_blocks                                        # noqa: E402
+from generators import vector_pose_unsupervised_segmentation_noBottleneck as ref_gen     # noqa: E402
+from discriminators import no_landmarks as ref_dis                                        # noqa: E402
+from criterions import adversarial as ref_adv, featmat as ref_fm, dice as ref_dice, dis_embed as ref_de  # noqa: E402
+
+
+def npy(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def sd_np(module, prefix):
+    return {f'{prefix}{k}': npy(v) for k, v in module.state_dict().items()}
+
+
+SMALL = dict(image_size=32, num_channels=4, max_num_channels=16, embed_channels=8, pose_embedding_size=4,
+             in_channels=3, out_channels=3, num_labels=5, dis_num_blocks=5)
+
+
+def small_args():
+    a = argparse.Namespace(**SMALL)
+    a.gen_padding = 'zero'; a.norm_layer = 'in'; a.gen_constant_input_size = 4; a.gen_num_residual_blocks = 2
+    a.dis_padding = 'zero'; a.device = 'cpu'
+    return a
+
+
+# ---- A. per-op fixtures ----------------------------------------------------------------------------------------------
+def make_ops():
+    torch.manual_seed(1)
+    out = {}
+    # AdaptiveNorm2d + ReLU
+    m = ref_blocks.AdaptiveNorm2d(6, 'in')
+    x = torch.randn(2, 6, 5, 7) * 2 + 0.5
+    g, b = torch.randn(2, 6), torch.randn(2, 6)
+    m.weight, m.bias = g, b
+    out.update(adain_x=npy(x), adain_gamma=npy(g), adain_beta=npy(b), adain_out=npy(torch.relu(m(x))))
+
+    # spectral-norm power-iteration sequence over 3 train forwards of one conv
+    conv = torch.nn.utils.spectral_norm(nn.Conv2d(6, 8, 3, 1, 1, bias=False), eps=1e-4)
+    out.update(sn_w=npy(conv.weight_orig), sn_u0=npy(conv.weight_u), sn_v0=npy(conv.weight_v))
+    conv.train()
+    xin = torch.randn(1, 6, 4, 4)
+    for i in range(3):
+        conv(xin)
+        out[f'sn_u{i + 1}'] = npy(conv.weight_u)
+        out[f'sn_v{i + 1}'] = npy(conv.weight_v)
+        out[f'sn_weff{i + 1}'] = npy(conv.weight)
+    conv.eval()
+    conv(xin)
+    out['sn_weff_eval'] = npy(conv.weight)
+
+    # ResBlocks: ada (same res), ada up (6->4), none down (4->6), none same-channels no-down (6->6)
+    for tag, cin, cout, up, down, norm in (('rb_ada', 6, 6, False, False, 'adain'), ('rb_up', 6, 4, True, False, 'adain'),
+                                           ('rb_down', 4, 6, False, True, 'none'), ('rb_none', 6, 6, False, False, 'none')):
+        blk = ref_blocks.ResBlock(cin, cout, nn.ZeroPad2d, upsample=up, downsample=down, norm_layer=norm)
+        blk.train()
+        out.update(sd_np(blk, f'{tag}.'))   # state BEFORE the forward (u/v pre power iteration)
+        x = (torch.randn(2, cin, 8, 8)).requires_grad_(True)
+        params = {}
+        if norm == 'adain':
+            ads = [mm for mm in blk.modules() if mm.__class__.__name__ == 'AdaptiveNorm2d']
+            for j, (ad, c) in enumerate(zip(ads, (cin, cout))):
+                gg = torch.randn(2, c).requires_grad_(True)
+                bb = torch.randn(2, c).requires_grad_(True)
+                ad.weight, ad.bias = gg, bb
+                params[f'g{j}'], params[f'b{j}'] = gg, bb
+        x_in = x.clone()     # the 'none' block mutates its input in place
+        y = blk(x_in)
+        gy = torch.randn_like(y)
+        y.backward(gy)
+        out.update({f'{tag}.x': npy(x), f'{tag}.y': npy(y), f'{tag}.gy': npy(gy), f'{tag}.gx': npy(x.grad),
+                    f'{tag}.x_after': npy(x_in)})
+        for k, v in params.items():
+            out[f'{tag}.{k}'] = npy(v)
+            out[f'{tag}.grad_{k}'] = npy(v.grad)
+        for k, p in blk.named_parameters():
+            out[f'{tag}.grad.{k}'] = npy(p.grad)
+        for k, v in blk.state_dict().items():
+            if k.endswith('_u') or k.endswith('_v'):
+                out[f'{tag}.after.{k}'] = npy(v)
+    np.savez_compressed(os.path.join(OUT, 'ops_small.npz'), **out)
+    print('ops_small.npz', len(out), 'arrays')
+
+
+# ---- B. generator ----------------------------------------------------------------------------------------------------
+def make_generator():
+    torch.manual_seed(2)
+    args = small_args()
+    G = ref_gen.Wrapper.get_net(args)
+    # make the learned constant non-trivial (its init is all-ones, which InstanceNorm maps to zero)
+    with torch.no_grad():
+        G.constant.constant.copy_(torch.randn_like(G.constant.constant))
+    out = dict(cfg=np.array([args.image_size, args.num_channels, args.max_num_channels, args.embed_channels,
+                             args.pose_embedding_size]))
+    out.update(sd_np(G, 'sd.'))
+    embeds = torch.randn(2, args.embed_channels).requires_grad_(True)
+    pose = torch.randn(2, args.pose_embedding_size).requires_grad_(True)
+    r1, r2 = torch.randn(2, 3, 32, 32), torch.randn(2, 1, 32, 32)
+    out.update(embeds=npy(embeds), pose=npy(pose), r1=npy(r1), r2=npy(r2))
+
+    # eval forward (no power iteration)
+    Ge = copy.deepcopy(G).eval()
+    dd = dict(embeds=embeds, pose_embedding=pose)
+    Ge(dd)
+    out.update(eval_fake_rgbs=npy(dd['fake_rgbs']), eval_fake_segm=npy(dd['fake_segm']))
+
+    # affine-param slice order probe (noBottleneck.py:108-125)
+    with torch.no_grad():
+        Gp = copy.deepcopy(G)
+        n_aff = Gp.get_num_affine_params()
+        Gp.assign_affine_params(torch.arange(n_aff, dtype=torch.float32)[None])
+        out['affine_first_bias'] = np.array([float(mm.bias[0, 0]) for mm in Gp.adains])
+        out['affine_first_weight'] = np.array([float(mm.weight[0, 0]) for mm in Gp.adains])
+
+    # train forward + backward
+    G.train()
+    dd = dict(embeds=embeds, pose_embedding=pose)
+    G(dd)
+    loss = (dd['fake_rgbs'] * r1).sum() + (dd['fake_segm'] * r2).sum()
+    loss.backward()
+    out.update(train_fake_rgbs=npy(dd['fake_rgbs']), train_fake_segm=npy(dd['fake_segm']),
+               grad_embeds=npy(embeds.grad), grad_pose=npy(pose.grad))
+    for k, p in G.named_parameters():
+        out[f'grad.{k}'] = npy(p.grad)
+    out.update({k: v for k, v in sd_np(G, 'sd_after.').items() if k.endswith('_u') or k.endswith('_v')})
+
+    # finetuning mode: identity_embedding becomes a parameter (noBottleneck.py:139-163)
+    Gf = ref_gen.Wrapper.get_net(args)      # (deepcopy of a forwarded SN module is not supported by torch)
+    Gf.load_state_dict(G.state_dict())
+    Gf.train()
+    e_hat = torch.randn(1, args.embed_channels)
+    Gf.enable_finetuning({'embeds': e_hat.clone()})
+    out['ft_identity'] = npy(e_hat)   # starting state of this run = 'sd.' weights with 'sd_after.' u/v buffers
+    pose2 = pose.detach().clone().requires_grad_(True)
+    dd = dict(pose_embedding=pose2)
+    Gf(dd)
+    loss = (dd['fake_rgbs'] * r1).sum() + (dd['fake_segm'] * r2).sum()
+    loss.backward()
+    out.update(ft_fake_rgbs=npy(dd['fake_rgbs']), ft_fake_segm=npy(dd['fake_segm']),
+               ft_grad_identity=npy(Gf.identity_embedding.grad), ft_grad_pose=npy(pose2.grad))
+    np.savez_compressed(os.path.join(OUT, 'generator_small.npz'), **out)
+    print('generator_small.npz', len(out), 'arrays; G params', sum(p.numel() for p in G.parameters()))
+
+
+# ---- C/D. discriminator + cheap criterions -------------------------------------------------------------------------
+def make_discriminator():
+    torch.manual_seed(3)
+    args = small_args()
+    D = ref_dis.Wrapper.get_net(args)
+    D.train()
+    out = dict(cfg=np.array([args.image_size, args.dis_num_blocks, args.num_labels]))
+    out.update(sd_np(D, 'sd.'))
+    fake = torch.rand(2, 3, 32, 32).requires_grad_(True)
+    real = torch.rand(2, 1, 3, 32, 32)
+    label = torch.tensor([3, 1])
+    dd = dict(fake_rgbs=fake, target_rgbs=real, label=label)
+    D(dd)
+    out.update(fake=npy(fake), real=npy(real), label=label.numpy())
+    for k in ('fake_score_G', 'fake_score_D', 'real_score', 'real_embedding'):
+        out[k] = npy(dd[k])
+    for i, (f, r) in enumerate(zip(dd['fake_features'], dd['real_features'])):
+        out[f'fake_feat{i}'] = npy(f)
+        out[f'real_feat{i}'] = npy(r)
+    # criterions on top
+    dd['fake_segm'] = torch.rand(2, 1, 32, 32).requires_grad_(True)
+    dd['real_segm'] = torch.rand(2, 1, 1, 32, 32).expand(2, 1, 3, 32, 32)
+    dd['embeds_elemwise'] = torch.randn(2, 8, args.embed_channels).requires_grad_(True)
+    out.update(fake_segm=npy(dd['fake_segm']), real_segm=npy(dd['real_segm']), embeds_elemwise=npy(dd['embeds_elemwise']))
+    lg, ld = ref_adv.Criterion('gan')(dd)
+    fm = ref_fm.Criterion(10.0)(dd)
+    dc = ref_dice.Criterion(1.0)(dd)
+    de = ref_de.Criterion(1e-2)(dd)
+    out.update(loss_adv_G=npy(lg['adversarial_G']), loss_adv_D=npy(ld['adversarial_D']),
+               loss_fm=npy(fm['feature_matching']), loss_dice=npy(dc['segmentation_dice']),
+               loss_dis_embed=npy(de['embedding_matching']))
+    loss_G = lg['adversarial_G'] + fm['feature_matching'] + dc['segmentation_dice'] + de['embedding_matching']
+    loss_D = ld['adversarial_D']
+    loss_G.backward(retain_graph=True)
+    out.update(gG_fake=npy(fake.grad), gG_fake_segm=npy(dd['fake_segm'].grad), gG_elemwise=npy(dd['embeds_elemwise'].grad))
+    for k, p in D.named_parameters():
+        out[f'gradG.{k}'] = npy(p.grad)
+    D.zero_grad()
+    loss_D.backward()
+    for k, p in D.named_parameters():
+        out[f'gradD.{k}'] = npy(p.grad)
+    out.update(sd_np(D, 'sd_after.'))
+    # finetuning variant of the embedding (no_landmarks.py:110-136): 1 x E matrix with default SN eps
+    Df = ref_dis.Wrapper.get_net(args)
+    Df.load_state_dict(D.state_dict())
+    Df.train()
+    e_hat = torch.randn(1, args.embed_channels)
+    Df.enable_finetuning({'embeds': e_hat.clone()})
+    out.update(sd_np(Df, 'ft_sd.'))
+    dd2 = dict(fake_rgbs=fake.detach(), target_rgbs=real, label=torch.zeros(2, dtype=torch.long))
+    Df(dd2)
+    out.update(ft_fake_score_G=npy(dd2['fake_score_G']), ft_real_score=npy(dd2['real_score']),
+               ft_real_embedding=npy(dd2['real_embedding']))
+    np.savez_compressed(os.path.join(OUT, 'discriminator_small.npz'), **out)
+    print('discriminator_small.npz', len(out), 'arrays; D params', sum(p.numel() for p in D.parameters()))
+
+
+# ---- E. perceptual (narrow VGG shim) + crop ------------------------------------------------------------------------
+def make_perceptual():
+    torch.manual_seed(4)
+    from criterions.common import perceptual_loss as ref_pl
+    from criterions import idt_embed as ref_idt
+    out = dict(width_div=np.array(WIDTH_DIV))
+    holder = {}
+    real_load = torch.load
+
+    def fake_load(path, *a, **k):
+        name = os.path.basename(str(path))
+        torch.manual_seed(100 if 'vgg19' in name else 200)
+        if 'vgg19' in name:
+            net = _vgg(CFG_E)
+            ren = {'classifier.0': 'classifier.1', 'classifier.3': 'classifier.4'}   # caffe-converted file's key names
+            sd = {ren.get(k2.rsplit('.', 1)[0], k2.rsplit('.', 1)[0]) + '.' + k2.rsplit('.', 1)[1]:
+                  torch.randn_like(v) * (0.35 if v.dim() > 1 else 0.1) for k2, v in net.state_dict().items()}
+        else:
+            net = _vgg(CFG_D).features
+            sd = {k2: torch.randn_like(v) * (0.35 if v.dim() > 1 else 0.1) for k2, v in net.state_dict().items()}
+        holder[name] = sd
+        return sd
+    torch.load = fake_load
+    try:
+        p19 = ref_pl.PerceptualLoss(3e-2, '/nonexistent', net='caffe').eval()
+        pface = ref_idt.Criterion(6e-3, '/nonexistent')
+    finally:
+        torch.load = real_load
+    for k, v in holder['vgg19-d01eb7cb.pth'].items():
+        if k.startswith('features.'):
+            out['vgg19.' + k[len('features.'):]] = npy(v)
+    for k, v in holder['vgg_face_weights.pth'].items():
+        out['vggface.' + k] = npy(v)
+    fake = (torch.rand(2, 3, 32, 32)).requires_grad_(True)
+    real = torch.rand(2, 3, 32, 32)
+    l19 = p19(fake, real)
+    l19.backward()
+    out.update(fake=npy(fake), real=npy(real), loss_vgg19=npy(l19), grad_vgg19=npy(fake.grad))
+    fake.grad = None
+    lf = pface({'fake_rgbs': fake, 'target_rgbs': real})['VGGFace']
+    lf.backward()
+    out.update(loss_vggface=npy(lf), grad_vggface=npy(fake.grad))
+    # crop_and_resize alone at two sizes
+    t, l = 32 * (1 - 1 / 1.8) / 2, 32 * (1 - 1 / 1.8) / 2
+    bb = torch.tensor([[t, 32 - t, l, 32 - l]]).expand(2, 4)
+    out['crop32'] = npy(ref_idt.crop_and_resize(real, bb))
+    x48 = torch.rand(1, 2, 48, 48)
+    t = 48 * (1 - 1 / 1.8) / 2
+    out['crop48_in'] = npy(x48)
+    out['crop48'] = npy(ref_idt.crop_and_resize(x48, torch.tensor([[t, 48 - t, t, 48 - t]])))
+    np.savez_compressed(os.path.join(OUT, 'perceptual_small.npz'), **out)
+    print('perceptual_small.npz', len(out), 'arrays')
+
+
+if __name__ == '__main__':
+    torch.set_num_threads(1)
+    which = sys.argv[1:] or ['ops', 'generator', 'discriminator', 'perceptual']
+    for w in which:
+        globals()['make_' + w]()
