@@ -1,0 +1,87 @@
+/* lp_hip.h -- C ABI of the MI355X (gfx950) latent-pose hot-path kernels.
+ *
+ * Drop-in boundary: the reference has no native layer -- its hot path is ATen calls issued from
+ * Python nn.Modules (generators/common/blocks.py, generators/vector_pose_unsupervised_segmentation_noBottleneck.py).
+ * Each entry point below replaces the group of ATen calls named in its comment.  Conventions:
+ *   - plain C: raw DEVICE pointers, explicit int sizes, scalar hyper-parameters, a hipStream_t passed as void*;
+ *   - the caller (PyTorch) owns every buffer, including scratch; nothing is allocated or freed here;
+ *   - all work is enqueued asynchronously on `stream`; no hidden synchronisation, no global mutable state;
+ *   - return value 0 = ok, negative = LP_ERR_*; lp_last_error() gives a thread-local message;
+ *   - activations are NHWC fp32 (torch channels_last storage), weights are the packed bf16 images produced by
+ *     lp_pack_weights; `prec` selects LP_PREC_BF16 (1 MFMA / k-step) or LP_PREC_BF16X3 (hi+lo split, fp32-class).
+ */
+#ifndef LP_HIP_H
+#define LP_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LP_OK 0
+#define LP_ERR_ARG (-1)
+#define LP_ERR_UNSUPPORTED (-2)
+#define LP_ERR_HIP (-3)
+
+#define LP_PREC_BF16 0
+#define LP_PREC_BF16X3 1
+
+const char* lp_last_error(void);
+int lp_abi_version(void);
+
+/* Re-layout + bf16 split of a conv/linear weight.  w: fp32 [Cout][Cin][T] (reference nn.Conv2d layout, T = k*k).
+ * mode 0 (forward):  out[t][co][ci] = w[co][ci][t]            rows padded to CoutP (x128), cols to CinP (x32)
+ * mode 1 (dgrad):    out[T-1-t][ci][co] = w[co][ci][t]        rows = Cin padded to RowsP, cols = Cout padded to ColsP
+ * hi/lo: bf16 images, lo = bf16(w - hi) (may be NULL).  Replaces nothing in the reference (cuDNN does this internally). */
+int lp_pack_weights(const float* w, uint16_t* hi, uint16_t* lo, int Cout, int Cin, int T, int RowsP, int ColsP, int mode, void* stream);
+
+/* Fused conv: y = alpha * conv_{k x k, pad k/2}( up2?( act(x) ) , w ) + bias + res
+ * Replaces, per conv of blocks.ResBlock (generators/common/blocks.py:70-111): instance_norm + mul + add (AdaptiveNorm2d,
+ * blocks.py:18-26) + relu + nn.Upsample(nearest x2) + F.conv2d + W/sigma scaling (spectral_norm) + residual add.
+ *   x [N][H/(up?2:1)][W/(up?2:1)][Cin], y [N][H][W][Cout], scale/shift [N][Cin] (pro=1), bias [Cout]|NULL,
+ *   res [N][H>>res_shift][W>>res_shift][Cout]|NULL, alpha device scalar|NULL (=1).
+ *   pro: 0 identity, 1 relu(x*scale+shift), 2 relu(x).  ksize 1|3.  Also the dgrad kernel (dY in, mode-1 pack). */
+int lp_conv_fwd(const float* x, const uint16_t* w_hi, const uint16_t* w_lo, float* y,
+                const float* scale, const float* shift, const float* bias, const float* res, const float* alpha,
+                int N, int H, int W, int Cin, int Cout, int CinP, int CoutP,
+                int ksize, int upsample, int pro, int res_shift, int prec, void* stream);
+
+/* Weight gradient: dw[co][ci][t] = sum_{n,y,x} dy[n,y,x,co] * up2?(act(x))[n,y+dy_t,x+dx_t,ci]  (autograd of F.conv2d
+ * w.r.t. weight, blocks.py:76-88).  Two launches: partial slabs over `splits` pixel ranges, then a reduction that also
+ * writes the reference [Cout][Cin][k][k] layout.  workspace: lp_conv_wgrad_workspace_bytes(). */
+long long lp_conv_wgrad_workspace_bytes(int Cin, int Cout, int ksize, int splits);
+int lp_conv_wgrad(const float* x, const float* dy, float* dw, float* workspace,
+                  const float* scale, const float* shift,
+                  int N, int H, int W, int Cin, int Cout, int ksize, int upsample, int pro, int splits, int prec, void* stream);
+
+/* Instance-norm statistics of x [N][H*W][C] and the AdaIN scale/shift derived from them (blocks.py:18-26):
+ *   mean/rstd [N][C] (biased variance, eps), scale = rstd*gamma, shift = beta - mean*scale.
+ * gamma/beta [N][C] with row stride `ab_stride` floats (they are slices of the projector output, noBottleneck.py:108-125).
+ * workspace: lp_instnorm_workspace_bytes(). */
+long long lp_instnorm_workspace_bytes(int N, int HW, int C);
+int lp_instnorm_stats(const float* x, const float* gamma, const float* beta, int ab_stride, float eps,
+                      float* mean, float* rstd, float* scale, float* shift, float* workspace,
+                      int N, int HW, int C, void* stream);
+
+/* Backward of relu(AdaIN(x)) [+ nearest x2 upsample]: (autograd of blocks.py:18-26,73-75)
+ *   g = sum2x2?(dA) * [x*scale+shift > 0];  dgamma = sum g*xhat;  dbeta = sum g;
+ *   dx = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat)) (+ add)
+ * dA [N][H<<up][W<<up][C], x/dx/add [N][H][W][C], dgamma/dbeta [N][C] with row stride ab_stride (written, not accumulated).
+ * workspace: lp_adain_bwd_workspace_bytes(). */
+long long lp_adain_bwd_workspace_bytes(int N, int HW, int C);
+int lp_adain_relu_bwd(const float* dA, const float* x, const float* add, const float* gamma, int ab_stride,
+                      const float* mean, const float* rstd, const float* scale, const float* shift,
+                      float* dx, float* dgamma, float* dbeta, float* workspace,
+                      int N, int H, int W, int C, int upsample, void* stream);
+
+/* out[n,y,x,c] = sum of the 2x2 block of in[n,2y..2y+1,2x..2x+1,c]  (adjoint of nearest x2 upsampling, blocks.py:95). */
+int lp_sum2x2(const float* in, float* out, int N, int H, int W, int C, void* stream);
+
+/* Generator head (noBottleneck.py:86-88,170-181): t = tanh(z), rgb = t[:3]*0.75+0.5, segm = t[3]*0.5+0.5,
+ * fake_rgbs = rgb*segm.  z/t NHWC [N][H][W][4]; fake_rgbs NCHW [N][3][H][W]; fake_segm NCHW [N][1][H][W]. */
+int lp_head_fwd(const float* z, float* t, float* fake_rgbs, float* fake_segm, int N, int H, int W, void* stream);
+int lp_head_bwd(const float* t, const float* d_rgbs, const float* d_segm, float* dz, int N, int H, int W, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

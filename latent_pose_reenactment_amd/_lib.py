@@ -1,0 +1,56 @@
+"""ctypes binding of liblp_hip.so (C ABI declared in include/lp_hip.h).
+
+There is deliberately NO fallback: if the library is missing or a call fails, an exception is raised."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'liblp_hip.so')
+
+PREC_BF16 = 0
+PREC_BF16X3 = 1
+
+_vp, _i, _f, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong
+
+# name -> (restype, argtypes); must list every symbol of include/lp_hip.h (tests/test_abi.py checks this)
+SIGNATURES = {
+    'lp_last_error': (ctypes.c_char_p, []),
+    'lp_abi_version': (_i, []),
+    'lp_pack_weights': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'lp_conv_fwd': (_i, [_vp] * 9 + [_i] * 12 + [_vp]),
+    'lp_conv_wgrad_workspace_bytes': (_ll, [_i, _i, _i, _i]),
+    'lp_conv_wgrad': (_i, [_vp] * 6 + [_i] * 10 + [_vp]),
+    'lp_instnorm_workspace_bytes': (_ll, [_i, _i, _i]),
+    'lp_instnorm_stats': (_i, [_vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'lp_adain_bwd_workspace_bytes': (_ll, [_i, _i, _i]),
+    'lp_adain_relu_bwd': (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'lp_sum2x2': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    'lp_head_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'lp_head_bwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+}
+
+_lib = None
+
+
+class LpError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LpError(f'{LIB_PATH} is missing: run `python -m latent_pose_reenactment_amd.build` '
+                          '(or __graft_entry__.build()); there is no fallback path')
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().lp_last_error()
+        raise LpError(f'{what} failed (rc={rc}): {msg.decode() if msg else ""}')

@@ -1,0 +1,56 @@
+"""Build liblp_hip.so (hand-written HIP kernels for gfx950) in-tree with hipcc.  No JIT, no torch extension machinery:
+the product is a plain C-ABI shared library (include/lp_hip.h) that travels with the source tree."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+INCLUDE = os.path.join(os.path.dirname(HERE), 'include')
+LIB = os.path.join(HERE, 'liblp_hip.so')
+SOURCES = ['lp_api.hip', 'elementwise.hip', 'conv_igemm.hip', 'conv_wgrad.hip']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I', INCLUDE, '-I', CSRC]
+
+
+def _newer(a, b):
+    return not os.path.exists(b) or os.path.getmtime(a) > os.path.getmtime(b)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    objdir = os.path.join(HERE, 'build')
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')] + [os.path.join(INCLUDE, 'lp_hip.h')]
+    jobs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(objdir, src.replace('.hip', '.o'))
+        if force or _newer(s, o) or any(_newer(h, o) for h in headers):
+            jobs.append((s, o))
+
+    def compile_one(job):
+        s, o = job
+        cmd = [hipcc] + FLAGS + ['-c', s, '-o', o]
+        if verbose:
+            print('[lp build]', ' '.join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f'hipcc failed for {s}:\n{r.stderr}')
+        return o
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(compile_one, jobs))
+    objs = [os.path.join(objdir, s.replace('.hip', '.o')) for s in SOURCES]
+    if jobs or not os.path.exists(LIB):
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+        if verbose:
+            print('[lp build]', ' '.join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f'link failed:\n{r.stderr}')
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv))

@@ -1,0 +1,241 @@
+// Weight-gradient of the fused conv for gfx950:
+//   dw[co][ci][tap] = sum_{n,y,x} dy[n,y,x,co] * up2?(act(x))[n, y+dy_t, x+dx_t, ci]
+// GEMM view: M = co, N = ci (per tap), K = pixels.  Both operands are pixel-major in HBM (NHWC), i.e. K is the slow
+// dimension of both -> the MFMA fragments (8 consecutive k per lane) are fetched from [pixel][channel] LDS tiles with
+// ds_read_b64_tr_b16 (gfx950 transposing LDS read; lane/element mapping verified by probes/probe_layout.hip):
+//   within a 16-lane group, lane i / element j receives the data of source lane 4j+(i>>2), element i&3; so source lane
+//   s = 4j+q must point at &tile[pixel_j][c0 + 4q] and lane i ends up with channel c0+i for the pixels 0..3.
+// One workgroup owns a 64(co) x 64(ci) x all-taps slab and walks a strided subset of the 128-pixel tiles (split-K);
+// the activated input halo and the dy tile are staged once per tile and reused by all taps.
+#include "lp_common.h"
+#include "lp_hip.h"
+#include "lp_internal.h"
+
+struct WgradParams {
+    const float* x; const float* dy; float* part;
+    const float* scale; const float* shift;
+    int N, H, W, Hin, Win, Cin, Cout, CoP, CiP;
+    int pro, splits, num_tiles;
+    int lTH, lTW, lNB, tiles_x, tiles_y;
+};
+
+typedef s16x4_t __attribute__((address_space(3))) * lds_s16x4_ptr;
+
+__device__ __forceinline__ s16x4_t tr_read(const unsigned char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(uintptr_t)p);
+}
+
+template <int KS, bool UPS, int PREC>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
+    constexpr bool SPLIT = (PREC == LP_PREC_BF16X3);
+    constexpr int T = KS * KS;
+    constexpr int CC = 64;
+    constexpr int SA = CC * 2 + 16, SD = 64 * 2 + 16;
+    constexpr int BMP = 128;                       // pixels per tile (k extent per stage)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int mh = wave >> 1, nh = wave & 1;       // wave -> 32(co) x 32(ci) sub-block
+    const int TH = 1 << p.lTH, TW = 1 << p.lTW, NBv = 1 << p.lNB;
+    const int co0 = blockIdx.y * 64, ci0 = blockIdx.z * 64;
+
+    int HH, HW;
+    if (KS == 1) { HH = TH; HW = TW; } else if (UPS) { HH = (TH >> 1) + 2; HW = (TW >> 1) + 2; } else { HH = TH + 2; HW = TW + 2; }
+    const int a_bytes = NBv * HH * HW * SA;
+    unsigned char* A_hi = smem;
+    unsigned char* A_lo = smem + a_bytes;
+    unsigned char* D_hi = smem + (SPLIT ? 2 : 1) * a_bytes;
+    unsigned char* D_lo = D_hi + BMP * SD;
+
+    f32x4_t acc[T][2][2];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[t][i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // source-lane role for the transposing reads
+    const int G = lane >> 4, sj = (lane & 15) >> 2, sq = lane & 3;
+
+    for (int tile = blockIdx.x; tile < p.num_tiles; tile += p.splits) {
+        int t = tile;
+        const int tx = t % p.tiles_x; t /= p.tiles_x;
+        const int ty = t % p.tiles_y; const int ng = t / p.tiles_y;
+        const int n0 = ng << p.lNB, y0 = ty << p.lTH, x0 = tx << p.lTW;
+        int oy, ox;
+        if (KS == 1) { oy = y0; ox = x0; } else if (UPS) { oy = (y0 >> 1) - 1; ox = (x0 >> 1) - 1; } else { oy = y0 - 1; ox = x0 - 1; }
+
+        __syncthreads();                 // previous tile fully consumed
+        stage_act_halo<CC, SPLIT>(A_hi, A_lo, SA, p.x, p.scale, p.shift, p.pro, p.N, p.Hin, p.Win, p.Cin,
+                                  n0, NBv, HH, HW, oy, ox, ci0, tid);
+        // dy tile: [128 pixels (row-major in patch)][64 co] -> bf16
+        for (int i = tid; i < BMP * 8; i += 256) {
+            int cg = i & 7, kp = i >> 3;
+            int nb, py, px;
+            tile_lin_decode(kp, p.lTH, p.lTW, nb, py, px);
+            int n = n0 + nb, yy = y0 + py, xx = x0 + px, c = co0 + cg * 8;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = 0.f;
+            if (n < p.N && yy < p.H && xx < p.W && c < p.Cout) {
+                const float* src = p.dy + ((size_t)(n * p.H + yy) * p.W + xx) * p.Cout + c;
+                if ((p.Cout & 3) == 0 && c + 8 <= p.Cout) {
+                    float4 p0 = *(const float4*)src, p1 = *(const float4*)(src + 4);
+                    v[0] = p0.x; v[1] = p0.y; v[2] = p0.z; v[3] = p0.w; v[4] = p1.x; v[5] = p1.y; v[6] = p1.z; v[7] = p1.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) if (c + j < p.Cout) v[j] = src[j];
+                }
+            }
+            s16x8_t hi, lo;
+            cvt8<SPLIT>(v, hi, lo);
+            *(s16x8_t*)(D_hi + kp * SD + cg * 16) = hi;
+            if (SPLIT) *(s16x8_t*)(D_lo + kp * SD + cg * 16) = lo;
+        }
+        __syncthreads();
+
+#pragma unroll 1
+        for (int ks = 0; ks < BMP / 32; ++ks) {
+            // this lane (as a SOURCE lane) serves pixel kp(h) = ks*32 + h*16 + G*4 + sj for the two halves h
+            int kp0 = ks * 32 + G * 4 + sj, kp1 = kp0 + 16;
+            int nb0, py0, px0, nb1, py1, px1;
+            tile_lin_decode(kp0, p.lTH, p.lTW, nb0, py0, px0);
+            tile_lin_decode(kp1, p.lTH, p.lTW, nb1, py1, px1);
+            // A operand (dy): fragments mf = 0,1 -> co = mh*32 + mf*16 + ...
+            s16x8_t a[2], al[2];
+#pragma unroll
+            for (int mf = 0; mf < 2; ++mf) {
+                int coff = (mh * 32 + mf * 16 + 4 * sq) * 2;
+                s16x4_t v0 = tr_read(D_hi + kp0 * SD + coff), v1 = tr_read(D_hi + kp1 * SD + coff);
+                a[mf] = (s16x8_t){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                if (SPLIT) {
+                    s16x4_t w0 = tr_read(D_lo + kp0 * SD + coff), w1 = tr_read(D_lo + kp1 * SD + coff);
+                    al[mf] = (s16x8_t){w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
+                }
+            }
+#pragma unroll
+            for (int tap = 0; tap < T; ++tap) {
+                const int dy = (KS == 3) ? tap / 3 : 0, dx = (KS == 3) ? tap % 3 : 0;
+                int hp0, hp1;
+                if (KS == 1) { hp0 = nb0 * HH * HW + py0 * HW + px0; hp1 = nb1 * HH * HW + py1 * HW + px1; }
+                else if (UPS) {
+                    hp0 = nb0 * HH * HW + (((py0 + dy - 1) >> 1) + 1) * HW + ((px0 + dx - 1) >> 1) + 1;
+                    hp1 = nb1 * HH * HW + (((py1 + dy - 1) >> 1) + 1) * HW + ((px1 + dx - 1) >> 1) + 1;
+                } else {
+                    hp0 = nb0 * HH * HW + (py0 + dy) * HW + px0 + dx;
+                    hp1 = nb1 * HH * HW + (py1 + dy) * HW + px1 + dx;
+                }
+#pragma unroll
+                for (int nf = 0; nf < 2; ++nf) {
+                    int coff = (nh * 32 + nf * 16 + 4 * sq) * 2;
+                    s16x4_t v0 = tr_read(A_hi + hp0 * SA + coff), v1 = tr_read(A_hi + hp1 * SA + coff);
+                    s16x8_t b = (s16x8_t){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    if (SPLIT) {
+                        s16x4_t w0 = tr_read(A_lo + hp0 * SA + coff), w1 = tr_read(A_lo + hp1 * SA + coff);
+                        s16x8_t bl = (s16x8_t){w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
+#pragma unroll
+                        for (int mf = 0; mf < 2; ++mf) {
+                            acc[tap][mf][nf] = mfma16(al[mf], b, acc[tap][mf][nf]);
+                            acc[tap][mf][nf] = mfma16(a[mf], bl, acc[tap][mf][nf]);
+                        }
+                    }
+#pragma unroll
+                    for (int mf = 0; mf < 2; ++mf) acc[tap][mf][nf] = mfma16(a[mf], b, acc[tap][mf][nf]);
+                }
+            }
+        }
+    }
+
+    // write the partial slab [split][tap][CoP][CiP]; C layout: row (co) = (lane>>4)*4 + r, col (ci) = lane&15
+#pragma unroll
+    for (int tap = 0; tap < T; ++tap)
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int co = co0 + mh * 32 + mf * 16 + (lane >> 4) * 4 + r;
+                    int ci = ci0 + nh * 32 + nf * 16 + (lane & 15);
+                    p.part[(((size_t)blockIdx.x * T + tap) * p.CoP + co) * p.CiP + ci] = acc[tap][mf][nf][r];
+                }
+}
+
+// dw[co][ci][tap] = sum_s part[s][tap][co][ci]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int S, int T, int Cout, int Cin,
+                                    int CoP, int CiP) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Cout * Cin) return;
+    int ci = idx % Cin, co = idx / Cin;
+    for (int t = 0; t < T; ++t) {
+        float s = 0.f;
+        for (int k = 0; k < S; ++k) s += part[(((size_t)k * T + t) * CoP + co) * CiP + ci];
+        dw[(size_t)idx * T + t] = s;
+    }
+}
+
+static int ilog2_floor_w(int v) { int l = 0; while ((1 << (l + 1)) <= v) ++l; return l; }
+
+template <int KS, bool UPS, int PREC>
+static int launch_wgrad(WgradParams& p, float* dw, hipStream_t stream) {
+    constexpr bool SPLIT = (PREC == LP_PREC_BF16X3);
+    constexpr int SA = 64 * 2 + 16, SD = 64 * 2 + 16;
+    // 128-pixel tiles, row-major inside the patch; TW >= 4 so that 4 consecutive k are 4 consecutive x
+    int ltw = ilog2_floor_w(p.W); if (ltw > 4) ltw = 4;
+    int lth = ilog2_floor_w(p.H); if (lth > 7 - ltw) lth = 7 - ltw;
+    int lnb = 7 - ltw - lth;
+    if (ltw < 2) return lp_set_error(LP_ERR_UNSUPPORTED, "wgrad needs W >= 4");
+    p.lTH = lth; p.lTW = ltw; p.lNB = lnb;
+    const int TH = 1 << lth, TW = 1 << ltw, NBv = 1 << lnb;
+    p.tiles_x = (p.W + TW - 1) / TW; p.tiles_y = (p.H + TH - 1) / TH;
+    p.num_tiles = p.tiles_x * p.tiles_y * ((p.N + NBv - 1) / NBv);
+    if (p.splits > p.num_tiles) p.splits = p.num_tiles;
+    int HH, HW;
+    if (KS == 1) { HH = TH; HW = TW; } else if (UPS) { HH = TH / 2 + 2; HW = TW / 2 + 2; } else { HH = TH + 2; HW = TW + 2; }
+    size_t lds = ((size_t)NBv * HH * HW * SA + 128 * SD) * (SPLIT ? 2 : 1);
+    if (lds > 160 * 1024) return lp_set_error(LP_ERR_UNSUPPORTED, "wgrad tile needs too much LDS");
+    auto kern = conv_wgrad_kernel<KS, UPS, PREC>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return lp_set_error(LP_ERR_HIP, "hipFuncSetAttribute failed");
+        attr_set = true;
+    }
+    dim3 grid(p.splits, p.CoP / 64, p.CiP / 64);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
+    int rc = lp_check_launch("conv_wgrad");
+    if (rc) return rc;
+    int total = p.Cout * p.Cin;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, p.part, dw, p.splits, KS * KS,
+                       p.Cout, p.Cin, p.CoP, p.CiP);
+    return lp_check_launch("wgrad_reduce");
+}
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+extern "C" long long lp_conv_wgrad_workspace_bytes(int Cin, int Cout, int ksize, int splits) {
+    return (long long)splits * ksize * ksize * round_up(Cout, 64) * round_up(Cin, 64) * 4;
+}
+
+extern "C" int lp_conv_wgrad(const float* x, const float* dy, float* dw, float* workspace, const float* scale, const float* shift,
+                             int N, int H, int W, int Cin, int Cout, int ksize, int upsample, int pro, int splits, int prec,
+                             void* stream) {
+    if (!x || !dy || !dw || !workspace) return lp_set_error(LP_ERR_ARG, "lp_conv_wgrad: null pointer");
+    if (pro == 1 && (!scale || !shift)) return lp_set_error(LP_ERR_ARG, "lp_conv_wgrad: pro=1 needs scale/shift");
+    if (splits < 1) return lp_set_error(LP_ERR_ARG, "lp_conv_wgrad: splits must be >= 1");
+    if (upsample && ((H | W) & 1)) return lp_set_error(LP_ERR_ARG, "lp_conv_wgrad: upsampled dims must be even");
+    WgradParams p;
+    p.x = x; p.dy = dy; p.part = workspace; p.scale = scale; p.shift = shift;
+    p.N = N; p.H = H; p.W = W; p.Hin = upsample ? H / 2 : H; p.Win = upsample ? W / 2 : W;
+    p.Cin = Cin; p.Cout = Cout; p.CoP = round_up(Cout, 64); p.CiP = round_up(Cin, 64);
+    p.pro = pro; p.splits = splits;
+    hipStream_t s = (hipStream_t)stream;
+#define LP_WG(KS_, UPS_) (prec == LP_PREC_BF16 ? launch_wgrad<KS_, UPS_, LP_PREC_BF16>(p, dw, s) : launch_wgrad<KS_, UPS_, LP_PREC_BF16X3>(p, dw, s))
+    if (prec != LP_PREC_BF16 && prec != LP_PREC_BF16X3) return lp_set_error(LP_ERR_ARG, "lp_conv_wgrad: unknown precision");
+    if (ksize == 3 && !upsample) return LP_WG(3, false);
+    if (ksize == 3 && upsample) return LP_WG(3, true);
+    if (ksize == 1 && !upsample) return LP_WG(1, false);
+#undef LP_WG
+    return lp_set_error(LP_ERR_UNSUPPORTED, "lp_conv_wgrad: unsupported configuration");
+}

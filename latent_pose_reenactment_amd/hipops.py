@@ -1,0 +1,154 @@
+"""Tensor-level wrappers around the C ABI.  Activations are NHWC fp32 contiguous CUDA tensors of shape [N,H,W,C].
+PyTorch here is plumbing only: it owns the buffers and the stream; all arithmetic happens in liblp_hip.so."""
+from typing import NamedTuple, Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import PREC_BF16, PREC_BF16X3, check
+
+Tensor = torch.Tensor
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t: Tensor, name: str):
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise ValueError(f'{name}: expected a contiguous fp32 CUDA tensor, got {t.dtype} {t.device} contiguous={t.is_contiguous()}')
+
+
+def _round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+class WeightPack(NamedTuple):
+    hi: Tensor
+    lo: Optional[Tensor]
+    rows: int      # logical rows (Cout for mode 0, Cin for mode 1)
+    cols: int
+    rows_p: int
+    cols_p: int
+    taps: int
+
+
+def pack_weights(w: Tensor, mode: int, prec: int, small_k: bool = False) -> WeightPack:
+    """w: [Cout, Cin, k, k] (or [Cout, Cin]) fp32.  mode 0 = forward pack, mode 1 = dgrad pack (flipped + transposed).
+    small_k pads the contraction dim to 32 instead of 64 (only valid for 3x3 non-upsampled convs)."""
+    _chk(w, 'w')
+    cout, cin = w.shape[0], w.shape[1]
+    taps = w.numel() // (cout * cin)
+    rows, cols = (cout, cin) if mode == 0 else (cin, cout)
+    rows_p = _round_up(rows, 128)
+    cols_p = _round_up(cols, 32 if (small_k and cols <= 32) else 64)
+    hi = torch.empty((taps, rows_p, cols_p), dtype=torch.int16, device=w.device)
+    lo = torch.empty_like(hi) if prec == PREC_BF16X3 else None
+    check(_lib.lib().lp_pack_weights(w.data_ptr(), hi.data_ptr(), _p(lo), cout, cin, taps, rows_p, cols_p, mode, _stream()),
+          'lp_pack_weights')
+    return WeightPack(hi, lo, rows, cols, rows_p, cols_p, taps)
+
+
+def conv(x: Tensor, pack: WeightPack, *, ksize: int, upsample: bool = False, pro: int = 0, scale: Optional[Tensor] = None,
+         shift: Optional[Tensor] = None, bias: Optional[Tensor] = None, res: Optional[Tensor] = None, res_shift: int = 0,
+         alpha: Optional[Tensor] = None, prec: int = PREC_BF16) -> Tensor:
+    """y = alpha * conv(up2?(act(x)), pack) + bias + res ; x [N,Hin,Win,Cin] -> y [N,H,W,Cout]."""
+    _chk(x, 'x')
+    n, hin, win, cin = x.shape
+    assert cin == pack.cols and pack.taps == ksize * ksize, (x.shape, pack.rows, pack.cols, pack.taps)
+    h, w = (hin * 2, win * 2) if upsample else (hin, win)
+    cout = pack.rows
+    y = torch.empty((n, h, w, cout), dtype=torch.float32, device=x.device)
+    for t, nm in ((scale, 'scale'), (shift, 'shift'), (bias, 'bias'), (res, 'res')):
+        if t is not None:
+            _chk(t, nm)
+    if res is not None:
+        assert res.shape == (n, h >> res_shift, w >> res_shift, cout), (res.shape, y.shape, res_shift)
+    check(_lib.lib().lp_conv_fwd(x.data_ptr(), pack.hi.data_ptr(), _p(pack.lo), y.data_ptr(), _p(scale), _p(shift), _p(bias), _p(res),
+                                 _p(alpha), n, h, w, cin, cout, pack.cols_p, pack.rows_p, ksize, int(upsample), pro, res_shift, prec,
+                                 _stream()), 'lp_conv_fwd')
+    return y
+
+
+def conv_wgrad(x: Tensor, dy: Tensor, *, ksize: int, upsample: bool = False, pro: int = 0, scale: Optional[Tensor] = None,
+               shift: Optional[Tensor] = None, prec: int = PREC_BF16, splits: Optional[int] = None) -> Tensor:
+    """dw [Cout,Cin,k,k] = sum_pixels dy (x) up2?(act(x)) (shifted by tap)."""
+    _chk(x, 'x'); _chk(dy, 'dy')
+    n, h, w, cout = dy.shape
+    cin = x.shape[3]
+    if splits is None:
+        blocks = _round_up(cout, 64) // 64 * (_round_up(cin, 64) // 64)
+        splits = max(1, min(1024 // blocks, (n * h * w + 127) // 128))
+    ws_bytes = _lib.lib().lp_conv_wgrad_workspace_bytes(cin, cout, ksize, splits)
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
+    dw = torch.empty((cout, cin, ksize, ksize), dtype=torch.float32, device=x.device)
+    check(_lib.lib().lp_conv_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), _p(scale), _p(shift), n, h, w, cin, cout,
+                                   ksize, int(upsample), pro, splits, prec, _stream()), 'lp_conv_wgrad')
+    return dw
+
+
+def instnorm_stats(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], eps: float
+                   ) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    """x [N,H,W,C]; gamma/beta: [N,C] views (last dim contiguous) of the projector output.  -> mean, rstd, scale, shift [N,C]."""
+    _chk(x, 'x')
+    n, h, w, c = x.shape
+    ab_stride = 0
+    if gamma is not None:
+        assert gamma.shape == (n, c) and beta.shape == (n, c) and gamma.stride(1) == 1 and beta.stride(1) == 1
+        assert gamma.stride(0) == beta.stride(0)
+        ab_stride = gamma.stride(0)
+    mean, rstd, scale, shift = (torch.empty((n, c), dtype=torch.float32, device=x.device) for _ in range(4))
+    ws = torch.empty(_lib.lib().lp_instnorm_workspace_bytes(n, h * w, c) // 4, dtype=torch.float32, device=x.device)
+    check(_lib.lib().lp_instnorm_stats(x.data_ptr(), _p(gamma), _p(beta), ab_stride, eps, mean.data_ptr(), rstd.data_ptr(),
+                                       scale.data_ptr(), shift.data_ptr(), ws.data_ptr(), n, h * w, c, _stream()), 'lp_instnorm_stats')
+    return mean, rstd, scale, shift
+
+
+def adain_relu_bwd(dA: Tensor, x: Tensor, add: Optional[Tensor], gamma: Tensor, mean: Tensor, rstd: Tensor, scale: Tensor,
+                   shift: Tensor, dgamma: Tensor, dbeta: Tensor, upsample: bool) -> Tensor:
+    """Backward of relu(AdaIN(x)) (+x2 upsample).  dgamma/dbeta: [N,C] views into the projector-output gradient (written)."""
+    _chk(dA, 'dA'); _chk(x, 'x')
+    n, h, w, c = x.shape
+    assert dA.shape == (n, h << int(upsample), w << int(upsample), c), (dA.shape, x.shape)
+    assert gamma.stride(1) == 1 and dgamma.stride(1) == 1 and dbeta.stride(1) == 1
+    assert gamma.stride(0) == dgamma.stride(0) == dbeta.stride(0)
+    dx = torch.empty_like(x)
+    ws = torch.empty(_lib.lib().lp_adain_bwd_workspace_bytes(n, h * w, c) // 4, dtype=torch.float32, device=x.device)
+    check(_lib.lib().lp_adain_relu_bwd(dA.data_ptr(), x.data_ptr(), _p(add), gamma.data_ptr(), gamma.stride(0), mean.data_ptr(),
+                                       rstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), dx.data_ptr(), dgamma.data_ptr(),
+                                       dbeta.data_ptr(), ws.data_ptr(), n, h, w, c, int(upsample), _stream()), 'lp_adain_relu_bwd')
+    return dx
+
+
+def sum2x2(x: Tensor) -> Tensor:
+    _chk(x, 'x')
+    n, h2, w2, c = x.shape
+    out = torch.empty((n, h2 // 2, w2 // 2, c), dtype=torch.float32, device=x.device)
+    check(_lib.lib().lp_sum2x2(x.data_ptr(), out.data_ptr(), n, h2 // 2, w2 // 2, c, _stream()), 'lp_sum2x2')
+    return out
+
+
+def head_fwd(z: Tensor, want_t: bool = True) -> Tuple[Optional[Tensor], Tensor, Tensor]:
+    """z [N,H,W,4] -> (tanh(z) NHWC, fake_rgbs NCHW [N,3,H,W], fake_segm NCHW [N,1,H,W])."""
+    _chk(z, 'z')
+    n, h, w, c = z.shape
+    assert c == 4
+    t = torch.empty_like(z) if want_t else None
+    rgbs = torch.empty((n, 3, h, w), dtype=torch.float32, device=z.device)
+    segm = torch.empty((n, 1, h, w), dtype=torch.float32, device=z.device)
+    check(_lib.lib().lp_head_fwd(z.data_ptr(), _p(t), rgbs.data_ptr(), segm.data_ptr(), n, h, w, _stream()), 'lp_head_fwd')
+    return t, rgbs, segm
+
+
+def head_bwd(t: Tensor, d_rgbs: Tensor, d_segm: Optional[Tensor]) -> Tensor:
+    _chk(t, 't'); _chk(d_rgbs, 'd_rgbs')
+    n, h, w, _ = t.shape
+    dz = torch.empty_like(t)
+    if d_segm is not None:
+        _chk(d_segm, 'd_segm')
+    check(_lib.lib().lp_head_bwd(t.data_ptr(), d_rgbs.data_ptr(), _p(d_segm), dz.data_ptr(), n, h, w, _stream()), 'lp_head_bwd')
+    return dz

@@ -1,0 +1,204 @@
+"""GPU parity tests of the individual HIP kernels (through the C ABI) against fp64 torch-CPU references.
+Tolerances (rel-L2): bf16x3 ('exact') mode 3e-5 -- fp32-class; bf16 mode 1e-2 -- operand rounding 2^-9."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = {0: 1e-2, 1: 3e-5}
+
+
+def _ops():
+    from latent_pose_reenactment_amd import hipops
+    return hipops
+
+
+def rel(a, b):
+    a = a.detach().double().cpu(); b = b.detach().double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def report(name, err, tol):
+    print(f'[parity] {name}: rel-L2 {err:.3e} (tol {tol:.0e})')
+    assert err < tol, f'{name}: rel-L2 {err:.3e} >= {tol}'
+
+
+def act_ref(x, pro, scale, shift, ups):
+    a = x
+    if pro == 1:
+        a = torch.relu(x * scale[:, :, None, None] + shift[:, :, None, None])
+    elif pro == 2:
+        a = torch.relu(x)
+    if ups:
+        a = a.repeat_interleave(2, 2).repeat_interleave(2, 3)
+    return a
+
+
+CONV_CASES = [
+    # N, H(out), W, Cin, Cout, ks, ups, pro, bias, res_shift(-1 none)
+    (2, 8, 8, 64, 128, 3, 0, 1, 0, -1),
+    (8, 4, 4, 64, 64, 3, 0, 1, 0, 0),
+    (3, 4, 4, 128, 256, 3, 0, 1, 0, -1),
+    (1, 16, 16, 128, 64, 3, 1, 1, 0, -1),
+    (2, 8, 8, 64, 192, 3, 1, 1, 0, 1),
+    (2, 32, 32, 64, 64, 3, 1, 1, 0, 1),
+    (2, 32, 32, 64, 4, 3, 0, 1, 1, -1),
+    (2, 16, 16, 4, 64, 3, 0, 0, 0, -1),
+    (2, 16, 16, 3, 64, 3, 0, 0, 1, -1),
+    (2, 8, 8, 64, 128, 1, 0, 0, 1, -1),
+    (2, 16, 16, 128, 24, 1, 0, 2, 1, -1),
+    (1, 32, 32, 16, 8, 3, 0, 2, 1, 0),
+    (2, 64, 64, 64, 64, 3, 0, 1, 0, -1),
+]
+
+
+@pytest.mark.parametrize('prec', [1, 0])
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_fwd(case, prec):
+    ops = _ops()
+    n, h, w, cin, cout, ks, ups, pro, has_bias, rs = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    hin, win = (h // 2, w // 2) if ups else (h, w)
+    x = torch.randn(n, cin, hin, win, generator=g, dtype=torch.float64)
+    wgt = torch.randn(cout, cin, ks, ks, generator=g, dtype=torch.float64) / (cin * ks * ks) ** 0.5
+    scale = torch.randn(n, cin, generator=g, dtype=torch.float64)
+    shift = torch.randn(n, cin, generator=g, dtype=torch.float64) * 0.5
+    bias = torch.randn(cout, generator=g, dtype=torch.float64) if has_bias else None
+    res = torch.randn(n, cout, h >> rs, w >> rs, generator=g, dtype=torch.float64) if rs >= 0 else None
+    alpha = torch.tensor(0.73, dtype=torch.float64)
+    ref = alpha * F.conv2d(act_ref(x, pro, scale, shift, ups), wgt, None, 1, ks // 2)
+    if bias is not None:
+        ref = ref + bias[None, :, None, None]
+    if res is not None:
+        r = res
+        for _ in range(rs):
+            r = r.repeat_interleave(2, 2).repeat_interleave(2, 3)
+        ref = ref + r
+    dev = 'cuda'
+    f32 = lambda t: None if t is None else t.float().to(dev).contiguous()
+    small_k = (ks == 3 and not ups and cin <= 32)
+    pack = ops.pack_weights(f32(wgt), 0, prec, small_k=small_k)
+    y = ops.conv(f32(nhwc(x)), pack, ksize=ks, upsample=bool(ups), pro=pro, scale=f32(scale), shift=f32(shift), bias=f32(bias),
+                 res=None if res is None else f32(nhwc(res)), res_shift=max(rs, 0), alpha=f32(alpha), prec=prec)
+    torch.cuda.synchronize()
+    report(f'conv_fwd{case} prec={prec}', rel(y.permute(0, 3, 1, 2), ref), TOL[prec])
+
+
+@pytest.mark.parametrize('prec', [1, 0])
+@pytest.mark.parametrize('case', [(2, 8, 8, 64, 128, 3), (2, 16, 16, 64, 4, 3), (2, 16, 16, 128, 64, 1), (8, 4, 4, 128, 64, 3)])
+def test_conv_dgrad(case, prec):
+    """data gradient = same kernel on dY with the mode-1 (flipped, transposed) pack"""
+    ops = _ops()
+    n, h, w, cin, cout, ks = case
+    g = torch.Generator().manual_seed(5)
+    wgt = torch.randn(cout, cin, ks, ks, generator=g, dtype=torch.float64) / (cin * ks * ks) ** 0.5
+    dy = torch.randn(n, cout, h, w, generator=g, dtype=torch.float64)
+    a = torch.zeros(n, cin, h, w, dtype=torch.float64, requires_grad=True)
+    F.conv2d(a, wgt, None, 1, ks // 2).backward(dy)
+    f32 = lambda t: t.float().cuda().contiguous()
+    pack = ops.pack_weights(f32(wgt), 1, prec, small_k=(ks == 3 and cout <= 32))
+    da = ops.conv(f32(nhwc(dy)), pack, ksize=ks, prec=prec)
+    torch.cuda.synchronize()
+    report(f'conv_dgrad{case} prec={prec}', rel(da.permute(0, 3, 1, 2), a.grad), TOL[prec])
+
+
+WGRAD_CASES = [
+    # N, H(out), W, Cin, Cout, ks, ups, pro
+    (2, 8, 8, 64, 64, 3, 0, 1),
+    (8, 4, 4, 64, 128, 3, 0, 1),
+    (2, 16, 16, 128, 64, 3, 1, 1),
+    (1, 32, 32, 64, 4, 3, 0, 1),
+    (2, 16, 16, 64, 128, 1, 0, 0),
+    (2, 32, 32, 16, 8, 3, 1, 1),
+    (2, 16, 16, 3, 64, 3, 0, 0),
+    (2, 64, 64, 64, 64, 3, 0, 1),
+]
+
+
+@pytest.mark.parametrize('prec', [1, 0])
+@pytest.mark.parametrize('case', WGRAD_CASES)
+def test_conv_wgrad(case, prec):
+    ops = _ops()
+    n, h, w, cin, cout, ks, ups, pro = case
+    g = torch.Generator().manual_seed(11)
+    hin, win = (h // 2, w // 2) if ups else (h, w)
+    x = torch.randn(n, cin, hin, win, generator=g, dtype=torch.float64)
+    scale = torch.randn(n, cin, generator=g, dtype=torch.float64)
+    shift = torch.randn(n, cin, generator=g, dtype=torch.float64) * 0.5
+    dy = torch.randn(n, cout, h, w, generator=g, dtype=torch.float64)
+    wgt = torch.zeros(cout, cin, ks, ks, dtype=torch.float64, requires_grad=True)
+    F.conv2d(act_ref(x, pro, scale, shift, ups), wgt, None, 1, ks // 2).backward(dy)
+    f32 = lambda t: t.float().cuda().contiguous()
+    dw = ops.conv_wgrad(f32(nhwc(x)), f32(nhwc(dy)), ksize=ks, upsample=bool(ups), pro=pro, scale=f32(scale), shift=f32(shift), prec=prec)
+    torch.cuda.synchronize()
+    report(f'conv_wgrad{case} prec={prec}', rel(dw, wgt.grad), TOL[prec])
+
+
+@pytest.mark.parametrize('shape', [(2, 4, 4, 64), (3, 16, 16, 128), (2, 128, 128, 16), (1, 32, 32, 8)])
+def test_instnorm_stats(shape):
+    ops = _ops()
+    n, h, w, c = shape
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(n, c, h, w, generator=g, dtype=torch.float64) * 3 + 10.0      # large mean: cancellation check
+    aff = torch.randn(n, 3 * c, generator=g, dtype=torch.float64)
+    gamma, beta = aff[:, c:2 * c], aff[:, :c]
+    mean = x.mean((2, 3)); var = x.var((2, 3), unbiased=False); rstd = 1 / torch.sqrt(var + 1e-4)
+    affc = aff.float().cuda()
+    m, r, sc, sh = ops.instnorm_stats(nhwc(x).float().cuda(), affc[:, c:2 * c], affc[:, :c], 1e-4)
+    torch.cuda.synchronize()
+    report('mean', rel(m, mean), 1e-6); report('rstd', rel(r, rstd), 2e-5)
+    report('scale', rel(sc, rstd * gamma), 2e-5); report('shift', rel(sh, beta - mean * rstd * gamma), 2e-4)
+
+
+@pytest.mark.parametrize('ups', [0, 1])
+@pytest.mark.parametrize('shape', [(2, 4, 4, 64), (2, 16, 16, 32), (1, 128, 128, 8)])
+def test_adain_relu_bwd(shape, ups):
+    ops = _ops()
+    n, h, w, c = shape
+    g = torch.Generator().manual_seed(4)
+    x = (torch.randn(n, c, h, w, generator=g, dtype=torch.float64) * 2 + 1).requires_grad_(True)
+    aff = torch.randn(n, 2 * c, generator=g, dtype=torch.float64).requires_grad_(True)
+    gamma, beta = aff[:, c:], aff[:, :c]
+    mean = x.mean((2, 3), keepdim=True); var = x.var((2, 3), unbiased=False, keepdim=True)
+    a = torch.relu((x - mean) / torch.sqrt(var + 1e-4) * gamma[:, :, None, None] + beta[:, :, None, None])
+    if ups:
+        a = a.repeat_interleave(2, 2).repeat_interleave(2, 3)
+    dA = torch.randn(a.shape, generator=g, dtype=torch.float64)
+    add = torch.randn(n, c, h, w, generator=g, dtype=torch.float64)
+    a.backward(dA)
+    affc = aff.detach().float().cuda()
+    xc = nhwc(x.detach()).float().cuda()
+    m, r, sc, sh = ops.instnorm_stats(xc, affc[:, c:], affc[:, :c], 1e-4)
+    daff = torch.zeros_like(affc)
+    dx = ops.adain_relu_bwd(nhwc(dA).float().cuda(), xc, nhwc(add).float().cuda(), affc[:, c:], m, r, sc, sh, daff[:, c:], daff[:, :c],
+                            bool(ups))
+    torch.cuda.synchronize()
+    report('dx', rel(dx.permute(0, 3, 1, 2), x.grad + add), 2e-5)
+    report('daffine', rel(daff, aff.grad), 2e-5)
+
+
+def test_sum2x2_and_head():
+    ops = _ops()
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 8, 16, 16, generator=g, dtype=torch.float64)
+    s = ops.sum2x2(nhwc(x).float().cuda())
+    report('sum2x2', rel(s.permute(0, 3, 1, 2), F.avg_pool2d(x, 2) * 4), 1e-6)
+    z = torch.randn(2, 4, 16, 16, generator=g, dtype=torch.float64, requires_grad=True)
+    t = torch.tanh(z)
+    rgb = t[:, :3] * 0.75 + 0.5; segm = t[:, 3:] * 0.5 + 0.5
+    fake = rgb * segm
+    d1 = torch.randn(fake.shape, generator=g, dtype=torch.float64); d2 = torch.randn(segm.shape, generator=g, dtype=torch.float64)
+    ((fake * d1).sum() + (segm * d2).sum()).backward()
+    tt, r, sg = ops.head_fwd(nhwc(z.detach()).float().cuda())
+    dz = ops.head_bwd(tt, d1.float().cuda(), d2.float().cuda())
+    torch.cuda.synchronize()
+    report('fake_rgbs', rel(r, fake), 1e-6); report('fake_segm', rel(sg, segm), 1e-6)
+    report('head dz', rel(dz.permute(0, 3, 1, 2), z.grad), 1e-5)
