@@ -1,0 +1,334 @@
+"""nn.Modules of the hot path, backed by the gfx950 kernels in liblp_hip.so.
+
+The module tree reproduces the reference's ``state_dict`` keys and ``parameters()`` order exactly, so
+reference checkpoints and optimizer states drop in:
+  * generator  -- generators/vector_pose_unsupervised_segmentation_noBottleneck.py:40-181 (+ generators/common/blocks.py)
+The arithmetic below the Module boundary is NOT torch: the whole decoder (17 AdaIN+ReLU prologues, 23 convs, upsampling,
+residual adds, tanh/compose head) runs as one ``torch.autograd.Function`` whose forward and backward are sequences of
+C-ABI kernel launches on the current stream.  There is no CPU or eager fallback: without a GPU / the .so it raises.
+"""
+from __future__ import annotations
+
+import math
+import os
+from typing import List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import hipops as ops
+from ._lib import PREC_BF16, PREC_BF16X3
+
+ADAIN_EPS = 1e-4
+SN_EPS_CONV = 1e-4
+SN_EPS_DEFAULT = 1e-12
+
+PREC_NAMES = {'bf16': PREC_BF16, 'bf16x3': PREC_BF16X3}
+
+
+def default_prec() -> int:
+    """Contraction operand precision: LP_PREC=bf16 (1 MFMA per k-step) | bf16x3 (hi/lo split, fp32-class; default)."""
+    return PREC_NAMES[os.environ.get('LP_PREC', 'bf16x3')]
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# spectral-norm parameter holder with the legacy-hook key names (weight_orig / weight_u / weight_v [+ bias])
+# ----------------------------------------------------------------------------------------------------------------------
+class SNWeight(nn.Module):
+    """Parameter/buffer set of ``torch.nn.utils.spectral_norm(nn.Conv2d|nn.Linear|nn.Embedding)``.
+
+    ``effective_weight()`` follows the legacy hook (torch/nn/utils/spectral_norm.py::compute_weight) as used at
+    generators/common/blocks.py:76-88: in train mode one in-place power iteration on (u, v) under no_grad, then
+    ``W_orig / (u . W v)`` with u, v constant for autograd."""
+
+    def __init__(self, shape: Tuple[int, ...], bias: bool, eps: float, fan_in: Optional[int] = None):
+        super().__init__()
+        out_f = shape[0]
+        in_flat = int(math.prod(shape[1:]))
+        fan_in = fan_in or in_flat
+        if bias:   # registered first: the reference's parameter order per layer is [bias, weight_orig]
+            bound = 1 / math.sqrt(fan_in)
+            self.bias = nn.Parameter(torch.empty(out_f).uniform_(-bound, bound))
+        else:
+            self.register_parameter('bias', None)
+        w = torch.empty(shape)
+        nn.init.kaiming_uniform_(w.view(out_f, in_flat), a=math.sqrt(5))
+        self.weight_orig = nn.Parameter(w)
+        self.register_buffer('weight_u', F.normalize(torch.randn(out_f), dim=0, eps=eps))
+        self.register_buffer('weight_v', F.normalize(torch.randn(in_flat), dim=0, eps=eps))
+        self.eps = eps
+
+    def effective_weight(self) -> torch.Tensor:
+        w = self.weight_orig
+        w_mat = w.reshape(w.shape[0], -1)
+        u, v = self.weight_u, self.weight_v
+        if self.training:
+            with torch.no_grad():
+                v = F.normalize(torch.mv(w_mat.t(), u), dim=0, eps=self.eps, out=self.weight_v)
+                u = F.normalize(torch.mv(w_mat, v), dim=0, eps=self.eps, out=self.weight_u)
+                u, v = u.clone(), v.clone()
+        sigma = torch.dot(u, torch.mv(w_mat, v))
+        return w / sigma
+
+
+class _Indexed(nn.Module):
+    """Container whose children are named by explicit integer positions (mirrors the sparse indices that
+    nn.Sequential gives parameter-less layers in the reference: e.g. ``block.3`` / ``block.7``)."""
+
+    def __init__(self, **children: nn.Module):
+        super().__init__()
+        for k, m in children.items():
+            self.add_module(k.lstrip('_'), m)
+
+
+class _ResBlockParams(nn.Module):
+    """Parameters of blocks.ResBlock(norm_layer='adain') -- generators/common/blocks.py:47-103."""
+
+    def __init__(self, cin: int, cout: int, upsample: bool):
+        super().__init__()
+        i1, i2 = ('4', '8') if upsample else ('3', '7')
+        self.i1, self.i2 = i1, i2
+        self.block = _Indexed(**{'_' + i1: SNWeight((cout, cin, 3, 3), False, SN_EPS_CONV),
+                                 '_' + i2: SNWeight((cout, cout, 3, 3), False, SN_EPS_CONV)})
+        self.has_skip = cin != cout or upsample
+        if self.has_skip:
+            key = '1' if upsample else '0'
+            self.skip_key = key
+            self.skip = _Indexed(**{'_' + key: SNWeight((cout, cin, 1, 1), True, SN_EPS_CONV)})
+        self.cin, self.cout, self.upsample = cin, cout, upsample
+
+    def convs(self):
+        c1, c2 = getattr(self.block, self.i1), getattr(self.block, self.i2)
+        sk = getattr(self.skip, self.skip_key) if self.has_skip else None
+        return c1, c2, sk
+
+
+class Constant(nn.Module):
+    """noBottleneck.py:31-37 (learned 1 x C x s x s input, init ones)."""
+
+    def __init__(self, *shape):
+        super().__init__()
+        self.constant = nn.Parameter(torch.ones(1, *shape))
+
+
+def generator_channels(num_channels: int, max_num_channels: int, image_size: int, const_size: int, num_res_blocks: int):
+    """(cin, cout, upsample) per decoder block -- noBottleneck.py:60-78."""
+    n_up = int(math.log2(image_size / const_size))
+    nonclamped = num_channels * (2 ** n_up)
+    cur = min(nonclamped, max_num_channels)
+    blocks = [(cur, cur, False)] * num_res_blocks
+    for _ in range(n_up):
+        cin = cur
+        nonclamped //= 2
+        cur = min(nonclamped, max_num_channels)
+        blocks.append((cin, cur, True))
+    return blocks
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the decoder as ONE autograd Function over HIP kernels
+# ----------------------------------------------------------------------------------------------------------------------
+class _DecoderFunction(torch.autograd.Function):
+    """inputs: affine [B, n_aff] (projector output; per AdaIN: C biases then C weights, noBottleneck.py:108-125),
+    constant [1,C,s,s], then per block (w1, w2[, w_skip, b_skip]) and (w_head, b_head) -- effective (W/sigma) weights.
+    outputs: fake_rgbs [B,3,S,S], fake_segm [B,1,S,S] (NCHW, noBottleneck.py:170-181)."""
+
+    @staticmethod
+    def forward(ctx, cfg, affine, constant, *weights):
+        blocks, prec = cfg['blocks'], cfg['prec']
+        need_grad = cfg['need_grad']
+        B = affine.shape[0]
+        affine = affine.contiguous()
+        wl = list(weights)
+        x = constant.detach().permute(0, 2, 3, 1).expand(B, -1, -1, -1).contiguous()    # NHWC
+        saved = []
+        off = 0
+        wi = 0
+
+        def aff(c):
+            nonlocal off
+            beta, gamma = affine[:, off:off + c], affine[:, off + c:off + 2 * c]
+            o = off
+            off += 2 * c
+            return gamma, beta, o
+
+        for (cin, cout, up) in blocks:
+            w1, w2 = wl[wi], wl[wi + 1]
+            wi += 2
+            has_skip = (cin != cout) or up
+            g0, b0, o0 = aff(cin)
+            g1, b1, o1 = aff(cout)
+            st0 = ops.instnorm_stats(x, g0, b0, ADAIN_EPS)
+            p1 = ops.pack_weights(w1.detach().contiguous(), 0, prec)
+            h1 = ops.conv(x, p1, ksize=3, upsample=up, pro=1, scale=st0[2], shift=st0[3], prec=prec)
+            st1 = ops.instnorm_stats(h1, g1, b1, ADAIN_EPS)
+            if has_skip:
+                ws, bs = wl[wi], wl[wi + 1]
+                wi += 2
+                ps = ops.pack_weights(ws.detach().contiguous(), 0, prec)
+                s = ops.conv(x, ps, ksize=1, bias=bs.detach().contiguous(), prec=prec)     # 1x1 commutes with nearest upsampling
+                rs = 1 if up else 0
+            else:
+                s, rs = x, 0
+            p2 = ops.pack_weights(w2.detach().contiguous(), 0, prec)
+            out = ops.conv(h1, p2, ksize=3, pro=1, scale=st1[2], shift=st1[3], res=s, res_shift=rs, prec=prec)
+            if need_grad:
+                saved.append((x, h1, st0, st1, o0, o1))
+            x = out
+        ch = blocks[-1][1]
+        gh, bh, oh = aff(ch)
+        sth = ops.instnorm_stats(x, gh, bh, ADAIN_EPS)
+        wh, bhd = wl[wi], wl[wi + 1]
+        ph = ops.pack_weights(wh.detach().contiguous(), 0, prec)
+        z = ops.conv(x, ph, ksize=3, pro=1, scale=sth[2], shift=sth[3], bias=bhd.detach().contiguous(), prec=prec)
+        t, rgbs, segm = ops.head_fwd(z, want_t=need_grad)
+        if need_grad:
+            ctx.cfg = cfg
+            ctx.saved = saved
+            ctx.head = (x, sth, oh, t)
+            ctx.affine = affine
+            ctx.weights = [w.detach() for w in wl]
+            ctx.const_shape = constant.shape
+        return rgbs, segm
+
+    @staticmethod
+    def backward(ctx, d_rgbs, d_segm):
+        cfg = ctx.cfg
+        blocks, prec = cfg['blocks'], cfg['prec']
+        affine, wl = ctx.affine, ctx.weights
+        d_affine = torch.zeros_like(affine)
+        grads: List[Optional[torch.Tensor]] = [None] * len(wl)
+
+        def slices(o, c):      # (gamma, dgamma, dbeta) views for the AdaIN whose params start at column o
+            return affine[:, o + c:o + 2 * c], d_affine[:, o + c:o + 2 * c], d_affine[:, o:o + c]
+
+        x, sth, oh, t = ctx.head
+        ch = blocks[-1][1]
+        dz = ops.head_bwd(t, d_rgbs.contiguous(), None if d_segm is None else d_segm.contiguous())
+        wi = len(wl) - 2
+        grads[wi] = ops.conv_wgrad(x, dz, ksize=3, pro=1, scale=sth[2], shift=sth[3], prec=prec)
+        grads[wi + 1] = dz.sum(dim=(0, 1, 2))
+        pT = ops.pack_weights(wl[wi].contiguous(), 1, prec, small_k=True)
+        dA = ops.conv(dz, pT, ksize=3, prec=prec)
+        g, dg, db = slices(oh, ch)
+        dx = ops.adain_relu_bwd(dA, x, None, g, sth[0], sth[1], sth[2], sth[3], dg, db, False)
+        dbg = cfg.get('debug')
+        if dbg is not None:
+            dbg['dz'] = dz; dbg['dA_head'] = dA; dbg[f'dx{len(blocks)}'] = dx
+
+        for bi in range(len(blocks) - 1, -1, -1):
+            cin, cout, up = blocks[bi]
+            has_skip = (cin != cout) or up
+            x, h1, st0, st1, o0, o1 = ctx.saved[bi]
+            wi -= 4 if has_skip else 2
+            w1, w2 = wl[wi], wl[wi + 1]
+            d_out = dx
+            # conv2 (+ AdaIN1/ReLU prologue)
+            grads[wi + 1] = ops.conv_wgrad(h1, d_out, ksize=3, pro=1, scale=st1[2], shift=st1[3], prec=prec)
+            dA1 = ops.conv(d_out, ops.pack_weights(w2.contiguous(), 1, prec), ksize=3, prec=prec)
+            g, dg, db = slices(o1, cout)
+            dh1 = ops.adain_relu_bwd(dA1, h1, None, g, st1[0], st1[1], st1[2], st1[3], dg, db, False)
+            # skip branch: out += up2(conv1x1(x) + b)
+            if has_skip:
+                ws = wl[wi + 2]
+                ds = ops.sum2x2(d_out) if up else d_out
+                grads[wi + 2] = ops.conv_wgrad(x, ds, ksize=1, prec=prec)
+                grads[wi + 3] = ds.sum(dim=(0, 1, 2))
+                dx_skip = ops.conv(ds, ops.pack_weights(ws.contiguous(), 1, prec), ksize=1, prec=prec)
+            else:
+                dx_skip = d_out
+            # conv1 (+ AdaIN0/ReLU/upsample prologue)
+            grads[wi] = ops.conv_wgrad(x, dh1, ksize=3, upsample=up, pro=1, scale=st0[2], shift=st0[3], prec=prec)
+            dA0 = ops.conv(dh1, ops.pack_weights(w1.contiguous(), 1, prec), ksize=3, prec=prec)
+            g, dg, db = slices(o0, cin)
+            dx = ops.adain_relu_bwd(dA0, x, dx_skip, g, st0[0], st0[1], st0[2], st0[3], dg, db, up)
+            if dbg is not None:
+                dbg[f'dx{bi}'] = dx; dbg[f'dh1_{bi}'] = dh1; dbg[f'dxskip{bi}'] = dx_skip
+        d_const = dx.sum(dim=0, keepdim=True).permute(0, 3, 1, 2).contiguous()
+        return (None, d_affine, d_const, *grads)
+
+
+class Generator(nn.Module):
+    """Drop-in for generators/vector_pose_unsupervised_segmentation_noBottleneck.py::Generator (same constructor
+    arguments, state_dict keys, forward(data_dict) contract, enable_finetuning)."""
+
+    def __init__(self, padding, in_channels, out_channels, num_channels, max_num_channels, identity_embedding_size,
+                 pose_embedding_size, norm_layer, gen_constant_input_size, gen_num_residual_blocks, output_image_size,
+                 prec: Optional[int] = None):
+        super().__init__()
+        if padding != 'zero':
+            raise NotImplementedError("only gen_padding='zero' (the shipped configs) is implemented on the HIP path")
+        if 'in' not in norm_layer:
+            raise NotImplementedError("only norm_layer='in' is implemented on the HIP path")
+        assert math.log2(output_image_size / gen_constant_input_size).is_integer(), \
+            "`gen_constant_input_size` must be `image_size` divided by a power of 2"
+        if out_channels != 4:
+            raise NotImplementedError('the head kernel composes exactly RGB + mask (out_channels + 1 == 4)')
+        self.blocks_cfg = generator_channels(num_channels, max_num_channels, output_image_size, gen_constant_input_size,
+                                             gen_num_residual_blocks)
+        c0 = self.blocks_cfg[0][0]
+        self.constant = Constant(c0, gen_constant_input_size, gen_constant_input_size)
+        dec = {}
+        for i, (cin, cout, up) in enumerate(self.blocks_cfg):
+            dec[f'_{i}'] = _ResBlockParams(cin, cout, up)
+        nb = len(self.blocks_cfg)
+        # indices nb, nb+1 are the head AdaIN and ReLU (no parameters), nb+2 the SN conv, nb+3 the Tanh
+        dec[f'_{nb + 2}'] = SNWeight((out_channels, self.blocks_cfg[-1][1], 3, 3), True, SN_EPS_CONV)
+        self.decoder_blocks = _Indexed(**dec)
+        self.identity_embedding_size = identity_embedding_size
+        self.pose_embedding_size = pose_embedding_size
+        joint = identity_embedding_size + pose_embedding_size
+        hidden = max(joint, 512)
+        self.num_affine_params = sum(2 * (a + b) for a, b, _ in self.blocks_cfg) + 2 * self.blocks_cfg[-1][1]
+        self.affine_params_projector = _Indexed(_0=SNWeight((hidden, joint), True, SN_EPS_DEFAULT),
+                                                _2=SNWeight((self.num_affine_params, hidden), True, SN_EPS_DEFAULT))
+        self.finetuning = False
+        self.prec = default_prec() if prec is None else prec
+
+    def get_num_affine_params(self):
+        return self.num_affine_params
+
+    def enable_finetuning(self, data_dict=None):
+        """noBottleneck.py:139-163: the identity embedding becomes a trainable parameter."""
+        if data_dict is None:
+            some_parameter = next(iter(self.parameters()))
+            identity_embedding = torch.rand(1, self.identity_embedding_size).to(some_parameter)
+        else:
+            identity_embedding = data_dict['embeds']
+        if self.finetuning:
+            with torch.no_grad():
+                self.identity_embedding.copy_(identity_embedding)
+        else:
+            self.identity_embedding = nn.Parameter(identity_embedding)
+            self.finetuning = True
+
+    def _affine_params(self, data_dict):
+        if self.finetuning:
+            identity = self.identity_embedding.expand(len(data_dict['pose_embedding']), -1)
+        else:
+            identity = data_dict['embeds']
+        joint = torch.cat((identity, data_dict['pose_embedding']), dim=1)
+        p0, p2 = self.affine_params_projector._modules['0'], self.affine_params_projector._modules['2']
+        # plain library GEMMs (rocBLAS through torch) -- B x 768 x 768 and B x 768 x 13056
+        h = torch.relu(F.linear(joint, p0.effective_weight(), p0.bias))
+        return F.linear(h, p2.effective_weight(), p2.bias)
+
+    def forward(self, data_dict):
+        affine = self._affine_params(data_dict)
+        if not affine.is_cuda:
+            raise RuntimeError('the generator runs on the MI355X HIP path only (no CPU fallback); move the model and inputs to cuda')
+        weights = []
+        nb = len(self.blocks_cfg)
+        for i in range(nb):
+            c1, c2, sk = self.decoder_blocks._modules[str(i)].convs()
+            weights += [c1.effective_weight(), c2.effective_weight()]
+            if sk is not None:
+                weights += [sk.effective_weight(), sk.bias]
+        head = self.decoder_blocks._modules[str(nb + 2)]
+        weights += [head.effective_weight(), head.bias]
+        need_grad = torch.is_grad_enabled() and (affine.requires_grad or any(w.requires_grad for w in weights))
+        cfg = dict(blocks=self.blocks_cfg, prec=self.prec, need_grad=need_grad, debug=getattr(self, '_debug', None))
+        rgbs, segm = _DecoderFunction.apply(cfg, affine, self.constant.constant, *weights)
+        data_dict['fake_rgbs'] = rgbs
+        data_dict['fake_segm'] = segm

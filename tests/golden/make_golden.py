@@ -146,19 +146,57 @@ def make_ops():
 
 
 # ---- B. generator ----------------------------------------------------------------------------------------------------
-def make_generator():
-    torch.manual_seed(2)
-    args = small_args()
-    G = ref_gen.Wrapper.get_net(args)
-    # make the learned constant non-trivial (its init is all-ones, which InstanceNorm maps to zero)
+def _relu_tie_margin(G, embeds, pose):
+    """smallest |pre-ReLU activation| relative to its tensor's RMS over all ReLUs of the generator (eval forward)"""
+    margins = []
+    hooks = []
+    for mod in G.modules():
+        if isinstance(mod, nn.ReLU):
+            hooks.append(mod.register_forward_pre_hook(
+                lambda _m, inp: margins.append((inp[0].abs().min() / inp[0].pow(2).mean().sqrt()).item())))
+    Gc = G
+    was = Gc.training
+    Gc.eval()
     with torch.no_grad():
-        G.constant.constant.copy_(torch.randn_like(G.constant.constant))
+        Gc(dict(embeds=embeds, pose_embedding=pose))
+    Gc.train(was)
+    for h in hooks:
+        h.remove()
+    return min(margins)
+
+
+def make_generator():
+    # ReLU gradients are discontinuous at 0: two correct fp32 implementations may disagree on the mask of an element whose
+    # pre-activation is ~1e-7, which in this tiny net (4 channels x 1024 pixels in the last layer) is a several-% gradient
+    # change.  Pick the first seed whose smallest |pre-ReLU| is comfortably above fp32/bf16x3 rounding.
+    args = small_args()
+    for seed in range(2, 200):
+        torch.manual_seed(seed)
+        G = ref_gen.Wrapper.get_net(args)
+        with torch.no_grad():
+            # make the learned constant non-trivial (its init is all-ones, which InstanceNorm maps to zero)
+            G.constant.constant.copy_(torch.randn_like(G.constant.constant))
+        embeds = torch.randn(2, args.embed_channels).requires_grad_(True)
+        pose = torch.randn(2, args.pose_embedding_size).requires_grad_(True)
+        r1, r2 = torch.randn(2, 3, 32, 32), torch.randn(2, 1, 32, 32)
+        Gm = ref_gen.Wrapper.get_net(args); Gm.load_state_dict(G.state_dict())
+        margin = _relu_tie_margin(Gm, embeds.detach(), pose.detach())
+        # train mode runs a power iteration first -> different weights; check that forward too
+        Gm2 = ref_gen.Wrapper.get_net(args); Gm2.load_state_dict(G.state_dict()); Gm2.train()
+        margins2 = []
+        hooks = [m.register_forward_pre_hook(lambda _m, inp: margins2.append((inp[0].abs().min() / inp[0].pow(2).mean().sqrt()).item()))
+                 for m in Gm2.modules() if isinstance(m, nn.ReLU)]
+        with torch.no_grad():
+            Gm2(dict(embeds=embeds.detach(), pose_embedding=pose.detach()))
+        margin = min(margin, min(margins2))
+        if margin > 1e-4:
+            print(f'generator fixture: seed {seed}, ReLU tie margin {margin:.2e}')
+            break
+    else:
+        raise RuntimeError('no seed with a safe ReLU tie margin found')
     out = dict(cfg=np.array([args.image_size, args.num_channels, args.max_num_channels, args.embed_channels,
                              args.pose_embedding_size]))
     out.update(sd_np(G, 'sd.'))
-    embeds = torch.randn(2, args.embed_channels).requires_grad_(True)
-    pose = torch.randn(2, args.pose_embedding_size).requires_grad_(True)
-    r1, r2 = torch.randn(2, 3, 32, 32), torch.randn(2, 1, 32, 32)
     out.update(embeds=npy(embeds), pose=npy(pose), r1=npy(r1), r2=npy(r2))
 
     # eval forward (no power iteration)

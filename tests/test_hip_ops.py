@@ -93,7 +93,8 @@ def test_conv_fwd(case, prec):
 
 
 @pytest.mark.parametrize('prec', [1, 0])
-@pytest.mark.parametrize('case', [(2, 8, 8, 64, 128, 3), (2, 16, 16, 64, 4, 3), (2, 16, 16, 128, 64, 1), (8, 4, 4, 128, 64, 3)])
+@pytest.mark.parametrize('case', [(2, 8, 8, 64, 128, 3), (2, 16, 16, 64, 4, 3), (2, 16, 16, 128, 64, 1), (8, 4, 4, 128, 64, 3),
+                                  (2, 32, 32, 4, 4, 3), (2, 32, 32, 8, 4, 3), (1, 64, 64, 64, 4, 3)])
 def test_conv_dgrad(case, prec):
     """data gradient = same kernel on dY with the mode-1 (flipped, transposed) pack"""
     ops = _ops()
@@ -142,7 +143,7 @@ def test_conv_wgrad(case, prec):
     report(f'conv_wgrad{case} prec={prec}', rel(dw, wgt.grad), TOL[prec])
 
 
-@pytest.mark.parametrize('shape', [(2, 4, 4, 64), (3, 16, 16, 128), (2, 128, 128, 16), (1, 32, 32, 8)])
+@pytest.mark.parametrize('shape', [(2, 4, 4, 64), (3, 16, 16, 128), (2, 128, 128, 16), (1, 32, 32, 8), (2, 32, 32, 4)])
 def test_instnorm_stats(shape):
     ops = _ops()
     n, h, w, c = shape
@@ -159,7 +160,7 @@ def test_instnorm_stats(shape):
 
 
 @pytest.mark.parametrize('ups', [0, 1])
-@pytest.mark.parametrize('shape', [(2, 4, 4, 64), (2, 16, 16, 32), (1, 128, 128, 8)])
+@pytest.mark.parametrize('shape', [(2, 4, 4, 64), (2, 16, 16, 32), (1, 128, 128, 8), (2, 32, 32, 4), (2, 8, 8, 16)])
 def test_adain_relu_bwd(shape, ups):
     ops = _ops()
     n, h, w, c = shape
