@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""bench.py -- train-step images/s at 256x256, per-GPU bs=8 (BASELINE.json metric), on N MI355X GPUs.
+
+Workload at N=1 = BASELINE.json configs[1]: the fine-tuning step of configs/finetuning-base.yaml
+(criterions adversarial, featmat, idt_embed, perceptual, dice; RAdam lr_gen 5e-4 / lr_dis 8e-4; EMA 0.972), bs=8,
+256x256, synthetic VoxCeleb2-shaped batch, random-init weights (no network for datasets/checkpoints).  One "step" =
+runners/holycow.py:230-257: E(pose) -> G -> D x3 -> criterions -> G backward/step -> D backward/step -> EMA.
+Round-1 scope ("generator-only HIP path"): the generator forward/backward runs on the hand-written gfx950 kernels; the
+pose encoder, discriminator and VGG criterions run on stock PyTorch-ROCm ops.  For N>1 the same per-GPU step runs data
+parallel with the RCCL gradient all-reduce of latent_pose_reenactment_amd.parallel (weak scaling).
+
+Prints ONE JSON line on rank 0 (see README/DESIGN for the field definitions)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'latent_pose_reenactment_amd'))    # plugin packages: generators/, criterions/, ...
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+GEN_FWD_GFLOP_PER_IMAGE = 60.72      # SURVEY 8d / BASELINE.md: dense 2*MAC, as executed by the reference
+MFMA_BF16_PEAK_TFLOPS = 2500.0       # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+
+
+def make_args(image_size, batch_size, device, num_gpus, rank, prec_name):
+    a = argparse.Namespace(
+        image_size=image_size, batch_size=batch_size * num_gpus, num_gpus=num_gpus, world_size=num_gpus, rank=rank, device=device,
+        in_channels=3, out_channels=3, num_channels=64, max_num_channels=512, embed_channels=512, pose_embedding_size=256,
+        gen_padding='zero', norm_layer='in', gen_constant_input_size=4, gen_num_residual_blocks=2,
+        dis_padding='zero', dis_num_blocks=7, num_labels=98000, average_function='sum',
+        gan_type='gan', fm_weight=10.0, dice_weight=1.0, perc_weight=3e-2, idt_embed_weight=0.6e-2,
+        vgg_weights_dir='/nonexistent', synthetic_vgg_seed=1234,
+        optimizer='RAdam', lr_gen=5e-4, lr_dis=8e-4, beta1=0.0, finetune=True, random_seed=123)
+    os.environ['LP_PREC'] = prec_name
+    return a
+
+
+def build(args):
+    from generators.vector_pose_unsupervised_segmentation_noBottleneck import Wrapper as GW
+    from embedders.unsupervised_pose_separate_embResNeXt_segmentation import Wrapper as EW
+    from discriminators.no_landmarks import Wrapper as DW
+    from criterions import adversarial, featmat, idt_embed, perceptual, dice
+    from runners import holycow
+    torch.manual_seed(args.random_seed)
+    D = DW.get_net(args)
+    G = GW.get_net(args)
+    E = EW.get_net(args)
+    crits = [m.Wrapper.get_net(args) for m in (adversarial, featmat, idt_embed, perceptual, dice)]
+    tm = holycow.TrainingModule(E, G, D, crits, [], {})
+    # fine-tuning bootstrap (train.py:218-279): identity embedding e_hat -> generator parameter / discriminator row
+    e_hat = torch.randn(1, args.embed_channels, device=args.device) * 0.1
+    dd = {'embeds': e_hat}
+    tm.embedder.enable_finetuning()
+    tm.generator.enable_finetuning(dd)
+    tm.discriminator.enable_finetuning(dd)
+    tm.running_averages['generator'].enable_finetuning(dd)
+    tm.running_averages['embedder'].enable_finetuning()
+    opt_G = holycow.get_optimizer(tm.embedder, tm.generator, args)
+    opt_D = DW.get_optimizer(tm.discriminator, args)
+    tm.train()
+    return tm, opt_G, opt_D, holycow
+
+
+def synthetic_batch(args, per_gpu_batch, seed):
+    from dataloaders.synthetic_voxceleb2 import make_sample
+    datas, targets = zip(*[make_sample(i, args.image_size, 1, args.num_labels, True, seed) for i in range(per_gpu_batch)])
+    data = {k: torch.stack([d[k] for d in datas]).to(args.device) for k in datas[0]}
+    target = {'real_segm': torch.stack([t['real_segm'] for t in targets]).to(args.device),
+              'label': torch.tensor([t['label'] for t in targets], device=args.device)}
+    return data, target
+
+
+def cpu_baseline(args, sample_batch=1):
+    """The oracle (oracle/lp_oracle.py: fp32 CPU restatement, parity-pinned against the reference) timed on this box's
+    host cores on a bounded sample: ONE generator forward+backward of `sample_batch` images at 256x256 (the hot path's
+    generator step; 182.2 GFLOP/image), all cores."""
+    import math
+    from oracle import lp_oracle as O
+    import torch.nn.functional as F
+    cores = min(os.cpu_count() or 1, 32)      # torch-CPU oversubscribes badly beyond one CCD group (256 threads: 100x slower)
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(0)
+    sd = {}
+    blocks = O.generator_channels(64, 512, args.image_size)
+
+    def sn(prefix, shape, bias):
+        fan_in = math.prod(shape[1:])
+        sd[prefix + '.weight_orig'] = ((torch.rand(shape, generator=g) * 2 - 1) / math.sqrt(fan_in)).requires_grad_(True)
+        sd[prefix + '.weight_u'] = F.normalize(torch.randn(shape[0], generator=g), dim=0)
+        sd[prefix + '.weight_v'] = F.normalize(torch.randn(fan_in, generator=g), dim=0)
+        if bias:
+            sd[prefix + '.bias'] = torch.zeros(shape[0], requires_grad=True)
+    for i, (cin, cout, up) in enumerate(blocks):
+        i1, i2 = (4, 8) if up else (3, 7)
+        sn(f'decoder_blocks.{i}.block.{i1}', (cout, cin, 3, 3), False)
+        sn(f'decoder_blocks.{i}.block.{i2}', (cout, cout, 3, 3), False)
+        if up:
+            sn(f'decoder_blocks.{i}.skip.1', (cout, cin, 1, 1), True)
+    nb = len(blocks)
+    sn(f'decoder_blocks.{nb + 2}', (4, blocks[-1][1], 3, 3), True)
+    naff = sum(2 * (a + b) for a, b, _ in blocks) + 2 * blocks[-1][1]
+    sn('affine_params_projector.0', (768, 768), True)
+    sn('affine_params_projector.2', (naff, 768), True)
+    sd['constant.constant'] = torch.randn(1, blocks[0][0], 4, 4, generator=g).requires_grad_(True)
+    e = torch.randn(1, 512, generator=g)
+    p = torch.randn(sample_batch, 256, generator=g)
+
+    def one():
+        rgb, segm = O.generator_forward(sd, e, p, num_channels=64, max_num_channels=512, image_size=args.image_size, train=True)
+        (rgb.mean() + segm.mean()).backward()
+    one()                                   # warm-up (oneDNN primitive creation)
+    t0 = time.time()
+    reps = 0
+    while reps < 3 and time.time() - t0 < 20.0:
+        one()
+        reps += 1
+    dt = (time.time() - t0) / reps
+    return {'value': sample_batch / dt, 'unit': 'generator fwd+bwd images/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{reps} x generator forward+backward of {sample_batch} image(s) at {args.image_size}x{args.image_size} '
+                      f'(oracle/lp_oracle.py, torch CPU fp32, {cores} threads); {dt:.2f} s each'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=8, help='per-GPU batch')
+    ap.add_argument('--image_size', type=int, default=256)
+    ap.add_argument('--prec', default=os.environ.get('LP_PREC', 'bf16x3'), choices=['bf16', 'bf16x3'])
+    ap.add_argument('--workload', default='finetune_step', choices=['finetune_step', 'generator'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    a = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU fallback for the HIP path)')
+    torch.cuda.set_device(local_rank)
+    device = f'cuda:{local_rank}'
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', init_method='env://')
+    assert world == a.gpus, f'--gpus {a.gpus} but WORLD_SIZE={world}'
+
+    args = make_args(a.image_size, a.batch, device, world, rank, a.prec)
+    tm, opt_G, opt_D, holycow = build(args)
+    if world > 1:
+        from latent_pose_reenactment_amd.parallel import GradReducer
+        tm.reducer = GradReducer(tm, finetune=True)
+    data, target = synthetic_batch(args, a.batch, seed=123 + rank)
+
+    from latent_pose_reenactment_amd import hipops
+
+    def gen_only_step():
+        dd = {'pose_embedding': pose_static}
+        tm.generator(dd)
+        (dd['fake_rgbs'].mean() + dd['fake_segm'].mean()).backward()
+
+    if a.workload == 'generator':
+        pose_static = torch.randn(a.batch, 256, device=device)
+        step = gen_only_step
+    else:
+        def step():
+            holycow.train_step(tm, data, target, opt_G, opt_D, args)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    sync()
+    hipops.PROFILE = []
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    prof, hipops.PROFILE = hipops.PROFILE, None
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+
+    # live roofline of the dominant kernel family (HIP events recorded on the launch stream inside the timed region)
+    agg = {}
+    for kind, flops, e0, e1 in prof:
+        d = agg.setdefault(kind, [0.0, 0.0, 0])
+        d[0] += flops; d[1] += e0.elapsed_time(e1) * 1e-3; d[2] += 1
+    roof = None
+    extra = {}
+    for kind, (fl, sec, cnt) in agg.items():
+        ach = fl / sec / 1e12 if sec > 0 else 0.0
+        entry = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                 'frac': round(ach / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': None, 'kernel': kind,
+                 'launches': cnt, 'avg_launch_us': round(sec / max(cnt, 1) * 1e6, 1),
+                 'algorithmic_gflop_per_launch': round(fl / max(cnt, 1) / 1e9, 3)}
+        if kind == 'conv_igemm':
+            roof = entry
+        else:
+            extra['roofline_' + kind] = entry
+
+    if rank == 0:
+        imgs = a.batch * world * a.steps
+        out = {
+            'metric': 'train-step images/sec at 256x256 bs=8' if a.workload == 'finetune_step' else 'generator fwd+bwd images/sec at 256x256 bs=8',
+            'value': round(imgs / dt, 3), 'unit': 'images/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'bf16x3 (hi+lo split bf16 MFMA operands, fp32 accumulate)' if a.prec == 'bf16x3' else 'bf16 (MFMA operands, fp32 accumulate)',
+            'data': 'synthetic VoxCeleb2-shaped batch, random-init weights (VGG weights seeded He-normal)',
+            'config': {'workload': 'finetuning-base.yaml step (configs[1]): G on HIP kernels; E(pose)/D/VGG on torch-ROCm'
+                       if a.workload == 'finetune_step' else 'generator forward+backward only (HIP kernels)',
+                       'image_size': a.image_size, 'per_gpu_batch': a.batch, 'global_batch': a.batch * world,
+                       'parallelism': f'dp{world}', 'precision_mode': a.prec},
+            'roofline': roof,
+        }
+        out.update(extra)
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                out['cpu_baseline'] = cpu_baseline(args)
+            except Exception as ex:      # never lose the GPU line because of the baseline leg
+                out['cpu_baseline'] = {'error': repr(ex)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -4,6 +4,9 @@ There is deliberately NO fallback: if the library is missing or a call fails, an
 import ctypes
 import os
 
+import torch  # noqa: F401  -- MUST precede CDLL: torch bundles its own libamdhip64; loading it first makes liblp_hip.so bind
+#                              to the same HIP runtime instance (otherwise launches fail with "no ROCm-capable device")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'liblp_hip.so')
 

@@ -1,0 +1,64 @@
+"""VGGFace identity criterion on a fixed centre crop (reference API: criterions/idt_embed.py:4-104)."""
+import torch
+import torch.nn.functional as F
+
+from .common.perceptual_loss import PerceptualLoss
+
+
+class Wrapper:
+    @staticmethod
+    def get_args(parser):
+        parser.add('--idt_embed_weight', type=float, default=2e-3)
+
+    @staticmethod
+    def get_net(args):
+        seed = getattr(args, 'synthetic_vgg_seed', None)
+        return Criterion(args.idt_embed_weight, args.vgg_weights_dir, None if seed is None else seed + 1).to(args.device)
+
+
+def crop_and_resize(images, bboxes, target_size=None):
+    """images B x C x H x W, bboxes B x 4 = [t, b, l, r] in pixels -> crops resampled (bilinear, reflection padding,
+    align_corners=False) to ``target_size`` (default H x W) -- idt_embed.py:58-83."""
+    t, b, l, r = bboxes.t().float()
+    n, c, h, w = images.shape
+    theta = torch.zeros(n, 2, 3, dtype=torch.float32, device=images.device)
+    theta[:, 0, 0] = (r - l) / w
+    theta[:, 0, 2] = (l + r) / w - 1
+    theta[:, 1, 1] = (b - t) / h
+    theta[:, 1, 2] = (t + b) / h - 1
+    grid = F.affine_grid(theta, (n, c) + tuple(target_size or (h, w)), align_corners=False)
+    return F.grid_sample(images, grid, mode='bilinear', padding_mode='reflection', align_corners=False)
+
+
+def compute_bboxes_from_keypoints(keypoints):
+    """68 x 2 landmarks -> rough [t, b, l, r] (idt_embed.py:85-104)."""
+    x, y = keypoints.float().view(-1, 68, 2).transpose(0, 2)
+    face_height = y[8] - y[27]
+    b = y[8] + face_height * 0.2
+    t = y[27] - face_height * 0.47
+    mid = (x.min() + x.max()) / 2
+    half = (b - t) * 0.5
+    return torch.stack([t, b, mid - half, mid + half], dim=1)
+
+
+class Criterion(torch.nn.Module):
+    def __init__(self, idt_embed_weight, vgg_weights_dir, synthetic_seed=None):
+        super().__init__()
+        self.idt_embed_crit = PerceptualLoss(idt_embed_weight, vgg_weights_dir, 'face', synthetic_seed).eval()
+
+    def forward(self, data_dict):
+        fake, real = data_dict['fake_rgbs'], data_dict['target_rgbs']
+        if fake.dim() > 4:
+            fake = fake[:, 0]
+        if real.dim() > 4:
+            real = real[:, 0]
+        h, w = real.shape[2:]
+        if 'dec_keypoints' in data_dict:
+            boxes = compute_bboxes_from_keypoints(data_dict['dec_keypoints'])
+            boxes[:, 0:2] *= h
+            boxes[:, 2:4] *= w
+        else:
+            keep = 1 / 1.8
+            t, l = h * (1 - keep) / 2, w * (1 - keep) / 2
+            boxes = torch.tensor([[t, h - t, l, w - l]], dtype=torch.float32, device=real.device).expand(len(real), 4)
+        return {'VGGFace': self.idt_embed_crit(crop_and_resize(fake, boxes), crop_and_resize(real, boxes))}

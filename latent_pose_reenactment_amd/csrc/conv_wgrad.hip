@@ -162,17 +162,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
                 }
 }
 
-// dw[co][ci][tap] = sum_s part[s][tap][co][ci]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int S, int T, int Cout, int Cin,
-                                    int CoP, int CiP) {
+// dw[co][ci][tap] = sum_s part[s][tap][co][ci].  One thread per (tap, co, ci) with ci fastest -> every partial read is
+// coalesced; 8 independent accumulators keep 8 loads in flight per thread (the slabs are streamed once from HBM/L2).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int S, int T,
+                                                           int Cout, int Cin, int CoP, int CiP) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= Cout * Cin) return;
-    int ci = idx % Cin, co = idx / Cin;
-    for (int t = 0; t < T; ++t) {
-        float s = 0.f;
-        for (int k = 0; k < S; ++k) s += part[(((size_t)k * T + t) * CoP + co) * CiP + ci];
-        dw[(size_t)idx * T + t] = s;
+    if (idx >= T * Cout * Cin) return;
+    int ci = idx % Cin, r = idx / Cin;
+    int co = r % Cout, t = r / Cout;
+    const size_t slab = (size_t)T * CoP * CiP;
+    const float* p = part + ((size_t)t * CoP + co) * CiP + ci;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    for (; k + 8 <= S; k += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += p[(size_t)(k + j) * slab];
     }
+    for (; k < S; ++k) a[0] += p[(size_t)k * slab];
+    dw[((size_t)co * Cin + ci) * T + t] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
 }
 
 static int ilog2_floor_w(int v) { int l = 0; while ((1 << (l + 1)) <= v) ++l; return l; }
@@ -206,7 +213,7 @@ static int launch_wgrad(WgradParams& p, float* dw, hipStream_t stream) {
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
     int rc = lp_check_launch("conv_wgrad");
     if (rc) return rc;
-    int total = p.Cout * p.Cin;
+    int total = KS * KS * p.Cout * p.Cin;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, p.part, dw, p.splits, KS * KS,
                        p.Cout, p.Cin, p.CoP, p.CiP);
     return lp_check_launch("wgrad_reduce");

@@ -42,7 +42,7 @@ extern "C" int lp_pack_weights(const float* w, uint16_t* hi, uint16_t* lo, int C
 //            merged with Chan's parallel-variance formula (no E[x^2]-E[x]^2 cancellation).
 //   stage 2: one thread per (n,c) merges the splits in fp64 and emits mean, rstd, scale, shift.
 // ------------------------------------------------------------------------------------------------------------------
-#define STAT_SPLIT_PIX 4096   // pixels per stage-1 block
+#define STAT_SPLIT_PIX 1024   // pixels per stage-1 block (256^2 x 64ch x 8 images -> 4096 blocks)
 
 __device__ __forceinline__ void chan_merge(float& n_a, float& mean_a, float& m2_a, float n_b, float mean_b, float m2_b) {
     if (n_b == 0.f) return;

@@ -1,0 +1,135 @@
+"""Projection-discriminator plugin (reference API: discriminators/no_landmarks.py:11-166), key-compatible state_dict.
+
+Behavioural notes reproduced on purpose:
+  * every norm-'none' ResBlock starts with ReLU(inplace) on its *input* (generators/common/blocks.py:71-73), so its skip
+    branch / identity add see relu(x), and the features handed to feature matching are post-ReLU except the last one;
+  * pass_inputs runs three times per step (fake->G, fake.detach->D, real), each doing its own power iteration.
+Round-1 status: the convolutions of this module still run on stock PyTorch-ROCm ops (the round-1 scope is the
+"generator-only HIP path", BASELINE.json configs[1]); they map 1:1 onto lp_conv_fwd (pro=2 ReLU prologue) next."""
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from latent_pose_reenactment_amd.nn import SNWeight, _Indexed, SN_EPS_CONV, SN_EPS_DEFAULT
+from latent_pose_reenactment_amd.utils import radam as _radam
+
+torch.optim.RAdam = _radam.RAdam      # the reference swaps in its own RAdam the same way (no_landmarks.py:5-6)
+
+
+class Wrapper:
+    @staticmethod
+    def get_args(parser):
+        parser.add('--dis_padding', type=str, default='zero', help='zero (reflection is not implemented)')
+        parser.add('--dis_num_blocks', type=int, default=7)
+        parser.add('--lr_dis', type=float, default=2e-4)
+
+    @staticmethod
+    def get_net(args):
+        return Discriminator(args.dis_padding, args.in_channels, args.out_channels, args.num_channels, args.max_num_channels,
+                             args.embed_channels, args.dis_num_blocks, args.image_size, args.num_labels).to(args.device)
+
+    @staticmethod
+    def get_optimizer(discriminator, args):
+        opt = torch.optim.__dict__[args.optimizer]
+        return opt(discriminator.parameters(), lr=args.lr_dis, betas=(args.beta1, 0.999), eps=1e-5)
+
+
+class _DisBlock(nn.Module):
+    """parameters of blocks.ResBlock(norm_layer='none'): block.2, block.5 (3x3 + bias) and optional skip.0 (1x1 + bias)"""
+
+    def __init__(self, cin, cout, downsample):
+        super().__init__()
+        self.block = _Indexed(_2=SNWeight((cout, cin, 3, 3), True, SN_EPS_CONV), _5=SNWeight((cout, cout, 3, 3), True, SN_EPS_CONV))
+        self.has_skip = cin != cout or downsample
+        if self.has_skip:
+            self.skip = _Indexed(_0=SNWeight((cout, cin, 1, 1), True, SN_EPS_CONV))
+        self.downsample = downsample
+
+    def forward(self, x_relu):
+        c1, c2 = self.block._modules['2'], self.block._modules['5']
+        h = F.conv2d(x_relu, c1.effective_weight(), c1.bias, 1, 1)
+        h = F.conv2d(torch.relu(h), c2.effective_weight(), c2.bias, 1, 1)
+        if self.downsample:
+            h = F.avg_pool2d(h, 2)
+        if self.has_skip:
+            sk = self.skip._modules['0']
+            s = F.conv2d(x_relu, sk.effective_weight(), sk.bias)
+            return h + (F.avg_pool2d(s, 2) if self.downsample else s)
+        return h + x_relu
+
+
+class Discriminator(nn.Module):
+    def __init__(self, padding, in_channels, out_channels, num_channels, max_num_channels, embed_channels, dis_num_blocks,
+                 image_size, num_labels):
+        super().__init__()
+        if padding != 'zero':
+            raise NotImplementedError("only dis_padding='zero' is implemented")
+        self.out_channels = embed_channels
+        self.down_block = _Indexed(_0=SNWeight((num_channels, in_channels, 3, 3), True, SN_EPS_CONV),
+                                   _2=SNWeight((num_channels, num_channels, 3, 3), True, SN_EPS_CONV))
+        self.skip = _Indexed(_0=SNWeight((num_channels, in_channels, 1, 1), True, SN_EPS_CONV))
+        self.blocks = nn.ModuleList()
+        num_down = min(int(math.log(image_size, 2)) - 2, dis_num_blocks)
+        cin = num_channels
+        cout = cin
+        for i in range(1, num_down):
+            cout = min(cin * 2, max_num_channels)
+            if i == dis_num_blocks - 1:
+                cout = self.out_channels
+            self.blocks.append(_DisBlock(cin, cout, True))
+            cin = cout
+        for i in range(num_down, dis_num_blocks):
+            if i == dis_num_blocks - 1:
+                cout = self.out_channels
+            self.blocks.append(_DisBlock(cin, cout, False))
+        self.linear = SNWeight((1, self.out_channels), True, SN_EPS_CONV)
+        self.embed = SNWeight((num_labels, self.out_channels), False, SN_EPS_CONV)
+        with torch.no_grad():
+            self.embed.weight_orig.uniform_(-0.1, 0.1)
+        self.finetuning = False
+
+    def pass_inputs(self, x, embed=None):
+        d0, d2, sk = self.down_block._modules['0'], self.down_block._modules['2'], self.skip._modules['0']
+        h = torch.relu(F.conv2d(x, d0.effective_weight(), d0.bias, 1, 1))
+        h = F.avg_pool2d(F.conv2d(h, d2.effective_weight(), d2.bias, 1, 1), 2)
+        out = h + F.avg_pool2d(F.conv2d(x, sk.effective_weight(), sk.bias), 2)
+        feats = []
+        for block in self.blocks:
+            out_relu = torch.relu(out)           # what the reference's in-place ReLU leaves behind in its feature list
+            feats.append(out_relu)
+            out = block(out_relu)
+        feats.append(out)
+        pooled = torch.relu(out).flatten(2).sum(2)
+        score = F.linear(pooled, self.linear.effective_weight(), self.linear.bias)[:, 0]
+        if embed is not None:
+            score = (pooled * embed).sum(1) + score
+        return score, feats
+
+    def enable_finetuning(self, data_dict=None):
+        """no_landmarks.py:110-136: the label embedding matrix collapses to one row holding the identity embedding."""
+        ref = next(iter(self.parameters()))
+        if data_dict is None:
+            data_dict = {'embeds': torch.rand(1, self.out_channels).to(ref)}
+        with torch.no_grad():
+            if self.finetuning:
+                self.embed.weight_orig.copy_(data_dict['embeds'])
+            else:
+                fresh = SNWeight((1, self.out_channels), False, SN_EPS_DEFAULT).to(ref)
+                fresh.weight_orig.copy_(data_dict['embeds'])
+                self.embed = fresh
+                self.finetuning = True
+
+    def forward(self, data_dict):
+        fake, real, label = data_dict['fake_rgbs'], data_dict['target_rgbs'], data_dict['label']
+        if fake.dim() > 4:
+            fake = fake[:, 0]
+        if real.dim() > 4:
+            real = real[:, 0]
+        embed = F.embedding(label, self.embed.effective_weight())
+        fake_score_G, fake_features = self.pass_inputs(fake, embed)
+        fake_score_D, _ = self.pass_inputs(fake.detach(), embed.detach())
+        real_score, real_features = self.pass_inputs(real, embed)
+        data_dict.update(fake_features=fake_features, real_features=real_features, real_embedding=embed,
+                         fake_score_G=fake_score_G, fake_score_D=fake_score_D, real_score=real_score)

@@ -14,6 +14,28 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# Optional live profiling hook used by bench.py: when PROFILE is a list, every conv / wgrad launch is bracketed by
+# HIP events recorded on the launch stream and appended as (kind, flops, start_event, end_event).
+PROFILE = None
+
+
+class _Timed:
+    def __init__(self, kind, flops):
+        self.kind, self.flops = kind, flops
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if PROFILE is not None:
+            self.e1.record()
+            PROFILE.append((self.kind, self.flops, self.e0, self.e1))
+
+
 def _p(t: Optional[Tensor]):
     return None if t is None else t.data_ptr()
 
@@ -68,9 +90,10 @@ def conv(x: Tensor, pack: WeightPack, *, ksize: int, upsample: bool = False, pro
             _chk(t, nm)
     if res is not None:
         assert res.shape == (n, h >> res_shift, w >> res_shift, cout), (res.shape, y.shape, res_shift)
-    check(_lib.lib().lp_conv_fwd(x.data_ptr(), pack.hi.data_ptr(), _p(pack.lo), y.data_ptr(), _p(scale), _p(shift), _p(bias), _p(res),
-                                 _p(alpha), n, h, w, cin, cout, pack.cols_p, pack.rows_p, ksize, int(upsample), pro, res_shift, prec,
-                                 _stream()), 'lp_conv_fwd')
+    with _Timed('conv_igemm', 2.0 * n * h * w * cout * cin * ksize * ksize):
+        check(_lib.lib().lp_conv_fwd(x.data_ptr(), pack.hi.data_ptr(), _p(pack.lo), y.data_ptr(), _p(scale), _p(shift), _p(bias),
+                                     _p(res), _p(alpha), n, h, w, cin, cout, pack.cols_p, pack.rows_p, ksize, int(upsample), pro,
+                                     res_shift, prec, _stream()), 'lp_conv_fwd')
     return y
 
 
@@ -82,12 +105,13 @@ def conv_wgrad(x: Tensor, dy: Tensor, *, ksize: int, upsample: bool = False, pro
     cin = x.shape[3]
     if splits is None:
         blocks = _round_up(cout, 64) // 64 * (_round_up(cin, 64) // 64)
-        splits = max(1, min(1024 // blocks, (n * h * w + 127) // 128))
+        splits = max(1, min(512 // blocks, (n * h * w + 127) // 128))     # ~2 workgroups per CU in total
     ws_bytes = _lib.lib().lp_conv_wgrad_workspace_bytes(cin, cout, ksize, splits)
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
     dw = torch.empty((cout, cin, ksize, ksize), dtype=torch.float32, device=x.device)
-    check(_lib.lib().lp_conv_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), _p(scale), _p(shift), n, h, w, cin, cout,
-                                   ksize, int(upsample), pro, splits, prec, _stream()), 'lp_conv_wgrad')
+    with _Timed('conv_wgrad', 2.0 * n * h * w * cout * cin * ksize * ksize):
+        check(_lib.lib().lp_conv_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), _p(scale), _p(shift), n, h, w, cin,
+                                       cout, ksize, int(upsample), pro, splits, prec, _stream()), 'lp_conv_wgrad')
     return dw
 
 

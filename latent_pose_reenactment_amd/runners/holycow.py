@@ -1,0 +1,187 @@
+"""Training runner (reference API: runners/holycow.py:18-402): ``get_args``, ``get_optimizer``, ``TrainingModule``,
+``run_epoch``.  The step ordering of run_epoch is part of parity:
+  zero_grad(G) -> loss_G.backward(retain_graph) -> [all-reduce] -> step(G) -> zero_grad(D) -> loss_D.backward() ->
+  [all-reduce] -> step(D) -> EMA(0.999 | 0.972 when fine-tuning).
+The reference's apex ``Reducer`` is replaced by ``parallel.GradReducer`` (RCCL all-reduce over xGMI of exactly the
+gradients each optimizer is about to consume).  TensorBoard / image-grid logging branches (holycow.py:266-400) are
+observability and out of scope; scalar losses go to ``Meter`` as in the reference."""
+import copy
+import itertools
+import logging
+import time
+
+import torch
+from torch import nn
+
+from latent_pose_reenactment_amd.utils import radam as _radam
+from latent_pose_reenactment_amd.utils.utils import Meter, dict_to_device
+
+torch.optim.RAdam = _radam.RAdam
+logger = logging.getLogger('runner')
+
+
+def get_args(parser):
+    parser.add('--iteration', type=int, default=0, help="Optional iteration number to start from")
+    parser.add('--log_frequency_loss', type=int, default=1)
+    parser.add('--log_frequency_images', type=int, default=100)
+    parser.add('--log_frequency_fixed_images', type=int, default=2500)
+    parser.add('--detailed_metrics', action='store_bool', default=True)
+    parser.add('--num_visuals_per_img', default=2, type=int)
+    parser.add('--fixed_val_ids', action='append', type=int, default=[50, 100, 200, 250, 300])
+    parser.add('--batch_size_inference', default=5, type=int)
+    return parser
+
+
+def get_optimizer(embedder, generator, args):
+    params = list(generator.parameters())
+    if not getattr(args, 'finetune', False):
+        params += list(embedder.parameters())
+    opt = torch.optim.__dict__[args.optimizer]
+    return opt(params, lr=args.lr_gen, betas=(args.beta1, 0.999), eps=1e-5)
+
+
+class _Toggle:
+    """attribute override usable both as a plain call and as a context manager (holycow.py:111-151)"""
+
+    def __init__(self, obj, name, value):
+        self.obj, self.name, self.old = obj, name, getattr(obj, name)
+        setattr(obj, name, value)
+
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        setattr(self.obj, self.name, self.old)
+
+
+class TrainingModule(nn.Module):
+    def __init__(self, embedder, generator, discriminator, criterion_list, metric_list, running_averages={}):
+        super().__init__()
+        self.embedder, self.generator, self.discriminator = embedder, generator, discriminator
+        self.criterion_list = nn.ModuleList(criterion_list)
+        self.metric_list = nn.ModuleList(metric_list)
+        self.compute_losses = True
+        self.use_running_averages = False
+        self.initialize_running_averages(running_averages)
+
+    def initialize_running_averages(self, initial_values={}):
+        """EMA copies of embedder and generator kept in a plain dict (not sub-modules: they are neither broadcast nor
+        reduced nor optimised); ``None`` disables them -- holycow.py:65-97."""
+        self.running_averages = {}
+        if initial_values is not None:
+            for name in ('embedder', 'generator'):
+                avg = copy.deepcopy(getattr(self, name))
+                if name in initial_values:
+                    try:
+                        avg.load_state_dict(initial_values[name])
+                    except Exception:
+                        logger.warning(f"running-average state of {name} does not fit the module; initialising by cloning")
+                        avg.load_state_dict(getattr(self, name).state_dict())
+                else:
+                    logger.info(f"No initial value of weights' running averages provided for {name}. Initializing by cloning")
+                self.running_averages[name] = avg
+        for module in self.running_averages.values():
+            module.eval()
+            module.requires_grad_(False)
+
+    def update_running_average(self, alpha=0.999):
+        with torch.no_grad():
+            for name, avg in self.running_averages.items():
+                cur = getattr(self, name)
+                for p, p_avg in zip(cur.parameters(), avg.parameters()):
+                    p_avg.mul_(alpha).add_(p * (1 - alpha))
+                for b, b_avg in zip(cur.buffers(), avg.buffers()):
+                    b_avg.copy_(b)
+
+    def set_use_running_averages(self, use_running_averages=True):
+        return _Toggle(self, 'use_running_averages', use_running_averages)
+
+    def set_compute_losses(self, compute_losses=True):
+        return _Toggle(self, 'compute_losses', compute_losses)
+
+    def forward(self, data_dict, target_dict):
+        if self.running_averages and self.use_running_averages:
+            embedder, generator = self.running_averages['embedder'], self.running_averages['generator']
+        else:
+            embedder, generator = self.embedder, self.generator
+        data_dict = copy.copy(data_dict)          # inputs only; modules add their outputs
+        embedder(data_dict)
+        generator(data_dict)
+        data_dict.update(target_dict)
+        if self.compute_losses:
+            self.discriminator(data_dict)
+        losses_G, losses_D = {}, {}
+        for criterion in self.criterion_list:
+            try:
+                out = criterion(data_dict)
+            except Exception:
+                if self.compute_losses:
+                    raise
+                continue                          # visual/eval forwards lack targets: skip that loss
+            if isinstance(out, tuple):
+                if len(out) != 2:
+                    raise TypeError(f'Unexpected number of outputs in criterion {type(criterion)}: expected 2, got {len(out)}')
+                losses_G.update(out[0])
+                losses_D.update(out[1])
+            elif isinstance(out, dict):
+                losses_G.update(out)
+            else:
+                raise TypeError(f'Unexpected type of {type(criterion)} output: expected dict or tuple of two dicts, got {type(out)}')
+        return data_dict, losses_G, losses_D
+
+    def compute_metrics(self, data_dict):
+        meter = Meter()
+        for metric in self.metric_list:
+            values, counts = metric(data_dict)
+            for k, v in values.items():
+                meter.add(k, v, counts[k])
+        return meter
+
+
+def train_step(training_module, data_dict, target_dict, optimizer_G, optimizer_D, args):
+    """one iteration of the hot loop (holycow.py:230-257); returns (all_data_dict, losses_G, losses_D)"""
+    all_data, losses_G, losses_D = training_module(data_dict, target_dict)
+    loss_G = sum(v for v in losses_G.values() if isinstance(v, torch.Tensor))
+    loss_D = sum(v for v in losses_D.values() if isinstance(v, torch.Tensor))
+    reducer = getattr(training_module, 'reducer', None)
+    multi = 1 < args.num_gpus <= 8 and reducer is not None
+    optimizer_G.zero_grad()
+    loss_G.backward(retain_graph=True)
+    if multi:
+        reducer.reduce_generator_side()
+    optimizer_G.step()
+    if losses_D:
+        optimizer_D.zero_grad()
+        loss_D.backward()
+        if multi:
+            reducer.reduce_discriminator_side()
+        optimizer_D.step()
+    training_module.update_running_average(0.972 if args.finetune else 0.999)
+    return all_data, losses_G, losses_D
+
+
+def run_epoch(dataloader, training_module, optimizer_G, optimizer_D, epoch, args, phase, writer=None, saver=None):
+    meter = Meter()
+    if phase == 'train':
+        optimizer_G.zero_grad()
+        if optimizer_D:
+            optimizer_D.zero_grad()
+    end = time.time()
+    for it, (data_dict, target_dict) in enumerate(dataloader):
+        meter.add('Data_time', time.time() - end)
+        dict_to_device(data_dict, args.device)
+        dict_to_device(target_dict, args.device)
+        if phase == 'train':
+            all_data, losses_G, losses_D = train_step(training_module, data_dict, target_dict, optimizer_G, optimizer_D, args)
+        else:
+            all_data, losses_G, losses_D = training_module(data_dict, target_dict)
+            if saver is not None:
+                saver.save(epoch=epoch, data=all_data)
+        if args.detailed_metrics:
+            for name, value in itertools.chain(losses_G.items(), losses_D.items()):
+                meter.add(f'Loss_{name}', float(value))      # device->host sync, as in the reference (holycow.py:260-262)
+        if writer is not None and phase == 'train':
+            args.iteration += 1                              # the reference counts iterations only on the logging rank
+        meter.add('Batch_time', time.time() - end)
+        end = time.time()
+    return meter
