@@ -81,6 +81,28 @@ int lp_sum2x2(const float* in, float* out, int N, int H, int W, int C, void* str
 int lp_head_fwd(const float* z, float* t, float* fake_rgbs, float* fake_segm, int N, int H, int W, void* stream);
 int lp_head_bwd(const float* t, const float* d_rgbs, const float* d_segm, float* dz, int N, int H, int W, void* stream);
 
+/* ---- discriminator / perceptual-loss helpers (discriminators/no_landmarks.py:52-108, criterions/common/perceptual_loss.py) ---- */
+/* dx = dA * [x > 0]                       (autograd of nn.ReLU, blocks.py:71-73,84) */
+int lp_relu_bwd(const float* dA, const float* x, float* dx, long long numel, void* stream);
+/* y = AvgPool2d(2)(relu?(x)); x [N][2H][2W][C], y [N][H][W][C]   (nn.AvgPool2d, blocks.py:89-90; perceptual_loss.py:77) */
+int lp_avgpool2_fwd(const float* x, float* y, int N, int H, int W, int C, int relu_in, void* stream);
+/* dx [N][H][W][C] = 0.25 * dy[.., y>>1, x>>1, ..] * (relu_in ? [x>0] : 1); H, W = full-resolution dims */
+int lp_avgpool2_bwd(const float* dy, const float* x, float* dx, int N, int H, int W, int C, int relu_in, void* stream);
+/* L1 taps: partial[lp_l1_partial_blocks()] block sums of |relu?(a) - relu?(b)| (F.l1_loss numerator; featmat.py:17, perceptual_loss.py:107);
+ * backward: da = coef * grad_out[0] * sign(relu?(a) - relu?(b)) * (relu_in ? [a>0] : 1) */
+int lp_l1_partial_blocks(void);
+int lp_l1_fwd(const float* a, const float* b, float* partial, long long numel, int relu_in, void* stream);
+int lp_l1_bwd(const float* a, const float* b, const float* grad_out, float coef, float* da, long long numel, int relu_in, void* stream);
+
+/* ---- fused multi-tensor optimizers + EMA (runners/holycow.py:34-41,99-109; utils/radam.py:29-95; torch.optim.Adam) ----
+ * table: DEVICE array of {float* p; const float* g; float* m; float* v; long long n;} (lp_mt_desc_bytes() each), one per
+ * parameter tensor; step: DEVICE int64 counter, incremented by the call (graph-replay safe).  kind 0 = RAdam, 1 = Adam.
+ * lp_mt_ema: p <- p*alpha + g*(1-alpha) (copy_only=1: p <- g, used for buffers). */
+int lp_mt_desc_bytes(void);
+int lp_mt_optimizer_step(const void* table, int num_tensors, long long max_numel, long long* step, int kind, float lr,
+                         float beta1, float beta2, float eps, void* stream);
+int lp_mt_ema(const void* table, int num_tensors, long long max_numel, float alpha, int copy_only, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,13 +5,17 @@ AvgPool; inputs mapped (x+1)/2 then (x - mean_bgr/255)*255 on RGB-ordered channe
 is the sum over all 13 ReLU outputs of mean|f(fake) - f(real)| times ``weight``.  The VGG definitions come from
 torchvision in the reference (absent here); the standard 'E' / 'D' configurations are restated below.  State-dict keys of
 ``self.model`` are the ``features`` indices (``0.weight`` ...), as in the reference.
-Round-1 status: stock PyTorch-ROCm convolutions (generator-only HIP scope); maps onto lp_conv_fwd next."""
+The feature stack runs on the gfx950 kernels: every conv is lp_conv_fwd (the preceding ReLU fused as its prologue),
+ReLU+AvgPool is lp_avgpool2_fwd, each tap is the fused L1-of-ReLUs kernel; the frozen weights are packed to bf16 once."""
 import os
 from collections import OrderedDict
 
 import torch
 import torch.nn.functional as F
 from torch import nn
+
+from latent_pose_reenactment_amd import hipops as ops
+from latent_pose_reenactment_amd.nn import AvgPool2Fn, default_prec, hip_conv, hip_l1, to_nhwc
 
 CFG = {
     'vgg19': [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512, 512, 'M', 512, 512, 512, 512, 'M'],
@@ -46,6 +50,7 @@ class PerceptualLoss(nn.Module):
             sd = torch.load(path, map_location='cpu')
             sd = OrderedDict((k[len('features.'):] if k.startswith('features.') else k, v) for k, v in sd.items()
                              if not k.startswith('classifier'))
+            sd = OrderedDict((k, v) for k, v in sd.items() if int(k.split('.')[0]) < 30)     # only the first 30 modules are used
             self.model.load_state_dict(sd)
         elif synthetic_seed is not None:
             g = torch.Generator().manual_seed(synthetic_seed)
@@ -67,12 +72,43 @@ class PerceptualLoss(nn.Module):
     def normalize_inputs(self, x):
         return (x - self.mean) / self.std
 
+    def _packs(self, prec):
+        """frozen weights: (forward, dgrad) bf16 packs per conv, built once per precision mode"""
+        cache = self.__dict__.setdefault('_pack_cache', {})
+        key = (prec, self.mean.device)
+        if key not in cache:
+            packs = {}
+            for i, m in enumerate(self.model):
+                if isinstance(m, nn.Conv2d):
+                    w = m.weight.detach().contiguous()
+                    packs[i] = (ops.pack_weights(w, 0, prec, small_k=w.shape[1] <= 32), ops.pack_weights(w, 1, prec, small_k=w.shape[0] <= 32))
+            cache[key] = packs
+        return cache[key]
+
+    def _features(self, x, packs, prec, taps):
+        cur, pending_relu = to_nhwc(x), False
+        for i, layer in enumerate(self.model):
+            if isinstance(layer, nn.Conv2d):
+                cur = hip_conv(cur, layer.weight, layer.bias, ksize=3, pro=2 if pending_relu else 0, prec=prec, packs=packs[i])
+                pending_relu = True
+            elif isinstance(layer, nn.ReLU):
+                taps.append(cur)                 # pre-ReLU conv output; the ReLU is fused into its consumers
+            else:
+                cur = AvgPool2Fn.apply(cur, pending_relu)
+                pending_relu = False
+        return taps
+
     def forward(self, input, target):
+        if not input.is_cuda:
+            raise RuntimeError('PerceptualLoss runs on the MI355X HIP path only (no CPU fallback)')
+        prec = default_prec()
+        packs = self._packs(prec)
         fi = self.normalize_inputs((input + 1) / 2)
-        ft = self.normalize_inputs((target.detach() + 1) / 2)
+        with torch.no_grad():
+            ft = self.normalize_inputs((target.detach() + 1) / 2)
+            taps_t = self._features(ft, packs, prec, [])
+        taps_i = self._features(fi, packs, prec, [])
         loss = 0
-        for layer in self.model:
-            fi, ft = layer(fi), layer(ft)
-            if isinstance(layer, nn.ReLU):
-                loss = loss + F.l1_loss(fi, ft)
+        for a, b in zip(taps_i, taps_t):
+            loss = loss + hip_l1(a, b, relu_in=True)
         return loss * self.weight

@@ -2,6 +2,8 @@
 import torch.nn.functional as F
 from torch import nn
 
+from latent_pose_reenactment_amd.nn import hip_l1
+
 
 class Wrapper:
     @staticmethod
@@ -20,5 +22,10 @@ class Criterion(nn.Module):
 
     def forward(self, data_dict):
         fake, real = data_dict['fake_features'], data_dict['real_features']
-        total = sum(F.l1_loss(f, r.detach()) for f, r in zip(fake, real))
+        def l1(f, r):
+            # discriminator features arrive as channels_last views: feed their NHWC storage to the fused kernel
+            if f.is_cuda and f.dim() == 4 and f.numel() % 4 == 0:
+                return hip_l1(f.permute(0, 2, 3, 1).contiguous(), r.detach().permute(0, 2, 3, 1).contiguous())
+            return F.l1_loss(f, r.detach())
+        total = sum(l1(f, r) for f, r in zip(fake, real))
         return {'feature_matching': total / len(fake) * self.fm_weight}

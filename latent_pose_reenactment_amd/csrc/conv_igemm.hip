@@ -192,13 +192,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
 static int ilog2_floor(int v) { int l = 0; while ((1 << (l + 1)) <= v) ++l; return l; }
 
 // choose NB x TH x TW = BM with TH<=H, TW<=W (powers of two), preferring wide patches (TW up to 16)
-static void choose_tile(int BM, int H, int W, int* lTH, int* lTW, int* lNB) {
+static void choose_tile(int BM, int N, int H, int W, int* lTH, int* lTW, int* lNB) {
     int lbm = ilog2_floor(BM);
     int ltw = ilog2_floor(W); if (ltw > 4) ltw = 4;
     int lth = ilog2_floor(H); if (lth > lbm - ltw) lth = lbm - ltw;
     if (lth < 1) lth = 1;
     if (ltw < 1) ltw = 1;
     int lnb = lbm - ltw - lth; if (lnb < 0) lnb = 0;
+    while (lnb > 0 && (1 << (lnb - 1)) >= N) --lnb;      // no more images per tile than exist (keeps the LDS halo small)
     *lTH = lth; *lTW = ltw; *lNB = lnb;
 }
 
@@ -207,7 +208,7 @@ static int launch_conv(ConvParams& p, hipStream_t stream) {
     constexpr int BM = WM * MR * 16, BN = WN * NR * 16;
     constexpr int SA = CC * 2 + 16, SB = CC * 2 + 16;
     constexpr bool SPLIT = (PREC == LP_PREC_BF16X3);
-    choose_tile(BM, p.H, p.W, &p.lTH, &p.lTW, &p.lNB);
+    choose_tile(BM, p.N, p.H, p.W, &p.lTH, &p.lTW, &p.lNB);
     const int TH = 1 << p.lTH, TW = 1 << p.lTW, NBv = 1 << p.lNB;
     p.tiles_x = (p.W + TW - 1) / TW; p.tiles_y = (p.H + TH - 1) / TH;
     int HH, HW;

@@ -191,7 +191,7 @@ static int launch_wgrad(WgradParams& p, float* dw, hipStream_t stream) {
     // 128-pixel tiles, row-major inside the patch; TW >= 4 so that 4 consecutive k are 4 consecutive x
     int ltw = ilog2_floor_w(p.W); if (ltw > 4) ltw = 4;
     int lth = ilog2_floor_w(p.H); if (lth > 7 - ltw) lth = 7 - ltw;
-    int lnb = 7 - ltw - lth;
+    int lnb = 7 - ltw - lth;     // NOT capped by N: every one of the 128 k-slots must decode to a staged (zero-filled) halo pixel
     if (ltw < 2) return lp_set_error(LP_ERR_UNSUPPORTED, "wgrad needs W >= 4");
     p.lTH = lth; p.lTW = ltw; p.lNB = lnb;
     const int TH = 1 << lth, TW = 1 << ltw, NBv = 1 << lnb;

@@ -330,3 +330,241 @@ extern "C" int lp_head_bwd(const float* t, const float* d_rgbs, const float* d_s
     hipLaunchKernelGGL(head_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, t, d_rgbs, d_segm, dz, N, H * W);
     return lp_check_launch("head_bwd");
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// discriminator / VGG helpers: ReLU backward, (ReLU +) 2x2 average pool forward/backward, L1 between ReLU'd features
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void relu_bwd_kernel(const float4* __restrict__ dA, const float4* __restrict__ x, float4* __restrict__ dx, long long total4) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < total4; i += stride) {
+        float4 g = dA[i], v = x[i];
+        g.x = v.x > 0.f ? g.x : 0.f; g.y = v.y > 0.f ? g.y : 0.f; g.z = v.z > 0.f ? g.z : 0.f; g.w = v.w > 0.f ? g.w : 0.f;
+        dx[i] = g;
+    }
+}
+
+extern "C" int lp_relu_bwd(const float* dA, const float* x, float* dx, long long numel, void* stream) {
+    if (!dA || !x || !dx) return lp_set_error(LP_ERR_ARG, "lp_relu_bwd: null pointer");
+    if (numel & 3) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_relu_bwd: numel must be a multiple of 4");
+    long long total4 = numel / 4;
+    int blocks = (int)((total4 + 255) / 256); if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)dA, (const float4*)x, (float4*)dx, total4);
+    return lp_check_launch("relu_bwd");
+}
+
+// y[n,Y,X,c] = 0.25 * sum_{2x2} act(x[n,2Y+i,2X+j,c]),  act = relu if relu_in else identity.  H, W = OUTPUT dims.
+__global__ void avgpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long total4, int H, int W, int C, int relu_in) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const int C4 = C >> 2;
+    for (; i < total4; i += stride) {
+        int c = (int)(i % C4) * 4;
+        long long pix = i / C4;
+        int xx = (int)(pix % W); long long t = pix / W;
+        int yy = (int)(t % H); int n = (int)(t / H);
+        const float* b = x + (((size_t)n * 2 * H + 2 * yy) * 2 * W + 2 * xx) * C + c;
+        float4 a0 = *(const float4*)b, a1 = *(const float4*)(b + C), a2 = *(const float4*)(b + (size_t)2 * W * C),
+               a3 = *(const float4*)(b + (size_t)2 * W * C + C), o;
+        if (relu_in) {
+            a0.x = fmaxf(a0.x, 0.f); a0.y = fmaxf(a0.y, 0.f); a0.z = fmaxf(a0.z, 0.f); a0.w = fmaxf(a0.w, 0.f);
+            a1.x = fmaxf(a1.x, 0.f); a1.y = fmaxf(a1.y, 0.f); a1.z = fmaxf(a1.z, 0.f); a1.w = fmaxf(a1.w, 0.f);
+            a2.x = fmaxf(a2.x, 0.f); a2.y = fmaxf(a2.y, 0.f); a2.z = fmaxf(a2.z, 0.f); a2.w = fmaxf(a2.w, 0.f);
+            a3.x = fmaxf(a3.x, 0.f); a3.y = fmaxf(a3.y, 0.f); a3.z = fmaxf(a3.z, 0.f); a3.w = fmaxf(a3.w, 0.f);
+        }
+        o.x = 0.25f * ((a0.x + a1.x) + (a2.x + a3.x)); o.y = 0.25f * ((a0.y + a1.y) + (a2.y + a3.y));
+        o.z = 0.25f * ((a0.z + a1.z) + (a2.z + a3.z)); o.w = 0.25f * ((a0.w + a1.w) + (a2.w + a3.w));
+        ((float4*)y)[i] = o;
+    }
+}
+
+// dx[n,y,x,c] = 0.25 * dy[n,y>>1,x>>1,c] * (relu_in ? [x>0] : 1).  H, W = INPUT (full-res) dims; one thread per 2x2 block.
+__global__ void avgpool2_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx, long long total4,
+                                    int H, int W, int C, int relu_in) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const int C4 = C >> 2, Ho = H >> 1, Wo = W >> 1;
+    for (; i < total4; i += stride) {
+        int c = (int)(i % C4) * 4;
+        long long pix = i / C4;
+        int xx = (int)(pix % Wo); long long t = pix / Wo;
+        int yy = (int)(t % Ho); int n = (int)(t / Ho);
+        float4 g = ((const float4*)dy)[i];
+        g.x *= 0.25f; g.y *= 0.25f; g.z *= 0.25f; g.w *= 0.25f;
+        size_t base = (((size_t)n * H + 2 * yy) * W + 2 * xx) * C + c;
+        const size_t offs[4] = {0, (size_t)C, (size_t)W * C, (size_t)W * C + C};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float4 o = g;
+            if (relu_in) {
+                float4 v = *(const float4*)(x + base + offs[k]);
+                o.x = v.x > 0.f ? o.x : 0.f; o.y = v.y > 0.f ? o.y : 0.f; o.z = v.z > 0.f ? o.z : 0.f; o.w = v.w > 0.f ? o.w : 0.f;
+            }
+            *(float4*)(dx + base + offs[k]) = o;
+        }
+    }
+}
+
+extern "C" int lp_avgpool2_fwd(const float* x, float* y, int N, int H, int W, int C, int relu_in, void* stream) {
+    if (!x || !y) return lp_set_error(LP_ERR_ARG, "lp_avgpool2_fwd: null pointer");
+    if (C & 3) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_avgpool2_fwd: C must be a multiple of 4");
+    long long total4 = (long long)N * H * W * C / 4;
+    int blocks = (int)((total4 + 255) / 256); if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(avgpool2_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, total4, H, W, C, relu_in);
+    return lp_check_launch("avgpool2_fwd");
+}
+
+extern "C" int lp_avgpool2_bwd(const float* dy, const float* x, float* dx, int N, int H, int W, int C, int relu_in, void* stream) {
+    if (!dy || !dx || (relu_in && !x)) return lp_set_error(LP_ERR_ARG, "lp_avgpool2_bwd: null pointer");
+    if ((C & 3) || (H & 1) || (W & 1)) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_avgpool2_bwd: C%4, H%2, W%2 must be 0");
+    long long total4 = (long long)N * (H / 2) * (W / 2) * C / 4;
+    int blocks = (int)((total4 + 255) / 256); if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, dx, total4, H, W, C, relu_in);
+    return lp_check_launch("avgpool2_bwd");
+}
+
+// partial[b] = sum over this block's elements of |relu?(a) - relu?(b)|   (criterions/common/perceptual_loss.py:104-108 L1 taps)
+__global__ __launch_bounds__(256) void l1_partial_kernel(const float4* __restrict__ a, const float4* __restrict__ b,
+                                                         float* __restrict__ part, long long total4, int relu_in) {
+    __shared__ float sh[4];
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    float s = 0.f;
+    for (; i < total4; i += stride) {
+        float4 u = a[i], v = b[i];
+        if (relu_in) {
+            u.x = fmaxf(u.x, 0.f); u.y = fmaxf(u.y, 0.f); u.z = fmaxf(u.z, 0.f); u.w = fmaxf(u.w, 0.f);
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        s += (fabsf(u.x - v.x) + fabsf(u.y - v.y)) + (fabsf(u.z - v.z) + fabsf(u.w - v.w));
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// da = coef * g[0] * sign(relu?(a) - relu?(b)) * (relu_in ? [a>0] : 1)
+__global__ void l1_bwd_kernel(const float4* __restrict__ a, const float4* __restrict__ b, const float* __restrict__ g, float coef,
+                              float4* __restrict__ da, long long total4, int relu_in) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const float k = coef * g[0];
+    for (; i < total4; i += stride) {
+        float4 u = a[i], v = b[i], o;
+        float ux = relu_in ? fmaxf(u.x, 0.f) : u.x, uy = relu_in ? fmaxf(u.y, 0.f) : u.y, uz = relu_in ? fmaxf(u.z, 0.f) : u.z,
+              uw = relu_in ? fmaxf(u.w, 0.f) : u.w;
+        float vx = relu_in ? fmaxf(v.x, 0.f) : v.x, vy = relu_in ? fmaxf(v.y, 0.f) : v.y, vz = relu_in ? fmaxf(v.z, 0.f) : v.z,
+              vw = relu_in ? fmaxf(v.w, 0.f) : v.w;
+        o.x = (ux > vx ? k : (ux < vx ? -k : 0.f)); o.y = (uy > vy ? k : (uy < vy ? -k : 0.f));
+        o.z = (uz > vz ? k : (uz < vz ? -k : 0.f)); o.w = (uw > vw ? k : (uw < vw ? -k : 0.f));
+        if (relu_in) { o.x = u.x > 0.f ? o.x : 0.f; o.y = u.y > 0.f ? o.y : 0.f; o.z = u.z > 0.f ? o.z : 0.f; o.w = u.w > 0.f ? o.w : 0.f; }
+        da[i] = o;
+    }
+}
+
+#define L1_BLOCKS 1024
+extern "C" int lp_l1_partial_blocks(void) { return L1_BLOCKS; }
+
+extern "C" int lp_l1_fwd(const float* a, const float* b, float* partial, long long numel, int relu_in, void* stream) {
+    if (!a || !b || !partial) return lp_set_error(LP_ERR_ARG, "lp_l1_fwd: null pointer");
+    if (numel & 3) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_l1_fwd: numel must be a multiple of 4");
+    hipLaunchKernelGGL(l1_partial_kernel, dim3(L1_BLOCKS), dim3(256), 0, (hipStream_t)stream, (const float4*)a, (const float4*)b, partial,
+                       numel / 4, relu_in);
+    return lp_check_launch("l1_fwd");
+}
+
+extern "C" int lp_l1_bwd(const float* a, const float* b, const float* grad_out, float coef, float* da, long long numel, int relu_in,
+                         void* stream) {
+    if (!a || !b || !grad_out || !da) return lp_set_error(LP_ERR_ARG, "lp_l1_bwd: null pointer");
+    if (numel & 3) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_l1_bwd: numel must be a multiple of 4");
+    long long total4 = numel / 4;
+    int blocks = (int)((total4 + 255) / 256); if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(l1_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)a, (const float4*)b, grad_out, coef,
+                       (float4*)da, total4, relu_in);
+    return lp_check_launch("l1_bwd");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// fused multi-tensor optimizers + EMA.  One launch updates every parameter tensor of an optimizer:
+// `table` is a device array of MtDesc, blockIdx.y = tensor, blockIdx.x strides over its elements.  The step counter
+// lives on the device (int64 *step, incremented by a 1-thread kernel) so a captured hipGraph replays correctly.
+//   RAdam  -- utils/radam.py:29-95 (degenerated_to_sgd=True, weight_decay=0)
+//   Adam   -- torch.optim.Adam (no amsgrad / weight decay), as used by runners/holycow.py:34-41 with betas=(beta1, 0.999), eps=1e-5
+//   EMA    -- runners/holycow.py:99-109: avg = avg*alpha + cur*(1-alpha)
+// ------------------------------------------------------------------------------------------------------------------
+struct MtDesc { float* p; const float* g; float* m; float* v; long long n; };
+
+__global__ void mt_step_inc_kernel(long long* step) { step[0] += 1; }
+
+__global__ void mt_radam_kernel(const MtDesc* __restrict__ table, const long long* __restrict__ step_ptr, float lr, float beta1,
+                                float beta2, float eps) {
+    const MtDesc d = table[blockIdx.y];
+    const double step = (double)step_ptr[0];
+    // rectification term, evaluated in double like the Python reference
+    const double beta2_t = pow((double)beta2, step);
+    const double n_max = 2.0 / (1.0 - (double)beta2) - 1.0;
+    const double n_sma = n_max - 2.0 * step * beta2_t / (1.0 - beta2_t);
+    const double bc1 = 1.0 - pow((double)beta1, step);
+    const bool rect = n_sma >= 5.0;
+    const float step_size = rect ? (float)(sqrt((1 - beta2_t) * (n_sma - 4) / (n_max - 4) * (n_sma - 2) / n_sma * n_max / (n_max - 2)) / bc1 * lr)
+                                 : (float)(1.0 / bc1 * lr);
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < d.n; i += stride) {
+        float g = d.g[i];
+        float v = d.v[i] * beta2 + (1.f - beta2) * g * g;
+        float m = d.m[i] * beta1 + (1.f - beta1) * g;
+        d.v[i] = v; d.m[i] = m;
+        float p = d.p[i];
+        p -= rect ? step_size * m / (sqrtf(v) + eps) : step_size * m;
+        d.p[i] = p;
+    }
+}
+
+__global__ void mt_adam_kernel(const MtDesc* __restrict__ table, const long long* __restrict__ step_ptr, float lr, float beta1,
+                               float beta2, float eps) {
+    const MtDesc d = table[blockIdx.y];
+    const double step = (double)step_ptr[0];
+    const float bc1 = (float)(1.0 - pow((double)beta1, step));
+    const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, step));
+    const float step_size = lr / bc1;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < d.n; i += stride) {
+        float g = d.g[i];
+        float m = d.m[i] * beta1 + (1.f - beta1) * g;
+        float v = d.v[i] * beta2 + (1.f - beta2) * g * g;
+        d.m[i] = m; d.v[i] = v;
+        d.p[i] -= step_size * m / (sqrtf(v) / bc2_sqrt + eps);
+    }
+}
+
+// table[k].p = running average, table[k].g = current value; m/v unused
+__global__ void mt_ema_kernel(const MtDesc* __restrict__ table, float alpha, int copy_only) {
+    const MtDesc d = table[blockIdx.y];
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const float om = 1.f - alpha;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < d.n; i += stride)
+        d.p[i] = copy_only ? d.g[i] : d.p[i] * alpha + d.g[i] * om;
+}
+
+extern "C" int lp_mt_desc_bytes(void) { return (int)sizeof(MtDesc); }
+
+extern "C" int lp_mt_optimizer_step(const void* table, int num_tensors, long long max_numel, long long* step, int kind, float lr,
+                                    float beta1, float beta2, float eps, void* stream) {
+    if (!table || !step || num_tensors <= 0) return lp_set_error(LP_ERR_ARG, "lp_mt_optimizer_step: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(mt_step_inc_kernel, dim3(1), dim3(1), 0, st, step);
+    int bx = (int)((max_numel + 1023) / 1024); if (bx < 1) bx = 1; if (bx > 64) bx = 64;
+    dim3 grid(bx, num_tensors);
+    if (kind == 0) hipLaunchKernelGGL(mt_radam_kernel, grid, dim3(256), 0, st, (const MtDesc*)table, step, lr, beta1, beta2, eps);
+    else if (kind == 1) hipLaunchKernelGGL(mt_adam_kernel, grid, dim3(256), 0, st, (const MtDesc*)table, step, lr, beta1, beta2, eps);
+    else return lp_set_error(LP_ERR_ARG, "lp_mt_optimizer_step: kind must be 0 (RAdam) or 1 (Adam)");
+    return lp_check_launch("mt_optimizer_step");
+}
+
+extern "C" int lp_mt_ema(const void* table, int num_tensors, long long max_numel, float alpha, int copy_only, void* stream) {
+    if (!table || num_tensors <= 0) return lp_set_error(LP_ERR_ARG, "lp_mt_ema: bad arguments");
+    int bx = (int)((max_numel + 1023) / 1024); if (bx < 1) bx = 1; if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(mt_ema_kernel, dim3(bx, num_tensors), dim3(256), 0, (hipStream_t)stream, (const MtDesc*)table, alpha, copy_only);
+    return lp_check_launch("mt_ema");
+}

@@ -4,15 +4,18 @@ Behavioural notes reproduced on purpose:
   * every norm-'none' ResBlock starts with ReLU(inplace) on its *input* (generators/common/blocks.py:71-73), so its skip
     branch / identity add see relu(x), and the features handed to feature matching are post-ReLU except the last one;
   * pass_inputs runs three times per step (fake->G, fake.detach->D, real), each doing its own power iteration.
-Round-1 status: the convolutions of this module still run on stock PyTorch-ROCm ops (the round-1 scope is the
-"generator-only HIP path", BASELINE.json configs[1]); they map 1:1 onto lp_conv_fwd (pro=2 ReLU prologue) next."""
+All convolutions run on the gfx950 kernels (lp_conv_fwd with the ReLU prologue / bias / residual epilogue, lp_conv_wgrad,
+lp_avgpool2_*); activations are NHWC inside and are handed out as logical N x C x H x W views (channels_last strides).
+avgpool(a) + avgpool(b) is evaluated as avgpool(a + b) (the skip conv result is the residual operand of conv2's epilogue):
+identical algebra, one rounding fewer."""
 import math
 
 import torch
 import torch.nn.functional as F
 from torch import nn
 
-from latent_pose_reenactment_amd.nn import SNWeight, _Indexed, SN_EPS_CONV, SN_EPS_DEFAULT
+from latent_pose_reenactment_amd.nn import (SNWeight, _Indexed, SN_EPS_CONV, SN_EPS_DEFAULT, AvgPool2Fn, as_nchw_view, hip_conv,
+                                            to_nhwc)
 from latent_pose_reenactment_amd.utils import radam as _radam
 
 torch.optim.RAdam = _radam.RAdam      # the reference swaps in its own RAdam the same way (no_landmarks.py:5-6)
@@ -32,8 +35,14 @@ class Wrapper:
 
     @staticmethod
     def get_optimizer(discriminator, args):
-        opt = torch.optim.__dict__[args.optimizer]
-        return opt(discriminator.parameters(), lr=args.lr_dis, betas=(args.beta1, 0.999), eps=1e-5)
+        from runners.holycow import optimizer_class
+        return optimizer_class(args.optimizer, args.device)(discriminator.parameters(), lr=args.lr_dis, betas=(args.beta1, 0.999), eps=1e-5)
+
+
+def _wb(sn, track):
+    """(effective weight, bias) of an SN layer; ``track=False`` detaches them from autograd (the power iteration still runs)"""
+    w, b = sn.effective_weight(), sn.bias
+    return (w, b) if track else (w.detach(), None if b is None else b.detach())
 
 
 class _DisBlock(nn.Module):
@@ -47,17 +56,17 @@ class _DisBlock(nn.Module):
             self.skip = _Indexed(_0=SNWeight((cout, cin, 1, 1), True, SN_EPS_CONV))
         self.downsample = downsample
 
-    def forward(self, x_relu):
+    def forward(self, x_relu, track=True):
+        """x_relu: NHWC relu(x) (the reference's in-place ReLU makes every consumer of the block input see relu(x))"""
         c1, c2 = self.block._modules['2'], self.block._modules['5']
-        h = F.conv2d(x_relu, c1.effective_weight(), c1.bias, 1, 1)
-        h = F.conv2d(torch.relu(h), c2.effective_weight(), c2.bias, 1, 1)
-        if self.downsample:
-            h = F.avg_pool2d(h, 2)
+        h = hip_conv(x_relu, *_wb(c1, track), ksize=3)
         if self.has_skip:
-            sk = self.skip._modules['0']
-            s = F.conv2d(x_relu, sk.effective_weight(), sk.bias)
-            return h + (F.avg_pool2d(s, 2) if self.downsample else s)
-        return h + x_relu
+            shortcut = hip_conv(x_relu, *_wb(self.skip._modules['0'], track), ksize=1)
+        else:
+            shortcut = x_relu
+        w2, b2 = _wb(c2, track)
+        out = hip_conv(h, w2, b2, res=shortcut, ksize=3, pro=2)
+        return AvgPool2Fn.apply(out, False) if self.downsample else out
 
 
 class Discriminator(nn.Module):
@@ -90,19 +99,26 @@ class Discriminator(nn.Module):
             self.embed.weight_orig.uniform_(-0.1, 0.1)
         self.finetuning = False
 
-    def pass_inputs(self, x, embed=None):
+    def pass_inputs(self, x, embed=None, track_weights=True):
+        """``track_weights=False``: the discriminator's own parameters are constants for autograd in this pass (gradients
+        still flow to ``x`` and ``embed``)."""
+        if not x.is_cuda:
+            raise RuntimeError('the discriminator runs on the MI355X HIP path only (no CPU fallback)')
         d0, d2, sk = self.down_block._modules['0'], self.down_block._modules['2'], self.skip._modules['0']
-        h = torch.relu(F.conv2d(x, d0.effective_weight(), d0.bias, 1, 1))
-        h = F.avg_pool2d(F.conv2d(h, d2.effective_weight(), d2.bias, 1, 1), 2)
-        out = h + F.avg_pool2d(F.conv2d(x, sk.effective_weight(), sk.bias), 2)
+        xn = to_nhwc(x)
+        h = hip_conv(xn, *_wb(d0, track_weights), ksize=3)
+        shortcut = hip_conv(xn, *_wb(sk, track_weights), ksize=1)
+        w2, b2 = _wb(d2, track_weights)
+        out = AvgPool2Fn.apply(hip_conv(h, w2, b2, res=shortcut, ksize=3, pro=2), False)
         feats = []
         for block in self.blocks:
             out_relu = torch.relu(out)           # what the reference's in-place ReLU leaves behind in its feature list
-            feats.append(out_relu)
-            out = block(out_relu)
-        feats.append(out)
-        pooled = torch.relu(out).flatten(2).sum(2)
-        score = F.linear(pooled, self.linear.effective_weight(), self.linear.bias)[:, 0]
+            feats.append(as_nchw_view(out_relu))
+            out = block(out_relu, track_weights)
+        feats.append(as_nchw_view(out))
+        pooled = torch.relu(out).sum(dim=(1, 2))
+        wl, bl = _wb(self.linear, track_weights)
+        score = F.linear(pooled, wl, bl)[:, 0]
         if embed is not None:
             score = (pooled * embed).sum(1) + score
         return score, feats
@@ -128,7 +144,11 @@ class Discriminator(nn.Module):
         if real.dim() > 4:
             real = real[:, 0]
         embed = F.embedding(label, self.embed.effective_weight())
-        fake_score_G, fake_features = self.pass_inputs(fake, embed)
+        # Pass 1 feeds only generator-side losses; the gradients it would deposit on the discriminator's parameters are erased
+        # by optimizer_D.zero_grad() before loss_D.backward (runners/holycow.py:246-248) and no optimizer reads them, so they
+        # are not computed unless ``keep_reference_waste`` asks for the reference's exact .grad side effects (parity tests).
+        track1 = bool(getattr(self, 'keep_reference_waste', False))
+        fake_score_G, fake_features = self.pass_inputs(fake, embed if track1 else embed.detach(), track_weights=track1)
         fake_score_D, _ = self.pass_inputs(fake.detach(), embed.detach())
         real_score, real_features = self.pass_inputs(real, embed)
         data_dict.update(fake_features=fake_features, real_features=real_features, real_embedding=embed,

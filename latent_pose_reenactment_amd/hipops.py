@@ -176,3 +176,44 @@ def head_bwd(t: Tensor, d_rgbs: Tensor, d_segm: Optional[Tensor]) -> Tensor:
         _chk(d_segm, 'd_segm')
     check(_lib.lib().lp_head_bwd(t.data_ptr(), d_rgbs.data_ptr(), _p(d_segm), dz.data_ptr(), n, h, w, _stream()), 'lp_head_bwd')
     return dz
+
+
+def relu_bwd(dA: Tensor, x: Tensor) -> Tensor:
+    _chk(dA, 'dA'); _chk(x, 'x')
+    dx = torch.empty_like(x)
+    check(_lib.lib().lp_relu_bwd(dA.data_ptr(), x.data_ptr(), dx.data_ptr(), x.numel(), _stream()), 'lp_relu_bwd')
+    return dx
+
+
+def avgpool2_fwd(x: Tensor, relu_in: bool) -> Tensor:
+    _chk(x, 'x')
+    n, h2, w2, c = x.shape
+    y = torch.empty((n, h2 // 2, w2 // 2, c), dtype=torch.float32, device=x.device)
+    check(_lib.lib().lp_avgpool2_fwd(x.data_ptr(), y.data_ptr(), n, h2 // 2, w2 // 2, c, int(relu_in), _stream()), 'lp_avgpool2_fwd')
+    return y
+
+
+def avgpool2_bwd(dy: Tensor, x: Tensor, relu_in: bool) -> Tensor:
+    _chk(dy, 'dy'); _chk(x, 'x')
+    n, h, w, c = x.shape
+    dx = torch.empty_like(x)
+    check(_lib.lib().lp_avgpool2_bwd(dy.data_ptr(), x.data_ptr(), dx.data_ptr(), n, h, w, c, int(relu_in), _stream()), 'lp_avgpool2_bwd')
+    return dx
+
+
+def l1_sum(a: Tensor, b: Tensor, relu_in: bool) -> Tensor:
+    """sum |relu?(a) - relu?(b)| as a 0-d tensor (block partials + one tiny torch sum)"""
+    _chk(a, 'a'); _chk(b, 'b')
+    assert a.shape == b.shape
+    part = torch.empty(_lib.lib().lp_l1_partial_blocks(), dtype=torch.float32, device=a.device)
+    check(_lib.lib().lp_l1_fwd(a.data_ptr(), b.data_ptr(), part.data_ptr(), a.numel(), int(relu_in), _stream()), 'lp_l1_fwd')
+    return part.sum()
+
+
+def l1_bwd(a: Tensor, b: Tensor, grad_out: Tensor, coef: float, relu_in: bool) -> Tensor:
+    _chk(a, 'a'); _chk(b, 'b')
+    g = grad_out.reshape(1).contiguous().float()
+    da = torch.empty_like(a)
+    check(_lib.lib().lp_l1_bwd(a.data_ptr(), b.data_ptr(), g.data_ptr(), float(coef), da.data_ptr(), a.numel(), int(relu_in), _stream()),
+          'lp_l1_bwd')
+    return da

@@ -332,3 +332,89 @@ class Generator(nn.Module):
         rgbs, segm = _DecoderFunction.apply(cfg, affine, self.constant.constant, *weights)
         data_dict['fake_rgbs'] = rgbs
         data_dict['fake_segm'] = segm
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# generic HIP layers for the discriminator and the VGG criterions (NHWC fp32 tensors)
+# ----------------------------------------------------------------------------------------------------------------------
+def to_nhwc(x: torch.Tensor) -> torch.Tensor:
+    """logical NCHW -> contiguous [N,H,W,C] (zero-copy when the tensor already has channels_last strides)"""
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def as_nchw_view(x_nhwc: torch.Tensor) -> torch.Tensor:
+    """[N,H,W,C] storage presented with the reference's logical N x C x H x W shape (channels_last strides, no copy)"""
+    return x_nhwc.permute(0, 3, 1, 2)
+
+
+class ConvFn(torch.autograd.Function):
+    """y = conv_{k x k, pad k//2}(act(x), w) + bias + res,  act = identity (pro=0) | ReLU (pro=2);  x, res, y NHWC.
+    Forward = lp_conv_fwd; backward = lp_conv_fwd on dY with the flipped/transposed pack (dgrad) [+ lp_relu_bwd],
+    lp_conv_wgrad, and a channel sum for the bias.  ``packs`` = optional cached (forward, dgrad) WeightPacks of a frozen w."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, res, ksize, pro, prec, packs):
+        small_k = ksize == 3 and w.shape[1] <= 32
+        wd = w.detach().contiguous()
+        pack = packs[0] if packs is not None else ops.pack_weights(wd, 0, prec, small_k=small_k)
+        y = ops.conv(x, pack, ksize=ksize, pro=pro, bias=None if bias is None else bias.detach().contiguous(), res=res, prec=prec)
+        ctx.save_for_backward(x, wd)
+        ctx.cfg = (ksize, pro, prec, packs, bias is not None, res is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wd = ctx.saved_tensors
+        ksize, pro, prec, packs, has_bias, has_res = ctx.cfg
+        dy = dy.contiguous()
+        dx = dw = db = dres = None
+        if ctx.needs_input_grad[0]:
+            packT = packs[1] if packs is not None else ops.pack_weights(wd, 1, prec, small_k=(ksize == 3 and wd.shape[0] <= 32))
+            dA = ops.conv(dy, packT, ksize=ksize, prec=prec)
+            dx = ops.relu_bwd(dA, x) if pro == 2 else dA
+        if ctx.needs_input_grad[1]:
+            dw = ops.conv_wgrad(x, dy, ksize=ksize, pro=pro, prec=prec)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum(dim=(0, 1, 2))
+        if has_res and ctx.needs_input_grad[3]:
+            dres = dy
+        return dx, dw, db, dres, None, None, None, None
+
+
+def hip_conv(x, w, bias=None, res=None, ksize=3, pro=0, prec=None, packs=None):
+    return ConvFn.apply(x, w, bias, res, ksize, pro, default_prec() if prec is None else prec, packs)
+
+
+class AvgPool2Fn(torch.autograd.Function):
+    """AvgPool2d(2) of relu?(x), NHWC (blocks.py:89-90 / perceptual_loss.py:77 with the preceding ReLU fused)."""
+
+    @staticmethod
+    def forward(ctx, x, relu_in):
+        ctx.save_for_backward(x)
+        ctx.relu_in = relu_in
+        return ops.avgpool2_fwd(x, relu_in)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.avgpool2_bwd(dy.contiguous(), x, ctx.relu_in), None
+
+
+class L1Fn(torch.autograd.Function):
+    """mean |relu?(a) - relu?(b)|  (F.l1_loss with the preceding ReLUs fused); gradient only w.r.t. ``a`` (b is detached in
+    every call site of the reference: featmat.py:17, perceptual_loss.py:93)."""
+
+    @staticmethod
+    def forward(ctx, a, b, relu_in):
+        ctx.save_for_backward(a, b)
+        ctx.relu_in = relu_in
+        return ops.l1_sum(a, b, relu_in) / a.numel()
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        return ops.l1_bwd(a, b, g, 1.0 / a.numel(), ctx.relu_in), None, None
+
+
+def hip_l1(a, b, relu_in=False):
+    return L1Fn.apply(a, b.detach(), relu_in)

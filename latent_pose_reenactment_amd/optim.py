@@ -1,0 +1,131 @@
+"""Fused multi-tensor optimizers and EMA on the gfx950 kernels (lp_mt_optimizer_step / lp_mt_ema).
+
+``FusedRAdam`` / ``FusedAdam`` are drop-ins for the reference's ``utils.radam.RAdam`` and ``torch.optim.Adam`` as configured
+by runners/holycow.py:34-41 and discriminators/no_landmarks.py:26-28 (betas=(beta1, 0.999), eps=1e-5, no weight decay): same
+constructor, same per-parameter state (``step``, ``exp_avg``, ``exp_avg_sq``) in ``state_dict()``, but ONE kernel launch per
+``step()`` over all parameters and a device-resident step counter, so the whole training step can be captured in a hipGraph."""
+import struct
+
+import torch
+from torch.optim.optimizer import Optimizer
+
+from . import _lib
+from ._lib import check
+
+
+def _build_table(entries, device):
+    """entries: list of (p, g, m, v) tensors (m/v may be None) -> (device uint8 tensor with the packed MtDesc array, max numel)"""
+    assert _lib.lib().lp_mt_desc_bytes() == 40
+    blob = bytearray()
+    max_n = 0
+    for p, g, m, v in entries:
+        for t in (p, g) + ((m, v) if m is not None else ()):
+            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), 'fused optimizers need contiguous fp32 CUDA tensors'
+        blob += struct.pack('<QQQQq', p.data_ptr(), g.data_ptr(), m.data_ptr() if m is not None else 0,
+                            v.data_ptr() if v is not None else 0, p.numel())
+        max_n = max(max_n, p.numel())
+    table = torch.frombuffer(blob, dtype=torch.uint8).clone().to(device)
+    return table, max_n
+
+
+class _FusedBase(Optimizer):
+    KIND = None
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, **_ignored):
+        if weight_decay != 0:
+            raise NotImplementedError('weight decay is not used by the reference configs and is not fused')
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._tables = {}
+
+    def _prepare(self, gi, group):
+        params = [p for p in group['params'] if p.requires_grad]
+        dev = params[0].device
+        for p in params:
+            st = self.state[p]
+            if 'exp_avg' not in st:
+                st['exp_avg'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st['step'] = 0
+            if p.grad is None:      # persistent gradient buffers: the table holds raw pointers
+                p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in params)
+        cached = self._tables.get(gi)
+        if cached is None or cached[0] != key:
+            table, max_n = _build_table([(p.data, p.grad, self.state[p]['exp_avg'], self.state[p]['exp_avg_sq']) for p in params], dev)
+            step0 = max((int(self.state[p]['step']) for p in params), default=0)
+            step = cached[3] if cached is not None else torch.tensor([step0], dtype=torch.int64, device=dev)
+            cached = (key, table, max_n, step, len(params))
+            self._tables[gi] = cached
+        return cached
+
+    def zero_grad(self, set_to_none: bool = False):
+        """gradients are zeroed IN PLACE (never released): the fused kernel addresses them by raw pointer"""
+        for group in self.param_groups:
+            for p in group['params']:
+                if p.grad is not None:
+                    p.grad.detach_()
+                    p.grad.zero_()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for gi, group in enumerate(self.param_groups):
+            _, table, max_n, step, n = self._prepare(gi, group)
+            b1, b2 = group['betas']
+            check(_lib.lib().lp_mt_optimizer_step(table.data_ptr(), n, max_n, step.data_ptr(), self.KIND, group['lr'], b1, b2,
+                                                  group['eps'], torch.cuda.current_stream().cuda_stream), 'lp_mt_optimizer_step')
+        return loss
+
+    def state_dict(self):
+        for gi, group in enumerate(self.param_groups):      # publish the device step counter in the reference's per-param layout
+            if gi in self._tables and not torch.cuda.is_current_stream_capturing():
+                s = int(self._tables[gi][3].item())
+                for p in group['params']:
+                    if p in self.state:
+                        self.state[p]['step'] = s
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._tables = {}
+
+
+class FusedRAdam(_FusedBase):
+    KIND = 0
+
+
+class FusedAdam(_FusedBase):
+    KIND = 1
+
+
+class FusedEMA:
+    """running averages of a module's parameters (alpha-blend) and buffers (copy) in two launches -- holycow.py:99-109"""
+
+    def __init__(self, current: torch.nn.Module, average: torch.nn.Module):
+        pc, pa = list(current.parameters()), list(average.parameters())
+        bc, ba = list(current.buffers()), list(average.buffers())
+        assert len(pc) == len(pa) and len(bc) == len(ba)
+        self.keep = (pc, pa, bc, ba)
+        dev = pc[0].device
+        self.ptable, self.pmax = _build_table([(a.data, c.data, None, None) for c, a in zip(pc, pa)], dev)
+        fb = [(a, c) for c, a in zip(bc, ba) if c.dtype == torch.float32 and c.numel() > 0]
+        self.other = [(a, c) for c, a in zip(bc, ba) if c.dtype != torch.float32 and c.numel() > 0]     # e.g. BN num_batches_tracked
+        self.btable, self.bmax = _build_table([(a.data, c.data, None, None) for a, c in fb], dev) if fb else (None, 0)
+        self.np, self.nb = len(pc), len(fb)
+        self.key = tuple(t.data_ptr() for t in pc + pa + bc + ba)
+
+    def valid(self):
+        pc, pa, bc, ba = self.keep
+        return self.key == tuple(t.data_ptr() for t in pc + pa + bc + ba)
+
+    @torch.no_grad()
+    def update(self, alpha: float):
+        st = torch.cuda.current_stream().cuda_stream
+        check(_lib.lib().lp_mt_ema(self.ptable.data_ptr(), self.np, self.pmax, alpha, 0, st), 'lp_mt_ema')
+        if self.btable is not None:
+            check(_lib.lib().lp_mt_ema(self.btable.data_ptr(), self.nb, self.bmax, 0.0, 1, st), 'lp_mt_ema')
+        for a, c in self.other:
+            a.copy_(c)

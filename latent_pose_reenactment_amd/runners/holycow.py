@@ -32,12 +32,20 @@ def get_args(parser):
     return parser
 
 
+def optimizer_class(name, device):
+    """Adam | RAdam (train.py --optimizer).  On the GPU the fused multi-tensor HIP kernels are used (one launch per step,
+    device-side step counter); on CPU the plain Python implementations with identical update rules."""
+    if str(device).startswith('cuda'):
+        from latent_pose_reenactment_amd.optim import FusedAdam, FusedRAdam
+        return {'Adam': FusedAdam, 'RAdam': FusedRAdam}[name]
+    return {'Adam': torch.optim.Adam, 'RAdam': _radam.RAdam}[name]
+
+
 def get_optimizer(embedder, generator, args):
     params = list(generator.parameters())
     if not getattr(args, 'finetune', False):
         params += list(embedder.parameters())
-    opt = torch.optim.__dict__[args.optimizer]
-    return opt(params, lr=args.lr_gen, betas=(args.beta1, 0.999), eps=1e-5)
+    return optimizer_class(args.optimizer, args.device)(params, lr=args.lr_gen, betas=(args.beta1, 0.999), eps=1e-5)
 
 
 class _Toggle:
@@ -88,6 +96,14 @@ class TrainingModule(nn.Module):
         with torch.no_grad():
             for name, avg in self.running_averages.items():
                 cur = getattr(self, name)
+                first = next(iter(cur.parameters()), None)
+                if first is not None and first.is_cuda:
+                    from latent_pose_reenactment_amd.optim import FusedEMA
+                    cache = self.__dict__.setdefault('_fused_ema', {})
+                    if name not in cache or not cache[name].valid():
+                        cache[name] = FusedEMA(cur, avg)
+                    cache[name].update(alpha)       # two launches for the whole module (lp_mt_ema)
+                    continue
                 for p, p_avg in zip(cur.parameters(), avg.parameters()):
                     p_avg.mul_(alpha).add_(p * (1 - alpha))
                 for b, b_avg in zip(cur.buffers(), avg.buffers()):
@@ -105,7 +121,10 @@ class TrainingModule(nn.Module):
         else:
             embedder, generator = self.embedder, self.generator
         data_dict = copy.copy(data_dict)          # inputs only; modules add their outputs
-        embedder(data_dict)
+        # In fine-tuning the optimizer holds generator parameters only (get_optimizer above, holycow.py:34-41), so the pose
+        # encoder's weight gradients are never consumed: run it without autograd (bit-identical parameters afterwards).
+        with torch.set_grad_enabled(torch.is_grad_enabled() and not getattr(generator, 'finetuning', False)):
+            embedder(data_dict)
         generator(data_dict)
         data_dict.update(target_dict)
         if self.compute_losses:

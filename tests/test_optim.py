@@ -1,0 +1,64 @@
+"""Fused multi-tensor optimizers / EMA (GPU) against the plain implementations with the reference's update rules, and the
+plain RAdam against the oracle formula (CPU)."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'latent_pose_reenactment_amd'))
+
+
+def test_python_radam_matches_oracle_formula():
+    from latent_pose_reenactment_amd.utils.radam import RAdam
+    from oracle import lp_oracle as O
+    torch.manual_seed(0)
+    p = torch.nn.Parameter(torch.randn(37))
+    ref, m, v = p.detach().clone(), torch.zeros(37), torch.zeros(37)
+    opt = RAdam([p], lr=5e-4, betas=(0.0, 0.999), eps=1e-5)
+    for step in range(1, 9):
+        g = torch.randn(37)
+        p.grad = g.clone()
+        opt.step()
+        O.radam_step(ref, g, m, v, step, 5e-4, 0.0, 0.999, 1e-5)
+        assert torch.allclose(p.detach(), ref, rtol=1e-6, atol=1e-7), step
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind', ['RAdam', 'Adam'])
+def test_fused_optimizer_matches_plain(kind):
+    from latent_pose_reenactment_amd.optim import FusedAdam, FusedRAdam
+    from latent_pose_reenactment_amd.utils.radam import RAdam
+    torch.manual_seed(1)
+    shapes = [(64, 32, 3, 3), (17,), (5, 7), (1, 512)]
+    ps_f = [torch.nn.Parameter(torch.randn(s, device='cuda')) for s in shapes]
+    ps_r = [torch.nn.Parameter(p.detach().clone()) for p in ps_f]
+    kw = dict(lr=5e-4, betas=(0.0 if kind == 'RAdam' else 0.5, 0.999), eps=1e-5)
+    fused = (FusedRAdam if kind == 'RAdam' else FusedAdam)(ps_f, **kw)
+    plain = (RAdam if kind == 'RAdam' else torch.optim.Adam)(ps_r, **kw)
+    for step in range(12):                      # crosses the n_sma >= 5 rectification switch of RAdam (step 6)
+        fused.zero_grad(); plain.zero_grad()
+        for a, b in zip(ps_f, ps_r):
+            g = torch.randn_like(a)
+            a.grad = g.clone() if a.grad is None else a.grad.copy_(g)
+            b.grad = g.clone()
+        fused.step(); plain.step()
+        for a, b in zip(ps_f, ps_r):
+            assert torch.allclose(a, b, rtol=2e-5, atol=1e-7), (kind, step, (a - b).abs().max().item())
+    sd = fused.state_dict()
+    assert sd['state'][0]['step'] == 12 and 'exp_avg' in sd['state'][0] and 'exp_avg_sq' in sd['state'][0]
+
+
+@pytest.mark.gpu
+def test_fused_ema():
+    from latent_pose_reenactment_amd.optim import FusedEMA
+    torch.manual_seed(2)
+    cur = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3), torch.nn.BatchNorm2d(8)).cuda()
+    avg = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3), torch.nn.BatchNorm2d(8)).cuda()
+    cur[1].running_mean.normal_(); cur[1].num_batches_tracked.fill_(5)
+    expect = [a.detach() * 0.972 + c.detach() * (1 - 0.972) for c, a in zip(cur.parameters(), avg.parameters())]
+    FusedEMA(cur, avg).update(0.972)
+    for a, e in zip(avg.parameters(), expect):
+        assert torch.allclose(a, e, rtol=1e-6, atol=1e-7)
+    assert torch.equal(avg[1].running_mean, cur[1].running_mean) and int(avg[1].num_batches_tracked) == 5
