@@ -135,6 +135,7 @@ def main():
     ap.add_argument('--prec', default=os.environ.get('LP_PREC', 'bf16x3'), choices=['bf16', 'bf16x3'])
     ap.add_argument('--workload', default='finetune_step', choices=['finetune_step', 'generator'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--eager', action='store_true', help='do not capture the step into hipGraphs')
     a = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -167,8 +168,17 @@ def main():
         pose_static = torch.randn(a.batch, 256, device=device)
         step = gen_only_step
     else:
-        def step():
+        def eager_step():
             holycow.train_step(tm, data, target, opt_G, opt_D, args)
+        step = eager_step
+        mode = 'eager'
+        if not a.eager:
+            try:
+                step = holycow.GraphedTrainStep(tm, opt_G, opt_D, args, data, target, warmup_steps=max(a.warmup, 2))
+                mode = 'hipgraph'
+            except Exception as ex:        # keep the bench alive: fall back to the eager loop and say so
+                print(f'[bench] hipGraph capture failed ({ex!r}); running eagerly', file=sys.stderr)
+                step = eager_step
 
     def sync():
         if world > 1:
@@ -178,12 +188,19 @@ def main():
     for _ in range(a.warmup):
         step()
     sync()
-    hipops.PROFILE = []
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     sync()
     dt = time.perf_counter() - t0
+    # Live per-kernel timing for the roofline entry: HIP events recorded on the launch stream around every conv launch.
+    # Graph replays cannot carry per-kernel events, so the instrumented steps run eagerly right after the timed region
+    # (same process, same buffers, same kernels); they are not part of `value`.
+    hipops.PROFILE = []
+    inst = eager_step if a.workload == 'finetune_step' else step
+    for _ in range(2):
+        inst()
+    torch.cuda.synchronize()
     prof, hipops.PROFILE = hipops.PROFILE, None
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -219,7 +236,8 @@ def main():
             'config': {'workload': 'finetuning-base.yaml step (configs[1]): G on HIP kernels; E(pose)/D/VGG on torch-ROCm'
                        if a.workload == 'finetune_step' else 'generator forward+backward only (HIP kernels)',
                        'image_size': a.image_size, 'per_gpu_batch': a.batch, 'global_batch': a.batch * world,
-                       'parallelism': f'dp{world}', 'precision_mode': a.prec},
+                       'parallelism': f'dp{world}', 'precision_mode': a.prec,
+                       'launch_mode': mode if a.workload == 'finetune_step' else 'eager'},
             'roofline': roof,
         }
         out.update(extra)

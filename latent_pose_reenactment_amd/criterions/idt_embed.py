@@ -60,5 +60,9 @@ class Criterion(torch.nn.Module):
         else:
             keep = 1 / 1.8
             t, l = h * (1 - keep) / 2, w * (1 - keep) / 2
-            boxes = torch.tensor([[t, h - t, l, w - l]], dtype=torch.float32, device=real.device).expand(len(real), 4)
+            key = (h, w, real.device)
+            cache = self.__dict__.setdefault('_box_cache', {})
+            if key not in cache:       # built once: a host->device copy per step would also break hipGraph capture
+                cache[key] = torch.tensor([[t, h - t, l, w - l]], dtype=torch.float32, device=real.device)
+            boxes = cache[key].expand(len(real), 4)
         return {'VGGFace': self.idt_embed_crit(crop_and_resize(fake, boxes), crop_and_resize(real, boxes))}

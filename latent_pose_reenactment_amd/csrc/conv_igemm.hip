@@ -13,6 +13,7 @@
 #include "lp_common.h"
 #include "lp_hip.h"
 #include "lp_internal.h"
+#include <stdlib.h>
 
 struct ConvParams {
     const float* x; const uint16_t* w_hi; const uint16_t* w_lo; float* y;
@@ -20,23 +21,39 @@ struct ConvParams {
     int N, H, W, Hin, Win, Cin, Cout, CinP, CoutP;
     int res_shift, pro;
     int lTH, lTW, lNB, tiles_x, tiles_y;
+    int a_dbuf;               // activation halo double-buffered in LDS (1) or single-buffered with an extra barrier (0)
 };
 
-template <int KS, bool UPS, int WM, int WN, int MR, int NR, int CC, int PREC>
+// Main-loop structure (one workgroup = 4 waves, one wave per SIMD, up to 160 KiB LDS):
+//   stage = one kernel ROW (KS taps) of one CC-channel chunk.  The weight tile of a stage ([KS*BN rows][CC] bf16) travels
+//   HBM -> LDS by LDS-DMA (global_load_lds, 16 B/lane, no VGPRs) into one of two stage buffers, issued one stage ahead so the
+//   DMA of stage s+1 overlaps the MFMAs of stage s.  The DMA destination is lane-linear, so the XOR bank swizzle is applied to
+//   the per-lane SOURCE address (16-byte chunk index ^ row key) and undone on the ds_read_b128 side -- conflict-free B-fragment
+//   reads without padding.  The activated input halo of a chunk is staged once (AdaIN/ReLU/upsample prologue in registers) into
+//   one of two halo buffers while the previous chunk's last stage is still being multiplied.
+template <int KS, bool UPS, int WM, int WN, int MR, int NR, int CC, int PREC, bool FAST>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     constexpr bool SPLIT = (PREC == LP_PREC_BF16X3);
     constexpr int BM = WM * MR * 16, BN = WN * NR * 16;
-    constexpr int T = KS * KS;
-    constexpr int SA = CC * 2 + 16, SB = CC * 2 + 16;     // padded LDS row strides (bytes)
-    constexpr int CG = CC / 8;
-    constexpr int B_ITEMS = BN * CG;                       // 16-byte weight items per tap tile
-    constexpr int B_PER_THREAD = (B_ITEMS + 255) / 256;
+    constexpr int SA = CC * 2 + 16;                 // padded halo row stride (bytes)
+    constexpr int ROWB = CC * 2;                    // weight row bytes (unpadded, swizzled)
+    constexpr int SLOTS = CC / 8;                   // 16-byte chunks per weight row
+    constexpr int RPI = 64 / SLOTS;                 // weight rows covered by one wave-wide LDS-DMA (1 KiB)
+    constexpr int B_STAGE = KS * BN * ROWB;         // bytes of one stage (hi part)
+    constexpr int B_BUF = B_STAGE * (SPLIT ? 2 : 1);
+    constexpr int NQ = B_STAGE / 1024;              // DMA instructions per stage (hi part)
     static_assert(!(UPS && KS == 1), "1x1 convs commute with nearest upsampling: run them at low resolution");
     static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(B_STAGE % 1024 == 0, "stage must be a whole number of 1 KiB DMA pieces");
+    // FAST halo staging: every thread owns up to AIT (pixel, 8-channel group) items whose loads are issued together
+    constexpr int CG = CC / 8, PPP = 256 / CG;                       // pixels covered by one pass of the 256 threads
+    constexpr int MAXHALO = (BM == 128) ? 10 * 18 : 18 * 18;        // 8x16 / 16x16 patch + 1-pixel border
+    constexpr int AIT = FAST ? (MAXHALO + PPP - 1) / PPP : 1;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int TH = 1 << p.lTH, TW = 1 << p.lTW, NBv = 1 << p.lNB;
 
@@ -46,19 +63,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     const int n0 = ng << p.lNB, y0 = ty << p.lTH, x0 = tx << p.lTW;
     const int co0 = blockIdx.y * BN;
 
-    // halo geometry (input coordinates)
     int HH, HW, oy, ox;
     if (KS == 1) { HH = TH; HW = TW; oy = y0; ox = x0; }
     else if (UPS) { HH = (TH >> 1) + 2; HW = (TW >> 1) + 2; oy = (y0 >> 1) - 1; ox = (x0 >> 1) - 1; }
     else { HH = TH + 2; HW = TW + 2; oy = y0 - 1; ox = x0 - 1; }
     const int a_bytes = NBv * HH * HW * SA;
-    unsigned char* A_hi = smem;
-    unsigned char* A_lo = smem + a_bytes;
-    unsigned char* B_base = smem + (SPLIT ? 2 : 1) * a_bytes;         // [2 buffers][hi|lo][BN rows][SB]
-    constexpr int B_TILE = BN * SB;
-    constexpr int B_BUF = B_TILE * (SPLIT ? 2 : 1);
+    const int a_buf = a_bytes * (SPLIT ? 2 : 1);                       // one halo buffer: [hi][lo]
+    unsigned char* B_base = smem + a_buf * (FAST ? 2 : 1);             // FAST: two halo buffers; then two stage buffers [hi][lo]
 
-    // per-lane A-fragment rows
     int a_nbbase[MR], a_py[MR], a_px[MR];
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr) {
@@ -67,10 +79,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
         tile_row_decode(m, p.lTH, p.lTW, nb, py, px);
         a_nbbase[mr] = nb * HH * HW; a_py[mr] = py; a_px[mr] = px;
     }
-    const int kb16 = (lane >> 4) * 16;
+    const int kb = lane >> 4, kb16 = kb * 16;
+    const int bkey = (SLOTS == 8) ? (lane & 7) : ((lane >> 2) & 3);    // swizzle key of this lane's weight rows (row & 15 == lane & 15)
     int b_off[NR];
 #pragma unroll
-    for (int nr = 0; nr < NR; ++nr) b_off[nr] = (wn * (NR * 16) + nr * 16 + (lane & 15)) * SB + kb16;
+    for (int nr = 0; nr < NR; ++nr) b_off[nr] = (wn * (NR * 16) + nr * 16 + (lane & 15)) * ROWB;
 
     f32x4_t acc[MR][NR];
 #pragma unroll
@@ -78,48 +91,95 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
 #pragma unroll
         for (int nr = 0; nr < NR; ++nr) acc[mr][nr] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    s16x8_t breg_hi[B_PER_THREAD], breg_lo[B_PER_THREAD];
-    auto load_b = [&](int c0, int tap) {
+    // ---- FAST halo staging descriptors (chunk independent): pixel index in x, -1 = zero padding, -2 = not an item
+    const int halo_px = NBv * HH * HW;
+    const int a_cg = tid % CG, a_hp0 = tid / CG;
+    int a_pix[AIT];
 #pragma unroll
-        for (int k = 0; k < B_PER_THREAD; ++k) {
-            int i = tid + k * 256;
-            if (B_ITEMS % 256 == 0 || i < B_ITEMS) {
-                int cg = i % CG, n = i / CG;
-                size_t off = ((size_t)(tap * p.CoutP + co0 + n) * p.CinP + c0 + cg * 8);
-                breg_hi[k] = *(const s16x8_t*)(p.w_hi + off);
-                if (SPLIT) breg_lo[k] = *(const s16x8_t*)(p.w_lo + off);
-            }
+    for (int k = 0; k < AIT; ++k) {
+        const int hp = a_hp0 + k * PPP;
+        const int hx = hp % HW, hy = hp / HW;
+        const int iy = oy + hy, ix = ox + hx;
+        const bool inb = (hp < halo_px) && (n0 < p.N) && (iy >= 0) && (iy < p.Hin) && (ix >= 0) && (ix < p.Win);
+        a_pix[k] = inb ? ((n0 * p.Hin + iy) * p.Win + ix) : (hp < halo_px ? -1 : -2);
+    }
+    float4 a_ld[AIT][2];
+    // issue the global loads of chunk `chunk` (no waits): they stay in flight across the MFMAs that follow.  The loads are
+    // UNCONDITIONAL (out-of-image items read pixel 0 and are zeroed at write time): a branch per item would make hipcc wait
+    // for every load separately.
+    auto load_a = [&](int chunk) {
+        int c = chunk * CC + a_cg * 8;
+        c = c < p.Cin ? c : 0;
+#pragma unroll
+        for (int k = 0; k < AIT; ++k) {
+            const int pix = a_pix[k] >= 0 ? a_pix[k] : 0;
+            const float* src = p.x + (size_t)pix * p.Cin + c;
+            a_ld[k][0] = *(const float4*)src; a_ld[k][1] = *(const float4*)(src + 4);
         }
     };
-    auto store_b = [&](int buf) {
-        unsigned char* dst = B_base + buf * B_BUF;
+    // prologue (AdaIN affine / ReLU), bf16 (hi, lo) conversion and LDS write of the loaded items
+    auto write_a = [&](int chunk, int buf) {
+        unsigned char* A = smem + buf * a_buf;
+        const int c = chunk * CC + a_cg * 8;
+        const bool cok = c < p.Cin;
+        const int cs = cok ? c : 0;
+        float4 s0 = make_float4(1.f, 1.f, 1.f, 1.f), s1 = s0, t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0;
+        if (p.pro == 1) {
+            const float* sp = p.scale + (size_t)n0 * p.Cin + cs; const float* tp = p.shift + (size_t)n0 * p.Cin + cs;
+            s0 = *(const float4*)sp; s1 = *(const float4*)(sp + 4); t0 = *(const float4*)tp; t1 = *(const float4*)(tp + 4);
+        }
+        const float lo_clamp = (p.pro != 0) ? 0.f : -3.0e38f;          // ReLU for pro 1|2, identity for pro 0
 #pragma unroll
-        for (int k = 0; k < B_PER_THREAD; ++k) {
-            int i = tid + k * 256;
-            if (B_ITEMS % 256 == 0 || i < B_ITEMS) {
-                int cg = i % CG, n = i / CG;
-                *(s16x8_t*)(dst + n * SB + cg * 16) = breg_hi[k];
-                if (SPLIT) *(s16x8_t*)(dst + B_TILE + n * SB + cg * 16) = breg_lo[k];
+        for (int k = 0; k < AIT; ++k) {
+            float v[8] = {a_ld[k][0].x, a_ld[k][0].y, a_ld[k][0].z, a_ld[k][0].w, a_ld[k][1].x, a_ld[k][1].y, a_ld[k][1].z, a_ld[k][1].w};
+            v[0] = fmaxf(fmaf(v[0], s0.x, t0.x), lo_clamp); v[1] = fmaxf(fmaf(v[1], s0.y, t0.y), lo_clamp);
+            v[2] = fmaxf(fmaf(v[2], s0.z, t0.z), lo_clamp); v[3] = fmaxf(fmaf(v[3], s0.w, t0.w), lo_clamp);
+            v[4] = fmaxf(fmaf(v[4], s1.x, t1.x), lo_clamp); v[5] = fmaxf(fmaf(v[5], s1.y, t1.y), lo_clamp);
+            v[6] = fmaxf(fmaf(v[6], s1.z, t1.z), lo_clamp); v[7] = fmaxf(fmaf(v[7], s1.w, t1.w), lo_clamp);
+            const bool keep = (a_pix[k] >= 0) && cok;            // zero padding is applied AFTER the activation
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = keep ? v[j] : 0.f;
+            s16x8_t hi, lo;
+            cvt8<SPLIT>(v, hi, lo);
+            const int off = (a_hp0 + k * PPP) * SA + a_cg * 16;
+            if (a_pix[k] != -2) {
+                *(s16x8_t*)(A + off) = hi;
+                if (SPLIT) *(s16x8_t*)(A + a_bytes + off) = lo;
             }
         }
     };
 
-    int step = 0;
-    load_b(0, 0);
-    for (int c0 = 0; c0 < p.CinP; c0 += CC) {
-        __syncthreads();                        // all waves finished reading the previous chunk's halo
-        stage_act_halo<CC, SPLIT>(A_hi, A_lo, SA, p.x, p.scale, p.shift, p.pro, p.N, p.Hin, p.Win, p.Cin,
-                                  n0, NBv, HH, HW, oy, ox, c0, tid);
+    // LDS-DMA of the weight tile of stage (chunk, ky) into stage buffer `buf`
+    auto issue_b = [&](int chunk, int ky, int buf) {
+        const int c0 = chunk * CC;
+        const unsigned dst_lds = (unsigned)(uintptr_t)(B_base + buf * B_BUF);      // LDS byte address (wave-uniform)
+        const int rr = lane / SLOTS, slot = lane % SLOTS;
 #pragma unroll
-        for (int tap = 0; tap < T; ++tap, ++step) {
-            const int buf = step & 1;
-            store_b(buf);
-            __syncthreads();
-            // prefetch the next weight tile (next tap, or tap 0 of the next chunk) while computing this one
-            if (tap + 1 < T) load_b(c0, tap + 1);
-            else if (c0 + CC < p.CinP) load_b(c0 + CC, 0);
-
-            const int dy = (KS == 3) ? tap / 3 : 0, dx = (KS == 3) ? tap % 3 : 0;
+        for (int q0 = 0; q0 < NQ; q0 += 4) {
+            const int q = q0 + wave;
+            if (NQ % 4 == 0 || q < NQ) {
+                const int r = q * RPI + rr;                                           // row inside the stage: kx * BN + n
+                const int key = (SLOTS == 8) ? (r & 7) : ((r >> 2) & 3);
+                const int kx = r / BN, n = r % BN;
+                const size_t off = ((size_t)((ky * KS + kx) * p.CoutP + co0 + n) * p.CinP + c0 + ((slot ^ key) * 8));
+                lp_glds16(p.w_hi + off, dst_lds + q * 1024);
+                if (SPLIT) lp_glds16(p.w_lo + off, dst_lds + B_STAGE + q * 1024);
+            }
+        }
+    };
+    auto stage_a_slow = [&](int chunk, int buf) {
+        unsigned char* A = smem + buf * a_buf;
+        stage_act_halo<CC, SPLIT>(A, A + a_bytes, SA, p.x, p.scale, p.shift, p.pro, p.N, p.Hin, p.Win, p.Cin,
+                                  n0, NBv, HH, HW, oy, ox, chunk * CC, tid);
+    };
+    // MFMAs of one stage: kernel row ky of the chunk whose halo is in halo buffer `abuf`, weights in stage buffer `bbuf`
+    auto compute = [&](int ky, int abuf, int bbuf) {
+        const unsigned char* A_hi = smem + abuf * a_buf;
+        const unsigned char* A_lo = A_hi + a_bytes;
+        const unsigned char* Bc = B_base + bbuf * B_BUF;
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+            const int dy = (KS == 3) ? ky : 0, dx = (KS == 3) ? kx : 0;
             int a_off[MR];
 #pragma unroll
             for (int mr = 0; mr < MR; ++mr) {
@@ -129,9 +189,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
                 else { hy = a_py[mr] + dy; hx = a_px[mr] + dx; }
                 a_off[mr] = (a_nbbase[mr] + hy * HW + hx) * SA + kb16;
             }
-            const unsigned char* Bc = B_base + buf * B_BUF;
+            const unsigned char* Bk = Bc + kx * (BN * ROWB);
 #pragma unroll
             for (int kk = 0; kk < CC / 32; ++kk) {
+                const int bslot = (((kk * 4 + kb) ^ bkey) * 16);
                 s16x8_t a[MR], b[NR], al[MR], bl[NR];
 #pragma unroll
                 for (int mr = 0; mr < MR; ++mr) {
@@ -140,8 +201,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
                 }
 #pragma unroll
                 for (int nr = 0; nr < NR; ++nr) {
-                    b[nr] = *(const s16x8_t*)(Bc + b_off[nr] + kk * 64);
-                    if (SPLIT) bl[nr] = *(const s16x8_t*)(Bc + B_TILE + b_off[nr] + kk * 64);
+                    b[nr] = *(const s16x8_t*)(Bk + b_off[nr] + bslot);
+                    if (SPLIT) bl[nr] = *(const s16x8_t*)(Bk + B_STAGE + b_off[nr] + bslot);
                 }
 #pragma unroll
                 for (int mr = 0; mr < MR; ++mr)
@@ -154,6 +215,52 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
                         acc[mr][nr] = mfma16(a[mr], b[nr], acc[mr][nr]);
                     }
             }
+        }
+    };
+
+    const int nch = p.CinP / CC;
+    issue_b(0, 0, 0);
+    if (FAST) { load_a(0); write_a(0, 0); } else stage_a_slow(0, 0);
+
+    if (FAST) {
+        // Straight-line pipeline (no data-dependent control flow around memory ops, so hipcc places no early vmcnt waits):
+        // stage = kernel row.  Top of stage: wait own DMA, barrier; issue next stage's DMA; [last row: issue next chunk's
+        // halo loads]; MFMAs; [last row: prologue + LDS write of the next halo into the other halo buffer].
+        int chunk = 0, abuf = 0;
+        for (; chunk + 1 < nch; ++chunk) {
+#pragma unroll
+            for (int ky = 0; ky < KS; ++ky) {
+                lp_wait_vm0();
+                __syncthreads();
+                const int bbuf = (ky + chunk * KS) & 1;
+                if (ky + 1 < KS) issue_b(chunk, ky + 1, bbuf ^ 1); else issue_b(chunk + 1, 0, bbuf ^ 1);
+                if (ky == KS - 1) load_a(chunk + 1);
+                compute(ky, abuf, bbuf);
+                if (ky == KS - 1) write_a(chunk + 1, abuf ^ 1);
+            }
+            abuf ^= 1;
+        }
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky) {                    // last chunk: nothing left to prefetch after its last row
+            lp_wait_vm0();
+            __syncthreads();
+            const int bbuf = (ky + chunk * KS) & 1;
+            if (ky + 1 < KS) issue_b(chunk, ky + 1, bbuf ^ 1);
+            compute(ky, abuf, bbuf);
+        }
+    } else {
+        // generic path (several images per tile / odd channel counts): single halo buffer, synchronous staging
+        for (int chunk = 0; chunk < nch; ++chunk) {
+#pragma unroll
+            for (int ky = 0; ky < KS; ++ky) {
+                lp_wait_vm0();
+                __syncthreads();
+                const int bbuf = (ky + chunk * KS) & 1;
+                if (ky + 1 < KS) issue_b(chunk, ky + 1, bbuf ^ 1);
+                else if (chunk + 1 < nch) issue_b(chunk + 1, 0, bbuf ^ 1);
+                compute(ky, 0, bbuf);
+            }
+            if (chunk + 1 < nch) { __syncthreads(); stage_a_slow(chunk + 1, 0); }
         }
     }
 
@@ -203,52 +310,68 @@ static void choose_tile(int BM, int N, int H, int W, int* lTH, int* lTW, int* lN
     *lTH = lth; *lTW = ltw; *lNB = lnb;
 }
 
-template <int KS, bool UPS, int WM, int WN, int MR, int NR, int CC, int PREC>
-static int launch_conv(ConvParams& p, hipStream_t stream) {
-    constexpr int BM = WM * MR * 16, BN = WN * NR * 16;
-    constexpr int SA = CC * 2 + 16, SB = CC * 2 + 16;
-    constexpr bool SPLIT = (PREC == LP_PREC_BF16X3);
-    choose_tile(BM, p.N, p.H, p.W, &p.lTH, &p.lTW, &p.lNB);
-    const int TH = 1 << p.lTH, TW = 1 << p.lTW, NBv = 1 << p.lNB;
-    p.tiles_x = (p.W + TW - 1) / TW; p.tiles_y = (p.H + TH - 1) / TH;
-    int HH, HW;
-    if (KS == 1) { HH = TH; HW = TW; } else if (UPS) { HH = TH / 2 + 2; HW = TW / 2 + 2; } else { HH = TH + 2; HW = TW + 2; }
-    size_t lds = (size_t)NBv * HH * HW * SA * (SPLIT ? 2 : 1) + (size_t)2 * BN * SB * (SPLIT ? 2 : 1);
-    if (lds > 160 * 1024) return lp_set_error(LP_ERR_UNSUPPORTED, "conv tile needs too much LDS");
-    auto kern = conv_igemm_kernel<KS, UPS, WM, WN, MR, NR, CC, PREC>;
+template <int KS, bool UPS, int WM, int WN, int MR, int NR, int CC, int PREC, bool FAST>
+static int launch_conv_v(ConvParams& p, size_t lds, dim3 grid, hipStream_t stream) {
+    auto kern = conv_igemm_kernel<KS, UPS, WM, WN, MR, NR, CC, PREC, FAST>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return lp_set_error(LP_ERR_HIP, "hipFuncSetAttribute failed");
         attr_set = true;
     }
-    dim3 grid(p.tiles_x * p.tiles_y * ((p.N + NBv - 1) / NBv), (p.Cout + BN - 1) / BN);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
     return lp_check_launch("conv_igemm");
 }
 
-template <int PREC>
-static int dispatch_conv(ConvParams& p, int ks, int ups, hipStream_t s) {
-    const bool small_cin = p.CinP % 64 != 0;   // packs of tiny-Cin layers are padded to 32 only
+template <int KS, bool UPS, int WM, int WN, int MR, int NR, int CC, int PREC>
+static int launch_conv(ConvParams& p, hipStream_t stream) {
+    constexpr int BM = WM * MR * 16, BN = WN * NR * 16;
+    constexpr int SA = CC * 2 + 16;
+    constexpr bool SPLIT = (PREC == LP_PREC_BF16X3);
+    constexpr size_t B_BUF = (size_t)KS * BN * CC * 2 * (SPLIT ? 2 : 1);
+    constexpr size_t LDS_MAX = 160 * 1024;
+    constexpr int PPP = 256 / (CC / 8);
+    constexpr int AIT = (((BM == 128) ? 10 * 18 : 18 * 18) + PPP - 1) / PPP;
+    choose_tile(BM, p.N, p.H, p.W, &p.lTH, &p.lTW, &p.lNB);
+    const int TH = 1 << p.lTH, TW = 1 << p.lTW, NBv = 1 << p.lNB;
+    p.tiles_x = (p.W + TW - 1) / TW; p.tiles_y = (p.H + TH - 1) / TH;
+    int HH, HW;
+    if (KS == 1) { HH = TH; HW = TW; } else if (UPS) { HH = TH / 2 + 2; HW = TW / 2 + 2; } else { HH = TH + 2; HW = TW + 2; }
+    const size_t a_buf = (size_t)NBv * HH * HW * SA * (SPLIT ? 2 : 1);
+    const bool fast = (NBv == 1) && ((p.Cin & 7) == 0) && (HH * HW <= AIT * PPP) && (2 * a_buf + 2 * B_BUF <= LDS_MAX);
+    p.a_dbuf = fast ? 1 : 0;
+    const size_t lds = a_buf * (fast ? 2 : 1) + 2 * B_BUF;
+    if (lds > LDS_MAX) return lp_set_error(LP_ERR_UNSUPPORTED, "conv tile needs too much LDS");
+    dim3 grid(p.tiles_x * p.tiles_y * ((p.N + NBv - 1) / NBv), (p.Cout + BN - 1) / BN);
+    if (fast) return launch_conv_v<KS, UPS, WM, WN, MR, NR, CC, PREC, true>(p, lds, grid, stream);
+    return launch_conv_v<KS, UPS, WM, WN, MR, NR, CC, PREC, false>(p, lds, grid, stream);
+}
+
+// Channel-chunk size: 64 for bf16; 32 for bf16x3 (hi+lo images double every LDS tile) and for tiny-Cin packs (CinP % 64 != 0).
+template <int PREC, int CC>
+static int dispatch_conv_cc(ConvParams& p, int ks, int ups, hipStream_t s) {
     const bool big_img = p.H * p.W >= 256;     // a 256-pixel patch fits inside one image
-    if (small_cin) {
-        if (ks == 3 && !ups) return launch_conv<3, false, 4, 1, 4, 4, 32, PREC>(p, s);
-        return lp_set_error(LP_ERR_UNSUPPORTED, "CinP%64!=0 only supported for 3x3 non-upsampled convs");
-    }
     if (ks == 3 && !ups) {
-        if (p.Cout <= 16 && big_img) return launch_conv<3, false, 4, 1, 4, 1, 64, PREC>(p, s);
-        if (p.Cout <= 64 && big_img) return launch_conv<3, false, 4, 1, 4, 4, 64, PREC>(p, s);
-        return launch_conv<3, false, 2, 2, 4, 4, 64, PREC>(p, s);
+        if (p.Cout <= 16 && big_img) return launch_conv<3, false, 4, 1, 4, 1, CC, PREC>(p, s);
+        if (p.Cout <= 64 && big_img) return launch_conv<3, false, 4, 1, 4, 4, CC, PREC>(p, s);
+        return launch_conv<3, false, 2, 2, 4, 4, CC, PREC>(p, s);
     }
     if (ks == 3 && ups) {
-        if (p.Cout <= 64 && big_img) return launch_conv<3, true, 4, 1, 4, 4, 64, PREC>(p, s);
-        return launch_conv<3, true, 2, 2, 4, 4, 64, PREC>(p, s);
+        if (p.Cout <= 64 && big_img) return launch_conv<3, true, 4, 1, 4, 4, CC, PREC>(p, s);
+        return launch_conv<3, true, 2, 2, 4, 4, CC, PREC>(p, s);
     }
     if (ks == 1 && !ups) {
-        if (p.Cout <= 64 && big_img) return launch_conv<1, false, 4, 1, 4, 4, 64, PREC>(p, s);
-        return launch_conv<1, false, 2, 2, 4, 4, 64, PREC>(p, s);
+        if (p.Cout <= 64 && big_img) return launch_conv<1, false, 4, 1, 4, 4, CC, PREC>(p, s);
+        return launch_conv<1, false, 2, 2, 4, 4, CC, PREC>(p, s);
     }
     return lp_set_error(LP_ERR_UNSUPPORTED, "unsupported conv configuration");
+}
+
+template <int PREC>
+static int dispatch_conv(ConvParams& p, int ks, int ups, hipStream_t s) {
+    static const int force_cc = getenv("LP_CONV_CC") ? atoi(getenv("LP_CONV_CC")) : 0;     // tuning knob: 32 | 64
+    if (force_cc == 32 || (force_cc != 64 && PREC == LP_PREC_BF16X3) || p.CinP % 64 != 0) return dispatch_conv_cc<PREC, 32>(p, ks, ups, s);
+    return dispatch_conv_cc<PREC, 64>(p, ks, ups, s);
 }
 
 extern "C" int lp_conv_fwd(const float* x, const uint16_t* w_hi, const uint16_t* w_lo, float* y,
@@ -265,6 +388,7 @@ extern "C" int lp_conv_fwd(const float* x, const uint16_t* w_hi, const uint16_t*
     p.x = x; p.w_hi = w_hi; p.w_lo = w_lo; p.y = y; p.scale = scale; p.shift = shift; p.bias = bias; p.res = res; p.alpha = alpha;
     p.N = N; p.H = H; p.W = W; p.Hin = upsample ? H / 2 : H; p.Win = upsample ? W / 2 : W;
     p.Cin = Cin; p.Cout = Cout; p.CinP = CinP; p.CoutP = CoutP; p.res_shift = res_shift; p.pro = pro;
+
     hipStream_t s = (hipStream_t)stream;
     if (prec == LP_PREC_BF16) return dispatch_conv<LP_PREC_BF16>(p, ksize, upsample, s);
     if (prec == LP_PREC_BF16X3) return dispatch_conv<LP_PREC_BF16X3>(p, ksize, upsample, s);

@@ -32,6 +32,17 @@ __device__ __forceinline__ f32x4_t mfma16(s16x8_t a, s16x8_t b, f32x4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 
+// LDS-DMA (16 B per lane, wave-uniform LDS destination + lane*16) issued through inline asm: hipcc's waitcnt pass would
+// otherwise put `s_waitcnt vmcnt(0)` in front of the next ds_read (it cannot prove the DMA target does not alias it), which
+// serialises the prefetch with the MFMAs.  The caller owns the completion: `lp_wait_vm0()` + barrier before reading the tile.
+// M0 is compiler-reserved, so it is saved/restored inside the same statement (cdna_hip_programming.md 5.7).
+__device__ __forceinline__ void lp_glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void lp_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // Geometry of one output tile: NB images x (TH x TW) pixel patch, all powers of two, TH,TW >= 2.
 struct TileGeom {
     int lTH, lTW, lNB;        // log2

@@ -204,3 +204,68 @@ def run_epoch(dataloader, training_module, optimizer_G, optimizer_D, epoch, args
         meter.add('Batch_time', time.time() - end)
         end = time.time()
     return meter
+
+
+class GraphedTrainStep:
+    """The training iteration of ``train_step`` captured into hipGraphs (MI355X: thousands of short launches per step make the
+    eager loop host-bound; replaying graphs removes the per-launch CPU cost -- "HIP graphs instead of a tracing compiler").
+
+    Three graphs share one memory pool and are replayed in order; the data-parallel all-reduces run eagerly BETWEEN them
+    (collectives are never captured):
+        g1: forward (E, G, D x3, criterions) + zero_grad(G) + loss_G.backward
+        --  all-reduce of the generator-side gradients (N > 1)
+        g2: optimizer_G.step + zero_grad(D) + loss_D.backward
+        --  all-reduce of the discriminator gradients (N > 1)
+        g3: optimizer_D.step + EMA
+    Same arithmetic and ordering as the eager step (holycow.py:235-257).  Inputs are static buffers: ``load_batch`` copies a
+    new batch into them.  Needs the fused (device-step-counter) optimizers; loss values live in ``losses_G`` / ``losses_D``."""
+
+    def __init__(self, training_module, optimizer_G, optimizer_D, args, data_dict, target_dict, warmup_steps=3):
+        self.tm, self.opt_G, self.opt_D, self.args = training_module, optimizer_G, optimizer_D, args
+        self.data = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in data_dict.items()}
+        self.target = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in target_dict.items()}
+        self.reducer = getattr(training_module, 'reducer', None) if 1 < args.num_gpus <= 8 else None
+        self.alpha = 0.972 if args.finetune else 0.999
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                # eager warm-up: lazy state (optimizer moments, packs, MIOpen plans)
+            for _ in range(warmup_steps):
+                train_step(self.tm, self.data, self.target, self.opt_G, self.opt_D, args)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.g1, self.g2, self.g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g1):
+            _, self.losses_G, self.losses_D = self.tm(self.data, self.target)
+            loss_G = sum(v for v in self.losses_G.values() if isinstance(v, torch.Tensor))
+            loss_D = sum(v for v in self.losses_D.values() if isinstance(v, torch.Tensor))
+            self.opt_G.zero_grad()
+            loss_G.backward(retain_graph=True)
+        pool = self.g1.pool()
+        if self.reducer is not None:
+            self.reducer.reduce_generator_side()
+        with torch.cuda.graph(self.g2, pool=pool):
+            self.opt_G.step()
+            self.opt_D.zero_grad()
+            loss_D.backward()
+        if self.reducer is not None:
+            self.reducer.reduce_discriminator_side()
+        with torch.cuda.graph(self.g3, pool=pool):
+            self.opt_D.step()
+            self.tm.update_running_average(self.alpha)
+        del loss_G, loss_D
+        torch.cuda.synchronize()
+
+    def load_batch(self, data_dict, target_dict):
+        for dst, src in ((self.data, data_dict), (self.target, target_dict)):
+            for k, v in src.items():
+                if torch.is_tensor(v):
+                    dst[k].copy_(v, non_blocking=True)
+
+    def __call__(self):
+        self.g1.replay()
+        if self.reducer is not None:
+            self.reducer.reduce_generator_side()
+        self.g2.replay()
+        if self.reducer is not None:
+            self.reducer.reduce_discriminator_side()
+        self.g3.replay()
