@@ -1,0 +1,122 @@
+"""CPU tests of the host-side mirror of the reference: config merge order, store_bool flags, plugin loader, checkpoint
+format round trip, Meter, embedder backbones' torchvision-compatible keys, and the RCCL reducer on a 2-rank gloo group."""
+import argparse
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, 'latent_pose_reenactment_amd')
+sys.path.insert(0, PKG)
+
+
+def test_store_bool_and_config_resolution_order(tmp_path, monkeypatch):
+    import importlib
+    train = importlib.import_module('train')
+    monkeypatch.chdir(PKG)
+    monkeypatch.setattr(sys, 'argv', ['train.py', '--config_name=finetuning-base', '--lr_gen', '1e-3', '--no-logging',
+                                      '--dataloader', 'synthetic_voxceleb2', '--generator', 'vector_pose_unsupervised_segmentation_noBottleneck',
+                                      '--embedder', 'unsupervised_pose_separate_embResNeXt_segmentation', '--discriminator', 'no_landmarks',
+                                      '--runner', 'holycow'])
+    from utils.utils import get_args_and_modules
+    args, default_args, m, ckpt = get_args_and_modules(train.build_parser(), use_checkpoint_args=True)
+    assert args.finetune is True and args.optimizer == 'RAdam'          # from the yaml
+    assert args.lr_gen == 1e-3                                           # command line beats yaml (5e-4)
+    assert args.lr_dis == 8e-4 and args.logging is False                 # yaml beats plugin default; --no-logging
+    assert args.criterions.replace(' ', '') == 'adversarial,featmat,idt_embed,perceptual,dice'
+    assert [c.__module__ for c in m['criterion_list']] == ['criterions.adversarial', 'criterions.featmat', 'criterions.idt_embed',
+                                                            'criterions.perceptual', 'criterions.dice']
+    assert default_args.lr_gen == 5e-4 and ckpt is None            # parse_args([]) after set_defaults(yaml), as in the reference
+    assert args.gen_num_residual_blocks == 2 and args.dis_num_blocks == 7 and args.num_labels == 98000
+
+
+def test_meter_nan_handling():
+    from utils.utils import Meter
+    m = Meter()
+    m.add('a', 2.0); m.add('a', float('nan')); m.add('a', 4.0, 3)
+    assert m.get_average('a') == pytest.approx(14 / 4) and m.get_num_measurements('a') == 4
+    other = Meter(); other.add('a', 1.0)
+    m += other
+    assert m.get_last('a') == 1.0
+
+
+def test_backbone_keys_follow_torchvision_layout():
+    from embedders.backbones import mobilenet_v2, resnext50_32x4d
+    mb = mobilenet_v2(num_classes=256)
+    keys = list(mb.state_dict().keys())
+    assert keys[0] == 'features.0.0.weight' and 'features.1.conv.0.0.weight' in keys and 'features.2.conv.1.0.weight' in keys
+    assert 'features.18.1.running_var' in keys and keys[-2:] == ['classifier.1.weight', 'classifier.1.bias']
+    assert sum(p.numel() for p in mb.parameters()) == 2551808
+    rx = resnext50_32x4d(num_classes=512)
+    rk = rx.state_dict()
+    assert rk['layer1.0.conv2.weight'].shape == (128, 4, 3, 3) and 'layer4.2.bn3.weight' in rk and 'layer1.0.downsample.0.weight' in rk
+    assert sum(p.numel() for p in rx.parameters()) == 24028992
+
+
+def test_checkpoint_round_trip_and_finetune_structure(tmp_path):
+    """save_model writes the reference's dict layout; load_model_from_checkpoint rebuilds modules incl. the finetune switch"""
+    from utils import utils
+    from runners import holycow
+    from generators.vector_pose_unsupervised_segmentation_noBottleneck import Wrapper as GW
+    from embedders.unsupervised_pose_separate_embResNeXt_segmentation import Wrapper as EW
+    from discriminators.no_landmarks import Wrapper as DW
+    a = argparse.Namespace(image_size=16, num_channels=4, max_num_channels=8, embed_channels=8, pose_embedding_size=4, in_channels=3,
+                           out_channels=3, gen_padding='zero', norm_layer='in', gen_constant_input_size=4, gen_num_residual_blocks=1,
+                           dis_padding='zero', dis_num_blocks=3, num_labels=5, average_function='sum', device='cpu', optimizer='Adam',
+                           lr_gen=1e-4, lr_dis=1e-4, beta1=0.0, finetune=False, rank=0, num_gpus=1, iteration=7,
+                           experiment_dir=str(tmp_path), generator='vector_pose_unsupervised_segmentation_noBottleneck',
+                           embedder='unsupervised_pose_separate_embResNeXt_segmentation', discriminator='no_landmarks', runner='holycow')
+    E, G, D = EW.get_net(a), GW.get_net(a), DW.get_net(a)
+    tm = holycow.TrainingModule(E, G, D, [], [], {})
+    oG, oD = holycow.get_optimizer(E, G, a), DW.get_optimizer(D, a)
+    path = utils.save_model(tm, oG, oD, a)
+    assert os.path.basename(path) == 'model_00000007.pth'
+    ck = utils.torch_load(path)
+    assert set(ck) == {'embedder', 'generator', 'discriminator', 'optimizer_G', 'optimizer_D', 'running_averages', 'args'}
+    assert set(ck['running_averages']) == {'embedder', 'generator'}
+    a2 = argparse.Namespace(**vars(a)); a2.finetune = True
+    E2, G2, D2, ra, saved, o1, o2 = utils.load_model_from_checkpoint(ck, a2)
+    assert G2.finetuning and D2.finetuning and 'identity_embedding' in G2.state_dict() and D2.embed.weight_orig.shape == (1, 8)
+    assert torch.equal(G2.constant.constant, G.constant.constant)
+
+
+REDUCER_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], 'latent_pose_reenactment_amd'))
+from latent_pose_reenactment_amd.parallel import GradReducer
+rank = int(os.environ['RANK'])
+dist.init_process_group('gloo', init_method='env://')
+torch.manual_seed(0)
+class TM(torch.nn.Module):
+    def __init__(s):
+        super().__init__()
+        s.embedder = torch.nn.Linear(3, 2); s.generator = torch.nn.Linear(4, 3); s.discriminator = torch.nn.Linear(5, 1)
+tm = TM()
+if rank == 1:
+    for p in tm.parameters(): p.data.add_(1.0)            # will be overwritten by the rank-0 broadcast
+red = GradReducer(tm, finetune=False)
+for p in tm.parameters(): p.grad = torch.full_like(p, float(rank + 1))
+red.reduce_generator_side(async_op=True); red.wait_generator_side()
+ok = all(torch.allclose(p.grad, torch.full_like(p, 1.5)) for p in list(tm.generator.parameters()) + list(tm.embedder.parameters()))
+ok &= all(torch.allclose(p.grad, torch.full_like(p, float(rank + 1))) for p in tm.discriminator.parameters())   # untouched so far
+red.reduce_discriminator_side()
+ok &= all(torch.allclose(p.grad, torch.full_like(p, 1.5)) for p in tm.discriminator.parameters())
+w = [p.detach().clone() for p in tm.parameters()]
+gathered = [None, None]; dist.all_gather_object(gathered, [t.tolist() for t in w])
+ok &= gathered[0] == gathered[1]                            # parameters identical after the broadcast
+print('REDUCER_OK' if ok else 'REDUCER_FAIL', flush=True)
+dist.destroy_process_group()
+'''
+
+
+def test_grad_reducer_two_rank_gloo(tmp_path):
+    script = tmp_path / 'worker.py'
+    script.write_text(REDUCER_WORKER)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', WORLD_SIZE='2')
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    assert all('REDUCER_OK' in o for o in outs), outs
