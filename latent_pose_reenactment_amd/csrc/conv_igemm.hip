@@ -21,6 +21,7 @@ struct ConvParams {
     int N, H, W, Hin, Win, Cin, Cout, CinP, CoutP;
     int res_shift, pro;
     int lTH, lTW, lNB, tiles_x, tiles_y;
+    int ksplit;               // split-K: gridDim.z workgroups share one output tile (fp32 atomic epilogue onto a zeroed y)
     int a_dbuf;               // activation halo double-buffered in LDS (1) or single-buffered with an extra barrier (0)
 };
 
@@ -31,8 +32,8 @@ struct ConvParams {
 //   the per-lane SOURCE address (16-byte chunk index ^ row key) and undone on the ds_read_b128 side -- conflict-free B-fragment
 //   reads without padding.  The activated input halo of a chunk is staged once (AdaIN/ReLU/upsample prologue in registers) into
 //   one of two halo buffers while the previous chunk's last stage is still being multiplied.
-template <int KS, bool UPS, int WM, int WN, int MR, int NR, int CC, int PREC, bool FAST>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
+template <int KS, bool UPS, int WM, int WN, int MR, int NR, int CC, int PREC, bool FAST, int NBUF>
+__global__ __launch_bounds__(256, (CC == 32 && PREC == LP_PREC_BF16 && NBUF == 2) ? 2 : 1) void conv_igemm_kernel(ConvParams p) {
     constexpr bool SPLIT = (PREC == LP_PREC_BF16X3);
     constexpr int BM = WM * MR * 16, BN = WN * NR * 16;
     constexpr int SA = CC * 2 + 16;                 // padded halo row stride (bytes)
@@ -42,6 +43,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     constexpr int B_STAGE = KS * BN * ROWB;         // bytes of one stage (hi part)
     constexpr int B_BUF = B_STAGE * (SPLIT ? 2 : 1);
     constexpr int NQ = B_STAGE / 1024;              // DMA instructions per stage (hi part)
+    constexpr int DMA_PER_WAVE = ((NQ + 3) / 4) * (SPLIT ? 2 : 1);   // LDS-DMA instructions one wave issues per stage
+    static_assert(NBUF == 2 || (NBUF == 3 && NQ % 4 == 0), "3-deep ring needs a uniform DMA count per wave");
     static_assert(!(UPS && KS == 1), "1x1 convs commute with nearest upsampling: run them at low resolution");
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(B_STAGE % 1024 == 0, "stage must be a whole number of 1 KiB DMA pieces");
@@ -218,35 +221,38 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
         }
     };
 
-    const int nch = p.CinP / CC;
-    issue_b(0, 0, 0);
-    if (FAST) { load_a(0); write_a(0, 0); } else stage_a_slow(0, 0);
+    const int nch_total = p.CinP / CC;
+    const int per = (nch_total + p.ksplit - 1) / p.ksplit;
+    const int cbeg = blockIdx.z * per;
+    const int nch = min(nch_total, cbeg + per) - cbeg;        // chunks of this workgroup: [cbeg, cbeg + nch)
+    if (nch <= 0) return;                                       // (uniform) nothing to contribute
+    issue_b(cbeg, 0, 0);
+    if (FAST) { load_a(cbeg); write_a(cbeg, 0); } else stage_a_slow(cbeg, 0);
 
     if (FAST) {
         // Straight-line pipeline (no data-dependent control flow around memory ops, so hipcc places no early vmcnt waits):
         // stage = kernel row.  Top of stage: wait own DMA, barrier; issue next stage's DMA; [last row: issue next chunk's
         // halo loads]; MFMAs; [last row: prologue + LDS write of the next halo into the other halo buffer].
-        int chunk = 0, abuf = 0;
-        for (; chunk + 1 < nch; ++chunk) {
+        // NBUF-deep weight ring: at the top of stage s the DMA of stage s+NBUF-1 is issued; only the DMA of stage s itself
+        // must have landed, so with NBUF == 3 one stage's worth of DMA instructions stays in flight across the barrier.
+        const int S = nch * KS;
+        int abuf = 0;
+        if (NBUF == 3 && S > 1) issue_b(cbeg + (KS > 1 ? 0 : 1), KS > 1 ? 1 : 0, 1);
+        for (int chunk = 0; chunk < nch; ++chunk) {
+            const bool has_next = chunk + 1 < nch;
 #pragma unroll
             for (int ky = 0; ky < KS; ++ky) {
-                lp_wait_vm0();
+                const int s = chunk * KS + ky;
+                if (NBUF == 3) { if (s + 1 < S) lp_wait_vm<DMA_PER_WAVE>(); else lp_wait_vm0(); } else lp_wait_vm0();
                 __syncthreads();
-                const int bbuf = (ky + chunk * KS) & 1;
-                if (ky + 1 < KS) issue_b(chunk, ky + 1, bbuf ^ 1); else issue_b(chunk + 1, 0, bbuf ^ 1);
-                if (ky == KS - 1) load_a(chunk + 1);
+                const int bbuf = s % NBUF;
+                const int sp = s + NBUF - 1;                       // stage to prefetch now
+                if (sp < S) issue_b(cbeg + sp / KS, sp % KS, sp % NBUF);
+                if (ky == KS - 1 && has_next) load_a(cbeg + chunk + 1);
                 compute(ky, abuf, bbuf);
-                if (ky == KS - 1) write_a(chunk + 1, abuf ^ 1);
+                if (ky == KS - 1 && has_next) write_a(cbeg + chunk + 1, abuf ^ 1);
             }
             abuf ^= 1;
-        }
-#pragma unroll
-        for (int ky = 0; ky < KS; ++ky) {                    // last chunk: nothing left to prefetch after its last row
-            lp_wait_vm0();
-            __syncthreads();
-            const int bbuf = (ky + chunk * KS) & 1;
-            if (ky + 1 < KS) issue_b(chunk, ky + 1, bbuf ^ 1);
-            compute(ky, abuf, bbuf);
         }
     } else {
         // generic path (several images per tile / odd channel counts): single halo buffer, synchronous staging
@@ -256,11 +262,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
                 lp_wait_vm0();
                 __syncthreads();
                 const int bbuf = (ky + chunk * KS) & 1;
-                if (ky + 1 < KS) issue_b(chunk, ky + 1, bbuf ^ 1);
-                else if (chunk + 1 < nch) issue_b(chunk + 1, 0, bbuf ^ 1);
+                if (ky + 1 < KS) issue_b(cbeg + chunk, ky + 1, bbuf ^ 1);
+                else if (chunk + 1 < nch) issue_b(cbeg + chunk + 1, 0, bbuf ^ 1);
                 compute(ky, 0, bbuf);
             }
-            if (chunk + 1 < nch) { __syncthreads(); stage_a_slow(chunk + 1, 0); }
+            if (chunk + 1 < nch) { __syncthreads(); stage_a_slow(cbeg + chunk + 1, 0); }
         }
     }
 
@@ -284,9 +290,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
                 const int co = co0 + wn * (NR * 16) + nr * 16 + (lane & 15);
                 if (co < p.Cout) {
                     float v = acc[mr][nr][r] * alpha;
-                    if (p.bias) v += p.bias[co];
-                    if (p.res) v += p.res[rpix + co];
-                    p.y[pix + co] = v;
+                    if (p.ksplit == 1 || blockIdx.z == 0) {
+                        if (p.bias) v += p.bias[co];
+                        if (p.res) v += p.res[rpix + co];
+                    }
+                    if (p.ksplit == 1) p.y[pix + co] = v;
+                    else unsafeAtomicAdd(p.y + pix + co, v);       // y was zeroed by lp_conv_fwd (hipMemsetAsync on the stream)
                 }
             }
         }
@@ -310,9 +319,9 @@ static void choose_tile(int BM, int N, int H, int W, int* lTH, int* lTW, int* lN
     *lTH = lth; *lTW = ltw; *lNB = lnb;
 }
 
-template <int KS, bool UPS, int WM, int WN, int MR, int NR, int CC, int PREC, bool FAST>
+template <int KS, bool UPS, int WM, int WN, int MR, int NR, int CC, int PREC, bool FAST, int NBUF>
 static int launch_conv_v(ConvParams& p, size_t lds, dim3 grid, hipStream_t stream) {
-    auto kern = conv_igemm_kernel<KS, UPS, WM, WN, MR, NR, CC, PREC, FAST>;
+    auto kern = conv_igemm_kernel<KS, UPS, WM, WN, MR, NR, CC, PREC, FAST, NBUF>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -340,11 +349,25 @@ static int launch_conv(ConvParams& p, hipStream_t stream) {
     const size_t a_buf = (size_t)NBv * HH * HW * SA * (SPLIT ? 2 : 1);
     const bool fast = (NBv == 1) && ((p.Cin & 7) == 0) && (HH * HW <= AIT * PPP) && (2 * a_buf + 2 * B_BUF <= LDS_MAX);
     p.a_dbuf = fast ? 1 : 0;
-    const size_t lds = a_buf * (fast ? 2 : 1) + 2 * B_BUF;
+    static const int want_nbuf = getenv("LP_CONV_NBUF") ? atoi(getenv("LP_CONV_NBUF")) : 2;       // tuning knob: 2 | 3
+    constexpr bool ring3_ok = (CC == 32) && (KS == 3) && (BN >= 64) && !SPLIT;
+    const bool ring3 = ring3_ok && fast && want_nbuf == 3 && (2 * a_buf + 3 * B_BUF <= LDS_MAX);
+    const size_t lds = a_buf * (fast ? 2 : 1) + (ring3 ? 3 : 2) * B_BUF;
     if (lds > LDS_MAX) return lp_set_error(LP_ERR_UNSUPPORTED, "conv tile needs too much LDS");
     dim3 grid(p.tiles_x * p.tiles_y * ((p.N + NBv - 1) / NBv), (p.Cout + BN - 1) / BN);
-    if (fast) return launch_conv_v<KS, UPS, WM, WN, MR, NR, CC, PREC, true>(p, lds, grid, stream);
-    return launch_conv_v<KS, UPS, WM, WN, MR, NR, CC, PREC, false>(p, lds, grid, stream);
+    {   // split-K when the output tiling alone cannot fill the 256 CUs (4x4 ... 32x32 layers with K = 9*512)
+        static const int max_split = getenv("LP_CONV_KSPLIT") ? atoi(getenv("LP_CONV_KSPLIT")) : 8;
+        const int wgs = grid.x * grid.y, nch = p.CinP / CC;
+        int ks = 1;
+        while (ks < max_split && wgs * ks * 2 <= 256 && nch / (ks * 2) >= 2) ks *= 2;
+        p.ksplit = ks;
+        grid.z = ks;
+        if (ks > 1 && hipMemsetAsync(p.y, 0, (size_t)p.N * p.H * p.W * p.Cout * sizeof(float), stream) != hipSuccess)
+            return lp_set_error(LP_ERR_HIP, "hipMemsetAsync failed");
+    }
+    if constexpr (ring3_ok) { if (ring3) return launch_conv_v<KS, UPS, WM, WN, MR, NR, CC, PREC, true, 3>(p, lds, grid, stream); }
+    if (fast) return launch_conv_v<KS, UPS, WM, WN, MR, NR, CC, PREC, true, 2>(p, lds, grid, stream);
+    return launch_conv_v<KS, UPS, WM, WN, MR, NR, CC, PREC, false, 2>(p, lds, grid, stream);
 }
 
 // Channel-chunk size: 64 for bf16; 32 for bf16x3 (hi+lo images double every LDS tile) and for tiny-Cin packs (CinP % 64 != 0).
@@ -370,7 +393,8 @@ static int dispatch_conv_cc(ConvParams& p, int ks, int ups, hipStream_t s) {
 template <int PREC>
 static int dispatch_conv(ConvParams& p, int ks, int ups, hipStream_t s) {
     static const int force_cc = getenv("LP_CONV_CC") ? atoi(getenv("LP_CONV_CC")) : 0;     // tuning knob: 32 | 64
-    if (force_cc == 32 || (force_cc != 64 && PREC == LP_PREC_BF16X3) || p.CinP % 64 != 0) return dispatch_conv_cc<PREC, 32>(p, ks, ups, s);
+    // default CC = 32: two workgroups fit per CU (78 KB LDS, <= 256 registers) and hide each other's staging latency
+    if (force_cc != 64 || p.CinP % 64 != 0) return dispatch_conv_cc<PREC, 32>(p, ks, ups, s);
     return dispatch_conv_cc<PREC, 64>(p, ks, ups, s);
 }
 

@@ -42,6 +42,7 @@ __device__ __forceinline__ void lp_glds16(const void* gsrc, unsigned lds_dst) {
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 __device__ __forceinline__ void lp_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+template <int N> __device__ __forceinline__ void lp_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory"); }
 
 // Geometry of one output tile: NB images x (TH x TW) pixel patch, all powers of two, TH,TW >= 2.
 struct TileGeom {
