@@ -103,6 +103,18 @@ int lp_mt_optimizer_step(const void* table, int num_tensors, long long max_numel
                          float beta1, float beta2, float eps, void* stream);
 int lp_mt_ema(const void* table, int num_tensors, long long max_numel, float alpha, int copy_only, void* stream);
 
+/* ---- batched spectral normalisation (legacy torch.nn.utils.spectral_norm hook; generators/common/blocks.py:76-88) ----
+ * table: DEVICE array of {const float* w; float* u; float* v; float* u_out; float* v_out; float* sig_out; int rows; int cols;
+ * float* part; int rows; int cols; float eps; int pad;} (lp_sn_desc_bytes() each), one per layer; `part` = scratch of
+ * ceil(rows/lp_sn_row_block())*cols + rows floats.  do_iter=1 (train): v <- normalize(W^T u), u <- normalize(W v) in place;
+ * always: u_out/v_out = the vectors used, sig_out = {sigma = u^T W v, 1/sigma}.  Four launches, row-blocked over many workgroups.
+ * lp_sn_grad_apply: g <- g/sigma - (<g, w_orig>/sigma^2) u v^T in place (autograd of W/sigma with u, v constant); dot = scratch. */
+int lp_sn_desc_bytes(void);
+int lp_sn_row_block(void);
+int lp_sn_power_iter(const void* table, int num_layers, int do_iter, int max_rows, int max_cols, void* stream);
+int lp_sn_grad_apply(float* g, const float* w_orig, const float* u, const float* v, const float* sig, float* dot, int rows, int cols,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,6 +39,10 @@ SIGNATURES = {
     'lp_mt_desc_bytes': (_i, []),
     'lp_mt_optimizer_step': (_i, [_vp, _i, _ll, _vp, _i, _f, _f, _f, _f, _vp]),
     'lp_mt_ema': (_i, [_vp, _i, _ll, _f, _i, _vp]),
+    'lp_sn_desc_bytes': (_i, []),
+    'lp_sn_power_iter': (_i, [_vp, _i, _i, _i, _i, _vp]),
+    'lp_sn_row_block': (_i, []),
+    'lp_sn_grad_apply': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
 }
 
 _lib = None

@@ -14,8 +14,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from latent_pose_reenactment_amd.nn import (SNWeight, _Indexed, SN_EPS_CONV, SN_EPS_DEFAULT, AvgPool2Fn, as_nchw_view, hip_conv,
-                                            to_nhwc)
+from latent_pose_reenactment_amd.nn import (SNWeight, SNBatch, SNLinearFn, _Indexed, SN_EPS_CONV, SN_EPS_DEFAULT, AvgPool2Fn,
+                                            as_nchw_view, hip_conv, to_nhwc)
 from latent_pose_reenactment_amd.utils import radam as _radam
 
 torch.optim.RAdam = _radam.RAdam      # the reference swaps in its own RAdam the same way (no_landmarks.py:5-6)
@@ -39,10 +39,12 @@ class Wrapper:
         return optimizer_class(args.optimizer, args.device)(discriminator.parameters(), lr=args.lr_dis, betas=(args.beta1, 0.999), eps=1e-5)
 
 
-def _wb(sn, track):
-    """(effective weight, bias) of an SN layer; ``track=False`` detaches them from autograd (the power iteration still runs)"""
-    w, b = sn.effective_weight(), sn.bias
-    return (w, b) if track else (w.detach(), None if b is None else b.detach())
+def _wb(layer, track, states):
+    """(W_orig, bias, sn-state) of an SN conv for ``hip_conv``; ``track=False`` detaches the parameters from autograd"""
+    w, b = layer.weight_orig, layer.bias
+    if not track:
+        w, b = w.detach(), (None if b is None else b.detach())
+    return w, b, states[id(layer)]
 
 
 class _DisBlock(nn.Module):
@@ -56,16 +58,21 @@ class _DisBlock(nn.Module):
             self.skip = _Indexed(_0=SNWeight((cout, cin, 1, 1), True, SN_EPS_CONV))
         self.downsample = downsample
 
-    def forward(self, x_relu, track=True):
+    def sn_layers(self):
+        return [self.block._modules['2'], self.block._modules['5']] + ([self.skip._modules['0']] if self.has_skip else [])
+
+    def forward(self, x_relu, track, states):
         """x_relu: NHWC relu(x) (the reference's in-place ReLU makes every consumer of the block input see relu(x))"""
         c1, c2 = self.block._modules['2'], self.block._modules['5']
-        h = hip_conv(x_relu, *_wb(c1, track), ksize=3)
+        w1, b1, s1 = _wb(c1, track, states)
+        h = hip_conv(x_relu, w1, b1, ksize=3, sn=s1)
         if self.has_skip:
-            shortcut = hip_conv(x_relu, *_wb(self.skip._modules['0'], track), ksize=1)
+            ws, bs, ss = _wb(self.skip._modules['0'], track, states)
+            shortcut = hip_conv(x_relu, ws, bs, ksize=1, sn=ss)
         else:
             shortcut = x_relu
-        w2, b2 = _wb(c2, track)
-        out = hip_conv(h, w2, b2, res=shortcut, ksize=3, pro=2)
+        w2, b2, s2 = _wb(c2, track, states)
+        out = hip_conv(h, w2, b2, res=shortcut, ksize=3, pro=2, sn=s2)
         return AvgPool2Fn.apply(out, False) if self.downsample else out
 
 
@@ -105,20 +112,30 @@ class Discriminator(nn.Module):
         if not x.is_cuda:
             raise RuntimeError('the discriminator runs on the MI355X HIP path only (no CPU fallback)')
         d0, d2, sk = self.down_block._modules['0'], self.down_block._modules['2'], self.skip._modules['0']
+        # one launch power-iterates all spectrally normalised layers of this pass (every pass does its own iteration)
+        layers = self.__dict__.get('_sn_layer_cache')
+        if layers is None:
+            layers = [d0, d2, sk] + [l for blk in self.blocks for l in blk.sn_layers()] + [self.linear]
+            self.__dict__['_sn_layer_cache'] = layers
+            self.__dict__['_sn_batch'] = SNBatch(layers)
+        st = self._sn_batch.update(self.training)
+        states = {id(l): s for l, s in zip(layers, st)}
         xn = to_nhwc(x)
-        h = hip_conv(xn, *_wb(d0, track_weights), ksize=3)
-        shortcut = hip_conv(xn, *_wb(sk, track_weights), ksize=1)
-        w2, b2 = _wb(d2, track_weights)
-        out = AvgPool2Fn.apply(hip_conv(h, w2, b2, res=shortcut, ksize=3, pro=2), False)
+        w0, b0, s0 = _wb(d0, track_weights, states)
+        h = hip_conv(xn, w0, b0, ksize=3, sn=s0)
+        wk, bk, sk_state = _wb(sk, track_weights, states)
+        shortcut = hip_conv(xn, wk, bk, ksize=1, sn=sk_state)
+        w2, b2, s2 = _wb(d2, track_weights, states)
+        out = AvgPool2Fn.apply(hip_conv(h, w2, b2, res=shortcut, ksize=3, pro=2, sn=s2), False)
         feats = []
         for block in self.blocks:
             out_relu = torch.relu(out)           # what the reference's in-place ReLU leaves behind in its feature list
             feats.append(as_nchw_view(out_relu))
-            out = block(out_relu, track_weights)
+            out = block(out_relu, track_weights, states)
         feats.append(as_nchw_view(out))
         pooled = torch.relu(out).sum(dim=(1, 2))
-        wl, bl = _wb(self.linear, track_weights)
-        score = F.linear(pooled, wl, bl)[:, 0]
+        wl, bl, sl = _wb(self.linear, track_weights, states)
+        score = SNLinearFn.apply(pooled, wl, bl, *sl)[:, 0]
         if embed is not None:
             score = (pooled * embed).sum(1) + score
         return score, feats

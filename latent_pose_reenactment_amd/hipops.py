@@ -98,8 +98,10 @@ def conv(x: Tensor, pack: WeightPack, *, ksize: int, upsample: bool = False, pro
 
 
 def conv_wgrad(x: Tensor, dy: Tensor, *, ksize: int, upsample: bool = False, pro: int = 0, scale: Optional[Tensor] = None,
-               shift: Optional[Tensor] = None, prec: int = PREC_BF16, splits: Optional[int] = None) -> Tensor:
-    """dw [Cout,Cin,k,k] = sum_pixels dy (x) up2?(act(x)) (shifted by tap)."""
+               shift: Optional[Tensor] = None, prec: int = PREC_BF16, splits: Optional[int] = None, sn=None) -> Tensor:
+    """dw [Cout,Cin,k,k] = sum_pixels dy (x) up2?(act(x)) (shifted by tap).
+    ``sn`` = (w_orig, u, v, sig): the layer is spectrally normalised (forward used alpha = 1/sigma in the conv epilogue); the
+    returned gradient is then w.r.t. W_orig: dw/sigma - <dw, W_orig>/sigma^2 u v^T."""
     _chk(x, 'x'); _chk(dy, 'dy')
     n, h, w, cout = dy.shape
     cin = x.shape[3]
@@ -109,9 +111,14 @@ def conv_wgrad(x: Tensor, dy: Tensor, *, ksize: int, upsample: bool = False, pro
     ws_bytes = _lib.lib().lp_conv_wgrad_workspace_bytes(cin, cout, ksize, splits)
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
     dw = torch.empty((cout, cin, ksize, ksize), dtype=torch.float32, device=x.device)
+    dot = torch.empty(1, dtype=torch.float32, device=x.device) if sn is not None else None
     with _Timed('conv_wgrad', 2.0 * n * h * w * cout * cin * ksize * ksize):
         check(_lib.lib().lp_conv_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), _p(scale), _p(shift), n, h, w, cin,
                                        cout, ksize, int(upsample), pro, splits, prec, _stream()), 'lp_conv_wgrad')
+    if sn is not None:
+        w_orig, u, v, sig = sn
+        check(_lib.lib().lp_sn_grad_apply(dw.data_ptr(), w_orig.data_ptr(), u.data_ptr(), v.data_ptr(), sig.data_ptr(), dot.data_ptr(),
+                                          cout, cin * ksize * ksize, _stream()), 'lp_sn_grad_apply')
     return dw
 
 

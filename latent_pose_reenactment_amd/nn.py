@@ -72,6 +72,88 @@ class SNWeight(nn.Module):
         return w / sigma
 
 
+class SNBatch:
+    """One-launch spectral normalisation of many ``SNWeight`` layers (lp_sn_power_iter): in train mode each layer's (u, v)
+    buffers take one power-iteration step in place, and for every layer the call yields ``(u_used, v_used, sig)`` with
+    ``sig = [sigma, 1/sigma]`` (device tensors).  ``1/sigma`` becomes the conv kernels' epilogue scale, so ``W / sigma`` is never
+    materialised; backward uses the saved (u, v).  Outputs rotate over a few static buffer sets (a discriminator runs three
+    passes per step, each needing its own copies until its backward is done; static addresses keep hipGraph capture valid)."""
+    SETS = 4
+
+    def __init__(self, layers):
+        self.layers = list(layers)
+        self.sets = None
+        self.key = None
+        self.next = 0
+
+    def _build(self):
+        import struct
+        from . import _lib
+        assert _lib.lib().lp_sn_desc_bytes() == 72
+        rb = _lib.lib().lp_sn_row_block()
+        dev = self.layers[0].weight_orig.device
+        rows = [l.weight_orig.shape[0] for l in self.layers]
+        cols = [l.weight_orig[0].numel() for l in self.layers]
+        self.max_rows, self.max_cols = max(rows), max(cols)
+        self.sets = []
+        for _ in range(self.SETS):
+            sig = torch.zeros(len(self.layers), 2, dtype=torch.float32, device=dev)
+            uo = torch.zeros(sum(rows), dtype=torch.float32, device=dev)
+            vo = torch.zeros(sum(cols), dtype=torch.float32, device=dev)
+            need = [((r + rb - 1) // rb) * c + r for r, c in zip(rows, cols)]
+            scratch = torch.zeros(sum(need), dtype=torch.float32, device=dev)
+            blob = bytearray()
+            states = []
+            ro = co = so = 0
+            for i, l in enumerate(self.layers):
+                w, u, v = l.weight_orig.data, l.weight_u, l.weight_v
+                assert w.is_contiguous() and w.dtype == torch.float32
+                ui, vi, si, pi = uo[ro:ro + rows[i]], vo[co:co + cols[i]], sig[i], scratch[so:so + need[i]]
+                blob += struct.pack('<QQQQQQQiifi', w.data_ptr(), u.data_ptr(), v.data_ptr(), ui.data_ptr(), vi.data_ptr(), si.data_ptr(),
+                                    pi.data_ptr(), rows[i], cols[i], float(l.eps), 0)
+                states.append((ui, vi, si))
+                ro += rows[i]; co += cols[i]; so += need[i]
+            table = torch.frombuffer(blob, dtype=torch.uint8).clone().to(dev)
+            self.sets.append((table, states, (sig, uo, vo, scratch)))
+
+    def update(self, training: bool):
+        from . import _lib
+        key = tuple((l.weight_orig.data_ptr(), l.weight_u.data_ptr(), l.weight_v.data_ptr()) for l in self.layers)
+        if self.sets is None or key != self.key:
+            self._build()
+            self.key = key
+        table, states, _ = self.sets[self.next]
+        self.next = (self.next + 1) % self.SETS
+        _lib.check(_lib.lib().lp_sn_power_iter(table.data_ptr(), len(self.layers), int(training), self.max_rows, self.max_cols,
+                                               torch.cuda.current_stream().cuda_stream), 'lp_sn_power_iter')
+        return states
+
+
+class SNLinearFn(torch.autograd.Function):
+    """y = (x W_orig^T) / sigma + b for a spectrally normalised nn.Linear whose sigma comes from SNBatch (plain library GEMMs);
+    backward applies the legacy-hook rule dW_orig = G/sigma - <G, W_orig>/sigma^2 u v^T with u, v constant."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, u, v, sig):
+        ctx.save_for_backward(x, w, u, v, sig)
+        y = F.linear(x, w) * sig[1]
+        return y + b if b is not None else y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, u, v, sig = ctx.saved_tensors
+        alpha = sig[1]
+        dx = (g @ w) * alpha if ctx.needs_input_grad[0] else None
+        dw = db = None
+        if ctx.needs_input_grad[1]:
+            graw = g.reshape(-1, g.shape[-1]).t() @ x.reshape(-1, x.shape[-1])
+            dot = (graw * w).sum()
+            dw = graw * alpha - (dot * alpha * alpha) * torch.outer(u, v)
+        if ctx.needs_input_grad[2]:
+            db = g.reshape(-1, g.shape[-1]).sum(0)
+        return dx, dw, db, None, None, None
+
+
 class _Indexed(nn.Module):
     """Container whose children are named by explicit integer positions (mirrors the sparse indices that
     nn.Sequential gives parameter-less layers in the reference: e.g. ``block.3`` / ``block.7``)."""
@@ -138,6 +220,7 @@ class _DecoderFunction(torch.autograd.Function):
     def forward(ctx, cfg, affine, constant, *weights):
         blocks, prec = cfg['blocks'], cfg['prec']
         need_grad = cfg['need_grad']
+        sn = cfg['sn']                    # per entry of `weights`: (u_used, v_used, [sigma, 1/sigma]) for conv weights, None for biases
         B = affine.shape[0]
         affine = affine.contiguous()
         wl = list(weights)
@@ -161,18 +244,19 @@ class _DecoderFunction(torch.autograd.Function):
             g1, b1, o1 = aff(cout)
             st0 = ops.instnorm_stats(x, g0, b0, ADAIN_EPS)
             p1 = ops.pack_weights(w1.detach().contiguous(), 0, prec)
-            h1 = ops.conv(x, p1, ksize=3, upsample=up, pro=1, scale=st0[2], shift=st0[3], prec=prec)
+            h1 = ops.conv(x, p1, ksize=3, upsample=up, pro=1, scale=st0[2], shift=st0[3], alpha=sn[wi - 2][2][1:], prec=prec)
             st1 = ops.instnorm_stats(h1, g1, b1, ADAIN_EPS)
             if has_skip:
                 ws, bs = wl[wi], wl[wi + 1]
                 wi += 2
                 ps = ops.pack_weights(ws.detach().contiguous(), 0, prec)
-                s = ops.conv(x, ps, ksize=1, bias=bs.detach().contiguous(), prec=prec)     # 1x1 commutes with nearest upsampling
+                s = ops.conv(x, ps, ksize=1, bias=bs.detach().contiguous(), alpha=sn[wi - 2][2][1:], prec=prec)   # 1x1 commutes with nearest upsampling
                 rs = 1 if up else 0
             else:
                 s, rs = x, 0
             p2 = ops.pack_weights(w2.detach().contiguous(), 0, prec)
-            out = ops.conv(h1, p2, ksize=3, pro=1, scale=st1[2], shift=st1[3], res=s, res_shift=rs, prec=prec)
+            i2 = wi - (3 if has_skip else 1)
+            out = ops.conv(h1, p2, ksize=3, pro=1, scale=st1[2], shift=st1[3], res=s, res_shift=rs, alpha=sn[i2][2][1:], prec=prec)
             if need_grad:
                 saved.append((x, h1, st0, st1, o0, o1))
             x = out
@@ -181,7 +265,7 @@ class _DecoderFunction(torch.autograd.Function):
         sth = ops.instnorm_stats(x, gh, bh, ADAIN_EPS)
         wh, bhd = wl[wi], wl[wi + 1]
         ph = ops.pack_weights(wh.detach().contiguous(), 0, prec)
-        z = ops.conv(x, ph, ksize=3, pro=1, scale=sth[2], shift=sth[3], bias=bhd.detach().contiguous(), prec=prec)
+        z = ops.conv(x, ph, ksize=3, pro=1, scale=sth[2], shift=sth[3], bias=bhd.detach().contiguous(), alpha=sn[wi][2][1:], prec=prec)
         t, rgbs, segm = ops.head_fwd(z, want_t=need_grad)
         if need_grad:
             ctx.cfg = cfg
@@ -196,8 +280,12 @@ class _DecoderFunction(torch.autograd.Function):
     def backward(ctx, d_rgbs, d_segm):
         cfg = ctx.cfg
         blocks, prec = cfg['blocks'], cfg['prec']
+        sn = cfg['sn']
         affine, wl = ctx.affine, ctx.weights
         d_affine = torch.zeros_like(affine)
+
+        def snw(i):          # (W_orig, u, v, sig) of conv weight i -> wgrad returns the gradient w.r.t. W_orig
+            return (wl[i],) + tuple(sn[i])
         grads: List[Optional[torch.Tensor]] = [None] * len(wl)
 
         def slices(o, c):      # (gamma, dgamma, dbeta) views for the AdaIN whose params start at column o
@@ -207,10 +295,10 @@ class _DecoderFunction(torch.autograd.Function):
         ch = blocks[-1][1]
         dz = ops.head_bwd(t, d_rgbs.contiguous(), None if d_segm is None else d_segm.contiguous())
         wi = len(wl) - 2
-        grads[wi] = ops.conv_wgrad(x, dz, ksize=3, pro=1, scale=sth[2], shift=sth[3], prec=prec)
+        grads[wi] = ops.conv_wgrad(x, dz, ksize=3, pro=1, scale=sth[2], shift=sth[3], prec=prec, sn=snw(wi))
         grads[wi + 1] = dz.sum(dim=(0, 1, 2))
         pT = ops.pack_weights(wl[wi].contiguous(), 1, prec, small_k=True)
-        dA = ops.conv(dz, pT, ksize=3, prec=prec)
+        dA = ops.conv(dz, pT, ksize=3, alpha=sn[wi][2][1:], prec=prec)
         g, dg, db = slices(oh, ch)
         dx = ops.adain_relu_bwd(dA, x, None, g, sth[0], sth[1], sth[2], sth[3], dg, db, False)
         dbg = cfg.get('debug')
@@ -225,22 +313,22 @@ class _DecoderFunction(torch.autograd.Function):
             w1, w2 = wl[wi], wl[wi + 1]
             d_out = dx
             # conv2 (+ AdaIN1/ReLU prologue)
-            grads[wi + 1] = ops.conv_wgrad(h1, d_out, ksize=3, pro=1, scale=st1[2], shift=st1[3], prec=prec)
-            dA1 = ops.conv(d_out, ops.pack_weights(w2.contiguous(), 1, prec), ksize=3, prec=prec)
+            grads[wi + 1] = ops.conv_wgrad(h1, d_out, ksize=3, pro=1, scale=st1[2], shift=st1[3], prec=prec, sn=snw(wi + 1))
+            dA1 = ops.conv(d_out, ops.pack_weights(w2.contiguous(), 1, prec), ksize=3, alpha=sn[wi + 1][2][1:], prec=prec)
             g, dg, db = slices(o1, cout)
             dh1 = ops.adain_relu_bwd(dA1, h1, None, g, st1[0], st1[1], st1[2], st1[3], dg, db, False)
             # skip branch: out += up2(conv1x1(x) + b)
             if has_skip:
                 ws = wl[wi + 2]
                 ds = ops.sum2x2(d_out) if up else d_out
-                grads[wi + 2] = ops.conv_wgrad(x, ds, ksize=1, prec=prec)
+                grads[wi + 2] = ops.conv_wgrad(x, ds, ksize=1, prec=prec, sn=snw(wi + 2))
                 grads[wi + 3] = ds.sum(dim=(0, 1, 2))
-                dx_skip = ops.conv(ds, ops.pack_weights(ws.contiguous(), 1, prec), ksize=1, prec=prec)
+                dx_skip = ops.conv(ds, ops.pack_weights(ws.contiguous(), 1, prec), ksize=1, alpha=sn[wi + 2][2][1:], prec=prec)
             else:
                 dx_skip = d_out
             # conv1 (+ AdaIN0/ReLU/upsample prologue)
-            grads[wi] = ops.conv_wgrad(x, dh1, ksize=3, upsample=up, pro=1, scale=st0[2], shift=st0[3], prec=prec)
-            dA0 = ops.conv(dh1, ops.pack_weights(w1.contiguous(), 1, prec), ksize=3, prec=prec)
+            grads[wi] = ops.conv_wgrad(x, dh1, ksize=3, upsample=up, pro=1, scale=st0[2], shift=st0[3], prec=prec, sn=snw(wi))
+            dA0 = ops.conv(dh1, ops.pack_weights(w1.contiguous(), 1, prec), ksize=3, alpha=sn[wi][2][1:], prec=prec)
             g, dg, db = slices(o0, cin)
             dx = ops.adain_relu_bwd(dA0, x, dx_skip, g, st0[0], st0[1], st0[2], st0[3], dg, db, up)
             if dbg is not None:
@@ -309,26 +397,55 @@ class Generator(nn.Module):
         else:
             identity = data_dict['embeds']
         joint = torch.cat((identity, data_dict['pose_embedding']), dim=1)
+        if not joint.is_cuda:
+            raise RuntimeError('the generator runs on the MI355X HIP path only (no CPU fallback); move the model and inputs to cuda')
+        # ONE launch power-iterates every spectrally normalised layer of the generator (23 convs + 2 projector linears)
+        layers, slots = self._sn_layers()
+        if self.__dict__.get('_sn_batch') is None or self._sn_batch.layers != layers:
+            self.__dict__['_sn_batch'] = SNBatch(layers)
+        states = self._sn_batch.update(self.training)
+        self.__dict__['_sn_states'] = states
         p0, p2 = self.affine_params_projector._modules['0'], self.affine_params_projector._modules['2']
         # plain library GEMMs (rocBLAS through torch) -- B x 768 x 768 and B x 768 x 13056
-        h = torch.relu(F.linear(joint, p0.effective_weight(), p0.bias))
+        h = torch.relu(SNLinearFn.apply(joint, p0.weight_orig, p0.bias, *states[-1]))
+        # the 13 056 x 768 output projection (10 M weights) is too large for the one-workgroup-per-layer SN kernel: torch ops
         return F.linear(h, p2.effective_weight(), p2.bias)
+
+    def _sn_layers(self):
+        """batched SNWeight layers in a fixed order: decoder convs (block order, w1, w2[, skip]), head conv, projector.0"""
+        cached = self.__dict__.get('_sn_layer_cache')
+        if cached is None:
+            layers = []
+            nb = len(self.blocks_cfg)
+            for i in range(nb):
+                c1, c2, sk = self.decoder_blocks._modules[str(i)].convs()
+                layers += [c1, c2] + ([sk] if sk is not None else [])
+            layers.append(self.decoder_blocks._modules[str(nb + 2)])
+            layers += [self.affine_params_projector._modules['0']]
+            cached = (layers, None)
+            self.__dict__['_sn_layer_cache'] = cached
+        return cached
 
     def forward(self, data_dict):
         affine = self._affine_params(data_dict)
-        if not affine.is_cuda:
-            raise RuntimeError('the generator runs on the MI355X HIP path only (no CPU fallback); move the model and inputs to cuda')
-        weights = []
+        states = self._sn_states
+        weights, sn = [], []
         nb = len(self.blocks_cfg)
+        k = 0
         for i in range(nb):
             c1, c2, sk = self.decoder_blocks._modules[str(i)].convs()
-            weights += [c1.effective_weight(), c2.effective_weight()]
+            weights += [c1.weight_orig, c2.weight_orig]
+            sn += [states[k], states[k + 1]]
+            k += 2
             if sk is not None:
-                weights += [sk.effective_weight(), sk.bias]
+                weights += [sk.weight_orig, sk.bias]
+                sn += [states[k], None]
+                k += 1
         head = self.decoder_blocks._modules[str(nb + 2)]
-        weights += [head.effective_weight(), head.bias]
+        weights += [head.weight_orig, head.bias]
+        sn += [states[k], None]
         need_grad = torch.is_grad_enabled() and (affine.requires_grad or any(w.requires_grad for w in weights))
-        cfg = dict(blocks=self.blocks_cfg, prec=self.prec, need_grad=need_grad, debug=getattr(self, '_debug', None))
+        cfg = dict(blocks=self.blocks_cfg, prec=self.prec, need_grad=need_grad, sn=sn, debug=getattr(self, '_debug', None))
         rgbs, segm = _DecoderFunction.apply(cfg, affine, self.constant.constant, *weights)
         data_dict['fake_rgbs'] = rgbs
         data_dict['fake_segm'] = segm
@@ -353,36 +470,38 @@ class ConvFn(torch.autograd.Function):
     lp_conv_wgrad, and a channel sum for the bias.  ``packs`` = optional cached (forward, dgrad) WeightPacks of a frozen w."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, res, ksize, pro, prec, packs):
+    def forward(ctx, x, w, bias, res, ksize, pro, prec, packs, sn=None):
+        """``sn`` = (u_used, v_used, [sigma, 1/sigma]) from SNBatch when ``w`` is a spectrally normalised W_orig"""
         small_k = ksize == 3 and w.shape[1] <= 32
         wd = w.detach().contiguous()
         pack = packs[0] if packs is not None else ops.pack_weights(wd, 0, prec, small_k=small_k)
-        y = ops.conv(x, pack, ksize=ksize, pro=pro, bias=None if bias is None else bias.detach().contiguous(), res=res, prec=prec)
+        y = ops.conv(x, pack, ksize=ksize, pro=pro, bias=None if bias is None else bias.detach().contiguous(), res=res,
+                     alpha=None if sn is None else sn[2][1:], prec=prec)
         ctx.save_for_backward(x, wd)
-        ctx.cfg = (ksize, pro, prec, packs, bias is not None, res is not None)
+        ctx.cfg = (ksize, pro, prec, packs, bias is not None, res is not None, sn)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, wd = ctx.saved_tensors
-        ksize, pro, prec, packs, has_bias, has_res = ctx.cfg
+        ksize, pro, prec, packs, has_bias, has_res, sn = ctx.cfg
         dy = dy.contiguous()
         dx = dw = db = dres = None
         if ctx.needs_input_grad[0]:
             packT = packs[1] if packs is not None else ops.pack_weights(wd, 1, prec, small_k=(ksize == 3 and wd.shape[0] <= 32))
-            dA = ops.conv(dy, packT, ksize=ksize, prec=prec)
+            dA = ops.conv(dy, packT, ksize=ksize, alpha=None if sn is None else sn[2][1:], prec=prec)
             dx = ops.relu_bwd(dA, x) if pro == 2 else dA
         if ctx.needs_input_grad[1]:
-            dw = ops.conv_wgrad(x, dy, ksize=ksize, pro=pro, prec=prec)
+            dw = ops.conv_wgrad(x, dy, ksize=ksize, pro=pro, prec=prec, sn=None if sn is None else (wd,) + tuple(sn))
         if has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(dim=(0, 1, 2))
         if has_res and ctx.needs_input_grad[3]:
             dres = dy
-        return dx, dw, db, dres, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None
 
 
-def hip_conv(x, w, bias=None, res=None, ksize=3, pro=0, prec=None, packs=None):
-    return ConvFn.apply(x, w, bias, res, ksize, pro, default_prec() if prec is None else prec, packs)
+def hip_conv(x, w, bias=None, res=None, ksize=3, pro=0, prec=None, packs=None, sn=None):
+    return ConvFn.apply(x, w, bias, res, ksize, pro, default_prec() if prec is None else prec, packs, sn)
 
 
 class AvgPool2Fn(torch.autograd.Function):
