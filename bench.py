@@ -5,8 +5,8 @@ Workload at N=1 = BASELINE.json configs[1]: the fine-tuning step of configs/fine
 (criterions adversarial, featmat, idt_embed, perceptual, dice; RAdam lr_gen 5e-4 / lr_dis 8e-4; EMA 0.972), bs=8,
 256x256, synthetic VoxCeleb2-shaped batch, random-init weights (no network for datasets/checkpoints).  One "step" =
 runners/holycow.py:230-257: E(pose) -> G -> D x3 -> criterions -> G backward/step -> D backward/step -> EMA.
-Round-1 scope ("generator-only HIP path"): the generator forward/backward runs on the hand-written gfx950 kernels; the
-pose encoder, discriminator and VGG criterions run on stock PyTorch-ROCm ops.  For N>1 the same per-GPU step runs data
+The generator, the discriminator, the VGG19/VGGFace criterions, RAdam, EMA and the spectral-norm power iterations run on the
+hand-written gfx950 kernels of liblp_hip.so; only the MobileNetV2 pose encoder (forward only in fine-tuning) is stock torch-ROCm.  For N>1 the same per-GPU step runs data
 parallel with the RCCL gradient all-reduce of latent_pose_reenactment_amd.parallel (weak scaling).
 
 Prints ONE JSON line on rank 0 (see README/DESIGN for the field definitions)."""
@@ -76,53 +76,79 @@ def synthetic_batch(args, per_gpu_batch, seed):
 
 
 def cpu_baseline(args, sample_batch=1):
-    """The oracle (oracle/lp_oracle.py: fp32 CPU restatement, parity-pinned against the reference) timed on this box's
-    host cores on a bounded sample: ONE generator forward+backward of `sample_batch` images at 256x256 (the hot path's
-    generator step; 182.2 GFLOP/image), all cores."""
-    import math
+    """The oracle (oracle/lp_oracle.py: fp32 torch-CPU restatement, parity-pinned against the reference) running the SAME
+    fine-tuning step on this box's host cores, on a bounded sample: `sample_batch` image(s) per step, repeated until ~20 s.
+    Step = pose encoder -> generator -> discriminator x3 -> adversarial/featmat/VGGFace/VGG19/dice -> loss_G.backward ->
+    RAdam(G) -> loss_D.backward -> RAdam(D) -> EMA(G)."""
+    import copy
     from oracle import lp_oracle as O
-    import torch.nn.functional as F
-    cores = min(os.cpu_count() or 1, 32)      # torch-CPU oversubscribes badly beyond one CCD group (256 threads: 100x slower)
+    from generators.vector_pose_unsupervised_segmentation_noBottleneck import Wrapper as GW
+    from discriminators.no_landmarks import Wrapper as DW
+    from embedders.backbones import mobilenet_v2
+    from criterions.common.perceptual_loss import PerceptualLoss
+    from dataloaders.synthetic_voxceleb2 import make_sample
+    cores = min(os.cpu_count() or 1, 32)      # torch-CPU oversubscribes badly beyond that (256 threads measured 100x slower)
     torch.set_num_threads(cores)
-    g = torch.Generator().manual_seed(0)
-    sd = {}
-    blocks = O.generator_channels(64, 512, args.image_size)
+    a = copy.copy(args)
+    a.device = 'cpu'
+    torch.manual_seed(0)
+    G, D, pose_net = GW.get_net(a), DW.get_net(a), mobilenet_v2(256)
+    e_hat = torch.randn(1, 512) * 0.1
+    G.enable_finetuning({'embeds': e_hat}); D.enable_finetuning({'embeds': e_hat})
+    vgg19 = PerceptualLoss(a.perc_weight, '/nonexistent', 'caffe', synthetic_seed=1234).model.state_dict()
+    vggf = PerceptualLoss(a.idt_embed_weight, '/nonexistent', 'face', synthetic_seed=1235).model.state_dict()
 
-    def sn(prefix, shape, bias):
-        fan_in = math.prod(shape[1:])
-        sd[prefix + '.weight_orig'] = ((torch.rand(shape, generator=g) * 2 - 1) / math.sqrt(fan_in)).requires_grad_(True)
-        sd[prefix + '.weight_u'] = F.normalize(torch.randn(shape[0], generator=g), dim=0)
-        sd[prefix + '.weight_v'] = F.normalize(torch.randn(fan_in, generator=g), dim=0)
-        if bias:
-            sd[prefix + '.bias'] = torch.zeros(shape[0], requires_grad=True)
-    for i, (cin, cout, up) in enumerate(blocks):
-        i1, i2 = (4, 8) if up else (3, 7)
-        sn(f'decoder_blocks.{i}.block.{i1}', (cout, cin, 3, 3), False)
-        sn(f'decoder_blocks.{i}.block.{i2}', (cout, cout, 3, 3), False)
-        if up:
-            sn(f'decoder_blocks.{i}.skip.1', (cout, cin, 1, 1), True)
-    nb = len(blocks)
-    sn(f'decoder_blocks.{nb + 2}', (4, blocks[-1][1], 3, 3), True)
-    naff = sum(2 * (a + b) for a, b, _ in blocks) + 2 * blocks[-1][1]
-    sn('affine_params_projector.0', (768, 768), True)
-    sn('affine_params_projector.2', (naff, 768), True)
-    sd['constant.constant'] = torch.randn(1, blocks[0][0], 4, 4, generator=g).requires_grad_(True)
-    e = torch.randn(1, 512, generator=g)
-    p = torch.randn(sample_batch, 256, generator=g)
+    def as_sd(module):
+        sd = {k: v.detach().clone() for k, v in module.state_dict().items()}
+        params = [k for k, _ in module.named_parameters()]
+        for k in params:
+            sd[k].requires_grad_(True)
+        return sd, params
+    sdG, pG = as_sd(G)
+    sdD, pD = as_sd(D)
+    ema = {k: sdG[k].detach().clone() for k in pG}
+    mom = {id(sd): {k: (torch.zeros_like(sd[k]), torch.zeros_like(sd[k])) for k in ps} for sd, ps in ((sdG, pG), (sdD, pD))}
+    data, target = zip(*[make_sample(i, a.image_size, 1, a.num_labels, True, 7) for i in range(sample_batch)])
+    pose_in = torch.stack([d['pose_input_rgbs'][0] for d in data])
+    tgt = torch.stack([d['target_rgbs'][0] for d in data])
+    real_segm = torch.stack([t['real_segm'] for t in target])
+    label = torch.zeros(sample_batch, dtype=torch.long)
+    step_no = [0]
 
     def one():
-        rgb, segm = O.generator_forward(sd, e, p, num_channels=64, max_num_channels=512, image_size=args.image_size, train=True)
-        (rgb.mean() + segm.mean()).backward()
+        step_no[0] += 1
+        with torch.no_grad():
+            pose = pose_net(pose_in)
+        rgb, segm = O.generator_forward(sdG, sdG['identity_embedding'], pose, num_channels=64, max_num_channels=512,
+                                        image_size=a.image_size, train=True)
+        out = O.discriminator_forward(sdD, rgb, tgt, label, image_size=a.image_size, dis_num_blocks=7, train=True,
+                                      embed_eps=O.SN_EPS_DEFAULT)
+        lg, ld = O.adversarial_gan(out['fake_score_G'], out['fake_score_D'], out['real_score'])
+        loss_G = lg + O.feature_matching(out['fake_features'], out['real_features']) \
+            + O.perceptual_loss(vggf, O.crop_and_resize_fixed(rgb), O.crop_and_resize_fixed(tgt), a.idt_embed_weight, O.VGG16_CFG) \
+            + O.perceptual_loss(vgg19, rgb, tgt, a.perc_weight, O.VGG19_CFG) + O.dice(segm, real_segm)
+        gG = torch.autograd.grad(loss_G, [sdG[k] for k in pG], retain_graph=True, allow_unused=True)
+        with torch.no_grad():
+            for k, g in zip(pG, gG):
+                if g is not None:
+                    O.radam_step(sdG[k], g, *mom[id(sdG)][k], step_no[0], a.lr_gen, 0.0, 0.999, 1e-5)
+        gD = torch.autograd.grad(ld, [sdD[k] for k in pD], allow_unused=True)
+        with torch.no_grad():
+            for k, g in zip(pD, gD):
+                if g is not None:
+                    O.radam_step(sdD[k], g, *mom[id(sdD)][k], step_no[0], a.lr_dis, 0.0, 0.999, 1e-5)
+            for k in pG:
+                O.ema_update(ema[k], sdG[k], 0.972)
     one()                                   # warm-up (oneDNN primitive creation)
     t0 = time.time()
     reps = 0
-    while reps < 3 and time.time() - t0 < 20.0:
+    while reps < 5 and time.time() - t0 < 20.0:
         one()
         reps += 1
     dt = (time.time() - t0) / reps
-    return {'value': sample_batch / dt, 'unit': 'generator fwd+bwd images/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{reps} x generator forward+backward of {sample_batch} image(s) at {args.image_size}x{args.image_size} '
-                      f'(oracle/lp_oracle.py, torch CPU fp32, {cores} threads); {dt:.2f} s each'}
+    return {'value': round(sample_batch / dt, 4), 'unit': 'images/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{reps} fine-tuning step(s) of {sample_batch} image(s) at {a.image_size}x{a.image_size} through '
+                      f'oracle/lp_oracle.py (torch CPU fp32, {cores} threads); {dt:.2f} s per step'}
 
 
 def main():
@@ -233,7 +259,8 @@ def main():
             'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16x3 (hi+lo split bf16 MFMA operands, fp32 accumulate)' if a.prec == 'bf16x3' else 'bf16 (MFMA operands, fp32 accumulate)',
             'data': 'synthetic VoxCeleb2-shaped batch, random-init weights (VGG weights seeded He-normal)',
-            'config': {'workload': 'finetuning-base.yaml step (configs[1]): G on HIP kernels; E(pose)/D/VGG on torch-ROCm'
+            'config': {'workload': 'finetuning-base.yaml step (configs[1]): G, D, VGG19/VGGFace criterions, RAdam, EMA, spectral norm on '
+                                   'hand-written gfx950 kernels; MobileNetV2 pose encoder on torch-ROCm'
                        if a.workload == 'finetune_step' else 'generator forward+backward only (HIP kernels)',
                        'image_size': a.image_size, 'per_gpu_batch': a.batch, 'global_batch': a.batch * world,
                        'parallelism': f'dp{world}', 'precision_mode': a.prec,
