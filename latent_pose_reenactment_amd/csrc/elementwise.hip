@@ -543,8 +543,17 @@ __global__ void mt_ema_kernel(const MtDesc* __restrict__ table, float alpha, int
     const MtDesc d = table[blockIdx.y];
     const long long stride = (long long)gridDim.x * blockDim.x;
     const float om = 1.f - alpha;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < d.n; i += stride)
-        d.p[i] = copy_only ? d.g[i] : d.p[i] * alpha + d.g[i] * om;
+    float* avg = d.p;
+    const float* cur = d.g;          // NOT __restrict__: may alias avg (see below)
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < d.n; i += stride) {
+        if (copy_only) { avg[i] = cur[i]; continue; }
+        // Two in-place steps exactly like runners/holycow.py:104-106 (`p_avg *= alpha; p_avg += p * (1 - alpha)`).  This matters:
+        // in fine-tuning the reference hands the SAME tensor to generator.enable_finetuning and to the EMA generator
+        // (train.py:263-272), so both identity_embedding Parameters alias one storage and every iteration multiplies it by
+        // alpha + (1 - alpha) * alpha.  Re-reading cur[i] after the store reproduces that.
+        avg[i] = avg[i] * alpha;
+        avg[i] = avg[i] + cur[i] * om;
+    }
 }
 
 extern "C" int lp_mt_desc_bytes(void) { return (int)sizeof(MtDesc); }
