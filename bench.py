@@ -151,6 +151,53 @@ def cpu_baseline(args, sample_batch=1):
                       f'oracle/lp_oracle.py (torch CPU fp32, {cores} threads); {dt:.2f} s per step'}
 
 
+def drive_fps(args, frames=60):
+    """drive.py hot loop (drive.py:84-88): per frame pose encoder + generator, B = 1, eval mode, replayed as one hipGraph."""
+    from generators.vector_pose_unsupervised_segmentation_noBottleneck import Wrapper as GW
+    from embedders.unsupervised_pose_separate_embResNeXt_segmentation import Wrapper as EW
+    torch.manual_seed(5)
+    G, E = GW.get_net(args), EW.get_net(args)
+    G.enable_finetuning({'embeds': torch.randn(1, args.embed_channels, device=args.device) * 0.1})
+    E.enable_finetuning()
+    G.eval(); E.eval()
+    frame = torch.rand(1, 1, 3, args.image_size, args.image_size, device=args.device)
+    out = {}
+
+    def one():
+        d = {'pose_input_rgbs': frame}
+        E.get_pose_embedding(d)
+        G(d)
+        out['rgb'] = d['fake_rgbs']
+    with torch.no_grad():
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                one()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        step = one
+        mode = 'eager'
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                one()
+            step, mode = g.replay, 'hipgraph'
+        except Exception as ex:
+            print(f'[bench] drive graph capture failed ({ex!r}); eager', file=sys.stderr)
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    return {'value': round(frames / dt, 2), 'unit': 'frames/s', 'ms_per_frame': round(dt / frames * 1e3, 3), 'batch': 1,
+            'launch_mode': mode, 'note': 'drive.py:84-88 loop (MobileNetV2 pose encoder on torch-ROCm + HIP generator, eval mode, '
+                                          'bf16 weight packs cached), frames resident in HBM'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -268,6 +315,11 @@ def main():
             'roofline': roof,
         }
         out.update(extra)
+        if world == 1:
+            try:
+                out['drive'] = drive_fps(args)
+            except Exception as ex:
+                out['drive'] = {'error': repr(ex)}
         if world == 1 and not a.no_cpu_baseline:
             try:
                 out['cpu_baseline'] = cpu_baseline(args)

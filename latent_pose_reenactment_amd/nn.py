@@ -221,6 +221,10 @@ class _DecoderFunction(torch.autograd.Function):
         blocks, prec = cfg['blocks'], cfg['prec']
         need_grad = cfg['need_grad']
         sn = cfg['sn']                    # per entry of `weights`: (u_used, v_used, [sigma, 1/sigma]) for conv weights, None for biases
+        packs = cfg.get('packs')          # inference: forward packs of the (unchanged) weights, cached by the module
+
+        def fpack(i, w):
+            return packs[i] if packs is not None else ops.pack_weights(w.detach().contiguous(), 0, prec)
         B = affine.shape[0]
         affine = affine.contiguous()
         wl = list(weights)
@@ -243,19 +247,19 @@ class _DecoderFunction(torch.autograd.Function):
             g0, b0, o0 = aff(cin)
             g1, b1, o1 = aff(cout)
             st0 = ops.instnorm_stats(x, g0, b0, ADAIN_EPS)
-            p1 = ops.pack_weights(w1.detach().contiguous(), 0, prec)
+            p1 = fpack(wi - 2, w1)
             h1 = ops.conv(x, p1, ksize=3, upsample=up, pro=1, scale=st0[2], shift=st0[3], alpha=sn[wi - 2][2][1:], prec=prec)
             st1 = ops.instnorm_stats(h1, g1, b1, ADAIN_EPS)
             if has_skip:
                 ws, bs = wl[wi], wl[wi + 1]
                 wi += 2
-                ps = ops.pack_weights(ws.detach().contiguous(), 0, prec)
+                ps = fpack(wi - 2, ws)
                 s = ops.conv(x, ps, ksize=1, bias=bs.detach().contiguous(), alpha=sn[wi - 2][2][1:], prec=prec)   # 1x1 commutes with nearest upsampling
                 rs = 1 if up else 0
             else:
                 s, rs = x, 0
-            p2 = ops.pack_weights(w2.detach().contiguous(), 0, prec)
             i2 = wi - (3 if has_skip else 1)
+            p2 = fpack(i2, w2)
             out = ops.conv(h1, p2, ksize=3, pro=1, scale=st1[2], shift=st1[3], res=s, res_shift=rs, alpha=sn[i2][2][1:], prec=prec)
             if need_grad:
                 saved.append((x, h1, st0, st1, o0, o1))
@@ -264,7 +268,7 @@ class _DecoderFunction(torch.autograd.Function):
         gh, bh, oh = aff(ch)
         sth = ops.instnorm_stats(x, gh, bh, ADAIN_EPS)
         wh, bhd = wl[wi], wl[wi + 1]
-        ph = ops.pack_weights(wh.detach().contiguous(), 0, prec)
+        ph = fpack(wi, wh)
         z = ops.conv(x, ph, ksize=3, pro=1, scale=sth[2], shift=sth[3], bias=bhd.detach().contiguous(), alpha=sn[wi][2][1:], prec=prec)
         t, rgbs, segm = ops.head_fwd(z, want_t=need_grad)
         if need_grad:
@@ -445,7 +449,17 @@ class Generator(nn.Module):
         weights += [head.weight_orig, head.bias]
         sn += [states[k], None]
         need_grad = torch.is_grad_enabled() and (affine.requires_grad or any(w.requires_grad for w in weights))
-        cfg = dict(blocks=self.blocks_cfg, prec=self.prec, need_grad=need_grad, sn=sn, debug=getattr(self, '_debug', None))
+        packs = None
+        if not need_grad and not self.training:
+            # inference (drive.py): the weights do not change between frames -> pack them to bf16 once
+            key = (self.prec,) + tuple((w.data_ptr(), w._version) for w in weights)
+            cache = self.__dict__.get('_pack_cache')
+            if cache is None or cache[0] != key:
+                cache = (key, [ops.pack_weights(w.detach().contiguous(), 0, self.prec) if s_ is not None else None
+                               for w, s_ in zip(weights, sn)])
+                self.__dict__['_pack_cache'] = cache
+            packs = cache[1]
+        cfg = dict(blocks=self.blocks_cfg, prec=self.prec, need_grad=need_grad, sn=sn, packs=packs, debug=getattr(self, '_debug', None))
         rgbs, segm = _DecoderFunction.apply(cfg, affine, self.constant.constant, *weights)
         data_dict['fake_rgbs'] = rgbs
         data_dict['fake_segm'] = segm
