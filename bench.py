@@ -209,6 +209,7 @@ def main():
     ap.add_argument('--workload', default='finetune_step', choices=['finetune_step', 'generator'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eager', action='store_true', help='do not capture the step into hipGraphs')
+    ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only for functional tests)')
     a = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -216,11 +217,12 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback for the HIP path)')
-    torch.cuda.set_device(local_rank)
-    device = f'cuda:{local_rank}'
+    dev_index = local_rank % torch.cuda.device_count()      # (modulo only matters for single-GPU functional tests of the N > 1 path)
+    torch.cuda.set_device(dev_index)
+    device = f'cuda:{dev_index}'
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='nccl', init_method='env://')
+        dist.init_process_group(backend=a.backend, init_method='env://')
     assert world == a.gpus, f'--gpus {a.gpus} but WORLD_SIZE={world}'
 
     args = make_args(a.image_size, a.batch, device, world, rank, a.prec)

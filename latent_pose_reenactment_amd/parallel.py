@@ -27,11 +27,7 @@ class _Bucket:
         n = sum(p.grad.numel() for p in self.live)
         if self.flat is None or self.flat.numel() != n or self.flat.device != self.live[0].grad.device:
             self.flat = torch.empty(n, dtype=torch.float32, device=self.live[0].grad.device)
-        off = 0
-        for p in self.live:
-            k = p.grad.numel()
-            self.flat[off:off + k].copy_(p.grad.reshape(-1))
-            off += k
+        torch.cat([p.grad.reshape(-1) for p in self.live], out=self.flat)      # one gather kernel instead of one copy per tensor
         self.handle = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
         if not async_op:
             self.finish(world_size)
@@ -43,11 +39,12 @@ class _Bucket:
             self.handle.wait()
             self.handle = None
         self.flat.div_(world_size)
-        off = 0
+        views, off = [], 0
         for p in self.live:
             k = p.grad.numel()
-            p.grad.copy_(self.flat[off:off + k].view_as(p.grad))
+            views.append(self.flat[off:off + k].view_as(p.grad))
             off += k
+        torch._foreach_copy_([p.grad for p in self.live], views)              # one multi-tensor scatter
         self.live = []
 
 
