@@ -272,6 +272,47 @@ __global__ __launch_bounds__(256, (CC == 32 && PREC == LP_PREC_BF16 && NBUF == 2
 
     // epilogue: C layout of mfma 16x16: col = lane&15 (channel), row = (lane>>4)*4 + reg (tile row)
     const float alpha = p.alpha ? *p.alpha : 1.f;
+    if (p.ksplit == 1 && (p.Cout & 3) == 0) {
+        // Coalesced path: every wave transposes its (MR*16) x (NR*16) accumulator block through LDS (the staging buffers are
+        // dead now) and writes whole pixel rows -- NR*64 contiguous bytes per pixel, 16 B per lane -- instead of 64-B
+        // fragments; bias and the residual are read the same way.
+        constexpr int WR = MR * 16, WC = NR * 16, LDW = WC + 4;          // +4 floats: rows land on different banks
+        __syncthreads();                                                  // all waves are done with the halo / weight buffers
+        float* tile = (float*)smem + wave * (WR * LDW);
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    tile[(mr * 16 + (lane >> 4) * 4 + r) * LDW + nr * 16 + (lane & 15)] = acc[mr][nr][r];
+        // (a wave only reads back what it wrote itself: no workgroup barrier needed, just the LDS write->read order)
+        constexpr int C4 = WC / 4;                 // float4 columns per row
+        constexpr int RPP = 64 / C4;               // rows per pass of the wave
+        const int c4 = lane % C4, rsub = lane / C4;
+        const int co = co0 + wn * WC + c4 * 4;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias && co < p.Cout) bv = *(const float4*)(p.bias + co);
+#pragma unroll 4
+        for (int r0 = 0; r0 < WR; r0 += RPP) {
+            const int row = r0 + rsub;             // row inside the wave block
+            const int m = wm * WR + row;
+            int nb, py, px;
+            tile_row_decode(m, p.lTH, p.lTW, nb, py, px);
+            const int n = n0 + nb, oyy = y0 + py, oxx = x0 + px;
+            if (n < p.N && oyy < p.H && oxx < p.W && co < p.Cout) {
+                float4 v = *(const float4*)(tile + row * LDW + c4 * 4);
+                v.x = fmaf(v.x, alpha, bv.x); v.y = fmaf(v.y, alpha, bv.y); v.z = fmaf(v.z, alpha, bv.z); v.w = fmaf(v.w, alpha, bv.w);
+                if (p.res) {
+                    const float4 rv = *(const float4*)(p.res + ((size_t)(n * (p.H >> p.res_shift) + (oyy >> p.res_shift)) * (p.W >> p.res_shift)
+                                                                + (oxx >> p.res_shift)) * p.Cout + co);
+                    v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                }
+                *(float4*)(p.y + ((size_t)(n * p.H + oyy) * p.W + oxx) * p.Cout + co) = v;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr) {
         int m0 = wm * (MR * 16) + mr * 16 + (lane >> 4) * 4;
@@ -352,7 +393,9 @@ static int launch_conv(ConvParams& p, hipStream_t stream) {
     static const int want_nbuf = getenv("LP_CONV_NBUF") ? atoi(getenv("LP_CONV_NBUF")) : 2;       // tuning knob: 2 | 3
     constexpr bool ring3_ok = (CC == 32) && (KS == 3) && (BN >= 64) && !SPLIT;
     const bool ring3 = ring3_ok && fast && want_nbuf == 3 && (2 * a_buf + 3 * B_BUF <= LDS_MAX);
-    const size_t lds = a_buf * (fast ? 2 : 1) + (ring3 ? 3 : 2) * B_BUF;
+    size_t lds = a_buf * (fast ? 2 : 1) + (ring3 ? 3 : 2) * B_BUF;
+    const size_t epi = (size_t)4 * (MR * 16) * (NR * 16 + 4) * sizeof(float);       // LDS transpose of the coalesced epilogue
+    if (lds < epi) lds = epi;
     if (lds > LDS_MAX) return lp_set_error(LP_ERR_UNSUPPORTED, "conv tile needs too much LDS");
     dim3 grid(p.tiles_x * p.tiles_y * ((p.N + NBv - 1) / NBv), (p.Cout + BN - 1) / BN);
     {   // split-K when the output tiling alone cannot fill the 256 CUs (4x4 ... 32x32 layers with K = 9*512)
