@@ -229,7 +229,7 @@ def main():
     tm, opt_G, opt_D, holycow = build(args)
     if world > 1:
         from latent_pose_reenactment_amd.parallel import GradReducer
-        tm.reducer = GradReducer(tm, finetune=True)
+        tm.reducer = GradReducer(tm, finetune=True, optimizer_G=opt_G, optimizer_D=opt_D)
     data, target = synthetic_batch(args, a.batch, seed=123 + rank)
 
     from latent_pose_reenactment_amd import hipops

@@ -37,17 +37,40 @@ class _FusedBase(Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._tables = {}
 
+    def ensure_flat(self, gi=0):
+        """Gradient arena: all gradients of a parameter group are views into ONE flat fp32 buffer (created once).  zero_grad is a
+        single memset, the fused step addresses the views by pointer, and the data-parallel all-reduce (parallel.GradReducer)
+        runs directly on the arena without gather/scatter copies."""
+        flats = self.__dict__.setdefault('_flat', {})
+        group = self.param_groups[gi]
+        params = [p for p in group['params'] if p.requires_grad]
+        key = tuple(p.data_ptr() for p in params)
+        cur = flats.get(gi)
+        if cur is None or cur[0] != key or any(p.grad is None or p.grad.data_ptr() != v.data_ptr() for p, v in zip(params, cur[2])):
+            total = sum(p.numel() for p in params)
+            flat = torch.zeros(total, dtype=torch.float32, device=params[0].device)
+            views, off = [], 0
+            for p in params:
+                v = flat[off:off + p.numel()].view_as(p)
+                if p.grad is not None:
+                    v.copy_(p.grad)
+                p.grad = v
+                views.append(v)
+                off += p.numel()
+            cur = (key, flat, views)
+            flats[gi] = cur
+        return cur[1]
+
     def _prepare(self, gi, group):
         params = [p for p in group['params'] if p.requires_grad]
         dev = params[0].device
+        self.ensure_flat(gi)
         for p in params:
             st = self.state[p]
             if 'exp_avg' not in st:
                 st['exp_avg'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 st['step'] = 0
-            if p.grad is None:      # persistent gradient buffers: the table holds raw pointers
-                p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
         key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in params)
         cached = self._tables.get(gi)
         if cached is None or cached[0] != key:
@@ -59,12 +82,10 @@ class _FusedBase(Optimizer):
         return cached
 
     def zero_grad(self, set_to_none: bool = False):
-        """gradients are zeroed IN PLACE (never released): the fused kernel addresses them by raw pointer"""
-        for group in self.param_groups:
-            for p in group['params']:
-                if p.grad is not None:
-                    p.grad.detach_()
-                    p.grad.zero_()
+        """gradients are zeroed IN PLACE (never released): the fused kernel addresses them by raw pointer -- one memset per group"""
+        for gi, group in enumerate(self.param_groups):
+            if any(p.requires_grad for p in group['params']):
+                self.ensure_flat(gi).zero_()
 
     @torch.no_grad()
     def step(self, closure=None):

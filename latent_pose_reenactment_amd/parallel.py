@@ -14,13 +14,22 @@ import torch.distributed as dist
 
 
 class _Bucket:
-    def __init__(self, params: Iterable[torch.nn.Parameter]):
+    def __init__(self, params: Iterable[torch.nn.Parameter], optimizer=None):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.flat: Optional[torch.Tensor] = None
         self.handle = None
         self.live: List[torch.nn.Parameter] = []
+        self.optimizer = optimizer if hasattr(optimizer, 'ensure_flat') else None
+        self.arena = None
 
     def start(self, world_size: int, async_op: bool):
+        if self.optimizer is not None and len(self.optimizer.param_groups) == 1:
+            # fused optimizers keep every gradient in one flat arena: reduce it in place, no gather/scatter
+            self.arena = self.optimizer.ensure_flat(0)
+            self.handle = dist.all_reduce(self.arena, op=dist.ReduceOp.SUM, async_op=async_op)
+            if not async_op:
+                self.finish(world_size)
+            return
         self.live = [p for p in self.params if p.grad is not None]
         if not self.live:
             return
@@ -33,6 +42,13 @@ class _Bucket:
             self.finish(world_size)
 
     def finish(self, world_size: int):
+        if self.arena is not None:
+            if self.handle is not None and hasattr(self.handle, 'wait'):
+                self.handle.wait()
+            self.handle = None
+            self.arena.div_(world_size)
+            self.arena = None
+            return
         if not self.live:
             return
         if self.handle is not None:
@@ -49,13 +65,14 @@ class _Bucket:
 
 
 class GradReducer:
-    def __init__(self, training_module, finetune: bool = False, broadcast: bool = True):
+    def __init__(self, training_module, finetune: bool = False, broadcast: bool = True, optimizer_G=None, optimizer_D=None):
+        """``optimizer_G/_D`` (optional): the fused optimizers; their flat gradient arenas are then all-reduced in place."""
         self.world_size = dist.get_world_size()
         g_side = list(training_module.generator.parameters())
         if not finetune:
             g_side += list(training_module.embedder.parameters())
-        self.g_bucket = _Bucket(g_side)
-        self.d_bucket = _Bucket(training_module.discriminator.parameters())
+        self.g_bucket = _Bucket(g_side, optimizer_G)
+        self.d_bucket = _Bucket(training_module.discriminator.parameters(), optimizer_D)
         if broadcast:        # apex Reducer broadcasts rank 0's parameters at construction
             with torch.no_grad():
                 for t in training_module.parameters():      # parameters only, like apex (buffers/EMA stay rank-local)

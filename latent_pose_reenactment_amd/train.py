@@ -134,7 +134,7 @@ def main():
 
     if 1 < args.num_gpus <= 8:
         from latent_pose_reenactment_amd.parallel import GradReducer
-        training_module.reducer = GradReducer(training_module, finetune=args.finetune)
+        training_module.reducer = GradReducer(training_module, finetune=args.finetune)      # (re-created below when the optimizers change)
         training_module.__dict__['module'] = training_module
 
     if args.finetune:

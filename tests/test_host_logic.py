@@ -104,6 +104,21 @@ ok = all(torch.allclose(p.grad, torch.full_like(p, 1.5)) for p in list(tm.genera
 ok &= all(torch.allclose(p.grad, torch.full_like(p, float(rank + 1))) for p in tm.discriminator.parameters())   # untouched so far
 red.reduce_discriminator_side()
 ok &= all(torch.allclose(p.grad, torch.full_like(p, 1.5)) for p in tm.discriminator.parameters())
+# arena path: a (stand-in) fused optimizer owning one flat gradient buffer per side is reduced in place
+class Arena:
+    def __init__(s, params):
+        s.params = list(params); s.param_groups = [{'params': s.params}]
+        s.flat = torch.zeros(sum(p.numel() for p in s.params)); off = 0
+        for p in s.params:
+            p.grad = s.flat[off:off + p.numel()].view_as(p); off += p.numel()
+    def ensure_flat(s, gi=0):
+        return s.flat
+oG, oD = Arena(list(tm.generator.parameters()) + list(tm.embedder.parameters())), Arena(tm.discriminator.parameters())
+red2 = GradReducer(tm, finetune=False, broadcast=False, optimizer_G=oG, optimizer_D=oD)
+oG.flat.fill_(float(rank + 1)); oD.flat.fill_(float(10 * (rank + 1)))
+red2.reduce_generator_side(async_op=True); red2.wait_generator_side(); red2.reduce_discriminator_side()
+ok &= bool(torch.allclose(oG.flat, torch.full_like(oG.flat, 1.5))) and bool(torch.allclose(oD.flat, torch.full_like(oD.flat, 15.0)))
+ok &= all(torch.allclose(p.grad, torch.full_like(p, 1.5)) for p in tm.generator.parameters())
 w = [p.detach().clone() for p in tm.parameters()]
 gathered = [None, None]; dist.all_gather_object(gathered, [t.tolist() for t in w])
 ok &= gathered[0] == gathered[1]                            # parameters identical after the broadcast
