@@ -57,6 +57,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
 
     // source-lane role for the transposing reads
     const int G = lane >> 4, sj = (lane & 15) >> 2, sq = lane & 3;
+    // fast staging (one image per tile, channel counts multiple of 8): 8 channel groups x 32 pixels per pass of the block
+    constexpr int AIT = (10 * 18 + 31) / 32;                 // 8x16 patch + border = 180 halo pixels -> 6 items per thread
+    const int halo_px = NBv * HH * HW;
+    // measured: pays only where the kernel is LDS-limited to one workgroup per CU anyway (bf16x3, full-size halo); the bf16 kernel
+    // keeps its small register footprint (2-3 workgroups per CU hide the staging latency instead)
+    const bool fast = SPLIT && !UPS && (NBv == 1) && ((p.Cin & 7) == 0) && ((p.Cout & 7) == 0) && (halo_px <= AIT * 32);
+    const int a_cg = tid & 7, a_hp0 = tid >> 3;
 
     for (int tile = blockIdx.x; tile < p.num_tiles; tile += p.splits) {
         int t = tile;
@@ -67,6 +74,74 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
         if (KS == 1) { oy = y0; ox = x0; } else if (UPS) { oy = (y0 >> 1) - 1; ox = (x0 >> 1) - 1; } else { oy = y0 - 1; ox = x0 - 1; }
 
         __syncthreads();                 // previous tile fully consumed
+        if (SPLIT && !UPS && fast) {
+            // all global loads of the tile (activation halo + dY) are issued back to back and unconditionally (out-of-image
+            // items read pixel 0 and are zeroed afterwards), then transformed and written: one exposed memory latency per tile
+            float4 ald[AIT][2], dld[4][2];
+            int apix[AIT];
+            const int cA = ci0 + a_cg * 8;
+            const bool cokA = cA < p.Cin;
+#pragma unroll
+            for (int k = 0; k < AIT; ++k) {
+                const int hp = a_hp0 + k * 32;
+                const int hx = hp % HW, hy = hp / HW;
+                const int iy = oy + hy, ix = ox + hx;
+                const bool inb = (hp < halo_px) && (n0 < p.N) && (iy >= 0) && (iy < p.Hin) && (ix >= 0) && (ix < p.Win);
+                apix[k] = inb ? ((n0 * p.Hin + iy) * p.Win + ix) : (hp < halo_px ? -1 : -2);
+                const float* src = p.x + (size_t)(apix[k] >= 0 ? apix[k] : 0) * p.Cin + (cokA ? cA : 0);
+                ald[k][0] = *(const float4*)src; ald[k][1] = *(const float4*)(src + 4);
+            }
+            int dpix[4];
+            const int cD = co0 + a_cg * 8;
+            const bool cokD = cD < p.Cout;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int kp = a_hp0 + k * 32;                       // 128 pixels x 8 channel groups = 1024 items = 4 per thread
+                int nb, py, px;
+                tile_lin_decode(kp, p.lTH, p.lTW, nb, py, px);
+                const int n = n0 + nb, yy = y0 + py, xx = x0 + px;
+                dpix[k] = (n < p.N && yy < p.H && xx < p.W) ? ((n * p.H + yy) * p.W + xx) : -1;
+                const float* src = p.dy + (size_t)(dpix[k] >= 0 ? dpix[k] : 0) * p.Cout + (cokD ? cD : 0);
+                dld[k][0] = *(const float4*)src; dld[k][1] = *(const float4*)(src + 4);
+            }
+            float4 s0 = make_float4(1.f, 1.f, 1.f, 1.f), s1 = s0, t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0;
+            if (p.pro == 1) {
+                const float* sp = p.scale + (size_t)(n0 < p.N ? n0 : 0) * p.Cin + (cokA ? cA : 0);
+                const float* tp = p.shift + (size_t)(n0 < p.N ? n0 : 0) * p.Cin + (cokA ? cA : 0);
+                s0 = *(const float4*)sp; s1 = *(const float4*)(sp + 4); t0 = *(const float4*)tp; t1 = *(const float4*)(tp + 4);
+            }
+            const float lo_clamp = (p.pro != 0) ? 0.f : -3.0e38f;
+#pragma unroll
+            for (int k = 0; k < AIT; ++k) {
+                float v[8] = {ald[k][0].x, ald[k][0].y, ald[k][0].z, ald[k][0].w, ald[k][1].x, ald[k][1].y, ald[k][1].z, ald[k][1].w};
+                v[0] = fmaxf(fmaf(v[0], s0.x, t0.x), lo_clamp); v[1] = fmaxf(fmaf(v[1], s0.y, t0.y), lo_clamp);
+                v[2] = fmaxf(fmaf(v[2], s0.z, t0.z), lo_clamp); v[3] = fmaxf(fmaf(v[3], s0.w, t0.w), lo_clamp);
+                v[4] = fmaxf(fmaf(v[4], s1.x, t1.x), lo_clamp); v[5] = fmaxf(fmaf(v[5], s1.y, t1.y), lo_clamp);
+                v[6] = fmaxf(fmaf(v[6], s1.z, t1.z), lo_clamp); v[7] = fmaxf(fmaf(v[7], s1.w, t1.w), lo_clamp);
+                const bool keep = (apix[k] >= 0) && cokA;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = keep ? v[j] : 0.f;
+                s16x8_t hi, lo;
+                cvt8<SPLIT>(v, hi, lo);
+                const int off = (a_hp0 + k * 32) * SA + a_cg * 16;
+                if (apix[k] != -2) {
+                    *(s16x8_t*)(A_hi + off) = hi;
+                    if (SPLIT) *(s16x8_t*)(A_lo + off) = lo;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float v[8] = {dld[k][0].x, dld[k][0].y, dld[k][0].z, dld[k][0].w, dld[k][1].x, dld[k][1].y, dld[k][1].z, dld[k][1].w};
+                const bool keep = (dpix[k] >= 0) && cokD;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = keep ? v[j] : 0.f;
+                s16x8_t hi, lo;
+                cvt8<SPLIT>(v, hi, lo);
+                const int off = (a_hp0 + k * 32) * SD + a_cg * 16;
+                *(s16x8_t*)(D_hi + off) = hi;
+                if (SPLIT) *(s16x8_t*)(D_lo + off) = lo;
+            }
+        } else {
         stage_act_halo<CC, SPLIT>(A_hi, A_lo, SA, p.x, p.scale, p.shift, p.pro, p.N, p.Hin, p.Win, p.Cin,
                                   n0, NBv, HH, HW, oy, ox, ci0, tid);
         // dy tile: [128 pixels (row-major in patch)][64 co] -> bf16
@@ -92,6 +167,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
             cvt8<SPLIT>(v, hi, lo);
             *(s16x8_t*)(D_hi + kp * SD + cg * 16) = hi;
             if (SPLIT) *(s16x8_t*)(D_lo + kp * SD + cg * 16) = lo;
+        }
         }
         __syncthreads();
 
