@@ -8,7 +8,7 @@ import torch  # noqa: F401  -- MUST precede CDLL: torch bundles its own libamdhi
 #                              to the same HIP runtime instance (otherwise launches fail with "no ROCm-capable device")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'liblp_hip.so')
+LIB_PATH = os.environ.get('LP_LIB_OVERRIDE') or os.path.join(_HERE, 'liblp_hip.so')      # override: ablation builds (probes/)
 
 PREC_BF16 = 0
 PREC_BF16X3 = 1

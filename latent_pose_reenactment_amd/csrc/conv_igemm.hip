@@ -15,12 +15,21 @@
 #include "lp_internal.h"
 #include <stdlib.h>
 
+#ifdef LP_DBG
+static unsigned long long* g_prof = nullptr;
+extern "C" void lp_dbg_set_prof(unsigned long long* ptr) { g_prof = ptr; }
+#endif
+
 struct ConvParams {
     const float* x; const uint16_t* w_hi; const uint16_t* w_lo; float* y;
     const float* scale; const float* shift; const float* bias; const float* res; const float* alpha;
     int N, H, W, Hin, Win, Cin, Cout, CinP, CoutP;
     int res_shift, pro;
     int lTH, lTW, lNB, tiles_x, tiles_y;
+#ifdef LP_DBG
+    unsigned long long* prof; // [6] cycle counters of block 0 / wave 0: sync, dma issue, halo load issue, mfma, halo write, total
+    int dbg;                  // ablation bitmask (LP_CONV_DBG): 1 skip halo restaging, 2 skip weight DMA, 4 skip MFMAs, 8 skip epilogue
+#endif
     int ksplit;               // split-K: gridDim.z workgroups share one output tile (fp32 atomic epilogue onto a zeroed y)
     int a_dbuf;               // activation halo double-buffered in LDS (1) or single-buffered with an extra barrier (0)
 };
@@ -237,23 +246,49 @@ __global__ __launch_bounds__(256, (CC == 32 && PREC == LP_PREC_BF16 && NBUF == 2
         // must have landed, so with NBUF == 3 one stage's worth of DMA instructions stays in flight across the barrier.
         const int S = nch * KS;
         int abuf = 0;
+#ifdef LP_DBG
+        unsigned long long pc[6] = {0, 0, 0, 0, 0, 0};
+        const unsigned long long tstart = __builtin_amdgcn_s_memtime();
+#define LP_T(var) __builtin_amdgcn_sched_barrier(0); const unsigned long long var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
+#endif
         if (NBUF == 3 && S > 1) issue_b(cbeg + (KS > 1 ? 0 : 1), KS > 1 ? 1 : 0, 1);
         for (int chunk = 0; chunk < nch; ++chunk) {
             const bool has_next = chunk + 1 < nch;
 #pragma unroll
             for (int ky = 0; ky < KS; ++ky) {
                 const int s = chunk * KS + ky;
+#ifdef LP_DBG
+                LP_T(q0)
+#endif
                 if (NBUF == 3) { if (s + 1 < S) lp_wait_vm<DMA_PER_WAVE>(); else lp_wait_vm0(); } else lp_wait_vm0();
                 __syncthreads();
                 const int bbuf = s % NBUF;
                 const int sp = s + NBUF - 1;                       // stage to prefetch now
+#ifdef LP_DBG
+                LP_T(q1)
+                if (sp < S && !(p.dbg & 2)) issue_b(cbeg + sp / KS, sp % KS, sp % NBUF);
+                LP_T(q2)
+                if (ky == KS - 1 && has_next && !(p.dbg & 1)) load_a(cbeg + chunk + 1);
+                LP_T(q3)
+                if (!(p.dbg & 4)) compute(ky, abuf, bbuf);
+                LP_T(q4)
+                if (ky == KS - 1 && has_next && !(p.dbg & 1)) write_a(cbeg + chunk + 1, abuf ^ 1);
+                LP_T(q5)
+                pc[0] += q1 - q0; pc[1] += q2 - q1; pc[2] += q3 - q2; pc[3] += q4 - q3; pc[4] += q5 - q4;
+#else
                 if (sp < S) issue_b(cbeg + sp / KS, sp % KS, sp % NBUF);
                 if (ky == KS - 1 && has_next) load_a(cbeg + chunk + 1);
                 compute(ky, abuf, bbuf);
                 if (ky == KS - 1 && has_next) write_a(cbeg + chunk + 1, abuf ^ 1);
+#endif
             }
             abuf ^= 1;
         }
+#ifdef LP_DBG
+        pc[5] = __builtin_amdgcn_s_memtime() - tstart;
+        if (p.prof && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0)
+            for (int i = 0; i < 6; ++i) p.prof[i] = pc[i];
+#endif
     } else {
         // generic path (several images per tile / odd channel counts): single halo buffer, synchronous staging
         for (int chunk = 0; chunk < nch; ++chunk) {
@@ -271,6 +306,9 @@ __global__ __launch_bounds__(256, (CC == 32 && PREC == LP_PREC_BF16 && NBUF == 2
     }
 
     // epilogue: C layout of mfma 16x16: col = lane&15 (channel), row = (lane>>4)*4 + reg (tile row)
+#ifdef LP_DBG
+    if (p.dbg & 8) return;
+#endif
     const float alpha = p.alpha ? *p.alpha : 1.f;
     if (p.ksplit == 1 && (p.Cout & 3) == 0) {
         // Coalesced path: every wave transposes its (MR*16) x (NR*16) accumulator block through LDS (the staging buffers are
@@ -455,6 +493,11 @@ extern "C" int lp_conv_fwd(const float* x, const uint16_t* w_hi, const uint16_t*
     p.x = x; p.w_hi = w_hi; p.w_lo = w_lo; p.y = y; p.scale = scale; p.shift = shift; p.bias = bias; p.res = res; p.alpha = alpha;
     p.N = N; p.H = H; p.W = W; p.Hin = upsample ? H / 2 : H; p.Win = upsample ? W / 2 : W;
     p.Cin = Cin; p.Cout = Cout; p.CinP = CinP; p.CoutP = CoutP; p.res_shift = res_shift; p.pro = pro;
+#ifdef LP_DBG
+    static const int dbgv = getenv("LP_CONV_DBG") ? atoi(getenv("LP_CONV_DBG")) : 0;
+    p.dbg = dbgv;
+    p.prof = g_prof;
+#endif
 
     hipStream_t s = (hipStream_t)stream;
     if (prec == LP_PREC_BF16) return dispatch_conv<LP_PREC_BF16>(p, ksize, upsample, s);

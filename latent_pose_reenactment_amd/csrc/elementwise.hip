@@ -563,7 +563,7 @@ extern "C" int lp_mt_optimizer_step(const void* table, int num_tensors, long lon
     if (!table || !step || num_tensors <= 0) return lp_set_error(LP_ERR_ARG, "lp_mt_optimizer_step: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(mt_step_inc_kernel, dim3(1), dim3(1), 0, st, step);
-    int bx = (int)((max_numel + 1023) / 1024); if (bx < 1) bx = 1; if (bx > 64) bx = 64;
+    int bx = (int)((max_numel + 2047) / 2048); if (bx < 1) bx = 1; if (bx > 1024) bx = 1024;     // large tensors need the whole chip
     dim3 grid(bx, num_tensors);
     if (kind == 0) hipLaunchKernelGGL(mt_radam_kernel, grid, dim3(256), 0, st, (const MtDesc*)table, step, lr, beta1, beta2, eps);
     else if (kind == 1) hipLaunchKernelGGL(mt_adam_kernel, grid, dim3(256), 0, st, (const MtDesc*)table, step, lr, beta1, beta2, eps);
@@ -573,7 +573,7 @@ extern "C" int lp_mt_optimizer_step(const void* table, int num_tensors, long lon
 
 extern "C" int lp_mt_ema(const void* table, int num_tensors, long long max_numel, float alpha, int copy_only, void* stream) {
     if (!table || num_tensors <= 0) return lp_set_error(LP_ERR_ARG, "lp_mt_ema: bad arguments");
-    int bx = (int)((max_numel + 1023) / 1024); if (bx < 1) bx = 1; if (bx > 64) bx = 64;
+    int bx = (int)((max_numel + 2047) / 2048); if (bx < 1) bx = 1; if (bx > 1024) bx = 1024;
     hipLaunchKernelGGL(mt_ema_kernel, dim3(bx, num_tensors), dim3(256), 0, (hipStream_t)stream, (const MtDesc*)table, alpha, copy_only);
     return lp_check_launch("mt_ema");
 }

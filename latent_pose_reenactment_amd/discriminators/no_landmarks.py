@@ -47,6 +47,13 @@ def _wb(layer, track, states):
     return w, b, states[id(layer)]
 
 
+def _conv(x, layer, track, states, **kw):
+    """SN conv through the HIP kernels; the bf16 packs of W_orig are shared by the three passes of a step and their backward
+    passes (only 1/sigma differs between passes) through the per-step cache ``states['packs']``"""
+    w, b, st = _wb(layer, track, states)
+    return hip_conv(x, w, b, sn=st, packs=states['packs'], **kw)
+
+
 class _DisBlock(nn.Module):
     """parameters of blocks.ResBlock(norm_layer='none'): block.2, block.5 (3x3 + bias) and optional skip.0 (1x1 + bias)"""
 
@@ -64,15 +71,9 @@ class _DisBlock(nn.Module):
     def forward(self, x_relu, track, states):
         """x_relu: NHWC relu(x) (the reference's in-place ReLU makes every consumer of the block input see relu(x))"""
         c1, c2 = self.block._modules['2'], self.block._modules['5']
-        w1, b1, s1 = _wb(c1, track, states)
-        h = hip_conv(x_relu, w1, b1, ksize=3, sn=s1)
-        if self.has_skip:
-            ws, bs, ss = _wb(self.skip._modules['0'], track, states)
-            shortcut = hip_conv(x_relu, ws, bs, ksize=1, sn=ss)
-        else:
-            shortcut = x_relu
-        w2, b2, s2 = _wb(c2, track, states)
-        out = hip_conv(h, w2, b2, res=shortcut, ksize=3, pro=2, sn=s2)
+        h = _conv(x_relu, c1, track, states, ksize=3)
+        shortcut = _conv(x_relu, self.skip._modules['0'], track, states, ksize=1) if self.has_skip else x_relu
+        out = _conv(h, c2, track, states, res=shortcut, ksize=3, pro=2)
         return AvgPool2Fn.apply(out, False) if self.downsample else out
 
 
@@ -120,13 +121,11 @@ class Discriminator(nn.Module):
             self.__dict__['_sn_batch'] = SNBatch(layers)
         st = self._sn_batch.update(self.training)
         states = {id(l): s for l, s in zip(layers, st)}
+        states['packs'] = self.__dict__.setdefault('_step_packs', {})
         xn = to_nhwc(x)
-        w0, b0, s0 = _wb(d0, track_weights, states)
-        h = hip_conv(xn, w0, b0, ksize=3, sn=s0)
-        wk, bk, sk_state = _wb(sk, track_weights, states)
-        shortcut = hip_conv(xn, wk, bk, ksize=1, sn=sk_state)
-        w2, b2, s2 = _wb(d2, track_weights, states)
-        out = AvgPool2Fn.apply(hip_conv(h, w2, b2, res=shortcut, ksize=3, pro=2, sn=s2), False)
+        h = _conv(xn, d0, track_weights, states, ksize=3)
+        shortcut = _conv(xn, sk, track_weights, states, ksize=1)
+        out = AvgPool2Fn.apply(_conv(h, d2, track_weights, states, res=shortcut, ksize=3, pro=2), False)
         feats = []
         for block in self.blocks:
             out_relu = torch.relu(out)           # what the reference's in-place ReLU leaves behind in its feature list
@@ -160,6 +159,7 @@ class Discriminator(nn.Module):
             fake = fake[:, 0]
         if real.dim() > 4:
             real = real[:, 0]
+        self.__dict__['_step_packs'] = {}       # new step: the optimizer has changed W_orig since the last forward
         embed = F.embedding(label, self.embed.effective_weight())
         # Pass 1 feeds only generator-side losses; the gradients it would deposit on the discriminator's parameters are erased
         # by optimizer_D.zero_grad() before loss_D.backward (runners/holycow.py:246-248) and no optimizer reads them, so they

@@ -488,7 +488,13 @@ class ConvFn(torch.autograd.Function):
         """``sn`` = (u_used, v_used, [sigma, 1/sigma]) from SNBatch when ``w`` is a spectrally normalised W_orig"""
         small_k = ksize == 3 and w.shape[1] <= 32
         wd = w.detach().contiguous()
-        pack = packs[0] if packs is not None else ops.pack_weights(wd, 0, prec, small_k=small_k)
+        if isinstance(packs, dict):          # per-step cache shared by several calls on the same W_orig (discriminator passes)
+            key = (wd.data_ptr(), 0)
+            if key not in packs:
+                packs[key] = ops.pack_weights(wd, 0, prec, small_k=small_k)
+            pack = packs[key]
+        else:
+            pack = packs[0] if packs is not None else ops.pack_weights(wd, 0, prec, small_k=small_k)
         y = ops.conv(x, pack, ksize=ksize, pro=pro, bias=None if bias is None else bias.detach().contiguous(), res=res,
                      alpha=None if sn is None else sn[2][1:], prec=prec)
         ctx.save_for_backward(x, wd)
@@ -502,7 +508,13 @@ class ConvFn(torch.autograd.Function):
         dy = dy.contiguous()
         dx = dw = db = dres = None
         if ctx.needs_input_grad[0]:
-            packT = packs[1] if packs is not None else ops.pack_weights(wd, 1, prec, small_k=(ksize == 3 and wd.shape[0] <= 32))
+            if isinstance(packs, dict):
+                key = (wd.data_ptr(), 1)
+                if key not in packs:
+                    packs[key] = ops.pack_weights(wd, 1, prec, small_k=(ksize == 3 and wd.shape[0] <= 32))
+                packT = packs[key]
+            else:
+                packT = packs[1] if packs is not None else ops.pack_weights(wd, 1, prec, small_k=(ksize == 3 and wd.shape[0] <= 32))
             dA = ops.conv(dy, packT, ksize=ksize, alpha=None if sn is None else sn[2][1:], prec=prec)
             dx = ops.relu_bwd(dA, x) if pro == 2 else dA
         if ctx.needs_input_grad[1]:
