@@ -108,12 +108,13 @@ int lp_mt_ema(const void* table, int num_tensors, long long max_numel, float alp
  * float* part; int rows; int cols; float eps; int pad;} (lp_sn_desc_bytes() each), one per layer; `part` = scratch of
  * ceil(rows/lp_sn_row_block())*cols + rows floats.  do_iter=1 (train): v <- normalize(W^T u), u <- normalize(W v) in place;
  * always: u_out/v_out = the vectors used, sig_out = {sigma = u^T W v, 1/sigma}.  Four launches, row-blocked over many workgroups.
- * lp_sn_grad_apply: g <- g/sigma - (<g, w_orig>/sigma^2) u v^T in place (autograd of W/sigma with u, v constant); dot = scratch. */
+ * lp_sn_grad_apply: g/sigma - (<g, w_orig>/sigma^2) u v^T (autograd of W/sigma with u, v constant), written in place on g, or
+ * added to `accum` when that is non-NULL (fused accumulation into the parameter's .grad; g is then left untouched); dot = scratch. */
 int lp_sn_desc_bytes(void);
 int lp_sn_row_block(void);
 int lp_sn_power_iter(const void* table, int num_layers, int do_iter, int max_rows, int max_cols, void* stream);
-int lp_sn_grad_apply(float* g, const float* w_orig, const float* u, const float* v, const float* sig, float* dot, int rows, int cols,
-                     void* stream);
+int lp_sn_grad_apply(float* g, const float* w_orig, const float* u, const float* v, const float* sig, float* dot, float* accum,
+                     int rows, int cols, void* stream);
 
 #ifdef __cplusplus
 }

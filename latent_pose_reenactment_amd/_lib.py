@@ -42,7 +42,7 @@ SIGNATURES = {
     'lp_sn_desc_bytes': (_i, []),
     'lp_sn_power_iter': (_i, [_vp, _i, _i, _i, _i, _vp]),
     'lp_sn_row_block': (_i, []),
-    'lp_sn_grad_apply': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    'lp_sn_grad_apply': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
 }
 
 _lib = None

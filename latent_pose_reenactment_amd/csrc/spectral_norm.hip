@@ -25,16 +25,44 @@ __device__ __forceinline__ float block_sum_256(float x, float* red) {
 }
 
 // phase 1: part[rb][c] = sum_{r in row block rb} W[r][c] * u[r]            grid (max_row_blocks, layers)
+// HBM-bound: each lane owns 4 consecutive columns (16-B loads) and keeps 4 rows in flight.
 __global__ __launch_bounds__(256) void sn_wtu_kernel(const SnDesc* __restrict__ table) {
     const SnDesc d = table[blockIdx.y];
     const int r0 = blockIdx.x * SN_RB;
     if (r0 >= d.rows) return;
     const int r1 = min(d.rows, r0 + SN_RB), C = d.cols;
+    __shared__ float us[SN_RB];
+    if (threadIdx.x < SN_RB) us[threadIdx.x] = (r0 + (int)threadIdx.x < r1) ? d.u[r0 + threadIdx.x] : 0.f;
+    __syncthreads();
+    if ((C & 3) == 0 && (((size_t)d.w | (size_t)d.part) & 15) == 0) {
+        const int C4 = C >> 2;
+        const float4* w4 = reinterpret_cast<const float4*>(d.w);
+        float4* out = reinterpret_cast<float4*>(d.part + (size_t)blockIdx.x * C);
+        for (int c = threadIdx.x; c < C4; c += 256) {
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+            int r = r0;
+            for (; r + 4 <= r1; r += 4) {
+                const float4 x0 = w4[(size_t)r * C4 + c], x1 = w4[(size_t)(r + 1) * C4 + c];
+                const float4 x2 = w4[(size_t)(r + 2) * C4 + c], x3 = w4[(size_t)(r + 3) * C4 + c];
+                const float u0 = us[r - r0], u1 = us[r - r0 + 1], u2 = us[r - r0 + 2], u3 = us[r - r0 + 3];
+                a.x = fmaf(x0.x, u0, a.x); a.y = fmaf(x0.y, u0, a.y); a.z = fmaf(x0.z, u0, a.z); a.w = fmaf(x0.w, u0, a.w);
+                b.x = fmaf(x1.x, u1, b.x); b.y = fmaf(x1.y, u1, b.y); b.z = fmaf(x1.z, u1, b.z); b.w = fmaf(x1.w, u1, b.w);
+                a.x = fmaf(x2.x, u2, a.x); a.y = fmaf(x2.y, u2, a.y); a.z = fmaf(x2.z, u2, a.z); a.w = fmaf(x2.w, u2, a.w);
+                b.x = fmaf(x3.x, u3, b.x); b.y = fmaf(x3.y, u3, b.y); b.z = fmaf(x3.z, u3, b.z); b.w = fmaf(x3.w, u3, b.w);
+            }
+            for (; r < r1; ++r) {
+                const float4 x0 = w4[(size_t)r * C4 + c]; const float u0 = us[r - r0];
+                a.x = fmaf(x0.x, u0, a.x); a.y = fmaf(x0.y, u0, a.y); a.z = fmaf(x0.z, u0, a.z); a.w = fmaf(x0.w, u0, a.w);
+            }
+            out[c] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+        }
+        return;
+    }
     for (int c = threadIdx.x; c < C; c += 256) {
         float a0 = 0.f, a1 = 0.f;
         int r = r0;
-        for (; r + 2 <= r1; r += 2) { a0 = fmaf(d.w[(size_t)r * C + c], d.u[r], a0); a1 = fmaf(d.w[(size_t)(r + 1) * C + c], d.u[r + 1], a1); }
-        if (r < r1) a0 = fmaf(d.w[(size_t)r * C + c], d.u[r], a0);
+        for (; r + 2 <= r1; r += 2) { a0 = fmaf(d.w[(size_t)r * C + c], us[r - r0], a0); a1 = fmaf(d.w[(size_t)(r + 1) * C + c], us[r - r0 + 1], a1); }
+        if (r < r1) a0 = fmaf(d.w[(size_t)r * C + c], us[r - r0], a0);
         d.part[(size_t)blockIdx.x * C + c] = a0 + a1;
     }
 }
@@ -55,7 +83,7 @@ __global__ __launch_bounds__(256) void sn_v_kernel(const SnDesc* __restrict__ ta
     for (int c = threadIdx.x; c < C; c += 256) { float t = d.v_out[c] * inv; d.v_out[c] = t; d.v[c] = t; }
 }
 
-// phase 3: s[r] = W[r] . v_out  for the rows of one block (one wave per row)                  grid (max_row_blocks, layers)
+// phase 3: s[r] = W[r] . v_out  for the rows of one block (one wave per row, 16-B loads, 4 in flight)   grid (max_row_blocks, layers)
 __global__ __launch_bounds__(256) void sn_wv_kernel(const SnDesc* __restrict__ table) {
     const SnDesc d = table[blockIdx.y];
     const int r0 = blockIdx.x * SN_RB;
@@ -63,10 +91,32 @@ __global__ __launch_bounds__(256) void sn_wv_kernel(const SnDesc* __restrict__ t
     const int r1 = min(d.rows, r0 + SN_RB), C = d.cols, nrb = (d.rows + SN_RB - 1) / SN_RB;
     float* s = d.part + (size_t)nrb * C;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool vec = (C & 3) == 0 && (((size_t)d.w | (size_t)d.v_out) & 15) == 0;
+    const int C4 = C >> 2;
+    const float4* v4 = reinterpret_cast<const float4*>(d.v_out);
     for (int r = r0 + wave; r < r1; r += 4) {
         const float* wr = d.w + (size_t)r * C;
         float a = 0.f;
-        for (int c = lane; c < C; c += 64) a = fmaf(wr[c], d.v_out[c], a);
+        if (vec) {
+            const float4* w4 = reinterpret_cast<const float4*>(wr);
+            float a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            int c = lane;
+            for (; c + 192 < C4; c += 256) {
+                const float4 x0 = w4[c], x1 = w4[c + 64], x2 = w4[c + 128], x3 = w4[c + 192];
+                const float4 y0 = v4[c], y1 = v4[c + 64], y2 = v4[c + 128], y3 = v4[c + 192];
+                a  = fmaf(x0.x, y0.x, fmaf(x0.y, y0.y, fmaf(x0.z, y0.z, fmaf(x0.w, y0.w, a))));
+                a1 = fmaf(x1.x, y1.x, fmaf(x1.y, y1.y, fmaf(x1.z, y1.z, fmaf(x1.w, y1.w, a1))));
+                a2 = fmaf(x2.x, y2.x, fmaf(x2.y, y2.y, fmaf(x2.z, y2.z, fmaf(x2.w, y2.w, a2))));
+                a3 = fmaf(x3.x, y3.x, fmaf(x3.y, y3.y, fmaf(x3.z, y3.z, fmaf(x3.w, y3.w, a3))));
+            }
+            for (; c < C4; c += 64) {
+                const float4 x0 = w4[c], y0 = v4[c];
+                a = fmaf(x0.x, y0.x, fmaf(x0.y, y0.y, fmaf(x0.z, y0.z, fmaf(x0.w, y0.w, a))));
+            }
+            a = (a + a1) + (a2 + a3);
+        } else {
+            for (int c = lane; c < C; c += 64) a = fmaf(wr[c], d.v_out[c], a);
+        }
         for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
         if (lane == 0) s[r] = a;
     }
@@ -118,26 +168,29 @@ __global__ __launch_bounds__(256) void sn_dot_kernel(const float* __restrict__ g
     if (threadIdx.x == 0) unsafeAtomicAdd(dot, a);
 }
 
-// dW_orig = alpha * G - (<G, W_orig> * alpha^2) * u v^T, in place on G  (legacy-hook autograd: u, v constants).
-// <G, W_orig> is computed here first (sn_dot_kernel, scratch scalar `dot`).
+// dW_orig = alpha * G - (<G, W_orig> * alpha^2) * u v^T  (legacy-hook autograd: u, v constants), written in place
+// on G, or -- `accum` given -- added to accum (the parameter's .grad: fused gradient accumulation, G untouched).
+// <G, W_orig> is computed first (sn_dot_kernel, scratch scalar `dot`).
 __global__ void sn_grad_apply_kernel(float* __restrict__ g, const float* __restrict__ u, const float* __restrict__ v,
-                                     const float* __restrict__ sig, const float* __restrict__ dot, int R, int C) {
+                                     const float* __restrict__ sig, const float* __restrict__ dot, float* __restrict__ accum, int R,
+                                     int C) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)R * C) return;
     const float alpha = sig[1];
     const float k = dot[0] * alpha * alpha;
     int r = (int)(i / C), c = (int)(i % C);
-    g[i] = fmaf(alpha, g[i], -k * u[r] * v[c]);
+    const float val = fmaf(alpha, g[i], -k * u[r] * v[c]);
+    if (accum) accum[i] += val; else g[i] = val;
 }
 
-extern "C" int lp_sn_grad_apply(float* g, const float* w_orig, const float* u, const float* v, const float* sig, float* dot, int rows,
-                                int cols, void* stream) {
+extern "C" int lp_sn_grad_apply(float* g, const float* w_orig, const float* u, const float* v, const float* sig, float* dot,
+                                float* accum, int rows, int cols, void* stream) {
     if (!g || !w_orig || !u || !v || !sig || !dot) return lp_set_error(LP_ERR_ARG, "lp_sn_grad_apply: null pointer");
     long long total = (long long)rows * cols;
     if (hipMemsetAsync(dot, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) return lp_set_error(LP_ERR_HIP, "hipMemsetAsync failed");
     int db = (int)((total + 1023) / 1024); if (db > 512) db = 512; if (db < 1) db = 1;
     hipLaunchKernelGGL(sn_dot_kernel, dim3(db), dim3(256), 0, (hipStream_t)stream, g, w_orig, dot, total);
     hipLaunchKernelGGL(sn_grad_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, u, v, sig, dot,
-                       rows, cols);
+                       accum, rows, cols);
     return lp_check_launch("sn_grad_apply");
 }

@@ -98,10 +98,12 @@ def conv(x: Tensor, pack: WeightPack, *, ksize: int, upsample: bool = False, pro
 
 
 def conv_wgrad(x: Tensor, dy: Tensor, *, ksize: int, upsample: bool = False, pro: int = 0, scale: Optional[Tensor] = None,
-               shift: Optional[Tensor] = None, prec: int = PREC_BF16, splits: Optional[int] = None, sn=None) -> Tensor:
+               shift: Optional[Tensor] = None, prec: int = PREC_BF16, splits: Optional[int] = None, sn=None,
+               accum: Optional[Tensor] = None) -> Optional[Tensor]:
     """dw [Cout,Cin,k,k] = sum_pixels dy (x) up2?(act(x)) (shifted by tap).
     ``sn`` = (w_orig, u, v, sig): the layer is spectrally normalised (forward used alpha = 1/sigma in the conv epilogue); the
-    returned gradient is then w.r.t. W_orig: dw/sigma - <dw, W_orig>/sigma^2 u v^T."""
+    returned gradient is then w.r.t. W_orig: dw/sigma - <dw, W_orig>/sigma^2 u v^T.
+    ``accum`` (with ``sn``): add that gradient to this tensor (the parameter's .grad) instead and return None."""
     _chk(x, 'x'); _chk(dy, 'dy')
     n, h, w, cout = dy.shape
     cin = x.shape[3]
@@ -117,8 +119,12 @@ def conv_wgrad(x: Tensor, dy: Tensor, *, ksize: int, upsample: bool = False, pro
                                        cout, ksize, int(upsample), pro, splits, prec, _stream()), 'lp_conv_wgrad')
     if sn is not None:
         w_orig, u, v, sig = sn
+        if accum is not None:
+            assert accum.is_contiguous() and accum.dtype == torch.float32 and accum.numel() == dw.numel()
         check(_lib.lib().lp_sn_grad_apply(dw.data_ptr(), w_orig.data_ptr(), u.data_ptr(), v.data_ptr(), sig.data_ptr(), dot.data_ptr(),
-                                          cout, cin * ksize * ksize, _stream()), 'lp_sn_grad_apply')
+                                          _p(accum), cout, cin * ksize * ksize, _stream()), 'lp_sn_grad_apply')
+        if accum is not None:
+            return None
     return dw
 
 

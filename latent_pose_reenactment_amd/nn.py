@@ -72,6 +72,31 @@ class SNWeight(nn.Module):
         return w / sigma
 
 
+_FUSED_ACCUM = [False]
+
+
+class fused_grad_accumulation:
+    """Context for ``loss.backward()`` of the training step: spectrally normalised conv weights whose ``.grad`` already exists
+    (the optimizers' flat gradient arena, zeroed by ``zero_grad``) get their gradient ADDED to ``.grad`` by the kernel that
+    finishes it (lp_sn_grad_apply), and autograd receives None for them -- one AccumulateGrad ``add`` launch and one pass over the
+    gradient less per weight.  The sum is the same ``0 + g`` / ``g1 + g2`` autograd would form.  Off by default (plain autograd
+    semantics, e.g. for torch.autograd.grad and for tests that read the returned gradients)."""
+
+    def __enter__(self):
+        self.prev = _FUSED_ACCUM[0]
+        _FUSED_ACCUM[0] = True
+
+    def __exit__(self, *exc):
+        _FUSED_ACCUM[0] = self.prev
+
+
+def _accum_target(w):
+    if not _FUSED_ACCUM[0] or not (w.is_leaf and w.requires_grad):
+        return None
+    g = w.grad
+    return g if (g is not None and g.is_contiguous() and g.dtype == torch.float32 and g.shape == w.shape) else None
+
+
 class SNBatch:
     """One-launch spectral normalisation of many ``SNWeight`` layers (lp_sn_power_iter): in train mode each layer's (u, v)
     buffers take one power-iteration step in place, and for every layer the call yields ``(u_used, v_used, sig)`` with
@@ -98,9 +123,10 @@ class SNBatch:
         self.sets = []
         for _ in range(self.SETS):
             sig = torch.zeros(len(self.layers), 2, dtype=torch.float32, device=dev)
-            uo = torch.zeros(sum(rows), dtype=torch.float32, device=dev)
-            vo = torch.zeros(sum(cols), dtype=torch.float32, device=dev)
-            need = [((r + rb - 1) // rb) * c + r for r, c in zip(rows, cols)]
+            al = lambda n: (n + 3) // 4 * 4                 # 16-byte aligned slices: the mat-vec kernels use 16-B loads
+            uo = torch.zeros(sum(al(r) for r in rows), dtype=torch.float32, device=dev)
+            vo = torch.zeros(sum(al(c) for c in cols), dtype=torch.float32, device=dev)
+            need = [al(((r + rb - 1) // rb) * c + r) for r, c in zip(rows, cols)]
             scratch = torch.zeros(sum(need), dtype=torch.float32, device=dev)
             blob = bytearray()
             states = []
@@ -112,7 +138,7 @@ class SNBatch:
                 blob += struct.pack('<QQQQQQQiifi', w.data_ptr(), u.data_ptr(), v.data_ptr(), ui.data_ptr(), vi.data_ptr(), si.data_ptr(),
                                     pi.data_ptr(), rows[i], cols[i], float(l.eps), 0)
                 states.append((ui, vi, si))
-                ro += rows[i]; co += cols[i]; so += need[i]
+                ro += al(rows[i]); co += al(cols[i]); so += need[i]
             table = torch.frombuffer(blob, dtype=torch.uint8).clone().to(dev)
             self.sets.append((table, states, (sig, uo, vo, scratch)))
 
@@ -277,6 +303,7 @@ class _DecoderFunction(torch.autograd.Function):
             ctx.head = (x, sth, oh, t)
             ctx.affine = affine
             ctx.weights = [w.detach() for w in wl]
+            ctx.params = wl                  # the parameter tensors themselves: fused accumulation adds into their .grad
             ctx.const_shape = constant.shape
         return rgbs, segm
 
@@ -286,6 +313,7 @@ class _DecoderFunction(torch.autograd.Function):
         blocks, prec = cfg['blocks'], cfg['prec']
         sn = cfg['sn']
         affine, wl = ctx.affine, ctx.weights
+        params = ctx.params
         d_affine = torch.zeros_like(affine)
 
         def snw(i):          # (W_orig, u, v, sig) of conv weight i -> wgrad returns the gradient w.r.t. W_orig
@@ -299,7 +327,7 @@ class _DecoderFunction(torch.autograd.Function):
         ch = blocks[-1][1]
         dz = ops.head_bwd(t, d_rgbs.contiguous(), None if d_segm is None else d_segm.contiguous())
         wi = len(wl) - 2
-        grads[wi] = ops.conv_wgrad(x, dz, ksize=3, pro=1, scale=sth[2], shift=sth[3], prec=prec, sn=snw(wi))
+        grads[wi] = ops.conv_wgrad(x, dz, ksize=3, pro=1, scale=sth[2], shift=sth[3], prec=prec, sn=snw(wi), accum=_accum_target(params[wi]))
         grads[wi + 1] = dz.sum(dim=(0, 1, 2))
         pT = ops.pack_weights(wl[wi].contiguous(), 1, prec, small_k=True)
         dA = ops.conv(dz, pT, ksize=3, alpha=sn[wi][2][1:], prec=prec)
@@ -317,7 +345,8 @@ class _DecoderFunction(torch.autograd.Function):
             w1, w2 = wl[wi], wl[wi + 1]
             d_out = dx
             # conv2 (+ AdaIN1/ReLU prologue)
-            grads[wi + 1] = ops.conv_wgrad(h1, d_out, ksize=3, pro=1, scale=st1[2], shift=st1[3], prec=prec, sn=snw(wi + 1))
+            grads[wi + 1] = ops.conv_wgrad(h1, d_out, ksize=3, pro=1, scale=st1[2], shift=st1[3], prec=prec, sn=snw(wi + 1),
+                                           accum=_accum_target(params[wi + 1]))
             dA1 = ops.conv(d_out, ops.pack_weights(w2.contiguous(), 1, prec), ksize=3, alpha=sn[wi + 1][2][1:], prec=prec)
             g, dg, db = slices(o1, cout)
             dh1 = ops.adain_relu_bwd(dA1, h1, None, g, st1[0], st1[1], st1[2], st1[3], dg, db, False)
@@ -325,13 +354,14 @@ class _DecoderFunction(torch.autograd.Function):
             if has_skip:
                 ws = wl[wi + 2]
                 ds = ops.sum2x2(d_out) if up else d_out
-                grads[wi + 2] = ops.conv_wgrad(x, ds, ksize=1, prec=prec, sn=snw(wi + 2))
+                grads[wi + 2] = ops.conv_wgrad(x, ds, ksize=1, prec=prec, sn=snw(wi + 2), accum=_accum_target(params[wi + 2]))
                 grads[wi + 3] = ds.sum(dim=(0, 1, 2))
                 dx_skip = ops.conv(ds, ops.pack_weights(ws.contiguous(), 1, prec), ksize=1, alpha=sn[wi + 2][2][1:], prec=prec)
             else:
                 dx_skip = d_out
             # conv1 (+ AdaIN0/ReLU/upsample prologue)
-            grads[wi] = ops.conv_wgrad(x, dh1, ksize=3, upsample=up, pro=1, scale=st0[2], shift=st0[3], prec=prec, sn=snw(wi))
+            grads[wi] = ops.conv_wgrad(x, dh1, ksize=3, upsample=up, pro=1, scale=st0[2], shift=st0[3], prec=prec, sn=snw(wi),
+                                       accum=_accum_target(params[wi]))
             dA0 = ops.conv(dh1, ops.pack_weights(w1.contiguous(), 1, prec), ksize=3, alpha=sn[wi][2][1:], prec=prec)
             g, dg, db = slices(o0, cin)
             dx = ops.adain_relu_bwd(dA0, x, dx_skip, g, st0[0], st0[1], st0[2], st0[3], dg, db, up)
@@ -498,6 +528,7 @@ class ConvFn(torch.autograd.Function):
         y = ops.conv(x, pack, ksize=ksize, pro=pro, bias=None if bias is None else bias.detach().contiguous(), res=res,
                      alpha=None if sn is None else sn[2][1:], prec=prec)
         ctx.save_for_backward(x, wd)
+        ctx.w_param = w if (sn is not None and w.requires_grad and w.is_leaf) else None
         ctx.cfg = (ksize, pro, prec, packs, bias is not None, res is not None, sn)
         return y
 
@@ -518,7 +549,8 @@ class ConvFn(torch.autograd.Function):
             dA = ops.conv(dy, packT, ksize=ksize, alpha=None if sn is None else sn[2][1:], prec=prec)
             dx = ops.relu_bwd(dA, x) if pro == 2 else dA
         if ctx.needs_input_grad[1]:
-            dw = ops.conv_wgrad(x, dy, ksize=ksize, pro=pro, prec=prec, sn=None if sn is None else (wd,) + tuple(sn))
+            dw = ops.conv_wgrad(x, dy, ksize=ksize, pro=pro, prec=prec, sn=None if sn is None else (wd,) + tuple(sn),
+                                accum=None if ctx.w_param is None else _accum_target(ctx.w_param))
         if has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(dim=(0, 1, 2))
         if has_res and ctx.needs_input_grad[3]:
