@@ -28,7 +28,7 @@ struct ConvParams {
     int lTH, lTW, lNB, tiles_x, tiles_y;
 #ifdef LP_DBG
     unsigned long long* prof; // [6] cycle counters of block 0 / wave 0: sync, dma issue, halo load issue, mfma, halo write, total
-    int dbg;                  // ablation bitmask (LP_CONV_DBG): 1 skip halo restaging, 2 skip weight DMA, 4 skip MFMAs, 8 skip epilogue
+    int dbg;                  // ablation bitmask (LP_CONV_DBG): 1 skip halo restaging, 2 skip weight DMA, 4 skip MFMAs, 8 skip epilogue, 16 one fragment fetch per stage
 #endif
     int ksplit;               // split-K: gridDim.z workgroups share one output tile (fp32 atomic epilogue onto a zeroed y)
     int a_dbuf;               // activation halo double-buffered in LDS (1) or single-buffered with an extra barrier (0)
@@ -42,7 +42,9 @@ struct ConvParams {
 //   reads without padding.  The activated input halo of a chunk is staged once (AdaIN/ReLU/upsample prologue in registers) into
 //   one of two halo buffers while the previous chunk's last stage is still being multiplied.
 template <int KS, bool UPS, int WM, int WN, int MR, int NR, int CC, int PREC, bool FAST, int NBUF>
-__global__ __launch_bounds__(256, (CC == 32 && PREC == LP_PREC_BF16 && NBUF == 2) ? 2 : 1) void conv_igemm_kernel(ConvParams p) {
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && CC == 32 && PREC == LP_PREC_BF16 && NBUF == 2) ? 2 : 1)
+void conv_igemm_kernel(ConvParams p) {
+    constexpr int NWAVE = WM * WN, NT = NWAVE * 64;      // 4 waves (one per SIMD) or 8 (two per SIMD: each hides the other's staging)
     constexpr bool SPLIT = (PREC == LP_PREC_BF16X3);
     constexpr int BM = WM * MR * 16, BN = WN * NR * 16;
     constexpr int SA = CC * 2 + 16;                 // padded halo row stride (bytes)
@@ -52,13 +54,13 @@ __global__ __launch_bounds__(256, (CC == 32 && PREC == LP_PREC_BF16 && NBUF == 2
     constexpr int B_STAGE = KS * BN * ROWB;         // bytes of one stage (hi part)
     constexpr int B_BUF = B_STAGE * (SPLIT ? 2 : 1);
     constexpr int NQ = B_STAGE / 1024;              // DMA instructions per stage (hi part)
-    constexpr int DMA_PER_WAVE = ((NQ + 3) / 4) * (SPLIT ? 2 : 1);   // LDS-DMA instructions one wave issues per stage
-    static_assert(NBUF == 2 || (NBUF == 3 && NQ % 4 == 0), "3-deep ring needs a uniform DMA count per wave");
+    constexpr int DMA_PER_WAVE = ((NQ + NWAVE - 1) / NWAVE) * (SPLIT ? 2 : 1);   // LDS-DMA instructions one wave issues per stage
+    static_assert(NBUF == 2 || (NBUF == 3 && NQ % NWAVE == 0), "3-deep ring needs a uniform DMA count per wave");
     static_assert(!(UPS && KS == 1), "1x1 convs commute with nearest upsampling: run them at low resolution");
-    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(NWAVE == 4 || NWAVE == 8, "4 or 8 waves per workgroup");
     static_assert(B_STAGE % 1024 == 0, "stage must be a whole number of 1 KiB DMA pieces");
     // FAST halo staging: every thread owns up to AIT (pixel, 8-channel group) items whose loads are issued together
-    constexpr int CG = CC / 8, PPP = 256 / CG;                       // pixels covered by one pass of the 256 threads
+    constexpr int CG = CC / 8, PPP = NT / CG;                        // pixels covered by one pass of the workgroup's threads
     constexpr int MAXHALO = (BM == 128) ? 10 * 18 : 18 * 18;        // 8x16 / 16x16 patch + 1-pixel border
     constexpr int AIT = FAST ? (MAXHALO + PPP - 1) / PPP : 1;
 
@@ -167,9 +169,13 @@ __global__ __launch_bounds__(256, (CC == 32 && PREC == LP_PREC_BF16 && NBUF == 2
         const unsigned dst_lds = (unsigned)(uintptr_t)(B_base + buf * B_BUF);      // LDS byte address (wave-uniform)
         const int rr = lane / SLOTS, slot = lane % SLOTS;
 #pragma unroll
-        for (int q0 = 0; q0 < NQ; q0 += 4) {
+        for (int q0 = 0; q0 < NQ; q0 += NWAVE) {
             const int q = q0 + wave;
-            if (NQ % 4 == 0 || q < NQ) {
+            bool doit = (NQ % NWAVE == 0 || q < NQ);
+#ifdef LP_DBG
+            if ((p.dbg & 32) && ((q0 / NWAVE) & 1)) doit = false;      // ablation: half the DMA pieces
+#endif
+            if (doit) {
                 const int r = q * RPI + rr;                                           // row inside the stage: kx * BN + n
                 const int key = (SLOTS == 8) ? (r & 7) : ((r >> 2) & 3);
                 const int kx = r / BN, n = r % BN;
@@ -181,7 +187,7 @@ __global__ __launch_bounds__(256, (CC == 32 && PREC == LP_PREC_BF16 && NBUF == 2
     };
     auto stage_a_slow = [&](int chunk, int buf) {
         unsigned char* A = smem + buf * a_buf;
-        stage_act_halo<CC, SPLIT>(A, A + a_bytes, SA, p.x, p.scale, p.shift, p.pro, p.N, p.Hin, p.Win, p.Cin,
+        stage_act_halo<CC, SPLIT, NT>(A, A + a_bytes, SA, p.x, p.scale, p.shift, p.pro, p.N, p.Hin, p.Win, p.Cin,
                                   n0, NBv, HH, HW, oy, ox, chunk * CC, tid);
     };
     // MFMAs of one stage: kernel row ky of the chunk whose halo is in halo buffer `abuf`, weights in stage buffer `bbuf`
@@ -189,44 +195,53 @@ __global__ __launch_bounds__(256, (CC == 32 && PREC == LP_PREC_BF16 && NBUF == 2
         const unsigned char* A_hi = smem + abuf * a_buf;
         const unsigned char* A_lo = A_hi + a_bytes;
         const unsigned char* Bc = B_base + bbuf * B_BUF;
-#pragma unroll
-        for (int kx = 0; kx < KS; ++kx) {
+        // k-steps of the stage = (kx, kk); fragments are double-buffered in registers and those of step s+1 are requested before
+        // the MFMAs of step s, so with one wave per SIMD the LDS latency hides behind a full k-step of matrix work.
+        constexpr int KK = CC / 32, STEPS = KS * KK;
+        s16x8_t fa[2][MR], fb[2][NR], fal[2][MR], fbl[2][NR];
+        auto fetch = [&](int st, int set) {
+            const int kx = st / KK, kk = st % KK;
             const int dy = (KS == 3) ? ky : 0, dx = (KS == 3) ? kx : 0;
-            int a_off[MR];
+            const unsigned char* Bk = Bc + kx * (BN * ROWB);
+            const int bslot = (((kk * 4 + kb) ^ bkey) * 16);
 #pragma unroll
             for (int mr = 0; mr < MR; ++mr) {
                 int hy, hx;
                 if (KS == 1) { hy = a_py[mr]; hx = a_px[mr]; }
                 else if (UPS) { hy = ((a_py[mr] + dy - 1) >> 1) + 1; hx = ((a_px[mr] + dx - 1) >> 1) + 1; }
                 else { hy = a_py[mr] + dy; hx = a_px[mr] + dx; }
-                a_off[mr] = (a_nbbase[mr] + hy * HW + hx) * SA + kb16;
+                const int off = (a_nbbase[mr] + hy * HW + hx) * SA + kb16 + kk * 64;
+                fa[set][mr] = *(const s16x8_t*)(A_hi + off);
+                if (SPLIT) fal[set][mr] = *(const s16x8_t*)(A_lo + off);
             }
-            const unsigned char* Bk = Bc + kx * (BN * ROWB);
 #pragma unroll
-            for (int kk = 0; kk < CC / 32; ++kk) {
-                const int bslot = (((kk * 4 + kb) ^ bkey) * 16);
-                s16x8_t a[MR], b[NR], al[MR], bl[NR];
+            for (int nr = 0; nr < NR; ++nr) {
+                fb[set][nr] = *(const s16x8_t*)(Bk + b_off[nr] + bslot);
+                if (SPLIT) fbl[set][nr] = *(const s16x8_t*)(Bk + B_STAGE + b_off[nr] + bslot);
+            }
+        };
+        fetch(0, 0);
+#ifdef LP_DBG
+        if (p.dbg & 16) fetch(0, 1);                     // ablation: one fragment fetch per stage, MFMAs re-use it
+#endif
 #pragma unroll
-                for (int mr = 0; mr < MR; ++mr) {
-                    a[mr] = *(const s16x8_t*)(A_hi + a_off[mr] + kk * 64);
-                    if (SPLIT) al[mr] = *(const s16x8_t*)(A_lo + a_off[mr] + kk * 64);
-                }
+        for (int st = 0; st < STEPS; ++st) {
+            const int cur = st & 1;
+#ifdef LP_DBG
+            if (st + 1 < STEPS && !(p.dbg & 16)) fetch(st + 1, cur ^ 1);
+#else
+            if (st + 1 < STEPS) fetch(st + 1, cur ^ 1);
+#endif
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
                 for (int nr = 0; nr < NR; ++nr) {
-                    b[nr] = *(const s16x8_t*)(Bk + b_off[nr] + bslot);
-                    if (SPLIT) bl[nr] = *(const s16x8_t*)(Bk + B_STAGE + b_off[nr] + bslot);
-                }
-#pragma unroll
-                for (int mr = 0; mr < MR; ++mr)
-#pragma unroll
-                    for (int nr = 0; nr < NR; ++nr) {
-                        if (SPLIT) {
-                            acc[mr][nr] = mfma16(al[mr], b[nr], acc[mr][nr]);
-                            acc[mr][nr] = mfma16(a[mr], bl[nr], acc[mr][nr]);
-                        }
-                        acc[mr][nr] = mfma16(a[mr], b[nr], acc[mr][nr]);
+                    if (SPLIT) {
+                        acc[mr][nr] = mfma16(fal[cur][mr], fb[cur][nr], acc[mr][nr]);
+                        acc[mr][nr] = mfma16(fa[cur][mr], fbl[cur][nr], acc[mr][nr]);
                     }
-            }
+                    acc[mr][nr] = mfma16(fa[cur][mr], fb[cur][nr], acc[mr][nr]);
+                }
         }
     };
 
@@ -249,7 +264,11 @@ __global__ __launch_bounds__(256, (CC == 32 && PREC == LP_PREC_BF16 && NBUF == 2
 #ifdef LP_DBG
         unsigned long long pc[6] = {0, 0, 0, 0, 0, 0};
         const unsigned long long tstart = __builtin_amdgcn_s_memtime();
+#ifdef LP_PROF
 #define LP_T(var) __builtin_amdgcn_sched_barrier(0); const unsigned long long var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
+#else
+#define LP_T(var) const unsigned long long var = 0;
+#endif
 #endif
         if (NBUF == 3 && S > 1) issue_b(cbeg + (KS > 1 ? 0 : 1), KS > 1 ? 1 : 0, 1);
         for (int chunk = 0; chunk < nch; ++chunk) {
@@ -407,7 +426,7 @@ static int launch_conv_v(ConvParams& p, size_t lds, dim3 grid, hipStream_t strea
             return lp_set_error(LP_ERR_HIP, "hipFuncSetAttribute failed");
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
+    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, stream, p);
     return lp_check_launch("conv_igemm");
 }
 
@@ -418,7 +437,7 @@ static int launch_conv(ConvParams& p, hipStream_t stream) {
     constexpr bool SPLIT = (PREC == LP_PREC_BF16X3);
     constexpr size_t B_BUF = (size_t)KS * BN * CC * 2 * (SPLIT ? 2 : 1);
     constexpr size_t LDS_MAX = 160 * 1024;
-    constexpr int PPP = 256 / (CC / 8);
+    constexpr int PPP = WM * WN * 64 / (CC / 8);
     constexpr int AIT = (((BM == 128) ? 10 * 18 : 18 * 18) + PPP - 1) / PPP;
     choose_tile(BM, p.N, p.H, p.W, &p.lTH, &p.lTW, &p.lNB);
     const int TH = 1 << p.lTH, TW = 1 << p.lTW, NBv = 1 << p.lNB;
@@ -432,7 +451,7 @@ static int launch_conv(ConvParams& p, hipStream_t stream) {
     constexpr bool ring3_ok = (CC == 32) && (KS == 3) && (BN >= 64) && !SPLIT;
     const bool ring3 = ring3_ok && fast && want_nbuf == 3 && (2 * a_buf + 3 * B_BUF <= LDS_MAX);
     size_t lds = a_buf * (fast ? 2 : 1) + (ring3 ? 3 : 2) * B_BUF;
-    const size_t epi = (size_t)4 * (MR * 16) * (NR * 16 + 4) * sizeof(float);       // LDS transpose of the coalesced epilogue
+    const size_t epi = (size_t)(WM * WN) * (MR * 16) * (NR * 16 + 4) * sizeof(float);       // LDS transpose of the coalesced epilogue
     if (lds < epi) lds = epi;
     if (lds > LDS_MAX) return lp_set_error(LP_ERR_UNSUPPORTED, "conv tile needs too much LDS");
     dim3 grid(p.tiles_x * p.tiles_y * ((p.N + NBv - 1) / NBv), (p.Cout + BN - 1) / BN);
@@ -455,6 +474,18 @@ static int launch_conv(ConvParams& p, hipStream_t stream) {
 template <int PREC, int CC>
 static int dispatch_conv_cc(ConvParams& p, int ks, int ups, hipStream_t s) {
     const bool big_img = p.H * p.W >= 256;     // a 256-pixel patch fits inside one image
+    // 8-wave workgroups (two waves per SIMD, each 64 x 32 of the 128 x 128 tile) for the small feature maps (<= 16x16): those
+    // run split-K with few stages per workgroup, so the prologue (first halo + weight stage) and the epilogue dominate, and
+    // twice the threads finish them sooner (measured 4x4: 43 -> 30 us, 16x16: 64 -> 51 us in bf16x3; 32x32 and up are better
+    // with 4 waves: the phases of all waves are aligned by the stage barrier, so a second wave per SIMD hides nothing there).
+    // LP_CONV_W8 = 0 | 1 forces it off / on for every shape.
+    static const int w8_env = getenv("LP_CONV_W8") ? atoi(getenv("LP_CONV_W8")) : -1;
+    const bool w8 = w8_env >= 0 ? (w8_env != 0) : (p.H * p.W <= 256);
+    if (w8 && p.Cout > 64) {
+        if (ks == 3 && !ups) return launch_conv<3, false, 2, 4, 4, 2, CC, PREC>(p, s);
+        if (ks == 3 && ups) return launch_conv<3, true, 2, 4, 4, 2, CC, PREC>(p, s);
+        if (ks == 1 && !ups) return launch_conv<1, false, 2, 4, 4, 2, CC, PREC>(p, s);
+    }
     if (ks == 3 && !ups) {
         if (p.Cout <= 16 && big_img) return launch_conv<3, false, 4, 1, 4, 1, CC, PREC>(p, s);
         if (p.Cout <= 64 && big_img) return launch_conv<3, false, 4, 1, 4, 4, CC, PREC>(p, s);

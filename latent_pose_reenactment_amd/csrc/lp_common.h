@@ -74,7 +74,7 @@ __device__ __forceinline__ void tile_lin_decode(int kpix, int lTH, int lTW, int&
 //   pro    : 0 none, 1 relu(x*scale[n,c]+shift[n,c]) (AdaIN), 2 relu(x)
 //   halo   : NBv images x HH x HW pixels, origin (oy, ox) in input coordinates; out-of-image pixels are ZERO
 //            (zero padding is applied after the activation, blocks.py:76-88 conv padding=1).
-template <int CC, bool SPLIT>
+template <int CC, bool SPLIT, int NT = 256>
 __device__ __forceinline__ void stage_act_halo(unsigned char* __restrict__ lds_hi, unsigned char* __restrict__ lds_lo, int SA,
                                                const float* __restrict__ x, const float* __restrict__ scale,
                                                const float* __restrict__ shift, int pro, int N, int Hin, int Win, int Cin,
@@ -82,7 +82,7 @@ __device__ __forceinline__ void stage_act_halo(unsigned char* __restrict__ lds_h
     constexpr int CG = CC / 8;
     const int items = NBv * HH * HW * CG;
     const bool vec_ok = (Cin & 3) == 0;
-    for (int i = tid; i < items; i += 256) {
+    for (int i = tid; i < items; i += NT) {
         int cg = i % CG, hp = i / CG;
         int hx = hp % HW, t2 = hp / HW;
         int hy = t2 % HH, nb = t2 / HH;
