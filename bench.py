@@ -209,6 +209,7 @@ def main():
     ap.add_argument('--workload', default='finetune_step', choices=['finetune_step', 'generator'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eager', action='store_true', help='do not capture the step into hipGraphs')
+    ap.add_argument('--shapes', default=None, help='write the per-shape conv / wgrad timing table of the instrumented steps (CSV)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only for functional tests)')
     a = ap.parse_args()
 
@@ -284,7 +285,10 @@ def main():
 
     # live roofline of the dominant kernel family (HIP events recorded on the launch stream inside the timed region)
     agg = {}
-    for kind, flops, e0, e1 in prof:
+    shapes = {}
+    for kind, flops, e0, e1, tag in prof:
+        sd = shapes.setdefault((kind, tag), [0.0, 0.0, 0])
+        sd[0] += flops; sd[1] += e0.elapsed_time(e1) * 1e-3; sd[2] += 1
         d = agg.setdefault(kind, [0.0, 0.0, 0])
         d[0] += flops; d[1] += e0.elapsed_time(e1) * 1e-3; d[2] += 1
     roof = None
@@ -300,6 +304,12 @@ def main():
         else:
             extra['roofline_' + kind] = entry
 
+    if rank == 0 and a.shapes:
+        with open(a.shapes, 'w') as f:
+            f.write('kind,N,H,W,Cin,Cout,ksize,upsample,prologue,launches,total_us,avg_us,TFLOPs\n')
+            for (kind, tag), (fl, sec, cnt) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
+                f.write(','.join([kind] + [str(v) for v in (tag or ())] + [str(cnt), f'{sec * 1e6:.1f}', f'{sec / cnt * 1e6:.1f}',
+                                                                          f'{fl / sec / 1e12:.1f}']) + '\n')
     if rank == 0:
         imgs = a.batch * world * a.steps
         out = {

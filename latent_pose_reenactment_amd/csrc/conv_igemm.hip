@@ -41,10 +41,20 @@ struct ConvParams {
 //   the per-lane SOURCE address (16-byte chunk index ^ row key) and undone on the ds_read_b128 side -- conflict-free B-fragment
 //   reads without padding.  The activated input halo of a chunk is staged once (AdaIN/ReLU/upsample prologue in registers) into
 //   one of two halo buffers while the previous chunk's last stage is still being multiplied.
-template <int KS, bool UPS, int WM, int WN, int MR, int NR, int CC, int PREC, bool FAST, int NBUF>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && CC == 32 && PREC == LP_PREC_BF16 && NBUF == 2) ? 2 : 1)
+//
+// Ping-pong variant (PP): the workgroup has TWO groups of 4 waves (one wave of each group on every SIMD).  Each group owns
+// its own output tile (adjacent M tiles, same N tile) and its own single halo buffer; the weight stages are shared, so they
+// are fetched once for both tiles.  A stage slot has two phases separated by workgroup barriers: in phase A group 0 runs the
+// stage's MFMAs while group 1 does its staging work (its share of the next stage's weight DMA, halo loads / prologue / LDS
+// write), in phase B the roles swap.  The matrix pipe of every SIMD therefore always has one wave multiplying while the
+// other wave's LDS-DMA issue, address math and fp32->bf16 conversion run beside it, instead of all waves staging (pipe idle)
+// and then all waves multiplying as in the one-group schedule.
+template <int KS, bool UPS, int WM, int WN, int MR, int NR, int CC, int PREC, bool FAST, int NBUF, bool PP = false>
+__global__ __launch_bounds__(WM * WN * 64 * (PP ? 2 : 1), (!PP && WM * WN == 4 && CC == 32 && PREC == LP_PREC_BF16 && NBUF == 2) ? 2 : 1)
 void conv_igemm_kernel(ConvParams p) {
-    constexpr int NWAVE = WM * WN, NT = NWAVE * 64;      // 4 waves (one per SIMD) or 8 (two per SIMD: each hides the other's staging)
+    constexpr int NWAVE = WM * WN, NT = NWAVE * 64;      // waves / threads of one group: 4 waves (one per SIMD) or 8
+    constexpr int NWD = PP ? 2 * NWAVE : NWAVE;          // waves that share the weight DMA of a stage
+    static_assert(!PP || (FAST && KS == 3 && NBUF == 2 && NWAVE == 4), "ping-pong: two 4-wave groups, 3x3, fast staging");
     constexpr bool SPLIT = (PREC == LP_PREC_BF16X3);
     constexpr int BM = WM * MR * 16, BN = WN * NR * 16;
     constexpr int SA = CC * 2 + 16;                 // padded halo row stride (bytes)
@@ -54,8 +64,8 @@ void conv_igemm_kernel(ConvParams p) {
     constexpr int B_STAGE = KS * BN * ROWB;         // bytes of one stage (hi part)
     constexpr int B_BUF = B_STAGE * (SPLIT ? 2 : 1);
     constexpr int NQ = B_STAGE / 1024;              // DMA instructions per stage (hi part)
-    constexpr int DMA_PER_WAVE = ((NQ + NWAVE - 1) / NWAVE) * (SPLIT ? 2 : 1);   // LDS-DMA instructions one wave issues per stage
-    static_assert(NBUF == 2 || (NBUF == 3 && NQ % NWAVE == 0), "3-deep ring needs a uniform DMA count per wave");
+    constexpr int DMA_PER_WAVE = ((NQ + NWD - 1) / NWD) * (SPLIT ? 2 : 1);   // LDS-DMA instructions one wave issues per stage
+    static_assert(NBUF == 2 || (NBUF == 3 && NQ % NWD == 0), "3-deep ring needs a uniform DMA count per wave");
     static_assert(!(UPS && KS == 1), "1x1 convs commute with nearest upsampling: run them at low resolution");
     static_assert(NWAVE == 4 || NWAVE == 8, "4 or 8 waves per workgroup");
     static_assert(B_STAGE % 1024 == 0, "stage must be a whole number of 1 KiB DMA pieces");
@@ -66,13 +76,15 @@ void conv_igemm_kernel(ConvParams p) {
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int grp = PP ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;     // ping-pong group of this wave
+    const int tid = PP ? ((int)threadIdx.x & 255) : (int)threadIdx.x, lane = tid & 63;       // thread / wave index inside the group
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_d = PP ? grp * NWAVE + wave : wave;                                       // index among the waves sharing the DMA
     const int wm = wave / WN, wn = wave % WN;
     const int TH = 1 << p.lTH, TW = 1 << p.lTW, NBv = 1 << p.lNB;
 
-    int t = blockIdx.x;
-    const int tx = t % p.tiles_x; t /= p.tiles_x;
+    int t = PP ? (int)blockIdx.x * 2 + grp : (int)blockIdx.x;     // (an odd tile count leaves group 1 of the last workgroup a
+    const int tx = t % p.tiles_x; t /= p.tiles_x;                 //  tile past the last image: fully masked)
     const int ty = t % p.tiles_y; const int ng = t / p.tiles_y;
     const int n0 = ng << p.lNB, y0 = ty << p.lTH, x0 = tx << p.lTW;
     const int co0 = blockIdx.y * BN;
@@ -169,11 +181,11 @@ void conv_igemm_kernel(ConvParams p) {
         const unsigned dst_lds = (unsigned)(uintptr_t)(B_base + buf * B_BUF);      // LDS byte address (wave-uniform)
         const int rr = lane / SLOTS, slot = lane % SLOTS;
 #pragma unroll
-        for (int q0 = 0; q0 < NQ; q0 += NWAVE) {
-            const int q = q0 + wave;
-            bool doit = (NQ % NWAVE == 0 || q < NQ);
+        for (int q0 = 0; q0 < NQ; q0 += NWD) {
+            const int q = q0 + wave_d;
+            bool doit = (NQ % NWD == 0 || q < NQ);
 #ifdef LP_DBG
-            if ((p.dbg & 32) && ((q0 / NWAVE) & 1)) doit = false;      // ablation: half the DMA pieces
+            if ((p.dbg & 32) && ((q0 / NWD) & 1)) doit = false;      // ablation: half the DMA pieces
 #endif
             if (doit) {
                 const int r = q * RPI + rr;                                           // row inside the stage: kx * BN + n
@@ -251,9 +263,47 @@ void conv_igemm_kernel(ConvParams p) {
     const int nch = min(nch_total, cbeg + per) - cbeg;        // chunks of this workgroup: [cbeg, cbeg + nch)
     if (nch <= 0) return;                                       // (uniform) nothing to contribute
     issue_b(cbeg, 0, 0);
-    if (FAST) { load_a(cbeg); write_a(cbeg, 0); } else stage_a_slow(cbeg, 0);
+    if (FAST) { load_a(cbeg); write_a(cbeg, PP ? grp : 0); } else stage_a_slow(cbeg, 0);
 
-    if (FAST) {
+    if constexpr (PP) {
+        // slot k = stage k of both groups.  Phase A(k): group 0 multiplies stage k, group 1 stages; phase B(k): swapped.
+        // Staging duties of a group in slot k:
+        //   * its share of the weight DMA of stage k + 1 (buffer (k+1)&1: last read in phase B(k-1), which is over);
+        //   * one phase before its compute of the first stage of the next chunk: prologue + LDS write of that chunk's halo into
+        //     the group's (single) halo buffer -- the group itself is the only reader and it is not multiplying now;
+        //   * one staging phase earlier: issue the global loads of that halo (they fly during the compute phase in between).
+        // Weight DMA is untracked inline asm and is always issued BEFORE the halo loads of the same phase, so "at most
+        // 2*AIT loads outstanding" == "all DMA landed".
+        const int S = nch * KS;
+        for (int chunk = 0; chunk < nch; ++chunk) {
+            const bool has_next = chunk + 1 < nch;
+#pragma unroll
+            for (int ky = 0; ky < KS; ++ky) {
+                const int k = chunk * KS + ky;
+                const int bbuf = k & 1;
+                // halo loads issued in the previous slot may stay in flight: group 0 issues them in B(k) with ky == KS-2,
+                // group 1 in A(k) with ky == KS-1 (both: only if a next chunk exists)
+                const bool loads_in_flight = (grp == 0) ? (ky == KS - 1 && has_next) : (ky == 0 && chunk > 0);
+                if (loads_in_flight) lp_wait_vm<2 * AIT>(); else lp_wait_vm0();
+                __syncthreads();                                   // ---- phase A(k)
+                if (grp == 0) {
+                    compute(ky, 0, bbuf);
+                } else {
+                    if (ky == 0 && chunk > 0) write_a(cbeg + chunk, 1);               // halo of this chunk (loaded in A(k-1))
+                    if (k + 1 < S) issue_b(cbeg + (k + 1) / KS, (k + 1) % KS, bbuf ^ 1);
+                    if (ky == KS - 1 && has_next) load_a(cbeg + chunk + 1);
+                }
+                __syncthreads();                                   // ---- phase B(k)
+                if (grp == 1) {
+                    compute(ky, 1, bbuf);
+                } else {
+                    if (ky == KS - 1 && has_next) write_a(cbeg + chunk + 1, 0);       // halo of the next chunk (loaded in B(k-1))
+                    if (k + 1 < S) issue_b(cbeg + (k + 1) / KS, (k + 1) % KS, bbuf ^ 1);
+                    if (ky == KS - 2 && has_next) load_a(cbeg + chunk + 1);
+                }
+            }
+        }
+    } else if (FAST) {
         // Straight-line pipeline (no data-dependent control flow around memory ops, so hipcc places no early vmcnt waits):
         // stage = kernel row.  Top of stage: wait own DMA, barrier; issue next stage's DMA; [last row: issue next chunk's
         // halo loads]; MFMAs; [last row: prologue + LDS write of the next halo into the other halo buffer].
@@ -335,7 +385,7 @@ void conv_igemm_kernel(ConvParams p) {
         // fragments; bias and the residual are read the same way.
         constexpr int WR = MR * 16, WC = NR * 16, LDW = WC + 4;          // +4 floats: rows land on different banks
         __syncthreads();                                                  // all waves are done with the halo / weight buffers
-        float* tile = (float*)smem + wave * (WR * LDW);
+        float* tile = (float*)smem + wave_d * (WR * LDW);
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
@@ -417,16 +467,16 @@ static void choose_tile(int BM, int N, int H, int W, int* lTH, int* lTW, int* lN
     *lTH = lth; *lTW = ltw; *lNB = lnb;
 }
 
-template <int KS, bool UPS, int WM, int WN, int MR, int NR, int CC, int PREC, bool FAST, int NBUF>
+template <int KS, bool UPS, int WM, int WN, int MR, int NR, int CC, int PREC, bool FAST, int NBUF, bool PP = false>
 static int launch_conv_v(ConvParams& p, size_t lds, dim3 grid, hipStream_t stream) {
-    auto kern = conv_igemm_kernel<KS, UPS, WM, WN, MR, NR, CC, PREC, FAST, NBUF>;
+    auto kern = conv_igemm_kernel<KS, UPS, WM, WN, MR, NR, CC, PREC, FAST, NBUF, PP>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return lp_set_error(LP_ERR_HIP, "hipFuncSetAttribute failed");
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, stream, p);
+    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64 * (PP ? 2 : 1)), lds, stream, p);
     return lp_check_launch("conv_igemm");
 }
 
@@ -451,10 +501,21 @@ static int launch_conv(ConvParams& p, hipStream_t stream) {
     constexpr bool ring3_ok = (CC == 32) && (KS == 3) && (BN >= 64) && !SPLIT;
     const bool ring3 = ring3_ok && fast && want_nbuf == 3 && (2 * a_buf + 3 * B_BUF <= LDS_MAX);
     size_t lds = a_buf * (fast ? 2 : 1) + (ring3 ? 3 : 2) * B_BUF;
-    const size_t epi = (size_t)(WM * WN) * (MR * 16) * (NR * 16 + 4) * sizeof(float);       // LDS transpose of the coalesced epilogue
+    size_t epi = (size_t)(WM * WN) * (MR * 16) * (NR * 16 + 4) * sizeof(float);       // LDS transpose of the coalesced epilogue
+    // ping-pong schedule (two 4-wave groups, two adjacent M tiles per workgroup): default for bf16x3, whose single-group kernel
+    // runs one wave per SIMD; the bf16 kernel already interleaves two workgroups per CU.  LP_CONV_PP = 0 | 1 overrides.
+    constexpr bool pp_ok = (KS == 3) && (WM * WN == 4) && (CC == 32);
+    static const int pp_env = getenv("LP_CONV_PP") ? atoi(getenv("LP_CONV_PP")) : -1;
+    const int tiles = p.tiles_x * p.tiles_y * ((p.N + NBv - 1) / NBv);
+    // (pairing tiles halves the workgroup count: only when the paired grid still covers the CUs -- measured on 8x32x32x512, 256
+    //  tiles: 121 us single-group vs 125 us ping-pong + split-K 2)
+    const long long pp_wgs = (long long)((tiles + 1) / 2) * ((p.Cout + BN - 1) / BN);
+    const bool pp = pp_ok && fast && !ring3 && (pp_env >= 0 ? pp_env != 0 : (SPLIT && pp_wgs >= 200)) && tiles >= 2 &&
+                    (2 * a_buf + 2 * B_BUF <= LDS_MAX);
+    if (pp) { lds = 2 * a_buf + 2 * B_BUF; epi *= 2; }
     if (lds < epi) lds = epi;
     if (lds > LDS_MAX) return lp_set_error(LP_ERR_UNSUPPORTED, "conv tile needs too much LDS");
-    dim3 grid(p.tiles_x * p.tiles_y * ((p.N + NBv - 1) / NBv), (p.Cout + BN - 1) / BN);
+    dim3 grid(pp ? (tiles + 1) / 2 : tiles, (p.Cout + BN - 1) / BN);
     {   // split-K when the output tiling alone cannot fill the 256 CUs (4x4 ... 32x32 layers with K = 9*512)
         static const int max_split = getenv("LP_CONV_KSPLIT") ? atoi(getenv("LP_CONV_KSPLIT")) : 8;
         const int wgs = grid.x * grid.y, nch = p.CinP / CC;
@@ -466,6 +527,7 @@ static int launch_conv(ConvParams& p, hipStream_t stream) {
             return lp_set_error(LP_ERR_HIP, "hipMemsetAsync failed");
     }
     if constexpr (ring3_ok) { if (ring3) return launch_conv_v<KS, UPS, WM, WN, MR, NR, CC, PREC, true, 3>(p, lds, grid, stream); }
+    if constexpr (pp_ok) { if (pp) return launch_conv_v<KS, UPS, WM, WN, MR, NR, CC, PREC, true, 2, true>(p, lds, grid, stream); }
     if (fast) return launch_conv_v<KS, UPS, WM, WN, MR, NR, CC, PREC, true, 2>(p, lds, grid, stream);
     return launch_conv_v<KS, UPS, WM, WN, MR, NR, CC, PREC, false, 2>(p, lds, grid, stream);
 }

@@ -20,8 +20,8 @@ PROFILE = None
 
 
 class _Timed:
-    def __init__(self, kind, flops):
-        self.kind, self.flops = kind, flops
+    def __init__(self, kind, flops, tag=None):
+        self.kind, self.flops, self.tag = kind, flops, tag
 
     def __enter__(self):
         if PROFILE is not None:
@@ -33,7 +33,7 @@ class _Timed:
     def __exit__(self, *exc):
         if PROFILE is not None:
             self.e1.record()
-            PROFILE.append((self.kind, self.flops, self.e0, self.e1))
+            PROFILE.append((self.kind, self.flops, self.e0, self.e1, self.tag))
 
 
 def _p(t: Optional[Tensor]):
@@ -90,7 +90,7 @@ def conv(x: Tensor, pack: WeightPack, *, ksize: int, upsample: bool = False, pro
             _chk(t, nm)
     if res is not None:
         assert res.shape == (n, h >> res_shift, w >> res_shift, cout), (res.shape, y.shape, res_shift)
-    with _Timed('conv_igemm', 2.0 * n * h * w * cout * cin * ksize * ksize):
+    with _Timed('conv_igemm', 2.0 * n * h * w * cout * cin * ksize * ksize, (n, h, w, cin, cout, ksize, int(upsample), pro)):
         check(_lib.lib().lp_conv_fwd(x.data_ptr(), pack.hi.data_ptr(), _p(pack.lo), y.data_ptr(), _p(scale), _p(shift), _p(bias),
                                      _p(res), _p(alpha), n, h, w, cin, cout, pack.cols_p, pack.rows_p, ksize, int(upsample), pro,
                                      res_shift, prec, _stream()), 'lp_conv_fwd')
@@ -114,7 +114,7 @@ def conv_wgrad(x: Tensor, dy: Tensor, *, ksize: int, upsample: bool = False, pro
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
     dw = torch.empty((cout, cin, ksize, ksize), dtype=torch.float32, device=x.device)
     dot = torch.empty(1, dtype=torch.float32, device=x.device) if sn is not None else None
-    with _Timed('conv_wgrad', 2.0 * n * h * w * cout * cin * ksize * ksize):
+    with _Timed('conv_wgrad', 2.0 * n * h * w * cout * cin * ksize * ksize, (n, h, w, cin, cout, ksize, int(upsample), pro)):
         check(_lib.lib().lp_conv_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), _p(scale), _p(shift), n, h, w, cin,
                                        cout, ksize, int(upsample), pro, splits, prec, _stream()), 'lp_conv_wgrad')
     if sn is not None:
