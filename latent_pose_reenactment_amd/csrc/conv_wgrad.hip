@@ -10,6 +10,7 @@
 #include "lp_common.h"
 #include "lp_hip.h"
 #include "lp_internal.h"
+#include <stdlib.h>
 
 struct WgradParams {
     const float* x; const float* dy; float* part;
@@ -25,19 +26,23 @@ __device__ __forceinline__ s16x4_t tr_read(const unsigned char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(uintptr_t)p);
 }
 
-template <int KS, bool UPS, int PREC>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
+// COB = output channels per workgroup: 64 (4 waves) or 128 (8 waves, two per SIMD: the staged input halo is shared by twice
+// the matrix work, and the per-thread share of the fp32 -> bf16 staging work shrinks accordingly).
+template <int KS, bool UPS, int PREC, int COB = 64>
+__global__ __launch_bounds__(COB * 4) void conv_wgrad_kernel(WgradParams p) {
+    constexpr int NT = COB * 4;                    // threads: one wave per 32(co) x 32(ci) sub-block
+    constexpr int DCG = COB / 8;                   // 8-channel groups of the dy tile
     constexpr bool SPLIT = (PREC == LP_PREC_BF16X3);
     constexpr int T = KS * KS;
     constexpr int CC = 64;
-    constexpr int SA = CC * 2 + 16, SD = 64 * 2 + 16;
+    constexpr int SA = CC * 2 + 16, SD = COB * 2 + 16;
     constexpr int BMP = 128;                       // pixels per tile (k extent per stage)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int mh = wave >> 1, nh = wave & 1;       // wave -> 32(co) x 32(ci) sub-block
     const int TH = 1 << p.lTH, TW = 1 << p.lTW, NBv = 1 << p.lNB;
-    const int co0 = blockIdx.y * 64, ci0 = blockIdx.z * 64;
+    const int co0 = blockIdx.y * COB, ci0 = blockIdx.z * 64;
 
     int HH, HW;
     if (KS == 1) { HH = TH; HW = TW; } else if (UPS) { HH = (TH >> 1) + 2; HW = (TW >> 1) + 2; } else { HH = TH + 2; HW = TW + 2; }
@@ -58,119 +63,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
     // source-lane role for the transposing reads
     const int G = lane >> 4, sj = (lane & 15) >> 2, sq = lane & 3;
     // fast staging (one image per tile, channel counts multiple of 8): 8 channel groups x 32 pixels per pass of the block
-    constexpr int AIT = (10 * 18 + 31) / 32;                 // 8x16 patch + border = 180 halo pixels -> 6 items per thread
+    constexpr int APP = NT / 8;                              // halo pixels per pass of the workgroup (8 channel groups each)
+    constexpr int AIT = (10 * 18 + APP - 1) / APP;           // 8x16 patch + border = 180 halo pixels -> 6 (3) items per thread
     const int halo_px = NBv * HH * HW;
     // measured: pays only where the kernel is LDS-limited to one workgroup per CU anyway (bf16x3, full-size halo); the bf16 kernel
     // keeps its small register footprint (2-3 workgroups per CU hide the staging latency instead)
-    const bool fast = SPLIT && !UPS && (NBv == 1) && ((p.Cin & 7) == 0) && ((p.Cout & 7) == 0) && (halo_px <= AIT * 32);
+    const bool fast = SPLIT && !UPS && (NBv == 1) && ((p.Cin & 7) == 0) && ((p.Cout & 7) == 0) && (halo_px <= AIT * APP);
     const int a_cg = tid & 7, a_hp0 = tid >> 3;
+    const int d_cg = tid % DCG, d_p0 = tid / DCG;           // dy tile: 128 pixels x DCG groups = 4 items per thread
 
-    for (int tile = blockIdx.x; tile < p.num_tiles; tile += p.splits) {
+    // tile geometry (tile index -> image / patch origin)
+    auto tile_origin = [&](int tile, int& n0, int& y0, int& x0, int& oy, int& ox) {
         int t = tile;
         const int tx = t % p.tiles_x; t /= p.tiles_x;
         const int ty = t % p.tiles_y; const int ng = t / p.tiles_y;
-        const int n0 = ng << p.lNB, y0 = ty << p.lTH, x0 = tx << p.lTW;
-        int oy, ox;
+        n0 = ng << p.lNB; y0 = ty << p.lTH; x0 = tx << p.lTW;
         if (KS == 1) { oy = y0; ox = x0; } else if (UPS) { oy = (y0 >> 1) - 1; ox = (x0 >> 1) - 1; } else { oy = y0 - 1; ox = x0 - 1; }
-
-        __syncthreads();                 // previous tile fully consumed
-        if (SPLIT && !UPS && fast) {
-            // all global loads of the tile (activation halo + dY) are issued back to back and unconditionally (out-of-image
-            // items read pixel 0 and are zeroed afterwards), then transformed and written: one exposed memory latency per tile
-            float4 ald[AIT][2], dld[4][2];
-            int apix[AIT];
-            const int cA = ci0 + a_cg * 8;
-            const bool cokA = cA < p.Cin;
-#pragma unroll
-            for (int k = 0; k < AIT; ++k) {
-                const int hp = a_hp0 + k * 32;
-                const int hx = hp % HW, hy = hp / HW;
-                const int iy = oy + hy, ix = ox + hx;
-                const bool inb = (hp < halo_px) && (n0 < p.N) && (iy >= 0) && (iy < p.Hin) && (ix >= 0) && (ix < p.Win);
-                apix[k] = inb ? ((n0 * p.Hin + iy) * p.Win + ix) : (hp < halo_px ? -1 : -2);
-                const float* src = p.x + (size_t)(apix[k] >= 0 ? apix[k] : 0) * p.Cin + (cokA ? cA : 0);
-                ald[k][0] = *(const float4*)src; ald[k][1] = *(const float4*)(src + 4);
-            }
-            int dpix[4];
-            const int cD = co0 + a_cg * 8;
-            const bool cokD = cD < p.Cout;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int kp = a_hp0 + k * 32;                       // 128 pixels x 8 channel groups = 1024 items = 4 per thread
-                int nb, py, px;
-                tile_lin_decode(kp, p.lTH, p.lTW, nb, py, px);
-                const int n = n0 + nb, yy = y0 + py, xx = x0 + px;
-                dpix[k] = (n < p.N && yy < p.H && xx < p.W) ? ((n * p.H + yy) * p.W + xx) : -1;
-                const float* src = p.dy + (size_t)(dpix[k] >= 0 ? dpix[k] : 0) * p.Cout + (cokD ? cD : 0);
-                dld[k][0] = *(const float4*)src; dld[k][1] = *(const float4*)(src + 4);
-            }
-            float4 s0 = make_float4(1.f, 1.f, 1.f, 1.f), s1 = s0, t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0;
-            if (p.pro == 1) {
-                const float* sp = p.scale + (size_t)(n0 < p.N ? n0 : 0) * p.Cin + (cokA ? cA : 0);
-                const float* tp = p.shift + (size_t)(n0 < p.N ? n0 : 0) * p.Cin + (cokA ? cA : 0);
-                s0 = *(const float4*)sp; s1 = *(const float4*)(sp + 4); t0 = *(const float4*)tp; t1 = *(const float4*)(tp + 4);
-            }
-            const float lo_clamp = (p.pro != 0) ? 0.f : -3.0e38f;
-#pragma unroll
-            for (int k = 0; k < AIT; ++k) {
-                float v[8] = {ald[k][0].x, ald[k][0].y, ald[k][0].z, ald[k][0].w, ald[k][1].x, ald[k][1].y, ald[k][1].z, ald[k][1].w};
-                v[0] = fmaxf(fmaf(v[0], s0.x, t0.x), lo_clamp); v[1] = fmaxf(fmaf(v[1], s0.y, t0.y), lo_clamp);
-                v[2] = fmaxf(fmaf(v[2], s0.z, t0.z), lo_clamp); v[3] = fmaxf(fmaf(v[3], s0.w, t0.w), lo_clamp);
-                v[4] = fmaxf(fmaf(v[4], s1.x, t1.x), lo_clamp); v[5] = fmaxf(fmaf(v[5], s1.y, t1.y), lo_clamp);
-                v[6] = fmaxf(fmaf(v[6], s1.z, t1.z), lo_clamp); v[7] = fmaxf(fmaf(v[7], s1.w, t1.w), lo_clamp);
-                const bool keep = (apix[k] >= 0) && cokA;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = keep ? v[j] : 0.f;
-                s16x8_t hi, lo;
-                cvt8<SPLIT>(v, hi, lo);
-                const int off = (a_hp0 + k * 32) * SA + a_cg * 16;
-                if (apix[k] != -2) {
-                    *(s16x8_t*)(A_hi + off) = hi;
-                    if (SPLIT) *(s16x8_t*)(A_lo + off) = lo;
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float v[8] = {dld[k][0].x, dld[k][0].y, dld[k][0].z, dld[k][0].w, dld[k][1].x, dld[k][1].y, dld[k][1].z, dld[k][1].w};
-                const bool keep = (dpix[k] >= 0) && cokD;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = keep ? v[j] : 0.f;
-                s16x8_t hi, lo;
-                cvt8<SPLIT>(v, hi, lo);
-                const int off = (a_hp0 + k * 32) * SD + a_cg * 16;
-                *(s16x8_t*)(D_hi + off) = hi;
-                if (SPLIT) *(s16x8_t*)(D_lo + off) = lo;
-            }
-        } else {
-        stage_act_halo<CC, SPLIT>(A_hi, A_lo, SA, p.x, p.scale, p.shift, p.pro, p.N, p.Hin, p.Win, p.Cin,
-                                  n0, NBv, HH, HW, oy, ox, ci0, tid);
-        // dy tile: [128 pixels (row-major in patch)][64 co] -> bf16
-        for (int i = tid; i < BMP * 8; i += 256) {
-            int cg = i & 7, kp = i >> 3;
-            int nb, py, px;
-            tile_lin_decode(kp, p.lTH, p.lTW, nb, py, px);
-            int n = n0 + nb, yy = y0 + py, xx = x0 + px, c = co0 + cg * 8;
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = 0.f;
-            if (n < p.N && yy < p.H && xx < p.W && c < p.Cout) {
-                const float* src = p.dy + ((size_t)(n * p.H + yy) * p.W + xx) * p.Cout + c;
-                if ((p.Cout & 3) == 0 && c + 8 <= p.Cout) {
-                    float4 p0 = *(const float4*)src, p1 = *(const float4*)(src + 4);
-                    v[0] = p0.x; v[1] = p0.y; v[2] = p0.z; v[3] = p0.w; v[4] = p1.x; v[5] = p1.y; v[6] = p1.z; v[7] = p1.w;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) if (c + j < p.Cout) v[j] = src[j];
-                }
-            }
-            s16x8_t hi, lo;
-            cvt8<SPLIT>(v, hi, lo);
-            *(s16x8_t*)(D_hi + kp * SD + cg * 16) = hi;
-            if (SPLIT) *(s16x8_t*)(D_lo + kp * SD + cg * 16) = lo;
-        }
-        }
-        __syncthreads();
-
+    };
+    // MFMAs of the tile that is staged in LDS (tile independent: the pixel -> patch decode only depends on the tile shape)
+    auto compute_tile = [&]() {
 #pragma unroll 1
         for (int ks = 0; ks < BMP / 32; ++ks) {
             // this lane (as a SOURCE lane) serves pixel kp(h) = ks*32 + h*16 + G*4 + sj for the two halves h
@@ -190,8 +101,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
                     al[mf] = (s16x8_t){w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
                 }
             }
-#pragma unroll
-            for (int tap = 0; tap < T; ++tap) {
+            // B operand (activated input) fragments of tap t+1 are requested before the MFMAs of tap t (register double buffer):
+            // the bf16x3 kernel runs one wave per SIMD, so nothing else would hide the LDS latency of 8 transposing reads per tap
+            s16x8_t bf[2][2], bfl[2][2];
+            auto fetch_b = [&](int tap, int set) {
                 const int dy = (KS == 3) ? tap / 3 : 0, dx = (KS == 3) ? tap % 3 : 0;
                 int hp0, hp1;
                 if (KS == 1) { hp0 = nb0 * HH * HW + py0 * HW + px0; hp1 = nb1 * HH * HW + py1 * HW + px1; }
@@ -206,20 +119,161 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
                 for (int nf = 0; nf < 2; ++nf) {
                     int coff = (nh * 32 + nf * 16 + 4 * sq) * 2;
                     s16x4_t v0 = tr_read(A_hi + hp0 * SA + coff), v1 = tr_read(A_hi + hp1 * SA + coff);
-                    s16x8_t b = (s16x8_t){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    bf[set][nf] = (s16x8_t){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                     if (SPLIT) {
                         s16x4_t w0 = tr_read(A_lo + hp0 * SA + coff), w1 = tr_read(A_lo + hp1 * SA + coff);
-                        s16x8_t bl = (s16x8_t){w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
+                        bfl[set][nf] = (s16x8_t){w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
+                    }
+                }
+            };
+            fetch_b(0, 0);
+#pragma unroll
+            for (int tap = 0; tap < T; ++tap) {
+                const int cur = tap & 1;
+                if (tap + 1 < T) { fetch_b(tap + 1, cur ^ 1); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+                for (int nf = 0; nf < 2; ++nf) {
+                    if (SPLIT) {
 #pragma unroll
                         for (int mf = 0; mf < 2; ++mf) {
-                            acc[tap][mf][nf] = mfma16(al[mf], b, acc[tap][mf][nf]);
-                            acc[tap][mf][nf] = mfma16(a[mf], bl, acc[tap][mf][nf]);
+                            acc[tap][mf][nf] = mfma16(al[mf], bf[cur][nf], acc[tap][mf][nf]);
+                            acc[tap][mf][nf] = mfma16(a[mf], bfl[cur][nf], acc[tap][mf][nf]);
                         }
                     }
 #pragma unroll
-                    for (int mf = 0; mf < 2; ++mf) acc[tap][mf][nf] = mfma16(a[mf], b, acc[tap][mf][nf]);
+                    for (int mf = 0; mf < 2; ++mf) acc[tap][mf][nf] = mfma16(a[mf], bf[cur][nf], acc[tap][mf][nf]);
                 }
             }
+        }
+    };
+
+    if (SPLIT && !UPS && fast) {
+        // bf16x3: registers and LDS admit one workgroup per CU, so nothing else hides the global latency of the staging loads:
+        // the loads of the NEXT tile are issued before the MFMAs of the current one and converted / written to LDS afterwards
+        // (issue and use inside one loop iteration, unconditional with a clamped tile index -> no early waits).
+        float4 ald[AIT][2], dld[4][2];
+        int apix[AIT], dpix[4];
+        int n0, y0, x0, oy, ox;
+        const int cA = ci0 + a_cg * 8, cD = co0 + d_cg * 8;
+        const bool cokA = cA < p.Cin, cokD = cD < p.Cout;
+        auto issue_loads = [&](int tile) {
+            tile_origin(tile, n0, y0, x0, oy, ox);
+            // all global loads of the tile (activation halo + dY) are issued back to back and unconditionally (out-of-image
+            // items read pixel 0 and are zeroed afterwards), then transformed and written: one exposed memory latency per tile
+#pragma unroll
+            for (int k = 0; k < AIT; ++k) {
+                const int hp = a_hp0 + k * APP;
+                const int hx = hp % HW, hy = hp / HW;
+                const int iy = oy + hy, ix = ox + hx;
+                const bool inb = (hp < halo_px) && (n0 < p.N) && (iy >= 0) && (iy < p.Hin) && (ix >= 0) && (ix < p.Win);
+                apix[k] = inb ? ((n0 * p.Hin + iy) * p.Win + ix) : (hp < halo_px ? -1 : -2);
+                const float* src = p.x + (size_t)(apix[k] >= 0 ? apix[k] : 0) * p.Cin + (cokA ? cA : 0);
+                ald[k][0] = *(const float4*)src; ald[k][1] = *(const float4*)(src + 4);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int kp = d_p0 + k * 32;
+                int nb, py, px;
+                tile_lin_decode(kp, p.lTH, p.lTW, nb, py, px);
+                const int n = n0 + nb, yy = y0 + py, xx = x0 + px;
+                dpix[k] = (n < p.N && yy < p.H && xx < p.W) ? ((n * p.H + yy) * p.W + xx) : -1;
+                const float* src = p.dy + (size_t)(dpix[k] >= 0 ? dpix[k] : 0) * p.Cout + (cokD ? cD : 0);
+                dld[k][0] = *(const float4*)src; dld[k][1] = *(const float4*)(src + 4);
+            }
+        };
+        auto convert_write = [&]() {
+            float4 s0 = make_float4(1.f, 1.f, 1.f, 1.f), s1 = s0, t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0;
+            if (p.pro == 1) {
+                const float* sp = p.scale + (size_t)(n0 < p.N ? n0 : 0) * p.Cin + (cokA ? cA : 0);
+                const float* tp = p.shift + (size_t)(n0 < p.N ? n0 : 0) * p.Cin + (cokA ? cA : 0);
+                s0 = *(const float4*)sp; s1 = *(const float4*)(sp + 4); t0 = *(const float4*)tp; t1 = *(const float4*)(tp + 4);
+            }
+            const float lo_clamp = (p.pro != 0) ? 0.f : -3.0e38f;
+#pragma unroll
+            for (int k = 0; k < AIT; ++k) {
+                float v[8] = {ald[k][0].x, ald[k][0].y, ald[k][0].z, ald[k][0].w, ald[k][1].x, ald[k][1].y, ald[k][1].z, ald[k][1].w};
+                v[0] = fmaxf(fmaf(v[0], s0.x, t0.x), lo_clamp); v[1] = fmaxf(fmaf(v[1], s0.y, t0.y), lo_clamp);
+                v[2] = fmaxf(fmaf(v[2], s0.z, t0.z), lo_clamp); v[3] = fmaxf(fmaf(v[3], s0.w, t0.w), lo_clamp);
+                v[4] = fmaxf(fmaf(v[4], s1.x, t1.x), lo_clamp); v[5] = fmaxf(fmaf(v[5], s1.y, t1.y), lo_clamp);
+                v[6] = fmaxf(fmaf(v[6], s1.z, t1.z), lo_clamp); v[7] = fmaxf(fmaf(v[7], s1.w, t1.w), lo_clamp);
+                const bool keep = (apix[k] >= 0) && cokA;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = keep ? v[j] : 0.f;
+                s16x8_t hi, lo;
+                cvt8<SPLIT>(v, hi, lo);
+                const int off = (a_hp0 + k * APP) * SA + a_cg * 16;
+                if (apix[k] != -2) {
+                    *(s16x8_t*)(A_hi + off) = hi;
+                    if (SPLIT) *(s16x8_t*)(A_lo + off) = lo;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float v[8] = {dld[k][0].x, dld[k][0].y, dld[k][0].z, dld[k][0].w, dld[k][1].x, dld[k][1].y, dld[k][1].z, dld[k][1].w};
+                const bool keep = (dpix[k] >= 0) && cokD;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = keep ? v[j] : 0.f;
+                s16x8_t hi, lo;
+                cvt8<SPLIT>(v, hi, lo);
+                const int off = (d_p0 + k * 32) * SD + d_cg * 16;
+                *(s16x8_t*)(D_hi + off) = hi;
+                if (SPLIT) *(s16x8_t*)(D_lo + off) = lo;
+            }
+        };
+        if (COB == 64) {
+            int tile = blockIdx.x;
+            if (tile < p.num_tiles) { issue_loads(tile); convert_write(); }
+            for (; tile < p.num_tiles; tile += p.splits) {
+                const int next = tile + p.splits;
+                issue_loads(next < p.num_tiles ? next : tile);       // (past the end: harmless re-load of the current tile)
+                __syncthreads();                                     // staged tile visible
+                compute_tile();
+                __syncthreads();                                     // everyone is done reading the tile
+                if (next < p.num_tiles) convert_write();
+            }
+        } else {
+            // 8 waves share 256 registers per SIMD lane pair: no room to hold the next tile's loads across the MFMAs
+            for (int tile = blockIdx.x; tile < p.num_tiles; tile += p.splits) {
+                issue_loads(tile);
+                __syncthreads();                                     // previous tile fully consumed
+                convert_write();
+                __syncthreads();
+                compute_tile();
+            }
+        }
+    } else {
+        for (int tile = blockIdx.x; tile < p.num_tiles; tile += p.splits) {
+            int n0, y0, x0, oy, ox;
+            tile_origin(tile, n0, y0, x0, oy, ox);
+            __syncthreads();                 // previous tile fully consumed
+            stage_act_halo<CC, SPLIT, NT>(A_hi, A_lo, SA, p.x, p.scale, p.shift, p.pro, p.N, p.Hin, p.Win, p.Cin,
+                                      n0, NBv, HH, HW, oy, ox, ci0, tid);
+            // dy tile: [128 pixels (row-major in patch)][64 co] -> bf16
+            for (int i = tid; i < BMP * DCG; i += NT) {
+                int cg = i % DCG, kp = i / DCG;
+                int nb, py, px;
+                tile_lin_decode(kp, p.lTH, p.lTW, nb, py, px);
+                int n = n0 + nb, yy = y0 + py, xx = x0 + px, c = co0 + cg * 8;
+                float v[8];
+    #pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = 0.f;
+                if (n < p.N && yy < p.H && xx < p.W && c < p.Cout) {
+                    const float* src = p.dy + ((size_t)(n * p.H + yy) * p.W + xx) * p.Cout + c;
+                    if ((p.Cout & 3) == 0 && c + 8 <= p.Cout) {
+                        float4 p0 = *(const float4*)src, p1 = *(const float4*)(src + 4);
+                        v[0] = p0.x; v[1] = p0.y; v[2] = p0.z; v[3] = p0.w; v[4] = p1.x; v[5] = p1.y; v[6] = p1.z; v[7] = p1.w;
+                    } else {
+    #pragma unroll
+                        for (int j = 0; j < 8; ++j) if (c + j < p.Cout) v[j] = src[j];
+                    }
+                }
+                s16x8_t hi, lo;
+                cvt8<SPLIT>(v, hi, lo);
+                *(s16x8_t*)(D_hi + kp * SD + cg * 16) = hi;
+                if (SPLIT) *(s16x8_t*)(D_lo + kp * SD + cg * 16) = lo;
+            }
+            __syncthreads();
+            compute_tile();
         }
     }
 
@@ -234,7 +288,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
                 for (int r = 0; r < 4; ++r) {
                     int co = co0 + mh * 32 + mf * 16 + (lane >> 4) * 4 + r;
                     int ci = ci0 + nh * 32 + nf * 16 + (lane & 15);
-                    p.part[(((size_t)blockIdx.x * T + tap) * p.CoP + co) * p.CiP + ci] = acc[tap][mf][nf][r];
+                    if (COB == 64 || co < p.CoP) p.part[(((size_t)blockIdx.x * T + tap) * p.CoP + co) * p.CiP + ci] = acc[tap][mf][nf][r];
                 }
 }
 
@@ -260,10 +314,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 static int ilog2_floor_w(int v) { int l = 0; while ((1 << (l + 1)) <= v) ++l; return l; }
 
-template <int KS, bool UPS, int PREC>
+template <int KS, bool UPS, int PREC, int COB = 64>
 static int launch_wgrad(WgradParams& p, float* dw, hipStream_t stream) {
     constexpr bool SPLIT = (PREC == LP_PREC_BF16X3);
-    constexpr int SA = 64 * 2 + 16, SD = 64 * 2 + 16;
+    constexpr int SA = 64 * 2 + 16, SD = COB * 2 + 16;
     // 128-pixel tiles, row-major inside the patch; TW >= 4 so that 4 consecutive k are 4 consecutive x
     int ltw = ilog2_floor_w(p.W); if (ltw > 4) ltw = 4;
     int lth = ilog2_floor_w(p.H); if (lth > 7 - ltw) lth = 7 - ltw;
@@ -278,15 +332,15 @@ static int launch_wgrad(WgradParams& p, float* dw, hipStream_t stream) {
     if (KS == 1) { HH = TH; HW = TW; } else if (UPS) { HH = TH / 2 + 2; HW = TW / 2 + 2; } else { HH = TH + 2; HW = TW + 2; }
     size_t lds = ((size_t)NBv * HH * HW * SA + 128 * SD) * (SPLIT ? 2 : 1);
     if (lds > 160 * 1024) return lp_set_error(LP_ERR_UNSUPPORTED, "wgrad tile needs too much LDS");
-    auto kern = conv_wgrad_kernel<KS, UPS, PREC>;
+    auto kern = conv_wgrad_kernel<KS, UPS, PREC, COB>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return lp_set_error(LP_ERR_HIP, "hipFuncSetAttribute failed");
         attr_set = true;
     }
-    dim3 grid(p.splits, p.CoP / 64, p.CiP / 64);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
+    dim3 grid(p.splits, (p.CoP + COB - 1) / COB, p.CiP / 64);
+    hipLaunchKernelGGL(kern, grid, dim3(COB * 4), lds, stream, p);
     int rc = lp_check_launch("conv_wgrad");
     if (rc) return rc;
     int total = KS * KS * p.Cout * p.Cin;
@@ -316,6 +370,13 @@ extern "C" int lp_conv_wgrad(const float* x, const float* dy, float* dw, float* 
     hipStream_t s = (hipStream_t)stream;
 #define LP_WG(KS_, UPS_) (prec == LP_PREC_BF16 ? launch_wgrad<KS_, UPS_, LP_PREC_BF16>(p, dw, s) : launch_wgrad<KS_, UPS_, LP_PREC_BF16X3>(p, dw, s))
     if (prec != LP_PREC_BF16 && prec != LP_PREC_BF16X3) return lp_set_error(LP_ERR_ARG, "lp_conv_wgrad: unknown precision");
+    // 128 output channels per workgroup (8 waves) where the layer is wide enough; LP_WGRAD_COB = 64 | 128 overrides
+    static const int cob_env = getenv("LP_WGRAD_COB") ? atoi(getenv("LP_WGRAD_COB")) : 0;
+    const bool cob128 = cob_env ? (cob_env == 128) : true;      // measured: -9 % (bf16x3), -6 % (bf16) on the 64..512-channel layers
+    if (cob128 && Cout >= 128 && ksize == 3) {
+        if (prec == LP_PREC_BF16) return upsample ? launch_wgrad<3, true, LP_PREC_BF16, 128>(p, dw, s) : launch_wgrad<3, false, LP_PREC_BF16, 128>(p, dw, s);
+        return upsample ? launch_wgrad<3, true, LP_PREC_BF16X3, 128>(p, dw, s) : launch_wgrad<3, false, LP_PREC_BF16X3, 128>(p, dw, s);
+    }
     if (ksize == 3 && !upsample) return LP_WG(3, false);
     if (ksize == 3 && upsample) return LP_WG(3, true);
     if (ksize == 1 && !upsample) return LP_WG(1, false);
