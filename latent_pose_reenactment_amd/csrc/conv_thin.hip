@@ -1,0 +1,166 @@
+// Weight gradient of the convs with a THIN side (<= 4 channels) for gfx950: the image-side convs of the critics and the VGG
+// stacks (Cin = 3 -> 64) and the generator head (64 -> 4).  On the MFMA wgrad kernel these pad the thin side to 64 channels
+// (21x / 16x wasted matrix work plus the generic halo staging) and ran at 6-12 TFLOP/s; the work is really a bandwidth-bound
+// reduction over pixels of (wide operand, 64 lanes) x (thin operand, <= 4 values x taps), so it is done in fp32 on the VALU:
+//
+//   dw[co][ci][tap] = sum_{n,y,x} dy[n,y,x,co] * act(x)[n, y+ky-1, x+kx-1, ci]
+//
+// One workgroup walks a strided set of 4-row groups.  The thin operand's rows (with the 1-pixel border, zero padded, channels
+// padded to 4 = one 16-byte LDS word per pixel) are staged in LDS and read back as wave-wide BROADCASTS; the wide operand is
+// streamed from HBM exactly once, 64 consecutive channels per wave (256-byte rows); wave w takes the pixels x = w, w+4, ...
+//   THIN_X:  thin = input x (Cin <= 4, no prologue),  wide = dy;       acc[tap][ci] += dy[p][co] * x[p + tap][ci]
+//   !THIN_X: thin = dy (Cout <= 4),  wide = act(x) (AdaIN/ReLU prologue applied on the fly);
+//                                                                       acc[tap][co] += act(x)[q][ci] * dy[q - tap][co]
+// Partial sums per workgroup go to the workspace and are reduced by wgrad_thin_reduce_kernel (deterministic, no atomics).
+#include "lp_common.h"
+#include "lp_hip.h"
+#include "lp_internal.h"
+
+struct ThinParams {
+    const float* x; const float* dy; float* part; float* dw;
+    const float* scale; const float* shift;
+    int N, H, W, Cin, Cout, pro, G;
+};
+
+template <int KS, bool THIN_X>
+__global__ __launch_bounds__(256) void wgrad_thin_kernel(ThinParams p) {
+    constexpr int T = KS * KS, PAD = KS / 2;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int tid = threadIdx.x, lane = tid & 63, ph = tid >> 6;
+    const int thinC = THIN_X ? p.Cin : p.Cout, wideC = THIN_X ? p.Cout : p.Cin;
+    const int wc = blockIdx.y * 64 + lane;                               // this lane's channel of the wide operand
+    const float* thin = THIN_X ? p.x : p.dy;
+    const float* wide = THIN_X ? p.dy : p.x;
+    const int RW = p.W + 2 * PAD;                                        // staged row width (pixels)
+    float acc[T][4];              // (scalar FMAs: v_pk_fma_f32 pairs measured 1.4x SLOWER here)
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[t][c] = 0.f;
+
+    // a block iteration = RB consecutive rows of one image (+ border rows of the thin operand); the wide operand's loads are
+    // issued UB at a time before they are used, so every wave keeps UB x 256 B in flight (the kernel is a pure HBM stream)
+    constexpr int RB = 4, UB = (KS == 1) ? 16 : 8;
+    const int gpi = (p.H + RB - 1) / RB;                                 // row groups per image
+    for (int grp = blockIdx.x; grp < p.N * gpi; grp += gridDim.x) {
+        const int n = grp / gpi, y0 = (grp % gpi) * RB;
+        __syncthreads();                                                 // previous group fully consumed
+        for (int i = tid; i < (RB + 2 * PAD) * RW; i += 256) {
+            const int r = i / RW, hx = i % RW;
+            const int iy = y0 + r - PAD, ix = hx - PAD;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+                const float* src = thin + ((size_t)(n * p.H + iy) * p.W + ix) * thinC;
+                v.x = src[0];
+                if (thinC > 1) v.y = src[1];
+                if (thinC > 2) v.z = src[2];
+                if (thinC > 3) v.w = src[3];
+            }
+            *(float4*)(sm + (size_t)i * 4) = v;
+        }
+        __syncthreads();
+        float sc = 1.f, sh = 0.f;
+        if (!THIN_X && p.pro == 1) { sc = p.scale[(size_t)n * p.Cin + wc]; sh = p.shift[(size_t)n * p.Cin + wc]; }
+        const int nrow = min(RB, p.H - y0);
+        const int npx = nrow * p.W;                                      // pixels of the group, row-major; this wave: ph, ph+4, ...
+        const float* wbase = wide + (size_t)(n * p.H + y0) * p.W * wideC + wc;
+        for (int j0 = ph; j0 < npx; j0 += 4 * UB) {
+            float av[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int j = j0 + 4 * u;
+                av[u] = wbase[(size_t)(j < npx ? j : 0) * wideC];          // unconditional load, masked below
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int j = j0 + 4 * u;
+                float a = av[u];
+                if (!THIN_X && p.pro != 0) a = fmaxf(fmaf(a, sc, sh), 0.f);
+                a = j < npx ? a : 0.f;
+                const int rr = j / p.W, xx = j - rr * p.W;
+                const int jr = j < npx ? rr : 0;
+#pragma unroll
+                for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < KS; ++kx) {
+                        // THIN_X: x pixel (y+ky-1, xx+kx-1) -> staged row rr+ky, column xx+kx.   else: dy pixel (y-ky+1, xx-kx+1)
+                        // -> staged row rr+2-ky (rows y0-1..), column xx-kx+2
+                        const int r = jr + (THIN_X ? ky : (KS - 1 - ky)), c = THIN_X ? (xx + kx) : (xx + KS - 1 - kx);
+                        const float4 v = *(const float4*)(sm + ((size_t)r * RW + c) * 4);
+                        acc[ky * KS + kx][0] = fmaf(a, v.x, acc[ky * KS + kx][0]);
+                        acc[ky * KS + kx][1] = fmaf(a, v.y, acc[ky * KS + kx][1]);
+                        acc[ky * KS + kx][2] = fmaf(a, v.z, acc[ky * KS + kx][2]);
+                        acc[ky * KS + kx][3] = fmaf(a, v.w, acc[ky * KS + kx][3]);
+                    }
+            }
+        }
+    }
+    // sum the four pixel phases (waves) through LDS, then one partial slab per workgroup: part[wg][tap][thin c][wide c]
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sm[((ph * T + t) * 4 + c) * 64 + lane] = acc[t][c];
+    __syncthreads();
+    for (int i = tid; i < T * 4 * 64; i += 256) {
+        const float s = (sm[i] + sm[T * 256 + i]) + (sm[2 * T * 256 + i] + sm[3 * T * 256 + i]);
+        const int l = i & 63, c = (i >> 6) & 3, t = i >> 8;
+        if (c < thinC) p.part[(((size_t)blockIdx.x * T + t) * thinC + c) * wideC + blockIdx.y * 64 + l] = s;
+    }
+}
+
+// dw[co][ci][tap] = sum_wg part[wg][tap][thin][wide]
+template <bool THIN_X>
+__global__ __launch_bounds__(256) void wgrad_thin_reduce_kernel(ThinParams p, int T) {
+    const int thinC = THIN_X ? p.Cin : p.Cout, wideC = THIN_X ? p.Cout : p.Cin;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= T * thinC * wideC) return;
+    const int w = idx % wideC, c = (idx / wideC) % thinC, t = idx / (wideC * thinC);
+    const size_t slab = (size_t)T * thinC * wideC;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int g = 0;
+    for (; g + 4 <= p.G; g += 4) {
+        a0 += p.part[(size_t)g * slab + idx]; a1 += p.part[(size_t)(g + 1) * slab + idx];
+        a2 += p.part[(size_t)(g + 2) * slab + idx]; a3 += p.part[(size_t)(g + 3) * slab + idx];
+    }
+    for (; g < p.G; ++g) a0 += p.part[(size_t)g * slab + idx];
+    const int co = THIN_X ? w : c, ci = THIN_X ? c : w;
+    p.dw[((size_t)co * p.Cin + ci) * T + t] = (a0 + a1) + (a2 + a3);
+}
+
+bool lp_wgrad_thin_supported(int Cin, int Cout, int ksize, int upsample, int pro) {
+    if (upsample || (ksize != 1 && ksize != 3)) return false;
+    if (Cin <= 4 && Cout % 64 == 0 && pro == 0) return true;
+    if (Cout <= 4 && Cin % 64 == 0 && ksize == 3) return true;
+    return false;
+}
+
+// workspace: the caller's lp_conv_wgrad workspace (splits * T * 64 * 64k floats) holds G <= 16 * splits slabs of T * 4 * wide
+int lp_wgrad_thin(const float* x, const float* dy, float* dw, float* workspace, const float* scale, const float* shift, int N, int H,
+                  int W, int Cin, int Cout, int ksize, int pro, int splits, hipStream_t stream) {
+    const bool thin_x = (Cin <= 4 && Cout % 64 == 0 && pro == 0);
+    ThinParams p;
+    p.x = x; p.dy = dy; p.part = workspace; p.dw = dw; p.scale = scale; p.shift = shift;
+    p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.pro = pro;
+    int G = N * ((H + 3) / 4);                  // row groups (RB = 4 rows each)
+    if (G > 16 * splits) G = 16 * splits;
+    if (G > 2048) G = 2048;
+    p.G = G;
+    const int T = ksize * ksize, wide = thin_x ? Cout : Cin, thinC = thin_x ? Cin : Cout;
+    const size_t stage = (size_t)(4 + 2 * (ksize / 2)) * (W + 2 * (ksize / 2)) * 16, red = (size_t)4 * T * 4 * 64 * 4;
+    const size_t lds = stage > red ? stage : red;
+    if (lds > 64 * 1024) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_conv_wgrad (thin): image row too wide for LDS");
+    dim3 grid(G, wide / 64);
+    if (thin_x) {
+        if (ksize == 3) hipLaunchKernelGGL((wgrad_thin_kernel<3, true>), grid, dim3(256), lds, stream, p);
+        else hipLaunchKernelGGL((wgrad_thin_kernel<1, true>), grid, dim3(256), lds, stream, p);
+    } else {
+        hipLaunchKernelGGL((wgrad_thin_kernel<3, false>), grid, dim3(256), lds, stream, p);
+    }
+    int rc = lp_check_launch("wgrad_thin");
+    if (rc) return rc;
+    const int total = T * thinC * wide;
+    if (thin_x) hipLaunchKernelGGL(wgrad_thin_reduce_kernel<true>, dim3((total + 255) / 256), dim3(256), 0, stream, p, T);
+    else hipLaunchKernelGGL(wgrad_thin_reduce_kernel<false>, dim3((total + 255) / 256), dim3(256), 0, stream, p, T);
+    return lp_check_launch("wgrad_thin_reduce");
+}

@@ -362,6 +362,12 @@ extern "C" int lp_conv_wgrad(const float* x, const float* dy, float* dw, float* 
     if (pro == 1 && (!scale || !shift)) return lp_set_error(LP_ERR_ARG, "lp_conv_wgrad: pro=1 needs scale/shift");
     if (splits < 1) return lp_set_error(LP_ERR_ARG, "lp_conv_wgrad: splits must be >= 1");
     if (upsample && ((H | W) & 1)) return lp_set_error(LP_ERR_ARG, "lp_conv_wgrad: upsampled dims must be even");
+    if (prec != LP_PREC_BF16 && prec != LP_PREC_BF16X3) return lp_set_error(LP_ERR_ARG, "lp_conv_wgrad: unknown precision");
+    {   // <= 4 channels on one side (image-side convs, generator head): bandwidth-bound fp32 reduction, not an MFMA problem
+        static const int thin_env = getenv("LP_WGRAD_THIN") ? atoi(getenv("LP_WGRAD_THIN")) : 1;
+        if (thin_env && lp_wgrad_thin_supported(Cin, Cout, ksize, upsample, pro))
+            return lp_wgrad_thin(x, dy, dw, workspace, scale, shift, N, H, W, Cin, Cout, ksize, pro, splits, (hipStream_t)stream);
+    }
     WgradParams p;
     p.x = x; p.dy = dy; p.part = workspace; p.scale = scale; p.shift = shift;
     p.N = N; p.H = H; p.W = W; p.Hin = upsample ? H / 2 : H; p.Win = upsample ? W / 2 : W;

@@ -3,3 +3,8 @@
 #include <hip/hip_runtime.h>
 int lp_set_error(int code, const char* msg);
 int lp_check_launch(const char* what);
+
+// conv_thin.hip: fp32 VALU weight gradient for convs with <= 4 channels on one side
+bool lp_wgrad_thin_supported(int Cin, int Cout, int ksize, int upsample, int pro);
+int lp_wgrad_thin(const float* x, const float* dy, float* dw, float* workspace, const float* scale, const float* shift, int N, int H,
+                  int W, int Cin, int Cout, int ksize, int pro, int splits, hipStream_t stream);

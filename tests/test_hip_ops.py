@@ -121,6 +121,10 @@ WGRAD_CASES = [
     (2, 32, 32, 16, 8, 3, 1, 1),
     (2, 16, 16, 3, 64, 3, 0, 0),
     (2, 64, 64, 64, 64, 3, 0, 1),
+    (2, 20, 12, 3, 64, 1, 0, 0),        # thin-side fp32 kernels: 1x1 image-side skip conv, odd image size
+    (3, 12, 20, 3, 128, 3, 0, 0),
+    (2, 20, 12, 128, 4, 3, 0, 2),       # generator-head shape with a plain ReLU prologue
+    (2, 16, 16, 64, 3, 3, 0, 0),
 ]
 
 
