@@ -582,6 +582,12 @@ extern "C" int lp_conv_fwd(const float* x, const uint16_t* w_hi, const uint16_t*
     if (upsample && ((H | W) & 1)) return lp_set_error(LP_ERR_ARG, "lp_conv_fwd: upsampled output dims must be even");
     if (CinP % 32 || CinP < Cin || CoutP % 128 || CoutP < Cout) return lp_set_error(LP_ERR_ARG, "lp_conv_fwd: bad padded dims");
     if (H < 2 || W < 2) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_conv_fwd: H,W must be >= 2");
+    {   // RGB -> 64 first convs: direct fp32 kernel (conv_thin.hip); LP_CONV_THIN=0 sends them through the MFMA kernel instead
+        static const int thin_env = getenv("LP_CONV_THIN") ? atoi(getenv("LP_CONV_THIN")) : 1;
+        if (thin_env && lp_conv_thin_fwd_supported(Cin, Cout, ksize, upsample, pro, res != nullptr, W))
+            return lp_conv_thin_fwd(x, w_hi, prec == LP_PREC_BF16X3 ? w_lo : nullptr, y, bias, alpha, N, H, W, Cin, Cout, CinP, CoutP, ksize,
+                                    (hipStream_t)stream);
+    }
     ConvParams p;
     p.x = x; p.w_hi = w_hi; p.w_lo = w_lo; p.y = y; p.scale = scale; p.shift = shift; p.bias = bias; p.res = res; p.alpha = alpha;
     p.N = N; p.H = H; p.W = W; p.Hin = upsample ? H / 2 : H; p.Win = upsample ? W / 2 : W;

@@ -22,7 +22,8 @@ struct ThinParams {
     int N, H, W, Cin, Cout, pro, G;
 };
 
-template <int KS, bool THIN_X>
+// C4: the thin side really has 4 channels (else <= 3: the fourth FMA per tap is skipped)
+template <int KS, bool THIN_X, bool C4>
 __global__ __launch_bounds__(256) void wgrad_thin_kernel(ThinParams p) {
     constexpr int T = KS * KS, PAD = KS / 2;
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) void wgrad_thin_kernel(ThinParams p) {
                         acc[ky * KS + kx][0] = fmaf(a, v.x, acc[ky * KS + kx][0]);
                         acc[ky * KS + kx][1] = fmaf(a, v.y, acc[ky * KS + kx][1]);
                         acc[ky * KS + kx][2] = fmaf(a, v.z, acc[ky * KS + kx][2]);
-                        acc[ky * KS + kx][3] = fmaf(a, v.w, acc[ky * KS + kx][3]);
+                        if (C4) acc[ky * KS + kx][3] = fmaf(a, v.w, acc[ky * KS + kx][3]);
                     }
             }
         }
@@ -151,11 +152,15 @@ int lp_wgrad_thin(const float* x, const float* dy, float* dw, float* workspace, 
     const size_t lds = stage > red ? stage : red;
     if (lds > 64 * 1024) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_conv_wgrad (thin): image row too wide for LDS");
     dim3 grid(G, wide / 64);
+    const bool c4 = thinC == 4;
     if (thin_x) {
-        if (ksize == 3) hipLaunchKernelGGL((wgrad_thin_kernel<3, true>), grid, dim3(256), lds, stream, p);
-        else hipLaunchKernelGGL((wgrad_thin_kernel<1, true>), grid, dim3(256), lds, stream, p);
+        if (ksize == 3) { if (c4) hipLaunchKernelGGL((wgrad_thin_kernel<3, true, true>), grid, dim3(256), lds, stream, p);
+                          else hipLaunchKernelGGL((wgrad_thin_kernel<3, true, false>), grid, dim3(256), lds, stream, p); }
+        else { if (c4) hipLaunchKernelGGL((wgrad_thin_kernel<1, true, true>), grid, dim3(256), lds, stream, p);
+               else hipLaunchKernelGGL((wgrad_thin_kernel<1, true, false>), grid, dim3(256), lds, stream, p); }
     } else {
-        hipLaunchKernelGGL((wgrad_thin_kernel<3, false>), grid, dim3(256), lds, stream, p);
+        if (c4) hipLaunchKernelGGL((wgrad_thin_kernel<3, false, true>), grid, dim3(256), lds, stream, p);
+        else hipLaunchKernelGGL((wgrad_thin_kernel<3, false, false>), grid, dim3(256), lds, stream, p);
     }
     int rc = lp_check_launch("wgrad_thin");
     if (rc) return rc;
@@ -163,4 +168,99 @@ int lp_wgrad_thin(const float* x, const float* dy, float* dw, float* workspace, 
     if (thin_x) hipLaunchKernelGGL(wgrad_thin_reduce_kernel<true>, dim3((total + 255) / 256), dim3(256), 0, stream, p, T);
     else hipLaunchKernelGGL(wgrad_thin_reduce_kernel<false>, dim3((total + 255) / 256), dim3(256), 0, stream, p, T);
     return lp_check_launch("wgrad_thin_reduce");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Forward conv with <= 4 input channels (RGB -> 64: first conv of the critics and of both VGG stacks).  27 MACs per output:
+// the MFMA kernel pads K to 9 x 32 and stages a 32-channel halo for 3 real channels.  Here the image rows are staged in LDS
+// (one 16-byte word per pixel), every lane owns one output channel with its 9 x 4 weights in registers (decoded from the
+// bf16 (hi [+ lo]) pack, i.e. the same weight values the MFMA path would use), pixels are broadcast from LDS, and the output
+// row is written 256 bytes per wave-store.  fp32 activations are used as they are (more exact than the bf16 operand path).
+// ------------------------------------------------------------------------------------------------------------------
+struct ThinFwdParams {
+    const float* x; const uint16_t* w_hi; const uint16_t* w_lo; float* y; const float* bias; const float* alpha;
+    int N, H, W, Cin, Cout, CinP, CoutP;
+};
+
+template <int KS, bool C4>
+__global__ __launch_bounds__(256) void conv_thin_fwd_kernel(ThinFwdParams p) {
+    constexpr int T = KS * KS, PAD = KS / 2, RB = 4, UB = 4;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int tid = threadIdx.x, lane = tid & 63, ph = tid >> 6;
+    const int co = blockIdx.y * 64 + lane;
+    const int RW = p.W + 2 * PAD;
+    float w[T][4];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const size_t idx = ((size_t)t * p.CoutP + co) * p.CinP + c;         // pack layout [tap][CoutP][CinP], zero padded
+            float v = __uint_as_float((unsigned)p.w_hi[idx] << 16);
+            if (p.w_lo) v += __uint_as_float((unsigned)p.w_lo[idx] << 16);
+            w[t][c] = v;
+        }
+    const float alpha = p.alpha ? *p.alpha : 1.f;
+    const float bias = p.bias ? p.bias[co] : 0.f;
+    const int gpi = (p.H + RB - 1) / RB;
+    for (int grp = blockIdx.x; grp < p.N * gpi; grp += gridDim.x) {
+        const int n = grp / gpi, y0 = (grp % gpi) * RB;
+        __syncthreads();
+        for (int i = tid; i < (RB + 2 * PAD) * RW; i += 256) {
+            const int r = i / RW, hx = i % RW;
+            const int iy = y0 + r - PAD, ix = hx - PAD;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+                const float* src = p.x + ((size_t)(n * p.H + iy) * p.W + ix) * p.Cin;
+                v.x = src[0];
+                if (p.Cin > 1) v.y = src[1];
+                if (p.Cin > 2) v.z = src[2];
+                if (p.Cin > 3) v.w = src[3];
+            }
+            *(float4*)(sm + (size_t)i * 4) = v;
+        }
+        __syncthreads();
+        const int nrow = min(RB, p.H - y0), npx = nrow * p.W;
+        float* ybase = p.y + (size_t)(n * p.H + y0) * p.W * p.Cout + co;
+        for (int j0 = ph; j0 < npx; j0 += 4 * UB) {
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int j = j0 + 4 * u;
+                if (j < npx) {
+                    const int rr = j / p.W, xx = j - rr * p.W;
+                    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+                    for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < KS; ++kx) {
+                            const float4 v = *(const float4*)(sm + ((size_t)(rr + ky) * RW + xx + kx) * 4);
+                            const int t = ky * KS + kx;
+                            a0 = fmaf(v.x, w[t][0], a0); a1 = fmaf(v.y, w[t][1], a1);
+                            a0 = fmaf(v.z, w[t][2], a0); if (C4) a1 = fmaf(v.w, w[t][3], a1);
+                        }
+                    ybase[(size_t)j * p.Cout] = fmaf(a0 + a1, alpha, bias);
+                }
+            }
+        }
+    }
+}
+
+bool lp_conv_thin_fwd_supported(int Cin, int Cout, int ksize, int upsample, int pro, bool has_res, int W) {
+    return Cin <= 4 && (Cout % 64) == 0 && !upsample && pro == 0 && !has_res && (ksize == 1 || ksize == 3) &&
+           (size_t)(4 + 2) * (W + 2) * 16 <= 64 * 1024;
+}
+
+int lp_conv_thin_fwd(const float* x, const uint16_t* w_hi, const uint16_t* w_lo, float* y, const float* bias, const float* alpha, int N,
+                     int H, int W, int Cin, int Cout, int CinP, int CoutP, int ksize, hipStream_t stream) {
+    ThinFwdParams p;
+    p.x = x; p.w_hi = w_hi; p.w_lo = w_lo; p.y = y; p.bias = bias; p.alpha = alpha;
+    p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.CinP = CinP; p.CoutP = CoutP;
+    int G = N * ((H + 3) / 4);
+    if (G > 2048) G = 2048;
+    const size_t lds = (size_t)(4 + 2 * (ksize / 2)) * (W + 2 * (ksize / 2)) * 16;
+    dim3 grid(G, Cout / 64);
+    if (ksize == 3) { if (Cin == 4) hipLaunchKernelGGL((conv_thin_fwd_kernel<3, true>), grid, dim3(256), lds, stream, p);
+                      else hipLaunchKernelGGL((conv_thin_fwd_kernel<3, false>), grid, dim3(256), lds, stream, p); }
+    else { if (Cin == 4) hipLaunchKernelGGL((conv_thin_fwd_kernel<1, true>), grid, dim3(256), lds, stream, p);
+           else hipLaunchKernelGGL((conv_thin_fwd_kernel<1, false>), grid, dim3(256), lds, stream, p); }
+    return lp_check_launch("conv_thin_fwd");
 }

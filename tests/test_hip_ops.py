@@ -57,6 +57,8 @@ CONV_CASES = [
     (2, 16, 16, 128, 24, 1, 0, 2, 1, -1),
     (1, 32, 32, 16, 8, 3, 0, 2, 1, 0),
     (2, 64, 64, 64, 64, 3, 0, 1, 0, -1),
+    (2, 20, 12, 3, 128, 1, 0, 0, 1, -1),      # direct fp32 kernel for <= 4 input channels: 1x1, odd image size
+    (3, 12, 20, 3, 64, 3, 0, 0, 1, -1),
 ]
 
 
