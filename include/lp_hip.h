@@ -39,11 +39,13 @@ int lp_pack_weights(const float* w, uint16_t* hi, uint16_t* lo, int Cout, int Ci
  * blocks.py:18-26) + relu + nn.Upsample(nearest x2) + F.conv2d + W/sigma scaling (spectral_norm) + residual add.
  *   x [N][H/(up?2:1)][W/(up?2:1)][Cin], y [N][H][W][Cout], scale/shift [N][Cin] (pro=1), bias [Cout]|NULL,
  *   res [N][H>>res_shift][W>>res_shift][Cout]|NULL, alpha device scalar|NULL (=1).
- *   pro: 0 identity, 1 relu(x*scale+shift), 2 relu(x).  ksize 1|3.  Also the dgrad kernel (dY in, mode-1 pack). */
+ *   pro: 0 identity, 1 relu(x*scale+shift), 2 relu(x).  ksize 1|3.  Also the dgrad kernel (dY in, mode-1 pack).
+ *   relu_mask [N][H][W][Cout]|NULL: the output is zeroed where relu_mask <= 0 -- the backward of the ReLU that preceded the conv
+ *   whose data gradient this launch computes (replaces a separate dx = dA * (x > 0) pass; blocks.py:89-111 pre-activation). */
 int lp_conv_fwd(const float* x, const uint16_t* w_hi, const uint16_t* w_lo, float* y,
                 const float* scale, const float* shift, const float* bias, const float* res, const float* alpha,
                 int N, int H, int W, int Cin, int Cout, int CinP, int CoutP,
-                int ksize, int upsample, int pro, int res_shift, int prec, void* stream);
+                int ksize, int upsample, int pro, int res_shift, int prec, const float* relu_mask, void* stream);
 
 /* Weight gradient: dw[co][ci][t] = sum_{n,y,x} dy[n,y,x,co] * up2?(act(x))[n,y+dy_t,x+dx_t,ci]  (autograd of F.conv2d
  * w.r.t. weight, blocks.py:76-88).  Two launches: partial slabs over `splits` pixel ranges, then a reduction that also
@@ -108,6 +110,7 @@ int lp_mt_ema(const void* table, int num_tensors, long long max_numel, float alp
  * float* part; int rows; int cols; float eps; int pad;} (lp_sn_desc_bytes() each), one per layer; `part` = scratch of
  * ceil(rows/lp_sn_row_block())*cols + rows floats.  do_iter=1 (train): v <- normalize(W^T u), u <- normalize(W v) in place;
  * always: u_out/v_out = the vectors used, sig_out = {sigma = u^T W v, 1/sigma}.  Four launches, row-blocked over many workgroups.
+ * (dot = scratch of 512 floats: per-block partial sums of <g, w_orig>, no memset needed)
  * lp_sn_grad_apply: g/sigma - (<g, w_orig>/sigma^2) u v^T (autograd of W/sigma with u, v constant), written in place on g, or
  * added to `accum` when that is non-NULL (fused accumulation into the parameter's .grad; g is then left untouched); dot = scratch. */
 int lp_sn_desc_bytes(void);

@@ -20,7 +20,7 @@ SIGNATURES = {
     'lp_last_error': (ctypes.c_char_p, []),
     'lp_abi_version': (_i, []),
     'lp_pack_weights': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    'lp_conv_fwd': (_i, [_vp] * 9 + [_i] * 12 + [_vp]),
+    'lp_conv_fwd': (_i, [_vp] * 9 + [_i] * 12 + [_vp, _vp]),
     'lp_conv_wgrad_workspace_bytes': (_ll, [_i, _i, _i, _i]),
     'lp_conv_wgrad': (_i, [_vp] * 6 + [_i] * 10 + [_vp]),
     'lp_instnorm_workspace_bytes': (_ll, [_i, _i, _i]),

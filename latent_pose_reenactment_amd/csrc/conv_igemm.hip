@@ -23,6 +23,7 @@ extern "C" void lp_dbg_set_prof(unsigned long long* ptr) { g_prof = ptr; }
 struct ConvParams {
     const float* x; const uint16_t* w_hi; const uint16_t* w_lo; float* y;
     const float* scale; const float* shift; const float* bias; const float* res; const float* alpha;
+    const float* mask;        // epilogue: y = 0 where mask <= 0 (fused ReLU backward of the dgrad launch)
     int N, H, W, Hin, Win, Cin, Cout, CinP, CoutP;
     int res_shift, pro;
     int lTH, lTW, lNB, tiles_x, tiles_y;
@@ -415,6 +416,10 @@ void conv_igemm_kernel(ConvParams p) {
                                                                 + (oxx >> p.res_shift)) * p.Cout + co);
                     v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
                 }
+                if (p.mask) {
+                    const float4 mv = *(const float4*)(p.mask + ((size_t)(n * p.H + oyy) * p.W + oxx) * p.Cout + co);
+                    v.x = mv.x > 0.f ? v.x : 0.f; v.y = mv.y > 0.f ? v.y : 0.f; v.z = mv.z > 0.f ? v.z : 0.f; v.w = mv.w > 0.f ? v.w : 0.f;
+                }
                 *(float4*)(p.y + ((size_t)(n * p.H + oyy) * p.W + oxx) * p.Cout + co) = v;
             }
         }
@@ -442,6 +447,7 @@ void conv_igemm_kernel(ConvParams p) {
                         if (p.bias) v += p.bias[co];
                         if (p.res) v += p.res[rpix + co];
                     }
+                    if (p.mask && !(p.mask[pix + co] > 0.f)) v = 0.f;          // (0/1 mask: commutes with the split-K sum)
                     if (p.ksplit == 1) p.y[pix + co] = v;
                     else unsafeAtomicAdd(p.y + pix + co, v);       // y was zeroed by lp_conv_fwd (hipMemsetAsync on the stream)
                 }
@@ -575,7 +581,7 @@ static int dispatch_conv(ConvParams& p, int ks, int ups, hipStream_t s) {
 extern "C" int lp_conv_fwd(const float* x, const uint16_t* w_hi, const uint16_t* w_lo, float* y,
                            const float* scale, const float* shift, const float* bias, const float* res, const float* alpha,
                            int N, int H, int W, int Cin, int Cout, int CinP, int CoutP,
-                           int ksize, int upsample, int pro, int res_shift, int prec, void* stream) {
+                           int ksize, int upsample, int pro, int res_shift, int prec, const float* relu_mask, void* stream) {
     if (!x || !w_hi || !y) return lp_set_error(LP_ERR_ARG, "lp_conv_fwd: null pointer");
     if (pro == 1 && (!scale || !shift)) return lp_set_error(LP_ERR_ARG, "lp_conv_fwd: pro=1 needs scale/shift");
     if (prec == LP_PREC_BF16X3 && !w_lo) return lp_set_error(LP_ERR_ARG, "lp_conv_fwd: bf16x3 needs w_lo");
@@ -584,12 +590,12 @@ extern "C" int lp_conv_fwd(const float* x, const uint16_t* w_hi, const uint16_t*
     if (H < 2 || W < 2) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_conv_fwd: H,W must be >= 2");
     {   // RGB -> 64 first convs: direct fp32 kernel (conv_thin.hip); LP_CONV_THIN=0 sends them through the MFMA kernel instead
         static const int thin_env = getenv("LP_CONV_THIN") ? atoi(getenv("LP_CONV_THIN")) : 1;
-        if (thin_env && lp_conv_thin_fwd_supported(Cin, Cout, ksize, upsample, pro, res != nullptr, W))
+        if (thin_env && !relu_mask && lp_conv_thin_fwd_supported(Cin, Cout, ksize, upsample, pro, res != nullptr, W))
             return lp_conv_thin_fwd(x, w_hi, prec == LP_PREC_BF16X3 ? w_lo : nullptr, y, bias, alpha, N, H, W, Cin, Cout, CinP, CoutP, ksize,
                                     (hipStream_t)stream);
     }
     ConvParams p;
-    p.x = x; p.w_hi = w_hi; p.w_lo = w_lo; p.y = y; p.scale = scale; p.shift = shift; p.bias = bias; p.res = res; p.alpha = alpha;
+    p.x = x; p.w_hi = w_hi; p.w_lo = w_lo; p.y = y; p.scale = scale; p.shift = shift; p.bias = bias; p.res = res; p.alpha = alpha; p.mask = relu_mask;
     p.N = N; p.H = H; p.W = W; p.Hin = upsample ? H / 2 : H; p.Win = upsample ? W / 2 : W;
     p.Cin = Cin; p.Cout = Cout; p.CinP = CinP; p.CoutP = CoutP; p.res_shift = res_shift; p.pro = pro;
 #ifdef LP_DBG

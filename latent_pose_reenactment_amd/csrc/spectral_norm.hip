@@ -157,7 +157,9 @@ extern "C" int lp_sn_power_iter(const void* table, int num_layers, int do_iter, 
     return lp_check_launch("sn_power_iter");
 }
 
-// <g, w> with both operands contiguous (coalesced), one atomic per block
+// <g, w> with both operands contiguous (coalesced): one partial sum per block into dot[blockIdx.x] (<= SN_DOT_BLOCKS blocks;
+// deterministic, and no memset of an accumulator is needed)
+#define SN_DOT_BLOCKS 512
 __global__ __launch_bounds__(256) void sn_dot_kernel(const float* __restrict__ g, const float* __restrict__ w, float* __restrict__ dot,
                                                      long long total) {
     __shared__ float red[4];
@@ -165,19 +167,24 @@ __global__ __launch_bounds__(256) void sn_dot_kernel(const float* __restrict__ g
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) a = fmaf(g[i], w[i], a);
     a = block_sum_256(a, red);
-    if (threadIdx.x == 0) unsafeAtomicAdd(dot, a);
+    if (threadIdx.x == 0) dot[blockIdx.x] = a;
 }
 
 // dW_orig = alpha * G - (<G, W_orig> * alpha^2) * u v^T  (legacy-hook autograd: u, v constants), written in place
 // on G, or -- `accum` given -- added to accum (the parameter's .grad: fused gradient accumulation, G untouched).
 // <G, W_orig> is computed first (sn_dot_kernel, scratch scalar `dot`).
-__global__ void sn_grad_apply_kernel(float* __restrict__ g, const float* __restrict__ u, const float* __restrict__ v,
-                                     const float* __restrict__ sig, const float* __restrict__ dot, float* __restrict__ accum, int R,
-                                     int C) {
+__global__ __launch_bounds__(256) void sn_grad_apply_kernel(float* __restrict__ g, const float* __restrict__ u,
+                                                            const float* __restrict__ v, const float* __restrict__ sig,
+                                                            const float* __restrict__ dot, int ndot, float* __restrict__ accum, int R,
+                                                            int C) {
+    __shared__ float red[4];
+    float d = 0.f;
+    for (int j = threadIdx.x; j < ndot; j += 256) d += dot[j];          // every block re-sums the (<= 512, L2-resident) partials
+    d = block_sum_256(d, red);
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)R * C) return;
     const float alpha = sig[1];
-    const float k = dot[0] * alpha * alpha;
+    const float k = d * alpha * alpha;
     int r = (int)(i / C), c = (int)(i % C);
     const float val = fmaf(alpha, g[i], -k * u[r] * v[c]);
     if (accum) accum[i] += val; else g[i] = val;
@@ -187,10 +194,9 @@ extern "C" int lp_sn_grad_apply(float* g, const float* w_orig, const float* u, c
                                 float* accum, int rows, int cols, void* stream) {
     if (!g || !w_orig || !u || !v || !sig || !dot) return lp_set_error(LP_ERR_ARG, "lp_sn_grad_apply: null pointer");
     long long total = (long long)rows * cols;
-    if (hipMemsetAsync(dot, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) return lp_set_error(LP_ERR_HIP, "hipMemsetAsync failed");
-    int db = (int)((total + 1023) / 1024); if (db > 512) db = 512; if (db < 1) db = 1;
+    int db = (int)((total + 1023) / 1024); if (db > SN_DOT_BLOCKS) db = SN_DOT_BLOCKS; if (db < 1) db = 1;
     hipLaunchKernelGGL(sn_dot_kernel, dim3(db), dim3(256), 0, (hipStream_t)stream, g, w_orig, dot, total);
     hipLaunchKernelGGL(sn_grad_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, u, v, sig, dot,
-                       accum, rows, cols);
+                       db, accum, rows, cols);
     return lp_check_launch("sn_grad_apply");
 }

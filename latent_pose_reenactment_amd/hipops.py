@@ -77,15 +77,18 @@ def pack_weights(w: Tensor, mode: int, prec: int, small_k: bool = False) -> Weig
 
 def conv(x: Tensor, pack: WeightPack, *, ksize: int, upsample: bool = False, pro: int = 0, scale: Optional[Tensor] = None,
          shift: Optional[Tensor] = None, bias: Optional[Tensor] = None, res: Optional[Tensor] = None, res_shift: int = 0,
-         alpha: Optional[Tensor] = None, prec: int = PREC_BF16) -> Tensor:
-    """y = alpha * conv(up2?(act(x)), pack) + bias + res ; x [N,Hin,Win,Cin] -> y [N,H,W,Cout]."""
+         alpha: Optional[Tensor] = None, prec: int = PREC_BF16, relu_mask: Optional[Tensor] = None) -> Tensor:
+    """y = alpha * conv(up2?(act(x)), pack) + bias + res ; x [N,Hin,Win,Cin] -> y [N,H,W,Cout].
+    ``relu_mask`` [N,H,W,Cout]: y is zeroed where relu_mask <= 0 (fused ReLU backward when this launch is a data gradient)."""
     _chk(x, 'x')
     n, hin, win, cin = x.shape
     assert cin == pack.cols and pack.taps == ksize * ksize, (x.shape, pack.rows, pack.cols, pack.taps)
     h, w = (hin * 2, win * 2) if upsample else (hin, win)
     cout = pack.rows
     y = torch.empty((n, h, w, cout), dtype=torch.float32, device=x.device)
-    for t, nm in ((scale, 'scale'), (shift, 'shift'), (bias, 'bias'), (res, 'res')):
+    if relu_mask is not None:
+        assert relu_mask.shape == (n, h, w, cout), (relu_mask.shape, (n, h, w, cout))
+    for t, nm in ((scale, 'scale'), (shift, 'shift'), (bias, 'bias'), (res, 'res'), (relu_mask, 'relu_mask')):
         if t is not None:
             _chk(t, nm)
     if res is not None:
@@ -93,7 +96,7 @@ def conv(x: Tensor, pack: WeightPack, *, ksize: int, upsample: bool = False, pro
     with _Timed('conv_igemm', 2.0 * n * h * w * cout * cin * ksize * ksize, (n, h, w, cin, cout, ksize, int(upsample), pro)):
         check(_lib.lib().lp_conv_fwd(x.data_ptr(), pack.hi.data_ptr(), _p(pack.lo), y.data_ptr(), _p(scale), _p(shift), _p(bias),
                                      _p(res), _p(alpha), n, h, w, cin, cout, pack.cols_p, pack.rows_p, ksize, int(upsample), pro,
-                                     res_shift, prec, _stream()), 'lp_conv_fwd')
+                                     res_shift, prec, _p(relu_mask), _stream()), 'lp_conv_fwd')
     return y
 
 
@@ -113,7 +116,7 @@ def conv_wgrad(x: Tensor, dy: Tensor, *, ksize: int, upsample: bool = False, pro
     ws_bytes = _lib.lib().lp_conv_wgrad_workspace_bytes(cin, cout, ksize, splits)
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
     dw = torch.empty((cout, cin, ksize, ksize), dtype=torch.float32, device=x.device)
-    dot = torch.empty(1, dtype=torch.float32, device=x.device) if sn is not None else None
+    dot = torch.empty(512, dtype=torch.float32, device=x.device) if sn is not None else None      # per-block partials of <g, W>
     with _Timed('conv_wgrad', 2.0 * n * h * w * cout * cin * ksize * ksize, (n, h, w, cin, cout, ksize, int(upsample), pro)):
         check(_lib.lib().lp_conv_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), _p(scale), _p(shift), n, h, w, cin,
                                        cout, ksize, int(upsample), pro, splits, prec, _stream()), 'lp_conv_wgrad')

@@ -546,8 +546,8 @@ class ConvFn(torch.autograd.Function):
                 packT = packs[key]
             else:
                 packT = packs[1] if packs is not None else ops.pack_weights(wd, 1, prec, small_k=(ksize == 3 and wd.shape[0] <= 32))
-            dA = ops.conv(dy, packT, ksize=ksize, alpha=None if sn is None else sn[2][1:], prec=prec)
-            dx = ops.relu_bwd(dA, x) if pro == 2 else dA
+            # pro == 2: the forward applied ReLU to x first -> dx = dA * (x > 0), fused into the dgrad launch's epilogue
+            dx = ops.conv(dy, packT, ksize=ksize, alpha=None if sn is None else sn[2][1:], prec=prec, relu_mask=x if pro == 2 else None)
         if ctx.needs_input_grad[1]:
             dw = ops.conv_wgrad(x, dy, ksize=ksize, pro=pro, prec=prec, sn=None if sn is None else (wd,) + tuple(sn),
                                 accum=None if ctx.w_param is None else _accum_target(ctx.w_param))

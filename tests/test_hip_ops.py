@@ -113,6 +113,25 @@ def test_conv_dgrad(case, prec):
     report(f'conv_dgrad{case} prec={prec}', rel(da.permute(0, 3, 1, 2), a.grad), TOL[prec])
 
 
+@pytest.mark.parametrize('prec', [1, 0])
+@pytest.mark.parametrize('case', [(2, 16, 16, 64, 128, 3), (8, 4, 4, 128, 256, 3), (2, 32, 32, 6, 64, 3), (2, 64, 64, 64, 64, 1)])
+def test_conv_dgrad_fused_relu_mask(case, prec):
+    """dgrad launch with the ReLU backward fused in its epilogue == separate conv + lp_relu_bwd (coalesced, split-K and
+    narrow-channel epilogues)"""
+    ops = _ops()
+    n, h, w, cin, cout, ks = case
+    g = torch.Generator().manual_seed(9)
+    wgt = (torch.randn(cout, cin, ks, ks, generator=g) / (cin * ks * ks) ** 0.5).cuda()
+    dy = torch.randn(n, h, w, cout, generator=g).cuda()
+    x = torch.randn(n, h, w, cin, generator=g).cuda()
+    pack = ops.pack_weights(wgt, 1, prec, small_k=(ks == 3 and cout <= 32))
+    two = ops.relu_bwd(ops.conv(dy, pack, ksize=ks, prec=prec), x)
+    one = ops.conv(dy, pack, ksize=ks, prec=prec, relu_mask=x)
+    torch.cuda.synchronize()
+    assert torch.equal((one == 0), (two == 0))
+    report(f'dgrad_mask{case} prec={prec}', rel(one, two), 1e-6)
+
+
 WGRAD_CASES = [
     # N, H(out), W, Cin, Cout, ks, ups, pro
     (2, 8, 8, 64, 64, 3, 0, 1),
