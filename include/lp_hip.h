@@ -49,11 +49,15 @@ int lp_conv_fwd(const float* x, const uint16_t* w_hi, const uint16_t* w_lo, floa
 
 /* Weight gradient: dw[co][ci][t] = sum_{n,y,x} dy[n,y,x,co] * up2?(act(x))[n,y+dy_t,x+dx_t,ci]  (autograd of F.conv2d
  * w.r.t. weight, blocks.py:76-88).  Two launches: partial slabs over `splits` pixel ranges, then a reduction that also
- * writes the reference [Cout][Cin][k][k] layout.  workspace: lp_conv_wgrad_workspace_bytes(). */
+ * writes the reference [Cout][Cin][k][k] layout.  workspace: lp_conv_wgrad_workspace_bytes().
+ * dbias [Cout]|NULL: also emit the bias gradient sum_{n,y,x} dy[n,y,x,co] (the kernel streams dy anyway; replaces a separate
+ * column-sum pass).  Not produced (left untouched, return code LP_OK) for Cout <= 4: check lp_conv_wgrad_has_dbias(). */
 long long lp_conv_wgrad_workspace_bytes(int Cin, int Cout, int ksize, int splits);
+int lp_conv_wgrad_has_dbias(int Cin, int Cout, int ksize, int upsample, int pro);
 int lp_conv_wgrad(const float* x, const float* dy, float* dw, float* workspace,
                   const float* scale, const float* shift,
-                  int N, int H, int W, int Cin, int Cout, int ksize, int upsample, int pro, int splits, int prec, void* stream);
+                  int N, int H, int W, int Cin, int Cout, int ksize, int upsample, int pro, int splits, int prec, float* dbias,
+                  void* stream);
 
 /* Instance-norm statistics of x [N][H*W][C] and the AdaIN scale/shift derived from them (blocks.py:18-26):
  *   mean/rstd [N][C] (biased variance, eps), scale = rstd*gamma, shift = beta - mean*scale.

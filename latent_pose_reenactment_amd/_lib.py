@@ -22,7 +22,8 @@ SIGNATURES = {
     'lp_pack_weights': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'lp_conv_fwd': (_i, [_vp] * 9 + [_i] * 12 + [_vp, _vp]),
     'lp_conv_wgrad_workspace_bytes': (_ll, [_i, _i, _i, _i]),
-    'lp_conv_wgrad': (_i, [_vp] * 6 + [_i] * 10 + [_vp]),
+    'lp_conv_wgrad_has_dbias': (_i, [_i] * 5),
+    'lp_conv_wgrad': (_i, [_vp] * 6 + [_i] * 10 + [_vp, _vp]),
     'lp_instnorm_workspace_bytes': (_ll, [_i, _i, _i]),
     'lp_instnorm_stats': (_i, [_vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'lp_adain_bwd_workspace_bytes': (_ll, [_i, _i, _i]),

@@ -18,6 +18,7 @@
 
 struct ThinParams {
     const float* x; const float* dy; float* part; float* dw;
+    float* bpart; float* dbias;      // NULL | [G][Cout] partial column sums of dy (THIN_X only) and the bias gradient they reduce to
     const float* scale; const float* shift;
     int N, H, W, Cin, Cout, pro, G;
 };
@@ -33,6 +34,7 @@ __global__ __launch_bounds__(256) void wgrad_thin_kernel(ThinParams p) {
     const float* thin = THIN_X ? p.x : p.dy;
     const float* wide = THIN_X ? p.dy : p.x;
     const int RW = p.W + 2 * PAD;                                        // staged row width (pixels)
+    float bsum = 0.f;                                                    // THIN_X: column sum of dy (bias gradient)
     float acc[T][4];              // (scalar FMAs: v_pk_fma_f32 pairs measured 1.4x SLOWER here)
 #pragma unroll
     for (int t = 0; t < T; ++t)
@@ -78,6 +80,7 @@ __global__ __launch_bounds__(256) void wgrad_thin_kernel(ThinParams p) {
                 float a = av[u];
                 if (!THIN_X && p.pro != 0) a = fmaxf(fmaf(a, sc, sh), 0.f);
                 a = j < npx ? a : 0.f;
+                if (THIN_X) bsum += a;
                 const int rr = j / p.W, xx = j - rr * p.W;
                 const int jr = j < npx ? rr : 0;
 #pragma unroll
@@ -108,6 +111,12 @@ __global__ __launch_bounds__(256) void wgrad_thin_kernel(ThinParams p) {
         const int l = i & 63, c = (i >> 6) & 3, t = i >> 8;
         if (c < thinC) p.part[(((size_t)blockIdx.x * T + t) * thinC + c) * wideC + blockIdx.y * 64 + l] = s;
     }
+    if (THIN_X && p.bpart) {
+        __syncthreads();
+        sm[tid] = bsum;
+        __syncthreads();
+        if (tid < 64) p.bpart[(size_t)blockIdx.x * wideC + blockIdx.y * 64 + tid] = (sm[tid] + sm[64 + tid]) + (sm[128 + tid] + sm[192 + tid]);
+    }
 }
 
 // dw[co][ci][tap] = sum_wg part[wg][tap][thin][wide]
@@ -115,6 +124,16 @@ template <bool THIN_X>
 __global__ __launch_bounds__(256) void wgrad_thin_reduce_kernel(ThinParams p, int T) {
     const int thinC = THIN_X ? p.Cin : p.Cout, wideC = THIN_X ? p.Cout : p.Cin;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (THIN_X && p.bpart && idx < wideC) {
+        float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+        int g = 0;
+        for (; g + 4 <= p.G; g += 4) {
+            b0 += p.bpart[(size_t)g * wideC + idx]; b1 += p.bpart[(size_t)(g + 1) * wideC + idx];
+            b2 += p.bpart[(size_t)(g + 2) * wideC + idx]; b3 += p.bpart[(size_t)(g + 3) * wideC + idx];
+        }
+        for (; g < p.G; ++g) b0 += p.bpart[(size_t)g * wideC + idx];
+        p.dbias[idx] = (b0 + b1) + (b2 + b3);
+    }
     if (idx >= T * thinC * wideC) return;
     const int w = idx % wideC, c = (idx / wideC) % thinC, t = idx / (wideC * thinC);
     const size_t slab = (size_t)T * thinC * wideC;
@@ -138,7 +157,7 @@ bool lp_wgrad_thin_supported(int Cin, int Cout, int ksize, int upsample, int pro
 
 // workspace: the caller's lp_conv_wgrad workspace (splits * T * 64 * 64k floats) holds G <= 16 * splits slabs of T * 4 * wide
 int lp_wgrad_thin(const float* x, const float* dy, float* dw, float* workspace, const float* scale, const float* shift, int N, int H,
-                  int W, int Cin, int Cout, int ksize, int pro, int splits, hipStream_t stream) {
+                  int W, int Cin, int Cout, int ksize, int pro, int splits, float* dbias, hipStream_t stream) {
     const bool thin_x = (Cin <= 4 && Cout % 64 == 0 && pro == 0);
     ThinParams p;
     p.x = x; p.dy = dy; p.part = workspace; p.dw = dw; p.scale = scale; p.shift = shift;
@@ -146,7 +165,11 @@ int lp_wgrad_thin(const float* x, const float* dy, float* dw, float* workspace, 
     int G = N * ((H + 3) / 4);                  // row groups (RB = 4 rows each)
     if (G > 16 * splits) G = 16 * splits;
     if (G > 2048) G = 2048;
+    const bool want_b = thin_x && dbias != nullptr;
+    if (want_b && G > splits) G = splits;          // the [G][Cout] bias partials live in the workspace's [splits][CoP] tail
     p.G = G;
+    p.bpart = want_b ? workspace + (size_t)splits * ksize * ksize * ((Cout + 63) / 64 * 64) * ((Cin + 63) / 64 * 64) : nullptr;
+    p.dbias = dbias;
     const int T = ksize * ksize, wide = thin_x ? Cout : Cin, thinC = thin_x ? Cin : Cout;
     const size_t stage = (size_t)(4 + 2 * (ksize / 2)) * (W + 2 * (ksize / 2)) * 16, red = (size_t)4 * T * 4 * 64 * 4;
     const size_t lds = stage > red ? stage : red;

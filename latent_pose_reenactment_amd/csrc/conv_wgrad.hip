@@ -14,6 +14,7 @@
 
 struct WgradParams {
     const float* x; const float* dy; float* part;
+    float* bpart;          // NULL | [splits][CoP] partial bias gradients (column sums of dy), written by the ci-block-0 workgroups
     const float* scale; const float* shift;
     int N, H, W, Hin, Win, Cin, Cout, CoP, CiP;
     int pro, splits, num_tiles;
@@ -60,6 +61,8 @@ __global__ __launch_bounds__(COB * 4) void conv_wgrad_kernel(WgradParams p) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[t][i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
+    // bias gradient: every thread stages dy items of ONE 8-channel group (tid % DCG) -> private fp32 column sums, combined at the end
+    float dsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // source-lane role for the transposing reads
     const int G = lane >> 4, sj = (lane & 15) >> 2, sq = lane & 3;
     // fast staging (one image per tile, channel counts multiple of 8): 8 channel groups x 32 pixels per pass of the block
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(COB * 4) void conv_wgrad_kernel(WgradParams p) {
                 float v[8] = {dld[k][0].x, dld[k][0].y, dld[k][0].z, dld[k][0].w, dld[k][1].x, dld[k][1].y, dld[k][1].z, dld[k][1].w};
                 const bool keep = (dpix[k] >= 0) && cokD;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = keep ? v[j] : 0.f;
+                for (int j = 0; j < 8; ++j) { v[j] = keep ? v[j] : 0.f; dsum[j] += v[j]; }
                 s16x8_t hi, lo;
                 cvt8<SPLIT>(v, hi, lo);
                 const int off = (d_p0 + k * 32) * SD + d_cg * 16;
@@ -267,6 +270,8 @@ __global__ __launch_bounds__(COB * 4) void conv_wgrad_kernel(WgradParams p) {
                         for (int j = 0; j < 8; ++j) if (c + j < p.Cout) v[j] = src[j];
                     }
                 }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dsum[j] += v[j];
                 s16x8_t hi, lo;
                 cvt8<SPLIT>(v, hi, lo);
                 *(s16x8_t*)(D_hi + kp * SD + cg * 16) = hi;
@@ -277,6 +282,18 @@ __global__ __launch_bounds__(COB * 4) void conv_wgrad_kernel(WgradParams p) {
         }
     }
 
+    if (p.bpart && blockIdx.z == 0) {                      // (uniform) column sums of dy over this workgroup's tiles
+        __syncthreads();
+        float* red = (float*)smem;                         // [NT / DCG][COB]
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[(tid / DCG) * COB + (tid % DCG) * 8 + j] = dsum[j];
+        __syncthreads();
+        if (tid < COB) {
+            float s = 0.f;
+            for (int r = 0; r < NT / DCG; ++r) s += red[r * COB + tid];
+            if (co0 + tid < p.CoP) p.bpart[(size_t)blockIdx.x * p.CoP + co0 + tid] = s;
+        }
+    }
     // write the partial slab [split][tap][CoP][CiP]; C layout: row (co) = (lane>>4)*4 + r, col (ci) = lane&15
 #pragma unroll
     for (int tap = 0; tap < T; ++tap)
@@ -295,7 +312,26 @@ __global__ __launch_bounds__(COB * 4) void conv_wgrad_kernel(WgradParams p) {
 // dw[co][ci][tap] = sum_s part[s][tap][co][ci].  One thread per (tap, co, ci) with ci fastest -> every partial read is
 // coalesced; 8 independent accumulators keep 8 loads in flight per thread (the slabs are streamed once from HBM/L2).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int S, int T,
-                                                           int Cout, int Cin, int CoP, int CiP) {
+                                                           int Cout, int Cin, int CoP, int CiP, const float* __restrict__ bpart,
+                                                           float* __restrict__ dbias, int wblocks) {
+    if ((int)blockIdx.x >= wblocks) {                 // trailing blocks: dbias[co] = sum_s bpart[s][co], 64 channels per block,
+        __shared__ float red[4][64];                  // the splits dealt to 4 thread groups x 4 independent accumulators
+        const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+        const int co = (blockIdx.x - wblocks) * 64 + c;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        if (co < Cout) {
+            int k = g;
+            for (; k + 12 < S; k += 16) {
+                a0 += bpart[(size_t)k * CoP + co]; a1 += bpart[(size_t)(k + 4) * CoP + co];
+                a2 += bpart[(size_t)(k + 8) * CoP + co]; a3 += bpart[(size_t)(k + 12) * CoP + co];
+            }
+            for (; k < S; k += 4) a0 += bpart[(size_t)k * CoP + co];
+        }
+        red[g][c] = (a0 + a1) + (a2 + a3);
+        __syncthreads();
+        if (g == 0 && co < Cout) dbias[co] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+        return;
+    }
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= T * Cout * Cin) return;
     int ci = idx % Cin, r = idx / Cin;
@@ -315,7 +351,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 static int ilog2_floor_w(int v) { int l = 0; while ((1 << (l + 1)) <= v) ++l; return l; }
 
 template <int KS, bool UPS, int PREC, int COB = 64>
-static int launch_wgrad(WgradParams& p, float* dw, hipStream_t stream) {
+static int launch_wgrad(WgradParams& p, float* dw, float* dbias, hipStream_t stream) {
     constexpr bool SPLIT = (PREC == LP_PREC_BF16X3);
     constexpr int SA = 64 * 2 + 16, SD = COB * 2 + 16;
     // 128-pixel tiles, row-major inside the patch; TW >= 4 so that 4 consecutive k are 4 consecutive x
@@ -331,6 +367,7 @@ static int launch_wgrad(WgradParams& p, float* dw, hipStream_t stream) {
     int HH, HW;
     if (KS == 1) { HH = TH; HW = TW; } else if (UPS) { HH = TH / 2 + 2; HW = TW / 2 + 2; } else { HH = TH + 2; HW = TW + 2; }
     size_t lds = ((size_t)NBv * HH * HW * SA + 128 * SD) * (SPLIT ? 2 : 1);
+    if (lds < (size_t)COB * 4 * 8 * sizeof(float)) lds = (size_t)COB * 4 * 8 * sizeof(float);      // bias-gradient reduction scratch
     if (lds > 160 * 1024) return lp_set_error(LP_ERR_UNSUPPORTED, "wgrad tile needs too much LDS");
     auto kern = conv_wgrad_kernel<KS, UPS, PREC, COB>;
     static bool attr_set = false;
@@ -344,20 +381,27 @@ static int launch_wgrad(WgradParams& p, float* dw, hipStream_t stream) {
     int rc = lp_check_launch("conv_wgrad");
     if (rc) return rc;
     int total = KS * KS * p.Cout * p.Cin;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, p.part, dw, p.splits, KS * KS,
-                       p.Cout, p.Cin, p.CoP, p.CiP);
+    const int wblocks = (total + 255) / 256, bblocks = p.bpart ? (p.Cout + 63) / 64 : 0;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wblocks + bblocks), dim3(256), 0, stream, p.part, dw, p.splits, KS * KS,
+                       p.Cout, p.Cin, p.CoP, p.CiP, p.bpart, dbias, wblocks);
     return lp_check_launch("wgrad_reduce");
 }
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 extern "C" long long lp_conv_wgrad_workspace_bytes(int Cin, int Cout, int ksize, int splits) {
-    return (long long)splits * ksize * ksize * round_up(Cout, 64) * round_up(Cin, 64) * 4;
+    // [splits][taps][CoP][CiP] weight-gradient slabs, then [splits][CoP] bias-gradient partials
+    return (long long)splits * ksize * ksize * round_up(Cout, 64) * round_up(Cin, 64) * 4 + (long long)splits * round_up(Cout, 64) * 4;
+}
+
+extern "C" int lp_conv_wgrad_has_dbias(int Cin, int Cout, int ksize, int upsample, int pro) {
+    (void)Cin; (void)ksize; (void)upsample; (void)pro;
+    return Cout > 4;           // the thin-dy kernel (Cout <= 4) leaves the 4-value bias gradient to the caller
 }
 
 extern "C" int lp_conv_wgrad(const float* x, const float* dy, float* dw, float* workspace, const float* scale, const float* shift,
                              int N, int H, int W, int Cin, int Cout, int ksize, int upsample, int pro, int splits, int prec,
-                             void* stream) {
+                             float* dbias, void* stream) {
     if (!x || !dy || !dw || !workspace) return lp_set_error(LP_ERR_ARG, "lp_conv_wgrad: null pointer");
     if (pro == 1 && (!scale || !shift)) return lp_set_error(LP_ERR_ARG, "lp_conv_wgrad: pro=1 needs scale/shift");
     if (splits < 1) return lp_set_error(LP_ERR_ARG, "lp_conv_wgrad: splits must be >= 1");
@@ -366,22 +410,23 @@ extern "C" int lp_conv_wgrad(const float* x, const float* dy, float* dw, float* 
     {   // <= 4 channels on one side (image-side convs, generator head): bandwidth-bound fp32 reduction, not an MFMA problem
         static const int thin_env = getenv("LP_WGRAD_THIN") ? atoi(getenv("LP_WGRAD_THIN")) : 1;
         if (thin_env && lp_wgrad_thin_supported(Cin, Cout, ksize, upsample, pro))
-            return lp_wgrad_thin(x, dy, dw, workspace, scale, shift, N, H, W, Cin, Cout, ksize, pro, splits, (hipStream_t)stream);
+            return lp_wgrad_thin(x, dy, dw, workspace, scale, shift, N, H, W, Cin, Cout, ksize, pro, splits, dbias, (hipStream_t)stream);
     }
     WgradParams p;
     p.x = x; p.dy = dy; p.part = workspace; p.scale = scale; p.shift = shift;
     p.N = N; p.H = H; p.W = W; p.Hin = upsample ? H / 2 : H; p.Win = upsample ? W / 2 : W;
     p.Cin = Cin; p.Cout = Cout; p.CoP = round_up(Cout, 64); p.CiP = round_up(Cin, 64);
     p.pro = pro; p.splits = splits;
+    p.bpart = (dbias && Cout > 4) ? workspace + (size_t)splits * ksize * ksize * p.CoP * p.CiP : nullptr;
     hipStream_t s = (hipStream_t)stream;
-#define LP_WG(KS_, UPS_) (prec == LP_PREC_BF16 ? launch_wgrad<KS_, UPS_, LP_PREC_BF16>(p, dw, s) : launch_wgrad<KS_, UPS_, LP_PREC_BF16X3>(p, dw, s))
+#define LP_WG(KS_, UPS_) (prec == LP_PREC_BF16 ? launch_wgrad<KS_, UPS_, LP_PREC_BF16>(p, dw, dbias, s) : launch_wgrad<KS_, UPS_, LP_PREC_BF16X3>(p, dw, dbias, s))
     if (prec != LP_PREC_BF16 && prec != LP_PREC_BF16X3) return lp_set_error(LP_ERR_ARG, "lp_conv_wgrad: unknown precision");
     // 128 output channels per workgroup (8 waves) where the layer is wide enough; LP_WGRAD_COB = 64 | 128 overrides
     static const int cob_env = getenv("LP_WGRAD_COB") ? atoi(getenv("LP_WGRAD_COB")) : 0;
     const bool cob128 = cob_env ? (cob_env == 128) : true;      // measured: -9 % (bf16x3), -6 % (bf16) on the 64..512-channel layers
     if (cob128 && Cout >= 128 && ksize == 3) {
-        if (prec == LP_PREC_BF16) return upsample ? launch_wgrad<3, true, LP_PREC_BF16, 128>(p, dw, s) : launch_wgrad<3, false, LP_PREC_BF16, 128>(p, dw, s);
-        return upsample ? launch_wgrad<3, true, LP_PREC_BF16X3, 128>(p, dw, s) : launch_wgrad<3, false, LP_PREC_BF16X3, 128>(p, dw, s);
+        if (prec == LP_PREC_BF16) return upsample ? launch_wgrad<3, true, LP_PREC_BF16, 128>(p, dw, dbias, s) : launch_wgrad<3, false, LP_PREC_BF16, 128>(p, dw, dbias, s);
+        return upsample ? launch_wgrad<3, true, LP_PREC_BF16X3, 128>(p, dw, dbias, s) : launch_wgrad<3, false, LP_PREC_BF16X3, 128>(p, dw, dbias, s);
     }
     if (ksize == 3 && !upsample) return LP_WG(3, false);
     if (ksize == 3 && upsample) return LP_WG(3, true);

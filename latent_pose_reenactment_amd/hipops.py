@@ -102,11 +102,13 @@ def conv(x: Tensor, pack: WeightPack, *, ksize: int, upsample: bool = False, pro
 
 def conv_wgrad(x: Tensor, dy: Tensor, *, ksize: int, upsample: bool = False, pro: int = 0, scale: Optional[Tensor] = None,
                shift: Optional[Tensor] = None, prec: int = PREC_BF16, splits: Optional[int] = None, sn=None,
-               accum: Optional[Tensor] = None) -> Optional[Tensor]:
+               accum: Optional[Tensor] = None, bias_grad: bool = False):
     """dw [Cout,Cin,k,k] = sum_pixels dy (x) up2?(act(x)) (shifted by tap).
     ``sn`` = (w_orig, u, v, sig): the layer is spectrally normalised (forward used alpha = 1/sigma in the conv epilogue); the
     returned gradient is then w.r.t. W_orig: dw/sigma - <dw, W_orig>/sigma^2 u v^T.
-    ``accum`` (with ``sn``): add that gradient to this tensor (the parameter's .grad) instead and return None."""
+    ``accum`` (with ``sn``): add that gradient to this tensor (the parameter's .grad) instead and return None.
+    ``bias_grad``: return ``(dw, db)`` with db [Cout] = sum_pixels dy, produced by the same launch (the kernel streams dy anyway)
+    or, for the <= 4-channel head where the kernel does not emit it, by a column sum."""
     _chk(x, 'x'); _chk(dy, 'dy')
     n, h, w, cout = dy.shape
     cin = x.shape[3]
@@ -117,9 +119,14 @@ def conv_wgrad(x: Tensor, dy: Tensor, *, ksize: int, upsample: bool = False, pro
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
     dw = torch.empty((cout, cin, ksize, ksize), dtype=torch.float32, device=x.device)
     dot = torch.empty(512, dtype=torch.float32, device=x.device) if sn is not None else None      # per-block partials of <g, W>
+    db = None
+    if bias_grad and _lib.lib().lp_conv_wgrad_has_dbias(cin, cout, ksize, int(upsample), pro):
+        db = torch.empty(cout, dtype=torch.float32, device=x.device)
     with _Timed('conv_wgrad', 2.0 * n * h * w * cout * cin * ksize * ksize, (n, h, w, cin, cout, ksize, int(upsample), pro)):
         check(_lib.lib().lp_conv_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), _p(scale), _p(shift), n, h, w, cin,
-                                       cout, ksize, int(upsample), pro, splits, prec, _stream()), 'lp_conv_wgrad')
+                                       cout, ksize, int(upsample), pro, splits, prec, _p(db), _stream()), 'lp_conv_wgrad')
+    if bias_grad and db is None:
+        db = dy.sum(dim=(0, 1, 2))
     if sn is not None:
         w_orig, u, v, sig = sn
         if accum is not None:
@@ -127,8 +134,8 @@ def conv_wgrad(x: Tensor, dy: Tensor, *, ksize: int, upsample: bool = False, pro
         check(_lib.lib().lp_sn_grad_apply(dw.data_ptr(), w_orig.data_ptr(), u.data_ptr(), v.data_ptr(), sig.data_ptr(), dot.data_ptr(),
                                           _p(accum), cout, cin * ksize * ksize, _stream()), 'lp_sn_grad_apply')
         if accum is not None:
-            return None
-    return dw
+            dw = None
+    return (dw, db) if bias_grad else dw
 
 
 def instnorm_stats(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], eps: float

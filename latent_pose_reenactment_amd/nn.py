@@ -327,8 +327,8 @@ class _DecoderFunction(torch.autograd.Function):
         ch = blocks[-1][1]
         dz = ops.head_bwd(t, d_rgbs.contiguous(), None if d_segm is None else d_segm.contiguous())
         wi = len(wl) - 2
-        grads[wi] = ops.conv_wgrad(x, dz, ksize=3, pro=1, scale=sth[2], shift=sth[3], prec=prec, sn=snw(wi), accum=_accum_target(params[wi]))
-        grads[wi + 1] = dz.sum(dim=(0, 1, 2))
+        grads[wi], grads[wi + 1] = ops.conv_wgrad(x, dz, ksize=3, pro=1, scale=sth[2], shift=sth[3], prec=prec, sn=snw(wi),
+                                                   accum=_accum_target(params[wi]), bias_grad=True)
         pT = ops.pack_weights(wl[wi].contiguous(), 1, prec, small_k=True)
         dA = ops.conv(dz, pT, ksize=3, alpha=sn[wi][2][1:], prec=prec)
         g, dg, db = slices(oh, ch)
@@ -354,8 +354,8 @@ class _DecoderFunction(torch.autograd.Function):
             if has_skip:
                 ws = wl[wi + 2]
                 ds = ops.sum2x2(d_out) if up else d_out
-                grads[wi + 2] = ops.conv_wgrad(x, ds, ksize=1, prec=prec, sn=snw(wi + 2), accum=_accum_target(params[wi + 2]))
-                grads[wi + 3] = ds.sum(dim=(0, 1, 2))
+                grads[wi + 2], grads[wi + 3] = ops.conv_wgrad(x, ds, ksize=1, prec=prec, sn=snw(wi + 2), accum=_accum_target(params[wi + 2]),
+                                                              bias_grad=True)
                 dx_skip = ops.conv(ds, ops.pack_weights(ws.contiguous(), 1, prec), ksize=1, alpha=sn[wi + 2][2][1:], prec=prec)
             else:
                 dx_skip = d_out
@@ -548,10 +548,13 @@ class ConvFn(torch.autograd.Function):
                 packT = packs[1] if packs is not None else ops.pack_weights(wd, 1, prec, small_k=(ksize == 3 and wd.shape[0] <= 32))
             # pro == 2: the forward applied ReLU to x first -> dx = dA * (x > 0), fused into the dgrad launch's epilogue
             dx = ops.conv(dy, packT, ksize=ksize, alpha=None if sn is None else sn[2][1:], prec=prec, relu_mask=x if pro == 2 else None)
+        want_db = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             dw = ops.conv_wgrad(x, dy, ksize=ksize, pro=pro, prec=prec, sn=None if sn is None else (wd,) + tuple(sn),
-                                accum=None if ctx.w_param is None else _accum_target(ctx.w_param))
-        if has_bias and ctx.needs_input_grad[2]:
+                                accum=None if ctx.w_param is None else _accum_target(ctx.w_param), bias_grad=want_db)
+            if want_db:
+                dw, db = dw
+        elif want_db:
             db = dy.sum(dim=(0, 1, 2))
         if has_res and ctx.needs_input_grad[3]:
             dres = dy

@@ -163,9 +163,11 @@ def test_conv_wgrad(case, prec):
     wgt = torch.zeros(cout, cin, ks, ks, dtype=torch.float64, requires_grad=True)
     F.conv2d(act_ref(x, pro, scale, shift, ups), wgt, None, 1, ks // 2).backward(dy)
     f32 = lambda t: t.float().cuda().contiguous()
-    dw = ops.conv_wgrad(f32(nhwc(x)), f32(nhwc(dy)), ksize=ks, upsample=bool(ups), pro=pro, scale=f32(scale), shift=f32(shift), prec=prec)
+    dw, db = ops.conv_wgrad(f32(nhwc(x)), f32(nhwc(dy)), ksize=ks, upsample=bool(ups), pro=pro, scale=f32(scale), shift=f32(shift), prec=prec,
+                            bias_grad=True)
     torch.cuda.synchronize()
     report(f'conv_wgrad{case} prec={prec}', rel(dw, wgt.grad), TOL[prec])
+    report(f'conv_wgrad bias grad{case}', rel(db, dy.sum(dim=(0, 2, 3))), 1e-5)       # fp32 column sums of dy, same launch
 
 
 @pytest.mark.parametrize('shape', [(2, 4, 4, 64), (3, 16, 16, 128), (2, 128, 128, 16), (1, 32, 32, 8), (2, 32, 32, 4)])
