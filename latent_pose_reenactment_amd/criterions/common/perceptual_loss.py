@@ -15,7 +15,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from latent_pose_reenactment_amd import hipops as ops
-from latent_pose_reenactment_amd.nn import AvgPool2Fn, default_prec, hip_conv, hip_l1, to_nhwc
+from latent_pose_reenactment_amd.nn import AvgPool2Fn, default_prec, hip_conv, hip_l1_tap, to_nhwc
 
 CFG = {
     'vgg19': [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512, 512, 'M', 512, 512, 512, 512, 'M'],
@@ -85,14 +85,21 @@ class PerceptualLoss(nn.Module):
             cache[key] = packs
         return cache[key]
 
-    def _features(self, x, packs, prec, taps):
+    def _features(self, x, packs, prec, taps, targets=None):
+        """``targets`` None: collect the taps (pre-ReLU conv outputs; the ReLU is fused into their consumers) into ``taps``.
+        ``targets`` = taps of the other image: append the L1 term of every tap instead (the tap tensor flows on through
+        L1TapFn so that its two gradients are summed inside the L1 backward kernel)."""
         cur, pending_relu = to_nhwc(x), False
         for i, layer in enumerate(self.model):
             if isinstance(layer, nn.Conv2d):
                 cur = hip_conv(cur, layer.weight, layer.bias, ksize=3, pro=2 if pending_relu else 0, prec=prec, packs=packs[i])
                 pending_relu = True
             elif isinstance(layer, nn.ReLU):
-                taps.append(cur)                 # pre-ReLU conv output; the ReLU is fused into its consumers
+                if targets is None:
+                    taps.append(cur)
+                else:
+                    cur, term = hip_l1_tap(cur, targets[len(taps)], relu_in=True)
+                    taps.append(term)
             else:
                 cur = AvgPool2Fn.apply(cur, pending_relu)
                 pending_relu = False
@@ -107,8 +114,7 @@ class PerceptualLoss(nn.Module):
         with torch.no_grad():
             ft = self.normalize_inputs((target.detach() + 1) / 2)
             taps_t = self._features(ft, packs, prec, [])
-        taps_i = self._features(fi, packs, prec, [])
         loss = 0
-        for a, b in zip(taps_i, taps_t):
-            loss = loss + hip_l1(a, b, relu_in=True)
+        for term in self._features(fi, packs, prec, [], targets=taps_t):
+            loss = loss + term
         return loss * self.weight

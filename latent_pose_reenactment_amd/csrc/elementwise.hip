@@ -444,9 +444,9 @@ __global__ __launch_bounds__(256) void l1_partial_kernel(const float4* __restric
     if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
-// da = coef * g[0] * sign(relu?(a) - relu?(b)) * (relu_in ? [a>0] : 1)
+// da = coef * g[0] * sign(relu?(a) - relu?(b)) * (relu_in ? [a>0] : 1)  (+ add: the gradient arriving at `a` from its other consumer)
 __global__ void l1_bwd_kernel(const float4* __restrict__ a, const float4* __restrict__ b, const float* __restrict__ g, float coef,
-                              float4* __restrict__ da, long long total4, int relu_in) {
+                              const float4* __restrict__ add, float4* __restrict__ da, long long total4, int relu_in) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long stride = (long long)gridDim.x * blockDim.x;
     const float k = coef * g[0];
@@ -459,6 +459,7 @@ __global__ void l1_bwd_kernel(const float4* __restrict__ a, const float4* __rest
         o.x = (ux > vx ? k : (ux < vx ? -k : 0.f)); o.y = (uy > vy ? k : (uy < vy ? -k : 0.f));
         o.z = (uz > vz ? k : (uz < vz ? -k : 0.f)); o.w = (uw > vw ? k : (uw < vw ? -k : 0.f));
         if (relu_in) { o.x = u.x > 0.f ? o.x : 0.f; o.y = u.y > 0.f ? o.y : 0.f; o.z = u.z > 0.f ? o.z : 0.f; o.w = u.w > 0.f ? o.w : 0.f; }
+        if (add) { const float4 e = add[i]; o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w; }
         da[i] = o;
     }
 }
@@ -474,14 +475,14 @@ extern "C" int lp_l1_fwd(const float* a, const float* b, float* partial, long lo
     return lp_check_launch("l1_fwd");
 }
 
-extern "C" int lp_l1_bwd(const float* a, const float* b, const float* grad_out, float coef, float* da, long long numel, int relu_in,
-                         void* stream) {
+extern "C" int lp_l1_bwd(const float* a, const float* b, const float* grad_out, float coef, const float* add, float* da, long long numel,
+                         int relu_in, void* stream) {
     if (!a || !b || !grad_out || !da) return lp_set_error(LP_ERR_ARG, "lp_l1_bwd: null pointer");
     if (numel & 3) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_l1_bwd: numel must be a multiple of 4");
     long long total4 = numel / 4;
     int blocks = (int)((total4 + 255) / 256); if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(l1_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)a, (const float4*)b, grad_out, coef,
-                       (float4*)da, total4, relu_in);
+                       (const float4*)add, (float4*)da, total4, relu_in);
     return lp_check_launch("l1_bwd");
 }
 

@@ -5,7 +5,28 @@ which is an un-vendored dependency and absent from this image; these are restate
 (He et al. / Xie et al. ResNeXt; Sandler et al. MobileNetV2) so that reference checkpoints load by key.  They run on
 stock PyTorch-ROCm ops: the embedder is the LAST row of the hot-path plan, not yet hand-written HIP."""
 import torch
+import torch.nn.functional as F
 from torch import nn
+
+_PENDING_COUNTERS = []
+
+
+class _BatchNorm2d(nn.BatchNorm2d):
+    """nn.BatchNorm2d (same parameters, buffers and state_dict keys) whose ``num_batches_tracked += 1`` -- one tiny launch per
+    layer per forward in train mode (52 per MobileNetV2 pass) -- is deferred and issued as ONE multi-tensor add by the backbone
+    at the end of its forward (momentum is a constant here, so the counter does not enter the statistics update)."""
+
+    def forward(self, x):
+        if self.training and self.track_running_stats:
+            _PENDING_COUNTERS.append(self.num_batches_tracked)
+            return F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, True, self.momentum, self.eps)
+        return F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, not self.track_running_stats, 0.0, self.eps)
+
+
+def _flush_bn_counters():
+    if _PENDING_COUNTERS:
+        torch._foreach_add_(_PENDING_COUNTERS, 1)
+        _PENDING_COUNTERS.clear()
 
 
 # ---------------------------------------------------------------- ResNeXt
@@ -16,11 +37,11 @@ class _Bottleneck(nn.Module):
         super().__init__()
         width = int(planes * (base_width / 64.0)) * groups
         self.conv1 = nn.Conv2d(inplanes, width, 1, bias=False)
-        self.bn1 = nn.BatchNorm2d(width)
+        self.bn1 = _BatchNorm2d(width)
         self.conv2 = nn.Conv2d(width, width, 3, stride, 1, groups=groups, bias=False)
-        self.bn2 = nn.BatchNorm2d(width)
+        self.bn2 = _BatchNorm2d(width)
         self.conv3 = nn.Conv2d(width, planes * 4, 1, bias=False)
-        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.bn3 = _BatchNorm2d(planes * 4)
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
 
@@ -37,7 +58,7 @@ class ResNeXt(nn.Module):
         super().__init__()
         self.inplanes = 64
         self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
-        self.bn1 = nn.BatchNorm2d(64)
+        self.bn1 = _BatchNorm2d(64)
         self.relu = nn.ReLU(inplace=True)
         self.maxpool = nn.MaxPool2d(3, 2, 1)
         self.layer1 = self._stage(64, layers[0], 1, groups, width_per_group)
@@ -53,7 +74,7 @@ class ResNeXt(nn.Module):
     def _stage(self, planes, blocks, stride, groups, base_width):
         down = None
         if stride != 1 or self.inplanes != planes * 4:
-            down = nn.Sequential(nn.Conv2d(self.inplanes, planes * 4, 1, stride, bias=False), nn.BatchNorm2d(planes * 4))
+            down = nn.Sequential(nn.Conv2d(self.inplanes, planes * 4, 1, stride, bias=False), _BatchNorm2d(planes * 4))
         seq = [_Bottleneck(self.inplanes, planes, stride, down, groups, base_width)]
         self.inplanes = planes * 4
         seq += [_Bottleneck(self.inplanes, planes, 1, None, groups, base_width) for _ in range(1, blocks)]
@@ -62,6 +83,7 @@ class ResNeXt(nn.Module):
     def forward(self, x):
         x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        _flush_bn_counters()
         return self.fc(torch.flatten(self.avgpool(x), 1))
 
 
@@ -72,7 +94,7 @@ def resnext50_32x4d(num_classes=1000):
 # ---------------------------------------------------------------- MobileNetV2
 class _ConvBNReLU(nn.Sequential):
     def __init__(self, cin, cout, k=3, stride=1, groups=1):
-        super().__init__(nn.Conv2d(cin, cout, k, stride, (k - 1) // 2, groups=groups, bias=False), nn.BatchNorm2d(cout),
+        super().__init__(nn.Conv2d(cin, cout, k, stride, (k - 1) // 2, groups=groups, bias=False), _BatchNorm2d(cout),
                          nn.ReLU6(inplace=True))
 
 
@@ -85,7 +107,7 @@ class _InvertedResidual(nn.Module):
         if t != 1:
             layers.append(_ConvBNReLU(inp, hidden, 1))
         layers += [_ConvBNReLU(hidden, hidden, 3, stride, groups=hidden), nn.Conv2d(hidden, oup, 1, 1, 0, bias=False),
-                   nn.BatchNorm2d(oup)]
+                   _BatchNorm2d(oup)]
         self.conv = nn.Sequential(*layers)
 
     def forward(self, x):
@@ -115,6 +137,7 @@ class MobileNetV2(nn.Module):
 
     def forward(self, x):
         x = self.features(x)
+        _flush_bn_counters()
         return self.classifier(x.mean([2, 3]))
 
 

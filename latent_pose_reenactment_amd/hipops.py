@@ -233,10 +233,13 @@ def l1_sum(a: Tensor, b: Tensor, relu_in: bool) -> Tensor:
     return part.sum()
 
 
-def l1_bwd(a: Tensor, b: Tensor, grad_out: Tensor, coef: float, relu_in: bool) -> Tensor:
+def l1_bwd(a: Tensor, b: Tensor, grad_out: Tensor, coef: float, relu_in: bool, add: Optional[Tensor] = None) -> Tensor:
+    """gradient of coef * sum|relu?(a) - relu?(b)| w.r.t. a, times grad_out; ``add`` (same shape) is summed in"""
     _chk(a, 'a'); _chk(b, 'b')
+    if add is not None:
+        _chk(add, 'add'); assert add.shape == a.shape
     g = grad_out.reshape(1).contiguous().float()
     da = torch.empty_like(a)
-    check(_lib.lib().lp_l1_bwd(a.data_ptr(), b.data_ptr(), g.data_ptr(), float(coef), da.data_ptr(), a.numel(), int(relu_in), _stream()),
+    check(_lib.lib().lp_l1_bwd(a.data_ptr(), b.data_ptr(), g.data_ptr(), float(coef), _p(add), da.data_ptr(), a.numel(), int(relu_in), _stream()),
           'lp_l1_bwd')
     return da

@@ -598,3 +598,29 @@ class L1Fn(torch.autograd.Function):
 
 def hip_l1(a, b, relu_in=False):
     return L1Fn.apply(a, b.detach(), relu_in)
+
+
+class L1TapFn(torch.autograd.Function):
+    """A feature tap of the perceptual stacks (perceptual_loss.py:86-108): returns ``(a, mean|relu?(a) - relu?(b)|)`` where the
+    first output is ``a`` itself, to be handed to the next layer.  ``a`` then has two consumers -- the L1 term and the next
+    conv / pool -- and autograd would sum their two gradients with a separate ``add`` pass over the feature map; here the sum
+    happens inside the L1 backward kernel (its optional ``add`` input)."""
+
+    @staticmethod
+    def forward(ctx, a, b, relu_in):
+        ctx.save_for_backward(a, b)
+        ctx.relu_in = relu_in
+        return a.view_as(a), ops.l1_sum(a, b, relu_in) / a.numel()
+
+    @staticmethod
+    def backward(ctx, g_next, g_loss):
+        a, b = ctx.saved_tensors
+        if g_loss is None:
+            return g_next, None, None
+        add = None if g_next is None else g_next.contiguous()
+        return ops.l1_bwd(a, b, g_loss, 1.0 / a.numel(), ctx.relu_in, add=add), None, None
+
+
+def hip_l1_tap(a, b, relu_in=False):
+    """-> (a passed through, l1 term); use the returned tensor as the input of the following layer"""
+    return L1TapFn.apply(a, b.detach(), relu_in)
