@@ -33,6 +33,11 @@ int lp_abi_version(void);
  * mode 1 (dgrad):    out[T-1-t][ci][co] = w[co][ci][t]        rows = Cin padded to RowsP, cols = Cout padded to ColsP
  * hi/lo: bf16 images, lo = bf16(w - hi) (may be NULL).  Replaces nothing in the reference (cuDNN does this internally). */
 int lp_pack_weights(const float* w, uint16_t* hi, uint16_t* lo, int Cout, int Cin, int T, int RowsP, int ColsP, int mode, void* stream);
+/* batched: table = DEVICE array of {const float* w; uint16_t* hi; uint16_t* lo; int Cout, Cin, T, RowsP, ColsP, mode;}
+ * (lp_pack_desc_bytes() each); one launch packs every (weight, orientation) entry -- all convs of a module after an optimizer step;
+ * max_elems = largest T*RowsP*ColsP of the table. */
+int lp_pack_desc_bytes(void);
+int lp_pack_weights_batch(const void* table, int num_entries, long long max_elems, void* stream);
 
 /* Fused conv: y = alpha * conv_{k x k, pad k/2}( up2?( act(x) ) , w ) + bias + res
  * Replaces, per conv of blocks.ResBlock (generators/common/blocks.py:70-111): instance_norm + mul + add (AdaptiveNorm2d,
@@ -114,8 +119,8 @@ int lp_mt_ema(const void* table, int num_tensors, long long max_numel, float alp
 /* ---- batched spectral normalisation (legacy torch.nn.utils.spectral_norm hook; generators/common/blocks.py:76-88) ----
  * table: DEVICE array of {const float* w; float* u; float* v; float* u_out; float* v_out; float* sig_out; int rows; int cols;
  * float* part; int rows; int cols; float eps; int pad;} (lp_sn_desc_bytes() each), one per layer; `part` = scratch of
- * ceil(rows/lp_sn_row_block())*cols + rows floats.  do_iter=1 (train): v <- normalize(W^T u), u <- normalize(W v) in place;
- * always: u_out/v_out = the vectors used, sig_out = {sigma = u^T W v, 1/sigma}.  Four launches, row-blocked over many workgroups.
+ * ceil(rows/lp_sn_row_block())*cols + rows + ceil(cols/256) floats.  do_iter=1 (train): v <- normalize(W^T u), u <- normalize(W v) in place;
+ * always: u_out/v_out = the vectors used, sig_out = {sigma = u^T W v, 1/sigma}.  Five launches, row-/column-blocked over many workgroups.
  * (dot = scratch of 512 floats: per-block partial sums of <g, w_orig>, no memset needed)
  * lp_sn_grad_apply: g/sigma - (<g, w_orig>/sigma^2) u v^T (autograd of W/sigma with u, v constant), written in place on g, or
  * added to `accum` when that is non-NULL (fused accumulation into the parameter's .grad; g is then left untouched); dot = scratch. */

@@ -20,6 +20,8 @@ SIGNATURES = {
     'lp_last_error': (ctypes.c_char_p, []),
     'lp_abi_version': (_i, []),
     'lp_pack_weights': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'lp_pack_desc_bytes': (_i, []),
+    'lp_pack_weights_batch': (_i, [_vp, _i, _ll, _vp]),
     'lp_conv_fwd': (_i, [_vp] * 9 + [_i] * 12 + [_vp, _vp]),
     'lp_conv_wgrad_workspace_bytes': (_ll, [_i, _i, _i, _i]),
     'lp_conv_wgrad_has_dbias': (_i, [_i] * 5),

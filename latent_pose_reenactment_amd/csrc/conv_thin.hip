@@ -119,33 +119,37 @@ __global__ __launch_bounds__(256) void wgrad_thin_kernel(ThinParams p) {
     }
 }
 
-// dw[co][ci][tap] = sum_wg part[wg][tap][thin][wide]
+// dw[co][ci][tap] = sum_wg part[wg][tap][thin][wide]; a block = 16 outputs x 16 slices of the G workgroup slabs (4 loads in
+// flight per thread), combined through LDS; trailing blocks do the same for the bias partials
 template <bool THIN_X>
-__global__ __launch_bounds__(256) void wgrad_thin_reduce_kernel(ThinParams p, int T) {
+__global__ __launch_bounds__(256) void wgrad_thin_reduce_kernel(ThinParams p, int T, int wblocks) {
+    __shared__ float red[16][17];
     const int thinC = THIN_X ? p.Cin : p.Cout, wideC = THIN_X ? p.Cout : p.Cin;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (THIN_X && p.bpart && idx < wideC) {
-        float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
-        int g = 0;
-        for (; g + 4 <= p.G; g += 4) {
-            b0 += p.bpart[(size_t)g * wideC + idx]; b1 += p.bpart[(size_t)(g + 1) * wideC + idx];
-            b2 += p.bpart[(size_t)(g + 2) * wideC + idx]; b3 += p.bpart[(size_t)(g + 3) * wideC + idx];
-        }
-        for (; g < p.G; ++g) b0 += p.bpart[(size_t)g * wideC + idx];
-        p.dbias[idx] = (b0 + b1) + (b2 + b3);
-    }
-    if (idx >= T * thinC * wideC) return;
-    const int w = idx % wideC, c = (idx / wideC) % thinC, t = idx / (wideC * thinC);
-    const size_t slab = (size_t)T * thinC * wideC;
+    const bool is_bias = (int)blockIdx.x >= wblocks;
+    const int total = is_bias ? wideC : T * thinC * wideC;
+    const float* src = is_bias ? p.bpart : p.part;
+    const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int idx = (is_bias ? (int)blockIdx.x - wblocks : (int)blockIdx.x) * 16 + o;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int g = 0;
-    for (; g + 4 <= p.G; g += 4) {
-        a0 += p.part[(size_t)g * slab + idx]; a1 += p.part[(size_t)(g + 1) * slab + idx];
-        a2 += p.part[(size_t)(g + 2) * slab + idx]; a3 += p.part[(size_t)(g + 3) * slab + idx];
+    if (idx < total) {
+        int g = sl;
+        for (; g + 48 < p.G; g += 64) {
+            a0 += src[(size_t)g * total + idx]; a1 += src[(size_t)(g + 16) * total + idx];
+            a2 += src[(size_t)(g + 32) * total + idx]; a3 += src[(size_t)(g + 48) * total + idx];
+        }
+        for (; g < p.G; g += 16) a0 += src[(size_t)g * total + idx];
     }
-    for (; g < p.G; ++g) a0 += p.part[(size_t)g * slab + idx];
-    const int co = THIN_X ? w : c, ci = THIN_X ? c : w;
-    p.dw[((size_t)co * p.Cin + ci) * T + t] = (a0 + a1) + (a2 + a3);
+    red[sl][o] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (sl == 0 && idx < total) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += red[k][o];
+        if (is_bias) { p.dbias[idx] = s; return; }
+        const int w = idx % wideC, c = (idx / wideC) % thinC, t = idx / (wideC * thinC);
+        const int co = THIN_X ? w : c, ci = THIN_X ? c : w;
+        p.dw[((size_t)co * p.Cin + ci) * T + t] = s;
+    }
 }
 
 bool lp_wgrad_thin_supported(int Cin, int Cout, int ksize, int upsample, int pro) {
@@ -188,8 +192,9 @@ int lp_wgrad_thin(const float* x, const float* dy, float* dw, float* workspace, 
     int rc = lp_check_launch("wgrad_thin");
     if (rc) return rc;
     const int total = T * thinC * wide;
-    if (thin_x) hipLaunchKernelGGL(wgrad_thin_reduce_kernel<true>, dim3((total + 255) / 256), dim3(256), 0, stream, p, T);
-    else hipLaunchKernelGGL(wgrad_thin_reduce_kernel<false>, dim3((total + 255) / 256), dim3(256), 0, stream, p, T);
+    const int wblocks = (total + 15) / 16, bblocks = p.bpart ? (wide + 15) / 16 : 0;
+    if (thin_x) hipLaunchKernelGGL(wgrad_thin_reduce_kernel<true>, dim3(wblocks + bblocks), dim3(256), 0, stream, p, T, wblocks);
+    else hipLaunchKernelGGL(wgrad_thin_reduce_kernel<false>, dim3(wblocks + bblocks), dim3(256), 0, stream, p, T, wblocks);
     return lp_check_launch("wgrad_thin_reduce");
 }
 

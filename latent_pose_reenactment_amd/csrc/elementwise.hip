@@ -25,6 +25,37 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, uint16_t* __res
     if (lo) { __bf16 l = (__bf16)(v - (float)h); lo[idx] = __builtin_bit_cast(uint16_t, l); }
 }
 
+// batched variant: blockIdx.y = entry of a device table (one per (weight, orientation)); one launch re-packs every conv weight
+// of a module after an optimizer step
+struct PackDesc { const float* w; uint16_t* hi; uint16_t* lo; int Cout, Cin, T, RowsP, ColsP, mode; };
+
+__global__ void pack_weights_batch_kernel(const PackDesc* __restrict__ table) {
+    const PackDesc d = table[blockIdx.y];
+    const long long total = (long long)d.T * d.RowsP * d.ColsP;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        int col = (int)(idx % d.ColsP);
+        int row = (int)((idx / d.ColsP) % d.RowsP);
+        int t = (int)(idx / ((long long)d.ColsP * d.RowsP));
+        float v = 0.f;
+        if (d.mode == 0) { if (row < d.Cout && col < d.Cin) v = d.w[((size_t)row * d.Cin + col) * d.T + t]; }
+        else { if (row < d.Cin && col < d.Cout) v = d.w[((size_t)col * d.Cin + row) * d.T + (d.T - 1 - t)]; }
+        __bf16 h = (__bf16)v;
+        d.hi[idx] = __builtin_bit_cast(uint16_t, h);
+        if (d.lo) { __bf16 l = (__bf16)(v - (float)h); d.lo[idx] = __builtin_bit_cast(uint16_t, l); }
+    }
+}
+
+extern "C" int lp_pack_desc_bytes(void) { return (int)sizeof(PackDesc); }
+
+extern "C" int lp_pack_weights_batch(const void* table, int num_entries, long long max_elems, void* stream) {
+    if (!table || num_entries <= 0) return lp_set_error(LP_ERR_ARG, "lp_pack_weights_batch: bad arguments");
+    long long bx = (max_elems + 1023) / 1024; if (bx < 1) bx = 1; if (bx > 256) bx = 256;
+    hipLaunchKernelGGL(pack_weights_batch_kernel, dim3((unsigned)bx, num_entries), dim3(256), 0, (hipStream_t)stream,
+                       (const PackDesc*)table);
+    return lp_check_launch("pack_weights_batch");
+}
+
 extern "C" int lp_pack_weights(const float* w, uint16_t* hi, uint16_t* lo, int Cout, int Cin, int T, int RowsP, int ColsP, int mode,
                                void* stream) {
     if (!w || !hi) return lp_set_error(LP_ERR_ARG, "lp_pack_weights: null pointer");

@@ -67,19 +67,36 @@ __global__ __launch_bounds__(256) void sn_wtu_kernel(const SnDesc* __restrict__ 
     }
 }
 
-// phase 2: v = normalize(sum_rb part[rb])  (do_iter) | v unchanged; v_out = v                 grid (layers)
-__global__ __launch_bounds__(256) void sn_v_kernel(const SnDesc* __restrict__ table, int do_iter) {
+// phase 2a: v_out = sum_rb part[rb] (unnormalised), one squared-norm partial per 256-column block, stored behind the layer's
+// scratch (part + nrb*cols + rows)                                                                        grid (col blocks, layers)
+__global__ __launch_bounds__(256) void sn_vsum_kernel(const SnDesc* __restrict__ table) {
     __shared__ float red[4];
+    const SnDesc d = table[blockIdx.y];
+    const int C = d.cols, nrb = (d.rows + SN_RB - 1) / SN_RB;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x * 256 >= C) return;
+    float t = 0.f;
+    if (c < C) {
+        float t1 = 0.f;
+        int k = 0;
+        for (; k + 2 <= nrb; k += 2) { t += d.part[(size_t)k * C + c]; t1 += d.part[(size_t)(k + 1) * C + c]; }
+        if (k < nrb) t += d.part[(size_t)k * C + c];
+        t += t1;
+        d.v_out[c] = t;
+    }
+    const float s = block_sum_256(c < C ? t * t : 0.f, red);
+    if (threadIdx.x == 0) d.part[(size_t)nrb * C + d.rows + blockIdx.x] = s;
+}
+
+// phase 2b: v = v_out = v_out / max(|v_out|, eps)  (do_iter) | v unchanged; v_out = v                 grid (layers)
+__global__ __launch_bounds__(256) void sn_v_kernel(const SnDesc* __restrict__ table, int do_iter) {
     const SnDesc d = table[blockIdx.x];
     const int C = d.cols, nrb = (d.rows + SN_RB - 1) / SN_RB;
     if (!do_iter) { for (int c = threadIdx.x; c < C; c += 256) d.v_out[c] = d.v[c]; return; }
     float sq = 0.f;
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float t = 0.f;
-        for (int k = 0; k < nrb; ++k) t += d.part[(size_t)k * C + c];
-        d.v_out[c] = t; sq += t * t;                         // v_out holds the unnormalised vector for a moment
-    }
-    const float inv = 1.f / fmaxf(sqrtf(block_sum_256(sq, red)), d.eps);
+    const int ncb = (C + 255) / 256;
+    for (int j = 0; j < ncb; ++j) sq += d.part[(size_t)nrb * C + d.rows + j];            // (same order in every thread: deterministic)
+    const float inv = 1.f / fmaxf(sqrtf(sq), d.eps);
     for (int c = threadIdx.x; c < C; c += 256) { float t = d.v_out[c] * inv; d.v_out[c] = t; d.v[c] = t; }
 }
 
@@ -146,11 +163,13 @@ extern "C" int lp_sn_row_block(void) { return SN_RB; }
 
 extern "C" int lp_sn_power_iter(const void* table, int num_layers, int do_iter, int max_rows, int max_cols, void* stream) {
     if (!table || num_layers <= 0) return lp_set_error(LP_ERR_ARG, "lp_sn_power_iter: bad arguments");
-    (void)max_cols;
     hipStream_t st = (hipStream_t)stream;
     const SnDesc* t = (const SnDesc*)table;
     const int nrb = (max_rows + SN_RB - 1) / SN_RB;
-    if (do_iter) hipLaunchKernelGGL(sn_wtu_kernel, dim3(nrb, num_layers), dim3(256), 0, st, t);
+    if (do_iter) {
+        hipLaunchKernelGGL(sn_wtu_kernel, dim3(nrb, num_layers), dim3(256), 0, st, t);
+        hipLaunchKernelGGL(sn_vsum_kernel, dim3((max_cols + 255) / 256, num_layers), dim3(256), 0, st, t);
+    }
     hipLaunchKernelGGL(sn_v_kernel, dim3(num_layers), dim3(256), 0, st, t, do_iter);
     hipLaunchKernelGGL(sn_wv_kernel, dim3(nrb, num_layers), dim3(256), 0, st, t);
     hipLaunchKernelGGL(sn_u_kernel, dim3(num_layers), dim3(256), 0, st, t, do_iter);

@@ -107,6 +107,29 @@ class Discriminator(nn.Module):
             self.embed.weight_orig.uniform_(-0.1, 0.1)
         self.finetuning = False
 
+    def _fresh_packs(self):
+        """bf16 packs (forward + dgrad) of every conv of the critic for this step's three passes, produced by one batched launch;
+        keyed like ConvFn's per-step cache: (W_orig.data_ptr(), mode)"""
+        from latent_pose_reenactment_amd import hipops as ops
+        from latent_pose_reenactment_amd.nn import default_prec
+        convs = [m for m in self.modules() if hasattr(m, 'weight_orig') and m.weight_orig.dim() == 4]
+        if not convs or not convs[0].weight_orig.is_cuda:
+            return {}
+        prec = default_prec()
+        specs = []
+        for m in convs:
+            w = m.weight_orig
+            ks = w.shape[-1]
+            specs.append((w, 0, ks == 3 and w.shape[1] <= 32))
+            specs.append((w, 1, ks == 3 and w.shape[0] <= 32))
+        key = tuple((w.data_ptr(), mode, bool(k_)) for w, mode, k_ in specs)
+        pb = self.__dict__.get('_pack_batch')
+        if pb is None or pb.prec != prec or pb.key != key:
+            pb = ops.PackBatch([(w.detach(), mode, k_) for w, mode, k_ in specs], prec)
+            self.__dict__['_pack_batch'] = pb
+        packs = pb.update()
+        return {(w.data_ptr(), mode): p for (w, mode, _), p in zip(specs, packs)}
+
     def pass_inputs(self, x, embed=None, track_weights=True):
         """``track_weights=False``: the discriminator's own parameters are constants for autograd in this pass (gradients
         still flow to ``x`` and ``embed``)."""
@@ -159,7 +182,7 @@ class Discriminator(nn.Module):
             fake = fake[:, 0]
         if real.dim() > 4:
             real = real[:, 0]
-        self.__dict__['_step_packs'] = {}       # new step: the optimizer has changed W_orig since the last forward
+        self.__dict__['_step_packs'] = self._fresh_packs()   # new step: the optimizer has changed W_orig since the last forward
         embed = F.embedding(label, self.embed.effective_weight())
         # Pass 1 feeds only generator-side losses; the gradients it would deposit on the discriminator's parameters are erased
         # by optimizer_D.zero_grad() before loss_D.backward (runners/holycow.py:246-248) and no optimizer reads them, so they

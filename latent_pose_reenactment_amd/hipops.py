@@ -75,6 +75,39 @@ def pack_weights(w: Tensor, mode: int, prec: int, small_k: bool = False) -> Weig
     return WeightPack(hi, lo, rows, cols, rows_p, cols_p, taps)
 
 
+class PackBatch:
+    """bf16 packs of MANY conv weights, refreshed by ONE launch (lp_pack_weights_batch).  ``specs`` = [(w, mode, small_k)];
+    the pack buffers and the device descriptor table are allocated once (static addresses: hipGraph friendly); ``update()``
+    re-packs all entries from the current weight values and returns the list of WeightPacks (same order as ``specs``)."""
+
+    def __init__(self, specs, prec: int):
+        import struct
+        assert _lib.lib().lp_pack_desc_bytes() == 48
+        self.prec = prec
+        self.key = tuple((w.data_ptr(), mode, bool(sk)) for w, mode, sk in specs)
+        self.packs = []
+        blob = bytearray()
+        self.max_elems = 1
+        for w, mode, small_k in specs:
+            _chk(w, 'w')
+            cout, cin = w.shape[0], w.shape[1]
+            taps = w.numel() // (cout * cin)
+            rows, cols = (cout, cin) if mode == 0 else (cin, cout)
+            rows_p = _round_up(rows, 128)
+            cols_p = _round_up(cols, 32 if (small_k and cols <= 32) else 64)
+            hi = torch.empty((taps, rows_p, cols_p), dtype=torch.int16, device=w.device)
+            lo = torch.empty_like(hi) if prec == PREC_BF16X3 else None
+            self.packs.append(WeightPack(hi, lo, rows, cols, rows_p, cols_p, taps))
+            blob += struct.pack('<QQQiiiiii', w.data_ptr(), hi.data_ptr(), 0 if lo is None else lo.data_ptr(), cout, cin, taps, rows_p,
+                                cols_p, mode)
+            self.max_elems = max(self.max_elems, taps * rows_p * cols_p)
+        self.table = torch.frombuffer(blob, dtype=torch.uint8).clone().to(specs[0][0].device)
+
+    def update(self):
+        check(_lib.lib().lp_pack_weights_batch(self.table.data_ptr(), len(self.packs), self.max_elems, _stream()), 'lp_pack_weights_batch')
+        return self.packs
+
+
 def conv(x: Tensor, pack: WeightPack, *, ksize: int, upsample: bool = False, pro: int = 0, scale: Optional[Tensor] = None,
          shift: Optional[Tensor] = None, bias: Optional[Tensor] = None, res: Optional[Tensor] = None, res_shift: int = 0,
          alpha: Optional[Tensor] = None, prec: int = PREC_BF16, relu_mask: Optional[Tensor] = None) -> Tensor:

@@ -126,7 +126,7 @@ class SNBatch:
             al = lambda n: (n + 3) // 4 * 4                 # 16-byte aligned slices: the mat-vec kernels use 16-B loads
             uo = torch.zeros(sum(al(r) for r in rows), dtype=torch.float32, device=dev)
             vo = torch.zeros(sum(al(c) for c in cols), dtype=torch.float32, device=dev)
-            need = [al(((r + rb - 1) // rb) * c + r) for r, c in zip(rows, cols)]
+            need = [al(((r + rb - 1) // rb) * c + r + (c + 255) // 256) for r, c in zip(rows, cols)]
             scratch = torch.zeros(sum(need), dtype=torch.float32, device=dev)
             blob = bytearray()
             states = []
@@ -247,7 +247,7 @@ class _DecoderFunction(torch.autograd.Function):
         blocks, prec = cfg['blocks'], cfg['prec']
         need_grad = cfg['need_grad']
         sn = cfg['sn']                    # per entry of `weights`: (u_used, v_used, [sigma, 1/sigma]) for conv weights, None for biases
-        packs = cfg.get('packs')          # inference: forward packs of the (unchanged) weights, cached by the module
+        packs = cfg.get('packs')          # forward packs prepared by the module (inference: cached; training: one batched launch)
 
         def fpack(i, w):
             return packs[i] if packs is not None else ops.pack_weights(w.detach().contiguous(), 0, prec)
@@ -329,7 +329,11 @@ class _DecoderFunction(torch.autograd.Function):
         wi = len(wl) - 2
         grads[wi], grads[wi + 1] = ops.conv_wgrad(x, dz, ksize=3, pro=1, scale=sth[2], shift=sth[3], prec=prec, sn=snw(wi),
                                                    accum=_accum_target(params[wi]), bias_grad=True)
-        pT = ops.pack_weights(wl[wi].contiguous(), 1, prec, small_k=True)
+        packsT = cfg.get('packsT')        # dgrad packs from the same batched launch (training), else packed on demand
+
+        def tpack(i, small_k=False):
+            return packsT[i] if packsT is not None else ops.pack_weights(wl[i].contiguous(), 1, prec, small_k=small_k)
+        pT = tpack(wi, small_k=True)
         dA = ops.conv(dz, pT, ksize=3, alpha=sn[wi][2][1:], prec=prec)
         g, dg, db = slices(oh, ch)
         dx = ops.adain_relu_bwd(dA, x, None, g, sth[0], sth[1], sth[2], sth[3], dg, db, False)
@@ -347,7 +351,7 @@ class _DecoderFunction(torch.autograd.Function):
             # conv2 (+ AdaIN1/ReLU prologue)
             grads[wi + 1] = ops.conv_wgrad(h1, d_out, ksize=3, pro=1, scale=st1[2], shift=st1[3], prec=prec, sn=snw(wi + 1),
                                            accum=_accum_target(params[wi + 1]))
-            dA1 = ops.conv(d_out, ops.pack_weights(w2.contiguous(), 1, prec), ksize=3, alpha=sn[wi + 1][2][1:], prec=prec)
+            dA1 = ops.conv(d_out, tpack(wi + 1), ksize=3, alpha=sn[wi + 1][2][1:], prec=prec)
             g, dg, db = slices(o1, cout)
             dh1 = ops.adain_relu_bwd(dA1, h1, None, g, st1[0], st1[1], st1[2], st1[3], dg, db, False)
             # skip branch: out += up2(conv1x1(x) + b)
@@ -356,13 +360,13 @@ class _DecoderFunction(torch.autograd.Function):
                 ds = ops.sum2x2(d_out) if up else d_out
                 grads[wi + 2], grads[wi + 3] = ops.conv_wgrad(x, ds, ksize=1, prec=prec, sn=snw(wi + 2), accum=_accum_target(params[wi + 2]),
                                                               bias_grad=True)
-                dx_skip = ops.conv(ds, ops.pack_weights(ws.contiguous(), 1, prec), ksize=1, alpha=sn[wi + 2][2][1:], prec=prec)
+                dx_skip = ops.conv(ds, tpack(wi + 2), ksize=1, alpha=sn[wi + 2][2][1:], prec=prec)
             else:
                 dx_skip = d_out
             # conv1 (+ AdaIN0/ReLU/upsample prologue)
             grads[wi] = ops.conv_wgrad(x, dh1, ksize=3, upsample=up, pro=1, scale=st0[2], shift=st0[3], prec=prec, sn=snw(wi),
                                        accum=_accum_target(params[wi]))
-            dA0 = ops.conv(dh1, ops.pack_weights(w1.contiguous(), 1, prec), ksize=3, alpha=sn[wi][2][1:], prec=prec)
+            dA0 = ops.conv(dh1, tpack(wi), ksize=3, alpha=sn[wi][2][1:], prec=prec)
             g, dg, db = slices(o0, cin)
             dx = ops.adain_relu_bwd(dA0, x, dx_skip, g, st0[0], st0[1], st0[2], st0[3], dg, db, up)
             if dbg is not None:
@@ -479,7 +483,19 @@ class Generator(nn.Module):
         weights += [head.weight_orig, head.bias]
         sn += [states[k], None]
         need_grad = torch.is_grad_enabled() and (affine.requires_grad or any(w.requires_grad for w in weights))
-        packs = None
+        packs = packsT = None
+        if need_grad and self.training:
+            # training: every conv weight changed in the last optimizer step -> ONE launch re-packs all of them, both orientations
+            conv_idx = [i for i, s_ in enumerate(sn) if s_ is not None]
+            specs = [(weights[i], 0, False) for i in conv_idx] + [(weights[i], 1, i == len(weights) - 2) for i in conv_idx]
+            pb = self.__dict__.get('_train_packs')
+            if pb is None or pb.prec != self.prec or pb.key != tuple((w.data_ptr(), m, bool(k_)) for w, m, k_ in specs):
+                pb = ops.PackBatch(specs, self.prec)
+                self.__dict__['_train_packs'] = pb
+            allp = pb.update()
+            packs, packsT = [None] * len(weights), [None] * len(weights)
+            for j, i in enumerate(conv_idx):
+                packs[i], packsT[i] = allp[j], allp[len(conv_idx) + j]
         if not need_grad and not self.training:
             # inference (drive.py): the weights do not change between frames -> pack them to bf16 once
             key = (self.prec,) + tuple((w.data_ptr(), w._version) for w in weights)
@@ -489,7 +505,8 @@ class Generator(nn.Module):
                                for w, s_ in zip(weights, sn)])
                 self.__dict__['_pack_cache'] = cache
             packs = cache[1]
-        cfg = dict(blocks=self.blocks_cfg, prec=self.prec, need_grad=need_grad, sn=sn, packs=packs, debug=getattr(self, '_debug', None))
+        cfg = dict(blocks=self.blocks_cfg, prec=self.prec, need_grad=need_grad, sn=sn, packs=packs, packsT=packsT,
+                   debug=getattr(self, '_debug', None))
         rgbs, segm = _DecoderFunction.apply(cfg, affine, self.constant.constant, *weights)
         data_dict['fake_rgbs'] = rgbs
         data_dict['fake_segm'] = segm
