@@ -33,11 +33,12 @@ int lp_abi_version(void);
  * mode 1 (dgrad):    out[T-1-t][ci][co] = w[co][ci][t]        rows = Cin padded to RowsP, cols = Cout padded to ColsP
  * hi/lo: bf16 images, lo = bf16(w - hi) (may be NULL).  Replaces nothing in the reference (cuDNN does this internally). */
 int lp_pack_weights(const float* w, uint16_t* hi, uint16_t* lo, int Cout, int Cin, int T, int RowsP, int ColsP, int mode, void* stream);
-/* batched: table = DEVICE array of {const float* w; uint16_t* hi; uint16_t* lo; int Cout, Cin, T, RowsP, ColsP, mode;}
- * (lp_pack_desc_bytes() each); one launch packs every (weight, orientation) entry -- all convs of a module after an optimizer step;
- * max_elems = largest T*RowsP*ColsP of the table. */
+/* batched: table = DEVICE array of {const float* w; uint16_t* hi; uint16_t* lo; int Cout, Cin, T, RowsP, ColsP, mode, chunk0, pad;}
+ * (lp_pack_desc_bytes() each); one launch packs every (weight, orientation) entry -- all convs of a module after an optimizer step.
+ * The grid is flat over 1024-element chunks: chunk0 = sum of ceil(T*RowsP*ColsP/1024) of the preceding entries (ascending),
+ * total_chunks = that sum over all entries. */
 int lp_pack_desc_bytes(void);
-int lp_pack_weights_batch(const void* table, int num_entries, long long max_elems, void* stream);
+int lp_pack_weights_batch(const void* table, int num_entries, long long total_chunks, void* stream);
 
 /* Fused conv: y = alpha * conv_{k x k, pad k/2}( up2?( act(x) ) , w ) + bias + res
  * Replaces, per conv of blocks.ResBlock (generators/common/blocks.py:70-111): instance_norm + mul + add (AdaptiveNorm2d,

@@ -27,13 +27,23 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, uint16_t* __res
 
 // batched variant: blockIdx.y = entry of a device table (one per (weight, orientation)); one launch re-packs every conv weight
 // of a module after an optimizer step
-struct PackDesc { const float* w; uint16_t* hi; uint16_t* lo; int Cout, Cin, T, RowsP, ColsP, mode; };
+// (a flat 1-D grid of 1024-element chunks: entry sizes differ by 1000x, so a (blocks, entries) grid either starves the big
+//  entries or floods the scheduler with empty blocks; chunk0 = first chunk of the entry, found by binary search)
+struct PackDesc { const float* w; uint16_t* hi; uint16_t* lo; int Cout, Cin, T, RowsP, ColsP, mode, chunk0, pad; };
 
-__global__ void pack_weights_batch_kernel(const PackDesc* __restrict__ table) {
-    const PackDesc d = table[blockIdx.y];
+__global__ __launch_bounds__(256) void pack_weights_batch_kernel(const PackDesc* __restrict__ table, int num_entries) {
+    int lo_e = 0, hi_e = num_entries - 1;
+    while (lo_e < hi_e) {                                  // last entry whose chunk0 <= blockIdx.x   (block-uniform)
+        const int mid = (lo_e + hi_e + 1) >> 1;
+        if (table[mid].chunk0 <= (int)blockIdx.x) lo_e = mid; else hi_e = mid - 1;
+    }
+    const PackDesc d = table[lo_e];
     const long long total = (long long)d.T * d.RowsP * d.ColsP;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+    const long long base = (long long)((int)blockIdx.x - d.chunk0) * 1024;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long long idx = base + k * 256 + threadIdx.x;
+        if (idx >= total) break;
         int col = (int)(idx % d.ColsP);
         int row = (int)((idx / d.ColsP) % d.RowsP);
         int t = (int)(idx / ((long long)d.ColsP * d.RowsP));
@@ -48,11 +58,12 @@ __global__ void pack_weights_batch_kernel(const PackDesc* __restrict__ table) {
 
 extern "C" int lp_pack_desc_bytes(void) { return (int)sizeof(PackDesc); }
 
-extern "C" int lp_pack_weights_batch(const void* table, int num_entries, long long max_elems, void* stream) {
+extern "C" int lp_pack_weights_batch(const void* table, int num_entries, long long max_elems /* total chunks */, void* stream) {
     if (!table || num_entries <= 0) return lp_set_error(LP_ERR_ARG, "lp_pack_weights_batch: bad arguments");
-    long long bx = (max_elems + 1023) / 1024; if (bx < 1) bx = 1; if (bx > 256) bx = 256;
-    hipLaunchKernelGGL(pack_weights_batch_kernel, dim3((unsigned)bx, num_entries), dim3(256), 0, (hipStream_t)stream,
-                       (const PackDesc*)table);
+    // (argument name kept for the ABI: here it is the TOTAL number of 1024-element chunks = chunk0 + chunks of the last entry)
+    if (max_elems < 1) return lp_set_error(LP_ERR_ARG, "lp_pack_weights_batch: no chunks");
+    hipLaunchKernelGGL(pack_weights_batch_kernel, dim3((unsigned)max_elems), dim3(256), 0, (hipStream_t)stream, (const PackDesc*)table,
+                       num_entries);
     return lp_check_launch("pack_weights_batch");
 }
 

@@ -82,12 +82,12 @@ class PackBatch:
 
     def __init__(self, specs, prec: int):
         import struct
-        assert _lib.lib().lp_pack_desc_bytes() == 48
+        assert _lib.lib().lp_pack_desc_bytes() == 56
         self.prec = prec
         self.key = tuple((w.data_ptr(), mode, bool(sk)) for w, mode, sk in specs)
         self.packs = []
         blob = bytearray()
-        self.max_elems = 1
+        self.chunks = 0
         for w, mode, small_k in specs:
             _chk(w, 'w')
             cout, cin = w.shape[0], w.shape[1]
@@ -98,13 +98,13 @@ class PackBatch:
             hi = torch.empty((taps, rows_p, cols_p), dtype=torch.int16, device=w.device)
             lo = torch.empty_like(hi) if prec == PREC_BF16X3 else None
             self.packs.append(WeightPack(hi, lo, rows, cols, rows_p, cols_p, taps))
-            blob += struct.pack('<QQQiiiiii', w.data_ptr(), hi.data_ptr(), 0 if lo is None else lo.data_ptr(), cout, cin, taps, rows_p,
-                                cols_p, mode)
-            self.max_elems = max(self.max_elems, taps * rows_p * cols_p)
+            blob += struct.pack('<QQQiiiiiiii', w.data_ptr(), hi.data_ptr(), 0 if lo is None else lo.data_ptr(), cout, cin, taps, rows_p,
+                                cols_p, mode, self.chunks, 0)
+            self.chunks += (taps * rows_p * cols_p + 1023) // 1024
         self.table = torch.frombuffer(blob, dtype=torch.uint8).clone().to(specs[0][0].device)
 
     def update(self):
-        check(_lib.lib().lp_pack_weights_batch(self.table.data_ptr(), len(self.packs), self.max_elems, _stream()), 'lp_pack_weights_batch')
+        check(_lib.lib().lp_pack_weights_batch(self.table.data_ptr(), len(self.packs), self.chunks, _stream()), 'lp_pack_weights_batch')
         return self.packs
 
 
