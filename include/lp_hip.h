@@ -104,7 +104,8 @@ int lp_avgpool2_bwd(const float* dy, const float* x, float* dx, int N, int H, in
  * backward: da = coef * grad_out[0] * sign(relu?(a) - relu?(b)) * (relu_in ? [a>0] : 1)  (+ add [numel]|NULL: the gradient that
  * reaches `a` from its other consumer -- the next conv / pool of the VGG stack -- summed here instead of by an autograd add) */
 int lp_l1_partial_blocks(void);
-int lp_l1_fwd(const float* a, const float* b, float* partial, long long numel, int relu_in, void* stream);
+/* out|NULL: a second tiny launch writes out[0] = coef * sum(partial) (fixed order) -- the finished loss term. */
+int lp_l1_fwd(const float* a, const float* b, float* partial, long long numel, int relu_in, float coef, float* out, void* stream);
 int lp_l1_bwd(const float* a, const float* b, const float* grad_out, float coef, const float* add, float* da, long long numel, int relu_in,
               void* stream);
 
@@ -120,7 +121,7 @@ int lp_mt_ema(const void* table, int num_tensors, long long max_numel, float alp
 /* ---- batched spectral normalisation (legacy torch.nn.utils.spectral_norm hook; generators/common/blocks.py:76-88) ----
  * table: DEVICE array of {const float* w; float* u; float* v; float* u_out; float* v_out; float* sig_out; int rows; int cols;
  * float* part; int rows; int cols; float eps; int pad;} (lp_sn_desc_bytes() each), one per layer; `part` = scratch of
- * ceil(rows/lp_sn_row_block())*cols + rows + ceil(cols/256) floats.  do_iter=1 (train): v <- normalize(W^T u), u <- normalize(W v) in place;
+ * ceil(rows/lp_sn_row_block())*cols + rows + ceil(cols/64) floats.  do_iter=1 (train): v <- normalize(W^T u), u <- normalize(W v) in place;
  * always: u_out/v_out = the vectors used, sig_out = {sigma = u^T W v, 1/sigma}.  Five launches, row-/column-blocked over many workgroups.
  * (dot = scratch of 512 floats: per-block partial sums of <g, w_orig>, no memset needed)
  * lp_sn_grad_apply: g/sigma - (<g, w_orig>/sigma^2) u v^T (autograd of W/sigma with u, v constant), written in place on g, or

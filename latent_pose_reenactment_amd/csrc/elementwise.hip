@@ -486,6 +486,18 @@ __global__ __launch_bounds__(256) void l1_partial_kernel(const float4* __restric
     if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
+// out[0] = coef * sum(part[0..n)) in a fixed order: the finished loss term (a device-wide "last block" ticket inside the partial
+// kernel was tried instead of this second launch: 1024 same-address atomics made the partial kernel 3x slower)
+__global__ __launch_bounds__(256) void l1_finalize_kernel(const float* __restrict__ part, int n, float coef, float* __restrict__ out) {
+    __shared__ float sh[4];
+    float t = 0.f;
+    for (int j = threadIdx.x; j < n; j += 256) t += part[j];
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = coef * ((sh[0] + sh[1]) + (sh[2] + sh[3]));
+}
+
 // da = coef * g[0] * sign(relu?(a) - relu?(b)) * (relu_in ? [a>0] : 1)  (+ add: the gradient arriving at `a` from its other consumer)
 __global__ void l1_bwd_kernel(const float4* __restrict__ a, const float4* __restrict__ b, const float* __restrict__ g, float coef,
                               const float4* __restrict__ add, float4* __restrict__ da, long long total4, int relu_in) {
@@ -509,11 +521,13 @@ __global__ void l1_bwd_kernel(const float4* __restrict__ a, const float4* __rest
 #define L1_BLOCKS 1024
 extern "C" int lp_l1_partial_blocks(void) { return L1_BLOCKS; }
 
-extern "C" int lp_l1_fwd(const float* a, const float* b, float* partial, long long numel, int relu_in, void* stream) {
+extern "C" int lp_l1_fwd(const float* a, const float* b, float* partial, long long numel, int relu_in, float coef, float* out,
+                         void* stream) {
     if (!a || !b || !partial) return lp_set_error(LP_ERR_ARG, "lp_l1_fwd: null pointer");
     if (numel & 3) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_l1_fwd: numel must be a multiple of 4");
     hipLaunchKernelGGL(l1_partial_kernel, dim3(L1_BLOCKS), dim3(256), 0, (hipStream_t)stream, (const float4*)a, (const float4*)b, partial,
                        numel / 4, relu_in);
+    if (out) hipLaunchKernelGGL(l1_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, L1_BLOCKS, coef, out);
     return lp_check_launch("l1_fwd");
 }
 

@@ -67,24 +67,35 @@ __global__ __launch_bounds__(256) void sn_wtu_kernel(const SnDesc* __restrict__ 
     }
 }
 
-// phase 2a: v_out = sum_rb part[rb] (unnormalised), one squared-norm partial per 256-column block, stored behind the layer's
-// scratch (part + nrb*cols + rows)                                                                        grid (col blocks, layers)
+// phase 2a: v_out = sum_rb part[rb] (unnormalised), one squared-norm partial per 64-column block, stored behind the layer's
+// scratch (part + nrb*cols + rows).  A block = 64 columns x 4 slices of the row-block partials (the 13 056-row projector
+// has 408 of them), 4 loads in flight per thread, combined through LDS.                                   grid (col blocks, layers)
+#define SN_VCOLS 64
 __global__ __launch_bounds__(256) void sn_vsum_kernel(const SnDesc* __restrict__ table) {
+    __shared__ float comb[4][SN_VCOLS];
     __shared__ float red[4];
     const SnDesc d = table[blockIdx.y];
     const int C = d.cols, nrb = (d.rows + SN_RB - 1) / SN_RB;
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (blockIdx.x * 256 >= C) return;
-    float t = 0.f;
+    if (blockIdx.x * SN_VCOLS >= C) return;
+    const int cl = threadIdx.x & (SN_VCOLS - 1), sl = threadIdx.x >> 6;
+    const int c = blockIdx.x * SN_VCOLS + cl;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     if (c < C) {
-        float t1 = 0.f;
-        int k = 0;
-        for (; k + 2 <= nrb; k += 2) { t += d.part[(size_t)k * C + c]; t1 += d.part[(size_t)(k + 1) * C + c]; }
-        if (k < nrb) t += d.part[(size_t)k * C + c];
-        t += t1;
+        int k = sl;
+        for (; k + 12 < nrb; k += 16) {
+            a0 += d.part[(size_t)k * C + c]; a1 += d.part[(size_t)(k + 4) * C + c];
+            a2 += d.part[(size_t)(k + 8) * C + c]; a3 += d.part[(size_t)(k + 12) * C + c];
+        }
+        for (; k < nrb; k += 4) a0 += d.part[(size_t)k * C + c];
+    }
+    comb[sl][cl] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    float t = 0.f;
+    if (sl == 0 && c < C) {
+        t = (comb[0][cl] + comb[1][cl]) + (comb[2][cl] + comb[3][cl]);
         d.v_out[c] = t;
     }
-    const float s = block_sum_256(c < C ? t * t : 0.f, red);
+    const float s = block_sum_256(t * t, red);
     if (threadIdx.x == 0) d.part[(size_t)nrb * C + d.rows + blockIdx.x] = s;
 }
 
@@ -94,7 +105,7 @@ __global__ __launch_bounds__(256) void sn_v_kernel(const SnDesc* __restrict__ ta
     const int C = d.cols, nrb = (d.rows + SN_RB - 1) / SN_RB;
     if (!do_iter) { for (int c = threadIdx.x; c < C; c += 256) d.v_out[c] = d.v[c]; return; }
     float sq = 0.f;
-    const int ncb = (C + 255) / 256;
+    const int ncb = (C + SN_VCOLS - 1) / SN_VCOLS;
     for (int j = 0; j < ncb; ++j) sq += d.part[(size_t)nrb * C + d.rows + j];            // (same order in every thread: deterministic)
     const float inv = 1.f / fmaxf(sqrtf(sq), d.eps);
     for (int c = threadIdx.x; c < C; c += 256) { float t = d.v_out[c] * inv; d.v_out[c] = t; d.v[c] = t; }
@@ -168,7 +179,7 @@ extern "C" int lp_sn_power_iter(const void* table, int num_layers, int do_iter, 
     const int nrb = (max_rows + SN_RB - 1) / SN_RB;
     if (do_iter) {
         hipLaunchKernelGGL(sn_wtu_kernel, dim3(nrb, num_layers), dim3(256), 0, st, t);
-        hipLaunchKernelGGL(sn_vsum_kernel, dim3((max_cols + 255) / 256, num_layers), dim3(256), 0, st, t);
+        hipLaunchKernelGGL(sn_vsum_kernel, dim3((max_cols + SN_VCOLS - 1) / SN_VCOLS, num_layers), dim3(256), 0, st, t);
     }
     hipLaunchKernelGGL(sn_v_kernel, dim3(num_layers), dim3(256), 0, st, t, do_iter);
     hipLaunchKernelGGL(sn_wv_kernel, dim3(nrb, num_layers), dim3(256), 0, st, t);

@@ -171,6 +171,20 @@ def conv_wgrad(x: Tensor, dy: Tensor, *, ksize: int, upsample: bool = False, pro
     return (dw, db) if bias_grad else dw
 
 
+def sn_grad_apply(g: Tensor, w_orig: Tensor, u: Tensor, v: Tensor, sig: Tensor, accum: Optional[Tensor] = None) -> Optional[Tensor]:
+    """gradient w.r.t. W_orig of a spectrally normalised layer from the raw gradient ``g`` w.r.t. W/sigma (legacy-hook autograd,
+    u and v constants): g/sigma - <g, W_orig>/sigma^2 u v^T, in place on ``g`` -- or added to ``accum`` (returns None)."""
+    _chk(g, 'g'); _chk(w_orig, 'w_orig')
+    rows = g.shape[0]
+    cols = g.numel() // rows
+    dot = torch.empty(512, dtype=torch.float32, device=g.device)
+    if accum is not None:
+        assert accum.is_contiguous() and accum.dtype == torch.float32 and accum.numel() == g.numel()
+    check(_lib.lib().lp_sn_grad_apply(g.data_ptr(), w_orig.data_ptr(), u.data_ptr(), v.data_ptr(), sig.data_ptr(), dot.data_ptr(),
+                                      _p(accum), rows, cols, _stream()), 'lp_sn_grad_apply')
+    return None if accum is not None else g
+
+
 def instnorm_stats(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], eps: float
                    ) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
     """x [N,H,W,C]; gamma/beta: [N,C] views (last dim contiguous) of the projector output.  -> mean, rstd, scale, shift [N,C]."""
@@ -257,13 +271,15 @@ def avgpool2_bwd(dy: Tensor, x: Tensor, relu_in: bool) -> Tensor:
     return dx
 
 
-def l1_sum(a: Tensor, b: Tensor, relu_in: bool) -> Tensor:
-    """sum |relu?(a) - relu?(b)| as a 0-d tensor (block partials + one tiny torch sum)"""
+def l1_sum(a: Tensor, b: Tensor, relu_in: bool, coef: float = 1.0) -> Tensor:
+    """coef * sum |relu?(a) - relu?(b)| as a 0-d tensor (block partials + a one-block finalize launch)"""
     _chk(a, 'a'); _chk(b, 'b')
     assert a.shape == b.shape
-    part = torch.empty(_lib.lib().lp_l1_partial_blocks(), dtype=torch.float32, device=a.device)
-    check(_lib.lib().lp_l1_fwd(a.data_ptr(), b.data_ptr(), part.data_ptr(), a.numel(), int(relu_in), _stream()), 'lp_l1_fwd')
-    return part.sum()
+    buf = torch.empty(_lib.lib().lp_l1_partial_blocks() + 1, dtype=torch.float32, device=a.device)
+    out = buf[-1:]
+    check(_lib.lib().lp_l1_fwd(a.data_ptr(), b.data_ptr(), buf.data_ptr(), a.numel(), int(relu_in), float(coef), out.data_ptr(),
+                               _stream()), 'lp_l1_fwd')
+    return out.reshape(())
 
 
 def l1_bwd(a: Tensor, b: Tensor, grad_out: Tensor, coef: float, relu_in: bool, add: Optional[Tensor] = None) -> Tensor:

@@ -126,7 +126,7 @@ class SNBatch:
             al = lambda n: (n + 3) // 4 * 4                 # 16-byte aligned slices: the mat-vec kernels use 16-B loads
             uo = torch.zeros(sum(al(r) for r in rows), dtype=torch.float32, device=dev)
             vo = torch.zeros(sum(al(c) for c in cols), dtype=torch.float32, device=dev)
-            need = [al(((r + rb - 1) // rb) * c + r + (c + 255) // 256) for r, c in zip(rows, cols)]
+            need = [al(((r + rb - 1) // rb) * c + r + (c + 63) // 64) for r, c in zip(rows, cols)]
             scratch = torch.zeros(sum(need), dtype=torch.float32, device=dev)
             blob = bytearray()
             states = []
@@ -162,6 +162,7 @@ class SNLinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, u, v, sig):
         ctx.save_for_backward(x, w, u, v, sig)
+        ctx.w_param = w if (w.requires_grad and w.is_leaf) else None
         y = F.linear(x, w) * sig[1]
         return y + b if b is not None else y
 
@@ -172,9 +173,12 @@ class SNLinearFn(torch.autograd.Function):
         dx = (g @ w) * alpha if ctx.needs_input_grad[0] else None
         dw = db = None
         if ctx.needs_input_grad[1]:
-            graw = g.reshape(-1, g.shape[-1]).t() @ x.reshape(-1, x.shape[-1])
-            dot = (graw * w).sum()
-            dw = graw * alpha - (dot * alpha * alpha) * torch.outer(u, v)
+            graw = (g.reshape(-1, g.shape[-1]).t() @ x.reshape(-1, x.shape[-1])).contiguous()
+            if graw.is_cuda:      # <G, W> + rank-1 correction in two launches, added straight into the gradient arena when possible
+                dw = ops.sn_grad_apply(graw, w.detach(), u, v, sig, accum=None if ctx.w_param is None else _accum_target(ctx.w_param))
+            else:
+                dot = (graw * w).sum()
+                dw = graw * alpha - (dot * alpha * alpha) * torch.outer(u, v)
         if ctx.needs_input_grad[2]:
             db = g.reshape(-1, g.shape[-1]).sum(0)
         return dx, dw, db, None, None, None
@@ -445,12 +449,11 @@ class Generator(nn.Module):
         self.__dict__['_sn_states'] = states
         p0, p2 = self.affine_params_projector._modules['0'], self.affine_params_projector._modules['2']
         # plain library GEMMs (rocBLAS through torch) -- B x 768 x 768 and B x 768 x 13056
-        h = torch.relu(SNLinearFn.apply(joint, p0.weight_orig, p0.bias, *states[-1]))
-        # the 13 056 x 768 output projection (10 M weights) is too large for the one-workgroup-per-layer SN kernel: torch ops
-        return F.linear(h, p2.effective_weight(), p2.bias)
+        h = torch.relu(SNLinearFn.apply(joint, p0.weight_orig, p0.bias, *states[-2]))
+        return SNLinearFn.apply(h, p2.weight_orig, p2.bias, *states[-1])
 
     def _sn_layers(self):
-        """batched SNWeight layers in a fixed order: decoder convs (block order, w1, w2[, skip]), head conv, projector.0"""
+        """batched SNWeight layers in a fixed order: decoder convs (block order, w1, w2[, skip]), head conv, projector.0, projector.2"""
         cached = self.__dict__.get('_sn_layer_cache')
         if cached is None:
             layers = []
@@ -459,7 +462,7 @@ class Generator(nn.Module):
                 c1, c2, sk = self.decoder_blocks._modules[str(i)].convs()
                 layers += [c1, c2] + ([sk] if sk is not None else [])
             layers.append(self.decoder_blocks._modules[str(nb + 2)])
-            layers += [self.affine_params_projector._modules['0']]
+            layers += [self.affine_params_projector._modules['0'], self.affine_params_projector._modules['2']]
             cached = (layers, None)
             self.__dict__['_sn_layer_cache'] = cached
         return cached
@@ -605,7 +608,7 @@ class L1Fn(torch.autograd.Function):
     def forward(ctx, a, b, relu_in):
         ctx.save_for_backward(a, b)
         ctx.relu_in = relu_in
-        return ops.l1_sum(a, b, relu_in) / a.numel()
+        return ops.l1_sum(a, b, relu_in, 1.0 / a.numel())
 
     @staticmethod
     def backward(ctx, g):
@@ -627,7 +630,7 @@ class L1TapFn(torch.autograd.Function):
     def forward(ctx, a, b, relu_in):
         ctx.save_for_backward(a, b)
         ctx.relu_in = relu_in
-        return a.view_as(a), ops.l1_sum(a, b, relu_in) / a.numel()
+        return a.view_as(a), ops.l1_sum(a, b, relu_in, 1.0 / a.numel())
 
     @staticmethod
     def backward(ctx, g_next, g_loss):

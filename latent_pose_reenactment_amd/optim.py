@@ -148,5 +148,5 @@ class FusedEMA:
         check(_lib.lib().lp_mt_ema(self.ptable.data_ptr(), self.np, self.pmax, alpha, 0, st), 'lp_mt_ema')
         if self.btable is not None:
             check(_lib.lib().lp_mt_ema(self.btable.data_ptr(), self.nb, self.bmax, 0.0, 1, st), 'lp_mt_ema')
-        for a, c in self.other:
-            a.copy_(c)
+        if self.other:                      # integer buffers (BatchNorm step counters): one multi-tensor copy, not one launch each
+            torch._foreach_copy_([a for a, _ in self.other], [c for _, c in self.other])
