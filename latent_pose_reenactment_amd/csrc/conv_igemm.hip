@@ -574,8 +574,13 @@ template <int PREC>
 static int dispatch_conv(ConvParams& p, int ks, int ups, hipStream_t s) {
     static const int force_cc = getenv("LP_CONV_CC") ? atoi(getenv("LP_CONV_CC")) : 0;     // tuning knob: 32 | 64
     // default CC = 32: two workgroups fit per CU (78 KB LDS, <= 256 registers) and hide each other's staging latency
-    if (force_cc != 64 || p.CinP % 64 != 0) return dispatch_conv_cc<PREC, 32>(p, ks, ups, s);
-    return dispatch_conv_cc<PREC, 64>(p, ks, ups, s);
+    // (bf16x3 doubles every LDS image: 64-channel chunks do not fit there, the knob only applies to the bf16 kernel)
+    if constexpr (PREC == LP_PREC_BF16X3) {
+        return dispatch_conv_cc<PREC, 32>(p, ks, ups, s);
+    } else {
+        if (force_cc != 64 || p.CinP % 64 != 0) return dispatch_conv_cc<PREC, 32>(p, ks, ups, s);
+        return dispatch_conv_cc<PREC, 64>(p, ks, ups, s);
+    }
 }
 
 extern "C" int lp_conv_fwd(const float* x, const uint16_t* w_hi, const uint16_t* w_lo, float* y,

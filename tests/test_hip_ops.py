@@ -59,6 +59,8 @@ CONV_CASES = [
     (2, 64, 64, 64, 64, 3, 0, 1, 0, -1),
     (2, 20, 12, 3, 128, 1, 0, 0, 1, -1),      # direct fp32 kernel for <= 4 input channels: 1x1, odd image size
     (3, 12, 20, 3, 64, 3, 0, 0, 1, -1),
+    (3, 8, 16, 64, 128, 3, 0, 1, 1, -1),        # 3 tiles: with the ping-pong schedule the last workgroup's second group is masked
+    (5, 16, 16, 64, 64, 3, 0, 2, 1, 0),         # 5 tiles of 256 pixels (Cout <= 64 tile), residual
 ]
 
 
