@@ -7,9 +7,13 @@
 // is staged into LDS, so the normalised/upsampled tensor never exists in HBM.  The same kernel is the data-gradient
 // kernel when fed dY and the flipped/transposed weight pack (lp_pack_weights mode 1).
 //
-// Tiling: one workgroup (256 threads = 4 waves) owns BM = WM*MR*16 output pixels (NB images x TH x TW patch) and
-// BN = WN*NR*16 output channels.  K loop = input-channel chunks of CC; per chunk the activated halo is staged ONCE and
-// reused by all KS*KS taps; the weight tile of each tap is double-buffered through registers -> LDS.
+// Tiling: a group of WM*WN waves (4, or 8 for the small feature maps) owns BM = WM*MR*16 output pixels (NB images x TH x TW
+// patch) and BN = WN*NR*16 output channels; a workgroup is one group, or two groups on adjacent pixel tiles in the ping-pong
+// schedule (see conv_igemm_kernel).  K loop = input-channel chunks of CC; per chunk the activated halo is staged ONCE and
+// reused by all KS*KS taps; the weight tile of each kernel row travels L2 -> LDS by LDS-DMA, double buffered.  Small feature
+// maps additionally split K over gridDim.z (fp32 atomic epilogue).  Convs with <= 4 input channels never get here
+// (conv_thin.hip).  Tuning / ablation knobs (read once per process): LP_CONV_PP, LP_CONV_W8, LP_CONV_KSPLIT, LP_CONV_NBUF,
+// LP_CONV_CC, LP_CONV_THIN; -DLP_DBG adds the LP_CONV_DBG ablation bits and (with -DLP_PROF) s_memtime phase counters.
 #include "lp_common.h"
 #include "lp_hip.h"
 #include "lp_internal.h"

@@ -54,3 +54,15 @@ def test_abi_version_and_error_string():
     # argument validation happens before any device work, so it is callable without a GPU
     rc = l.lp_pack_weights(None, None, None, 1, 1, 1, 128, 64, 0, None)
     assert rc == -1 and b'null' in l.lp_last_error()
+
+
+def test_descriptor_struct_sizes_match_the_python_packers():
+    """the device descriptor tables are packed with struct.pack on the host (nn.SNBatch '<QQQQQQQiifi', optim._build_table,
+    hipops.PackBatch '<QQQiiiiiiii'): their byte sizes must equal the C structs'"""
+    import struct
+    from latent_pose_reenactment_amd import _lib
+    l = _lib.lib()
+    assert l.lp_sn_desc_bytes() == struct.calcsize('<QQQQQQQiifi') == 72
+    assert l.lp_pack_desc_bytes() == struct.calcsize('<QQQiiiiiiii') == 56
+    assert l.lp_mt_desc_bytes() == struct.calcsize('<QQQQq') == 40
+    assert l.lp_sn_row_block() == 32 and l.lp_l1_partial_blocks() == 1024
