@@ -1,3 +1,8 @@
+"""Phase timing of the single-group conv_igemm pipeline (s_memtime counters of wave 0 / block 0: barrier wait, weight-DMA issue,
+halo load issue, MFMA phase, halo conversion + LDS write, total).  Needs an instrumented library:
+    scripts/build_variant.sh latent_pose_reenactment_amd/csrc/conv_igemm.hip probes/liblp_hip_dbg.so -DLP_DBG -DLP_PROF
+    LP_LIB_OVERRIDE=probes/liblp_hip_dbg.so LP_CONV_PP=0 PREC=1 python scripts/conv_prof.py
+(the counters live in the non-ping-pong FAST loop; LP_CONV_DBG=<bits> additionally ablates parts of the pipeline, see ConvParams)"""
 import os, sys, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
