@@ -238,7 +238,8 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         self.g1, self.g2, self.g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         # capture on the stream the warm-up ran on: the AccumulateGrad nodes autograd keeps per parameter stay on one stream
-        with torch.cuda.graph(self.g1, stream=side):
+        # thread_local error mode: CUDA calls of OTHER threads (the RCCL watchdog polling its events) must not invalidate the capture
+        with torch.cuda.graph(self.g1, stream=side, capture_error_mode='thread_local'):
             _, self.losses_G, self.losses_D = self.tm(self.data, self.target)
             loss_G = sum(v for v in self.losses_G.values() if isinstance(v, torch.Tensor))
             loss_D = sum(v for v in self.losses_D.values() if isinstance(v, torch.Tensor))
@@ -248,14 +249,14 @@ class GraphedTrainStep:
         pool = self.g1.pool()
         if self.reducer is not None:
             self.reducer.reduce_generator_side()
-        with torch.cuda.graph(self.g2, pool=pool, stream=side):
+        with torch.cuda.graph(self.g2, pool=pool, stream=side, capture_error_mode='thread_local'):
             self.opt_G.step()
             self.opt_D.zero_grad()
             with fused_grad_accumulation():
                 loss_D.backward()
         if self.reducer is not None:
             self.reducer.reduce_discriminator_side()
-        with torch.cuda.graph(self.g3, pool=pool, stream=side):
+        with torch.cuda.graph(self.g3, pool=pool, stream=side, capture_error_mode='thread_local'):
             self.opt_D.step()
             self.tm.update_running_average(self.alpha)
         del loss_G, loss_D
