@@ -298,7 +298,12 @@ def main():
         entry = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                  'frac': round(ach / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': None, 'kernel': kind,
                  'launches': cnt, 'avg_launch_us': round(sec / max(cnt, 1) * 1e6, 1),
-                 'algorithmic_gflop_per_launch': round(fl / max(cnt, 1) / 1e9, 3)}
+                 'algorithmic_gflop_per_launch': round(fl / max(cnt, 1) / 1e9, 3),
+                 # bf16x3 executes 3 MFMAs per algorithmic MAC (hi*hi + hi*lo + lo*hi): the matrix pipe's own utilisation
+                 'mfma_per_algorithmic_flop': 3 if a.prec == 'bf16x3' else 1,
+                 'mfma_work_tflops': round(ach * (3 if a.prec == 'bf16x3' else 1), 2),
+                 'traffic_note': 'PMC FETCH/WRITE_SIZE of this kernel per shape: profiles/r01_pmc_conv_igemm_bf16x3.csv '
+                                 '(a --pmc pass over the whole step hangs rocprofv3 on this pool)'}
         if kind == 'conv_igemm':
             roof = entry
         else:
