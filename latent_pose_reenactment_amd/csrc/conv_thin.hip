@@ -152,8 +152,9 @@ __global__ __launch_bounds__(256) void wgrad_thin_reduce_kernel(ThinParams p, in
     }
 }
 
-bool lp_wgrad_thin_supported(int Cin, int Cout, int ksize, int upsample, int pro) {
+bool lp_wgrad_thin_supported(int Cin, int Cout, int ksize, int upsample, int pro, int W) {
     if (upsample || (ksize != 1 && ksize != 3)) return false;
+    if ((size_t)(4 + 2 * (ksize / 2)) * (W + 2 * (ksize / 2)) * 16 > 64 * 1024) return false;      // staged rows must fit LDS
     if (Cin <= 4 && Cout % 64 == 0 && pro == 0) return true;
     if (Cout <= 4 && Cin % 64 == 0 && ksize == 3) return true;
     return false;

@@ -409,7 +409,7 @@ extern "C" int lp_conv_wgrad(const float* x, const float* dy, float* dw, float* 
     if (prec != LP_PREC_BF16 && prec != LP_PREC_BF16X3) return lp_set_error(LP_ERR_ARG, "lp_conv_wgrad: unknown precision");
     {   // <= 4 channels on one side (image-side convs, generator head): bandwidth-bound fp32 reduction, not an MFMA problem
         static const int thin_env = getenv("LP_WGRAD_THIN") ? atoi(getenv("LP_WGRAD_THIN")) : 1;
-        if (thin_env && lp_wgrad_thin_supported(Cin, Cout, ksize, upsample, pro))
+        if (thin_env && lp_wgrad_thin_supported(Cin, Cout, ksize, upsample, pro, W))
             return lp_wgrad_thin(x, dy, dw, workspace, scale, shift, N, H, W, Cin, Cout, ksize, pro, splits, dbias, (hipStream_t)stream);
     }
     WgradParams p;
