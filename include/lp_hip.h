@@ -7,8 +7,8 @@
  *   - the caller (PyTorch) owns every buffer, including scratch; nothing is allocated or freed here;
  *   - all work is enqueued asynchronously on `stream`; no hidden synchronisation, no global mutable state;
  *   - return value 0 = ok, negative = LP_ERR_*; lp_last_error() gives a thread-local message;
- *   - activations are NHWC fp32 (torch channels_last storage), weights are the packed bf16 images produced by
- *     lp_pack_weights; `prec` selects LP_PREC_BF16 (1 MFMA / k-step) or LP_PREC_BF16X3 (hi+lo split, fp32-class).
+ *   - activations are NHWC fp32 (torch channels_last storage); conv operands are 16-bit planes (lp_act_pack, lp_pack_weights);
+ *     `prec` selects the operand format: LP_PREC_BF16 | LP_PREC_F16 (1 MFMA / k-step) or LP_PREC_BF16X3 (hi+lo split, fp32-class).
  */
 #ifndef LP_HIP_H
 #define LP_HIP_H
@@ -24,46 +24,72 @@ extern "C" {
 
 #define LP_PREC_BF16 0
 #define LP_PREC_BF16X3 1
+#define LP_PREC_F16 2
 
 const char* lp_last_error(void);
 int lp_abi_version(void);
 
-/* Re-layout + bf16 split of a conv/linear weight.  w: fp32 [Cout][Cin][T] (reference nn.Conv2d layout, T = k*k).
+/* Re-layout + 16-bit conversion of a conv/linear weight.  w: fp32 [Cout][Cin][T] (reference nn.Conv2d layout, T = k*k).
  * mode 0 (forward):  out[t][co][ci] = w[co][ci][t]            rows padded to CoutP (x128), cols to CinP (x32)
  * mode 1 (dgrad):    out[T-1-t][ci][co] = w[co][ci][t]        rows = Cin padded to RowsP, cols = Cout padded to ColsP
- * hi/lo: bf16 images, lo = bf16(w - hi) (may be NULL).  Replaces nothing in the reference (cuDNN does this internally). */
-int lp_pack_weights(const float* w, uint16_t* hi, uint16_t* lo, int Cout, int Cin, int T, int RowsP, int ColsP, int mode, void* stream);
-/* batched: table = DEVICE array of {const float* w; uint16_t* hi; uint16_t* lo; int Cout, Cin, T, RowsP, ColsP, mode, chunk0, pad;}
+ * f16 = 0: hi = bf16(w), lo = bf16(w - hi) (may be NULL);  f16 = 1: hi = fp16(w) (saturating), lo unused.
+ * Replaces nothing in the reference (cuDNN does this internally). */
+int lp_pack_weights(const float* w, uint16_t* hi, uint16_t* lo, int Cout, int Cin, int T, int RowsP, int ColsP, int mode, int f16,
+                    void* stream);
+/* batched: table = DEVICE array of {const float* w; uint16_t* hi; uint16_t* lo; int Cout, Cin, T, RowsP, ColsP, mode, chunk0, f16;}
  * (lp_pack_desc_bytes() each); one launch packs every (weight, orientation) entry -- all convs of a module after an optimizer step.
  * The grid is flat over 1024-element chunks: chunk0 = sum of ceil(T*RowsP*ColsP/1024) of the preceding entries (ascending),
  * total_chunks = that sum over all entries. */
 int lp_pack_desc_bytes(void);
 int lp_pack_weights_batch(const void* table, int num_entries, long long total_chunks, void* stream);
 
-/* Fused conv: y = alpha * conv_{k x k, pad k/2}( up2?( act(x) ) , w ) + bias + res
- * Replaces, per conv of blocks.ResBlock (generators/common/blocks.py:70-111): instance_norm + mul + add (AdaptiveNorm2d,
- * blocks.py:18-26) + relu + nn.Upsample(nearest x2) + F.conv2d + W/sigma scaling (spectral_norm) + residual add.
- *   x [N][H/(up?2:1)][W/(up?2:1)][Cin], y [N][H][W][Cout], scale/shift [N][Cin] (pro=1), bias [Cout]|NULL,
- *   res [N][H>>res_shift][W>>res_shift][Cout]|NULL, alpha device scalar|NULL (=1).
- *   pro: 0 identity, 1 relu(x*scale+shift), 2 relu(x).  ksize 1|3.  Also the dgrad kernel (dY in, mode-1 pack).
- *   relu_mask [N][H][W][Cout]|NULL: the output is zeroed where relu_mask <= 0 -- the backward of the ReLU that preceded the conv
- *   whose data gradient this launch computes (replaces a separate dx = dA * (x > 0) pass; blocks.py:89-111 pre-activation). */
-int lp_conv_fwd(const float* x, const uint16_t* w_hi, const uint16_t* w_lo, float* y,
-                const float* scale, const float* shift, const float* bias, const float* res, const float* alpha,
-                int N, int H, int W, int Cin, int Cout, int CinP, int CoutP,
-                int ksize, int upsample, int pro, int res_shift, int prec, const float* relu_mask, void* stream);
+/* Operand planes of a conv input: hi (, lo) [N*HW][C8] 16-bit, C8 = C rounded up to 8 (pad channels zero), holding
+ *   act(x) * in_scale,  act: pro 0 identity | 1 relu(x*scale[n,c]+shift[n,c]) | 2 relu(x)
+ * in the operand format of `prec` (bf16 | bf16 hi+lo | fp16, saturating).  Replaces, once per tensor, the instance_norm + mul +
+ * add + relu chain of AdaptiveNorm2d/ReLU (generators/common/blocks.py:18-26,70-73) that the reference runs before every conv;
+ * the planes feed lp_conv16_fwd (forward / dgrad) and lp_conv16_wgrad.  in_scale: device scalar|NULL (fp16 gradient scaling). */
+int lp_act_pack(const float* x, const float* scale, const float* shift, int pro, uint16_t* hi, uint16_t* lo,
+                int N, int HW, int C, int prec, const float* in_scale, void* stream);
+/* out2 = {s, 1/s}: power-of-two scale that puts amax(x) into [2^12, 2^13) (fp16 gradient operands); workspace: lp_amax_workspace_floats(). */
+int lp_amax_workspace_floats(void);
+int lp_amax_scale(const float* x, long long numel, float* out2, float* workspace, void* stream);
 
-/* Weight gradient: dw[co][ci][t] = sum_{n,y,x} dy[n,y,x,co] * up2?(act(x))[n,y+dy_t,x+dx_t,ci]  (autograd of F.conv2d
- * w.r.t. weight, blocks.py:76-88).  Two launches: partial slabs over `splits` pixel ranges, then a reduction that also
- * writes the reference [Cout][Cin][k][k] layout.  workspace: lp_conv_wgrad_workspace_bytes().
- * dbias [Cout]|NULL: also emit the bias gradient sum_{n,y,x} dy[n,y,x,co] (the kernel streams dy anyway; replaces a separate
- * column-sum pass).  Not produced (left untouched, return code LP_OK) for Cout <= 4: check lp_conv_wgrad_has_dbias(). */
+/* Fused conv on operand planes: y = alpha * alpha2 * conv_{k x k, pad k/2}( up2?(a), w ) + bias + res
+ * Replaces, per conv of blocks.ResBlock (generators/common/blocks.py:70-111): nn.Upsample(nearest x2) + F.conv2d + W/sigma scaling
+ * (spectral_norm) + residual add; with the mode-1 pack and a = dY it is the data-gradient kernel.
+ *   a_hi/a_lo [N][H/(up?2:1)][W/(up?2:1)][C8] (lp_act_pack), y [N][H][W][Cout] fp32, bias [Cout]|NULL,
+ *   res [N][H>>res_shift][W>>res_shift][Cout]|NULL, alpha, alpha2: device scalars|NULL (=1; 1/sigma and 1/in_scale).  ksize 1|3.
+ *   relu_mask16 [N][H][W][Co8]|NULL: 16-bit activation plane; y is zeroed where it is <= 0 -- the backward of the ReLU that produced
+ *   the operand of the conv whose data gradient this launch computes (replaces a dx = dA * (x > 0) pass; blocks.py:71-73,84).
+ *   out_hi/out_lo [N][H][W][Co8]|NULL: also emit the operand planes of (out_relu ? relu(y) : y) for the consumer conv. */
+int lp_conv16_fwd(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* w_hi, const uint16_t* w_lo, float* y,
+                  const float* bias, const float* res, const float* alpha, const float* alpha2,
+                  int N, int H, int W, int Cin, int Cout, int CinP, int CoutP,
+                  int ksize, int upsample, int res_shift, int prec, const uint16_t* relu_mask16,
+                  uint16_t* out_hi, uint16_t* out_lo, int out_relu, void* stream);
+
+/* Weight gradient: dw[co][ci][t] = out_scale * sum_{n,y,x} dy[n,y,x,co] * up2?(a)[n,y+dy_t,x+dx_t,ci]  (autograd of F.conv2d
+ * w.r.t. weight, blocks.py:76-88) on operand planes: a = the planes the forward conv consumed, dy = lp_act_pack of the output
+ * gradient.  Two launches: partial slabs over `splits` pixel ranges, then a reduction that also writes the reference
+ * [Cout][Cin][k][k] layout.  workspace: lp_conv_wgrad_workspace_bytes().
+ * dbias [Cout]|NULL: also emit out_scale * sum_{n,y,x} dy[n,y,x,co] (the kernel streams dy anyway).  out_scale: device scalar|NULL. */
 long long lp_conv_wgrad_workspace_bytes(int Cin, int Cout, int ksize, int splits);
-int lp_conv_wgrad_has_dbias(int Cin, int Cout, int ksize, int upsample, int pro);
-int lp_conv_wgrad(const float* x, const float* dy, float* dw, float* workspace,
-                  const float* scale, const float* shift,
-                  int N, int H, int W, int Cin, int Cout, int ksize, int upsample, int pro, int splits, int prec, float* dbias,
-                  void* stream);
+int lp_conv16_wgrad(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* dy_hi, const uint16_t* dy_lo, float* dw,
+                    float* workspace, int N, int H, int W, int Cin, int Cout, int ksize, int upsample, int splits, int prec,
+                    float* dbias, const float* out_scale, void* stream);
+
+/* Thin-channel convs (<= 4 channels on one side: RGB -> 64 first convs of the critics / VGG stacks, the generator head's weight
+ * gradient): bandwidth-bound fp32 VALU kernels on plain NHWC fp32 activations (no operand planes); weights from the same packs.
+ *   lp_thin_conv_fwd:  y = alpha * conv(x, w) + bias for Cin <= 4, Cout % 64 == 0 (lp_thin_conv_supported).
+ *   lp_thin_wgrad:     dw (and dbias when lp_thin_wgrad_has_dbias) for Cin <= 4 (pro 0) or Cout <= 4 (3x3; the AdaIN/ReLU prologue
+ *                      pro/scale/shift of the wide input is applied on the fly); workspace as lp_conv_wgrad_workspace_bytes(). */
+int lp_thin_conv_supported(int Cin, int Cout, int ksize, int W);
+int lp_thin_conv_fwd(const float* x, const uint16_t* w_hi, const uint16_t* w_lo, float* y, const float* bias, const float* alpha,
+                     int N, int H, int W, int Cin, int Cout, int CinP, int CoutP, int ksize, int prec, void* stream);
+int lp_thin_wgrad_supported(int Cin, int Cout, int ksize, int pro, int W);
+int lp_thin_wgrad_has_dbias(int Cin, int Cout);
+int lp_thin_wgrad(const float* x, const float* dy, float* dw, float* workspace, const float* scale, const float* shift,
+                  int N, int H, int W, int Cin, int Cout, int ksize, int pro, int splits, float* dbias, void* stream);
 
 /* Instance-norm statistics of x [N][H*W][C] and the AdaIN scale/shift derived from them (blocks.py:18-26):
  *   mean/rstd [N][C] (biased variance, eps), scale = rstd*gamma, shift = beta - mean*scale.

@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get('LP_LIB_OVERRIDE') or os.path.join(_HERE, 'liblp_hip.s
 
 PREC_BF16 = 0
 PREC_BF16X3 = 1
+PREC_F16 = 2
 
 _vp, _i, _f, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong
 
@@ -19,13 +20,20 @@ _vp, _i, _f, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longl
 SIGNATURES = {
     'lp_last_error': (ctypes.c_char_p, []),
     'lp_abi_version': (_i, []),
-    'lp_pack_weights': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'lp_pack_weights': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'lp_pack_desc_bytes': (_i, []),
     'lp_pack_weights_batch': (_i, [_vp, _i, _ll, _vp]),
-    'lp_conv_fwd': (_i, [_vp] * 9 + [_i] * 12 + [_vp, _vp]),
+    'lp_act_pack': (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    'lp_amax_workspace_floats': (_i, []),
+    'lp_amax_scale': (_i, [_vp, _ll, _vp, _vp, _vp]),
+    'lp_conv16_fwd': (_i, [_vp] * 9 + [_i] * 11 + [_vp, _vp, _vp, _i, _vp]),
     'lp_conv_wgrad_workspace_bytes': (_ll, [_i, _i, _i, _i]),
-    'lp_conv_wgrad_has_dbias': (_i, [_i] * 5),
-    'lp_conv_wgrad': (_i, [_vp] * 6 + [_i] * 10 + [_vp, _vp]),
+    'lp_conv16_wgrad': (_i, [_vp] * 6 + [_i] * 9 + [_vp, _vp, _vp]),
+    'lp_thin_conv_supported': (_i, [_i] * 4),
+    'lp_thin_conv_fwd': (_i, [_vp] * 6 + [_i] * 9 + [_vp]),
+    'lp_thin_wgrad_supported': (_i, [_i] * 5),
+    'lp_thin_wgrad_has_dbias': (_i, [_i] * 2),
+    'lp_thin_wgrad': (_i, [_vp] * 6 + [_i] * 8 + [_vp, _vp]),
     'lp_instnorm_workspace_bytes': (_ll, [_i, _i, _i]),
     'lp_instnorm_stats': (_i, [_vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'lp_adain_bwd_workspace_bytes': (_ll, [_i, _i, _i]),

@@ -1,0 +1,158 @@
+// Operand packing for conv_dma.hip / conv_wgrad.hip (gfx950): the activated input of a conv is written ONCE as 16-bit planes
+//   hi[p][c] (, lo[p][c])  =  split( act( x[p][c] ) * in_scale ),   [N*HW][C8] with C8 = C rounded up to 8 (pad channels = 0)
+// act = identity | relu(x*scale[n,c]+shift[n,c]) (AdaIN + ReLU, generators/common/blocks.py:18-26,70-73) | relu(x).
+// Bandwidth-bound: 4 B read, 2 B (bf16 / f16) or 4 B (bf16x3: hi + lo) written per element; every thread converts 8 channels of
+// one pixel (two 16-B loads, one 16-B store per plane).  fp16 gradients are scaled by a power of two taken from the tensor's
+// amax (lp_amax_scale) so that they sit in the fp16 normal range; the consumer multiplies its result by 1/in_scale.
+#include "lp_common.h"
+#include "lp_hip.h"
+#include "lp_internal.h"
+
+// grid = (blocks, N): blockIdx.y = image; a thread walks the (pixel, 8-channel group) items of its image with a stride that is a
+// multiple of the group count G whenever G is a power of two, so its group -- and with it the AdaIN scale/shift of its 8 channels
+// -- is fixed and loaded once; 4 items are in flight per thread (8 x 16-B loads) to cover the HBM latency.
+template <int PREC>
+__global__ __launch_bounds__(256) void act_pack_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, int pro, uint16_t* __restrict__ hi,
+                                                       uint16_t* __restrict__ lo, int HW, int C, int C8,
+                                                       const float* __restrict__ in_scale) {
+    constexpr bool SPLIT = (PREC == LP_PREC_BF16X3), F16 = (PREC == LP_PREC_F16);
+    constexpr int U = 4;
+    const unsigned G = (unsigned)C8 >> 3;
+    const unsigned items = (unsigned)HW * G;
+    const unsigned stride = gridDim.x * 256u;
+    const int n = blockIdx.y;
+    const float isc = in_scale ? in_scale[0] : 1.f;
+    const bool vec = (C & 3) == 0;
+    const float lo_clamp = (pro != 0) ? 0.f : -3.0e38f;
+    const float* xn = x + (size_t)n * HW * C;
+    uint16_t* hn = hi + (size_t)n * HW * C8;
+    uint16_t* ln = SPLIT ? lo + (size_t)n * HW * C8 : nullptr;
+    const bool fixed_g = (stride % G) == 0;
+    float sc[8], sf[8];
+    auto load_affine = [&](unsigned g) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = (int)g * 8 + j;
+            sc[j] = (pro == 1 && c < C) ? scale[(size_t)n * C + c] : 1.f;
+            sf[j] = (pro == 1 && c < C) ? shift[(size_t)n * C + c] : 0.f;
+        }
+    };
+    unsigned i0 = blockIdx.x * 256u + threadIdx.x;
+    if (fixed_g) load_affine(i0 % G);
+    for (; i0 < items; i0 += U * stride) {
+        float v[U][8];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned i = i0 + u * stride;
+            const unsigned ic = i < items ? i : i0;                 // clamped: loads stay unconditional
+            const unsigned g = ic % G, pix = ic / G;
+            const int c = (int)g * 8;
+            const float* src = xn + (size_t)pix * C + c;
+            if (vec && c + 8 <= C) {
+                const float4 p0 = *(const float4*)src, p1 = *(const float4*)(src + 4);
+                v[u][0] = p0.x; v[u][1] = p0.y; v[u][2] = p0.z; v[u][3] = p0.w; v[u][4] = p1.x; v[u][5] = p1.y; v[u][6] = p1.z; v[u][7] = p1.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[u][j] = (c + j < C) ? src[j] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned i = i0 + u * stride;
+            if (i < items) {
+                const unsigned g = i % G;
+                const int c = (int)g * 8;
+                if (!fixed_g) load_affine(g);
+                s16x8_t h, l;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float q = fmaxf(fmaf(v[u][j], sc[j], sf[j]), lo_clamp) * isc;
+                    q = (c + j < C) ? q : 0.f;
+                    const uint16_t hb = lp_f32_to_op16<F16>(q);
+                    h[j] = (short)hb;
+                    if (SPLIT) l[j] = (short)lp_f32_to_op16<false>(q - lp_op16_to_f32<false>(hb));
+                }
+                *(s16x8_t*)(hn + (size_t)i * 8) = h;
+                if (SPLIT) *(s16x8_t*)(ln + (size_t)i * 8) = l;
+            }
+        }
+    }
+}
+
+extern "C" int lp_act_pack(const float* x, const float* scale, const float* shift, int pro, uint16_t* hi, uint16_t* lo,
+                           int N, int HW, int C, int prec, const float* in_scale, void* stream) {
+    if (!x || !hi) return lp_set_error(LP_ERR_ARG, "lp_act_pack: null pointer");
+    if (pro == 1 && (!scale || !shift)) return lp_set_error(LP_ERR_ARG, "lp_act_pack: pro=1 needs scale/shift");
+    if (prec == LP_PREC_BF16X3 && !lo) return lp_set_error(LP_ERR_ARG, "lp_act_pack: bf16x3 needs the lo plane");
+    const int C8 = (C + 7) & ~7;
+    const long long items = (long long)HW * (C8 >> 3);          // per image
+    if (items == 0 || N == 0) return LP_OK;
+    if (items >= (1ll << 31)) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_act_pack: image too large");
+    long long bx = (items + 1023) / 1024;                       // 4 items per thread
+    const long long cap = (4096 + N - 1) / N; if (bx > cap) bx = cap; if (bx < 1) bx = 1;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)bx, (unsigned)N);
+#define LP_AP(P) hipLaunchKernelGGL(act_pack_kernel<P>, grid, dim3(256), 0, st, x, scale, shift, pro, hi, lo, HW, C, C8, in_scale)
+    if (prec == LP_PREC_BF16) LP_AP(LP_PREC_BF16);
+    else if (prec == LP_PREC_BF16X3) LP_AP(LP_PREC_BF16X3);
+    else if (prec == LP_PREC_F16) LP_AP(LP_PREC_F16);
+    else return lp_set_error(LP_ERR_ARG, "lp_act_pack: unknown precision mode");
+#undef LP_AP
+    return lp_check_launch("act_pack");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// amax -> power-of-two input scale of an fp16 gradient operand: out = {s, 1/s}, s = 2^(13 - e) with amax = f * 2^e, f in [0.5, 1)
+// (the scaled tensor's amax lands in [2^12, 2^13): 3 binades of headroom below the fp16 maximum, 26 binades of normal range below)
+// ------------------------------------------------------------------------------------------------------------------
+#define AMAX_BLOCKS 1024
+__global__ __launch_bounds__(256) void amax_partial_kernel(const float4* __restrict__ x, long long total4, const float* __restrict__ tail,
+                                                           int ntail, float* __restrict__ part) {
+    __shared__ float sh[4];
+    float m = 0.f;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
+        const float4 v = x[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) m = fmaxf(m, fabsf(tail[threadIdx.x]));
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+
+__global__ __launch_bounds__(256) void amax_finalize_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
+    __shared__ float sh[4];
+    float m = 0.f;
+    for (int j = threadIdx.x; j < n; j += 256) m = fmaxf(m, part[j]);
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+        float s = 1.f, inv = 1.f;
+        if (m > 0.f && m < 3.0e38f) {
+            int e;
+            (void)frexpf(m, &e);
+            int k = 13 - e;
+            k = k > 100 ? 100 : (k < -100 ? -100 : k);
+            s = ldexpf(1.f, k); inv = ldexpf(1.f, -k);
+        }
+        out[0] = s; out[1] = inv;
+    }
+}
+
+extern "C" int lp_amax_workspace_floats(void) { return AMAX_BLOCKS; }
+
+extern "C" int lp_amax_scale(const float* x, long long numel, float* out2, float* workspace, void* stream) {
+    if (!x || !out2 || !workspace) return lp_set_error(LP_ERR_ARG, "lp_amax_scale: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const long long total4 = numel / 4;
+    long long blocks = (total4 + 255) / 256; if (blocks > AMAX_BLOCKS) blocks = AMAX_BLOCKS; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(amax_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float4*)x, total4, x + total4 * 4,
+                       (int)(numel - total4 * 4), workspace);
+    hipLaunchKernelGGL(amax_finalize_kernel, dim3(1), dim3(256), 0, st, workspace, (int)blocks, out2);
+    return lp_check_launch("amax_scale");
+}

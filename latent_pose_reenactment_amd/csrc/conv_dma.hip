@@ -1,0 +1,503 @@
+// Implicit-GEMM convolution for gfx950 whose two operands reach LDS by LDS-DMA only (no VGPR staging, no VALU work in the loop):
+//
+//   y[n,oy,ox,co] = alpha * alpha2 * sum_{tap,ci} a[n, oy+dy, ox+dx, ci] * w[tap][co][ci]  (+ bias[co]) (+ res[n,oy>>rs,ox>>rs,co])
+//
+// `a` is the ACTIVATED input of the conv -- relu(AdaIN(x)), relu(x), x or a gradient dY -- already stored in HBM as 16-bit
+// operand planes [N][Hin][Win][C8] (hi [, lo]) by the producer (lp_act_pack, or the epilogue of the previous conv): the
+// prologue of the pre-activation ResBlock (generators/common/blocks.py:70-88) is applied ONCE per tensor by a bandwidth-bound
+// pass instead of once per consumer tile on the VALU of the matrix kernel, the conv reads 2 bytes per activation instead of 4,
+// and the same planes are what the weight-gradient kernel multiplies (no prologue recomputation there either).  Nearest x2
+// upsampling stays fused (the halo is staged at the low resolution, the fragment reads apply the >>1 index map); zero padding
+// comes from a zero page that out-of-image DMA lanes read.
+//
+// Tiling: a group of WM*WN waves owns BM = WM*MR*16 output pixels (NB images x TH x TW patch, rows in LINEAR patch order) and
+// BN = WN*NR*16 output channels.  K loop = 32-channel chunks; per chunk the halo ((TH+2) x (TW+2) pixels x 64 B) is staged once
+// and reused by all KS*KS taps; the weights of one kernel row ([KS*BN][32] per stage) are double buffered.  Both images are
+// lane-linear (wave-uniform base + lane*16, the LDS-DMA contract): slot s of row r holds the 8-channel group s ^ ((r>>1)&3),
+// i.e. the XOR swizzle is applied to the per-lane SOURCE address and undone by the ds_read_b128 of the fragments -- conflict
+// free for 16 consecutive rows in the bank model of MI355X_MICROARCH.md (scripts/lds_swizzle_sim.py: 4 LDS cycles per read; the
+// key (r>>2)&3 of the round-1 kernel was 2-way conflicted).
+//
+// Ping-pong (PP): the workgroup has two 4-wave groups on adjacent M tiles sharing the weight stages; each stage slot has two
+// phases separated by workgroup barriers: group 0 multiplies while group 1 issues its share of the DMA, then they swap, so
+// every SIMD always has one wave in its MFMA phase while the other wave's DMA issue (~60-100 cycles per 1 KiB piece) runs
+// beside it.  Small feature maps: split-K over gridDim.z (fp32 atomics onto a zeroed y) and 8-wave groups.
+//
+// Precision modes (MFMA 16x16x32, fp32 accumulate): bf16 | f16 operands, 1 MFMA per k-step; bf16x3 = hi+lo split, 3 MFMAs.
+#include "lp_common.h"
+#include "lp_hip.h"
+#include "lp_internal.h"
+#include <stdlib.h>
+
+__device__ __attribute__((aligned(64))) unsigned int lp_zero_page[16];      // what out-of-image / out-of-channel DMA lanes read
+
+struct Conv16Params {
+    const uint16_t* a_hi; const uint16_t* a_lo; const uint16_t* w_hi; const uint16_t* w_lo;
+    float* y;
+    const float* bias; const float* res; const float* alpha; const float* alpha2;
+    const uint16_t* mask16;       // epilogue: y = 0 where this 16-bit activation plane [N][H][W][Co8] is <= 0 (fused ReLU backward)
+    uint16_t* o_hi; uint16_t* o_lo;   // optional: 16-bit planes [N][H][W][Co8] of (o_relu ? relu(y) : y) for the consumer conv
+    int o_relu;
+    int N, H, W, Hin, Win, Cin, C8, Cout, Co8, CinP, CoutP;
+    int res_shift;
+    int lTH, lTW, lNB, tiles_x, tiles_y;
+    int hit;                      // halo DMA instructions per wave and chunk
+    int a_dbuf;                   // single-group schedule: halo double buffered (1) or one buffer + an extra barrier per chunk (0)
+    int ksplit;
+};
+
+template <int KS, bool UPS, int WM, int WN, int MR, int NR, int PREC, bool PP>
+__global__ __launch_bounds__(WM * WN * 64 * (PP ? 2 : 1), (!PP && WM * WN == 4 && PREC != LP_PREC_BF16X3) ? 2 : 1)
+void conv_dma_kernel(Conv16Params p) {
+    constexpr int CC = 32, ROWB = 64;                    // channels per chunk, bytes per halo pixel / weight row of a chunk
+    constexpr bool SPLIT = (PREC == LP_PREC_BF16X3), F16 = (PREC == LP_PREC_F16);
+    constexpr int NWAVE = WM * WN;                       // waves of one group
+    constexpr int NWD = PP ? 2 * NWAVE : NWAVE;          // waves sharing the weight DMA of a stage
+    constexpr int BM = WM * MR * 16, BN = WN * NR * 16;
+    constexpr int B_STAGE = KS * BN * ROWB;              // bytes of one weight stage (hi)
+    constexpr int B_BUF = B_STAGE * (SPLIT ? 2 : 1);
+    constexpr int NQ = B_STAGE / 1024;                   // DMA instructions per stage (hi)
+    constexpr int AIT = (BM == 128) ? (NWAVE == 8 ? 3 : 5) : 6;     // max halo DMA instructions per wave (host checks p.hit <= AIT)
+    static_assert(B_STAGE % 1024 == 0, "stage must be a whole number of 1 KiB DMA pieces");
+    static_assert(!PP || (KS == 3 && NWAVE == 4), "ping-pong: two 4-wave groups, 3x3");
+    static_assert(!(UPS && KS == 1), "1x1 convs commute with nearest upsampling: run them at low resolution");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int grp = PP ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;
+    const int tid = PP ? ((int)threadIdx.x & 255) : (int)threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_d = PP ? grp * NWAVE + wave : wave;
+    const int wm = wave / WN, wn = wave % WN;
+    const int TH = 1 << p.lTH, TW = 1 << p.lTW, NBv = 1 << p.lNB;
+
+    int t = PP ? (int)blockIdx.x * 2 + grp : (int)blockIdx.x;
+    const int tx = t % p.tiles_x; t /= p.tiles_x;
+    const int ty = t % p.tiles_y; const int ng = t / p.tiles_y;
+    const int n0 = ng << p.lNB, y0 = ty << p.lTH, x0 = tx << p.lTW;
+    const int co0 = blockIdx.y * BN;
+
+    int HH, HW, oy, ox;
+    if (KS == 1) { HH = TH; HW = TW; oy = y0; ox = x0; }
+    else if (UPS) { HH = (TH >> 1) + 2; HW = (TW >> 1) + 2; oy = (y0 >> 1) - 1; ox = (x0 >> 1) - 1; }
+    else { HH = TH + 2; HW = TW + 2; oy = y0 - 1; ox = x0 - 1; }
+    const int halo_px = NBv * HH * HW;
+    const int a_bytes = p.hit * NWAVE * 1024;                          // one halo image (hi), rounded up to whole DMA pieces
+    const int a_buf = a_bytes * (SPLIT ? 2 : 1);                       // [hi][lo]
+    // LDS map: PP: [halo grp0][halo grp1][stage 0][stage 1];  else: [halo 0][halo 1 (a_dbuf)][stage 0][stage 1]
+    unsigned char* H_base = smem + (PP ? grp * a_buf : 0);
+    unsigned char* B_base = smem + ((PP || p.a_dbuf) ? 2 : 1) * a_buf;
+
+    // ---- fragment row geometry (linear patch order)
+    int a_nbbase[MR], a_py[MR], a_px[MR];
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr) {
+        int m = wm * (MR * 16) + mr * 16 + (lane & 15);
+        int nb, py, px;
+        tile_row_linear(m, p.lTH, p.lTW, nb, py, px);
+        a_nbbase[mr] = nb * HH * HW; a_py[mr] = py; a_px[mr] = px;
+    }
+    const int kb = lane >> 4;
+    const int bkey = (lane >> 1) & 3;                  // key of this lane's weight rows: (row >> 1) & 3 with row & 15 == lane & 15
+    int b_off[NR];
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) b_off[nr] = (wn * (NR * 16) + nr * 16 + (lane & 15)) * ROWB + ((kb ^ bkey) << 4);
+
+    f32x4_t acc[MR][NR];
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr) acc[mr][nr] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // ---- halo DMA descriptors (chunk independent).  Piece q = k*NWAVE + wave covers halo pixels 16q .. 16q+15; lane -> pixel
+    // 16q + lane/4, LDS slot lane%4, which holds channel group g = slot ^ ((hp>>1)&3) = (lane&3) ^ ((lane>>3)&3).
+    const int a_g8 = (((lane & 3) ^ ((lane >> 3) & 3))) * 8;
+    int a_off[AIT];                                    // element offset of (pixel, group) in the plane, or -1 (zero page)
+#pragma unroll
+    for (int k = 0; k < AIT; ++k) {
+        const int hp = (k * NWAVE + wave) * 16 + (lane >> 2);
+        const int hx = hp % HW, t2 = hp / HW;
+        const int hy = t2 % HH, nb = t2 / HH;
+        const int n = n0 + nb, iy = oy + hy, ix = ox + hx;
+        const bool inb = (k < p.hit) && (hp < halo_px) && (n < p.N) && (iy >= 0) && (iy < p.Hin) && (ix >= 0) && (ix < p.Win);
+        a_off[k] = inb ? (((n * p.Hin + iy) * p.Win + ix) * p.C8 + a_g8) : -1;
+    }
+    const uint16_t* zero16 = (const uint16_t*)lp_zero_page;
+    auto issue_a = [&](int chunk, unsigned char* Hbuf) {
+        const int c0 = chunk * CC;
+        const bool cok = (c0 + a_g8) < p.C8;
+        const unsigned dst = (unsigned)(uintptr_t)Hbuf;
+#pragma unroll
+        for (int k = 0; k < AIT; ++k) {
+            if (k < p.hit) {
+                const bool ok = cok && a_off[k] >= 0;
+                const size_t off = (size_t)(ok ? a_off[k] + c0 : 0);
+                const unsigned d = dst + (unsigned)((k * NWAVE + wave) * 1024);
+                lp_glds16(ok ? (p.a_hi + off) : zero16, d);
+                if (SPLIT) lp_glds16(ok ? (p.a_lo + off) : zero16, d + a_bytes);
+            }
+        }
+    };
+    // LDS-DMA of the weight tile of stage (chunk, ky) into stage buffer `buf`: piece q covers rows 16q .. 16q+15 of [KS*BN][32]
+    auto issue_b = [&](int chunk, int ky, int buf) {
+        const int c0 = chunk * CC;
+        const unsigned dst_lds = (unsigned)(uintptr_t)(B_base + buf * B_BUF);
+        const int rr = lane >> 2, slot = lane & 3;
+        const int g8 = (slot ^ ((rr >> 1) & 3)) * 8;
+#pragma unroll
+        for (int q0 = 0; q0 < NQ; q0 += NWD) {
+            const int q = q0 + wave_d;
+            if (NQ % NWD == 0 || q < NQ) {
+                const int r = q * 16 + rr;                                           // row inside the stage: kx * BN + n
+                const int kx = r / BN, n = r % BN;
+                const size_t off = ((size_t)((ky * KS + kx) * p.CoutP + co0 + n) * p.CinP + c0 + g8);
+                lp_glds16(p.w_hi + off, dst_lds + q * 1024);
+                if (SPLIT) lp_glds16(p.w_lo + off, dst_lds + B_STAGE + q * 1024);
+            }
+        }
+    };
+    // MFMAs of one stage: kernel row ky, halo image Hbuf, weights in stage buffer bbuf
+    auto compute = [&](int ky, const unsigned char* Hbuf, int bbuf) {
+        const unsigned char* A_hi = Hbuf;
+        const unsigned char* A_lo = Hbuf + a_bytes;
+        const unsigned char* Bc = B_base + bbuf * B_BUF;
+        s16x8_t fa[2][MR], fb[2][NR], fal[2][MR], fbl[2][NR];
+        auto fetch = [&](int kx, int set) {
+            const int dy = (KS == 3) ? ky : 0, dx = (KS == 3) ? kx : 0;
+            const unsigned char* Bk = Bc + kx * (BN * ROWB);
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr) {
+                int hy, hx;
+                if (KS == 1) { hy = a_py[mr]; hx = a_px[mr]; }
+                else if (UPS) { hy = ((a_py[mr] + dy - 1) >> 1) + 1; hx = ((a_px[mr] + dx - 1) >> 1) + 1; }
+                else { hy = a_py[mr] + dy; hx = a_px[mr] + dx; }
+                const int hp = a_nbbase[mr] + hy * HW + hx;
+                const int off = hp * ROWB + ((kb ^ ((hp >> 1) & 3)) << 4);
+                fa[set][mr] = *(const s16x8_t*)(A_hi + off);
+                if (SPLIT) fal[set][mr] = *(const s16x8_t*)(A_lo + off);
+            }
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) {
+                fb[set][nr] = *(const s16x8_t*)(Bk + b_off[nr]);
+                if (SPLIT) fbl[set][nr] = *(const s16x8_t*)(Bk + B_STAGE + b_off[nr]);
+            }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+            const int cur = kx & 1;
+            if (kx + 1 < KS) fetch(kx + 1, cur ^ 1);
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr) {
+                    if (SPLIT) {
+                        acc[mr][nr] = mfma16(fal[cur][mr], fb[cur][nr], acc[mr][nr]);
+                        acc[mr][nr] = mfma16(fa[cur][mr], fbl[cur][nr], acc[mr][nr]);
+                    }
+                    acc[mr][nr] = mfma16t<F16>(fa[cur][mr], fb[cur][nr], acc[mr][nr]);
+                }
+        }
+    };
+
+    const int nch_total = p.CinP / CC;
+    const int per = (nch_total + p.ksplit - 1) / p.ksplit;
+    const int cbeg = blockIdx.z * per;
+    const int nch = min(nch_total, cbeg + per) - cbeg;        // chunks of this workgroup: [cbeg, cbeg + nch)
+    if (nch <= 0) return;                                       // (uniform) nothing to contribute
+    const int S = nch * KS;
+    issue_b(cbeg, 0, 0);
+    issue_a(cbeg, H_base);
+
+    if constexpr (PP) {
+        // slot k = stage k of both groups.  Phase A(k): group 0 multiplies stage k, group 1 stages; phase B(k): swapped.  Staging
+        // duties: the group's share of the weight DMA of stage k+1 (buffer (k+1)&1, last read in slot k-1) and, in the phase right
+        // before its compute of a chunk's first stage, the halo of that chunk into the group's single halo buffer (the group itself
+        // is its only reader and it is not multiplying now).  Every barrier is preceded by vmcnt(0): all DMA issued so far has
+        // landed and is visible to the waves that pass the barrier.
+        for (int chunk = 0; chunk < nch; ++chunk) {
+            const bool has_next = chunk + 1 < nch;
+#pragma unroll
+            for (int ky = 0; ky < KS; ++ky) {
+                const int k = chunk * KS + ky;
+                const int bbuf = k & 1;
+                lp_wait_vm0();
+                __syncthreads();                                   // ---- phase A(k)
+                if (grp == 0) {
+                    compute(ky, H_base, bbuf);
+                } else {
+                    if (ky == 0 && chunk > 0) issue_a(cbeg + chunk, H_base);
+                    if (k + 1 < S) issue_b(cbeg + (k + 1) / KS, (k + 1) % KS, bbuf ^ 1);
+                }
+                lp_wait_vm0();
+                __syncthreads();                                   // ---- phase B(k)
+                if (grp == 1) {
+                    compute(ky, H_base, bbuf);
+                } else {
+                    if (ky == KS - 1 && has_next) issue_a(cbeg + chunk + 1, H_base);
+                    if (k + 1 < S) issue_b(cbeg + (k + 1) / KS, (k + 1) % KS, bbuf ^ 1);
+                }
+            }
+        }
+    } else {
+        // one group: top of stage s: own DMA landed, barrier (everyone finished stage s-1); issue the weights of stage s+1 and, in a
+        // chunk's first stage, the halo of the NEXT chunk into the other halo buffer (it has the whole chunk to land); multiply.
+        int abuf = 0;
+        for (int chunk = 0; chunk < nch; ++chunk) {
+            const bool has_next = chunk + 1 < nch;
+#pragma unroll
+            for (int ky = 0; ky < KS; ++ky) {
+                const int s = chunk * KS + ky;
+                lp_wait_vm0();
+                __syncthreads();
+                if (s + 1 < S) issue_b(cbeg + (s + 1) / KS, (s + 1) % KS, (s + 1) & 1);
+                if (p.a_dbuf && ky == 0 && has_next) issue_a(cbeg + chunk + 1, H_base + (abuf ^ 1) * a_buf);
+                compute(ky, H_base + abuf * a_buf, s & 1);
+                if (!p.a_dbuf && ky == KS - 1 && has_next) {      // (LDS-tight tiles) one halo buffer: restage it once everyone has read it
+                    __syncthreads();
+                    issue_a(cbeg + chunk + 1, H_base);
+                }
+            }
+            if (p.a_dbuf) abuf ^= 1;
+        }
+    }
+
+    // ---- epilogue.  C layout of mfma 16x16: col = lane&15 (channel), row = (lane>>4)*4 + reg (tile row)
+    float alpha = p.alpha ? *p.alpha : 1.f;
+    if (p.alpha2) alpha *= *p.alpha2;
+    if (p.ksplit == 1 && (p.Cout & 3) == 0) {
+        // Coalesced path: every wave transposes its (MR*16) x (NR*16) accumulator block through LDS (the staging buffers are dead
+        // now) and writes whole pixel rows -- NR*64 contiguous bytes per pixel, 16 B per lane; bias, residual, mask likewise.
+        constexpr int WR = MR * 16, WC = NR * 16, LDW = WC + 4;
+        __syncthreads();                                                  // all waves are done with the halo / weight buffers
+        float* tile = (float*)smem + wave_d * (WR * LDW);
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    tile[(mr * 16 + (lane >> 4) * 4 + r) * LDW + nr * 16 + (lane & 15)] = acc[mr][nr][r];
+        constexpr int C4 = WC / 4;                 // float4 columns per row
+        constexpr int RPP = 64 / C4;               // rows per pass of the wave
+        const int c4 = lane % C4, rsub = lane / C4;
+        const int co = co0 + wn * WC + c4 * 4;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias && co < p.Cout) bv = *(const float4*)(p.bias + co);
+#pragma unroll 4
+        for (int r0 = 0; r0 < WR; r0 += RPP) {
+            const int row = r0 + rsub;
+            const int m = wm * WR + row;
+            int nb, py, px;
+            tile_row_linear(m, p.lTH, p.lTW, nb, py, px);
+            const int n = n0 + nb, oyy = y0 + py, oxx = x0 + px;
+            if (n < p.N && oyy < p.H && oxx < p.W && co < p.Cout) {
+                float4 v = *(const float4*)(tile + row * LDW + c4 * 4);
+                v.x = fmaf(v.x, alpha, bv.x); v.y = fmaf(v.y, alpha, bv.y); v.z = fmaf(v.z, alpha, bv.z); v.w = fmaf(v.w, alpha, bv.w);
+                if (p.res) {
+                    const float4 rv = *(const float4*)(p.res + ((size_t)(n * (p.H >> p.res_shift) + (oyy >> p.res_shift)) * (p.W >> p.res_shift)
+                                                                + (oxx >> p.res_shift)) * p.Cout + co);
+                    v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                }
+                const size_t pix = (size_t)(n * p.H + oyy) * p.W + oxx;
+                if (p.mask16) {
+                    const ushort4 mv = *(const ushort4*)(p.mask16 + pix * p.Co8 + co);      // > 0  <=>  sign clear and magnitude non-zero
+                    v.x = (mv.x - 1u) < 0x7fffu ? v.x : 0.f; v.y = (mv.y - 1u) < 0x7fffu ? v.y : 0.f;
+                    v.z = (mv.z - 1u) < 0x7fffu ? v.z : 0.f; v.w = (mv.w - 1u) < 0x7fffu ? v.w : 0.f;
+                }
+                *(float4*)(p.y + pix * p.Cout + co) = v;
+                if (p.o_hi) {
+                    float o[4] = {v.x, v.y, v.z, v.w};
+                    ushort4 oh, ol;
+                    uint16_t* ohp = (uint16_t*)&oh; uint16_t* olp = (uint16_t*)&ol;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float q = p.o_relu ? fmaxf(o[j], 0.f) : o[j];
+                        ohp[j] = lp_f32_to_op16<F16>(q);
+                        if (SPLIT) olp[j] = lp_f32_to_op16<false>(q - lp_op16_to_f32<false>(ohp[j]));
+                    }
+                    *(ushort4*)(p.o_hi + pix * p.Co8 + co) = oh;
+                    if (SPLIT) *(ushort4*)(p.o_lo + pix * p.Co8 + co) = ol;
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = wm * (MR * 16) + mr * 16 + (lane >> 4) * 4 + r;
+            int nb, py, px;
+            tile_row_linear(m, p.lTH, p.lTW, nb, py, px);
+            const int n = n0 + nb, oyy = y0 + py, oxx = x0 + px;
+            if (n >= p.N || oyy >= p.H || oxx >= p.W) continue;
+            const size_t pixi = (size_t)(n * p.H + oyy) * p.W + oxx;
+            const size_t pix = pixi * p.Cout;
+            size_t rpix = 0;
+            if (p.res) rpix = ((size_t)(n * (p.H >> p.res_shift) + (oyy >> p.res_shift)) * (p.W >> p.res_shift) + (oxx >> p.res_shift)) * p.Cout;
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) {
+                const int co = co0 + wn * (NR * 16) + nr * 16 + (lane & 15);
+                if (co < p.Cout) {
+                    float v = acc[mr][nr][r] * alpha;
+                    if (p.ksplit == 1 || blockIdx.z == 0) {
+                        if (p.bias) v += p.bias[co];
+                        if (p.res) v += p.res[rpix + co];
+                    }
+                    if (p.mask16 && !((unsigned)(p.mask16[pixi * p.Co8 + co] - 1u) < 0x7fffu)) v = 0.f;   // (0/1 mask: commutes with the split-K sum)
+                    if (p.ksplit == 1) {
+                        p.y[pix + co] = v;
+                        if (p.o_hi) {
+                            const float q = p.o_relu ? fmaxf(v, 0.f) : v;
+                            const uint16_t h = lp_f32_to_op16<F16>(q);
+                            p.o_hi[pixi * p.Co8 + co] = h;
+                            if (SPLIT) p.o_lo[pixi * p.Co8 + co] = lp_f32_to_op16<false>(q - lp_op16_to_f32<false>(h));
+                        }
+                    } else unsafeAtomicAdd(p.y + pix + co, v);       // y was zeroed by lp_conv16_fwd (hipMemsetAsync on the stream)
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// host side: tile selection + dispatch
+// ------------------------------------------------------------------------------------------------------------------
+static int ilog2_floor(int v) { int l = 0; while ((1 << (l + 1)) <= v) ++l; return l; }
+
+// choose NB x TH x TW = BM with TH<=H, TW<=W (powers of two), preferring wide patches (TW up to 16)
+static void choose_tile(int BM, int N, int H, int W, int* lTH, int* lTW, int* lNB) {
+    int lbm = ilog2_floor(BM);
+    int ltw = ilog2_floor(W); if (ltw > 4) ltw = 4;
+    int lth = ilog2_floor(H); if (lth > lbm - ltw) lth = lbm - ltw;
+    if (lth < 1) lth = 1;
+    if (ltw < 1) ltw = 1;
+    int lnb = lbm - ltw - lth; if (lnb < 0) lnb = 0;
+    while (lnb > 0 && (1 << (lnb - 1)) >= N) --lnb;      // no more images per tile than exist (keeps the LDS halo small)
+    *lTH = lth; *lTW = ltw; *lNB = lnb;
+}
+
+template <int KS, bool UPS, int WM, int WN, int MR, int NR, int PREC, bool PP>
+static int launch_v(Conv16Params& p, size_t lds, dim3 grid, hipStream_t stream) {
+    auto kern = conv_dma_kernel<KS, UPS, WM, WN, MR, NR, PREC, PP>;
+    static thread_local int attr_dev = -1;                 // per host thread and device (main and autograd threads both launch)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return lp_set_error(LP_ERR_HIP, "hipGetDevice failed");
+    if (attr_dev != dev) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return lp_set_error(LP_ERR_HIP, "hipFuncSetAttribute failed");
+        attr_dev = dev;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64 * (PP ? 2 : 1)), lds, stream, p);
+    return lp_check_launch("conv_dma");
+}
+
+template <int KS, bool UPS, int WM, int WN, int MR, int NR, int PREC>
+static int launch_conv16(Conv16Params& p, hipStream_t stream) {
+    constexpr int BM = WM * MR * 16, BN = WN * NR * 16, NWAVE = WM * WN;
+    constexpr bool SPLIT = (PREC == LP_PREC_BF16X3);
+    constexpr size_t B_BUF = (size_t)KS * BN * 64 * (SPLIT ? 2 : 1);
+    constexpr size_t LDS_MAX = 160 * 1024;
+    constexpr int AIT = (BM == 128) ? (NWAVE == 8 ? 3 : 5) : 6;
+    choose_tile(BM, p.N, p.H, p.W, &p.lTH, &p.lTW, &p.lNB);
+    int HH, HW, halo_px;
+    for (;;) {       // fewer images per tile until the halo fits the per-wave descriptor budget (tiny feature maps)
+        const int TH = 1 << p.lTH, TW = 1 << p.lTW, NBv = 1 << p.lNB;
+        if (KS == 1) { HH = TH; HW = TW; } else if (UPS) { HH = TH / 2 + 2; HW = TW / 2 + 2; } else { HH = TH + 2; HW = TW + 2; }
+        halo_px = NBv * HH * HW;
+        if ((halo_px + 15) / 16 <= AIT * NWAVE || p.lNB == 0) break;
+        --p.lNB;
+    }
+    const int TH = 1 << p.lTH, TW = 1 << p.lTW, NBv = 1 << p.lNB;
+    p.tiles_x = (p.W + TW - 1) / TW; p.tiles_y = (p.H + TH - 1) / TH;
+    const int NH = (halo_px + 15) / 16;
+    p.hit = (NH + NWAVE - 1) / NWAVE;
+    if (p.hit > AIT) return lp_set_error(LP_ERR_UNSUPPORTED, "conv16: halo exceeds the DMA descriptor budget");
+    const size_t a_buf = (size_t)p.hit * NWAVE * 1024 * (SPLIT ? 2 : 1);
+    p.a_dbuf = (2 * a_buf + 2 * B_BUF <= LDS_MAX) ? 1 : 0;
+    size_t lds = (p.a_dbuf ? 2 : 1) * a_buf + 2 * B_BUF;
+    size_t epi = (size_t)NWAVE * (MR * 16) * (NR * 16 + 4) * sizeof(float);       // LDS transpose of the coalesced epilogue
+    const int tiles = p.tiles_x * p.tiles_y * ((p.N + NBv - 1) / NBv);
+    // ping-pong: two adjacent M tiles per workgroup, when the paired grid still covers the CUs.  LP_CONV_PP = 0 | 1 overrides.
+    constexpr bool pp_ok = (KS == 3) && (NWAVE == 4);
+    static const int pp_env = getenv("LP_CONV_PP") ? atoi(getenv("LP_CONV_PP")) : -1;
+    const long long pp_wgs = (long long)((tiles + 1) / 2) * ((p.Cout + BN - 1) / BN);
+    const bool pp = pp_ok && (pp_env >= 0 ? pp_env != 0 : pp_wgs >= 200) && tiles >= 2 && p.a_dbuf;
+    if (pp) epi *= 2;
+    if (lds < epi) lds = epi;
+    if (lds > LDS_MAX) return lp_set_error(LP_ERR_UNSUPPORTED, "conv16 tile needs too much LDS");
+    dim3 grid(pp ? (tiles + 1) / 2 : tiles, (p.Cout + BN - 1) / BN);
+    {   // split-K when the output tiling alone cannot fill the 256 CUs (4x4 ... 32x32 layers with K = 9*512)
+        static const int max_split = getenv("LP_CONV_KSPLIT") ? atoi(getenv("LP_CONV_KSPLIT")) : 8;
+        const int wgs = grid.x * grid.y, nch = p.CinP / 32;
+        int ks = 1;
+        while (ks < max_split && wgs * ks * 2 <= 256 && nch / (ks * 2) >= 2) ks *= 2;
+        p.ksplit = ks;
+        grid.z = ks;
+        if (ks > 1) { p.o_hi = nullptr; p.o_lo = nullptr; }      // partial sums: lp_conv16_fwd packs the finished y instead
+        if (ks > 1 && hipMemsetAsync(p.y, 0, (size_t)p.N * p.H * p.W * p.Cout * sizeof(float), stream) != hipSuccess)
+            return lp_set_error(LP_ERR_HIP, "hipMemsetAsync failed");
+    }
+    if constexpr (pp_ok) { if (pp) return launch_v<KS, UPS, WM, WN, MR, NR, PREC, true>(p, lds, grid, stream); }
+    return launch_v<KS, UPS, WM, WN, MR, NR, PREC, false>(p, lds, grid, stream);
+}
+
+template <int PREC>
+static int dispatch_conv16(Conv16Params& p, int ks, int ups, hipStream_t s) {
+    const bool big_img = p.H * p.W >= 256;     // a 256-pixel patch fits inside one image
+    // 8-wave groups (two waves per SIMD, each 64 x 32 of the 128 x 128 tile) for the small feature maps (<= 16x16): those run
+    // split-K with few stages per workgroup, so prologue and epilogue dominate.  LP_CONV_W8 = 0 | 1 forces it off / on.
+    static const int w8_env = getenv("LP_CONV_W8") ? atoi(getenv("LP_CONV_W8")) : -1;
+    const bool w8 = w8_env >= 0 ? (w8_env != 0) : (p.H * p.W <= 256);
+    if (w8 && p.Cout > 64) {
+        if (ks == 3 && !ups) return launch_conv16<3, false, 2, 4, 4, 2, PREC>(p, s);
+        if (ks == 3 && ups) return launch_conv16<3, true, 2, 4, 4, 2, PREC>(p, s);
+        if (ks == 1 && !ups) return launch_conv16<1, false, 2, 4, 4, 2, PREC>(p, s);
+    }
+    if (ks == 3 && !ups) {
+        if (p.Cout <= 16 && big_img) return launch_conv16<3, false, 4, 1, 4, 1, PREC>(p, s);
+        if (p.Cout <= 64 && big_img) return launch_conv16<3, false, 4, 1, 4, 4, PREC>(p, s);
+        return launch_conv16<3, false, 2, 2, 4, 4, PREC>(p, s);
+    }
+    if (ks == 3 && ups) {
+        if (p.Cout <= 64 && big_img) return launch_conv16<3, true, 4, 1, 4, 4, PREC>(p, s);
+        return launch_conv16<3, true, 2, 2, 4, 4, PREC>(p, s);
+    }
+    if (ks == 1 && !ups) {
+        if (p.Cout <= 64 && big_img) return launch_conv16<1, false, 4, 1, 4, 4, PREC>(p, s);
+        return launch_conv16<1, false, 2, 2, 4, 4, PREC>(p, s);
+    }
+    return lp_set_error(LP_ERR_UNSUPPORTED, "unsupported conv configuration");
+}
+
+extern "C" int lp_conv16_fwd(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* w_hi, const uint16_t* w_lo, float* y,
+                             const float* bias, const float* res, const float* alpha, const float* alpha2,
+                             int N, int H, int W, int Cin, int Cout, int CinP, int CoutP,
+                             int ksize, int upsample, int res_shift, int prec, const uint16_t* relu_mask16,
+                             uint16_t* out_hi, uint16_t* out_lo, int out_relu, void* stream) {
+    if (!a_hi || !w_hi || !y) return lp_set_error(LP_ERR_ARG, "lp_conv16_fwd: null pointer");
+    if (prec == LP_PREC_BF16X3 && (!w_lo || !a_lo)) return lp_set_error(LP_ERR_ARG, "lp_conv16_fwd: bf16x3 needs the lo planes");
+    if (prec == LP_PREC_BF16X3 && out_hi && !out_lo) return lp_set_error(LP_ERR_ARG, "lp_conv16_fwd: bf16x3 needs out_lo");
+    if (upsample && ((H | W) & 1)) return lp_set_error(LP_ERR_ARG, "lp_conv16_fwd: upsampled output dims must be even");
+    if (CinP % 32 || CinP < Cin || CoutP % 128 || CoutP < Cout) return lp_set_error(LP_ERR_ARG, "lp_conv16_fwd: bad padded dims");
+    if (H < 2 || W < 2) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_conv16_fwd: H,W must be >= 2");
+    Conv16Params p;
+    p.a_hi = a_hi; p.a_lo = a_lo; p.w_hi = w_hi; p.w_lo = w_lo; p.y = y; p.bias = bias; p.res = res; p.alpha = alpha; p.alpha2 = alpha2;
+    p.mask16 = relu_mask16; p.o_relu = out_relu;
+    p.o_hi = (Cout & 7) ? nullptr : out_hi; p.o_lo = (Cout & 7) ? nullptr : out_lo;   // (pad channels: the pack pass writes them)
+    p.N = N; p.H = H; p.W = W; p.Hin = upsample ? H / 2 : H; p.Win = upsample ? W / 2 : W;
+    p.Cin = Cin; p.C8 = (Cin + 7) & ~7; p.Cout = Cout; p.Co8 = (Cout + 7) & ~7; p.CinP = CinP; p.CoutP = CoutP; p.res_shift = res_shift;
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if (prec == LP_PREC_BF16) rc = dispatch_conv16<LP_PREC_BF16>(p, ksize, upsample, s);
+    else if (prec == LP_PREC_BF16X3) rc = dispatch_conv16<LP_PREC_BF16X3>(p, ksize, upsample, s);
+    else if (prec == LP_PREC_F16) rc = dispatch_conv16<LP_PREC_F16>(p, ksize, upsample, s);
+    else return lp_set_error(LP_ERR_ARG, "lp_conv16_fwd: unknown precision mode");
+    if (rc) return rc;
+    // the epilogue cannot emit the 16-bit planes from partial sums (split-K) or for channel counts it writes element-wise with
+    // padding channels: a bandwidth-bound pass over the finished y does it instead (same stream)
+    if (out_hi && !p.o_hi)
+        return lp_act_pack(y, nullptr, nullptr, out_relu ? 2 : 0, out_hi, out_lo, N, H * W, Cout, prec, nullptr, stream);
+    return LP_OK;
+}

@@ -208,7 +208,7 @@ int lp_wgrad_thin(const float* x, const float* dy, float* dw, float* workspace, 
 // ------------------------------------------------------------------------------------------------------------------
 struct ThinFwdParams {
     const float* x; const uint16_t* w_hi; const uint16_t* w_lo; float* y; const float* bias; const float* alpha;
-    int N, H, W, Cin, Cout, CinP, CoutP;
+    int N, H, W, Cin, Cout, CinP, CoutP, f16;
 };
 
 template <int KS, bool C4>
@@ -224,8 +224,8 @@ __global__ __launch_bounds__(256) void conv_thin_fwd_kernel(ThinFwdParams p) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const size_t idx = ((size_t)t * p.CoutP + co) * p.CinP + c;         // pack layout [tap][CoutP][CinP], zero padded
-            float v = __uint_as_float((unsigned)p.w_hi[idx] << 16);
-            if (p.w_lo) v += __uint_as_float((unsigned)p.w_lo[idx] << 16);
+            float v = p.f16 ? lp_op16_to_f32<true>(p.w_hi[idx]) : lp_op16_to_f32<false>(p.w_hi[idx]);
+            if (p.w_lo) v += lp_op16_to_f32<false>(p.w_lo[idx]);
             w[t][c] = v;
         }
     const float alpha = p.alpha ? *p.alpha : 1.f;
@@ -279,10 +279,10 @@ bool lp_conv_thin_fwd_supported(int Cin, int Cout, int ksize, int upsample, int 
 }
 
 int lp_conv_thin_fwd(const float* x, const uint16_t* w_hi, const uint16_t* w_lo, float* y, const float* bias, const float* alpha, int N,
-                     int H, int W, int Cin, int Cout, int CinP, int CoutP, int ksize, hipStream_t stream) {
+                     int H, int W, int Cin, int Cout, int CinP, int CoutP, int ksize, int f16, hipStream_t stream) {
     ThinFwdParams p;
     p.x = x; p.w_hi = w_hi; p.w_lo = w_lo; p.y = y; p.bias = bias; p.alpha = alpha;
-    p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.CinP = CinP; p.CoutP = CoutP;
+    p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.CinP = CinP; p.CoutP = CoutP; p.f16 = f16;
     int G = N * ((H + 3) / 4);
     if (G > 2048) G = 2048;
     const size_t lds = (size_t)(4 + 2 * (ksize / 2)) * (W + 2 * (ksize / 2)) * 16;
@@ -292,4 +292,31 @@ int lp_conv_thin_fwd(const float* x, const uint16_t* w_hi, const uint16_t* w_lo,
     else { if (Cin == 4) hipLaunchKernelGGL((conv_thin_fwd_kernel<1, true>), grid, dim3(256), lds, stream, p);
            else hipLaunchKernelGGL((conv_thin_fwd_kernel<1, false>), grid, dim3(256), lds, stream, p); }
     return lp_check_launch("conv_thin_fwd");
+}
+
+// ---- C ABI of the thin-channel kernels (fp32 activations in, no operand planes) --------------------------------------------------
+extern "C" int lp_thin_conv_supported(int Cin, int Cout, int ksize, int W) {
+    return lp_conv_thin_fwd_supported(Cin, Cout, ksize, 0, 0, false, W) ? 1 : 0;
+}
+
+extern "C" int lp_thin_conv_fwd(const float* x, const uint16_t* w_hi, const uint16_t* w_lo, float* y, const float* bias, const float* alpha,
+                                int N, int H, int W, int Cin, int Cout, int CinP, int CoutP, int ksize, int prec, void* stream) {
+    if (!x || !w_hi || !y) return lp_set_error(LP_ERR_ARG, "lp_thin_conv_fwd: null pointer");
+    if (!lp_conv_thin_fwd_supported(Cin, Cout, ksize, 0, 0, false, W)) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_thin_conv_fwd: unsupported shape");
+    return lp_conv_thin_fwd(x, w_hi, prec == LP_PREC_BF16X3 ? w_lo : nullptr, y, bias, alpha, N, H, W, Cin, Cout, CinP, CoutP, ksize,
+                            prec == LP_PREC_F16, (hipStream_t)stream);
+}
+
+extern "C" int lp_thin_wgrad_supported(int Cin, int Cout, int ksize, int pro, int W) {
+    return lp_wgrad_thin_supported(Cin, Cout, ksize, 0, pro, W) ? 1 : 0;
+}
+
+extern "C" int lp_thin_wgrad_has_dbias(int Cin, int Cout) { (void)Cin; return Cout > 4; }
+
+extern "C" int lp_thin_wgrad(const float* x, const float* dy, float* dw, float* workspace, const float* scale, const float* shift,
+                             int N, int H, int W, int Cin, int Cout, int ksize, int pro, int splits, float* dbias, void* stream) {
+    if (!x || !dy || !dw || !workspace) return lp_set_error(LP_ERR_ARG, "lp_thin_wgrad: null pointer");
+    if (pro == 1 && (!scale || !shift)) return lp_set_error(LP_ERR_ARG, "lp_thin_wgrad: pro=1 needs scale/shift");
+    if (!lp_wgrad_thin_supported(Cin, Cout, ksize, 0, pro, W)) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_thin_wgrad: unsupported shape");
+    return lp_wgrad_thin(x, dy, dw, workspace, scale, shift, N, H, W, Cin, Cout, ksize, pro, splits, dbias, (hipStream_t)stream);
 }

@@ -1,5 +1,7 @@
 // Weight-gradient of the fused conv for gfx950:
-//   dw[co][ci][tap] = sum_{n,y,x} dy[n,y,x,co] * up2?(act(x))[n, y+dy_t, x+dx_t, ci]
+//   dw[co][ci][tap] = sum_{n,y,x} dy[n,y,x,co] * up2?(a)[n, y+dy_t, x+dx_t, ci]
+// Both operands arrive as 16-bit operand planes (hi [, lo]; lp_act_pack / the conv epilogue): `a` is the ACTIVATED input the
+// forward conv multiplied (saved by the forward pass, so no prologue is recomputed here), dy the packed output gradient.
 // GEMM view: M = co, N = ci (per tap), K = pixels.  Both operands are pixel-major in HBM (NHWC), i.e. K is the slow
 // dimension of both -> the MFMA fragments (8 consecutive k per lane) are fetched from [pixel][channel] LDS tiles with
 // ds_read_b64_tr_b16 (gfx950 transposing LDS read; lane/element mapping verified by probes/probe_layout.hip):
@@ -13,13 +15,19 @@
 #include <stdlib.h>
 
 struct WgradParams {
-    const float* x; const float* dy; float* part;
+    const uint16_t* a_hi; const uint16_t* a_lo; const uint16_t* d_hi; const uint16_t* d_lo; float* part;
     float* bpart;          // NULL | [splits][CoP] partial bias gradients (column sums of dy), written by the ci-block-0 workgroups
-    const float* scale; const float* shift;
-    int N, H, W, Hin, Win, Cin, Cout, CoP, CiP;
-    int pro, splits, num_tiles;
+    int N, H, W, Hin, Win, Cin, Cout, C8, Co8, CoP, CiP;
+    int splits, num_tiles;
     int lTH, lTW, lNB, tiles_x, tiles_y;
 };
+
+// zero-masked 16-byte load of 8 consecutive 16-bit channels
+__device__ __forceinline__ s16x8_t ld16x8(const uint16_t* p) { return *(const s16x8_t*)p; }
+template <bool F16> __device__ __forceinline__ void acc8(float (&s)[8], s16x8_t v) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] += lp_op16_to_f32<F16>((uint16_t)v[j]);
+}
 
 typedef s16x4_t __attribute__((address_space(3))) * lds_s16x4_ptr;
 
@@ -33,7 +41,7 @@ template <int KS, bool UPS, int PREC, int COB = 64>
 __global__ __launch_bounds__(COB * 4) void conv_wgrad_kernel(WgradParams p) {
     constexpr int NT = COB * 4;                    // threads: one wave per 32(co) x 32(ci) sub-block
     constexpr int DCG = COB / 8;                   // 8-channel groups of the dy tile
-    constexpr bool SPLIT = (PREC == LP_PREC_BF16X3);
+    constexpr bool SPLIT = (PREC == LP_PREC_BF16X3), F16 = (PREC == LP_PREC_F16);
     constexpr int T = KS * KS;
     constexpr int CC = 64;
     constexpr int SA = CC * 2 + 16, SD = COB * 2 + 16;
@@ -71,7 +79,7 @@ __global__ __launch_bounds__(COB * 4) void conv_wgrad_kernel(WgradParams p) {
     const int halo_px = NBv * HH * HW;
     // measured: pays only where the kernel is LDS-limited to one workgroup per CU anyway (bf16x3, full-size halo); the bf16 kernel
     // keeps its small register footprint (2-3 workgroups per CU hide the staging latency instead)
-    const bool fast = SPLIT && !UPS && (NBv == 1) && ((p.Cin & 7) == 0) && ((p.Cout & 7) == 0) && (halo_px <= AIT * APP);
+    const bool fast = SPLIT && !UPS && (NBv == 1) && (halo_px <= AIT * APP);
     const int a_cg = tid & 7, a_hp0 = tid >> 3;
     const int d_cg = tid % DCG, d_p0 = tid / DCG;           // dy tile: 128 pixels x DCG groups = 4 items per thread
 
@@ -144,7 +152,7 @@ __global__ __launch_bounds__(COB * 4) void conv_wgrad_kernel(WgradParams p) {
                         }
                     }
 #pragma unroll
-                    for (int mf = 0; mf < 2; ++mf) acc[tap][mf][nf] = mfma16(a[mf], bf[cur][nf], acc[tap][mf][nf]);
+                    for (int mf = 0; mf < 2; ++mf) acc[tap][mf][nf] = mfma16t<F16>(a[mf], bf[cur][nf], acc[tap][mf][nf]);
                 }
             }
         }
@@ -152,17 +160,15 @@ __global__ __launch_bounds__(COB * 4) void conv_wgrad_kernel(WgradParams p) {
 
     if (SPLIT && !UPS && fast) {
         // bf16x3: registers and LDS admit one workgroup per CU, so nothing else hides the global latency of the staging loads:
-        // the loads of the NEXT tile are issued before the MFMAs of the current one and converted / written to LDS afterwards
+        // the loads of the NEXT tile are issued before the MFMAs of the current one and written to LDS afterwards
         // (issue and use inside one loop iteration, unconditional with a clamped tile index -> no early waits).
-        float4 ald[AIT][2], dld[4][2];
+        s16x8_t ald[AIT][2], dld[4][2];
         int apix[AIT], dpix[4];
         int n0, y0, x0, oy, ox;
         const int cA = ci0 + a_cg * 8, cD = co0 + d_cg * 8;
-        const bool cokA = cA < p.Cin, cokD = cD < p.Cout;
+        const bool cokA = cA < p.C8, cokD = cD < p.Co8;
         auto issue_loads = [&](int tile) {
             tile_origin(tile, n0, y0, x0, oy, ox);
-            // all global loads of the tile (activation halo + dY) are issued back to back and unconditionally (out-of-image
-            // items read pixel 0 and are zeroed afterwards), then transformed and written: one exposed memory latency per tile
 #pragma unroll
             for (int k = 0; k < AIT; ++k) {
                 const int hp = a_hp0 + k * APP;
@@ -170,8 +176,8 @@ __global__ __launch_bounds__(COB * 4) void conv_wgrad_kernel(WgradParams p) {
                 const int iy = oy + hy, ix = ox + hx;
                 const bool inb = (hp < halo_px) && (n0 < p.N) && (iy >= 0) && (iy < p.Hin) && (ix >= 0) && (ix < p.Win);
                 apix[k] = inb ? ((n0 * p.Hin + iy) * p.Win + ix) : (hp < halo_px ? -1 : -2);
-                const float* src = p.x + (size_t)(apix[k] >= 0 ? apix[k] : 0) * p.Cin + (cokA ? cA : 0);
-                ald[k][0] = *(const float4*)src; ald[k][1] = *(const float4*)(src + 4);
+                const size_t off = (size_t)(apix[k] >= 0 ? apix[k] : 0) * p.C8 + (cokA ? cA : 0);
+                ald[k][0] = ld16x8(p.a_hi + off); ald[k][1] = ld16x8(p.a_lo + off);
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -180,47 +186,29 @@ __global__ __launch_bounds__(COB * 4) void conv_wgrad_kernel(WgradParams p) {
                 tile_lin_decode(kp, p.lTH, p.lTW, nb, py, px);
                 const int n = n0 + nb, yy = y0 + py, xx = x0 + px;
                 dpix[k] = (n < p.N && yy < p.H && xx < p.W) ? ((n * p.H + yy) * p.W + xx) : -1;
-                const float* src = p.dy + (size_t)(dpix[k] >= 0 ? dpix[k] : 0) * p.Cout + (cokD ? cD : 0);
-                dld[k][0] = *(const float4*)src; dld[k][1] = *(const float4*)(src + 4);
+                const size_t off = (size_t)(dpix[k] >= 0 ? dpix[k] : 0) * p.Co8 + (cokD ? cD : 0);
+                dld[k][0] = ld16x8(p.d_hi + off); dld[k][1] = ld16x8(p.d_lo + off);
             }
         };
         auto convert_write = [&]() {
-            float4 s0 = make_float4(1.f, 1.f, 1.f, 1.f), s1 = s0, t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0;
-            if (p.pro == 1) {
-                const float* sp = p.scale + (size_t)(n0 < p.N ? n0 : 0) * p.Cin + (cokA ? cA : 0);
-                const float* tp = p.shift + (size_t)(n0 < p.N ? n0 : 0) * p.Cin + (cokA ? cA : 0);
-                s0 = *(const float4*)sp; s1 = *(const float4*)(sp + 4); t0 = *(const float4*)tp; t1 = *(const float4*)(tp + 4);
-            }
-            const float lo_clamp = (p.pro != 0) ? 0.f : -3.0e38f;
+            const s16x8_t z = (s16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int k = 0; k < AIT; ++k) {
-                float v[8] = {ald[k][0].x, ald[k][0].y, ald[k][0].z, ald[k][0].w, ald[k][1].x, ald[k][1].y, ald[k][1].z, ald[k][1].w};
-                v[0] = fmaxf(fmaf(v[0], s0.x, t0.x), lo_clamp); v[1] = fmaxf(fmaf(v[1], s0.y, t0.y), lo_clamp);
-                v[2] = fmaxf(fmaf(v[2], s0.z, t0.z), lo_clamp); v[3] = fmaxf(fmaf(v[3], s0.w, t0.w), lo_clamp);
-                v[4] = fmaxf(fmaf(v[4], s1.x, t1.x), lo_clamp); v[5] = fmaxf(fmaf(v[5], s1.y, t1.y), lo_clamp);
-                v[6] = fmaxf(fmaf(v[6], s1.z, t1.z), lo_clamp); v[7] = fmaxf(fmaf(v[7], s1.w, t1.w), lo_clamp);
                 const bool keep = (apix[k] >= 0) && cokA;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = keep ? v[j] : 0.f;
-                s16x8_t hi, lo;
-                cvt8<SPLIT>(v, hi, lo);
                 const int off = (a_hp0 + k * APP) * SA + a_cg * 16;
                 if (apix[k] != -2) {
-                    *(s16x8_t*)(A_hi + off) = hi;
-                    if (SPLIT) *(s16x8_t*)(A_lo + off) = lo;
+                    *(s16x8_t*)(A_hi + off) = keep ? ald[k][0] : z;
+                    *(s16x8_t*)(A_lo + off) = keep ? ald[k][1] : z;
                 }
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                float v[8] = {dld[k][0].x, dld[k][0].y, dld[k][0].z, dld[k][0].w, dld[k][1].x, dld[k][1].y, dld[k][1].z, dld[k][1].w};
                 const bool keep = (dpix[k] >= 0) && cokD;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { v[j] = keep ? v[j] : 0.f; dsum[j] += v[j]; }
-                s16x8_t hi, lo;
-                cvt8<SPLIT>(v, hi, lo);
+                const s16x8_t h = keep ? dld[k][0] : z, l = keep ? dld[k][1] : z;
+                acc8<false>(dsum, h); acc8<false>(dsum, l);
                 const int off = (d_p0 + k * 32) * SD + d_cg * 16;
-                *(s16x8_t*)(D_hi + off) = hi;
-                if (SPLIT) *(s16x8_t*)(D_lo + off) = lo;
+                *(s16x8_t*)(D_hi + off) = h;
+                *(s16x8_t*)(D_lo + off) = l;
             }
         };
         if (COB == 64) {
@@ -245,37 +233,41 @@ __global__ __launch_bounds__(COB * 4) void conv_wgrad_kernel(WgradParams p) {
             }
         }
     } else {
+        const s16x8_t z = (s16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
         for (int tile = blockIdx.x; tile < p.num_tiles; tile += p.splits) {
             int n0, y0, x0, oy, ox;
             tile_origin(tile, n0, y0, x0, oy, ox);
             __syncthreads();                 // previous tile fully consumed
-            stage_act_halo<CC, SPLIT, NT>(A_hi, A_lo, SA, p.x, p.scale, p.shift, p.pro, p.N, p.Hin, p.Win, p.Cin,
-                                      n0, NBv, HH, HW, oy, ox, ci0, tid);
-            // dy tile: [128 pixels (row-major in patch)][64 co] -> bf16
+            // activated input halo: [halo pixel][64 ci] 16-bit, out-of-image pixels and channels beyond C8 are zero
+            for (int i = tid; i < halo_px * 8; i += NT) {
+                const int cg = i & 7, hp = i >> 3;
+                const int hx = hp % HW, t2 = hp / HW;
+                const int hy = t2 % HH, nb = t2 / HH;
+                const int n = n0 + nb, iy = oy + hy, ix = ox + hx, c = ci0 + cg * 8;
+                const bool inb = (n < p.N) && (iy >= 0) && (iy < p.Hin) && (ix >= 0) && (ix < p.Win) && (c < p.C8);
+                const size_t off = inb ? ((size_t)((n * p.Hin + iy) * p.Win + ix) * p.C8 + c) : 0;
+                const s16x8_t h = ld16x8(p.a_hi + off);
+                *(s16x8_t*)(A_hi + (size_t)hp * SA + cg * 16) = inb ? h : z;
+                if (SPLIT) { const s16x8_t l = ld16x8(p.a_lo + off); *(s16x8_t*)(A_lo + (size_t)hp * SA + cg * 16) = inb ? l : z; }
+            }
+            // dy tile: [128 pixels (row-major in patch)][COB co] 16-bit
             for (int i = tid; i < BMP * DCG; i += NT) {
-                int cg = i % DCG, kp = i / DCG;
+                const int cg = i % DCG, kp = i / DCG;
                 int nb, py, px;
                 tile_lin_decode(kp, p.lTH, p.lTW, nb, py, px);
-                int n = n0 + nb, yy = y0 + py, xx = x0 + px, c = co0 + cg * 8;
-                float v[8];
-    #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = 0.f;
-                if (n < p.N && yy < p.H && xx < p.W && c < p.Cout) {
-                    const float* src = p.dy + ((size_t)(n * p.H + yy) * p.W + xx) * p.Cout + c;
-                    if ((p.Cout & 3) == 0 && c + 8 <= p.Cout) {
-                        float4 p0 = *(const float4*)src, p1 = *(const float4*)(src + 4);
-                        v[0] = p0.x; v[1] = p0.y; v[2] = p0.z; v[3] = p0.w; v[4] = p1.x; v[5] = p1.y; v[6] = p1.z; v[7] = p1.w;
-                    } else {
-    #pragma unroll
-                        for (int j = 0; j < 8; ++j) if (c + j < p.Cout) v[j] = src[j];
-                    }
+                const int n = n0 + nb, yy = y0 + py, xx = x0 + px, c = co0 + cg * 8;
+                const bool inb = (n < p.N && yy < p.H && xx < p.W && c < p.Co8);
+                const size_t off = inb ? ((size_t)((n * p.H + yy) * p.W + xx) * p.Co8 + c) : 0;
+                const s16x8_t h0 = ld16x8(p.d_hi + off);
+                const s16x8_t h = inb ? h0 : z;
+                acc8<F16>(dsum, h);
+                *(s16x8_t*)(D_hi + kp * SD + cg * 16) = h;
+                if (SPLIT) {
+                    const s16x8_t l0 = ld16x8(p.d_lo + off);
+                    const s16x8_t l = inb ? l0 : z;
+                    acc8<false>(dsum, l);
+                    *(s16x8_t*)(D_lo + kp * SD + cg * 16) = l;
                 }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) dsum[j] += v[j];
-                s16x8_t hi, lo;
-                cvt8<SPLIT>(v, hi, lo);
-                *(s16x8_t*)(D_hi + kp * SD + cg * 16) = hi;
-                if (SPLIT) *(s16x8_t*)(D_lo + kp * SD + cg * 16) = lo;
             }
             __syncthreads();
             compute_tile();
@@ -313,7 +305,8 @@ __global__ __launch_bounds__(COB * 4) void conv_wgrad_kernel(WgradParams p) {
 // coalesced; 8 independent accumulators keep 8 loads in flight per thread (the slabs are streamed once from HBM/L2).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int S, int T,
                                                            int Cout, int Cin, int CoP, int CiP, const float* __restrict__ bpart,
-                                                           float* __restrict__ dbias, int wblocks) {
+                                                           float* __restrict__ dbias, int wblocks, const float* __restrict__ out_scale) {
+    const float osc = out_scale ? out_scale[0] : 1.f;          // 1 / (input scale of the fp16 dy operand)
     if ((int)blockIdx.x >= wblocks) {                 // trailing blocks: dbias[co] = sum_s bpart[s][co], 64 channels per block,
         __shared__ float red[4][64];                  // the splits dealt to 4 thread groups x 4 independent accumulators
         const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
@@ -329,7 +322,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         }
         red[g][c] = (a0 + a1) + (a2 + a3);
         __syncthreads();
-        if (g == 0 && co < Cout) dbias[co] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+        if (g == 0 && co < Cout) dbias[co] = ((red[0][c] + red[1][c]) + (red[2][c] + red[3][c])) * osc;
         return;
     }
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -345,13 +338,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         for (int j = 0; j < 8; ++j) a[j] += p[(size_t)(k + j) * slab];
     }
     for (; k < S; ++k) a[0] += p[(size_t)k * slab];
-    dw[((size_t)co * Cin + ci) * T + t] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    dw[((size_t)co * Cin + ci) * T + t] = (((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) * osc;
 }
 
 static int ilog2_floor_w(int v) { int l = 0; while ((1 << (l + 1)) <= v) ++l; return l; }
 
 template <int KS, bool UPS, int PREC, int COB = 64>
-static int launch_wgrad(WgradParams& p, float* dw, float* dbias, hipStream_t stream) {
+static int launch_wgrad(WgradParams& p, float* dw, float* dbias, const float* out_scale, hipStream_t stream) {
     constexpr bool SPLIT = (PREC == LP_PREC_BF16X3);
     constexpr int SA = 64 * 2 + 16, SD = COB * 2 + 16;
     // 128-pixel tiles, row-major inside the patch; TW >= 4 so that 4 consecutive k are 4 consecutive x
@@ -370,11 +363,13 @@ static int launch_wgrad(WgradParams& p, float* dw, float* dbias, hipStream_t str
     if (lds < (size_t)COB * 4 * 8 * sizeof(float)) lds = (size_t)COB * 4 * 8 * sizeof(float);      // bias-gradient reduction scratch
     if (lds > 160 * 1024) return lp_set_error(LP_ERR_UNSUPPORTED, "wgrad tile needs too much LDS");
     auto kern = conv_wgrad_kernel<KS, UPS, PREC, COB>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static thread_local int attr_dev = -1;                 // per host thread and device (main and autograd threads both launch)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return lp_set_error(LP_ERR_HIP, "hipGetDevice failed");
+    if (attr_dev != dev) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return lp_set_error(LP_ERR_HIP, "hipFuncSetAttribute failed");
-        attr_set = true;
+        attr_dev = dev;
     }
     dim3 grid(p.splits, (p.CoP + COB - 1) / COB, p.CiP / 64);
     hipLaunchKernelGGL(kern, grid, dim3(COB * 4), lds, stream, p);
@@ -383,7 +378,7 @@ static int launch_wgrad(WgradParams& p, float* dw, float* dbias, hipStream_t str
     int total = KS * KS * p.Cout * p.Cin;
     const int wblocks = (total + 255) / 256, bblocks = p.bpart ? (p.Cout + 63) / 64 : 0;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wblocks + bblocks), dim3(256), 0, stream, p.part, dw, p.splits, KS * KS,
-                       p.Cout, p.Cin, p.CoP, p.CiP, p.bpart, dbias, wblocks);
+                       p.Cout, p.Cin, p.CoP, p.CiP, p.bpart, dbias, wblocks, out_scale);
     return lp_check_launch("wgrad_reduce");
 }
 
@@ -394,43 +389,35 @@ extern "C" long long lp_conv_wgrad_workspace_bytes(int Cin, int Cout, int ksize,
     return (long long)splits * ksize * ksize * round_up(Cout, 64) * round_up(Cin, 64) * 4 + (long long)splits * round_up(Cout, 64) * 4;
 }
 
-extern "C" int lp_conv_wgrad_has_dbias(int Cin, int Cout, int ksize, int upsample, int pro) {
-    (void)Cin; (void)ksize; (void)upsample; (void)pro;
-    return Cout > 4;           // the thin-dy kernel (Cout <= 4) leaves the 4-value bias gradient to the caller
-}
-
-extern "C" int lp_conv_wgrad(const float* x, const float* dy, float* dw, float* workspace, const float* scale, const float* shift,
-                             int N, int H, int W, int Cin, int Cout, int ksize, int upsample, int pro, int splits, int prec,
-                             float* dbias, void* stream) {
-    if (!x || !dy || !dw || !workspace) return lp_set_error(LP_ERR_ARG, "lp_conv_wgrad: null pointer");
-    if (pro == 1 && (!scale || !shift)) return lp_set_error(LP_ERR_ARG, "lp_conv_wgrad: pro=1 needs scale/shift");
-    if (splits < 1) return lp_set_error(LP_ERR_ARG, "lp_conv_wgrad: splits must be >= 1");
-    if (upsample && ((H | W) & 1)) return lp_set_error(LP_ERR_ARG, "lp_conv_wgrad: upsampled dims must be even");
-    if (prec != LP_PREC_BF16 && prec != LP_PREC_BF16X3) return lp_set_error(LP_ERR_ARG, "lp_conv_wgrad: unknown precision");
-    {   // <= 4 channels on one side (image-side convs, generator head): bandwidth-bound fp32 reduction, not an MFMA problem
-        static const int thin_env = getenv("LP_WGRAD_THIN") ? atoi(getenv("LP_WGRAD_THIN")) : 1;
-        if (thin_env && lp_wgrad_thin_supported(Cin, Cout, ksize, upsample, pro, W))
-            return lp_wgrad_thin(x, dy, dw, workspace, scale, shift, N, H, W, Cin, Cout, ksize, pro, splits, dbias, (hipStream_t)stream);
-    }
-    WgradParams p;
-    p.x = x; p.dy = dy; p.part = workspace; p.scale = scale; p.shift = shift;
-    p.N = N; p.H = H; p.W = W; p.Hin = upsample ? H / 2 : H; p.Win = upsample ? W / 2 : W;
-    p.Cin = Cin; p.Cout = Cout; p.CoP = round_up(Cout, 64); p.CiP = round_up(Cin, 64);
-    p.pro = pro; p.splits = splits;
-    p.bpart = (dbias && Cout > 4) ? workspace + (size_t)splits * ksize * ksize * p.CoP * p.CiP : nullptr;
-    hipStream_t s = (hipStream_t)stream;
-#define LP_WG(KS_, UPS_) (prec == LP_PREC_BF16 ? launch_wgrad<KS_, UPS_, LP_PREC_BF16>(p, dw, dbias, s) : launch_wgrad<KS_, UPS_, LP_PREC_BF16X3>(p, dw, dbias, s))
-    if (prec != LP_PREC_BF16 && prec != LP_PREC_BF16X3) return lp_set_error(LP_ERR_ARG, "lp_conv_wgrad: unknown precision");
+template <int PREC>
+static int dispatch_wgrad(WgradParams& p, float* dw, float* dbias, const float* out_scale, int ksize, int upsample, hipStream_t s) {
     // 128 output channels per workgroup (8 waves) where the layer is wide enough; LP_WGRAD_COB = 64 | 128 overrides
     static const int cob_env = getenv("LP_WGRAD_COB") ? atoi(getenv("LP_WGRAD_COB")) : 0;
     const bool cob128 = cob_env ? (cob_env == 128) : true;      // measured: -9 % (bf16x3), -6 % (bf16) on the 64..512-channel layers
-    if (cob128 && Cout >= 128 && ksize == 3) {
-        if (prec == LP_PREC_BF16) return upsample ? launch_wgrad<3, true, LP_PREC_BF16, 128>(p, dw, dbias, s) : launch_wgrad<3, false, LP_PREC_BF16, 128>(p, dw, dbias, s);
-        return upsample ? launch_wgrad<3, true, LP_PREC_BF16X3, 128>(p, dw, dbias, s) : launch_wgrad<3, false, LP_PREC_BF16X3, 128>(p, dw, dbias, s);
-    }
-    if (ksize == 3 && !upsample) return LP_WG(3, false);
-    if (ksize == 3 && upsample) return LP_WG(3, true);
-    if (ksize == 1 && !upsample) return LP_WG(1, false);
-#undef LP_WG
-    return lp_set_error(LP_ERR_UNSUPPORTED, "lp_conv_wgrad: unsupported configuration");
+    if (cob128 && p.Cout >= 128 && ksize == 3)
+        return upsample ? launch_wgrad<3, true, PREC, 128>(p, dw, dbias, out_scale, s) : launch_wgrad<3, false, PREC, 128>(p, dw, dbias, out_scale, s);
+    if (ksize == 3 && !upsample) return launch_wgrad<3, false, PREC>(p, dw, dbias, out_scale, s);
+    if (ksize == 3 && upsample) return launch_wgrad<3, true, PREC>(p, dw, dbias, out_scale, s);
+    if (ksize == 1 && !upsample) return launch_wgrad<1, false, PREC>(p, dw, dbias, out_scale, s);
+    return lp_set_error(LP_ERR_UNSUPPORTED, "lp_conv16_wgrad: unsupported configuration");
+}
+
+extern "C" int lp_conv16_wgrad(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* dy_hi, const uint16_t* dy_lo, float* dw,
+                               float* workspace, int N, int H, int W, int Cin, int Cout, int ksize, int upsample, int splits, int prec,
+                               float* dbias, const float* out_scale, void* stream) {
+    if (!a_hi || !dy_hi || !dw || !workspace) return lp_set_error(LP_ERR_ARG, "lp_conv16_wgrad: null pointer");
+    if (prec == LP_PREC_BF16X3 && (!a_lo || !dy_lo)) return lp_set_error(LP_ERR_ARG, "lp_conv16_wgrad: bf16x3 needs the lo planes");
+    if (splits < 1) return lp_set_error(LP_ERR_ARG, "lp_conv16_wgrad: splits must be >= 1");
+    if (upsample && ((H | W) & 1)) return lp_set_error(LP_ERR_ARG, "lp_conv16_wgrad: upsampled dims must be even");
+    WgradParams p;
+    p.a_hi = a_hi; p.a_lo = a_lo; p.d_hi = dy_hi; p.d_lo = dy_lo; p.part = workspace;
+    p.N = N; p.H = H; p.W = W; p.Hin = upsample ? H / 2 : H; p.Win = upsample ? W / 2 : W;
+    p.Cin = Cin; p.Cout = Cout; p.C8 = (Cin + 7) & ~7; p.Co8 = (Cout + 7) & ~7; p.CoP = round_up(Cout, 64); p.CiP = round_up(Cin, 64);
+    p.splits = splits;
+    p.bpart = dbias ? workspace + (size_t)splits * ksize * ksize * p.CoP * p.CiP : nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    if (prec == LP_PREC_BF16) return dispatch_wgrad<LP_PREC_BF16>(p, dw, dbias, out_scale, ksize, upsample, s);
+    if (prec == LP_PREC_BF16X3) return dispatch_wgrad<LP_PREC_BF16X3>(p, dw, dbias, out_scale, ksize, upsample, s);
+    if (prec == LP_PREC_F16) return dispatch_wgrad<LP_PREC_F16>(p, dw, dbias, out_scale, ksize, upsample, s);
+    return lp_set_error(LP_ERR_ARG, "lp_conv16_wgrad: unknown precision");
 }

@@ -10,7 +10,7 @@ static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b)
 // weight packing
 // ------------------------------------------------------------------------------------------------------------------
 __global__ void pack_weights_kernel(const float* __restrict__ w, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo,
-                                    int Cout, int Cin, int T, int RowsP, int ColsP, int mode) {
+                                    int Cout, int Cin, int T, int RowsP, int ColsP, int mode, int f16) {
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     long long total = (long long)T * RowsP * ColsP;
     if (idx >= total) return;
@@ -20,6 +20,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, uint16_t* __res
     float v = 0.f;
     if (mode == 0) { if (row < Cout && col < Cin) v = w[((size_t)row * Cin + col) * T + t]; }                 // [t][co][ci]
     else { if (row < Cin && col < Cout) v = w[((size_t)col * Cin + row) * T + (T - 1 - t)]; }                  // [T-1-t][ci][co]
+    if (f16) { hi[idx] = lp_f32_to_op16<true>(v); return; }
     __bf16 h = (__bf16)v;
     hi[idx] = __builtin_bit_cast(uint16_t, h);
     if (lo) { __bf16 l = (__bf16)(v - (float)h); lo[idx] = __builtin_bit_cast(uint16_t, l); }
@@ -29,7 +30,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, uint16_t* __res
 // of a module after an optimizer step
 // (a flat 1-D grid of 1024-element chunks: entry sizes differ by 1000x, so a (blocks, entries) grid either starves the big
 //  entries or floods the scheduler with empty blocks; chunk0 = first chunk of the entry, found by binary search)
-struct PackDesc { const float* w; uint16_t* hi; uint16_t* lo; int Cout, Cin, T, RowsP, ColsP, mode, chunk0, pad; };
+struct PackDesc { const float* w; uint16_t* hi; uint16_t* lo; int Cout, Cin, T, RowsP, ColsP, mode, chunk0, f16; };
 
 __global__ __launch_bounds__(256) void pack_weights_batch_kernel(const PackDesc* __restrict__ table, int num_entries) {
     int lo_e = 0, hi_e = num_entries - 1;
@@ -50,6 +51,7 @@ __global__ __launch_bounds__(256) void pack_weights_batch_kernel(const PackDesc*
         float v = 0.f;
         if (d.mode == 0) { if (row < d.Cout && col < d.Cin) v = d.w[((size_t)row * d.Cin + col) * d.T + t]; }
         else { if (row < d.Cin && col < d.Cout) v = d.w[((size_t)col * d.Cin + row) * d.T + (d.T - 1 - t)]; }
+        if (d.f16) { d.hi[idx] = lp_f32_to_op16<true>(v); continue; }
         __bf16 h = (__bf16)v;
         d.hi[idx] = __builtin_bit_cast(uint16_t, h);
         if (d.lo) { __bf16 l = (__bf16)(v - (float)h); d.lo[idx] = __builtin_bit_cast(uint16_t, l); }
@@ -58,23 +60,22 @@ __global__ __launch_bounds__(256) void pack_weights_batch_kernel(const PackDesc*
 
 extern "C" int lp_pack_desc_bytes(void) { return (int)sizeof(PackDesc); }
 
-extern "C" int lp_pack_weights_batch(const void* table, int num_entries, long long max_elems /* total chunks */, void* stream) {
+extern "C" int lp_pack_weights_batch(const void* table, int num_entries, long long total_chunks, void* stream) {
     if (!table || num_entries <= 0) return lp_set_error(LP_ERR_ARG, "lp_pack_weights_batch: bad arguments");
-    // (argument name kept for the ABI: here it is the TOTAL number of 1024-element chunks = chunk0 + chunks of the last entry)
-    if (max_elems < 1) return lp_set_error(LP_ERR_ARG, "lp_pack_weights_batch: no chunks");
-    hipLaunchKernelGGL(pack_weights_batch_kernel, dim3((unsigned)max_elems), dim3(256), 0, (hipStream_t)stream, (const PackDesc*)table,
+    if (total_chunks < 1) return lp_set_error(LP_ERR_ARG, "lp_pack_weights_batch: no chunks");
+    hipLaunchKernelGGL(pack_weights_batch_kernel, dim3((unsigned)total_chunks), dim3(256), 0, (hipStream_t)stream, (const PackDesc*)table,
                        num_entries);
     return lp_check_launch("pack_weights_batch");
 }
 
 extern "C" int lp_pack_weights(const float* w, uint16_t* hi, uint16_t* lo, int Cout, int Cin, int T, int RowsP, int ColsP, int mode,
-                               void* stream) {
+                               int f16, void* stream) {
     if (!w || !hi) return lp_set_error(LP_ERR_ARG, "lp_pack_weights: null pointer");
     int rows = mode == 0 ? Cout : Cin, cols = mode == 0 ? Cin : Cout;
     if (RowsP < rows || ColsP < cols || (ColsP & 7)) return lp_set_error(LP_ERR_ARG, "lp_pack_weights: bad padded dims");
     long long total = (long long)T * RowsP * ColsP;
     hipLaunchKernelGGL(pack_weights_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, hi, lo, Cout, Cin, T,
-                       RowsP, ColsP, mode);
+                       RowsP, ColsP, mode, f16);
     return lp_check_launch("pack_weights");
 }
 

@@ -13,6 +13,20 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 // precision modes of the contraction operands (accumulation is always fp32 in the MFMA)
 #define LP_PREC_BF16 0      // operands rounded to bf16 (RNE), 1 MFMA per k-step
 #define LP_PREC_BF16X3 1    // operands split hi+lo bf16, 3 MFMAs per k-step (~2^-16 relative operand error)
+#define LP_PREC_F16 2       // operands rounded to IEEE fp16 (RNE, 2^-12), 1 MFMA per k-step; gradients need a power-of-two input scale
+
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+
+// 16-bit operand element of a precision mode -> fp32 (used by the thin-channel kernels and bias-gradient sums)
+template <bool F16> __device__ __forceinline__ float lp_op16_to_f32(uint16_t b) {
+    if (F16) return (float)__builtin_bit_cast(_Float16, b);
+    return __uint_as_float((unsigned)b << 16);
+}
+// fp32 -> 16-bit operand (hi) and residual (lo, bf16x3 only); fp16 saturates instead of overflowing to inf
+template <bool F16> __device__ __forceinline__ uint16_t lp_f32_to_op16(float v) {
+    if (F16) { v = fminf(fmaxf(v, -65504.f), 65504.f); return __builtin_bit_cast(uint16_t, (_Float16)v); }
+    return __builtin_bit_cast(uint16_t, (__bf16)v);
+}
 
 // fp32 -> (hi, lo) bf16 split of 8 values; lo only computed when SPLIT
 template <bool SPLIT>
@@ -29,6 +43,11 @@ __device__ __forceinline__ void cvt8(const float (&v)[8], s16x8_t& hi, s16x8_t& 
 }
 
 __device__ __forceinline__ f32x4_t mfma16(s16x8_t a, s16x8_t b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+// element-type generic form: F16 operands use the fp16 MFMA (same rate and fragment layout as the bf16 one)
+template <bool F16> __device__ __forceinline__ f32x4_t mfma16t(s16x8_t a, s16x8_t b, f32x4_t c) {
+    if (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 
@@ -60,6 +79,15 @@ __device__ __forceinline__ void tile_row_decode(int m, int lTH, int lTW, int& nb
     nb = bq >> (lbw + lbh);
     py = 2 * by + (sub >> 1);
     px = 2 * bx + (sub & 1);
+}
+
+// Row index m of a tile in LINEAR order (row-major inside the patch) -> (image-in-tile, py, px): 16 consecutive rows are 16
+// consecutive pixels of one patch row (TW = 16), i.e. consecutive halo pixels -- what the lane-linear LDS-DMA image of
+// conv_dma.hip and its XOR key are designed for (scripts/lds_swizzle_sim.py).
+__device__ __forceinline__ void tile_row_linear(int m, int lTH, int lTW, int& nb, int& py, int& px) {
+    px = m & ((1 << lTW) - 1);
+    py = (m >> lTW) & ((1 << lTH) - 1);
+    nb = m >> (lTW + lTH);
 }
 
 // Linear pixel index kpix (row-major inside the patch) -> (image-in-tile, py, px); used for the wgrad k dimension.

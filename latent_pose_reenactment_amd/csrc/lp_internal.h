@@ -11,4 +11,4 @@ int lp_wgrad_thin(const float* x, const float* dy, float* dw, float* workspace, 
                   int W, int Cin, int Cout, int ksize, int pro, int splits, float* dbias, hipStream_t stream);
 bool lp_conv_thin_fwd_supported(int Cin, int Cout, int ksize, int upsample, int pro, bool has_res, int W);
 int lp_conv_thin_fwd(const float* x, const uint16_t* w_hi, const uint16_t* w_lo, float* y, const float* bias, const float* alpha, int N,
-                     int H, int W, int Cin, int Cout, int CinP, int CoutP, int ksize, hipStream_t stream);
+                     int H, int W, int Cin, int Cout, int CinP, int CoutP, int ksize, int f16, hipStream_t stream);

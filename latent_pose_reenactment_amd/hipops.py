@@ -1,11 +1,13 @@
-"""Tensor-level wrappers around the C ABI.  Activations are NHWC fp32 contiguous CUDA tensors of shape [N,H,W,C].
+"""Tensor-level wrappers around the C ABI.  Activations are NHWC fp32 contiguous CUDA tensors of shape [N,H,W,C]; the operands of
+the conv kernels are 16-bit planes (``Act16`` from ``act_pack`` / a conv epilogue, ``WeightPack``).
 PyTorch here is plumbing only: it owns the buffers and the stream; all arithmetic happens in liblp_hip.so."""
+import os
 from typing import NamedTuple, Optional, Tuple
 
 import torch
 
 from . import _lib
-from ._lib import PREC_BF16, PREC_BF16X3, check
+from ._lib import PREC_BF16, PREC_BF16X3, PREC_F16, check
 
 Tensor = torch.Tensor
 
@@ -49,6 +51,10 @@ def _round_up(v, m):
     return (v + m - 1) // m * m
 
 
+def _f16(prec: int) -> int:
+    return int(prec == PREC_F16)
+
+
 class WeightPack(NamedTuple):
     hi: Tensor
     lo: Optional[Tensor]
@@ -70,13 +76,13 @@ def pack_weights(w: Tensor, mode: int, prec: int, small_k: bool = False) -> Weig
     cols_p = _round_up(cols, 32 if (small_k and cols <= 32) else 64)
     hi = torch.empty((taps, rows_p, cols_p), dtype=torch.int16, device=w.device)
     lo = torch.empty_like(hi) if prec == PREC_BF16X3 else None
-    check(_lib.lib().lp_pack_weights(w.data_ptr(), hi.data_ptr(), _p(lo), cout, cin, taps, rows_p, cols_p, mode, _stream()),
+    check(_lib.lib().lp_pack_weights(w.data_ptr(), hi.data_ptr(), _p(lo), cout, cin, taps, rows_p, cols_p, mode, _f16(prec), _stream()),
           'lp_pack_weights')
     return WeightPack(hi, lo, rows, cols, rows_p, cols_p, taps)
 
 
 class PackBatch:
-    """bf16 packs of MANY conv weights, refreshed by ONE launch (lp_pack_weights_batch).  ``specs`` = [(w, mode, small_k)];
+    """16-bit packs of MANY conv weights, refreshed by ONE launch (lp_pack_weights_batch).  ``specs`` = [(w, mode, small_k)];
     the pack buffers and the device descriptor table are allocated once (static addresses: hipGraph friendly); ``update()``
     re-packs all entries from the current weight values and returns the list of WeightPacks (same order as ``specs``)."""
 
@@ -99,7 +105,7 @@ class PackBatch:
             lo = torch.empty_like(hi) if prec == PREC_BF16X3 else None
             self.packs.append(WeightPack(hi, lo, rows, cols, rows_p, cols_p, taps))
             blob += struct.pack('<QQQiiiiiiii', w.data_ptr(), hi.data_ptr(), 0 if lo is None else lo.data_ptr(), cout, cin, taps, rows_p,
-                                cols_p, mode, self.chunks, 0)
+                                cols_p, mode, self.chunks, _f16(prec))
             self.chunks += (taps * rows_p * cols_p + 1023) // 1024
         self.table = torch.frombuffer(blob, dtype=torch.uint8).clone().to(specs[0][0].device)
 
@@ -108,67 +114,195 @@ class PackBatch:
         return self.packs
 
 
-def conv(x: Tensor, pack: WeightPack, *, ksize: int, upsample: bool = False, pro: int = 0, scale: Optional[Tensor] = None,
-         shift: Optional[Tensor] = None, bias: Optional[Tensor] = None, res: Optional[Tensor] = None, res_shift: int = 0,
-         alpha: Optional[Tensor] = None, prec: int = PREC_BF16, relu_mask: Optional[Tensor] = None) -> Tensor:
-    """y = alpha * conv(up2?(act(x)), pack) + bias + res ; x [N,Hin,Win,Cin] -> y [N,H,W,Cout].
-    ``relu_mask`` [N,H,W,Cout]: y is zeroed where relu_mask <= 0 (fused ReLU backward when this launch is a data gradient)."""
+class Act16(NamedTuple):
+    """Operand planes of a conv input: ``hi`` (, ``lo``) int16 [N,H,W,C8] holding act(x) * scale in the operand format of the
+    precision mode; ``c`` = logical channels (C8 = c rounded up to 8, pad channels zero); ``inv`` = device scalar 1/scale of an
+    fp16 gradient operand (None: unscaled)."""
+    hi: Tensor
+    lo: Optional[Tensor]
+    c: int
+    inv: Optional[Tensor]
+
+    @property
+    def nhw(self):
+        return tuple(self.hi.shape[:3])
+
+
+def _alloc16(n, h, w, c, prec, device):
+    c8 = _round_up(c, 8)
+    hi = torch.empty((n, h, w, c8), dtype=torch.int16, device=device)
+    lo = torch.empty_like(hi) if prec == PREC_BF16X3 else None
+    return hi, lo
+
+
+def act_pack(x: Tensor, *, pro: int = 0, scale: Optional[Tensor] = None, shift: Optional[Tensor] = None, prec: int = PREC_BF16,
+             grad: bool = False) -> Act16:
+    """x [N,H,W,C] fp32 -> operand planes of act(x): pro 0 identity | 1 relu(x*scale[n,c]+shift[n,c]) | 2 relu(x).
+    ``grad``: x is a gradient (dY): in fp16 mode it is scaled by a power of two taken from its amax (two extra small launches) so
+    that it sits in the fp16 normal range; the consumer gets 1/scale through ``Act16.inv``."""
     _chk(x, 'x')
-    n, hin, win, cin = x.shape
-    assert cin == pack.cols and pack.taps == ksize * ksize, (x.shape, pack.rows, pack.cols, pack.taps)
+    n, h, w, c = x.shape
+    hi, lo = _alloc16(n, h, w, c, prec, x.device)
+    sc = None
+    if grad and prec == PREC_F16:
+        sc = torch.empty(2, dtype=torch.float32, device=x.device)
+        ws = torch.empty(_lib.lib().lp_amax_workspace_floats(), dtype=torch.float32, device=x.device)
+        check(_lib.lib().lp_amax_scale(x.data_ptr(), x.numel(), sc.data_ptr(), ws.data_ptr(), _stream()), 'lp_amax_scale')
+    for t, nm in ((scale, 'scale'), (shift, 'shift')):
+        if t is not None:
+            _chk(t, nm)
+    check(_lib.lib().lp_act_pack(x.data_ptr(), _p(scale), _p(shift), pro, hi.data_ptr(), _p(lo), n, h * w, c, prec, _p(sc), _stream()),
+          'lp_act_pack')
+    return Act16(hi, lo, c, None if sc is None else sc[1:])
+
+
+def conv16(a: Act16, pack: WeightPack, *, ksize: int, upsample: bool = False, bias: Optional[Tensor] = None,
+           res: Optional[Tensor] = None, res_shift: int = 0, alpha: Optional[Tensor] = None, prec: int = PREC_BF16,
+           relu_mask: Optional[Act16] = None, out16: Optional[int] = None):
+    """y = alpha * conv(up2?(a), pack) + bias + res on operand planes; a [N,Hin,Win,C8] -> y [N,H,W,Cout] fp32.
+    ``relu_mask``: operand planes [N,H,W,Co8] of the forward conv's input; y is zeroed where they are <= 0 (fused ReLU backward
+    when this launch is a data gradient).  ``out16`` = 0 | 1: also return the operand planes of y (1: of relu(y)) -> (y, Act16)."""
+    n, hin, win = a.nhw
+    cin = a.c
+    assert cin == pack.cols and pack.taps == ksize * ksize, (a.hi.shape, a.c, pack.rows, pack.cols, pack.taps)
     h, w = (hin * 2, win * 2) if upsample else (hin, win)
     cout = pack.rows
-    y = torch.empty((n, h, w, cout), dtype=torch.float32, device=x.device)
-    if relu_mask is not None:
-        assert relu_mask.shape == (n, h, w, cout), (relu_mask.shape, (n, h, w, cout))
-    for t, nm in ((scale, 'scale'), (shift, 'shift'), (bias, 'bias'), (res, 'res'), (relu_mask, 'relu_mask')):
+    y = torch.empty((n, h, w, cout), dtype=torch.float32, device=a.hi.device)
+    for t, nm in ((bias, 'bias'), (res, 'res')):
         if t is not None:
             _chk(t, nm)
     if res is not None:
         assert res.shape == (n, h >> res_shift, w >> res_shift, cout), (res.shape, y.shape, res_shift)
-    with _Timed('conv_igemm', 2.0 * n * h * w * cout * cin * ksize * ksize, (n, h, w, cin, cout, ksize, int(upsample), pro)):
-        check(_lib.lib().lp_conv_fwd(x.data_ptr(), pack.hi.data_ptr(), _p(pack.lo), y.data_ptr(), _p(scale), _p(shift), _p(bias),
-                                     _p(res), _p(alpha), n, h, w, cin, cout, pack.cols_p, pack.rows_p, ksize, int(upsample), pro,
-                                     res_shift, prec, _p(relu_mask), _stream()), 'lp_conv_fwd')
+    if relu_mask is not None:
+        assert relu_mask.hi.shape == (n, h, w, _round_up(cout, 8)), (relu_mask.hi.shape, (n, h, w, cout))
+    o_hi = o_lo = None
+    if out16 is not None:
+        o_hi, o_lo = _alloc16(n, h, w, cout, prec, y.device)
+    with _Timed('conv_igemm', 2.0 * n * h * w * cout * cin * ksize * ksize, (n, h, w, cin, cout, ksize, int(upsample), 0)):
+        check(_lib.lib().lp_conv16_fwd(a.hi.data_ptr(), _p(a.lo), pack.hi.data_ptr(), _p(pack.lo), y.data_ptr(), _p(bias), _p(res),
+                                       _p(alpha), _p(a.inv), n, h, w, cin, cout, pack.cols_p, pack.rows_p, ksize, int(upsample),
+                                       res_shift, prec, None if relu_mask is None else relu_mask.hi.data_ptr(), _p(o_hi), _p(o_lo),
+                                       int(bool(out16)), _stream()), 'lp_conv16_fwd')
+    if out16 is not None:
+        return y, Act16(o_hi, o_lo, cout, None)
     return y
+
+
+_THIN = os.environ.get('LP_THIN', '1') != '0'      # LP_THIN=0: thin-channel layers through the MFMA kernels (test knob)
+
+
+def thin_conv_supported(cin: int, cout: int, ksize: int, w: int) -> bool:
+    return _THIN and bool(_lib.lib().lp_thin_conv_supported(cin, cout, ksize, w))
+
+
+def thin_conv(x: Tensor, pack: WeightPack, *, ksize: int, bias: Optional[Tensor] = None, alpha: Optional[Tensor] = None,
+              prec: int = PREC_BF16) -> Tensor:
+    """conv with <= 4 input channels (RGB -> 64, dz -> 64): fp32 VALU kernel on the plain NHWC tensor (no operand planes)"""
+    _chk(x, 'x')
+    n, h, w, cin = x.shape
+    cout = pack.rows
+    y = torch.empty((n, h, w, cout), dtype=torch.float32, device=x.device)
+    with _Timed('conv_thin', 2.0 * n * h * w * cout * cin * ksize * ksize, (n, h, w, cin, cout, ksize, 0, 0)):
+        check(_lib.lib().lp_thin_conv_fwd(x.data_ptr(), pack.hi.data_ptr(), _p(pack.lo), y.data_ptr(), _p(bias), _p(alpha), n, h, w, cin,
+                                          cout, pack.cols_p, pack.rows_p, ksize, prec, _stream()), 'lp_thin_conv_fwd')
+    return y
+
+
+def conv(x: Tensor, pack: WeightPack, *, ksize: int, upsample: bool = False, pro: int = 0, scale: Optional[Tensor] = None,
+         shift: Optional[Tensor] = None, bias: Optional[Tensor] = None, res: Optional[Tensor] = None, res_shift: int = 0,
+         alpha: Optional[Tensor] = None, prec: int = PREC_BF16, relu_mask: Optional[Tensor] = None, grad: bool = False) -> Tensor:
+    """Convenience form on an fp32 NHWC tensor: y = alpha * conv(up2?(act(x)), pack) + bias + res = lp_act_pack + lp_conv16_fwd
+    (or the thin-channel kernel for <= 4 input channels).  ``relu_mask`` fp32 [N,H,W,Cout]: y zeroed where relu_mask <= 0.
+    ``grad``: x is a gradient (fp16 mode scales it).  Callers that reuse the planes (forward + weight gradient) use
+    ``act_pack`` / ``conv16`` directly."""
+    _chk(x, 'x')
+    cin = x.shape[3]
+    if (not upsample and pro == 0 and res is None and relu_mask is None and thin_conv_supported(cin, pack.rows, ksize, x.shape[2])):
+        return thin_conv(x, pack, ksize=ksize, bias=bias, alpha=alpha, prec=prec)
+    a = act_pack(x, pro=pro, scale=scale, shift=shift, prec=prec, grad=grad)
+    m16 = None
+    if relu_mask is not None:
+        m16 = act_pack(relu_mask, pro=0, prec=PREC_BF16)      # (bf16 keeps the sign / zero-ness of every normal fp32 value)
+    return conv16(a, pack, ksize=ksize, upsample=upsample, bias=bias, res=res, res_shift=res_shift, alpha=alpha, prec=prec, relu_mask=m16)
+
+
+def default_splits(n, h, w, cin, cout):
+    blocks = _round_up(cout, 64) // 64 * (_round_up(cin, 64) // 64)
+    return max(1, min(512 // blocks, (n * h * w + 127) // 128))     # ~2 workgroups per CU in total
+
+
+def conv_wgrad16(a: Act16, dy: Act16, *, ksize: int, upsample: bool = False, prec: int = PREC_BF16, splits: Optional[int] = None,
+                 sn=None, accum: Optional[Tensor] = None, bias_grad: bool = False):
+    """dw [Cout,Cin,k,k] = sum_pixels dy (x) up2?(a) (shifted by tap) on operand planes (a = what the forward conv consumed).
+    ``sn`` = (w_orig, u, v, sig): the layer is spectrally normalised (forward used alpha = 1/sigma in the conv epilogue); the
+    returned gradient is then w.r.t. W_orig: dw/sigma - <dw, W_orig>/sigma^2 u v^T.
+    ``accum`` (with ``sn``): add that gradient to this tensor (the parameter's .grad) instead and return None.
+    ``bias_grad``: return ``(dw, db)`` with db [Cout] = sum_pixels dy, produced by the same launch (the kernel streams dy anyway)."""
+    n, h, w = dy.nhw
+    cout, cin = dy.c, a.c
+    assert a.nhw == ((n, h // 2, w // 2) if upsample else (n, h, w)), (a.hi.shape, dy.hi.shape, upsample)
+    dev = dy.hi.device
+    if splits is None:
+        splits = default_splits(n, h, w, cin, cout)
+    ws = torch.empty(_lib.lib().lp_conv_wgrad_workspace_bytes(cin, cout, ksize, splits) // 4, dtype=torch.float32, device=dev)
+    dw = torch.empty((cout, cin, ksize, ksize), dtype=torch.float32, device=dev)
+    db = torch.empty(cout, dtype=torch.float32, device=dev) if bias_grad else None
+    with _Timed('conv_wgrad', 2.0 * n * h * w * cout * cin * ksize * ksize, (n, h, w, cin, cout, ksize, int(upsample), 0)):
+        check(_lib.lib().lp_conv16_wgrad(a.hi.data_ptr(), _p(a.lo), dy.hi.data_ptr(), _p(dy.lo), dw.data_ptr(), ws.data_ptr(), n, h, w, cin,
+                                         cout, ksize, int(upsample), splits, prec, _p(db), _p(dy.inv), _stream()), 'lp_conv16_wgrad')
+    dw = _sn_finish(dw, sn, accum)
+    return (dw, db) if bias_grad else dw
+
+
+def _sn_finish(dw, sn, accum):
+    if sn is None:
+        return dw
+    w_orig, u, v, sig = sn
+    cout = dw.shape[0]
+    dot = torch.empty(512, dtype=torch.float32, device=dw.device)      # per-block partials of <g, W>
+    if accum is not None:
+        assert accum.is_contiguous() and accum.dtype == torch.float32 and accum.numel() == dw.numel()
+    check(_lib.lib().lp_sn_grad_apply(dw.data_ptr(), w_orig.data_ptr(), u.data_ptr(), v.data_ptr(), sig.data_ptr(), dot.data_ptr(),
+                                      _p(accum), cout, dw.numel() // cout, _stream()), 'lp_sn_grad_apply')
+    return None if accum is not None else dw
+
+
+def thin_wgrad_supported(cin: int, cout: int, ksize: int, pro: int, w: int) -> bool:
+    return _THIN and bool(_lib.lib().lp_thin_wgrad_supported(cin, cout, ksize, pro, w))
+
+
+def thin_wgrad(x: Tensor, dy: Tensor, *, ksize: int, pro: int = 0, scale: Optional[Tensor] = None, shift: Optional[Tensor] = None,
+               splits: Optional[int] = None, sn=None, accum: Optional[Tensor] = None, bias_grad: bool = False):
+    """weight gradient of a conv with <= 4 channels on one side, fp32 NHWC tensors in (prologue of the wide input applied on the fly)"""
+    _chk(x, 'x'); _chk(dy, 'dy')
+    n, h, w, cout = dy.shape
+    cin = x.shape[3]
+    if splits is None:
+        splits = default_splits(n, h, w, cin, cout)
+    ws = torch.empty(_lib.lib().lp_conv_wgrad_workspace_bytes(cin, cout, ksize, splits) // 4, dtype=torch.float32, device=x.device)
+    dw = torch.empty((cout, cin, ksize, ksize), dtype=torch.float32, device=x.device)
+    db = None
+    if bias_grad and _lib.lib().lp_thin_wgrad_has_dbias(cin, cout):
+        db = torch.empty(cout, dtype=torch.float32, device=x.device)
+    with _Timed('wgrad_thin', 2.0 * n * h * w * cout * cin * ksize * ksize, (n, h, w, cin, cout, ksize, 0, pro)):
+        check(_lib.lib().lp_thin_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), _p(scale), _p(shift), n, h, w, cin, cout,
+                                       ksize, pro, splits, _p(db), _stream()), 'lp_thin_wgrad')
+    if bias_grad and db is None:
+        db = dy.sum(dim=(0, 1, 2))
+    dw = _sn_finish(dw, sn, accum)
+    return (dw, db) if bias_grad else dw
 
 
 def conv_wgrad(x: Tensor, dy: Tensor, *, ksize: int, upsample: bool = False, pro: int = 0, scale: Optional[Tensor] = None,
                shift: Optional[Tensor] = None, prec: int = PREC_BF16, splits: Optional[int] = None, sn=None,
                accum: Optional[Tensor] = None, bias_grad: bool = False):
-    """dw [Cout,Cin,k,k] = sum_pixels dy (x) up2?(act(x)) (shifted by tap).
-    ``sn`` = (w_orig, u, v, sig): the layer is spectrally normalised (forward used alpha = 1/sigma in the conv epilogue); the
-    returned gradient is then w.r.t. W_orig: dw/sigma - <dw, W_orig>/sigma^2 u v^T.
-    ``accum`` (with ``sn``): add that gradient to this tensor (the parameter's .grad) instead and return None.
-    ``bias_grad``: return ``(dw, db)`` with db [Cout] = sum_pixels dy, produced by the same launch (the kernel streams dy anyway)
-    or, for the <= 4-channel head where the kernel does not emit it, by a column sum."""
+    """Convenience form on fp32 NHWC tensors: packs act(x) and dy, then lp_conv16_wgrad (or the thin-channel kernel)."""
     _chk(x, 'x'); _chk(dy, 'dy')
-    n, h, w, cout = dy.shape
-    cin = x.shape[3]
-    if splits is None:
-        blocks = _round_up(cout, 64) // 64 * (_round_up(cin, 64) // 64)
-        splits = max(1, min(512 // blocks, (n * h * w + 127) // 128))     # ~2 workgroups per CU in total
-    ws_bytes = _lib.lib().lp_conv_wgrad_workspace_bytes(cin, cout, ksize, splits)
-    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
-    dw = torch.empty((cout, cin, ksize, ksize), dtype=torch.float32, device=x.device)
-    dot = torch.empty(512, dtype=torch.float32, device=x.device) if sn is not None else None      # per-block partials of <g, W>
-    db = None
-    if bias_grad and _lib.lib().lp_conv_wgrad_has_dbias(cin, cout, ksize, int(upsample), pro):
-        db = torch.empty(cout, dtype=torch.float32, device=x.device)
-    with _Timed('conv_wgrad', 2.0 * n * h * w * cout * cin * ksize * ksize, (n, h, w, cin, cout, ksize, int(upsample), pro)):
-        check(_lib.lib().lp_conv_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), _p(scale), _p(shift), n, h, w, cin,
-                                       cout, ksize, int(upsample), pro, splits, prec, _p(db), _stream()), 'lp_conv_wgrad')
-    if bias_grad and db is None:
-        db = dy.sum(dim=(0, 1, 2))
-    if sn is not None:
-        w_orig, u, v, sig = sn
-        if accum is not None:
-            assert accum.is_contiguous() and accum.dtype == torch.float32 and accum.numel() == dw.numel()
-        check(_lib.lib().lp_sn_grad_apply(dw.data_ptr(), w_orig.data_ptr(), u.data_ptr(), v.data_ptr(), sig.data_ptr(), dot.data_ptr(),
-                                          _p(accum), cout, cin * ksize * ksize, _stream()), 'lp_sn_grad_apply')
-        if accum is not None:
-            dw = None
-    return (dw, db) if bias_grad else dw
+    if not upsample and thin_wgrad_supported(x.shape[3], dy.shape[3], ksize, pro, dy.shape[2]):
+        return thin_wgrad(x, dy, ksize=ksize, pro=pro, scale=scale, shift=shift, splits=splits, sn=sn, accum=accum, bias_grad=bias_grad)
+    a = act_pack(x, pro=pro, scale=scale, shift=shift, prec=prec)
+    d = act_pack(dy, pro=0, prec=prec, grad=True)
+    return conv_wgrad16(a, d, ksize=ksize, upsample=upsample, prec=prec, splits=splits, sn=sn, accum=accum, bias_grad=bias_grad)
 
 
 def sn_grad_apply(g: Tensor, w_orig: Tensor, u: Tensor, v: Tensor, sig: Tensor, accum: Optional[Tensor] = None) -> Optional[Tensor]:

@@ -18,17 +18,17 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import hipops as ops
-from ._lib import PREC_BF16, PREC_BF16X3
+from ._lib import PREC_BF16, PREC_BF16X3, PREC_F16
 
 ADAIN_EPS = 1e-4
 SN_EPS_CONV = 1e-4
 SN_EPS_DEFAULT = 1e-12
 
-PREC_NAMES = {'bf16': PREC_BF16, 'bf16x3': PREC_BF16X3}
+PREC_NAMES = {'bf16': PREC_BF16, 'bf16x3': PREC_BF16X3, 'f16': PREC_F16}
 
 
 def default_prec() -> int:
-    """Contraction operand precision: LP_PREC=bf16 (1 MFMA per k-step) | bf16x3 (hi/lo split, fp32-class; default)."""
+    """Contraction operand precision: LP_PREC=bf16 | f16 (1 MFMA per k-step) | bf16x3 (hi/lo split, fp32-class; default)."""
     return PREC_NAMES[os.environ.get('LP_PREC', 'bf16x3')]
 
 
@@ -276,35 +276,42 @@ class _DecoderFunction(torch.autograd.Function):
             has_skip = (cin != cout) or up
             g0, b0, o0 = aff(cin)
             g1, b1, o1 = aff(cout)
+            # AdaIN + ReLU are applied ONCE per tensor while it is packed to the conv's 16-bit operand planes (the same planes feed
+            # the weight gradient in backward); the convs themselves stage their operands by LDS-DMA only
             st0 = ops.instnorm_stats(x, g0, b0, ADAIN_EPS)
+            a0 = ops.act_pack(x, pro=1, scale=st0[2], shift=st0[3], prec=prec)
             p1 = fpack(wi - 2, w1)
-            h1 = ops.conv(x, p1, ksize=3, upsample=up, pro=1, scale=st0[2], shift=st0[3], alpha=sn[wi - 2][2][1:], prec=prec)
+            h1 = ops.conv16(a0, p1, ksize=3, upsample=up, alpha=sn[wi - 2][2][1:], prec=prec)
             st1 = ops.instnorm_stats(h1, g1, b1, ADAIN_EPS)
+            a1 = ops.act_pack(h1, pro=1, scale=st1[2], shift=st1[3], prec=prec)
+            xs = None
             if has_skip:
                 ws, bs = wl[wi], wl[wi + 1]
                 wi += 2
                 ps = fpack(wi - 2, ws)
-                s = ops.conv(x, ps, ksize=1, bias=bs.detach().contiguous(), alpha=sn[wi - 2][2][1:], prec=prec)   # 1x1 commutes with nearest upsampling
+                xs = ops.act_pack(x, pro=0, prec=prec)
+                s = ops.conv16(xs, ps, ksize=1, bias=bs.detach().contiguous(), alpha=sn[wi - 2][2][1:], prec=prec)   # 1x1 commutes with nearest upsampling
                 rs = 1 if up else 0
             else:
                 s, rs = x, 0
             i2 = wi - (3 if has_skip else 1)
             p2 = fpack(i2, w2)
-            out = ops.conv(h1, p2, ksize=3, pro=1, scale=st1[2], shift=st1[3], res=s, res_shift=rs, alpha=sn[i2][2][1:], prec=prec)
+            out = ops.conv16(a1, p2, ksize=3, res=s, res_shift=rs, alpha=sn[i2][2][1:], prec=prec)
             if need_grad:
-                saved.append((x, h1, st0, st1, o0, o1))
+                saved.append((x, h1, st0, st1, o0, o1, a0, a1, xs))
             x = out
         ch = blocks[-1][1]
         gh, bh, oh = aff(ch)
         sth = ops.instnorm_stats(x, gh, bh, ADAIN_EPS)
         wh, bhd = wl[wi], wl[wi + 1]
         ph = fpack(wi, wh)
-        z = ops.conv(x, ph, ksize=3, pro=1, scale=sth[2], shift=sth[3], bias=bhd.detach().contiguous(), alpha=sn[wi][2][1:], prec=prec)
+        ah = ops.act_pack(x, pro=1, scale=sth[2], shift=sth[3], prec=prec)
+        z = ops.conv16(ah, ph, ksize=3, bias=bhd.detach().contiguous(), alpha=sn[wi][2][1:], prec=prec)
         t, rgbs, segm = ops.head_fwd(z, want_t=need_grad)
         if need_grad:
             ctx.cfg = cfg
             ctx.saved = saved
-            ctx.head = (x, sth, oh, t)
+            ctx.head = (x, sth, oh, t, ah)
             ctx.affine = affine
             ctx.weights = [w.detach() for w in wl]
             ctx.params = wl                  # the parameter tensors themselves: fused accumulation adds into their .grad
@@ -327,18 +334,22 @@ class _DecoderFunction(torch.autograd.Function):
         def slices(o, c):      # (gamma, dgamma, dbeta) views for the AdaIN whose params start at column o
             return affine[:, o + c:o + 2 * c], d_affine[:, o + c:o + 2 * c], d_affine[:, o:o + c]
 
-        x, sth, oh, t = ctx.head
+        x, sth, oh, t, ah = ctx.head
         ch = blocks[-1][1]
         dz = ops.head_bwd(t, d_rgbs.contiguous(), None if d_segm is None else d_segm.contiguous())
         wi = len(wl) - 2
-        grads[wi], grads[wi + 1] = ops.conv_wgrad(x, dz, ksize=3, pro=1, scale=sth[2], shift=sth[3], prec=prec, sn=snw(wi),
-                                                   accum=_accum_target(params[wi]), bias_grad=True)
+        if ops.thin_wgrad_supported(ch, dz.shape[3], 3, 1, dz.shape[2]):
+            grads[wi], grads[wi + 1] = ops.thin_wgrad(x, dz, ksize=3, pro=1, scale=sth[2], shift=sth[3], sn=snw(wi),
+                                                      accum=_accum_target(params[wi]), bias_grad=True)
+        else:
+            grads[wi], grads[wi + 1] = ops.conv_wgrad16(ah, ops.act_pack(dz, prec=prec, grad=True), ksize=3, prec=prec, sn=snw(wi),
+                                                        accum=_accum_target(params[wi]), bias_grad=True)
         packsT = cfg.get('packsT')        # dgrad packs from the same batched launch (training), else packed on demand
 
         def tpack(i, small_k=False):
             return packsT[i] if packsT is not None else ops.pack_weights(wl[i].contiguous(), 1, prec, small_k=small_k)
         pT = tpack(wi, small_k=True)
-        dA = ops.conv(dz, pT, ksize=3, alpha=sn[wi][2][1:], prec=prec)
+        dA = ops.conv(dz, pT, ksize=3, alpha=sn[wi][2][1:], prec=prec, grad=True)
         g, dg, db = slices(oh, ch)
         dx = ops.adain_relu_bwd(dA, x, None, g, sth[0], sth[1], sth[2], sth[3], dg, db, False)
         dbg = cfg.get('debug')
@@ -348,29 +359,31 @@ class _DecoderFunction(torch.autograd.Function):
         for bi in range(len(blocks) - 1, -1, -1):
             cin, cout, up = blocks[bi]
             has_skip = (cin != cout) or up
-            x, h1, st0, st1, o0, o1 = ctx.saved[bi]
+            x, h1, st0, st1, o0, o1, a0, a1, xs = ctx.saved[bi]
             wi -= 4 if has_skip else 2
-            w1, w2 = wl[wi], wl[wi + 1]
             d_out = dx
+            d16 = ops.act_pack(d_out, prec=prec, grad=True)       # packed once: operand of conv2's weight AND data gradient
             # conv2 (+ AdaIN1/ReLU prologue)
-            grads[wi + 1] = ops.conv_wgrad(h1, d_out, ksize=3, pro=1, scale=st1[2], shift=st1[3], prec=prec, sn=snw(wi + 1),
-                                           accum=_accum_target(params[wi + 1]))
-            dA1 = ops.conv(d_out, tpack(wi + 1), ksize=3, alpha=sn[wi + 1][2][1:], prec=prec)
+            grads[wi + 1] = ops.conv_wgrad16(a1, d16, ksize=3, prec=prec, sn=snw(wi + 1), accum=_accum_target(params[wi + 1]))
+            dA1 = ops.conv16(d16, tpack(wi + 1), ksize=3, alpha=sn[wi + 1][2][1:], prec=prec)
             g, dg, db = slices(o1, cout)
             dh1 = ops.adain_relu_bwd(dA1, h1, None, g, st1[0], st1[1], st1[2], st1[3], dg, db, False)
             # skip branch: out += up2(conv1x1(x) + b)
             if has_skip:
-                ws = wl[wi + 2]
-                ds = ops.sum2x2(d_out) if up else d_out
-                grads[wi + 2], grads[wi + 3] = ops.conv_wgrad(x, ds, ksize=1, prec=prec, sn=snw(wi + 2), accum=_accum_target(params[wi + 2]),
-                                                              bias_grad=True)
-                dx_skip = ops.conv(ds, tpack(wi + 2), ksize=1, alpha=sn[wi + 2][2][1:], prec=prec)
+                if up:
+                    ds = ops.sum2x2(d_out)
+                    ds16 = ops.act_pack(ds, prec=prec, grad=True)
+                else:
+                    ds16 = d16
+                grads[wi + 2], grads[wi + 3] = ops.conv_wgrad16(xs, ds16, ksize=1, prec=prec, sn=snw(wi + 2),
+                                                                accum=_accum_target(params[wi + 2]), bias_grad=True)
+                dx_skip = ops.conv16(ds16, tpack(wi + 2), ksize=1, alpha=sn[wi + 2][2][1:], prec=prec)
             else:
                 dx_skip = d_out
             # conv1 (+ AdaIN0/ReLU/upsample prologue)
-            grads[wi] = ops.conv_wgrad(x, dh1, ksize=3, upsample=up, pro=1, scale=st0[2], shift=st0[3], prec=prec, sn=snw(wi),
-                                       accum=_accum_target(params[wi]))
-            dA0 = ops.conv(dh1, tpack(wi), ksize=3, alpha=sn[wi][2][1:], prec=prec)
+            dh16 = ops.act_pack(dh1, prec=prec, grad=True)
+            grads[wi] = ops.conv_wgrad16(a0, dh16, ksize=3, upsample=up, prec=prec, sn=snw(wi), accum=_accum_target(params[wi]))
+            dA0 = ops.conv16(dh16, tpack(wi), ksize=3, alpha=sn[wi][2][1:], prec=prec)
             g, dg, db = slices(o0, cin)
             dx = ops.adain_relu_bwd(dA0, x, dx_skip, g, st0[0], st0[1], st0[2], st0[3], dg, db, up)
             if dbg is not None:
@@ -529,9 +542,11 @@ def as_nchw_view(x_nhwc: torch.Tensor) -> torch.Tensor:
 
 
 class ConvFn(torch.autograd.Function):
-    """y = conv_{k x k, pad k//2}(act(x), w) + bias + res,  act = identity (pro=0) | ReLU (pro=2);  x, res, y NHWC.
-    Forward = lp_conv_fwd; backward = lp_conv_fwd on dY with the flipped/transposed pack (dgrad) [+ lp_relu_bwd],
-    lp_conv_wgrad, and a channel sum for the bias.  ``packs`` = optional cached (forward, dgrad) WeightPacks of a frozen w."""
+    """y = conv_{k x k, pad k//2}(act(x), w) + bias + res,  act = identity (pro=0) | ReLU (pro=2);  x, res, y NHWC fp32.
+    Forward = lp_act_pack (act(x) -> 16-bit operand planes, kept for backward) + lp_conv16_fwd; backward = one lp_act_pack of dY
+    feeding both lp_conv16_fwd with the flipped/transposed pack (data gradient; the ReLU mask is read from the saved planes in its
+    epilogue) and lp_conv16_wgrad (which also emits the bias gradient).  Convs with <= 4 channels on one side use the fp32
+    thin-channel kernels.  ``packs`` = optional cached (forward, dgrad) WeightPacks of a frozen w."""
 
     @staticmethod
     def forward(ctx, x, w, bias, res, ksize, pro, prec, packs, sn=None):
@@ -545,19 +560,40 @@ class ConvFn(torch.autograd.Function):
             pack = packs[key]
         else:
             pack = packs[0] if packs is not None else ops.pack_weights(wd, 0, prec, small_k=small_k)
-        y = ops.conv(x, pack, ksize=ksize, pro=pro, bias=None if bias is None else bias.detach().contiguous(), res=res,
-                     alpha=None if sn is None else sn[2][1:], prec=prec)
-        ctx.save_for_backward(x, wd)
+        cin, cout, width = x.shape[3], wd.shape[0], x.shape[2]
+        bd = None if bias is None else bias.detach().contiguous()
+        alpha = None if sn is None else sn[2][1:]
+        need_w = w.requires_grad
+        thin_w = need_w and ops.thin_wgrad_supported(cin, cout, ksize, pro, width)       # the weight gradient will want fp32 x
+        a16 = None
+        if pro == 0 and res is None and ops.thin_conv_supported(cin, cout, ksize, width):
+            y = ops.thin_conv(x, pack, ksize=ksize, bias=bd, alpha=alpha, prec=prec)
+        else:
+            a16 = ops.act_pack(x, pro=pro, prec=prec)
+            y = ops.conv16(a16, pack, ksize=ksize, bias=bd, res=res, alpha=alpha, prec=prec)
+        if need_w and not thin_w and a16 is None:
+            a16 = ops.act_pack(x, pro=pro, prec=prec)
+        ctx.x = x if thin_w else None                               # fp32 input only where a thin-channel weight gradient needs it
+        ctx.a16 = a16 if ((need_w and not thin_w) or pro == 2) else None
+        ctx.wd = wd
         ctx.w_param = w if (sn is not None and w.requires_grad and w.is_leaf) else None
         ctx.cfg = (ksize, pro, prec, packs, bias is not None, res is not None, sn)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, wd = ctx.saved_tensors
+        wd, a16, x = ctx.wd, ctx.a16, ctx.x
         ksize, pro, prec, packs, has_bias, has_res, sn = ctx.cfg
         dy = dy.contiguous()
         dx = dw = db = dres = None
+        d16 = None
+
+        def dy16():
+            nonlocal d16
+            if d16 is None:
+                d16 = ops.act_pack(dy, prec=prec, grad=True)
+            return d16
+        cout, cin, width = dy.shape[3], wd.shape[1], dy.shape[2]
         if ctx.needs_input_grad[0]:
             if isinstance(packs, dict):
                 key = (wd.data_ptr(), 1)
@@ -566,12 +602,20 @@ class ConvFn(torch.autograd.Function):
                 packT = packs[key]
             else:
                 packT = packs[1] if packs is not None else ops.pack_weights(wd, 1, prec, small_k=(ksize == 3 and wd.shape[0] <= 32))
-            # pro == 2: the forward applied ReLU to x first -> dx = dA * (x > 0), fused into the dgrad launch's epilogue
-            dx = ops.conv(dy, packT, ksize=ksize, alpha=None if sn is None else sn[2][1:], prec=prec, relu_mask=x if pro == 2 else None)
+            alpha = None if sn is None else sn[2][1:]
+            if pro != 2 and ops.thin_conv_supported(cout, cin, ksize, width):
+                dx = ops.thin_conv(dy, packT, ksize=ksize, alpha=alpha, prec=prec)
+            else:
+                # pro == 2: the forward applied ReLU to x first -> dx = dA * (x > 0), fused into the dgrad launch's epilogue
+                dx = ops.conv16(dy16(), packT, ksize=ksize, alpha=alpha, prec=prec, relu_mask=a16 if pro == 2 else None)
         want_db = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            dw = ops.conv_wgrad(x, dy, ksize=ksize, pro=pro, prec=prec, sn=None if sn is None else (wd,) + tuple(sn),
-                                accum=None if ctx.w_param is None else _accum_target(ctx.w_param), bias_grad=want_db)
+            kw = dict(ksize=ksize, sn=None if sn is None else (wd,) + tuple(sn),
+                      accum=None if ctx.w_param is None else _accum_target(ctx.w_param), bias_grad=want_db)
+            if x is not None:
+                dw = ops.thin_wgrad(x, dy, pro=pro, **kw)
+            else:
+                dw = ops.conv_wgrad16(a16, dy16(), prec=prec, **kw)
             if want_db:
                 dw, db = dw
         elif want_db:

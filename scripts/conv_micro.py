@@ -1,28 +1,50 @@
+"""Per-layer micro-benchmark of lp_conv16_fwd (operand planes already packed: the conv kernel alone), lp_act_pack and
+lp_conv16_wgrad at the generator / critic / VGG layer classes, N = 8.  PREC = 0 bf16 | 1 bf16x3 | 2 f16; knobs LP_CONV_PP,
+LP_CONV_W8, LP_CONV_KSPLIT, LP_WGRAD_COB.  Prints us and ALGORITHMIC TF/s (2*MACs of the dense conv / time)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from latent_pose_reenactment_amd import hipops as ops
 SHAPES = [  # N, H, W, Cin, Cout, ks, ups
     (8, 4, 4, 512, 512, 3, 0), (8, 16, 16, 512, 512, 3, 0), (8, 32, 32, 512, 512, 3, 0), (8, 64, 64, 256, 256, 3, 0),
-    (8, 128, 128, 128, 128, 3, 0), (8, 256, 256, 64, 64, 3, 0), (8, 256, 256, 128, 64, 3, 1), (8, 256, 256, 64, 128, 3, 0), (8, 256, 256, 3, 64, 3, 0), (8, 256, 256, 3, 64, 1, 0)]
+    (8, 128, 128, 128, 128, 3, 0), (8, 256, 256, 64, 64, 3, 0), (8, 256, 256, 128, 64, 3, 1), (8, 256, 256, 64, 128, 3, 0),
+    (8, 64, 64, 512, 256, 3, 1), (8, 64, 64, 256, 128, 1, 0), (16, 128, 128, 128, 128, 3, 0), (16, 64, 64, 256, 256, 3, 0)]
 prec = int(os.environ.get('PREC', '0'))
 REPS = int(os.environ.get('REPS', '20'))
-for (n, h, w, cin, cout, ks, ups) in SHAPES:
-    hin, win = (h // 2, w // 2) if ups else (h, w)
-    x = torch.randn(n, hin, win, cin, device='cuda')
-    wgt = torch.randn(cout, cin, ks, ks, device='cuda') * 0.02
-    sc = torch.randn(n, cin, device='cuda'); sh = torch.randn(n, cin, device='cuda')
-    pack = ops.pack_weights(wgt, 0, prec, small_k=(ks == 3 and cin <= 32))
-    pro = 0 if cin <= 4 else 1
+WHAT = os.environ.get('WHAT', 'conv,pack,wgrad').split(',')
+
+
+def timeit(f):
     for _ in range(3):
-        ops.conv(x, pack, ksize=ks, upsample=bool(ups), pro=pro, scale=sc, shift=sh, prec=prec)
+        f()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(REPS):
-        ops.conv(x, pack, ksize=ks, upsample=bool(ups), pro=pro, scale=sc, shift=sh, prec=prec)
+        f()
     e1.record(); torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) / REPS * 1e3
+    return e0.elapsed_time(e1) / REPS * 1e3
+
+
+for (n, h, w, cin, cout, ks, ups) in SHAPES:
+    hin, win = (h // 2, w // 2) if ups else (h, w)
+    x = torch.randn(n, hin, win, cin, device='cuda')
+    dy = torch.randn(n, h, w, cout, device='cuda')
+    wgt = torch.randn(cout, cin, ks, ks, device='cuda') * 0.02
+    sc = torch.randn(n, cin, device='cuda'); sh = torch.randn(n, cin, device='cuda')
+    pack = ops.pack_weights(wgt, 0, prec)
+    a = ops.act_pack(x, pro=1, scale=sc, shift=sh, prec=prec)
+    d = ops.act_pack(dy, prec=prec, grad=True)
     fl = 2.0 * n * h * w * cin * cout * ks * ks
-    alg = x.numel() * 4 + wgt.numel() * 2 * (2 if prec else 1) + n * h * w * cout * 4   # fp32 x read + packed W read + fp32 y write
-    print(f'alg_bytes={alg} dbg={os.environ.get("LP_CONV_DBG","0"):>2s} cc={os.environ.get("LP_CONV_CC","-")} {str((n,h,w,cin,cout,ks,ups)):36s} {us:8.1f} us  {fl/us/1e6:7.1f} TF/s')
+    out = [f'prec={prec} {str((n, h, w, cin, cout, ks, ups)):40s}']
+    if 'conv' in WHAT:
+        us = timeit(lambda: ops.conv16(a, pack, ksize=ks, upsample=bool(ups), prec=prec))
+        out.append(f'conv {us:7.1f} us {fl / us / 1e6:7.1f} TF/s')
+    if 'pack' in WHAT:
+        us = timeit(lambda: ops.act_pack(x, pro=1, scale=sc, shift=sh, prec=prec))
+        gb = x.numel() * (4 + (4 if prec == 1 else 2)) / 1e3
+        out.append(f'pack {us:6.1f} us {gb / us:6.0f} GB/s')
+    if 'wgrad' in WHAT:
+        us = timeit(lambda: ops.conv_wgrad16(a, d, ksize=ks, upsample=bool(ups), prec=prec))
+        out.append(f'wgrad {us:7.1f} us {fl / us / 1e6:7.1f} TF/s')
+    print(' | '.join(out), flush=True)

@@ -1,6 +1,6 @@
 """Every tile / schedule variant of the HIP kernels must pass the same per-op parity tests, not only the variant the default
 heuristics pick for the (small) test shapes.  The variant knobs are read once per process (static env lookups in
-csrc/conv_igemm.hip, conv_wgrad.hip), so each setting runs tests/test_hip_ops.py in a fresh interpreter."""
+csrc/conv_dma.hip, conv_wgrad.hip; LP_THIN in hipops.py), so each setting runs tests/test_hip_ops.py in a fresh interpreter."""
 import os
 import subprocess
 import sys
@@ -14,10 +14,8 @@ VARIANTS = [
     {'LP_CONV_PP': '0'},                        # single-group schedule everywhere
     {'LP_CONV_W8': '1'},                        # 8-wave workgroups for every shape
     {'LP_CONV_W8': '0', 'LP_CONV_KSPLIT': '1'},  # no split-K, 4-wave tiles only
-    {'LP_CONV_NBUF': '3'},                      # 3-deep weight ring (bf16)
-    {'LP_CONV_CC': '64'},                       # 64-channel chunks
     {'LP_WGRAD_COB': '64'},                     # 64-output-channel wgrad workgroups only
-    {'LP_CONV_THIN': '0', 'LP_WGRAD_THIN': '0'},  # thin-channel layers through the MFMA kernels
+    {'LP_THIN': '0'},                           # thin-channel layers through the MFMA kernels (3- / 4-channel operand planes)
 ]
 
 
