@@ -205,7 +205,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=8, help='per-GPU batch')
     ap.add_argument('--image_size', type=int, default=256)
-    ap.add_argument('--prec', default=os.environ.get('LP_PREC', 'bf16x3'), choices=['bf16', 'bf16x3'])
+    ap.add_argument('--prec', default=os.environ.get('LP_PREC', 'bf16x3'), choices=['bf16', 'bf16x3', 'f16'])
     ap.add_argument('--workload', default='finetune_step', choices=['finetune_step', 'generator'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eager', action='store_true', help='do not capture the step into hipGraphs')

@@ -47,12 +47,14 @@ int lp_pack_weights_batch(const void* table, int num_entries, long long total_ch
  *   act(x) * in_scale,  act: pro 0 identity | 1 relu(x*scale[n,c]+shift[n,c]) | 2 relu(x)
  * in the operand format of `prec` (bf16 | bf16 hi+lo | fp16, saturating).  Replaces, once per tensor, the instance_norm + mul +
  * add + relu chain of AdaptiveNorm2d/ReLU (generators/common/blocks.py:18-26,70-73) that the reference runs before every conv;
- * the planes feed lp_conv16_fwd (forward / dgrad) and lp_conv16_wgrad.  in_scale: device scalar|NULL (fp16 gradient scaling). */
+ * the planes feed lp_conv16_fwd (forward / dgrad) and lp_conv16_wgrad.  in_scale: device scalar|NULL.
+ * fp16 gradient operands: amax_part = the lp_amax_blocks() block maxima of |x| written by lp_amax_partial (|NULL); the pack then
+ * scales by s = the power of two that puts amax(x) into [2^12, 2^13) and writes scale_out = {s, 1/s} (device, |NULL) for the
+ * consumers (alpha2 of lp_conv16_fwd, out_scale of lp_conv16_wgrad). */
 int lp_act_pack(const float* x, const float* scale, const float* shift, int pro, uint16_t* hi, uint16_t* lo,
-                int N, int HW, int C, int prec, const float* in_scale, void* stream);
-/* out2 = {s, 1/s}: power-of-two scale that puts amax(x) into [2^12, 2^13) (fp16 gradient operands); workspace: lp_amax_workspace_floats(). */
-int lp_amax_workspace_floats(void);
-int lp_amax_scale(const float* x, long long numel, float* out2, float* workspace, void* stream);
+                int N, int HW, int C, int prec, const float* in_scale, const float* amax_part, float* scale_out, void* stream);
+int lp_amax_blocks(void);
+int lp_amax_partial(const float* x, long long numel, float* part, void* stream);
 
 /* Fused conv on operand planes: y = alpha * alpha2 * conv_{k x k, pad k/2}( up2?(a), w ) + bias + res
  * Replaces, per conv of blocks.ResBlock (generators/common/blocks.py:70-111): nn.Upsample(nearest x2) + F.conv2d + W/sigma scaling

@@ -5,7 +5,7 @@ AvgPool; inputs mapped (x+1)/2 then (x - mean_bgr/255)*255 on RGB-ordered channe
 is the sum over all 13 ReLU outputs of mean|f(fake) - f(real)| times ``weight``.  The VGG definitions come from
 torchvision in the reference (absent here); the standard 'E' / 'D' configurations are restated below.  State-dict keys of
 ``self.model`` are the ``features`` indices (``0.weight`` ...), as in the reference.
-The feature stack runs on the gfx950 kernels: every conv is lp_conv_fwd (the preceding ReLU fused as its prologue),
+The feature stack runs on the gfx950 kernels: every conv is lp_conv16_fwd on 16-bit operand planes (relu fused into the producer's epilogue),
 ReLU+AvgPool is lp_avgpool2_fwd, each tap is the fused L1-of-ReLUs kernel; the frozen weights are packed to bf16 once."""
 import os
 from collections import OrderedDict
@@ -89,10 +89,15 @@ class PerceptualLoss(nn.Module):
         """``targets`` None: collect the taps (pre-ReLU conv outputs; the ReLU is fused into their consumers) into ``taps``.
         ``targets`` = taps of the other image: append the L1 term of every tap instead (the tap tensor flows on through
         L1TapFn so that its two gradients are summed inside the L1 backward kernel)."""
-        cur, pending_relu = to_nhwc(x), False
+        cur, pending_relu, cur16 = to_nhwc(x), False, None
+        n_layers = len(self.model)
         for i, layer in enumerate(self.model):
             if isinstance(layer, nn.Conv2d):
-                cur = hip_conv(cur, layer.weight, layer.bias, ksize=3, pro=2 if pending_relu else 0, prec=prec, packs=packs[i])
+                # conv -> ReLU -> conv: this conv's epilogue also writes the 16-bit operand planes of relu(y) for the next conv
+                emit = 1 if (i + 2 < n_layers and isinstance(self.model[i + 2], nn.Conv2d)) else None
+                out = hip_conv(cur, layer.weight, layer.bias, ksize=3, pro=2 if pending_relu else 0, prec=prec, packs=packs[i],
+                               x16=cur16, emit16=emit)
+                cur, cur16 = out if emit is not None else (out, None)
                 pending_relu = True
             elif isinstance(layer, nn.ReLU):
                 if targets is None:

@@ -11,18 +11,47 @@
 // grid = (blocks, N): blockIdx.y = image; a thread walks the (pixel, 8-channel group) items of its image with a stride that is a
 // multiple of the group count G whenever G is a power of two, so its group -- and with it the AdaIN scale/shift of its 8 channels
 // -- is fixed and loaded once; 4 items are in flight per thread (8 x 16-B loads) to cover the HBM latency.
+#define AMAX_BLOCKS 256
+// amax -> power-of-two input scale of an fp16 gradient operand: s = 2^(13 - e) with amax = f * 2^e, f in [0.5, 1): the scaled
+// tensor's amax lands in [2^12, 2^13) -- 3 binades of headroom below the fp16 maximum, 26 binades of normal range below
+__device__ __forceinline__ void amax_to_scale(float m, float& s, float& inv) {
+    s = 1.f; inv = 1.f;
+    if (m > 0.f && m < 3.0e38f) {
+        int e;
+        (void)frexpf(m, &e);
+        int k = 13 - e;
+        k = k > 100 ? 100 : (k < -100 ? -100 : k);
+        s = ldexpf(1.f, k); inv = ldexpf(1.f, -k);
+    }
+}
+
 template <int PREC>
 __global__ __launch_bounds__(256) void act_pack_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, int pro, uint16_t* __restrict__ hi,
                                                        uint16_t* __restrict__ lo, int HW, int C, int C8,
-                                                       const float* __restrict__ in_scale) {
+                                                       const float* __restrict__ in_scale, const float* __restrict__ amax_part,
+                                                       float* __restrict__ scale_out) {
     constexpr bool SPLIT = (PREC == LP_PREC_BF16X3), F16 = (PREC == LP_PREC_F16);
     constexpr int U = 4;
+    float isc = in_scale ? in_scale[0] : 1.f;
+    if (amax_part) {
+        // gradient operand: every block finishes the amax reduction itself (AMAX_BLOCKS partials from lp_amax_partial, L2 resident)
+        // and derives the same power-of-two scale; block (0,0) publishes {s, 1/s} for the consumers of the planes
+        __shared__ float sh[4];
+        float m = 0.f;
+        for (int j = threadIdx.x; j < AMAX_BLOCKS; j += 256) m = fmaxf(m, amax_part[j]);
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+        float inv;
+        amax_to_scale(m, isc, inv);
+        if (scale_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { scale_out[0] = isc; scale_out[1] = inv; }
+    }
     const unsigned G = (unsigned)C8 >> 3;
     const unsigned items = (unsigned)HW * G;
     const unsigned stride = gridDim.x * 256u;
     const int n = blockIdx.y;
-    const float isc = in_scale ? in_scale[0] : 1.f;
     const bool vec = (C & 3) == 0;
     const float lo_clamp = (pro != 0) ? 0.f : -3.0e38f;
     const float* xn = x + (size_t)n * HW * C;
@@ -81,7 +110,8 @@ __global__ __launch_bounds__(256) void act_pack_kernel(const float* __restrict__
 }
 
 extern "C" int lp_act_pack(const float* x, const float* scale, const float* shift, int pro, uint16_t* hi, uint16_t* lo,
-                           int N, int HW, int C, int prec, const float* in_scale, void* stream) {
+                           int N, int HW, int C, int prec, const float* in_scale, const float* amax_part, float* scale_out,
+                           void* stream) {
     if (!x || !hi) return lp_set_error(LP_ERR_ARG, "lp_act_pack: null pointer");
     if (pro == 1 && (!scale || !shift)) return lp_set_error(LP_ERR_ARG, "lp_act_pack: pro=1 needs scale/shift");
     if (prec == LP_PREC_BF16X3 && !lo) return lp_set_error(LP_ERR_ARG, "lp_act_pack: bf16x3 needs the lo plane");
@@ -93,7 +123,7 @@ extern "C" int lp_act_pack(const float* x, const float* scale, const float* shif
     const long long cap = (4096 + N - 1) / N; if (bx > cap) bx = cap; if (bx < 1) bx = 1;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)bx, (unsigned)N);
-#define LP_AP(P) hipLaunchKernelGGL(act_pack_kernel<P>, grid, dim3(256), 0, st, x, scale, shift, pro, hi, lo, HW, C, C8, in_scale)
+#define LP_AP(P) hipLaunchKernelGGL(act_pack_kernel<P>, grid, dim3(256), 0, st, x, scale, shift, pro, hi, lo, HW, C, C8, in_scale, amax_part, scale_out)
     if (prec == LP_PREC_BF16) LP_AP(LP_PREC_BF16);
     else if (prec == LP_PREC_BF16X3) LP_AP(LP_PREC_BF16X3);
     else if (prec == LP_PREC_F16) LP_AP(LP_PREC_F16);
@@ -103,10 +133,9 @@ extern "C" int lp_act_pack(const float* x, const float* scale, const float* shif
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// amax -> power-of-two input scale of an fp16 gradient operand: out = {s, 1/s}, s = 2^(13 - e) with amax = f * 2^e, f in [0.5, 1)
-// (the scaled tensor's amax lands in [2^12, 2^13): 3 binades of headroom below the fp16 maximum, 26 binades of normal range below)
+// amax partials of a gradient tensor: part[AMAX_BLOCKS] block maxima of |x| (every entry written); lp_act_pack finishes the
+// reduction (amax_part argument), so a gradient operand costs one extra streaming read and no extra finalize launch
 // ------------------------------------------------------------------------------------------------------------------
-#define AMAX_BLOCKS 1024
 __global__ __launch_bounds__(256) void amax_partial_kernel(const float4* __restrict__ x, long long total4, const float* __restrict__ tail,
                                                            int ntail, float* __restrict__ part) {
     __shared__ float sh[4];
@@ -123,36 +152,12 @@ __global__ __launch_bounds__(256) void amax_partial_kernel(const float4* __restr
     if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
 }
 
-__global__ __launch_bounds__(256) void amax_finalize_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
-    __shared__ float sh[4];
-    float m = 0.f;
-    for (int j = threadIdx.x; j < n; j += 256) m = fmaxf(m, part[j]);
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        m = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
-        float s = 1.f, inv = 1.f;
-        if (m > 0.f && m < 3.0e38f) {
-            int e;
-            (void)frexpf(m, &e);
-            int k = 13 - e;
-            k = k > 100 ? 100 : (k < -100 ? -100 : k);
-            s = ldexpf(1.f, k); inv = ldexpf(1.f, -k);
-        }
-        out[0] = s; out[1] = inv;
-    }
-}
+extern "C" int lp_amax_blocks(void) { return AMAX_BLOCKS; }
 
-extern "C" int lp_amax_workspace_floats(void) { return AMAX_BLOCKS; }
-
-extern "C" int lp_amax_scale(const float* x, long long numel, float* out2, float* workspace, void* stream) {
-    if (!x || !out2 || !workspace) return lp_set_error(LP_ERR_ARG, "lp_amax_scale: null pointer");
-    hipStream_t st = (hipStream_t)stream;
+extern "C" int lp_amax_partial(const float* x, long long numel, float* part, void* stream) {
+    if (!x || !part) return lp_set_error(LP_ERR_ARG, "lp_amax_partial: null pointer");
     const long long total4 = numel / 4;
-    long long blocks = (total4 + 255) / 256; if (blocks > AMAX_BLOCKS) blocks = AMAX_BLOCKS; if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(amax_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float4*)x, total4, x + total4 * 4,
-                       (int)(numel - total4 * 4), workspace);
-    hipLaunchKernelGGL(amax_finalize_kernel, dim3(1), dim3(256), 0, st, workspace, (int)blocks, out2);
-    return lp_check_launch("amax_scale");
+    hipLaunchKernelGGL(amax_partial_kernel, dim3(AMAX_BLOCKS), dim3(256), 0, (hipStream_t)stream, (const float4*)x, total4, x + total4 * 4,
+                       (int)(numel - total4 * 4), part);
+    return lp_check_launch("amax_partial");
 }

@@ -498,6 +498,6 @@ extern "C" int lp_conv16_fwd(const uint16_t* a_hi, const uint16_t* a_lo, const u
     // the epilogue cannot emit the 16-bit planes from partial sums (split-K) or for channel counts it writes element-wise with
     // padding channels: a bandwidth-bound pass over the finished y does it instead (same stream)
     if (out_hi && !p.o_hi)
-        return lp_act_pack(y, nullptr, nullptr, out_relu ? 2 : 0, out_hi, out_lo, N, H * W, Cout, prec, nullptr, stream);
+        return lp_act_pack(y, nullptr, nullptr, out_relu ? 2 : 0, out_hi, out_lo, N, H * W, Cout, prec, nullptr, nullptr, nullptr, stream);
     return LP_OK;
 }

@@ -4,7 +4,7 @@ Behavioural notes reproduced on purpose:
   * every norm-'none' ResBlock starts with ReLU(inplace) on its *input* (generators/common/blocks.py:71-73), so its skip
     branch / identity add see relu(x), and the features handed to feature matching are post-ReLU except the last one;
   * pass_inputs runs three times per step (fake->G, fake.detach->D, real), each doing its own power iteration.
-All convolutions run on the gfx950 kernels (lp_conv_fwd with the ReLU prologue / bias / residual epilogue, lp_conv_wgrad,
+All convolutions run on the gfx950 kernels (lp_act_pack / lp_conv16_fwd with bias / residual epilogue, lp_conv16_wgrad,
 lp_avgpool2_*); activations are NHWC inside and are handed out as logical N x C x H x W views (channels_last strides).
 avgpool(a) + avgpool(b) is evaluated as avgpool(a + b) (the skip conv result is the residual operand of conv2's epilogue):
 identical algebra, one rounding fewer."""
@@ -14,8 +14,9 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from latent_pose_reenactment_amd import hipops as ops
 from latent_pose_reenactment_amd.nn import (SNWeight, SNBatch, SNLinearFn, _Indexed, SN_EPS_CONV, SN_EPS_DEFAULT, AvgPool2Fn,
-                                            as_nchw_view, hip_conv, to_nhwc)
+                                            as_nchw_view, default_prec, hip_conv, to_nhwc)
 from latent_pose_reenactment_amd.utils import radam as _radam
 
 torch.optim.RAdam = _radam.RAdam      # the reference swaps in its own RAdam the same way (no_landmarks.py:5-6)
@@ -71,9 +72,11 @@ class _DisBlock(nn.Module):
     def forward(self, x_relu, track, states):
         """x_relu: NHWC relu(x) (the reference's in-place ReLU makes every consumer of the block input see relu(x))"""
         c1, c2 = self.block._modules['2'], self.block._modules['5']
-        h = _conv(x_relu, c1, track, states, ksize=3)
-        shortcut = _conv(x_relu, self.skip._modules['0'], track, states, ksize=1) if self.has_skip else x_relu
-        out = _conv(h, c2, track, states, res=shortcut, ksize=3, pro=2)
+        # relu(x) is packed to operand planes ONCE for its two consumers; conv1's epilogue emits the planes of relu(h) for conv2
+        xr16 = ops.act_pack(x_relu, pro=0, prec=default_prec())
+        h, h16 = _conv(x_relu, c1, track, states, ksize=3, x16=xr16, emit16=1)
+        shortcut = _conv(x_relu, self.skip._modules['0'], track, states, ksize=1, x16=xr16) if self.has_skip else x_relu
+        out = _conv(h, c2, track, states, res=shortcut, ksize=3, pro=2, x16=h16)
         return AvgPool2Fn.apply(out, False) if self.downsample else out
 
 
@@ -146,9 +149,9 @@ class Discriminator(nn.Module):
         states = {id(l): s for l, s in zip(layers, st)}
         states['packs'] = self.__dict__.setdefault('_step_packs', {})
         xn = to_nhwc(x)
-        h = _conv(xn, d0, track_weights, states, ksize=3)
+        h, h16 = _conv(xn, d0, track_weights, states, ksize=3, emit16=1)
         shortcut = _conv(xn, sk, track_weights, states, ksize=1)
-        out = AvgPool2Fn.apply(_conv(h, d2, track_weights, states, res=shortcut, ksize=3, pro=2), False)
+        out = AvgPool2Fn.apply(_conv(h, d2, track_weights, states, res=shortcut, ksize=3, pro=2, x16=h16), False)
         feats = []
         for block in self.blocks:
             out_relu = torch.relu(out)           # what the reference's in-place ReLU leaves behind in its feature list

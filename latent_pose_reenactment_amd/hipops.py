@@ -143,16 +143,17 @@ def act_pack(x: Tensor, *, pro: int = 0, scale: Optional[Tensor] = None, shift: 
     _chk(x, 'x')
     n, h, w, c = x.shape
     hi, lo = _alloc16(n, h, w, c, prec, x.device)
-    sc = None
+    sc = part = None
     if grad and prec == PREC_F16:
-        sc = torch.empty(2, dtype=torch.float32, device=x.device)
-        ws = torch.empty(_lib.lib().lp_amax_workspace_floats(), dtype=torch.float32, device=x.device)
-        check(_lib.lib().lp_amax_scale(x.data_ptr(), x.numel(), sc.data_ptr(), ws.data_ptr(), _stream()), 'lp_amax_scale')
+        nb = _lib.lib().lp_amax_blocks()
+        buf = torch.empty(nb + 2, dtype=torch.float32, device=x.device)
+        part, sc = buf[:nb], buf[nb:]
+        check(_lib.lib().lp_amax_partial(x.data_ptr(), x.numel(), part.data_ptr(), _stream()), 'lp_amax_partial')
     for t, nm in ((scale, 'scale'), (shift, 'shift')):
         if t is not None:
             _chk(t, nm)
-    check(_lib.lib().lp_act_pack(x.data_ptr(), _p(scale), _p(shift), pro, hi.data_ptr(), _p(lo), n, h * w, c, prec, _p(sc), _stream()),
-          'lp_act_pack')
+    check(_lib.lib().lp_act_pack(x.data_ptr(), _p(scale), _p(shift), pro, hi.data_ptr(), _p(lo), n, h * w, c, prec, None, _p(part), _p(sc),
+                                 _stream()), 'lp_act_pack')
     return Act16(hi, lo, c, None if sc is None else sc[1:])
 
 

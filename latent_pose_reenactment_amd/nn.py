@@ -299,6 +299,8 @@ class _DecoderFunction(torch.autograd.Function):
             out = ops.conv16(a1, p2, ksize=3, res=s, res_shift=rs, alpha=sn[i2][2][1:], prec=prec)
             if need_grad:
                 saved.append((x, h1, st0, st1, o0, o1, a0, a1, xs))
+            if cfg.get('debug') is not None:      # activation patterns of the AdaIN+ReLU sites (tie-masked parity checks)
+                cfg['debug'].setdefault('relu_planes', []).extend([a0.hi, a1.hi])
             x = out
         ch = blocks[-1][1]
         gh, bh, oh = aff(ch)
@@ -307,6 +309,8 @@ class _DecoderFunction(torch.autograd.Function):
         ph = fpack(wi, wh)
         ah = ops.act_pack(x, pro=1, scale=sth[2], shift=sth[3], prec=prec)
         z = ops.conv16(ah, ph, ksize=3, bias=bhd.detach().contiguous(), alpha=sn[wi][2][1:], prec=prec)
+        if cfg.get('debug') is not None:
+            cfg['debug'].setdefault('relu_planes', []).append(ah.hi)
         t, rgbs, segm = ops.head_fwd(z, want_t=need_grad)
         if need_grad:
             ctx.cfg = cfg
@@ -549,8 +553,11 @@ class ConvFn(torch.autograd.Function):
     thin-channel kernels.  ``packs`` = optional cached (forward, dgrad) WeightPacks of a frozen w."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, res, ksize, pro, prec, packs, sn=None):
-        """``sn`` = (u_used, v_used, [sigma, 1/sigma]) from SNBatch when ``w`` is a spectrally normalised W_orig"""
+    def forward(ctx, x, w, bias, res, ksize, pro, prec, packs, sn=None, x16=None, emit=None):
+        """``sn`` = (u_used, v_used, [sigma, 1/sigma]) from SNBatch when ``w`` is a spectrally normalised W_orig.
+        ``x16``: operand planes of act(x) that already exist (emitted by the producer conv's epilogue, or packed once for several
+        consumers) -- skips this call's lp_act_pack.  ``emit`` = (out_relu: 0|1, holder list): the conv epilogue also writes the
+        operand planes of (relu?)(y) for the consumer conv; they are appended to ``holder``."""
         small_k = ksize == 3 and w.shape[1] <= 32
         wd = w.detach().contiguous()
         if isinstance(packs, dict):          # per-step cache shared by several calls on the same W_orig (discriminator passes)
@@ -565,12 +572,18 @@ class ConvFn(torch.autograd.Function):
         alpha = None if sn is None else sn[2][1:]
         need_w = w.requires_grad
         thin_w = need_w and ops.thin_wgrad_supported(cin, cout, ksize, pro, width)       # the weight gradient will want fp32 x
-        a16 = None
-        if pro == 0 and res is None and ops.thin_conv_supported(cin, cout, ksize, width):
+        a16 = x16
+        if a16 is None and pro == 0 and res is None and ops.thin_conv_supported(cin, cout, ksize, width):
             y = ops.thin_conv(x, pack, ksize=ksize, bias=bd, alpha=alpha, prec=prec)
+            if emit is not None:
+                emit[1].append(ops.act_pack(y, pro=2 if emit[0] else 0, prec=prec))
         else:
-            a16 = ops.act_pack(x, pro=pro, prec=prec)
-            y = ops.conv16(a16, pack, ksize=ksize, bias=bd, res=res, alpha=alpha, prec=prec)
+            if a16 is None:
+                a16 = ops.act_pack(x, pro=pro, prec=prec)
+            y = ops.conv16(a16, pack, ksize=ksize, bias=bd, res=res, alpha=alpha, prec=prec, out16=None if emit is None else emit[0])
+            if emit is not None:
+                y, o16 = y
+                emit[1].append(o16)
         if need_w and not thin_w and a16 is None:
             a16 = ops.act_pack(x, pro=pro, prec=prec)
         ctx.x = x if thin_w else None                               # fp32 input only where a thin-channel weight gradient needs it
@@ -622,11 +635,18 @@ class ConvFn(torch.autograd.Function):
             db = dy.sum(dim=(0, 1, 2))
         if has_res and ctx.needs_input_grad[3]:
             dres = dy
-        return dx, dw, db, dres, None, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None, None
 
 
-def hip_conv(x, w, bias=None, res=None, ksize=3, pro=0, prec=None, packs=None, sn=None):
-    return ConvFn.apply(x, w, bias, res, ksize, pro, default_prec() if prec is None else prec, packs, sn)
+def hip_conv(x, w, bias=None, res=None, ksize=3, pro=0, prec=None, packs=None, sn=None, x16=None, emit16=None):
+    """``x16``: existing operand planes of act(x); ``emit16`` = 0 | 1: also return the operand planes of y (1: of relu(y)), written
+    by the conv's epilogue -> ``(y, Act16)``."""
+    prec = default_prec() if prec is None else prec
+    if emit16 is None:
+        return ConvFn.apply(x, w, bias, res, ksize, pro, prec, packs, sn, x16, None)
+    holder = []
+    y = ConvFn.apply(x, w, bias, res, ksize, pro, prec, packs, sn, x16, (int(emit16), holder))
+    return y, holder[0]
 
 
 class AvgPool2Fn(torch.autograd.Function):

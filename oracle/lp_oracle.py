@@ -104,15 +104,23 @@ def split_affine_params(affine: Tensor, blocks: List[Tuple[int, int, bool]]) -> 
     return out
 
 
-def resblock_ada(x: Tensor, sd: State, prefix: str, aff0, aff1, upsample: bool, train: bool) -> Tensor:
+def _relu_m(x: Tensor, mask: Optional[Tensor]) -> Tensor:
+    """ReLU, or -- tie-masked parity checks -- the same piecewise-linear branch with a PRESCRIBED activation pattern ``mask`` (the
+    pattern of the implementation under test): pre-activations within rounding distance of 0 flip between two correct
+    implementations, and a flipped unit changes a gradient by a whole term, so gradients are compared on the tested
+    implementation's own branch.  Forward outputs are always compared with the true ReLU."""
+    return torch.relu(x) if mask is None else x * mask.to(x.dtype)
+
+
+def resblock_ada(x: Tensor, sd: State, prefix: str, aff0, aff1, upsample: bool, train: bool, masks=(None, None)) -> Tensor:
     """blocks.ResBlock with norm_layer='adain' (blocks.py:47-111): pre-activation, convs without bias, SN eps 1e-4."""
     i1, i2 = (4, 8) if upsample else (3, 7)
-    h = torch.relu(adain(x, *aff0))
+    h = _relu_m(adain(x, *aff0), masks[0])
     if upsample:
         h = upsample2(h)
     w1 = sn_effective_weight(sd, f'{prefix}.block.{i1}', SN_EPS_CONV, train)
     h = F.conv2d(h, w1, None, 1, 1)
-    h = torch.relu(adain(h, *aff1))
+    h = _relu_m(adain(h, *aff1), masks[1])
     w2 = sn_effective_weight(sd, f'{prefix}.block.{i2}', SN_EPS_CONV, train)
     h = F.conv2d(h, w2, None, 1, 1)
     if f'{prefix}.skip.1.weight_orig' in sd:   # in != out or upsample (blocks.py:92-103); Upsample is skip.0
@@ -127,11 +135,12 @@ def resblock_ada(x: Tensor, sd: State, prefix: str, aff0, aff1, upsample: bool, 
 
 
 def generator_forward(sd: State, identity: Tensor, pose: Tensor, *, num_channels: int, max_num_channels: int,
-                      image_size: int, train: bool, const_size: int = 4, num_res_blocks: int = 2
-                      ) -> Tuple[Tensor, Tensor]:
+                      image_size: int, train: bool, const_size: int = 4, num_res_blocks: int = 2,
+                      relu_masks: Optional[List[Tensor]] = None) -> Tuple[Tensor, Tensor]:
     """Generator.forward (noBottleneck.py:165-181).  ``identity`` is data_dict['embeds'] (B x E) or the finetuned
     ``identity_embedding`` (1 x E, expanded).  Returns (fake_rgbs, fake_segm).  SN buffers in ``sd`` are updated in
-    place when ``train``."""
+    place when ``train``.  ``relu_masks``: prescribed activation patterns of the 17 AdaIN+ReLU sites in execution order
+    (tie-masked gradient checks, see ``_relu_m``)."""
     b = pose.shape[0]
     if identity.shape[0] == 1 and b != 1:
         identity = identity.expand(b, -1)
@@ -148,9 +157,10 @@ def generator_forward(sd: State, identity: Tensor, pose: Tensor, *, num_channels
     # NOTE on SN ordering: the hook fires per module at its forward, i.e. in execution order; power iterations of
     # distinct layers are independent so the order does not matter numerically.
     for i, (cin, cout, up) in enumerate(blocks):
-        x = resblock_ada(x, sd, f'decoder_blocks.{i}', affs[2 * i], affs[2 * i + 1], up, train)
+        mk = (None, None) if relu_masks is None else (relu_masks[2 * i], relu_masks[2 * i + 1])
+        x = resblock_ada(x, sd, f'decoder_blocks.{i}', affs[2 * i], affs[2 * i + 1], up, train, mk)
     nb = len(blocks)
-    x = torch.relu(adain(x, *affs[2 * nb]))
+    x = _relu_m(adain(x, *affs[2 * nb]), None if relu_masks is None else relu_masks[2 * nb])
     wh = sn_effective_weight(sd, f'decoder_blocks.{nb + 2}', SN_EPS_CONV, train)
     x = torch.tanh(F.conv2d(x, wh, sd[f'decoder_blocks.{nb + 2}.bias'], 1, 1))
     rgb = x[:, :-1] * 0.75 + 0.5
