@@ -27,15 +27,17 @@ GEN_FWD_GFLOP_PER_IMAGE = 60.72      # SURVEY 8d / BASELINE.md: dense 2*MAC, as 
 MFMA_BF16_PEAK_TFLOPS = 2500.0       # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 
 
-def make_args(image_size, batch_size, device, num_gpus, rank, prec_name):
+def make_args(image_size, batch_size, device, num_gpus, rank, prec_name, finetune=True):
+    """finetune=True: configs/finetuning-base.yaml (BASELINE configs[1]); False: configs/default.yaml meta-training (configs[2])"""
     a = argparse.Namespace(
         image_size=image_size, batch_size=batch_size * num_gpus, num_gpus=num_gpus, world_size=num_gpus, rank=rank, device=device,
         in_channels=3, out_channels=3, num_channels=64, max_num_channels=512, embed_channels=512, pose_embedding_size=256,
         gen_padding='zero', norm_layer='in', gen_constant_input_size=4, gen_num_residual_blocks=2,
         dis_padding='zero', dis_num_blocks=7, num_labels=98000, average_function='sum',
-        gan_type='gan', fm_weight=10.0, dice_weight=1.0, perc_weight=3e-2, idt_embed_weight=0.6e-2,
-        vgg_weights_dir='/nonexistent', synthetic_vgg_seed=1234,
-        optimizer='RAdam', lr_gen=5e-4, lr_dis=8e-4, beta1=0.0, finetune=True, random_seed=123)
+        gan_type='gan', fm_weight=10.0, dice_weight=1.0, perc_weight=3e-2, idt_embed_weight=0.6e-2, dis_embed_weight=1e-2,
+        vgg_weights_dir='/nonexistent', synthetic_vgg_seed=1234, n_frames_for_encoder=8,
+        optimizer='RAdam' if finetune else 'Adam', lr_gen=5e-4 if finetune else 5e-5, lr_dis=8e-4 if finetune else 2e-4, beta1=0.0,
+        finetune=finetune, random_seed=123)
     os.environ['LP_PREC'] = prec_name
     return a
 
@@ -44,22 +46,27 @@ def build(args):
     from generators.vector_pose_unsupervised_segmentation_noBottleneck import Wrapper as GW
     from embedders.unsupervised_pose_separate_embResNeXt_segmentation import Wrapper as EW
     from discriminators.no_landmarks import Wrapper as DW
-    from criterions import adversarial, featmat, idt_embed, perceptual, dice
+    from criterions import adversarial, featmat, idt_embed, perceptual, dice, dis_embed
     from runners import holycow
     torch.manual_seed(args.random_seed)
     D = DW.get_net(args)
     G = GW.get_net(args)
     E = EW.get_net(args)
-    crits = [m.Wrapper.get_net(args) for m in (adversarial, featmat, idt_embed, perceptual, dice)]
+    if args.finetune:
+        crit_modules = (adversarial, featmat, idt_embed, perceptual, dice)                  # configs/finetuning-base.yaml:7
+    else:
+        crit_modules = (idt_embed, perceptual, adversarial, featmat, dis_embed, dice)       # configs/default.yaml:5
+    crits = [m.Wrapper.get_net(args) for m in crit_modules]
     tm = holycow.TrainingModule(E, G, D, crits, [], {})
-    # fine-tuning bootstrap (train.py:218-279): identity embedding e_hat -> generator parameter / discriminator row
-    e_hat = torch.randn(1, args.embed_channels, device=args.device) * 0.1
-    dd = {'embeds': e_hat}
-    tm.embedder.enable_finetuning()
-    tm.generator.enable_finetuning(dd)
-    tm.discriminator.enable_finetuning(dd)
-    tm.running_averages['generator'].enable_finetuning(dd)
-    tm.running_averages['embedder'].enable_finetuning()
+    if args.finetune:
+        # fine-tuning bootstrap (train.py:218-279): identity embedding e_hat -> generator parameter / discriminator row
+        e_hat = torch.randn(1, args.embed_channels, device=args.device) * 0.1
+        dd = {'embeds': e_hat}
+        tm.embedder.enable_finetuning()
+        tm.generator.enable_finetuning(dd)
+        tm.discriminator.enable_finetuning(dd)
+        tm.running_averages['generator'].enable_finetuning(dd)
+        tm.running_averages['embedder'].enable_finetuning()
     opt_G = holycow.get_optimizer(tm.embedder, tm.generator, args)
     opt_D = DW.get_optimizer(tm.discriminator, args)
     tm.train()
@@ -68,7 +75,8 @@ def build(args):
 
 def synthetic_batch(args, per_gpu_batch, seed):
     from dataloaders.synthetic_voxceleb2 import make_sample
-    datas, targets = zip(*[make_sample(i, args.image_size, 1, args.num_labels, True, seed) for i in range(per_gpu_batch)])
+    frames = 1 if args.finetune else args.n_frames_for_encoder
+    datas, targets = zip(*[make_sample(i, args.image_size, frames, args.num_labels, args.finetune, seed) for i in range(per_gpu_batch)])
     data = {k: torch.stack([d[k] for d in datas]).to(args.device) for k in datas[0]}
     target = {'real_segm': torch.stack([t['real_segm'] for t in targets]).to(args.device),
               'label': torch.tensor([t['label'] for t in targets], device=args.device)}
@@ -206,7 +214,9 @@ def main():
     ap.add_argument('--batch', type=int, default=8, help='per-GPU batch')
     ap.add_argument('--image_size', type=int, default=256)
     ap.add_argument('--prec', default=os.environ.get('LP_PREC', 'bf16x3'), choices=['bf16', 'bf16x3', 'f16'])
-    ap.add_argument('--workload', default='finetune_step', choices=['finetune_step', 'generator'])
+    ap.add_argument('--workload', default=None, choices=['finetune_step', 'metatrain_step', 'generator'],
+                    help='default: finetune_step at --gpus 1 (BASELINE configs[1]; the reference refuses multi-GPU fine-tuning), '
+                         'metatrain_step at --gpus > 1 (configs[2], default.yaml: the configuration that IS trained data-parallel)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eager', action='store_true', help='do not capture the step into hipGraphs')
     ap.add_argument('--shapes', default=None, help='write the per-shape conv / wgrad timing table of the instrumented steps (CSV)')
@@ -226,11 +236,14 @@ def main():
         dist.init_process_group(backend=a.backend, init_method='env://')
     assert world == a.gpus, f'--gpus {a.gpus} but WORLD_SIZE={world}'
 
-    args = make_args(a.image_size, a.batch, device, world, rank, a.prec)
+    if a.workload is None:
+        a.workload = 'finetune_step' if world == 1 else 'metatrain_step'
+    finetune = a.workload != 'metatrain_step'
+    args = make_args(a.image_size, a.batch, device, world, rank, a.prec, finetune=finetune)
     tm, opt_G, opt_D, holycow = build(args)
     if world > 1:
         from latent_pose_reenactment_amd.parallel import GradReducer
-        tm.reducer = GradReducer(tm, finetune=True, optimizer_G=opt_G, optimizer_D=opt_D)
+        tm.reducer = GradReducer(tm, finetune=finetune, optimizer_G=opt_G, optimizer_D=opt_D)
     data, target = synthetic_batch(args, a.batch, seed=123 + rank)
 
     from latent_pose_reenactment_amd import hipops
@@ -273,7 +286,7 @@ def main():
     # Graph replays cannot carry per-kernel events, so the instrumented steps run eagerly right after the timed region
     # (same process, same buffers, same kernels); they are not part of `value`.
     hipops.PROFILE = []
-    inst = eager_step if a.workload == 'finetune_step' else step
+    inst = eager_step if a.workload != 'generator' else step
     for _ in range(2):
         inst()
     torch.cuda.synchronize()
@@ -318,17 +331,20 @@ def main():
     if rank == 0:
         imgs = a.batch * world * a.steps
         out = {
-            'metric': 'train-step images/sec at 256x256 bs=8' if a.workload == 'finetune_step' else 'generator fwd+bwd images/sec at 256x256 bs=8',
+            'metric': 'train-step images/sec at 256x256 bs=8' if a.workload != 'generator' else 'generator fwd+bwd images/sec at 256x256 bs=8',
             'value': round(imgs / dt, 3), 'unit': 'images/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16x3 (hi+lo split bf16 MFMA operands, fp32 accumulate)' if a.prec == 'bf16x3' else 'bf16 (MFMA operands, fp32 accumulate)',
             'data': 'synthetic VoxCeleb2-shaped batch, random-init weights (VGG weights seeded He-normal)',
-            'config': {'workload': 'finetuning-base.yaml step (configs[1]): G, D, VGG19/VGGFace criterions, RAdam, EMA, spectral norm on '
-                                   'hand-written gfx950 kernels; MobileNetV2 pose encoder on torch-ROCm'
-                       if a.workload == 'finetune_step' else 'generator forward+backward only (HIP kernels)',
+            'config': {'workload': {'finetune_step': 'finetuning-base.yaml step (configs[1]): G, D, VGG19/VGGFace criterions, RAdam, EMA, spectral '
+                                                     'norm on hand-written gfx950 kernels; MobileNetV2 pose encoder on torch-ROCm',
+                                    'metatrain_step': 'default.yaml meta-training step (configs[2]): ResNeXt50 identity encoder over 8 frames + '
+                                                      'MobileNetV2 pose encoder (torch-ROCm), G, D with the 98000x512 label embedding, '
+                                                      'VGG19/VGGFace/featmat/adversarial/dis_embed/dice criterions, Adam, EMA (gfx950 kernels)',
+                                    'generator': 'generator forward+backward only (HIP kernels)'}[a.workload],
                        'image_size': a.image_size, 'per_gpu_batch': a.batch, 'global_batch': a.batch * world,
                        'parallelism': f'dp{world}', 'precision_mode': a.prec,
-                       'launch_mode': mode if a.workload == 'finetune_step' else 'eager'},
+                       'launch_mode': mode if a.workload != 'generator' else 'eager'},
             'roofline': roof,
         }
         out.update(extra)

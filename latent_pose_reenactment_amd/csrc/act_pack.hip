@@ -11,7 +11,7 @@
 // grid = (blocks, N): blockIdx.y = image; a thread walks the (pixel, 8-channel group) items of its image with a stride that is a
 // multiple of the group count G whenever G is a power of two, so its group -- and with it the AdaIN scale/shift of its 8 channels
 // -- is fixed and loaded once; 4 items are in flight per thread (8 x 16-B loads) to cover the HBM latency.
-#define AMAX_BLOCKS 256
+#define AMAX_BLOCKS 1024
 // amax -> power-of-two input scale of an fp16 gradient operand: s = 2^(13 - e) with amax = f * 2^e, f in [0.5, 1): the scaled
 // tensor's amax lands in [2^12, 2^13) -- 3 binades of headroom below the fp16 maximum, 26 binades of normal range below
 __device__ __forceinline__ void amax_to_scale(float m, float& s, float& inv) {
@@ -141,7 +141,13 @@ __global__ __launch_bounds__(256) void amax_partial_kernel(const float4* __restr
     __shared__ float sh[4];
     float m = 0.f;
     const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < total4; i += 4 * stride) {          // 4 independent 16-B loads in flight per thread
+        const float4 a = x[i], b = x[i + stride], c = x[i + 2 * stride], d = x[i + 3 * stride];
+        m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))), fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w)))));
+        m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(c.x), fabsf(c.y)), fmaxf(fabsf(c.z), fabsf(c.w))), fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(d.z), fabsf(d.w)))));
+    }
+    for (; i < total4; i += stride) {
         const float4 v = x[i];
         m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
     }

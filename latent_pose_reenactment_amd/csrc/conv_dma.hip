@@ -46,8 +46,8 @@ struct Conv16Params {
     int ksplit;
 };
 
-template <int KS, bool UPS, int WM, int WN, int MR, int NR, int PREC, bool PP>
-__global__ __launch_bounds__(WM * WN * 64 * (PP ? 2 : 1), (!PP && WM * WN == 4 && PREC != LP_PREC_BF16X3) ? 2 : 1)
+template <int KS, bool UPS, int WM, int WN, int MR, int NR, int PREC, bool PP, int NBUF = 2>
+__global__ __launch_bounds__(WM * WN * 64 * (PP ? 2 : 1), (!PP && NBUF == 2 && WM * WN == 4 && PREC != LP_PREC_BF16X3) ? 2 : 1)
 void conv_dma_kernel(Conv16Params p) {
     constexpr int CC = 32, ROWB = 64;                    // channels per chunk, bytes per halo pixel / weight row of a chunk
     constexpr bool SPLIT = (PREC == LP_PREC_BF16X3), F16 = (PREC == LP_PREC_F16);
@@ -58,7 +58,9 @@ void conv_dma_kernel(Conv16Params p) {
     constexpr int B_BUF = B_STAGE * (SPLIT ? 2 : 1);
     constexpr int NQ = B_STAGE / 1024;                   // DMA instructions per stage (hi)
     constexpr int AIT = (BM == 128) ? (NWAVE == 8 ? 3 : 5) : 6;     // max halo DMA instructions per wave (host checks p.hit <= AIT)
+    constexpr int NBW = ((NQ + NWD - 1) / NWD) * (SPLIT ? 2 : 1);     // weight DMA instructions one wave issues per stage
     static_assert(B_STAGE % 1024 == 0, "stage must be a whole number of 1 KiB DMA pieces");
+    static_assert(NBUF == 2 || (NBUF == 3 && !PP && NQ % NWD == 0), "3-deep weight ring: single group, uniform DMA count per wave");
     static_assert(!PP || (KS == 3 && NWAVE == 4), "ping-pong: two 4-wave groups, 3x3");
     static_assert(!(UPS && KS == 1), "1x1 convs commute with nearest upsampling: run them at low resolution");
 
@@ -240,19 +242,24 @@ void conv_dma_kernel(Conv16Params p) {
             }
         }
     } else {
-        // one group: top of stage s: own DMA landed, barrier (everyone finished stage s-1); issue the weights of stage s+1 and, in a
-        // chunk's first stage, the halo of the NEXT chunk into the other halo buffer (it has the whole chunk to land); multiply.
+        // one group: top of stage s: own DMA landed, barrier (everyone finished stage s-1); issue the weights of stage s+NBUF-1 and, in
+        // a chunk's first stage, the halo of the NEXT chunk into the other halo buffer (it has the whole chunk to land); multiply.
+        // NBUF == 3 (grids of <= 1 workgroup per CU, where nothing else hides the L2/HBM latency of a stage's weights): the DMA of
+        // stage s+1 stays in flight across the barrier -- only what stage s needs (everything older, in issue order) is waited for.
         int abuf = 0;
+        if (NBUF == 3 && S > 1) issue_b(cbeg + 1 / KS, 1 % KS, 1);
         for (int chunk = 0; chunk < nch; ++chunk) {
             const bool has_next = chunk + 1 < nch;
 #pragma unroll
             for (int ky = 0; ky < KS; ++ky) {
                 const int s = chunk * KS + ky;
-                lp_wait_vm0();
+                if (NBUF == 3 && s + 1 < S) lp_wait_vm<NBW>(); else lp_wait_vm0();
                 __syncthreads();
-                if (s + 1 < S) issue_b(cbeg + (s + 1) / KS, (s + 1) % KS, (s + 1) & 1);
+                // (halo first: it is older than the weights issued below, so the counted wait of the next stage covers it)
                 if (p.a_dbuf && ky == 0 && has_next) issue_a(cbeg + chunk + 1, H_base + (abuf ^ 1) * a_buf);
-                compute(ky, H_base + abuf * a_buf, s & 1);
+                const int sp = s + NBUF - 1;
+                if (sp < S) issue_b(cbeg + sp / KS, sp % KS, sp % NBUF);
+                compute(ky, H_base + abuf * a_buf, s % NBUF);
                 if (!p.a_dbuf && ky == KS - 1 && has_next) {      // (LDS-tight tiles) one halo buffer: restage it once everyone has read it
                     __syncthreads();
                     issue_a(cbeg + chunk + 1, H_base);
@@ -378,9 +385,9 @@ static void choose_tile(int BM, int N, int H, int W, int* lTH, int* lTW, int* lN
     *lTH = lth; *lTW = ltw; *lNB = lnb;
 }
 
-template <int KS, bool UPS, int WM, int WN, int MR, int NR, int PREC, bool PP>
+template <int KS, bool UPS, int WM, int WN, int MR, int NR, int PREC, bool PP, int NBUF = 2>
 static int launch_v(Conv16Params& p, size_t lds, dim3 grid, hipStream_t stream) {
-    auto kern = conv_dma_kernel<KS, UPS, WM, WN, MR, NR, PREC, PP>;
+    auto kern = conv_dma_kernel<KS, UPS, WM, WN, MR, NR, PREC, PP, NBUF>;
     static thread_local int attr_dev = -1;                 // per host thread and device (main and autograd threads both launch)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return lp_set_error(LP_ERR_HIP, "hipGetDevice failed");
@@ -416,7 +423,8 @@ static int launch_conv16(Conv16Params& p, hipStream_t stream) {
     if (p.hit > AIT) return lp_set_error(LP_ERR_UNSUPPORTED, "conv16: halo exceeds the DMA descriptor budget");
     const size_t a_buf = (size_t)p.hit * NWAVE * 1024 * (SPLIT ? 2 : 1);
     p.a_dbuf = (2 * a_buf + 2 * B_BUF <= LDS_MAX) ? 1 : 0;
-    size_t lds = (p.a_dbuf ? 2 : 1) * a_buf + 2 * B_BUF;
+    const size_t lds_halo = (p.a_dbuf ? 2 : 1) * a_buf;
+    size_t lds = lds_halo + 2 * B_BUF;
     size_t epi = (size_t)NWAVE * (MR * 16) * (NR * 16 + 4) * sizeof(float);       // LDS transpose of the coalesced epilogue
     const int tiles = p.tiles_x * p.tiles_y * ((p.N + NBv - 1) / NBv);
     // ping-pong: two adjacent M tiles per workgroup, when the paired grid still covers the CUs.  LP_CONV_PP = 0 | 1 overrides.
@@ -430,9 +438,10 @@ static int launch_conv16(Conv16Params& p, hipStream_t stream) {
     dim3 grid(pp ? (tiles + 1) / 2 : tiles, (p.Cout + BN - 1) / BN);
     {   // split-K when the output tiling alone cannot fill the 256 CUs (4x4 ... 32x32 layers with K = 9*512)
         static const int max_split = getenv("LP_CONV_KSPLIT") ? atoi(getenv("LP_CONV_KSPLIT")) : 8;
+        static const int split_wgs = getenv("LP_CONV_SPLIT_WGS") ? atoi(getenv("LP_CONV_SPLIT_WGS")) : 256;   // split while <= this many workgroups result
         const int wgs = grid.x * grid.y, nch = p.CinP / 32;
         int ks = 1;
-        while (ks < max_split && wgs * ks * 2 <= 256 && nch / (ks * 2) >= 2) ks *= 2;
+        while (ks < max_split && wgs * ks * 2 <= split_wgs && nch / (ks * 2) >= 2) ks *= 2;
         p.ksplit = ks;
         grid.z = ks;
         if (ks > 1) { p.o_hi = nullptr; p.o_lo = nullptr; }      // partial sums: lp_conv16_fwd packs the finished y instead
@@ -440,6 +449,16 @@ static int launch_conv16(Conv16Params& p, hipStream_t stream) {
             return lp_set_error(LP_ERR_HIP, "hipMemsetAsync failed");
     }
     if constexpr (pp_ok) { if (pp) return launch_v<KS, UPS, WM, WN, MR, NR, PREC, true>(p, lds, grid, stream); }
+    // 3-deep weight ring when the grid gives each CU at most ~one workgroup (its LDS would exclude a second one anyway) and it fits
+    constexpr int NQ = KS * BN * 64 / 1024;
+    constexpr bool ring_ok = (NQ % NWAVE == 0);
+    static const int nbuf_env = getenv("LP_CONV_NBUF") ? atoi(getenv("LP_CONV_NBUF")) : 0;      // 2 | 3 forces
+    if constexpr (ring_ok) {
+        const size_t lds3 = lds_halo + 3 * B_BUF;
+        const long long total_wgs = (long long)grid.x * grid.y * grid.z;
+        const bool ring = (nbuf_env ? nbuf_env == 3 : total_wgs <= 320) && lds3 <= LDS_MAX;
+        if (ring) return launch_v<KS, UPS, WM, WN, MR, NR, PREC, false, 3>(p, lds3 > epi ? lds3 : epi, grid, stream);
+    }
     return launch_v<KS, UPS, WM, WN, MR, NR, PREC, false>(p, lds, grid, stream);
 }
 

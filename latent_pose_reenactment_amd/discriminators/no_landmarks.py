@@ -15,7 +15,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from latent_pose_reenactment_amd import hipops as ops
-from latent_pose_reenactment_amd.nn import (SNWeight, SNBatch, SNLinearFn, _Indexed, SN_EPS_CONV, SN_EPS_DEFAULT, AvgPool2Fn,
+from latent_pose_reenactment_amd.nn import (SNWeight, SNBatch, SNLinearFn, SNEmbeddingFn, _Indexed, SN_EPS_CONV, SN_EPS_DEFAULT, AvgPool2Fn,
                                             as_nchw_view, default_prec, hip_conv, to_nhwc)
 from latent_pose_reenactment_amd.utils import radam as _radam
 
@@ -186,7 +186,16 @@ class Discriminator(nn.Module):
         if real.dim() > 4:
             real = real[:, 0]
         self.__dict__['_step_packs'] = self._fresh_packs()   # new step: the optimizer has changed W_orig since the last forward
-        embed = F.embedding(label, self.embed.effective_weight())
+        # label embedding: power iteration on the (98000 x 512 | 1 x 512) matrix by the batched SN kernels, then a row gather scaled
+        # by 1/sigma -- W/sigma is never materialised and the backward is row-sparse + rank-1 (SNEmbeddingFn)
+        if not label.is_cuda:
+            raise RuntimeError('the discriminator runs on the MI355X HIP path only (no CPU fallback)')
+        esn = self.__dict__.get('_embed_sn')
+        if esn is None or esn.layers[0] is not self.embed:
+            esn = SNBatch([self.embed])
+            self.__dict__['_embed_sn'] = esn
+        eu, ev, esig = esn.update(self.training)[0]
+        embed = SNEmbeddingFn.apply(label, self.embed.weight_orig, eu, ev, esig, self.__dict__.setdefault('_embed_parts', {}))
         # Pass 1 feeds only generator-side losses; the gradients it would deposit on the discriminator's parameters are erased
         # by optimizer_D.zero_grad() before loss_D.backward (runners/holycow.py:246-248) and no optimizer reads them, so they
         # are not computed unless ``keep_reference_waste`` asks for the reference's exact .grad side effects (parity tests).

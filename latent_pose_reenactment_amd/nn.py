@@ -184,6 +184,38 @@ class SNLinearFn(torch.autograd.Function):
         return dx, dw, db, None, None, None
 
 
+class SNEmbeddingFn(torch.autograd.Function):
+    """rows = W_orig[label] / sigma of the spectrally normalised label embedding (discriminators/no_landmarks.py:84-86,152), sigma
+    from SNBatch (lp_sn_power_iter): neither W/sigma (98000 x 512 = 200 MB per step in the reference) nor F.embedding's dense
+    backward is materialised.  Gradient w.r.t. W_orig (legacy-hook rule, u and v constant):
+        G/sigma - (<G, W_orig>/sigma^2) u v^T,   G = scatter of d_rows at ``label``  (B non-zero rows)
+    i.e. B sparse rows plus ONE dense rank-1 term with a scalar coefficient.  With fused accumulation both parts are added straight
+    into the parameter's ``.grad`` (a rank-1 GEMM update and an index_add).  ``holder['parts']`` receives (label, rows of G/sigma,
+    coefficient, u, v): all a data-parallel peer needs to rebuild this rank's gradient -- parallel.GradReducer exchanges those
+    B x 513 + 1 numbers instead of all-reducing the dense 200 MB gradient."""
+
+    @staticmethod
+    def forward(ctx, label, w, u, v, sig, holder):
+        ctx.save_for_backward(label, w, u, v, sig)
+        ctx.holder = holder
+        ctx.w_param = w if (w.requires_grad and w.is_leaf) else None
+        return w.detach().index_select(0, label) * sig[1]
+
+    @staticmethod
+    def backward(ctx, d_rows):
+        label, w, u, v, sig = ctx.saved_tensors
+        alpha = sig[1]
+        g_rows = d_rows * alpha
+        coef = (d_rows * w.detach().index_select(0, label)).sum() * (alpha * alpha)
+        if ctx.holder is not None:
+            ctx.holder['parts'] = (label, g_rows, coef, u, v)
+        target = None if ctx.w_param is None else _accum_target(ctx.w_param)
+        out = target if target is not None else torch.zeros_like(w)
+        out.addmm_((u * (-coef))[:, None], v[None, :])        # dense rank-1 term: one read + one write of the gradient
+        out.index_add_(0, label, g_rows)
+        return None, (None if target is not None else out), None, None, None, None
+
+
 class _Indexed(nn.Module):
     """Container whose children are named by explicit integer positions (mirrors the sparse indices that
     nn.Sequential gives parameter-less layers in the reference: e.g. ``block.3`` / ``block.7``)."""
@@ -517,8 +549,11 @@ class Generator(nn.Module):
             for j, i in enumerate(conv_idx):
                 packs[i], packsT[i] = allp[j], allp[len(conv_idx) + j]
         if not need_grad and not self.training:
-            # inference (drive.py): the weights do not change between frames -> pack them to bf16 once
-            key = (self.prec,) + tuple((w.data_ptr(), w._version) for w in weights)
+            # inference (drive.py): the weights do not change between frames -> pack them to 16 bit once.  The key also carries the
+            # generation counter of the fused optimizer / EMA kernels: those update weights through raw pointers without bumping
+            # ``_version`` (a graph replay bumps neither: GraphedTrainStep.__call__ advances the counter itself).
+            from .optim import WEIGHTS_GENERATION
+            key = (self.prec, WEIGHTS_GENERATION[0]) + tuple((w.data_ptr(), w._version) for w in weights)
             cache = self.__dict__.get('_pack_cache')
             if cache is None or cache[0] != key:
                 cache = (key, [ops.pack_weights(w.detach().contiguous(), 0, self.prec) if s_ is not None else None

@@ -13,6 +13,11 @@ from . import _lib
 from ._lib import check
 
 
+# Bumped by every in-place weight update that bypasses autograd's version counters (the fused optimizer / EMA kernels write through
+# raw pointers): caches of derived data (the generator's inference weight packs) key on it.
+WEIGHTS_GENERATION = [0]
+
+
 def _build_table(entries, device):
     """entries: list of (p, g, m, v) tensors (m/v may be None) -> (device uint8 tensor with the packed MtDesc array, max numel)"""
     assert _lib.lib().lp_mt_desc_bytes() == 40
@@ -98,6 +103,7 @@ class _FusedBase(Optimizer):
             b1, b2 = group['betas']
             check(_lib.lib().lp_mt_optimizer_step(table.data_ptr(), n, max_n, step.data_ptr(), self.KIND, group['lr'], b1, b2,
                                                   group['eps'], torch.cuda.current_stream().cuda_stream), 'lp_mt_optimizer_step')
+        WEIGHTS_GENERATION[0] += 1
         return loss
 
     def state_dict(self):
@@ -145,6 +151,7 @@ class FusedEMA:
     @torch.no_grad()
     def update(self, alpha: float):
         st = torch.cuda.current_stream().cuda_stream
+        WEIGHTS_GENERATION[0] += 1
         check(_lib.lib().lp_mt_ema(self.ptable.data_ptr(), self.np, self.pmax, alpha, 0, st), 'lp_mt_ema')
         if self.btable is not None:
             check(_lib.lib().lp_mt_ema(self.btable.data_ptr(), self.nb, self.bmax, 0.0, 1, st), 'lp_mt_ema')

@@ -159,7 +159,12 @@ class TrainingModule(nn.Module):
 
 
 def train_step(training_module, data_dict, target_dict, optimizer_G, optimizer_D, args):
-    """one iteration of the hot loop (holycow.py:230-257); returns (all_data_dict, losses_G, losses_D)"""
+    """one iteration of the hot loop (holycow.py:230-257); returns (all_data_dict, losses_G, losses_D).
+
+    Data parallel (1 < num_gpus <= 8): the generator-side all-reduce is issued asynchronously right after loss_G.backward and
+    overlaps zero_grad(D) + loss_D.backward; optimizer_G.step waits for it.  Moving optimizer_G.step behind loss_D.backward is
+    result-identical: loss_D depends on fake.detach() and on tensors the discriminator saved in the forward pass, never on the
+    generator's parameters or gradients (the reference reduces, steps G, then runs the D backward, holycow.py:239-250)."""
     all_data, losses_G, losses_D = training_module(data_dict, target_dict)
     loss_G = sum(v for v in losses_G.values() if isinstance(v, torch.Tensor))
     loss_D = sum(v for v in losses_D.values() if isinstance(v, torch.Tensor))
@@ -169,17 +174,51 @@ def train_step(training_module, data_dict, target_dict, optimizer_G, optimizer_D
     with fused_grad_accumulation():
         loss_G.backward(retain_graph=True)
     if multi:
-        reducer.reduce_generator_side()
-    optimizer_G.step()
+        reducer.reduce_generator_side(async_op=True)
+    else:
+        optimizer_G.step()
     if losses_D:
         optimizer_D.zero_grad()
         with fused_grad_accumulation():
             loss_D.backward()
+    if multi:
+        reducer.wait_generator_side()
+        optimizer_G.step()
+    if losses_D:
         if multi:
             reducer.reduce_discriminator_side()
         optimizer_D.step()
     training_module.update_running_average(0.972 if args.finetune else 0.999)
     return all_data, losses_G, losses_D
+
+
+GRAPH_WARMUP_ITERATIONS = 3      # eager iterations before the step is captured (lazy state: optimizer moments, packs, MIOpen plans)
+
+
+def _graphed_step(training_module, data_dict, target_dict, optimizer_G, optimizer_D, args):
+    """``--hip_graph``: the first GRAPH_WARMUP_ITERATIONS iterations run eagerly (on the capture stream), then the step is captured
+    once (capturing executes nothing) and every further iteration copies its batch into the static input buffers and replays the
+    graphs -- the same sequence of optimizer steps as the eager loop.  A change of batch shape or of the optimizers re-captures."""
+    st = training_module.__dict__.setdefault('_graph_state', {'eager_done': 0, 'step': None, 'key': None, 'stream': torch.cuda.Stream()})
+    key = (id(optimizer_G), id(optimizer_D), training_module.training,
+           tuple((k, tuple(v.shape)) for k, v in sorted(data_dict.items()) if torch.is_tensor(v)),
+           tuple((k, tuple(v.shape)) for k, v in sorted(target_dict.items()) if torch.is_tensor(v)))
+    if st['key'] != key:
+        st.update(eager_done=0, step=None, key=key)
+    if st['step'] is None and st['eager_done'] < GRAPH_WARMUP_ITERATIONS:
+        st['stream'].wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st['stream']):
+            out = train_step(training_module, data_dict, target_dict, optimizer_G, optimizer_D, args)
+        torch.cuda.current_stream().wait_stream(st['stream'])
+        st['eager_done'] += 1
+        return out
+    if st['step'] is None:
+        st['step'] = GraphedTrainStep(training_module, optimizer_G, optimizer_D, args, data_dict, target_dict, warmup_steps=0,
+                                      stream=st['stream'])
+    g = st['step']
+    g.load_batch(data_dict, target_dict)
+    g()
+    return g.all_data, g.losses_G, g.losses_D
 
 
 def run_epoch(dataloader, training_module, optimizer_G, optimizer_D, epoch, args, phase, writer=None, saver=None):
@@ -188,22 +227,31 @@ def run_epoch(dataloader, training_module, optimizer_G, optimizer_D, epoch, args
         optimizer_G.zero_grad()
         if optimizer_D:
             optimizer_D.zero_grad()
+    use_graph = phase == 'train' and getattr(args, 'hip_graph', False) and str(args.device).startswith('cuda')
+    log_every = max(1, int(getattr(args, 'log_frequency_loss', 1)))
     end = time.time()
     for it, (data_dict, target_dict) in enumerate(dataloader):
         meter.add('Data_time', time.time() - end)
         dict_to_device(data_dict, args.device)
         dict_to_device(target_dict, args.device)
-        if phase == 'train':
+        if use_graph:
+            all_data, losses_G, losses_D = _graphed_step(training_module, data_dict, target_dict, optimizer_G, optimizer_D, args)
+        elif phase == 'train':
             all_data, losses_G, losses_D = train_step(training_module, data_dict, target_dict, optimizer_G, optimizer_D, args)
         else:
             all_data, losses_G, losses_D = training_module(data_dict, target_dict)
             if saver is not None:
                 saver.save(epoch=epoch, data=all_data)
-        if args.detailed_metrics:
+        # loss read-back = device->host sync, every iteration in the reference (holycow.py:260-262); with graph replay it is the
+        # only sync of the loop, so it honours --log_frequency_loss there
+        if args.detailed_metrics and (not use_graph or it % log_every == 0):
             for name, value in itertools.chain(losses_G.items(), losses_D.items()):
-                meter.add(f'Loss_{name}', float(value))      # device->host sync, as in the reference (holycow.py:260-262)
-        if writer is not None and phase == 'train':
-            args.iteration += 1                              # the reference counts iterations only on the logging rank
+                meter.add(f'Loss_{name}', float(value))
+        if phase == 'train':
+            # The reference advances args.iteration inside its TensorBoard branch, i.e. on the logging rank only (holycow.py:319,
+            # 389-390) -- the rank that also names the checkpoints model_{iteration:08}.pth.  Logging is out of scope here, so the
+            # counter advances on every rank and every training iteration: same checkpoint names as a logging reference run.
+            args.iteration += 1
         meter.add('Batch_time', time.time() - end)
         end = time.time()
     return meter
@@ -213,50 +261,70 @@ class GraphedTrainStep:
     """The training iteration of ``train_step`` captured into hipGraphs (MI355X: thousands of short launches per step make the
     eager loop host-bound; replaying graphs removes the per-launch CPU cost -- "HIP graphs instead of a tracing compiler").
 
-    Three graphs share one memory pool and are replayed in order; the data-parallel all-reduces run eagerly BETWEEN them
-    (collectives are never captured):
+    The graphs share one memory pool and are replayed in order; the data-parallel all-reduces run eagerly BETWEEN them
+    (collectives are never captured).  One GPU:
         g1: forward (E, G, D x3, criterions) + zero_grad(G) + loss_G.backward
-        --  all-reduce of the generator-side gradients (N > 1)
         g2: optimizer_G.step + zero_grad(D) + loss_D.backward
-        --  all-reduce of the discriminator gradients (N > 1)
         g3: optimizer_D.step + EMA
-    Same arithmetic and ordering as the eager step (holycow.py:235-257).  Inputs are static buffers: ``load_batch`` copies a
-    new batch into them.  Needs the fused (device-step-counter) optimizers; loss values live in ``losses_G`` / ``losses_D``."""
+    Data parallel (the step is re-cut so that the generator-side exchange hides behind the discriminator backward):
+        g1:  as above
+        --   all-reduce of the generator-side gradient arena, ASYNCHRONOUS on RCCL's stream
+        g2a: zero_grad(D) + loss_D.backward                    (runs concurrently with that all-reduce)
+        --   wait for the all-reduce
+        g2b: optimizer_G.step
+        --   discriminator-side exchange (arena all-reduce + row-sparse label-embedding exchange)
+        g3:  optimizer_D.step + EMA
+    Same arithmetic as the eager step (see ``train_step``).  Inputs are static buffers: ``load_batch`` copies a new batch into
+    them.  Needs the fused (device-step-counter) optimizers; loss values live in ``losses_G`` / ``losses_D``."""
 
-    def __init__(self, training_module, optimizer_G, optimizer_D, args, data_dict, target_dict, warmup_steps=3):
+    def __init__(self, training_module, optimizer_G, optimizer_D, args, data_dict, target_dict, warmup_steps=3, stream=None):
+        """``warmup_steps`` eager steps on the given batch precede the capture (they ARE optimizer steps: callers that must keep
+        the eager trajectory pass 0 and warm up with their own real iterations on ``stream``, see ``_graphed_step``)."""
         self.tm, self.opt_G, self.opt_D, self.args = training_module, optimizer_G, optimizer_D, args
         self.data = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in data_dict.items()}
         self.target = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in target_dict.items()}
         self.reducer = getattr(training_module, 'reducer', None) if 1 < args.num_gpus <= 8 else None
         self.alpha = 0.972 if args.finetune else 0.999
-        side = torch.cuda.Stream()
+        side = stream if stream is not None else torch.cuda.Stream()
+        self.stream = side
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                # eager warm-up: lazy state (optimizer moments, packs, MIOpen plans)
             for _ in range(warmup_steps):
                 train_step(self.tm, self.data, self.target, self.opt_G, self.opt_D, args)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self.g1, self.g2, self.g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        G = torch.cuda.CUDAGraph
+        kw = dict(stream=side, capture_error_mode='thread_local')
         # capture on the stream the warm-up ran on: the AccumulateGrad nodes autograd keeps per parameter stay on one stream
         # thread_local error mode: CUDA calls of OTHER threads (the RCCL watchdog polling its events) must not invalidate the capture
-        with torch.cuda.graph(self.g1, stream=side, capture_error_mode='thread_local'):
-            _, self.losses_G, self.losses_D = self.tm(self.data, self.target)
+        self.g1 = G()
+        with torch.cuda.graph(self.g1, **kw):
+            self.all_data, self.losses_G, self.losses_D = self.tm(self.data, self.target)
             loss_G = sum(v for v in self.losses_G.values() if isinstance(v, torch.Tensor))
             loss_D = sum(v for v in self.losses_D.values() if isinstance(v, torch.Tensor))
             self.opt_G.zero_grad()
             with fused_grad_accumulation():
                 loss_G.backward(retain_graph=True)
         pool = self.g1.pool()
-        if self.reducer is not None:
+        if self.reducer is None:
+            self.g2 = G()
+            with torch.cuda.graph(self.g2, pool=pool, **kw):
+                self.opt_G.step()
+                self.opt_D.zero_grad()
+                with fused_grad_accumulation():
+                    loss_D.backward()
+        else:
             self.reducer.reduce_generator_side()
-        with torch.cuda.graph(self.g2, pool=pool, stream=side, capture_error_mode='thread_local'):
-            self.opt_G.step()
-            self.opt_D.zero_grad()
-            with fused_grad_accumulation():
-                loss_D.backward()
-        if self.reducer is not None:
+            self.g2a, self.g2b = G(), G()
+            with torch.cuda.graph(self.g2a, pool=pool, **kw):
+                self.opt_D.zero_grad()
+                with fused_grad_accumulation():
+                    loss_D.backward()
+            with torch.cuda.graph(self.g2b, pool=pool, **kw):
+                self.opt_G.step()
             self.reducer.reduce_discriminator_side()
-        with torch.cuda.graph(self.g3, pool=pool, stream=side, capture_error_mode='thread_local'):
+        self.g3 = G()
+        with torch.cuda.graph(self.g3, pool=pool, **kw):
             self.opt_D.step()
             self.tm.update_running_average(self.alpha)
         del loss_G, loss_D
@@ -269,10 +337,15 @@ class GraphedTrainStep:
                     dst[k].copy_(v, non_blocking=True)
 
     def __call__(self):
+        from latent_pose_reenactment_amd.optim import WEIGHTS_GENERATION
+        WEIGHTS_GENERATION[0] += 1          # replays update weights without touching any Python-side counter
         self.g1.replay()
-        if self.reducer is not None:
-            self.reducer.reduce_generator_side()
-        self.g2.replay()
-        if self.reducer is not None:
+        if self.reducer is None:
+            self.g2.replay()
+        else:
+            self.reducer.reduce_generator_side(async_op=True)
+            self.g2a.replay()
+            self.reducer.wait_generator_side()
+            self.g2b.replay()
             self.reducer.reduce_discriminator_side()
         self.g3.replay()

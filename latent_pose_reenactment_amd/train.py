@@ -132,10 +132,15 @@ def main():
         signal.signal(signal.SIGINT, save_and_exit)
         signal.signal(signal.SIGTERM, save_and_exit)
 
-    if 1 < args.num_gpus <= 8:
-        from latent_pose_reenactment_amd.parallel import GradReducer
-        training_module.reducer = GradReducer(training_module, finetune=args.finetune)      # (re-created below when the optimizers change)
-        training_module.__dict__['module'] = training_module
+    def attach_reducer(broadcast):
+        """data-parallel gradient exchange over the optimizers' flat gradient arenas (in place, no gather/scatter); must be rebuilt
+        whenever the optimizers are (their arenas are what gets all-reduced)"""
+        if 1 < args.num_gpus <= 8:
+            from latent_pose_reenactment_amd.parallel import GradReducer
+            training_module.reducer = GradReducer(training_module, finetune=args.finetune, broadcast=broadcast,
+                                                  optimizer_G=optimizer_G, optimizer_D=optimizer_D)
+            training_module.__dict__['module'] = training_module
+    attach_reducer(broadcast=True)
 
     if args.finetune:
         # fine-tuning bootstrap (train.py:218-279): average identity embedding over all frames of the person
@@ -161,6 +166,7 @@ def main():
             training_module.initialize_running_averages(None)
         optimizer_G = runner.get_optimizer(training_module.embedder, training_module.generator, args)
         optimizer_D = m['discriminator'].get_optimizer(discriminator, args)
+        attach_reducer(broadcast=False)
 
     logger.info("Entering training loop")
     for epoch in range(args.num_epochs):

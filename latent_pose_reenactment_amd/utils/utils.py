@@ -182,7 +182,13 @@ def save_model(training_module, optimizer_G, optimizer_D, args):
         torch.save(save_dict, path, pickle_protocol=-1)
         log.info(f"Saved checkpoint {path}")
         return path
-    except (RuntimeError, OSError) as err:       # disk full: do not leave a truncated file behind
+    except (RuntimeError, OSError) as err:
+        # the reference's guard (utils/utils.py:286-295) is for a full disk: do not leave a truncated file behind.  Anything else
+        # (bad path, name too long, permissions) is a bug of the caller and must surface.
+        import errno
+        disk_full = isinstance(err, RuntimeError) or getattr(err, 'errno', None) in (errno.ENOSPC, errno.EDQUOT)
+        if not disk_full:
+            raise
         log.error(f"Could not write to {path}: {err}; removing that file")
         try:
             os.remove(path)

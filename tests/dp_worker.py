@@ -1,0 +1,91 @@
+"""Worker of tests/test_data_parallel_gpu.py: one rank of a `gloo` group whose ranks share the single GPU of the test box (RCCL
+refuses two ranks on one device; the collectives' semantics are the same).  Builds the small meta-training modules with identical
+seeds on every rank, takes its slice of the global batch, runs the REAL train step (runners.holycow.train_step or the re-cut
+GraphedTrainStep) with parallel.GradReducer, and -- rank 0 -- saves the gradient arenas / updated weights."""
+import argparse
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'latent_pose_reenactment_amd'))
+
+
+def small_args(world, rank, num_labels):
+    return argparse.Namespace(image_size=32, num_channels=4, max_num_channels=16, embed_channels=8, pose_embedding_size=4, in_channels=3,
+                              out_channels=3, num_labels=num_labels, dis_num_blocks=5, gen_padding='zero', norm_layer='in',
+                              gen_constant_input_size=4, gen_num_residual_blocks=2, dis_padding='zero', device='cuda', optimizer='Adam',
+                              lr_gen=5e-5, lr_dis=2e-4, beta1=0.0, finetune=False, num_gpus=world, world_size=world, rank=rank,
+                              average_function='sum', dis_embed_weight=1e-2)
+
+
+def build(a, seed=7):
+    from generators.vector_pose_unsupervised_segmentation_noBottleneck import Wrapper as GW
+    from embedders.unsupervised_pose_separate_embResNeXt_segmentation import Wrapper as EW
+    from discriminators.no_landmarks import Wrapper as DW
+    from criterions import adversarial, featmat, dis_embed
+    from runners import holycow
+    torch.manual_seed(seed)
+    D, G, E = DW.get_net(a), GW.get_net(a), EW.get_net(a)
+    with torch.no_grad():
+        G.constant.constant.normal_()
+    # mean-type losses only: dice is a ratio of batch sums (rank-local in the reference too), so it has no global-batch equivalent
+    crits = [adversarial.Criterion('gan'), featmat.Criterion(10.0), dis_embed.Criterion(1e-2)]
+    tm = holycow.TrainingModule(E, G, D, crits, [], {})
+    opt_G = holycow.get_optimizer(tm.embedder, tm.generator, a)
+    opt_D = DW.get_optimizer(tm.discriminator, a)
+    tm.train()
+    tm.embedder.eval()           # BatchNorm on running statistics, no dropout: every sample independent of its batch (and of the RNG)
+    return tm, opt_G, opt_D, holycow
+
+
+def global_batch(total, num_labels, seed=11):
+    g = torch.Generator().manual_seed(seed)
+    data = {'enc_rgbs': torch.rand(total, 2, 3, 32, 32, generator=g), 'pose_input_rgbs': torch.rand(total, 1, 3, 32, 32, generator=g),
+            'target_rgbs': torch.rand(total, 1, 3, 32, 32, generator=g)}
+    target = {'real_segm': torch.rand(total, 1, 1, 32, 32, generator=g).expand(total, 1, 3, 32, 32).contiguous(),
+              'label': torch.randint(0, num_labels, (total,), generator=g)}
+    return data, target
+
+
+def run(world, rank, mode, total, num_labels, steps, out_path):
+    a = small_args(world, rank, num_labels)
+    tm, opt_G, opt_D, holycow = build(a)
+    if world > 1:
+        from latent_pose_reenactment_amd.parallel import GradReducer
+        tm.reducer = GradReducer(tm, finetune=False, optimizer_G=opt_G, optimizer_D=opt_D)
+    data, target = global_batch(total, num_labels)
+    per = total // world
+    sl = slice(rank * per, (rank + 1) * per)
+    data = {k: v[sl].cuda() for k, v in data.items()}
+    target = {k: v[sl].cuda() for k, v in target.items()}
+    if mode == 'graph':
+        # first step eager (lazy state -- optimizer moments, weight packs, MIOpen plans -- must exist before a capture: state created
+        # INSIDE a capture would be re-initialised by every replay), then the captured step replayed for the rest
+        holycow.train_step(tm, data, target, opt_G, opt_D, a)
+        step = holycow.GraphedTrainStep(tm, opt_G, opt_D, a, data, target, warmup_steps=0)
+        for _ in range(steps - 1):
+            step()
+    else:
+        for _ in range(steps):
+            holycow.train_step(tm, data, target, opt_G, opt_D, a)
+    torch.cuda.synchronize()
+    if rank == 0:
+        torch.save({'gradG': opt_G.ensure_flat(0).cpu(), 'gradD': opt_D.ensure_flat(0).cpu(),
+                    'G': {k: v.cpu() for k, v in tm.generator.state_dict().items()},
+                    'D': {k: v.cpu() for k, v in tm.discriminator.state_dict().items()}}, out_path)
+
+
+if __name__ == '__main__':
+    mode, total, num_labels, steps, out_path = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+    world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
+    torch.cuda.set_device(0)
+    if world > 1:
+        dist.init_process_group(backend='gloo', init_method='env://')
+    run(world, rank, mode, total, num_labels, steps, out_path)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()

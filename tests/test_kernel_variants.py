@@ -14,6 +14,8 @@ VARIANTS = [
     {'LP_CONV_PP': '0'},                        # single-group schedule everywhere
     {'LP_CONV_W8': '1'},                        # 8-wave workgroups for every shape
     {'LP_CONV_W8': '0', 'LP_CONV_KSPLIT': '1'},  # no split-K, 4-wave tiles only
+    {'LP_CONV_NBUF': '3'},                      # 3-deep weight ring wherever it fits (default: only for grids of <= ~1 workgroup per CU)
+    {'LP_CONV_NBUF': '2', 'LP_CONV_SPLIT_WGS': '512'},   # no ring; deeper split-K
     {'LP_WGRAD_COB': '64'},                     # 64-output-channel wgrad workgroups only
     {'LP_THIN': '0'},                           # thin-channel layers through the MFMA kernels (3- / 4-channel operand planes)
 ]
