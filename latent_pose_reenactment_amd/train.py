@@ -172,7 +172,10 @@ def main():
     for epoch in range(args.num_epochs):
         training_module.train(not args.set_eval_mode_in_train)
         torch.set_grad_enabled(True)
-        runner.run_epoch(dataloader_train, training_module, optimizer_G, optimizer_D, epoch, args, phase='train')
+        meter = runner.run_epoch(dataloader_train, training_module, optimizer_G, optimizer_D, epoch, args, phase='train')
+        if args.rank == 0 and meter is not None:
+            logger.info(f"Epoch {epoch} (iteration {args.iteration}): " +
+                        ", ".join(f"{k} {meter.get_last(k):.6g} (avg {meter.get_average(k):.6g})" for k in sorted(meter.keys())))
         if not args.skip_eval:
             raise NotImplementedError("NYI: validation")
         if args.rank == 0:

@@ -4,6 +4,7 @@ synthetic dataloader, eager and with ``--hip_graph``: the graph-replayed run_epo
 iteration counter must advance (checkpoint names model_{iteration:08}.pth), and a stale weight-pack cache must not survive an
 optimizer step."""
 import os
+import re
 import subprocess
 import sys
 
@@ -16,10 +17,11 @@ pytestmark = pytest.mark.gpu
 
 COMMON = ['--generator', 'vector_pose_unsupervised_segmentation_noBottleneck', '--embedder', 'unsupervised_pose_separate_embResNeXt_segmentation',
           '--discriminator', 'no_landmarks', '--criterions', 'adversarial,featmat,dis_embed,dice', '--runner', 'holycow',
-          '--dataloader', 'synthetic_voxceleb2', '--image_size', '32', '--num_channels', '4', '--max_num_channels', '16',
+          '--dataloader', 'synthetic_voxceleb2', '--image_size', '64', '--num_channels', '4', '--max_num_channels', '16',
           '--embed_channels', '8', '--pose_embedding_size', '4', '--num_labels', '50', '--dis_num_blocks', '5', '--batch_size', '2',
-          '--synthetic_dataset_len', '16', '--n_frames_for_encoder', '2', '--num_epochs', '1', '--num_gpus', '1',
-          '--set_eval_mode_in_train', '--log_frequency_loss', '4']      # eval mode: no dropout / batch statistics -> bit-comparable runs
+          '--synthetic_dataset_len', '16', '--n_frames_for_encoder', '2', '--num_epochs', '1', '--num_gpus', '1']
+# (train mode: spectral-norm power iterations, BatchNorm batch statistics and the pose encoder's dropout are live; torch's graph-safe
+#  Philox generator hands a replayed step the same offsets the eager step would have used, so the two runs see the same dropout masks)
 
 
 def run_train(tmp, name, extra):
@@ -28,22 +30,40 @@ def run_train(tmp, name, extra):
     r = subprocess.run(cmd, cwd=PKG, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     ckpts = sorted(os.listdir(os.path.join(str(tmp), name, 'checkpoints')))
-    return ckpts, torch.load(os.path.join(str(tmp), name, 'checkpoints', ckpts[-1]), map_location='cpu', weights_only=False)
+    line = [l for l in r.stdout.splitlines() if 'Epoch 0 (iteration' in l][-1]
+    losses = {m.group(1): float(m.group(2)) for m in re.finditer(r'(Loss_\w+) ([-+.\deE]+) \(avg', line)}
+    return ckpts, torch.load(os.path.join(str(tmp), name, 'checkpoints', ckpts[-1]), map_location='cpu', weights_only=False), losses
+
+
+def _compare(a_ckpt, a_loss, b_ckpt, b_loss):
+    lerr = max(abs(b_loss[k] - a_loss[k]) / max(abs(a_loss[k]), 1e-2) for k in a_loss)
+    serr = 0.0
+    for part in ('generator', 'discriminator', 'embedder'):
+        # parameters only (BatchNorm running variances of 1x1 feature maps amplify any noise), as one vector per module
+        a = torch.cat([v.double().reshape(-1) for k, v in a_ckpt[part].items() if v.dtype == torch.float32 and 'running_' not in k])
+        b = torch.cat([v.double().reshape(-1) for k, v in b_ckpt[part].items() if v.dtype == torch.float32 and 'running_' not in k])
+        serr = max(serr, ((a - b).norm() / a.norm()).item())
+    return lerr, serr
 
 
 def test_run_epoch_with_hip_graph_equals_eager(tmp_path):
-    names_e, eager = run_train(tmp_path, 'eager', [])
-    names_g, graph = run_train(tmp_path, 'graph', ['--hip_graph'])
-    assert names_e == names_g == ['model_00000008.pth'], (names_e, names_g)      # 16 samples / batch 2 = 8 iterations, counted on rank 0
-    assert eager['args'].iteration == 8
-    worst = 0.0
-    for part in ('generator', 'discriminator', 'embedder'):
-        for k, v in eager[part].items():
-            if v.dtype == torch.float32:
-                d = ((graph[part][k].double() - v.double()).norm() / v.double().norm().clamp_min(1e-30)).item()
-                worst = max(worst, d)
-    print(f'[entry] --hip_graph vs eager after 8 iterations of run_epoch: worst state rel-L2 {worst:.2e}')
-    assert worst < 1e-5, worst
+    """Two EAGER runs of this loop already differ: split-K atomics and MIOpen reductions add rounding noise, BatchNorm over a
+    handful of values and Adam (which moves an element whose true gradient is ~0 by +-lr) amplify it.  So the replayed loop is
+    held to the eager loop's own run-to-run spread (measured here by a second eager run), on quantities that are smooth in the
+    weights: the losses of the LAST iteration -- off at once if a replay saw a stale batch or lost an update -- and each module's
+    parameter vector."""
+    names_e, eager, loss_e = run_train(tmp_path, 'eager', ['--log_frequency_loss', '1'])
+    _, eager2, loss_e2 = run_train(tmp_path, 'eager2', ['--log_frequency_loss', '1'])
+    names_g, graph, loss_g = run_train(tmp_path, 'graph', ['--hip_graph', '--log_frequency_loss', '1'])
+    assert names_e == names_g == ['model_00000008.pth'], (names_e, names_g)      # 16 samples / batch 2 = 8 iterations
+    assert eager['args'].iteration == 8 and graph['args'].iteration == 8
+    assert set(loss_e) == set(loss_g) and len(loss_e) >= 5, (loss_e, loss_g)
+    noise_l, noise_s = _compare(eager, loss_e, eager2, loss_e2)
+    lerr, serr = _compare(eager, loss_e, graph, loss_g)
+    print(f'[entry] --hip_graph vs eager after 8 iterations of run_epoch: last-iteration losses {lerr:.2e} (eager vs eager {noise_l:.2e}); '
+          f'parameter vectors {serr:.2e} (eager vs eager {noise_s:.2e})')
+    assert lerr < max(3 * noise_l, 2e-3), (lerr, noise_l, loss_e, loss_g)
+    assert serr < max(3 * noise_s, 1e-3), (serr, noise_s)
 
 
 def test_inference_pack_cache_follows_optimizer_and_ema_updates():
