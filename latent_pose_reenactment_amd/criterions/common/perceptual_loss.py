@@ -15,6 +15,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from latent_pose_reenactment_amd import hipops as ops
+from latent_pose_reenactment_amd import nn as lpnn
 from latent_pose_reenactment_amd.nn import AvgPool2Fn, default_prec, hip_conv, hip_l1_tap, to_nhwc
 
 CFG = {
@@ -100,6 +101,8 @@ class PerceptualLoss(nn.Module):
                 cur, cur16 = out if emit is not None else (out, None)
                 pending_relu = True
             elif isinstance(layer, nn.ReLU):
+                if cur16 is None:          # (a conv that emitted relu(y) planes has recorded this site already)
+                    lpnn.tape_relu(lambda: cur > 0)
                 if targets is None:
                     taps.append(cur)
                 else:

@@ -15,6 +15,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from latent_pose_reenactment_amd import hipops as ops
+from latent_pose_reenactment_amd import nn as lpnn
 from latent_pose_reenactment_amd.nn import (SNWeight, SNBatch, SNLinearFn, SNEmbeddingFn, _Indexed, SN_EPS_CONV, SN_EPS_DEFAULT, AvgPool2Fn,
                                             as_nchw_view, default_prec, hip_conv, to_nhwc)
 from latent_pose_reenactment_amd.utils import radam as _radam
@@ -113,8 +114,6 @@ class Discriminator(nn.Module):
     def _fresh_packs(self):
         """bf16 packs (forward + dgrad) of every conv of the critic for this step's three passes, produced by one batched launch;
         keyed like ConvFn's per-step cache: (W_orig.data_ptr(), mode)"""
-        from latent_pose_reenactment_amd import hipops as ops
-        from latent_pose_reenactment_amd.nn import default_prec
         convs = [m for m in self.modules() if hasattr(m, 'weight_orig') and m.weight_orig.dim() == 4]
         if not convs or not convs[0].weight_orig.is_cuda:
             return {}
@@ -155,9 +154,11 @@ class Discriminator(nn.Module):
         feats = []
         for block in self.blocks:
             out_relu = torch.relu(out)           # what the reference's in-place ReLU leaves behind in its feature list
+            lpnn.tape_relu(lambda: out_relu > 0)
             feats.append(as_nchw_view(out_relu))
             out = block(out_relu, track_weights, states)
         feats.append(as_nchw_view(out))
+        lpnn.tape_relu(lambda: out > 0)
         pooled = torch.relu(out).sum(dim=(1, 2))
         wl, bl, sl = _wb(self.linear, track_weights, states)
         score = SNLinearFn.apply(pooled, wl, bl, *sl)[:, 0]

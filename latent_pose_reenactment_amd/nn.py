@@ -72,6 +72,16 @@ class SNWeight(nn.Module):
         return w / sigma
 
 
+# Debug aid of the tie-masked parity tests: when a list, every ReLU site of the critic / VGG stacks appends its activation pattern
+# (bool, NHWC) in execution order while autograd is recording.  None in production.
+RELU_TAPE = None
+
+
+def tape_relu(pattern_fn):
+    if RELU_TAPE is not None and torch.is_grad_enabled():
+        RELU_TAPE.append(pattern_fn())
+
+
 _FUSED_ACCUM = [False]
 
 
@@ -612,13 +622,19 @@ class ConvFn(torch.autograd.Function):
             y = ops.thin_conv(x, pack, ksize=ksize, bias=bd, alpha=alpha, prec=prec)
             if emit is not None:
                 emit[1].append(ops.act_pack(y, pro=2 if emit[0] else 0, prec=prec))
+                if emit[0]:
+                    tape_relu(lambda: emit[1][-1].hi[..., :cout] > 0)
         else:
             if a16 is None:
                 a16 = ops.act_pack(x, pro=pro, prec=prec)
+                if pro == 2:
+                    tape_relu(lambda: a16.hi[..., :cin] > 0)
             y = ops.conv16(a16, pack, ksize=ksize, bias=bd, res=res, alpha=alpha, prec=prec, out16=None if emit is None else emit[0])
             if emit is not None:
                 y, o16 = y
                 emit[1].append(o16)
+                if emit[0]:
+                    tape_relu(lambda: o16.hi[..., :cout] > 0)
         if need_w and not thin_w and a16 is None:
             a16 = ops.act_pack(x, pro=pro, prec=prec)
         ctx.x = x if thin_w else None                               # fp32 input only where a thin-channel weight gradient needs it

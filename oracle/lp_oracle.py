@@ -104,6 +104,19 @@ def split_affine_params(affine: Tensor, blocks: List[Tuple[int, int, bool]]) -> 
     return out
 
 
+RELU_REPLAY: Optional[List[Tensor]] = None      # tie-masked checks of the critic / VGG stacks: activation patterns, consumed in site order
+
+
+def _relu(x: Tensor) -> Tensor:
+    """ReLU site of the discriminator / perceptual stacks: the true ReLU, or -- when ``RELU_REPLAY`` holds the activation patterns
+    recorded by the implementation under test -- that implementation's own piecewise-linear branch (see ``_relu_m``)."""
+    if RELU_REPLAY is None:
+        return torch.relu(x)
+    m = RELU_REPLAY.pop(0)
+    assert m.shape == x.shape, (m.shape, x.shape)
+    return x * m.to(x.dtype)
+
+
 def _relu_m(x: Tensor, mask: Optional[Tensor]) -> Tensor:
     """ReLU, or -- tie-masked parity checks -- the same piecewise-linear branch with a PRESCRIBED activation pattern ``mask`` (the
     pattern of the implementation under test): pre-activations within rounding distance of 0 flip between two correct
@@ -177,7 +190,7 @@ def resblock_none(x_relu: Tensor, sd: State, prefix: str, downsample: bool, trai
     (SURVEY Appendix B).  ``x_relu`` must already be relu(x)."""
     w1 = sn_effective_weight(sd, f'{prefix}.block.2', SN_EPS_CONV, train)
     h = F.conv2d(x_relu, w1, sd[f'{prefix}.block.2.bias'], 1, 1)
-    h = torch.relu(h)
+    h = _relu(h)
     w2 = sn_effective_weight(sd, f'{prefix}.block.5', SN_EPS_CONV, train)
     h = F.conv2d(h, w2, sd[f'{prefix}.block.5.bias'], 1, 1)
     if downsample:
@@ -202,7 +215,7 @@ def discriminator_pass(sd: State, x: Tensor, embed: Optional[Tensor], *, image_s
     """Discriminator.pass_inputs (no_landmarks.py:90-108).  Returned features are what the reference's list holds
     *after* the call: feats[0..n-2] post-ReLU (mutated in place by the next block), feats[n-1] pre-ReLU."""
     w = sn_effective_weight(sd, 'down_block.0', SN_EPS_CONV, train)
-    h = torch.relu(F.conv2d(x, w, sd['down_block.0.bias'], 1, 1))
+    h = _relu(F.conv2d(x, w, sd['down_block.0.bias'], 1, 1))
     w = sn_effective_weight(sd, 'down_block.2', SN_EPS_CONV, train)
     h = F.avg_pool2d(F.conv2d(h, w, sd['down_block.2.bias'], 1, 1), 2)
     w = sn_effective_weight(sd, 'skip.0', SN_EPS_CONV, train)
@@ -210,11 +223,11 @@ def discriminator_pass(sd: State, x: Tensor, embed: Optional[Tensor], *, image_s
     out = h + s
     feats = []
     for i, down in enumerate(discriminator_layout(image_size, dis_num_blocks)):
-        out_relu = torch.relu(out)
+        out_relu = _relu(out)
         feats.append(out_relu)
         out = resblock_none(out_relu, sd, f'blocks.{i}', down, train)
     feats.append(out)
-    h = torch.relu(out)
+    h = _relu(out)
     h = h.reshape(h.shape[0], h.shape[1], -1).sum(2)
     w = sn_effective_weight(sd, 'linear', SN_EPS_CONV, train)
     lin = F.linear(h, w, sd['linear.bias'])[:, 0]
@@ -304,7 +317,7 @@ def perceptual_loss(sd: State, fake: Tensor, real: Tensor, weight: float, cfg, n
             w, bb = sd[f'{key_prefix}{item[1]}.weight'], sd[f'{key_prefix}{item[1]}.bias']
             fi, ft = F.conv2d(fi, w, bb, 1, 1), F.conv2d(ft, w, bb, 1, 1)
         elif item[0] == 'relu':
-            fi, ft = torch.relu(fi), torch.relu(ft)
+            fi, ft = _relu(fi), torch.relu(ft)       # (only the fake branch carries gradient)
             loss = loss + F.l1_loss(fi, ft)
         else:
             fi, ft = F.avg_pool2d(fi, 2, 2), F.avg_pool2d(ft, 2, 2)

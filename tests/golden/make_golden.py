@@ -433,8 +433,173 @@ def make_train_step():
     print('train_step_small.npz', len(out), 'arrays')
 
 
+def _patched_vgg_criterions():
+    """the reference's perceptual + idt_embed criterions on the narrow VGG shim, weights seeded exactly as in make_perceptual (so the
+    product-side test can take them from perceptual_small.npz)"""
+    from criterions.common import perceptual_loss as ref_pl
+    from criterions import idt_embed as ref_idt, perceptual as ref_perc
+    real_load = torch.load
+
+    def fake_load(path, *a, **k):
+        name = os.path.basename(str(path))
+        torch.manual_seed(100 if 'vgg19' in name else 200)
+        if 'vgg19' in name:
+            net = _vgg(CFG_E)
+            ren = {'classifier.0': 'classifier.1', 'classifier.3': 'classifier.4'}
+            return {ren.get(k2.rsplit('.', 1)[0], k2.rsplit('.', 1)[0]) + '.' + k2.rsplit('.', 1)[1]:
+                    torch.randn_like(v) * (0.35 if v.dim() > 1 else 0.1) for k2, v in net.state_dict().items()}
+        net = _vgg(CFG_D).features
+        return {k2: torch.randn_like(v) * (0.35 if v.dim() > 1 else 0.1) for k2, v in net.state_dict().items()}
+    rng = torch.get_rng_state()
+    torch.load = fake_load
+    try:
+        perc = ref_perc.Criterion(3e-2, '/nonexistent')
+        idt = ref_idt.Criterion(6e-3, '/nonexistent')
+    finally:
+        torch.load = real_load
+        torch.set_rng_state(rng)
+    return idt, perc
+
+
+def _install_backbones():
+    import importlib
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(OUT)), 'latent_pose_reenactment_amd', 'embedders'))
+    backbones = importlib.import_module('backbones')
+    tv.models.resnext50_32x4d = backbones.resnext50_32x4d
+    tv.models.mobilenet_v2 = backbones.mobilenet_v2
+    for name in ('tqdm',):
+        if name not in sys.modules:
+            m = types.ModuleType(name); m.tqdm = lambda x, *a, **k: x; sys.modules[name] = m
+
+
+META_SEED = 21
+
+
+def make_metatrain_step():
+    """runners/holycow.run_epoch for ONE batch of the META-TRAINING configuration (configs/default.yaml: criterions idt_embed,
+    perceptual, adversarial, featmat, dis_embed, dice; Adam; embedder parameters in optimizer_G; many labels), reduced size, with
+    the reference's own TrainingModule / get_optimizer / Embedder.  torchvision is absent, so the reference's embedder receives this
+    repository's restated backbones (embedders/backbones.py); it runs in eval mode (BatchNorm on running statistics, no dropout) so
+    that the step is deterministic -- generator and discriminator are in train mode (power iterations live).  The embedder's 26.6 M
+    initial values are not stored: both sides construct it after torch.manual_seed(META_SEED) (checksums stored)."""
+    _install_backbones()
+    from runners import holycow as ref_runner
+    from embedders import unsupervised_pose_separate_embResNeXt_segmentation as ref_emb
+    out = {}
+    args = small_args()
+    args.average_function = 'sum'; args.optimizer = 'Adam'; args.lr_gen = 5e-5; args.lr_dis = 2e-4; args.beta1 = 0.0
+    args.finetune = False; args.num_gpus = 1; args.detailed_metrics = True; args.gan_type = 'gan'
+    torch.manual_seed(META_SEED)
+    E = ref_emb.Wrapper.get_net(args)
+    out['E.checksum'] = np.array([float(sum(p.double().sum() for p in E.parameters())), float(sum((p.double() ** 2).sum() for p in E.parameters()))])
+    G, D = ref_gen.Wrapper.get_net(args), ref_dis.Wrapper.get_net(args)
+    with torch.no_grad():
+        G.constant.constant.copy_(torch.randn_like(G.constant.constant))
+    idt, perc = _patched_vgg_criterions()
+    crits = [idt, perc, ref_adv.Criterion('gan'), ref_fm.Criterion(10.0), ref_de.Criterion(1e-2), ref_dice.Criterion(1.0)]
+    tm = ref_runner.TrainingModule(E, G, D, crits, [], {})
+    opt_G = ref_runner.get_optimizer(tm.embedder, tm.generator, args)
+    opt_D = ref_dis.Wrapper.get_optimizer(tm.discriminator, args)
+    tm.train()
+    tm.embedder.eval()
+    for nm, mod in (('G', tm.generator), ('D', tm.discriminator)):
+        out.update(sd_np(mod, f'init.{nm}.'))
+    g = torch.Generator().manual_seed(5)
+    data = {'enc_rgbs': torch.rand(2, 2, 3, 32, 32, generator=g), 'pose_input_rgbs': torch.rand(2, 1, 3, 32, 32, generator=g),
+            'target_rgbs': torch.rand(2, 1, 3, 32, 32, generator=g)}
+    target = {'real_segm': torch.rand(2, 1, 1, 32, 32, generator=g).expand(2, 1, 3, 32, 32).contiguous(), 'label': torch.tensor([3, 1])}
+    for k, v in {**data, **target}.items():
+        out['init.in.' + k] = npy(v)
+    captured = {}
+    orig_fwd = tm.embedder.forward
+
+    def rec_fwd(d):
+        orig_fwd(d)
+        captured['embeds'] = d['embeds'].detach().clone(); captured['pose'] = d['pose_embedding'].detach().clone()
+    tm.embedder.forward = rec_fwd
+    args.device = 'cpu'
+    meters = []
+    BaseMeter = ref_runner.Meter
+
+    class RecordingMeter(BaseMeter):
+        def __init__(self):
+            super().__init__()
+            meters.append(self)
+    ref_runner.Meter = RecordingMeter
+    try:
+        ref_runner.run_epoch([(data, target)], tm, opt_G, opt_D, 0, args, phase='train', writer=None)
+    finally:
+        ref_runner.Meter = BaseMeter
+    meter = meters[0]
+    out['embeds'] = npy(captured['embeds']); out['pose_embedding'] = npy(captured['pose'])
+    for key in meter.keys():
+        if key.startswith('Loss_'):
+            out['loss.' + key[len('Loss_'):]] = np.array(meter.get_last(key))
+    for nm, mod in (('G', tm.generator), ('D', tm.discriminator), ('G_ema', tm.running_averages['generator'])):
+        after = sd_np(mod, f'after.{nm}.')
+        after.pop(f'after.{nm}.affine_params_projector.2.weight_orig', None)
+        out.update(after)
+    # embedder: gradients left in .grad by the step (optimizer_G.step does not clear them) as per-tensor summaries
+    gp = torch.Generator().manual_seed(9)
+    summ = []
+    for p_ in tm.embedder.parameters():
+        r = torch.randn(p_.shape, generator=gp)
+        gr = p_.grad if p_.grad is not None else torch.zeros_like(p_)
+        summ.append([float(gr.double().norm()), float((gr.double() * r.double()).sum())])
+    out['E.grad_summary'] = np.array(summ)
+    np.savez_compressed(os.path.join(OUT, 'metatrain_step_small.npz'), **out)
+    print('metatrain_step_small.npz', len(out), 'arrays; losses', {k: float(v) for k, v in out.items() if k.startswith('loss.')})
+
+
+def make_checkpoint():
+    """A checkpoint WRITTEN BY THE REFERENCE's own save_model (utils/utils.py:251-295) at reduced size -- pins the on-disk format
+    (keys, nesting, optimizer state layout, argparse.Namespace with pathlib paths) that load_model_from_checkpoint / drive.py of
+    this package must read.  Generator, discriminator, TrainingModule, optimizers and save_model are the reference's; the embedder
+    plugin is tests/tiny_embedder.py (the real ResNeXt-50 + MobileNetV2 state would be 107 MB).  The file pickles only tensors,
+    dicts and an argparse.Namespace -- no reference classes -- so it loads without the reference."""
+    _install_backbones()
+    from pathlib import Path
+    from runners import holycow as ref_runner
+    from utils import utils as ref_utils
+    args = small_args()
+    args.average_function = 'sum'; args.optimizer = 'Adam'; args.lr_gen = 5e-5; args.lr_dis = 2e-4; args.beta1 = 0.0
+    args.finetune = False; args.num_gpus = 1; args.rank = 0; args.iteration = 1234
+    args.generator = 'vector_pose_unsupervised_segmentation_noBottleneck'; args.embedder = 'tiny_for_tests'
+    args.discriminator = 'no_landmarks'; args.runner = 'holycow'; args.criterions = 'adversarial, featmat, dice'
+    args.experiment_dir = Path(OUT) / '_ckpt_tmp'; args.experiments_dir = Path(OUT); args.experiment_name = '_ckpt_tmp'
+    args.set_eval_mode_in_test = True; args.set_eval_mode_in_train = False; args.dataloader = 'synthetic_voxceleb2'; args.inference = False
+    args.weights_running_average = True; args.world_size = 1; args.local_rank = 0; args.random_seed = 123
+    torch.manual_seed(31)
+    G, D = ref_gen.Wrapper.get_net(args), ref_dis.Wrapper.get_net(args)
+
+    sys.path.insert(0, os.path.dirname(OUT))
+    import tiny_embedder                    # tests/tiny_embedder.py: same plugin interface, two Linear layers (keeps the fixture small)
+    tiny_embedder.register()
+    E = tiny_embedder.Wrapper.get_net(args)
+    tm = ref_runner.TrainingModule(E, G, D, [ref_adv.Criterion('gan')], [], {})
+    opt_G = ref_runner.get_optimizer(tm.embedder, tm.generator, args)
+    opt_D = ref_dis.Wrapper.get_optimizer(tm.discriminator, args)
+    # one hand-made optimizer step so that the optimizer state dicts are populated in the reference's layout
+    for opt in (opt_G, opt_D):
+        for grp in opt.param_groups:
+            for p_ in grp['params']:
+                p_.grad = torch.randn_like(p_) * 1e-3
+        opt.step()
+    ckpt_dir = args.experiment_dir / 'checkpoints'
+    if ckpt_dir.exists():
+        for f in ckpt_dir.iterdir():
+            f.unlink()
+    ckpt_dir.mkdir(parents=True, exist_ok=True)      # (the reference's train.py creates it before the first save)
+    ref_utils.save_model(tm, opt_G, opt_D, args)
+    src = next(iter(sorted(ckpt_dir.iterdir())))
+    dst = os.path.join(OUT, 'reference_checkpoint_small.pth')
+    os.replace(src, dst)
+    ckpt_dir.rmdir(); args.experiment_dir.rmdir()
+    print('reference_checkpoint_small.pth', os.path.getsize(dst), 'bytes, written by the reference save_model as', src.name)
+
+
 if __name__ == '__main__':
     torch.set_num_threads(1)
-    which = sys.argv[1:] or ['ops', 'generator', 'discriminator', 'perceptual', 'train_step']
+    which = sys.argv[1:] or ['ops', 'generator', 'discriminator', 'perceptual', 'train_step', 'metatrain_step', 'checkpoint']
     for w in which:
         globals()['make_' + w]()

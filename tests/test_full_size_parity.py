@@ -78,3 +78,148 @@ def test_generator_256_vs_oracle(prec, tol_out, tol_grad):
           f'untied worst {max(gerr_untied.values()):.3e}')
     assert all(v < tol_out for v in errs.values()), errs
     assert all(v < tol_grad for v in gerr.values()), worst
+
+
+def _with_tape(fn):
+    """run ``fn`` (a forward through the HIP modules) while recording the activation pattern of every ReLU site -> (result, masks NCHW, CPU)"""
+    from latent_pose_reenactment_amd import nn as lpnn
+    lpnn.RELU_TAPE = []
+    try:
+        out = fn()
+        masks = [m.permute(0, 3, 1, 2).cpu() for m in lpnn.RELU_TAPE]
+    finally:
+        lpnn.RELU_TAPE = None
+    return out, masks
+
+
+# (mode, gate on forward quantities, gate on tie-masked gradients)
+@pytest.mark.parametrize('prec_name,tol_out,tol_grad', [('bf16x3', 1e-4, 2e-4), ('f16', 1e-3, 3e-3)])
+def test_discriminator_256_three_passes_vs_oracle(prec_name, tol_out, tol_grad, monkeypatch):
+    """The critic as the step runs it: 256x256, 64..512 channels, B = 2, three passes (fake -> G, fake.detach -> D, real) each with
+    its own power iteration, adversarial + feature-matching losses, both backward passes (runners/holycow.py:239-250)."""
+    monkeypatch.setenv('LP_PREC', prec_name)
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'latent_pose_reenactment_amd'))
+    from discriminators.no_landmarks import Discriminator
+    from oracle import lp_oracle as O
+    torch.manual_seed(0)
+    D = Discriminator('zero', 3, 3, 64, 512, 512, 7, 256, 100).cuda().train()
+    D.keep_reference_waste = True          # pass 1 also deposits (later discarded) weight gradients, as the reference does
+    g = torch.Generator().manual_seed(2)
+    fake0, real = torch.rand(2, 3, 256, 256, generator=g), torch.rand(2, 1, 3, 256, 256, generator=g)
+    label = torch.tensor([17, 3])
+    with torch.no_grad():
+        for _ in range(3):                  # settle the power iterations
+            D({'fake_rgbs': fake0.cuda(), 'target_rgbs': real.cuda(), 'label': label.cuda()})
+    sd = {k: v.detach().cpu().clone() for k, v in D.state_dict().items()}
+    fake = fake0.clone().cuda().requires_grad_(True)
+    dd = {'fake_rgbs': fake, 'target_rgbs': real.cuda(), 'label': label.cuda()}
+    _, masks = _with_tape(lambda: D(dd))
+
+    def losses(d):
+        lg = -d['fake_score_G'].mean() + 10.0 * sum(torch.nn.functional.l1_loss(f, r.detach()) for f, r in zip(d['fake_features'], d['real_features'])) / len(d['fake_features'])
+        ld = torch.relu(1.0 - d['real_score']).mean() + torch.relu(1.0 + d['fake_score_D']).mean()
+        return lg, ld
+    lg, ld = losses(dd)
+    params = dict(D.named_parameters())
+    gG = torch.autograd.grad(lg, [fake] + list(params.values()), retain_graph=True, allow_unused=True)
+    gD = torch.autograd.grad(ld, list(params.values()), allow_unused=True)
+    torch.cuda.synchronize()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+
+    def oracle(replay):
+        st = {k: v.clone() for k, v in sd.items()}
+        for k in params:
+            st[k].requires_grad_(True)
+        f = fake0.clone().requires_grad_(True)
+        O.RELU_REPLAY = None if replay is None else list(replay)
+        try:
+            out = O.discriminator_forward(st, f, real[:, 0], label, image_size=256, dis_num_blocks=7, train=True)
+        finally:
+            left = None if O.RELU_REPLAY is None else len(O.RELU_REPLAY)
+            O.RELU_REPLAY = None
+        assert not left, f'{left} recorded ReLU sites were not consumed by the oracle'
+        olg, old = losses(out)
+        oG = torch.autograd.grad(olg, [f] + [st[k] for k in params], retain_graph=True, allow_unused=True)
+        oD = torch.autograd.grad(old, [st[k] for k in params], allow_unused=True)
+        return out, olg, old, oG, oD
+    out, olg, old, _, _ = oracle(None)
+    _, _, _, oG, oD = oracle(masks)
+    errs = {'loss_G': rel(lg, olg), 'loss_D': rel(ld, old)}
+    for k in ('fake_score_G', 'fake_score_D', 'real_score'):
+        errs[k] = rel(dd[k], out[k])
+    for i, (a, b) in enumerate(zip(dd['fake_features'], out['fake_features'])):
+        errs[f'fake_feat{i}'] = rel(a, b)
+    gerr = {'G.d_fake': rel(gG[0], oG[0])}
+    for (k, _), a, b in zip(params.items(), gG[1:], oG[1:]):
+        if a is not None and b is not None and b.abs().max() > 0:
+            gerr['G.' + k] = rel(a, b)
+    for (k, _), a, b in zip(params.items(), gD, oD):
+        if a is not None and b is not None and b.abs().max() > 0:
+            gerr['D.' + k] = rel(a, b)
+    worst = sorted(gerr.items(), key=lambda kv: -kv[1])[:4]
+    print(f'[parity-256] critic {prec_name}: forward worst {max(errs.values()):.2e} ({max(errs, key=errs.get)}); tie-masked grads worst '
+          f'{[(k, round(v, 6)) for k, v in worst]} over {len(gerr)} tensors')
+    assert all(v < tol_out for v in errs.values()), errs
+    assert all(v < tol_grad for v in gerr.values()), worst
+
+
+@pytest.mark.parametrize('prec_name,tol_out,tol_grad', [('bf16x3', 1e-4, 2e-4), ('f16', 1e-3, 3e-3)])
+@pytest.mark.parametrize('net', ['caffe', 'face'])
+def test_vgg_stacks_256_vs_oracle(net, prec_name, tol_out, tol_grad, monkeypatch):
+    """VGG19 / VGGFace perceptual stacks at full width and 256x256 (thin-channel first conv at W = 256, 64..512-channel convs, fused
+    relu planes, avg-pools, 13 L1 taps): loss and its tie-masked gradient w.r.t. the fake image against the oracle."""
+    monkeypatch.setenv('LP_PREC', prec_name)
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'latent_pose_reenactment_amd'))
+    from criterions.common.perceptual_loss import PerceptualLoss
+    from oracle import lp_oracle as O
+    crit = PerceptualLoss(3e-2, '/nonexistent', net, synthetic_seed=77).cuda().eval()
+    g = torch.Generator().manual_seed(4)
+    fake0, real = torch.rand(1, 3, 256, 256, generator=g) * 2 - 1, torch.rand(1, 3, 256, 256, generator=g) * 2 - 1
+    fake = fake0.clone().cuda().requires_grad_(True)
+    loss, masks = _with_tape(lambda: crit(fake, real.cuda()))
+    loss.backward()
+    torch.cuda.synchronize()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    sd = {k: v.detach().cpu() for k, v in crit.model.state_dict().items()}
+    cfg = O.VGG19_CFG if net == 'caffe' else O.VGG16_CFG
+
+    def oracle(replay):
+        f = fake0.clone().requires_grad_(True)
+        O.RELU_REPLAY = None if replay is None else list(replay)
+        try:
+            l = O.perceptual_loss(sd, f, real, 3e-2, cfg)
+        finally:
+            left = None if O.RELU_REPLAY is None else len(O.RELU_REPLAY)
+            O.RELU_REPLAY = None
+        assert not left, left
+        l.backward()
+        return l, f.grad
+    l_true, g_true = oracle(None)
+    _, g_tied = oracle(masks)
+    e_l, e_g, e_gu = rel(loss, l_true), rel(fake.grad, g_tied), rel(fake.grad, g_true)
+    print(f'[parity-256] {net} stack {prec_name}: loss {e_l:.2e}, tie-masked d_fake {e_g:.2e} (untied {e_gu:.2e})')
+    assert e_l < tol_out and e_g < tol_grad, (e_l, e_g)
+
+
+@pytest.mark.parametrize('prec', [1, 2])
+def test_wide_image_first_conv_takes_the_mfma_path(prec):
+    """the thin-channel fp32 kernels stage whole image rows in LDS: a row that does not fit (W > 680) must fall back to the
+    operand-plane MFMA kernel (3-channel planes padded to 8) -- forward, data gradient and weight gradient"""
+    from latent_pose_reenactment_amd import hipops as ops
+    import torch.nn.functional as F
+    n, h, w, cin, cout = 1, 8, 1024, 3, 64
+    assert not ops.thin_conv_supported(cin, cout, 3, w) and ops.thin_conv_supported(cin, cout, 3, 256)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(n, cin, h, w, generator=g, dtype=torch.float64, requires_grad=True)
+    wgt = (torch.randn(cout, cin, 3, 3, generator=g, dtype=torch.float64) / 27 ** 0.5).requires_grad_(True)
+    dy = torch.randn(n, cout, h, w, generator=g, dtype=torch.float64)
+    F.conv2d(x, wgt, None, 1, 1).backward(dy)
+    f32 = lambda t: t.detach().float().cuda().contiguous()
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous()
+    y = ops.conv(f32(nhwc(x)), ops.pack_weights(f32(wgt), 0, prec, small_k=True), ksize=3, prec=prec)
+    dw = ops.conv_wgrad(f32(nhwc(x)), f32(nhwc(dy)), ksize=3, prec=prec)
+    tol = 3e-5 if prec == 1 else 1e-3
+    assert rel(y.permute(0, 3, 1, 2), F.conv2d(x, wgt, None, 1, 1)) < tol
+    assert rel(dw, wgt.grad) < tol

@@ -1,0 +1,92 @@
+"""BASELINE configs[2]: one iteration of the META-TRAINING configuration (configs/default.yaml: finetune=False, embedder parameters
+in optimizer_G, many labels, criterions idt_embed, perceptual, adversarial, featmat, dis_embed, dice, Adam) through this package's
+train_step against the reference's own run_epoch on identical state and batch (tests/golden/metatrain_step_small.npz, written by
+tests/golden/make_golden.py::make_metatrain_step from /root/reference)."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'latent_pose_reenactment_amd'))
+pytestmark = pytest.mark.gpu
+META_SEED = 21
+
+
+def rel(a, b):
+    a = torch.as_tensor(a).detach().double().cpu(); b = torch.as_tensor(b).double()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def test_metatrain_iteration_matches_reference_run_epoch(monkeypatch):
+    monkeypatch.setenv('LP_PREC', 'bf16x3')
+    z = dict(np.load(os.path.join(ROOT, 'tests', 'golden', 'metatrain_step_small.npz')))
+    zv = dict(np.load(os.path.join(ROOT, 'tests', 'golden', 'perceptual_small.npz')))
+    from generators.vector_pose_unsupervised_segmentation_noBottleneck import Wrapper as GW
+    from embedders.unsupervised_pose_separate_embResNeXt_segmentation import Wrapper as EW
+    from discriminators.no_landmarks import Wrapper as DW
+    from criterions import adversarial, featmat, dice, dis_embed, idt_embed, perceptual
+    from criterions.common.perceptual_loss import PerceptualLoss
+    from runners import holycow
+    a = argparse.Namespace(image_size=32, num_channels=4, max_num_channels=16, embed_channels=8, pose_embedding_size=4, in_channels=3,
+                           out_channels=3, num_labels=5, dis_num_blocks=5, gen_padding='zero', norm_layer='in', gen_constant_input_size=4,
+                           gen_num_residual_blocks=2, dis_padding='zero', device='cuda', optimizer='Adam', lr_gen=5e-5, lr_dis=2e-4,
+                           beta1=0.0, finetune=False, num_gpus=1, average_function='sum')
+    # the embedder's 26.6 M initial values come from the same seeded construction as on the reference side (checksum pinned)
+    a_cpu = argparse.Namespace(**{**vars(a), 'device': 'cpu'})
+    torch.manual_seed(META_SEED)
+    E = EW.get_net(a_cpu)
+    chk = np.array([float(sum(p.double().sum() for p in E.parameters())), float(sum((p.detach().double() ** 2).sum() for p in E.parameters()))])
+    assert np.allclose(chk, z['E.checksum'], rtol=1e-9), (chk, z['E.checksum'])
+    E = E.cuda()
+    G, D = GW.get_net(a), DW.get_net(a)
+    G.load_state_dict({k[len('init.G.'):]: torch.from_numpy(v) for k, v in z.items() if k.startswith('init.G.')})
+    D.load_state_dict({k[len('init.D.'):]: torch.from_numpy(v) for k, v in z.items() if k.startswith('init.D.')})
+    div = int(zv['width_div'])
+    p19 = perceptual.Criterion.__new__(perceptual.Criterion); torch.nn.Module.__init__(p19)
+    p19.perceptual_crit = PerceptualLoss(3e-2, '/nonexistent', 'caffe', synthetic_seed=0, width_div=div)
+    p19.perceptual_crit.model.load_state_dict({k[len('vgg19.'):]: torch.from_numpy(v) for k, v in zv.items()
+                                               if k.startswith('vgg19.') and int(k.split('.')[1]) < 30})
+    pf = idt_embed.Criterion.__new__(idt_embed.Criterion); torch.nn.Module.__init__(pf)
+    pf.idt_embed_crit = PerceptualLoss(6e-3, '/nonexistent', 'face', synthetic_seed=0, width_div=div).eval()
+    pf.idt_embed_crit.model.load_state_dict({k[len('vggface.'):]: torch.from_numpy(v) for k, v in zv.items()
+                                             if k.startswith('vggface.') and int(k.split('.')[1]) < 30})
+    crits = [pf.cuda(), p19.cuda(), adversarial.Criterion('gan'), featmat.Criterion(10.0), dis_embed.Criterion(1e-2), dice.Criterion(1.0)]
+    tm = holycow.TrainingModule(E, G, D, crits, [], {})
+    opt_G = holycow.get_optimizer(tm.embedder, tm.generator, a)
+    opt_D = DW.get_optimizer(tm.discriminator, a)
+    assert len(opt_G.param_groups[0]['params']) == len(list(G.parameters())) + len(list(E.parameters()))     # holycow.py:34-41
+    tm.train()
+    tm.embedder.eval()
+    data = {k[len('init.in.'):]: torch.from_numpy(v).cuda() for k, v in z.items() if k.startswith('init.in.') and 'segm' not in k and 'label' not in k}
+    target = {'real_segm': torch.from_numpy(z['init.in.real_segm']).cuda(), 'label': torch.from_numpy(z['init.in.label']).cuda()}
+    all_data, lG, lD = holycow.train_step(tm, data, target, opt_G, opt_D, a)
+    torch.cuda.synchronize()
+    assert set(lG) == {'VGGFace', 'VGG', 'adversarial_G', 'feature_matching', 'embedding_matching', 'segmentation_dice'} and set(lD) == {'adversarial_D'}
+    errs = {'embeds': rel(all_data['embeds'], z['embeds']), 'pose_embedding': rel(all_data['pose_embedding'], z['pose_embedding'])}
+    for name, v in {**lG, **lD}.items():
+        errs['loss.' + name] = rel(v, z['loss.' + name])
+    for nm, mod in (('G', tm.generator), ('D', tm.discriminator), ('G_ema', tm.running_averages['generator'])):
+        for k, v in mod.state_dict().items():
+            key = f'after.{nm}.{k}'
+            if key in z:
+                errs[f'{nm}.{k}'] = rel(v, z[key])
+    # embedder gradients (left in .grad by the step): per-tensor norm and projection on a seeded random direction
+    gp = torch.Generator().manual_seed(9)
+    summ = []
+    for p_ in tm.embedder.parameters():
+        r = torch.randn(p_.shape, generator=gp)
+        gr = p_.grad.detach().cpu() if p_.grad is not None else torch.zeros(p_.shape)
+        summ.append([float(gr.double().norm()), float((gr.double() * r.double()).sum())])
+    summ = np.array(summ)
+    ref = z['E.grad_summary']
+    errs['E.grad_norms'] = float(np.linalg.norm(summ[:, 0] - ref[:, 0]) / np.linalg.norm(ref[:, 0]))
+    errs['E.grad_projections'] = float(np.linalg.norm(summ[:, 1] - ref[:, 1]) / np.linalg.norm(ref[:, 1]))
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:8]
+    print('[parity] meta-train step (Adam, 6 criterions, embedder in optimizer_G): worst', [(k, f'{v:.2e}') for k, v in worst])
+    # state tensors: Adam moves every element by ~lr, so a wrong sign on a ~0-gradient element is lr-sized: absolute gate on states
+    bad = {k: v for k, v in errs.items() if v >= (5e-3 if k.startswith('E.grad') else 2e-4 if k.startswith('loss.') or k in ('embeds', 'pose_embedding') else 2e-3)}
+    assert not bad, bad
