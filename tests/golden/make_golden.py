@@ -563,7 +563,7 @@ def make_checkpoint():
     from utils import utils as ref_utils
     args = small_args()
     args.average_function = 'sum'; args.optimizer = 'Adam'; args.lr_gen = 5e-5; args.lr_dis = 2e-4; args.beta1 = 0.0
-    args.finetune = False; args.num_gpus = 1; args.rank = 0; args.iteration = 1234
+    args.finetune = True; args.num_gpus = 1; args.rank = 0; args.iteration = 1234
     args.generator = 'vector_pose_unsupervised_segmentation_noBottleneck'; args.embedder = 'tiny_for_tests'
     args.discriminator = 'no_landmarks'; args.runner = 'holycow'; args.criterions = 'adversarial, featmat, dice'
     args.experiment_dir = Path(OUT) / '_ckpt_tmp'; args.experiments_dir = Path(OUT); args.experiment_name = '_ckpt_tmp'
@@ -577,8 +577,15 @@ def make_checkpoint():
     tiny_embedder.register()
     E = tiny_embedder.Wrapper.get_net(args)
     tm = ref_runner.TrainingModule(E, G, D, [ref_adv.Criterion('gan')], [], {})
+    # a FINE-TUNED checkpoint (what drive.py consumes, drive.py:48-71): bootstrap as in train.py:263-272
+    boot = {'embeds': torch.randn(1, args.embed_channels) * 0.3}
+    tm.generator.enable_finetuning(boot); tm.discriminator.enable_finetuning(boot); tm.embedder.enable_finetuning()
+    tm.running_averages['generator'].enable_finetuning(boot); tm.running_averages['embedder'].enable_finetuning()
     opt_G = ref_runner.get_optimizer(tm.embedder, tm.generator, args)
     opt_D = ref_dis.Wrapper.get_optimizer(tm.discriminator, args)
+    with torch.no_grad():      # make the EMA weights differ from the current ones (drive.py must pick the EMA set)
+        for p_ in tm.running_averages['generator'].parameters():
+            p_.mul_(0.97)
     # one hand-made optimizer step so that the optimizer state dicts are populated in the reference's layout
     for opt in (opt_G, opt_D):
         for grp in opt.param_groups:
