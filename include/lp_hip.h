@@ -93,6 +93,22 @@ int lp_thin_wgrad_has_dbias(int Cin, int Cout);
 int lp_thin_wgrad(const float* x, const float* dy, float* dw, float* workspace, const float* scale, const float* shift,
                   int N, int H, int W, int Cin, int Cout, int ksize, int pro, int splits, float* dbias, void* stream);
 
+/* Small-batch linear layer y = alpha * x W^T + bias, x [B][K], W [N][K] (nn.Linear layout), 1 <= B <= 64, K % 4 == 0, K <= 1024:
+ * the AdaIN-parameter projector (noBottleneck.py:96-101) and the critic's 512 -> 1 head (no_landmarks.py:88,105) -- weight streams,
+ * not GEMMs.  alpha: device scalar|NULL (1/sigma of the spectral norm), bias [N]|NULL.
+ * Backward: dx [B][K] = alpha * g W (|NULL), dw [N][K] = g^T x (RAW gradient w.r.t. W/sigma: lp_sn_grad_apply turns it into the
+ * gradient w.r.t. W_orig; |NULL), db [N] = column sums of g (|NULL); workspace: lp_linear_bwd_workspace_bytes(). */
+int lp_linear_fwd(const float* x, const float* w, const float* bias, const float* alpha, float* y, int B, int N, int K, void* stream);
+long long lp_linear_bwd_workspace_bytes(int B, int N, int K);
+int lp_linear_bwd(const float* x, const float* w, const float* g, const float* alpha, float* dx, float* dw, float* db,
+                  float* workspace, int B, int N, int K, void* stream);
+
+/* criterions/idt_embed.py:58-83 crop_and_resize: images [N][C][H][W] (NCHW fp32), boxes [N][4] = t, b, l, r in pixels ->
+ * out [N][C][Ho][Wo]: affine_grid(align_corners=False) + grid_sample(bilinear, reflection padding).  The backward pass is the adjoint
+ * (dimages is zeroed, then accumulated with fp32 atomics). */
+int lp_grid_crop_fwd(const float* images, const float* boxes, float* out, int N, int C, int H, int W, int Ho, int Wo, void* stream);
+int lp_grid_crop_bwd(const float* dout, const float* boxes, float* dimages, int N, int C, int H, int W, int Ho, int Wo, void* stream);
+
 /* Instance-norm statistics of x [N][H*W][C] and the AdaIN scale/shift derived from them (blocks.py:18-26):
  *   mean/rstd [N][C] (biased variance, eps), scale = rstd*gamma, shift = beta - mean*scale.
  * gamma/beta [N][C] with row stride `ab_stride` floats (they are slices of the projector output, noBottleneck.py:108-125).

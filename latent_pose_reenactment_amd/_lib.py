@@ -34,6 +34,11 @@ SIGNATURES = {
     'lp_thin_wgrad_supported': (_i, [_i] * 5),
     'lp_thin_wgrad_has_dbias': (_i, [_i] * 2),
     'lp_thin_wgrad': (_i, [_vp] * 6 + [_i] * 8 + [_vp, _vp]),
+    'lp_linear_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'lp_linear_bwd_workspace_bytes': (_ll, [_i, _i, _i]),
+    'lp_linear_bwd': (_i, [_vp] * 8 + [_i, _i, _i, _vp]),
+    'lp_grid_crop_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'lp_grid_crop_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'lp_instnorm_workspace_bytes': (_ll, [_i, _i, _i]),
     'lp_instnorm_stats': (_i, [_vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'lp_adain_bwd_workspace_bytes': (_ll, [_i, _i, _i]),

@@ -16,9 +16,29 @@ class Wrapper:
         return Criterion(args.idt_embed_weight, args.vgg_weights_dir, None if seed is None else seed + 1).to(args.device)
 
 
+class _GridCropFn(torch.autograd.Function):
+    """crop_and_resize on the gfx950 kernels (lp_grid_crop_fwd / _bwd): one launch each way instead of affine_grid + grid_sample"""
+
+    @staticmethod
+    def forward(ctx, images, boxes, out_hw):
+        from latent_pose_reenactment_amd import hipops as ops
+        ctx.save_for_backward(boxes)
+        ctx.in_shape = tuple(images.shape)
+        return ops.grid_crop_fwd(images.detach().contiguous(), boxes, out_hw)
+
+    @staticmethod
+    def backward(ctx, dout):
+        from latent_pose_reenactment_amd import hipops as ops
+        (boxes,) = ctx.saved_tensors
+        return ops.grid_crop_bwd(dout.contiguous(), boxes, ctx.in_shape), None, None
+
+
 def crop_and_resize(images, bboxes, target_size=None):
     """images B x C x H x W, bboxes B x 4 = [t, b, l, r] in pixels -> crops resampled (bilinear, reflection padding,
     align_corners=False) to ``target_size`` (default H x W) -- idt_embed.py:58-83."""
+    if images.is_cuda and images.dtype == torch.float32:
+        n, c, h, w = images.shape
+        return _GridCropFn.apply(images, bboxes.float().contiguous().expand(n, 4).contiguous(), tuple(target_size or (h, w)))
     t, b, l, r = bboxes.t().float()
     n, c, h, w = images.shape
     theta = torch.zeros(n, 2, 3, dtype=torch.float32, device=images.device)

@@ -1,0 +1,22 @@
+"""Generator plugin (reference API: generators/FSTH_plus.py:8-29) -- the 512 x 512 configuration of BASELINE configs[4].
+Same AdaIN decoder on the gfx950 kernels as the default generator (one more up-block at 512 x 512; the conv kernels pick their
+LDS tiles from the feature-map size, nothing is specific to 256); the projector is plain Linear + LeakyReLU(0.05) and the pose
+vector is ``dec_keypoints[:, 0] - 0.5`` (so ``--pose_embedding_size`` must be 136)."""
+from latent_pose_reenactment_amd.nn import GeneratorFSTHPlus as Generator  # noqa: F401
+
+
+class Wrapper:
+    @staticmethod
+    def get_args(parser):
+        parser.add('--gen_constant_input_size', type=int, default=4)
+        parser.add('--gen_num_residual_blocks', type=int, default=2)
+        parser.add('--gen_padding', type=str, default='zero', help='zero (reflection is not implemented on the HIP path)')
+        parser.add('--norm_layer', type=str, default='in')
+
+    @staticmethod
+    def get_net(args):
+        const_size = getattr(args, 'gen_constant_input_size', 4)      # backward compatibility with old checkpoints' args
+        net = Generator(args.gen_padding, args.in_channels, args.out_channels + 1, args.num_channels, args.max_num_channels,
+                        args.embed_channels, args.pose_embedding_size, args.norm_layer, const_size,
+                        args.gen_num_residual_blocks, args.image_size)
+        return net.to(args.device)

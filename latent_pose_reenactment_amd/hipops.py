@@ -306,6 +306,53 @@ def conv_wgrad(x: Tensor, dy: Tensor, *, ksize: int, upsample: bool = False, pro
     return conv_wgrad16(a, d, ksize=ksize, upsample=upsample, prec=prec, splits=splits, sn=sn, accum=accum, bias_grad=bias_grad)
 
 
+def linear_supported(b: int, k: int) -> bool:
+    return 1 <= b <= 64 and k % 4 == 0 and k <= 1024
+
+
+def linear_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor], alpha: Optional[Tensor]) -> Tensor:
+    """y [B,N] = alpha * x W^T + bias (lp_linear_fwd: one pass over W, 1/sigma and bias fused)"""
+    _chk(x, 'x'); _chk(w, 'w')
+    b, k = x.shape
+    n = w.shape[0]
+    y = torch.empty((b, n), dtype=torch.float32, device=x.device)
+    check(_lib.lib().lp_linear_fwd(x.data_ptr(), w.data_ptr(), _p(bias), _p(alpha), y.data_ptr(), b, n, k, _stream()), 'lp_linear_fwd')
+    return y
+
+
+def linear_bwd(x: Tensor, w: Tensor, g: Tensor, alpha: Optional[Tensor], want_dx: bool, want_dw: bool, want_db: bool):
+    """-> (dx = alpha * g W | None, raw dw = g^T x | None, db | None) in one pass over W"""
+    _chk(x, 'x'); _chk(w, 'w'); _chk(g, 'g')
+    b, k = x.shape
+    n = w.shape[0]
+    dev = x.device
+    dx = torch.empty((b, k), dtype=torch.float32, device=dev) if want_dx else None
+    dw = torch.empty((n, k), dtype=torch.float32, device=dev) if want_dw else None
+    db = torch.empty(n, dtype=torch.float32, device=dev) if want_db else None
+    ws = torch.empty(_lib.lib().lp_linear_bwd_workspace_bytes(b, n, k) // 4, dtype=torch.float32, device=dev) if want_dx else None
+    check(_lib.lib().lp_linear_bwd(x.data_ptr(), w.data_ptr(), g.data_ptr(), _p(alpha), _p(dx), _p(dw), _p(db), _p(ws), b, n, k, _stream()),
+          'lp_linear_bwd')
+    return dx, dw, db
+
+
+def grid_crop_fwd(images: Tensor, boxes: Tensor, out_hw) -> Tensor:
+    """images [N,C,H,W] fp32 NCHW, boxes [N,4] (t, b, l, r) -> crops [N,C,Ho,Wo] (bilinear, reflection, align_corners=False)"""
+    _chk(images, 'images'); _chk(boxes, 'boxes')
+    n, c, h, w = images.shape
+    out = torch.empty((n, c) + tuple(out_hw), dtype=torch.float32, device=images.device)
+    check(_lib.lib().lp_grid_crop_fwd(images.data_ptr(), boxes.data_ptr(), out.data_ptr(), n, c, h, w, out_hw[0], out_hw[1], _stream()), 'lp_grid_crop_fwd')
+    return out
+
+
+def grid_crop_bwd(dout: Tensor, boxes: Tensor, in_shape) -> Tensor:
+    _chk(dout, 'dout'); _chk(boxes, 'boxes')
+    n, c, h, w = in_shape
+    dimg = torch.empty(in_shape, dtype=torch.float32, device=dout.device)
+    check(_lib.lib().lp_grid_crop_bwd(dout.data_ptr(), boxes.data_ptr(), dimg.data_ptr(), n, c, h, w, dout.shape[2], dout.shape[3], _stream()),
+          'lp_grid_crop_bwd')
+    return dimg
+
+
 def sn_grad_apply(g: Tensor, w_orig: Tensor, u: Tensor, v: Tensor, sig: Tensor, accum: Optional[Tensor] = None) -> Optional[Tensor]:
     """gradient w.r.t. W_orig of a spectrally normalised layer from the raw gradient ``g`` w.r.t. W/sigma (legacy-hook autograd,
     u and v constants): g/sigma - <g, W_orig>/sigma^2 u v^T, in place on ``g`` -- or added to ``accum`` (returns None)."""

@@ -77,8 +77,11 @@ class SNWeight(nn.Module):
 RELU_TAPE = None
 
 
-def tape_relu(pattern_fn):
-    if RELU_TAPE is not None and torch.is_grad_enabled():
+_TAPE_GRAD = [True]      # grad mode of the caller of the autograd.Function that is running (inside Function.forward it is always off)
+
+
+def tape_relu(pattern_fn, in_function=False):
+    if RELU_TAPE is not None and (_TAPE_GRAD[0] if in_function else torch.is_grad_enabled()):
         RELU_TAPE.append(pattern_fn())
 
 
@@ -166,13 +169,20 @@ class SNBatch:
 
 
 class SNLinearFn(torch.autograd.Function):
-    """y = (x W_orig^T) / sigma + b for a spectrally normalised nn.Linear whose sigma comes from SNBatch (plain library GEMMs);
-    backward applies the legacy-hook rule dW_orig = G/sigma - <G, W_orig>/sigma^2 u v^T with u, v constant."""
+    """y = (x W_orig^T) / sigma + b for a spectrally normalised nn.Linear whose sigma comes from SNBatch.  On the GPU both passes are
+    lp_linear_fwd / lp_linear_bwd (small-batch weight streams with 1/sigma and the bias fused; the backward reads W once for dx, the raw
+    weight gradient and the bias gradient) followed by lp_sn_grad_apply (legacy-hook rule dW_orig = G/sigma - <G, W_orig>/sigma^2 u v^T,
+    u, v constant)."""
 
     @staticmethod
     def forward(ctx, x, w, b, u, v, sig):
         ctx.save_for_backward(x, w, u, v, sig)
         ctx.w_param = w if (w.requires_grad and w.is_leaf) else None
+        x2 = x.reshape(-1, x.shape[-1])
+        ctx.hip = x.is_cuda and ops.linear_supported(x2.shape[0], x2.shape[1])
+        if ctx.hip:
+            y = ops.linear_fwd(x2.detach().contiguous(), w.detach().contiguous(), None if b is None else b.detach().contiguous(), sig[1:])
+            return y.reshape(x.shape[:-1] + (w.shape[0],))
         y = F.linear(x, w) * sig[1]
         return y + b if b is not None else y
 
@@ -180,17 +190,27 @@ class SNLinearFn(torch.autograd.Function):
     def backward(ctx, g):
         x, w, u, v, sig = ctx.saved_tensors
         alpha = sig[1]
-        dx = (g @ w) * alpha if ctx.needs_input_grad[0] else None
-        dw = db = None
+        g2, x2 = g.reshape(-1, g.shape[-1]).contiguous(), x.reshape(-1, x.shape[-1]).contiguous()
+        dx = dw = db = None
+        if ctx.hip:
+            dx, graw, db = ops.linear_bwd(x2.detach(), w.detach().contiguous(), g2, sig[1:], ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                          ctx.needs_input_grad[2])
+            if dx is not None:
+                dx = dx.reshape(x.shape)
+            if graw is not None:
+                dw = ops.sn_grad_apply(graw, w.detach(), u, v, sig, accum=None if ctx.w_param is None else _accum_target(ctx.w_param))
+            return dx, dw, db, None, None, None
+        if ctx.needs_input_grad[0]:
+            dx = (g @ w) * alpha
         if ctx.needs_input_grad[1]:
-            graw = (g.reshape(-1, g.shape[-1]).t() @ x.reshape(-1, x.shape[-1])).contiguous()
-            if graw.is_cuda:      # <G, W> + rank-1 correction in two launches, added straight into the gradient arena when possible
+            graw = (g2.t() @ x2).contiguous()
+            if graw.is_cuda:
                 dw = ops.sn_grad_apply(graw, w.detach(), u, v, sig, accum=None if ctx.w_param is None else _accum_target(ctx.w_param))
             else:
                 dot = (graw * w).sum()
                 dw = graw * alpha - (dot * alpha * alpha) * torch.outer(u, v)
         if ctx.needs_input_grad[2]:
-            db = g.reshape(-1, g.shape[-1]).sum(0)
+            db = g2.sum(0)
         return dx, dw, db, None, None, None
 
 
@@ -468,12 +488,28 @@ class Generator(nn.Module):
         self.identity_embedding_size = identity_embedding_size
         self.pose_embedding_size = pose_embedding_size
         joint = identity_embedding_size + pose_embedding_size
-        hidden = max(joint, 512)
         self.num_affine_params = sum(2 * (a + b) for a, b, _ in self.blocks_cfg) + 2 * self.blocks_cfg[-1][1]
-        self.affine_params_projector = _Indexed(_0=SNWeight((hidden, joint), True, SN_EPS_DEFAULT),
-                                                _2=SNWeight((self.num_affine_params, hidden), True, SN_EPS_DEFAULT))
+        self.affine_params_projector = self._build_projector(joint)
         self.finetuning = False
         self.prec = default_prec() if prec is None else prec
+
+    # ---- the projector is the only part in which the generator plugins differ (noBottleneck.py:96-101 vs FSTH_plus.py:96-103)
+    def _build_projector(self, joint):
+        hidden = max(joint, 512)
+        return _Indexed(_0=SNWeight((hidden, joint), True, SN_EPS_DEFAULT), _2=SNWeight((self.num_affine_params, hidden), True, SN_EPS_DEFAULT))
+
+    def _projector_sn_layers(self):
+        return [self.affine_params_projector._modules['0'], self.affine_params_projector._modules['2']]
+
+    def _pose_vector(self, data_dict):
+        return data_dict['pose_embedding']
+
+    def _project(self, joint, states):
+        """SN-Linear -> ReLU -> SN-Linear: plain library GEMMs (rocBLAS through torch) -- B x 768 x 768 and B x 768 x 13056 -- with the
+        1/sigma of the batched power iteration and the legacy-hook weight gradient rule (SNLinearFn)"""
+        p0, p2 = self.affine_params_projector._modules['0'], self.affine_params_projector._modules['2']
+        h = torch.relu(SNLinearFn.apply(joint, p0.weight_orig, p0.bias, *states[-2]))
+        return SNLinearFn.apply(h, p2.weight_orig, p2.bias, *states[-1])
 
     def get_num_affine_params(self):
         return self.num_affine_params
@@ -493,11 +529,12 @@ class Generator(nn.Module):
             self.finetuning = True
 
     def _affine_params(self, data_dict):
+        pose = self._pose_vector(data_dict)
         if self.finetuning:
-            identity = self.identity_embedding.expand(len(data_dict['pose_embedding']), -1)
+            identity = self.identity_embedding.expand(len(pose), -1)
         else:
             identity = data_dict['embeds']
-        joint = torch.cat((identity, data_dict['pose_embedding']), dim=1)
+        joint = torch.cat((identity, pose), dim=1)
         if not joint.is_cuda:
             raise RuntimeError('the generator runs on the MI355X HIP path only (no CPU fallback); move the model and inputs to cuda')
         # ONE launch power-iterates every spectrally normalised layer of the generator (23 convs + 2 projector linears)
@@ -506,10 +543,7 @@ class Generator(nn.Module):
             self.__dict__['_sn_batch'] = SNBatch(layers)
         states = self._sn_batch.update(self.training)
         self.__dict__['_sn_states'] = states
-        p0, p2 = self.affine_params_projector._modules['0'], self.affine_params_projector._modules['2']
-        # plain library GEMMs (rocBLAS through torch) -- B x 768 x 768 and B x 768 x 13056
-        h = torch.relu(SNLinearFn.apply(joint, p0.weight_orig, p0.bias, *states[-2]))
-        return SNLinearFn.apply(h, p2.weight_orig, p2.bias, *states[-1])
+        return self._project(joint, states)
 
     def _sn_layers(self):
         """batched SNWeight layers in a fixed order: decoder convs (block order, w1, w2[, skip]), head conv, projector.0, projector.2"""
@@ -521,7 +555,7 @@ class Generator(nn.Module):
                 c1, c2, sk = self.decoder_blocks._modules[str(i)].convs()
                 layers += [c1, c2] + ([sk] if sk is not None else [])
             layers.append(self.decoder_blocks._modules[str(nb + 2)])
-            layers += [self.affine_params_projector._modules['0'], self.affine_params_projector._modules['2']]
+            layers += self._projector_sn_layers()
             cached = (layers, None)
             self.__dict__['_sn_layer_cache'] = cached
         return cached
@@ -577,6 +611,28 @@ class Generator(nn.Module):
         data_dict['fake_segm'] = segm
 
 
+class GeneratorFSTHPlus(Generator):
+    """Drop-in for generators/FSTH_plus.py::Generator (BASELINE configs[4], 512 x 512): the same AdaIN decoder; the projector is three
+    plain ``nn.Linear`` with LeakyReLU(0.05) in between (FSTH_plus.py:96-103, no spectral norm) and the pose vector is
+    ``dec_keypoints[:, 0] - 0.5`` (FSTH_plus.py:129-139).  state_dict keys: ``affine_params_projector.{0,2,4}.{weight,bias}``."""
+
+    def _build_projector(self, joint):
+        hidden = max(512, joint)
+        return _Indexed(_0=nn.Linear(joint, hidden), _2=nn.Linear(hidden, hidden), _4=nn.Linear(hidden, self.num_affine_params))
+
+    def _projector_sn_layers(self):
+        return []
+
+    def _pose_vector(self, data_dict):
+        return data_dict['dec_keypoints'][:, 0] - 0.5
+
+    def _project(self, joint, states):
+        m = self.affine_params_projector._modules
+        h = F.leaky_relu(m['0'](joint), 0.05)
+        h = F.leaky_relu(m['2'](h), 0.05)
+        return m['4'](h)
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # generic HIP layers for the discriminator and the VGG criterions (NHWC fp32 tensors)
 # ----------------------------------------------------------------------------------------------------------------------
@@ -623,18 +679,18 @@ class ConvFn(torch.autograd.Function):
             if emit is not None:
                 emit[1].append(ops.act_pack(y, pro=2 if emit[0] else 0, prec=prec))
                 if emit[0]:
-                    tape_relu(lambda: emit[1][-1].hi[..., :cout] > 0)
+                    tape_relu(lambda: emit[1][-1].hi[..., :cout] > 0, True)
         else:
             if a16 is None:
                 a16 = ops.act_pack(x, pro=pro, prec=prec)
                 if pro == 2:
-                    tape_relu(lambda: a16.hi[..., :cin] > 0)
+                    tape_relu(lambda: a16.hi[..., :cin] > 0, True)
             y = ops.conv16(a16, pack, ksize=ksize, bias=bd, res=res, alpha=alpha, prec=prec, out16=None if emit is None else emit[0])
             if emit is not None:
                 y, o16 = y
                 emit[1].append(o16)
                 if emit[0]:
-                    tape_relu(lambda: o16.hi[..., :cout] > 0)
+                    tape_relu(lambda: o16.hi[..., :cout] > 0, True)
         if need_w and not thin_w and a16 is None:
             a16 = ops.act_pack(x, pro=pro, prec=prec)
         ctx.x = x if thin_w else None                               # fp32 input only where a thin-channel weight gradient needs it
@@ -693,6 +749,7 @@ def hip_conv(x, w, bias=None, res=None, ksize=3, pro=0, prec=None, packs=None, s
     """``x16``: existing operand planes of act(x); ``emit16`` = 0 | 1: also return the operand planes of y (1: of relu(y)), written
     by the conv's epilogue -> ``(y, Act16)``."""
     prec = default_prec() if prec is None else prec
+    _TAPE_GRAD[0] = torch.is_grad_enabled()
     if emit16 is None:
         return ConvFn.apply(x, w, bias, res, ksize, pro, prec, packs, sn, x16, None)
     holder = []
@@ -758,4 +815,6 @@ class L1TapFn(torch.autograd.Function):
 
 def hip_l1_tap(a, b, relu_in=False):
     """-> (a passed through, l1 term); use the returned tensor as the input of the following layer"""
+    if RELU_TAPE is not None:       # sign pattern of this L1 site (tie-masked parity tests)
+        tape_relu(lambda: torch.sign((torch.relu(a) if relu_in else a) - (torch.relu(b) if relu_in else b)).to(torch.int8))
     return L1TapFn.apply(a, b.detach(), relu_in)

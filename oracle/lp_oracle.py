@@ -117,6 +117,17 @@ def _relu(x: Tensor) -> Tensor:
     return x * m.to(x.dtype)
 
 
+def _l1(a: Tensor, b: Tensor) -> Tensor:
+    """F.l1_loss site of the perceptual stacks: mean|a - b|, or -- under ``RELU_REPLAY`` -- the same piecewise-linear branch with the
+    recorded sign pattern s of (a - b): mean(s * (a - b)).  sign() is the other discontinuity of this path: where two features
+    agree to within rounding the derivative +-1/numel flips between two correct implementations."""
+    if RELU_REPLAY is None:
+        return F.l1_loss(a, b)
+    sgn = RELU_REPLAY.pop(0)
+    assert sgn.shape == a.shape, (sgn.shape, a.shape)
+    return (sgn.to(a.dtype) * (a - b)).mean()
+
+
 def _relu_m(x: Tensor, mask: Optional[Tensor]) -> Tensor:
     """ReLU, or -- tie-masked parity checks -- the same piecewise-linear branch with a PRESCRIBED activation pattern ``mask`` (the
     pattern of the implementation under test): pre-activations within rounding distance of 0 flip between two correct
@@ -149,20 +160,26 @@ def resblock_ada(x: Tensor, sd: State, prefix: str, aff0, aff1, upsample: bool, 
 
 def generator_forward(sd: State, identity: Tensor, pose: Tensor, *, num_channels: int, max_num_channels: int,
                       image_size: int, train: bool, const_size: int = 4, num_res_blocks: int = 2,
-                      relu_masks: Optional[List[Tensor]] = None) -> Tuple[Tensor, Tensor]:
+                      relu_masks: Optional[List[Tensor]] = None, fsth_plus: bool = False) -> Tuple[Tensor, Tensor]:
     """Generator.forward (noBottleneck.py:165-181).  ``identity`` is data_dict['embeds'] (B x E) or the finetuned
     ``identity_embedding`` (1 x E, expanded).  Returns (fake_rgbs, fake_segm).  SN buffers in ``sd`` are updated in
     place when ``train``.  ``relu_masks``: prescribed activation patterns of the 17 AdaIN+ReLU sites in execution order
-    (tie-masked gradient checks, see ``_relu_m``)."""
+    (tie-masked gradient checks, see ``_relu_m``).  ``fsth_plus``: generators/FSTH_plus.py -- ``pose`` is then
+    ``dec_keypoints[:, 0] - 0.5`` and the projector three plain Linear layers with LeakyReLU(0.05) (FSTH_plus.py:96-103,129-139)."""
     b = pose.shape[0]
     if identity.shape[0] == 1 and b != 1:
         identity = identity.expand(b, -1)
     joint = torch.cat((identity, pose), dim=1)
-    # affine_params_projector: SN-Linear -> ReLU -> SN-Linear (noBottleneck.py:96-101), default SN eps
-    w0 = sn_effective_weight(sd, 'affine_params_projector.0', SN_EPS_DEFAULT, train)
-    h = torch.relu(F.linear(joint, w0, sd['affine_params_projector.0.bias']))
-    w2 = sn_effective_weight(sd, 'affine_params_projector.2', SN_EPS_DEFAULT, train)
-    affine = F.linear(h, w2, sd['affine_params_projector.2.bias'])
+    if fsth_plus:
+        h = F.leaky_relu(F.linear(joint, sd['affine_params_projector.0.weight'], sd['affine_params_projector.0.bias']), 0.05)
+        h = F.leaky_relu(F.linear(h, sd['affine_params_projector.2.weight'], sd['affine_params_projector.2.bias']), 0.05)
+        affine = F.linear(h, sd['affine_params_projector.4.weight'], sd['affine_params_projector.4.bias'])
+    else:
+        # affine_params_projector: SN-Linear -> ReLU -> SN-Linear (noBottleneck.py:96-101), default SN eps
+        w0 = sn_effective_weight(sd, 'affine_params_projector.0', SN_EPS_DEFAULT, train)
+        h = torch.relu(F.linear(joint, w0, sd['affine_params_projector.0.bias']))
+        w2 = sn_effective_weight(sd, 'affine_params_projector.2', SN_EPS_DEFAULT, train)
+        affine = F.linear(h, w2, sd['affine_params_projector.2.bias'])
 
     blocks = generator_channels(num_channels, max_num_channels, image_size, const_size, num_res_blocks)
     affs = split_affine_params(affine, blocks)
@@ -318,7 +335,7 @@ def perceptual_loss(sd: State, fake: Tensor, real: Tensor, weight: float, cfg, n
             fi, ft = F.conv2d(fi, w, bb, 1, 1), F.conv2d(ft, w, bb, 1, 1)
         elif item[0] == 'relu':
             fi, ft = _relu(fi), torch.relu(ft)       # (only the fake branch carries gradient)
-            loss = loss + F.l1_loss(fi, ft)
+            loss = loss + _l1(fi, ft)
         else:
             fi, ft = F.avg_pool2d(fi, 2, 2), F.avg_pool2d(ft, 2, 2)
     return loss * weight

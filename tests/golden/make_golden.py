@@ -605,8 +605,47 @@ def make_checkpoint():
     print('reference_checkpoint_small.pth', os.path.getsize(dst), 'bytes, written by the reference save_model as', src.name)
 
 
+def make_fsth_plus():
+    """generators/FSTH_plus.py (BASELINE configs[4]) at reduced size: train forward + backward of the reference's own module"""
+    from generators import FSTH_plus as ref_fp
+    args = small_args()
+    args.pose_embedding_size = 6          # = 2 * number of keypoints of this toy (136 in the 68-landmark configuration)
+    for seed in range(2, 200):
+        torch.manual_seed(seed)
+        G = ref_fp.Wrapper.get_net(args)
+        with torch.no_grad():
+            G.constant.constant.copy_(torch.randn_like(G.constant.constant))
+        embeds = torch.randn(2, args.embed_channels).requires_grad_(True)
+        kp = torch.rand(2, 1, args.pose_embedding_size).requires_grad_(True)
+        r1, r2 = torch.randn(2, 3, 32, 32), torch.randn(2, 1, 32, 32)
+        Gm = ref_fp.Wrapper.get_net(args); Gm.load_state_dict(G.state_dict()); Gm.train()
+        margins = []
+        hooks = [m.register_forward_pre_hook(lambda _m, inp: margins.append((inp[0].abs().min() / inp[0].pow(2).mean().sqrt()).item()))
+                 for m in Gm.modules() if isinstance(m, nn.ReLU)]
+        with torch.no_grad():
+            Gm(dict(embeds=embeds.detach(), dec_keypoints=kp.detach()))
+        if min(margins) > 1e-4:
+            print(f'FSTH_plus fixture: seed {seed}, ReLU tie margin {min(margins):.2e}')
+            break
+    else:
+        raise RuntimeError('no seed with a safe ReLU tie margin found')
+    out = dict(cfg=np.array([args.image_size, args.num_channels, args.max_num_channels, args.embed_channels, args.pose_embedding_size]))
+    out.update(sd_np(G, 'sd.'))
+    out.update(embeds=npy(embeds), dec_keypoints=npy(kp), r1=npy(r1), r2=npy(r2))
+    G.train()
+    dd = dict(embeds=embeds, dec_keypoints=kp)
+    G(dd)
+    ((dd['fake_rgbs'] * r1).sum() + (dd['fake_segm'] * r2).sum()).backward()
+    out.update(train_fake_rgbs=npy(dd['fake_rgbs']), train_fake_segm=npy(dd['fake_segm']), grad_embeds=npy(embeds.grad), grad_kp=npy(kp.grad))
+    for k, p in G.named_parameters():
+        out[f'grad.{k}'] = npy(p.grad)
+    out.update({k: v for k, v in sd_np(G, 'sd_after.').items() if k.endswith('_u') or k.endswith('_v')})
+    np.savez_compressed(os.path.join(OUT, 'fsth_plus_small.npz'), **out)
+    print('fsth_plus_small.npz', len(out), 'arrays; keys e.g.', [k for k in out if 'projector' in k][:6])
+
+
 if __name__ == '__main__':
     torch.set_num_threads(1)
-    which = sys.argv[1:] or ['ops', 'generator', 'discriminator', 'perceptual', 'train_step', 'metatrain_step', 'checkpoint']
+    which = sys.argv[1:] or ['ops', 'generator', 'discriminator', 'perceptual', 'train_step', 'metatrain_step', 'checkpoint', 'fsth_plus']
     for w in which:
         globals()['make_' + w]()

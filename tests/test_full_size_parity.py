@@ -116,11 +116,15 @@ def test_discriminator_256_three_passes_vs_oracle(prec_name, tol_out, tol_grad, 
     dd = {'fake_rgbs': fake, 'target_rgbs': real.cuda(), 'label': label.cuda()}
     _, masks = _with_tape(lambda: D(dd))
 
-    def losses(d):
-        lg = -d['fake_score_G'].mean() + 10.0 * sum(torch.nn.functional.l1_loss(f, r.detach()) for f, r in zip(d['fake_features'], d['real_features'])) / len(d['fake_features'])
+    # feature matching (featmat.py:16-20) on the common branch of its own discontinuity: |f - r| is evaluated as s * (f - r) with the
+    # sign pattern s of the HIP features on both sides (identical to |.| for the HIP side; no sign flips of near-equal features)
+    signs = [torch.sign(f.detach() - r.detach()) for f, r in zip(dd['fake_features'], dd['real_features'])]
+
+    def losses(d, dev='cpu'):
+        lg = -d['fake_score_G'].mean() + 10.0 * sum((s.to(dev) * (f - r.detach())).mean() for s, f, r in zip(signs, d['fake_features'], d['real_features'])) / len(signs)
         ld = torch.relu(1.0 - d['real_score']).mean() + torch.relu(1.0 + d['fake_score_D']).mean()
         return lg, ld
-    lg, ld = losses(dd)
+    lg, ld = losses(dd, 'cuda')
     params = dict(D.named_parameters())
     gG = torch.autograd.grad(lg, [fake] + list(params.values()), retain_graph=True, allow_unused=True)
     gD = torch.autograd.grad(ld, list(params.values()), allow_unused=True)

@@ -234,3 +234,50 @@ def test_sum2x2_and_head():
     torch.cuda.synchronize()
     report('fake_rgbs', rel(r, fake), 1e-6); report('fake_segm', rel(sg, segm), 1e-6)
     report('head dz', rel(dz.permute(0, 3, 1, 2), z.grad), 1e-5)
+
+
+@pytest.mark.parametrize('shape', [(8, 13056, 768), (1, 768, 768), (3, 1, 512), (11, 40, 64)])       # B, N, K (projector, drive B=1, critic head, two batch tiles)
+def test_linear_fwd_bwd(shape):
+    ops = _ops()
+    b, n, k = shape
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(b, k, generator=g, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(n, k, generator=g, dtype=torch.float64) / k ** 0.5).requires_grad_(True)
+    bias = torch.randn(n, generator=g, dtype=torch.float64, requires_grad=True)
+    gy = torch.randn(b, n, generator=g, dtype=torch.float64)
+    alpha = 0.37
+    (alpha * (x @ w.t()) + bias).backward(gy)
+    f32 = lambda t: t.detach().float().cuda().contiguous()
+    al = torch.tensor([alpha], dtype=torch.float32, device='cuda')
+    y = ops.linear_fwd(f32(x), f32(w), f32(bias), al)
+    dx, dw, db = ops.linear_bwd(f32(x), f32(w), f32(gy), al, True, True, True)
+    torch.cuda.synchronize()
+    report(f'linear_fwd{shape}', rel(y, alpha * (x @ w.t()) + bias), 2e-6)
+    report(f'linear dx{shape}', rel(dx, x.grad), 2e-6)
+    report(f'linear dw (raw){shape}', rel(dw * alpha, w.grad), 2e-6)        # the kernel returns the gradient w.r.t. W/sigma
+    report(f'linear db{shape}', rel(db, bias.grad), 2e-6)
+
+
+@pytest.mark.parametrize('case', [(2, 3, 32, 32, 32, 32, 1 / 1.8), (1, 2, 48, 40, 48, 40, 1 / 1.8), (2, 3, 24, 24, 32, 32, 1.3)])   # last: bbox beyond the image
+def test_grid_crop_fwd_bwd(case):
+    """crop_and_resize (idt_embed.py:58-83) incl. reflection when the box leaves the image, against torch's own affine_grid +
+    grid_sample in fp64"""
+    ops = _ops()
+    n, c, h, w, ho, wo, keep = case
+    g = torch.Generator().manual_seed(5)
+    img = torch.rand(n, c, h, w, generator=g, dtype=torch.float64, requires_grad=True)
+    t, l = h * (1 - keep) / 2 + 0.3, w * (1 - keep) / 2 - 0.2
+    boxes = torch.tensor([[t, h - t, l, w - l]], dtype=torch.float64).expand(n, 4).contiguous()
+    theta = torch.zeros(n, 2, 3, dtype=torch.float64)
+    bt, bb, bl, br = boxes.t()
+    theta[:, 0, 0] = (br - bl) / w; theta[:, 0, 2] = (bl + br) / w - 1
+    theta[:, 1, 1] = (bb - bt) / h; theta[:, 1, 2] = (bt + bb) / h - 1
+    grid = F.affine_grid(theta, (n, c, ho, wo), align_corners=False)
+    ref = F.grid_sample(img, grid, mode='bilinear', padding_mode='reflection', align_corners=False)
+    gout = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    ref.backward(gout)
+    out = ops.grid_crop_fwd(img.detach().float().cuda(), boxes.float().cuda(), (ho, wo))
+    dimg = ops.grid_crop_bwd(gout.float().cuda(), boxes.float().cuda(), (n, c, h, w))
+    torch.cuda.synchronize()
+    report(f'grid_crop fwd{case}', rel(out, ref), 1e-5)
+    report(f'grid_crop bwd{case}', rel(dimg, img.grad), 1e-5)
