@@ -102,7 +102,8 @@ def test_fsth_plus_512_batch4(prec, tol):
         all4 = {'embeds': emb.cuda(), 'dec_keypoints': kp.cuda()}; G(all4)
         one = {'embeds': emb[2:3].cuda(), 'dec_keypoints': kp[2:3].cuda()}; G(one)
         G.train()
-    assert rel(all4['fake_rgbs'][2:3], one['fake_rgbs'].cpu()) < 1e-5
+    # (fp16 operands: a 1e-7 difference in summation order -- other tile shapes at another batch size -- flips single fp16 roundings)
+    assert rel(all4['fake_rgbs'][2:3], one['fake_rgbs'].cpu()) < (1e-5 if prec == 1 else 1e-3)
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     with torch.no_grad():
         rgb, sg = O.generator_forward(sd, emb[:1], kp[:1, 0] - 0.5, num_channels=64, max_num_channels=512, image_size=512, train=True, fsth_plus=True)
