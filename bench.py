@@ -43,7 +43,8 @@ def make_args(image_size, batch_size, device, num_gpus, rank, prec_name, finetun
 
 
 def build(args):
-    from generators.vector_pose_unsupervised_segmentation_noBottleneck import Wrapper as GW
+    import importlib
+    GW = importlib.import_module('generators.' + getattr(args, 'generator', 'vector_pose_unsupervised_segmentation_noBottleneck')).Wrapper
     from embedders.unsupervised_pose_separate_embResNeXt_segmentation import Wrapper as EW
     from discriminators.no_landmarks import Wrapper as DW
     from criterions import adversarial, featmat, idt_embed, perceptual, dice, dis_embed
@@ -83,11 +84,10 @@ def synthetic_batch(args, per_gpu_batch, seed):
     return data, target
 
 
-def cpu_baseline(args, sample_batch=1):
-    """The oracle (oracle/lp_oracle.py: fp32 torch-CPU restatement, parity-pinned against the reference) running the SAME
-    fine-tuning step on this box's host cores, on a bounded sample: `sample_batch` image(s) per step, repeated until ~20 s.
-    Step = pose encoder -> generator -> discriminator x3 -> adversarial/featmat/VGGFace/VGG19/dice -> loss_G.backward ->
-    RAdam(G) -> loss_D.backward -> RAdam(D) -> EMA(G)."""
+def _cpu_step(args, sample_batch):
+    """-> a callable running ONE fine-tuning step of `sample_batch` images through the oracle (oracle/lp_oracle.py):
+    pose encoder -> generator -> discriminator x3 -> adversarial/featmat/VGGFace/VGG19/dice -> loss_G.backward -> RAdam(G) ->
+    loss_D.backward -> RAdam(D) -> EMA(G)."""
     import copy
     from oracle import lp_oracle as O
     from generators.vector_pose_unsupervised_segmentation_noBottleneck import Wrapper as GW
@@ -95,8 +95,6 @@ def cpu_baseline(args, sample_batch=1):
     from embedders.backbones import mobilenet_v2
     from criterions.common.perceptual_loss import PerceptualLoss
     from dataloaders.synthetic_voxceleb2 import make_sample
-    cores = min(os.cpu_count() or 1, 32)      # torch-CPU oversubscribes badly beyond that (256 threads measured 100x slower)
-    torch.set_num_threads(cores)
     a = copy.copy(args)
     a.device = 'cpu'
     torch.manual_seed(0)
@@ -147,16 +145,64 @@ def cpu_baseline(args, sample_batch=1):
                     O.radam_step(sdD[k], g, *mom[id(sdD)][k], step_no[0], a.lr_dis, 0.0, 0.999, 1e-5)
             for k in pG:
                 O.ema_update(ema[k], sdG[k], 0.972)
-    one()                                   # warm-up (oneDNN primitive creation)
-    t0 = time.time()
-    reps = 0
-    while reps < 5 and time.time() - t0 < 20.0:
-        one()
-        reps += 1
-    dt = (time.time() - t0) / reps
-    return {'value': round(sample_batch / dt, 4), 'unit': 'images/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{reps} fine-tuning step(s) of {sample_batch} image(s) at {a.image_size}x{a.image_size} through '
-                      f'oracle/lp_oracle.py (torch CPU fp32, {cores} threads); {dt:.2f} s per step'}
+    return one
+
+
+def _cpu_info():
+    model, phys = 'unknown', set()
+    try:
+        cur = {}
+        for line in open('/proc/cpuinfo'):
+            if ':' in line:
+                k, v = [t.strip() for t in line.split(':', 1)]
+                if k == 'model name':
+                    model = v
+                cur[k] = v
+            elif not line.strip() and cur:
+                phys.add((cur.get('physical id', '0'), cur.get('core id', cur.get('processor', '0'))))
+                cur = {}
+    except OSError:
+        pass
+    return model, len(phys) or (os.cpu_count() or 1), os.cpu_count() or 1
+
+
+def _median_time(fn, warm, reps, budget_s):
+    """median of up to `reps` timed calls after `warm` warm-up calls, inside a wall-clock budget: when the warm-up alone exhausts the
+    budget its last call is the (single) sample"""
+    t_all = time.time()
+    last = None
+    for _ in range(warm):
+        t0 = time.time(); fn(); last = time.time() - t0
+    ts = []
+    while len(ts) < reps and (time.time() - t_all < budget_s or (not ts and last is None)):
+        t0 = time.time(); fn(); ts.append(time.time() - t0)
+    if not ts:
+        return last, 1
+    ts.sort()
+    return ts[len(ts) // 2], len(ts)
+
+
+def cpu_baseline(args, full=False):
+    """The CPU path timed on this box's host cores: the oracle -- the parity-pinned fp32 torch-CPU restatement of
+    the reference -- running the SAME fine-tuning step on the SAME kind of synthetic batch.
+      all-core row : bs = 8 (the GPU workload's batch), every physical core, median of the timed steps;
+      1-thread row : how the reference configures itself (torch.set_num_threads(1), utils/utils.py:19), bs = 1 sample of the same step.
+    Default = a bounded sample (1 warm-up + 3 timed all-core steps, 1 + 2 one-thread steps: ~1 minute); --cpu-baseline-full runs the
+    >= 3 warm-up + >= 10 timed protocol."""
+    model, cores, logical = _cpu_info()
+    use = min(cores, 64)       # torch-CPU oversubscribes badly beyond the physical cores
+    warm, reps = (3, 10) if full else (1, 3)
+    torch.set_num_threads(use)
+    t_all, n_all = _median_time(_cpu_step(args, 8), warm, reps, 600 if full else 45)
+    torch.set_num_threads(1)
+    t_one, n_one = _median_time(_cpu_step(args, 1), warm if full else 1, reps if full else 2, 900 if full else 40)
+    torch.set_num_threads(use)
+    return {'value': round(8 / t_all, 4), 'unit': 'images/s', 'cores': use, 'kind': 'port', 'cpu_model': model, 'physical_cores': cores,
+            'logical_cpus': logical, 'one_thread': {'value': round(1 / t_one, 4), 'unit': 'images/s', 'cores': 1,
+                                                   'sample': f'median of {n_one} fine-tuning step(s) of 1 image at {args.image_size}x{args.image_size}, torch.set_num_threads(1): {t_one:.2f} s per step'},
+            'sample': f'median of {n_all} fine-tuning step(s) of the bs=8 batch at {args.image_size}x{args.image_size} through oracle/lp_oracle.py '
+                      f'(torch CPU fp32, {use} threads = physical cores of {model}); {t_all:.2f} s per step'
+                      + ('' if full else '; bounded sample -- the >= 3 + >= 10 protocol is `bench.py --cpu-baseline-full`, committed under profiles/')}
 
 
 def drive_fps(args, frames=60):
@@ -209,15 +255,20 @@ def drive_fps(args, frames=60):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--batch', type=int, default=8, help='per-GPU batch')
     ap.add_argument('--image_size', type=int, default=256)
-    ap.add_argument('--prec', default=os.environ.get('LP_PREC', 'bf16x3'), choices=['bf16', 'bf16x3', 'f16'])
+    ap.add_argument('--prec', default=os.environ.get('LP_PREC', 'f16'), choices=['bf16', 'bf16x3', 'f16'],
+                    help='MFMA operand mode: f16 (default; 1 MFMA per MAC, outputs 1.7e-4 from the fp32 CPU path), bf16x3 (strict: 3 MFMAs, 2.5e-6), bf16')
+    ap.add_argument('--cpu-baseline-full', action='store_true', help='BASELINE.md section 3 protocol (>= 3 warm-up + >= 10 timed CPU steps, minutes)')
+    ap.add_argument('--generator', default='vector_pose_unsupervised_segmentation_noBottleneck', choices=['vector_pose_unsupervised_segmentation_noBottleneck', 'FSTH_plus'],
+                    help='generator plugin of --workload generator (FSTH_plus with --image_size 512 --batch 4 = BASELINE configs[4])')
     ap.add_argument('--workload', default=None, choices=['finetune_step', 'metatrain_step', 'generator'],
                     help='default: finetune_step at --gpus 1 (BASELINE configs[1]; the reference refuses multi-GPU fine-tuning), '
                          'metatrain_step at --gpus > 1 (configs[2], default.yaml: the configuration that IS trained data-parallel)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-also', action='store_true', help='skip the side measurement of the strict bf16x3 mode')
     ap.add_argument('--eager', action='store_true', help='do not capture the step into hipGraphs')
     ap.add_argument('--shapes', default=None, help='write the per-shape conv / wgrad timing table of the instrumented steps (CSV)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only for functional tests)')
@@ -240,6 +291,9 @@ def main():
         a.workload = 'finetune_step' if world == 1 else 'metatrain_step'
     finetune = a.workload != 'metatrain_step'
     args = make_args(a.image_size, a.batch, device, world, rank, a.prec, finetune=finetune)
+    args.generator = a.generator
+    if a.generator == 'FSTH_plus':
+        args.pose_embedding_size = 136          # 68 landmarks x 2 (generators/FSTH_plus.py:129-139)
     tm, opt_G, opt_D, holycow = build(args)
     if world > 1:
         from latent_pose_reenactment_amd.parallel import GradReducer
@@ -249,12 +303,13 @@ def main():
     from latent_pose_reenactment_amd import hipops
 
     def gen_only_step():
-        dd = {'pose_embedding': pose_static}
+        dd = {'pose_embedding': pose_static, 'dec_keypoints': kp_static}
         tm.generator(dd)
         (dd['fake_rgbs'].mean() + dd['fake_segm'].mean()).backward()
 
     if a.workload == 'generator':
-        pose_static = torch.randn(a.batch, 256, device=device)
+        pose_static = torch.randn(a.batch, args.pose_embedding_size, device=device)
+        kp_static = torch.rand(a.batch, 1, 136, device=device)
         step = gen_only_step
     else:
         def eager_step():
@@ -315,9 +370,23 @@ def main():
                  # bf16x3 executes 3 MFMAs per algorithmic MAC (hi*hi + hi*lo + lo*hi): the matrix pipe's own utilisation
                  'mfma_per_algorithmic_flop': 3 if a.prec == 'bf16x3' else 1,
                  'mfma_work_tflops': round(ach * (3 if a.prec == 'bf16x3' else 1), 2),
-                 'traffic_note': 'PMC FETCH/WRITE_SIZE of this kernel per shape: profiles/r01_pmc_conv_igemm_bf16x3.csv '
-                                 '(a --pmc pass over the whole step hangs rocprofv3 on this pool)'}
+                 'traffic_note': None}
         if kind == 'conv_igemm':
+            # HBM bytes per launch of this kernel family from the committed PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs of
+            # `bench.py --workload generator` under rocprofv3, scripts/r02_artifacts.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md)
+            try:
+                pm = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc_conv_dma.json')))
+                entry['traffic'] = pm.get('hbm_bytes_per_launch')
+                entry['traffic_note'] = ('mean HBM bytes per conv_dma_kernel launch over the generator-only step (profiles/r02_pmc_conv_dma.json: '
+                                         '(2 x FETCH_SIZE + WRITE_SIZE) x 1024, separate rocprofv3 --pmc passes); per-shape values: '
+                                         'profiles/r02_pmc_conv_micro_f16.csv; MFMA busy fraction from SQ_VALU_MFMA_BUSY_CYCLES: '
+                                         f"{pm.get('mfma_busy_fraction')}")
+            except Exception:
+                entry['traffic_note'] = 'profiles/r02_pmc_conv_dma.json not present'
+            entry['algorithmic_bytes_note'] = ('f16 operands: 2 B per input activation (once per N tile), 2 B per weight, 4 B per fp32 output '
+                                               '(+ 2 B when the epilogue also emits the consumer planes)')
+        if kind == 'conv_igemm':
+            entry['kernel'] = 'conv_dma_kernel (lp_conv16_fwd: forward and data-gradient convs)'
             roof = entry
         else:
             extra['roofline_' + kind] = entry
@@ -334,7 +403,8 @@ def main():
             'metric': 'train-step images/sec at 256x256 bs=8' if a.workload != 'generator' else 'generator fwd+bwd images/sec at 256x256 bs=8',
             'value': round(imgs / dt, 3), 'unit': 'images/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'bf16x3 (hi+lo split bf16 MFMA operands, fp32 accumulate)' if a.prec == 'bf16x3' else 'bf16 (MFMA operands, fp32 accumulate)',
+            'dtype': {'bf16x3': 'bf16x3 (hi+lo split bf16 MFMA operands, 3 MFMAs per MAC, fp32 accumulate)', 'bf16': 'bf16 (MFMA operands, fp32 accumulate)',
+                      'f16': 'f16 (IEEE fp16 MFMA operands incl. power-of-two scaled gradient operands, fp32 accumulate, fp32 activations/weights/optimizer)'}[a.prec],
             'data': 'synthetic VoxCeleb2-shaped batch, random-init weights (VGG weights seeded He-normal)',
             'config': {'workload': {'finetune_step': 'finetuning-base.yaml step (configs[1]): G, D, VGG19/VGGFace criterions, RAdam, EMA, spectral '
                                                      'norm on hand-written gfx950 kernels; MobileNetV2 pose encoder on torch-ROCm',
@@ -353,9 +423,21 @@ def main():
                 out['drive'] = drive_fps(args)
             except Exception as ex:
                 out['drive'] = {'error': repr(ex)}
+        if world == 1 and a.prec == 'f16' and a.workload == 'finetune_step' and not a.no_also:
+            # the strict-parity mode (bf16x3: 3 MFMAs per MAC, fp32-class results) measured by the same script in a child process
+            try:
+                import subprocess
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), '--prec', 'bf16x3', '--steps', '20', '--warmup', '5',
+                                    '--no-cpu-baseline', '--no-also'], capture_output=True, text=True, timeout=600)
+                j = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+                out['strict_mode_bf16x3'] = {'value': j['value'], 'unit': j['unit'], 'ms_per_step': j['ms_per_step'],
+                                             'roofline_frac': (j.get('roofline') or {}).get('frac'),
+                                             'parity': 'outputs 2.5e-6, tie-masked gradients 2.7e-5 from the fp32 CPU path (tests/test_full_size_parity.py)'}
+            except Exception as ex:
+                out['strict_mode_bf16x3'] = {'error': repr(ex)}
         if world == 1 and not a.no_cpu_baseline:
             try:
-                out['cpu_baseline'] = cpu_baseline(args)
+                out['cpu_baseline'] = cpu_baseline(args, full=a.cpu_baseline_full)
             except Exception as ex:      # never lose the GPU line because of the baseline leg
                 out['cpu_baseline'] = {'error': repr(ex)}
         print(json.dumps(out))

@@ -1,18 +1,42 @@
-"""Aggregate a rocprofv3 --pmc counter_collection.csv per kernel: mean counter value per launch.
+"""Aggregate rocprofv3 --pmc counter_collection.csv files per kernel: mean counter value per launch.
 
 usage: python scripts/pmc_summary.py <counter_collection.csv> [...]  > summary.csv
-FETCH_SIZE / WRITE_SIZE are reported in KiB by rocprofv3; FETCH_SIZE is doubled as MI355X_MICROARCH.md (HBM section) prescribes
-for wide coalesced reads on gfx950.
-"""
-import csv, sys, collections
+       python scripts/pmc_summary.py --json <kernel name prefix> <counter_collection.csv> [...]  > traffic.json
+FETCH_SIZE / WRITE_SIZE are reported in KiB by rocprofv3; FETCH_SIZE is doubled as MI355X_MICROARCH.md (HBM section) prescribes for
+wide coalesced reads on gfx950.  The --json form sums over every launch of the kernels whose name starts with the prefix (all tile
+variants of one kernel family) -> average HBM bytes per launch, which bench.py reports as roofline.traffic."""
+import collections
+import csv
+import json
+import sys
 
+args = sys.argv[1:]
+prefix = None
+if args and args[0] == '--json':
+    prefix, args = args[1], args[2:]
 acc = collections.defaultdict(lambda: [0, 0.0])
-for path in sys.argv[1:]:
+fam = collections.defaultdict(lambda: [0, 0.0])
+for path in args:
     with open(path) as f:
         for r in csv.DictReader(f):
-            k = ((r.get('Kernel_Name') or r.get('Kernel Name') or '?')[:100] + ' grid=' + str(r.get('Grid_Size', '')), r['Counter_Name'])
+            name = (r.get('Kernel_Name') or r.get('Kernel Name') or '?')
+            k = (name[:100] + ' grid=' + str(r.get('Grid_Size', '')), r['Counter_Name'])
             acc[k][0] += 1
             acc[k][1] += float(r['Counter_Value'])
+            if prefix and prefix in name.split('(')[0]:
+                fam[r['Counter_Name']][0] += 1
+                fam[r['Counter_Name']][1] += float(r['Counter_Value'])
+if prefix:
+    out = {'kernel_family': prefix, 'counters': {c: {'launches': n, 'mean_per_launch': tot / max(n, 1)} for c, (n, tot) in fam.items()}}
+    f_, w_ = fam.get('FETCH_SIZE'), fam.get('WRITE_SIZE')
+    if f_ and w_ and f_[0] and w_[0]:
+        out['hbm_bytes_per_launch'] = int((2 * f_[1] / f_[0] + w_[1] / w_[0]) * 1024)
+        out['note'] = 'mean over all launches of the family in the profiled command: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B'
+    b, g = fam.get('SQ_VALU_MFMA_BUSY_CYCLES'), fam.get('GRBM_GUI_ACTIVE')
+    if b and g and g[1] > 0:
+        out['mfma_busy_fraction'] = round(b[1] / (g[1] * 256 * 4), 4)        # busy cycles summed over 256 CUs x 4 SIMDs / active cycles
+    print(json.dumps(out))
+    sys.exit(0)
 print('kernel,counter,launches,mean_per_launch_raw,mean_bytes_per_launch_corrected')
 rows = []
 for (name, ctr), (n, tot) in acc.items():
