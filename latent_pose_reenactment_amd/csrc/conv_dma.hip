@@ -46,10 +46,13 @@ struct Conv16Params {
     int ksplit;
 };
 
-template <int KS, bool UPS, int WM, int WN, int MR, int NR, int PREC, bool PP, int NBUF = 2>
+template <int KS, bool UPS, int WM, int WN, int MR, int NR, int PREC, bool PP, int NBUF = 2, int CC = 32>
 __global__ __launch_bounds__(WM * WN * 64 * (PP ? 2 : 1), (!PP && NBUF == 2 && WM * WN == 4 && PREC != LP_PREC_BF16X3) ? 2 : 1)
 void conv_dma_kernel(Conv16Params p) {
-    constexpr int CC = 32, ROWB = 64;                    // channels per chunk, bytes per halo pixel / weight row of a chunk
+    constexpr int ROWB = CC * 2;                         // CC channels per chunk; bytes per halo pixel / weight row of a chunk
+    constexpr int SL = CC / 8, RPI = 64 / SL;            // 16-byte slots per row; rows covered by one 1 KiB DMA piece
+    constexpr int KK = CC / 32;                          // k-steps (MFMA 16x16x32) per tap and chunk
+    static_assert(CC == 32 || CC == 64, "32- or 64-channel chunks");
     constexpr bool SPLIT = (PREC == LP_PREC_BF16X3), F16 = (PREC == LP_PREC_F16);
     constexpr int NWAVE = WM * WN;                       // waves of one group
     constexpr int NWD = PP ? 2 * NWAVE : NWAVE;          // waves sharing the weight DMA of a stage
@@ -57,7 +60,7 @@ void conv_dma_kernel(Conv16Params p) {
     constexpr int B_STAGE = KS * BN * ROWB;              // bytes of one weight stage (hi)
     constexpr int B_BUF = B_STAGE * (SPLIT ? 2 : 1);
     constexpr int NQ = B_STAGE / 1024;                   // DMA instructions per stage (hi)
-    constexpr int AIT = (BM == 128) ? (NWAVE == 8 ? 3 : 5) : 6;     // max halo DMA instructions per wave (host checks p.hit <= AIT)
+    constexpr int AIT = ((BM == 128) ? (NWAVE == 8 ? 3 : 5) : 6) * (CC / 32) - (CC == 64 ? 1 : 0);     // max halo DMA instructions per wave (host checks p.hit <= AIT)
     constexpr int NBW = ((NQ + NWD - 1) / NWD) * (SPLIT ? 2 : 1);     // weight DMA instructions one wave issues per stage
     static_assert(B_STAGE % 1024 == 0, "stage must be a whole number of 1 KiB DMA pieces");
     static_assert(NBUF == 2 || (NBUF == 3 && !PP && NQ % NWD == 0), "3-deep weight ring: single group, uniform DMA count per wave");
@@ -99,11 +102,13 @@ void conv_dma_kernel(Conv16Params p) {
         tile_row_linear(m, p.lTH, p.lTW, nb, py, px);
         a_nbbase[mr] = nb * HH * HW; a_py[mr] = py; a_px[mr] = px;
     }
+    // XOR key of row r (halo pixel / weight row): 64-B rows (r >> 1) & 3, 128-B rows r & 7 (scripts/lds_swizzle_sim.py: conflict free)
+    auto rkey = [](int r) { return CC == 32 ? ((r >> 1) & 3) : (r & 7); };
     const int kb = lane >> 4;
-    const int bkey = (lane >> 1) & 3;                  // key of this lane's weight rows: (row >> 1) & 3 with row & 15 == lane & 15
+    const int bkey = rkey(lane & 15);                  // key of this lane's weight rows (row & 15 == lane & 15)
     int b_off[NR];
 #pragma unroll
-    for (int nr = 0; nr < NR; ++nr) b_off[nr] = (wn * (NR * 16) + nr * 16 + (lane & 15)) * ROWB + ((kb ^ bkey) << 4);
+    for (int nr = 0; nr < NR; ++nr) b_off[nr] = (wn * (NR * 16) + nr * 16 + (lane & 15)) * ROWB;
 
     f32x4_t acc[MR][NR];
 #pragma unroll
@@ -111,13 +116,14 @@ void conv_dma_kernel(Conv16Params p) {
 #pragma unroll
         for (int nr = 0; nr < NR; ++nr) acc[mr][nr] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    // ---- halo DMA descriptors (chunk independent).  Piece q = k*NWAVE + wave covers halo pixels 16q .. 16q+15; lane -> pixel
-    // 16q + lane/4, LDS slot lane%4, which holds channel group g = slot ^ ((hp>>1)&3) = (lane&3) ^ ((lane>>3)&3).
-    const int a_g8 = (((lane & 3) ^ ((lane >> 3) & 3))) * 8;
+    // ---- halo DMA descriptors (chunk independent).  Piece q = k*NWAVE + wave covers halo pixels RPI*q .. RPI*q+RPI-1; lane -> pixel
+    // RPI*q + lane/SL, LDS slot lane%SL, which holds channel group g = slot ^ key(pixel); RPI*q is a multiple of 8, so the key only
+    // depends on the lane.
+    const int a_g8 = ((lane % SL) ^ rkey(lane / SL)) * 8;
     int a_off[AIT];                                    // element offset of (pixel, group) in the plane, or -1 (zero page)
 #pragma unroll
     for (int k = 0; k < AIT; ++k) {
-        const int hp = (k * NWAVE + wave) * 16 + (lane >> 2);
+        const int hp = (k * NWAVE + wave) * RPI + lane / SL;
         const int hx = hp % HW, t2 = hp / HW;
         const int hy = t2 % HH, nb = t2 / HH;
         const int n = n0 + nb, iy = oy + hy, ix = ox + hx;
@@ -144,13 +150,13 @@ void conv_dma_kernel(Conv16Params p) {
     auto issue_b = [&](int chunk, int ky, int buf) {
         const int c0 = chunk * CC;
         const unsigned dst_lds = (unsigned)(uintptr_t)(B_base + buf * B_BUF);
-        const int rr = lane >> 2, slot = lane & 3;
-        const int g8 = (slot ^ ((rr >> 1) & 3)) * 8;
+        const int rr = lane / SL, slot = lane % SL;
+        const int g8 = (slot ^ rkey(rr)) * 8;
 #pragma unroll
         for (int q0 = 0; q0 < NQ; q0 += NWD) {
             const int q = q0 + wave_d;
             if (NQ % NWD == 0 || q < NQ) {
-                const int r = q * 16 + rr;                                           // row inside the stage: kx * BN + n
+                const int r = q * RPI + rr;                                          // row inside the stage: kx * BN + n
                 const int kx = r / BN, n = r % BN;
                 const size_t off = ((size_t)((ky * KS + kx) * p.CoutP + co0 + n) * p.CinP + c0 + g8);
                 lp_glds16(p.w_hi + off, dst_lds + q * 1024);
@@ -164,9 +170,12 @@ void conv_dma_kernel(Conv16Params p) {
         const unsigned char* A_lo = Hbuf + a_bytes;
         const unsigned char* Bc = B_base + bbuf * B_BUF;
         s16x8_t fa[2][MR], fb[2][NR], fal[2][MR], fbl[2][NR];
-        auto fetch = [&](int kx, int set) {
+        constexpr int STEPS = KS * KK;
+        auto fetch = [&](int st, int set) {
+            const int kx = st / KK, kk = st % KK;
             const int dy = (KS == 3) ? ky : 0, dx = (KS == 3) ? kx : 0;
             const unsigned char* Bk = Bc + kx * (BN * ROWB);
+            const int grp8 = kk * 4 + kb;                                  // 8-channel group of this lane's fragment slice
 #pragma unroll
             for (int mr = 0; mr < MR; ++mr) {
                 int hy, hx;
@@ -174,21 +183,22 @@ void conv_dma_kernel(Conv16Params p) {
                 else if (UPS) { hy = ((a_py[mr] + dy - 1) >> 1) + 1; hx = ((a_px[mr] + dx - 1) >> 1) + 1; }
                 else { hy = a_py[mr] + dy; hx = a_px[mr] + dx; }
                 const int hp = a_nbbase[mr] + hy * HW + hx;
-                const int off = hp * ROWB + ((kb ^ ((hp >> 1) & 3)) << 4);
+                const int off = hp * ROWB + ((grp8 ^ rkey(hp)) << 4);
                 fa[set][mr] = *(const s16x8_t*)(A_hi + off);
                 if (SPLIT) fal[set][mr] = *(const s16x8_t*)(A_lo + off);
             }
+            const int bsl = (grp8 ^ bkey) << 4;
 #pragma unroll
             for (int nr = 0; nr < NR; ++nr) {
-                fb[set][nr] = *(const s16x8_t*)(Bk + b_off[nr]);
-                if (SPLIT) fbl[set][nr] = *(const s16x8_t*)(Bk + B_STAGE + b_off[nr]);
+                fb[set][nr] = *(const s16x8_t*)(Bk + b_off[nr] + bsl);
+                if (SPLIT) fbl[set][nr] = *(const s16x8_t*)(Bk + B_STAGE + b_off[nr] + bsl);
             }
         };
         fetch(0, 0);
 #pragma unroll
-        for (int kx = 0; kx < KS; ++kx) {
-            const int cur = kx & 1;
-            if (kx + 1 < KS) fetch(kx + 1, cur ^ 1);
+        for (int st = 0; st < STEPS; ++st) {
+            const int cur = st & 1;
+            if (st + 1 < STEPS) fetch(st + 1, cur ^ 1);
 #pragma unroll
             for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
@@ -385,9 +395,9 @@ static void choose_tile(int BM, int N, int H, int W, int* lTH, int* lTW, int* lN
     *lTH = lth; *lTW = ltw; *lNB = lnb;
 }
 
-template <int KS, bool UPS, int WM, int WN, int MR, int NR, int PREC, bool PP, int NBUF = 2>
+template <int KS, bool UPS, int WM, int WN, int MR, int NR, int PREC, bool PP, int NBUF = 2, int CC = 32>
 static int launch_v(Conv16Params& p, size_t lds, dim3 grid, hipStream_t stream) {
-    auto kern = conv_dma_kernel<KS, UPS, WM, WN, MR, NR, PREC, PP, NBUF>;
+    auto kern = conv_dma_kernel<KS, UPS, WM, WN, MR, NR, PREC, PP, NBUF, CC>;
     static thread_local int attr_dev = -1;                 // per host thread and device (main and autograd threads both launch)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return lp_set_error(LP_ERR_HIP, "hipGetDevice failed");
@@ -448,6 +458,8 @@ static int launch_conv16(Conv16Params& p, hipStream_t stream) {
         if (ks > 1 && hipMemsetAsync(p.y, 0, (size_t)p.N * p.H * p.W * p.Cout * sizeof(float), stream) != hipSuccess)
             return lp_set_error(LP_ERR_HIP, "hipMemsetAsync failed");
     }
+    // (64-channel chunks -- CC = 64, twice the MFMAs between two barriers -- were measured 7-15 % SLOWER on the 64^2..256^2 layers: their
+    //  146 KB of LDS leave one workgroup per CU, while the 72 KB of the 32-channel kernel let two ping-pong workgroups share a CU)
     if constexpr (pp_ok) { if (pp) return launch_v<KS, UPS, WM, WN, MR, NR, PREC, true>(p, lds, grid, stream); }
     // 3-deep weight ring when the grid gives each CU at most ~one workgroup (its LDS would exclude a second one anyway) and it fits
     constexpr int NQ = KS * BN * 64 / 1024;
