@@ -47,7 +47,10 @@ struct Conv16Params {
 };
 
 template <int KS, bool UPS, int WM, int WN, int MR, int NR, int PREC, bool PP, int NBUF = 2, int CC = 32>
-__global__ __launch_bounds__(WM * WN * 64 * (PP ? 2 : 1), (!PP && NBUF == 2 && WM * WN == 4 && PREC != LP_PREC_BF16X3) ? 2 : 1)
+#ifndef LP_PP_MINW
+#define LP_PP_MINW 2          // min waves per SIMD of the ping-pong kernels in the 16-bit modes: 2 = one workgroup per CU, 4 = two (<= 128 VGPRs)
+#endif
+__global__ __launch_bounds__(WM * WN * 64 * (PP ? 2 : 1), (PP && PREC != LP_PREC_BF16X3) ? LP_PP_MINW : (!PP && NBUF == 2 && WM * WN == 4 && PREC != LP_PREC_BF16X3) ? 2 : 1)
 void conv_dma_kernel(Conv16Params p) {
     constexpr int ROWB = CC * 2;                         // CC channels per chunk; bytes per halo pixel / weight row of a chunk
     constexpr int SL = CC / 8, RPI = 64 / SL;            // 16-byte slots per row; rows covered by one 1 KiB DMA piece
