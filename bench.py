@@ -182,27 +182,44 @@ def _median_time(fn, warm, reps, budget_s):
     return ts[len(ts) // 2], len(ts)
 
 
+def cpu_worker(spec):
+    """child process of cpu_baseline: `threads,batch,warm,reps,budget,image_size` -> one JSON line {"t": median seconds per step, "n": timed steps}
+    (its own process so that OMP_NUM_THREADS / torch.set_num_threads take effect before any CPU kernel has run)"""
+    threads, batch, warm, reps, budget, image_size = [int(float(v)) for v in spec.split(',')]
+    torch.set_num_threads(threads)
+    args = make_args(image_size, 8, 'cpu', 1, 0, 'bf16x3')
+    t, n = _median_time(_cpu_step(args, batch), warm, reps, budget)
+    print(json.dumps({'t': t, 'n': n, 'threads': torch.get_num_threads()}))
+
+
 def cpu_baseline(args, full=False):
     """The CPU path timed on this box's host cores: the oracle -- the parity-pinned fp32 torch-CPU restatement of
-    the reference -- running the SAME fine-tuning step on the SAME kind of synthetic batch.
+    the reference -- running the SAME fine-tuning step on the SAME kind of synthetic batch, each row in its own process.
       all-core row : bs = 8 (the GPU workload's batch), every physical core, median of the timed steps;
-      1-thread row : how the reference configures itself (torch.set_num_threads(1), utils/utils.py:19), bs = 1 sample of the same step.
-    Default = a bounded sample (1 warm-up + 3 timed all-core steps, 1 + 2 one-thread steps: ~1 minute); --cpu-baseline-full runs the
-    >= 3 warm-up + >= 10 timed protocol."""
+      1-thread row : how the reference configures itself (OMP_NUM_THREADS=1, torch.set_num_threads(1): train.py:2, utils/utils.py:19),
+                     bs = 1 sample of the same step.
+    Default = a bounded sample (1 warm-up + up to 3 timed all-core steps, 1 + up to 2 one-thread steps: 1-2 minutes);
+    --cpu-baseline-full runs the >= 3 warm-up + >= 10 timed protocol."""
+    import subprocess
     model, cores, logical = _cpu_info()
     use = min(cores, 64)       # torch-CPU oversubscribes badly beyond the physical cores
     warm, reps = (3, 10) if full else (1, 3)
-    torch.set_num_threads(use)
-    t_all, n_all = _median_time(_cpu_step(args, 8), warm, reps, 600 if full else 45)
-    torch.set_num_threads(1)
-    t_one, n_one = _median_time(_cpu_step(args, 1), warm if full else 1, reps if full else 2, 900 if full else 40)
-    torch.set_num_threads(use)
-    return {'value': round(8 / t_all, 4), 'unit': 'images/s', 'cores': use, 'kind': 'port', 'cpu_model': model, 'physical_cores': cores,
-            'logical_cpus': logical, 'one_thread': {'value': round(1 / t_one, 4), 'unit': 'images/s', 'cores': 1,
-                                                   'sample': f'median of {n_one} fine-tuning step(s) of 1 image at {args.image_size}x{args.image_size}, torch.set_num_threads(1): {t_one:.2f} s per step'},
-            'sample': f'median of {n_all} fine-tuning step(s) of the bs=8 batch at {args.image_size}x{args.image_size} through oracle/lp_oracle.py '
-                      f'(torch CPU fp32, {use} threads = physical cores of {model}); {t_all:.2f} s per step'
-                      + ('' if full else '; bounded sample -- the >= 3 + >= 10 protocol is `bench.py --cpu-baseline-full`, committed under profiles/')}
+
+    def run(threads, batch, w, r, budget):
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-worker', f'{threads},{batch},{w},{r},{budget},{args.image_size}'],
+                             env=env, capture_output=True, text=True, timeout=budget * 4 + 900)
+        return json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    a = run(use, 8, warm, reps, 600 if full else 45)
+    o = run(1, 1, warm if full else 1, reps if full else 2, 900 if full else 40)
+    return {'value': round(8 / a['t'], 4), 'unit': 'images/s', 'cores': use, 'kind': 'port', 'cpu_model': model, 'physical_cores': cores,
+            'logical_cpus': logical,
+            'one_thread': {'value': round(1 / o['t'], 4), 'unit': 'images/s', 'cores': 1,
+                           'sample': f"median of {o['n']} fine-tuning step(s) of 1 image at {args.image_size}x{args.image_size}, OMP_NUM_THREADS=1 / "
+                                     f"torch.set_num_threads(1): {o['t']:.2f} s per step"},
+            'sample': f"median of {a['n']} fine-tuning step(s) of the bs=8 batch at {args.image_size}x{args.image_size} through oracle/lp_oracle.py "
+                      f"(torch CPU fp32, {use} threads = physical cores of {model}); {a['t']:.2f} s per step"
+                      + ('' if full else '; bounded sample -- the >= 3 + >= 10 protocol is `bench.py --cpu-baseline-full` (profiles/)')}
 
 
 def drive_fps(args, frames=60):
@@ -272,7 +289,10 @@ def main():
     ap.add_argument('--eager', action='store_true', help='do not capture the step into hipGraphs')
     ap.add_argument('--shapes', default=None, help='write the per-shape conv / wgrad timing table of the instrumented steps (CSV)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only for functional tests)')
+    ap.add_argument('--cpu-worker', default=None, help=argparse.SUPPRESS)
     a = ap.parse_args()
+    if a.cpu_worker:
+        return cpu_worker(a.cpu_worker)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))

@@ -32,9 +32,13 @@ if prefix:
     if f_ and w_ and f_[0] and w_[0]:
         out['hbm_bytes_per_launch'] = int((2 * f_[1] / f_[0] + w_[1] / w_[0]) * 1024)
         out['note'] = 'mean over all launches of the family in the profiled command: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B'
-    b, g = fam.get('SQ_VALU_MFMA_BUSY_CYCLES'), fam.get('GRBM_GUI_ACTIVE')
+    b, g, m = fam.get('SQ_VALU_MFMA_BUSY_CYCLES'), fam.get('GRBM_GUI_ACTIVE'), fam.get('SQ_INSTS_VALU_MFMA_MOPS_F16')
     if b and g and g[1] > 0:
-        out['mfma_busy_fraction'] = round(b[1] / (g[1] * 256 * 4), 4)        # busy cycles summed over 256 CUs x 4 SIMDs / active cycles
+        # SQ_VALU_MFMA_BUSY_CYCLES: clocks with an MFMA in a SIMD's matrix pipe, summed over all 1024 SIMDs (checked: 16 per
+        # v_mfma_f32_16x16x32 = SQ_INSTS_VALU_MFMA_MOPS / 32 instructions); GRBM_GUI_ACTIVE: active clocks summed over the 8 XCDs
+        out['mfma_busy_fraction'] = round(b[1] / (g[1] / 8 * 256 * 4), 4)
+    if b and m and m[1] > 0:
+        out['mfma_busy_clocks_per_instruction'] = round(b[1] / (m[1] / 32), 2)   # MOPS counts 512-FLOP units; one 16x16x32 MFMA = 32 of them
     print(json.dumps(out))
     sys.exit(0)
 print('kernel,counter,launches,mean_per_launch_raw,mean_bytes_per_launch_corrected')
