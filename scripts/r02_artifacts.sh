@@ -21,14 +21,17 @@ done
 # PMC: HBM traffic (FETCH_SIZE, WRITE_SIZE) and MFMA utilisation of the conv kernels; each counter set in its own pass
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAVE_CYCLES"; do
   tag=$(echo $c | tr ' ' '+')
-  timeout 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/${R}_pmc_gen_$tag -o ${R} -- python bench.py --workload generator --steps 2 --warmup 1 --no-cpu-baseline > $O/${R}_pmc_gen_$tag.log 2>&1
-  rm -f $O/${R}_pmc_gen_$tag/${R}_kernel_trace.csv
+  case "$c" in *_SIZE) ;; *)       # (FETCH_SIZE / WRITE_SIZE passes over a whole step hang rocprofv3 on this pool: micro-benchmark only)
+    timeout 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/${R}_pmc_gen_$tag -o ${R} -- python bench.py --workload generator --steps 2 --warmup 1 --no-cpu-baseline > $O/${R}_pmc_gen_$tag.log 2>&1
+    rm -f $O/${R}_pmc_gen_$tag/${R}_kernel_trace.csv ;;
+  esac
   PREC=2 REPS=2 WHAT=conv timeout 150 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/${R}_pmc_micro_$tag -o ${R} -- python scripts/conv_micro.py > $O/${R}_pmc_micro_$tag.log 2>&1
   rm -f $O/${R}_pmc_micro_$tag/${R}_kernel_trace.csv
 done
 python scripts/pmc_summary.py $O/${R}_pmc_gen_*/*counter_collection.csv > $O/${R}_pmc_generator_step_f16.csv 2> $O/${R}_pmc_summary.err
 python scripts/pmc_summary.py $O/${R}_pmc_micro_*/*counter_collection.csv > $O/${R}_pmc_conv_micro_f16.csv 2>> $O/${R}_pmc_summary.err
-python scripts/pmc_summary.py --json conv_dma_kernel $O/${R}_pmc_gen_*/*counter_collection.csv > $O/${R}_pmc_conv_dma.json 2>> $O/${R}_pmc_summary.err
+python scripts/pmc_summary.py --json conv_dma_kernel $O/${R}_pmc_micro_*/*counter_collection.csv > $O/${R}_pmc_conv_dma.json 2>> $O/${R}_pmc_summary.err
+python scripts/pmc_summary.py --json conv_dma_kernel $O/${R}_pmc_gen_*/*counter_collection.csv > $O/${R}_pmc_conv_dma_generator_step_mfma.json 2>> $O/${R}_pmc_summary.err
 PREC=2 timeout 120 python scripts/conv_micro.py > $O/${R}_conv_micro_f16.txt 2>&1
 PREC=1 timeout 120 python scripts/conv_micro.py > $O/${R}_conv_micro_bf16x3.txt 2>&1
 cat $O/${R}_bench_f16.json | cut -c1-1500
