@@ -44,7 +44,7 @@ int lp_pack_desc_bytes(void);
 int lp_pack_weights_batch(const void* table, int num_entries, long long total_chunks, void* stream);
 
 /* Operand planes of a conv input: hi (, lo) [N*HW][C8] 16-bit, C8 = C rounded up to 8 (pad channels zero), holding
- *   act(x) * in_scale,  act: pro 0 identity | 1 relu(x*scale[n,c]+shift[n,c]) | 2 relu(x)
+ *   act(x) * in_scale,  act: pro 0 identity | 1 relu(x*scale[n,c]+shift[n,c]) | 2 relu(x) | 3 relu6(x*scale[c]+shift[c])
  * in the operand format of `prec` (bf16 | bf16 hi+lo | fp16, saturating).  Replaces, once per tensor, the instance_norm + mul +
  * add + relu chain of AdaptiveNorm2d/ReLU (generators/common/blocks.py:18-26,70-73) that the reference runs before every conv;
  * the planes feed lp_conv16_fwd (forward / dgrad) and lp_conv16_wgrad.  in_scale: device scalar|NULL.
@@ -108,6 +108,27 @@ int lp_linear_bwd(const float* x, const float* w, const float* g, const float* a
  * (dimages is zeroed, then accumulated with fp32 atomics). */
 int lp_grid_crop_fwd(const float* images, const float* boxes, float* out, int N, int C, int H, int W, int Ho, int Wo, void* stream);
 int lp_grid_crop_bwd(const float* dout, const float* boxes, float* dimages, int N, int C, int H, int W, int Ho, int Wo, void* stream);
+
+/* MobileNetV2 pose encoder, forward (embedders/unsupervised_pose_separate_embResNeXt_segmentation.py:26-28,56-58 = torchvision
+ * mobilenet_v2(num_classes)): the layers that are not dense contractions; the 1x1 convs are lp_conv16_fwd (ksize 1) on planes
+ * written by lp_act_pack (pro 3 = ReLU6 of a per-channel affine) or lp_affine_res.  BatchNorm enters as per-channel
+ * (scale, shift): running statistics in eval mode; lp_bn_stats in train mode.
+ *   lp_stem_conv_s2:  x [N][3][H][W] NCHW fp32, w [Cout][3][3][3] -> y [N][H/2][W/2][Cout]   (3x3, stride 2, pad 1, no bias)
+ *   lp_dwconv3x3_fwd: depthwise 3x3 pad 1 stride 1|2 on relu6(x*in_scale[c]+in_shift[c]) (in_scale NULL: on x), w [C][3][3]
+ *   lp_affine_res:    x = y*scale[c]+shift[c] (+res) over P positions; hi/lo|NULL: also the operand planes [P][C] of x (C % 8 == 0)
+ *   lp_affine_relu6_mean: out [N][C] = mean over HW of relu6(y*scale[c]+shift[c])            (features[18] BN + ReLU6 + avg-pool)
+ *   lp_bn_stats:      train-mode nn.BatchNorm2d over y [P][C] (P = N*H*W): scale = gamma/sqrt(var+eps), shift = beta - mean*scale
+ *                     (biased batch variance), running_mean/var|NULL updated with `momentum` (unbiased variance);
+ *                     workspace: lp_bn_stats_workspace_bytes(P, C) */
+int lp_stem_conv_s2(const float* x, const float* w, float* y, int N, int H, int W, int Cout, void* stream);
+int lp_dwconv3x3_fwd(const float* x, const float* w, const float* in_scale, const float* in_shift, float* y,
+                     int N, int H, int W, int C, int stride, void* stream);
+int lp_affine_res(const float* y, const float* scale, const float* shift, const float* res, float* x, uint16_t* hi, uint16_t* lo,
+                  long long P, int C, int prec, void* stream);
+int lp_affine_relu6_mean(const float* y, const float* scale, const float* shift, float* out, int N, int HW, int C, void* stream);
+long long lp_bn_stats_workspace_bytes(long long P, int C);
+int lp_bn_stats(const float* y, const float* gamma, const float* beta, float* running_mean, float* running_var, float* scale,
+                float* shift, float* workspace, long long P, int C, float eps, float momentum, void* stream);
 
 /* Instance-norm statistics of x [N][H*W][C] and the AdaIN scale/shift derived from them (blocks.py:18-26):
  *   mean/rstd [N][C] (biased variance, eps), scale = rstd*gamma, shift = beta - mean*scale.

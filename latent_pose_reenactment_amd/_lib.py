@@ -39,6 +39,12 @@ SIGNATURES = {
     'lp_linear_bwd': (_i, [_vp] * 8 + [_i, _i, _i, _vp]),
     'lp_grid_crop_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'lp_grid_crop_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'lp_stem_conv_s2': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'lp_dwconv3x3_fwd': (_i, [_vp] * 5 + [_i] * 5 + [_vp]),
+    'lp_affine_res': (_i, [_vp] * 7 + [_ll, _i, _i, _vp]),
+    'lp_affine_relu6_mean': (_i, [_vp] * 4 + [_i, _i, _i, _vp]),
+    'lp_bn_stats_workspace_bytes': (_ll, [_ll, _i]),
+    'lp_bn_stats': (_i, [_vp] * 8 + [_ll, _i, _f, _f, _vp]),
     'lp_instnorm_workspace_bytes': (_ll, [_i, _i, _i]),
     'lp_instnorm_stats': (_i, [_vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'lp_adain_bwd_workspace_bytes': (_ll, [_i, _i, _i]),

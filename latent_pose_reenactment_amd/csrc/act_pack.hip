@@ -54,6 +54,9 @@ __global__ __launch_bounds__(256) void act_pack_kernel(const float* __restrict__
     const int n = blockIdx.y;
     const bool vec = (C & 3) == 0;
     const float lo_clamp = (pro != 0) ? 0.f : -3.0e38f;
+    const float hi_clamp = (pro == 3) ? 6.f : 3.0e38f;          // pro 3 = ReLU6 of a per-channel (batch-norm) affine
+    const bool aff = (pro == 1 || pro == 3);
+    const size_t aoff = (pro == 1) ? (size_t)n * C : 0;
     const float* xn = x + (size_t)n * HW * C;
     uint16_t* hn = hi + (size_t)n * HW * C8;
     uint16_t* ln = SPLIT ? lo + (size_t)n * HW * C8 : nullptr;
@@ -63,8 +66,8 @@ __global__ __launch_bounds__(256) void act_pack_kernel(const float* __restrict__
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int c = (int)g * 8 + j;
-            sc[j] = (pro == 1 && c < C) ? scale[(size_t)n * C + c] : 1.f;
-            sf[j] = (pro == 1 && c < C) ? shift[(size_t)n * C + c] : 0.f;
+            sc[j] = (aff && c < C) ? scale[aoff + c] : 1.f;
+            sf[j] = (aff && c < C) ? shift[aoff + c] : 0.f;
         }
     };
     unsigned i0 = blockIdx.x * 256u + threadIdx.x;
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(256) void act_pack_kernel(const float* __restrict__
                 s16x8_t h, l;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    float q = fmaxf(fmaf(v[u][j], sc[j], sf[j]), lo_clamp) * isc;
+                    float q = fminf(fmaxf(fmaf(v[u][j], sc[j], sf[j]), lo_clamp), hi_clamp) * isc;
                     q = (c + j < C) ? q : 0.f;
                     const uint16_t hb = lp_f32_to_op16<F16>(q);
                     h[j] = (short)hb;
@@ -113,7 +116,7 @@ extern "C" int lp_act_pack(const float* x, const float* scale, const float* shif
                            int N, int HW, int C, int prec, const float* in_scale, const float* amax_part, float* scale_out,
                            void* stream) {
     if (!x || !hi) return lp_set_error(LP_ERR_ARG, "lp_act_pack: null pointer");
-    if (pro == 1 && (!scale || !shift)) return lp_set_error(LP_ERR_ARG, "lp_act_pack: pro=1 needs scale/shift");
+    if ((pro == 1 || pro == 3) && (!scale || !shift)) return lp_set_error(LP_ERR_ARG, "lp_act_pack: pro=1|3 needs scale/shift");
     if (prec == LP_PREC_BF16X3 && !lo) return lp_set_error(LP_ERR_ARG, "lp_act_pack: bf16x3 needs the lo plane");
     const int C8 = (C + 7) & ~7;
     const long long items = (long long)HW * (C8 >> 3);          // per image

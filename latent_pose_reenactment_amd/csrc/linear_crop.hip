@@ -136,7 +136,7 @@ static int linear_blocks(int N) { int b = (N + 3) / 4; return b > 512 ? 512 : (b
 
 extern "C" int lp_linear_fwd(const float* x, const float* w, const float* bias, const float* alpha, float* y, int B, int N, int K, void* stream) {
     if (!x || !w || !y) return lp_set_error(LP_ERR_ARG, "lp_linear_fwd: null pointer");
-    if (B < 1 || B > 64 || (K & 3) || K > LIN_MAXK) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_linear_fwd: needs 1 <= B <= 64, K % 4 == 0, K <= 1024");
+    if (B < 1 || B > 64 || (K & 3) || K > 2 * LIN_MAXK) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_linear_fwd: needs 1 <= B <= 64, K % 4 == 0, K <= 2048");
     dim3 grid(linear_blocks(N), (B + LIN_BT - 1) / LIN_BT);
     hipLaunchKernelGGL(linear_fwd_kernel, grid, dim3(256), (size_t)LIN_BT * K * sizeof(float), (hipStream_t)stream, x, w, bias, alpha, y, B, N, K);
     return lp_check_launch("linear_fwd");

@@ -7,9 +7,9 @@
 //   affine_res     x = y*scale[c] + shift[c] (+ residual): the linear BatchNorm that ends an inverted-residual block, also emitting
 //                  the 16-bit operand planes of x for the next block's 1x1 expand conv
 //   affine_relu6_mean   global average pool of relu6(BatchNorm(y)) -> [N][C] (input of the classifier)
-//   bn_running_update   running_mean / running_var momentum update from batch statistics (train-mode BatchNorm)
-// BatchNorm appears as a per-channel (scale, shift): from the running statistics in eval mode, from lp_instnorm_stats over the whole
-// batch (N*H*W positions per channel) in train mode.
+//   bn_stats       train-mode BatchNorm: batch statistics over the N*H*W positions of a channel -> (scale, shift), running_mean /
+//                  running_var momentum update, in two launches
+// BatchNorm appears as a per-channel (scale, shift): from the running statistics in eval mode, from lp_bn_stats in train mode.
 #include "lp_common.h"
 #include "lp_hip.h"
 #include "lp_internal.h"
@@ -173,23 +173,168 @@ extern "C" int lp_affine_relu6_mean(const float* y, const float* scale, const fl
     return lp_check_launch("affine_relu6_mean");
 }
 
-// train-mode BatchNorm bookkeeping: running_mean <- (1-m) running_mean + m mean;  running_var <- (1-m) running_var + m var * n/(n-1),
-// var = 1/rstd^2 - eps (lp_instnorm_stats hands out the biased batch variance as rstd)
-__global__ void bn_running_update_kernel(const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ rm, float* __restrict__ rv,
-                                         int C, float momentum, float eps, float unbias) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const float r = rstd[c];
-    const float var = 1.f / (r * r) - eps;
-    rm[c] = (1.f - momentum) * rm[c] + momentum * mean[c];
-    rv[c] = (1.f - momentum) * rv[c] + momentum * var * unbias;
+// ---- train-mode BatchNorm: batch statistics of y [P][C] -> (scale, shift), running-statistics update ------------------------------
+// Pass 1: the tensor is a stream of float4 channel groups; the grid's thread count is trimmed to a multiple of the C/4 groups per
+// position, so a thread meets the same 4 channels on every step and keeps (count, mean, M2) for them in registers (shifted by the
+// first value it sees: no cancellation at large |mean|/std).  Pass 2: one block per channel group merges the per-thread partials
+// (Chan et al. pairwise update), writes scale = gamma*rstd, shift = beta - mean*scale and the momentum update of running_mean /
+// running_var (unbiased variance, as nn.BatchNorm2d does).
+
+__device__ __forceinline__ void bn_merge(float& n_a, float& mean_a, float& m2_a, float n_b, float mean_b, float m2_b) {
+    if (n_b == 0.f) return;
+    if (n_a == 0.f) { n_a = n_b; mean_a = mean_b; m2_a = m2_b; return; }
+    const float n = n_a + n_b, d = mean_b - mean_a;
+    mean_a += d * (n_b / n);
+    m2_a += m2_b + d * d * (n_a * n_b / n);
+    n_a = n;
 }
 
-extern "C" int lp_bn_running_update(const float* mean, const float* rstd, float* running_mean, float* running_var, int C, float momentum,
-                                    float eps, long long count, void* stream) {
-    if (!mean || !rstd || !running_mean || !running_var) return lp_set_error(LP_ERR_ARG, "lp_bn_running_update: null pointer");
-    const float unbias = count > 1 ? (float)((double)count / (double)(count - 1)) : 1.f;
-    hipLaunchKernelGGL(bn_running_update_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, mean, rstd, running_mean, running_var, C,
-                       momentum, eps, unbias);
-    return lp_check_launch("bn_running_update");
+// launch shape: G4 <= 256: every block uses BT = 256 - 256 % G4 threads, so thread tid owns group tid % G4 and the block folds its
+// BT / G4 threads per group in LDS -> one partial per (block, group).  G4 > 256 (C = 1280: a few hundred positions): one partial per
+// thread of a grid trimmed to a multiple of G4.  Either way the partials of group g sit at the indices = g (mod G4) below `Tu`.
+struct BnShape { int blocks, BT, Tu, T; };
+static BnShape bn_shape(long long P, int C) {
+    const long long G4 = C >> 2, items = P * G4;
+    BnShape s;
+    if (G4 <= 256) {
+        s.BT = 256 - 256 % (int)G4;
+        long long nb = (items + 8ll * s.BT - 1) / (8ll * s.BT);       // >= 8 float4 per thread where the tensor is large enough
+        s.blocks = (int)(nb > 512 ? 512 : (nb < 1 ? 1 : nb));
+        s.Tu = s.blocks * (int)G4; s.T = s.Tu;
+    } else {
+        long long T = (items + 7) / 8;
+        if (T > 32768) T = 32768;
+        if (T < G4) T = G4;
+        T = (T + 255) / 256 * 256;
+        s.blocks = (int)(T / 256); s.BT = 256; s.T = (int)T; s.Tu = (int)(T - T % G4);
+    }
+    return s;
+}
+
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, float* __restrict__ part, long long items, int G4, int BT,
+                                                         int Tu, int T) {
+    __shared__ float sh[9][256];
+    const bool fold = G4 <= 256;
+    const long long stride = fold ? (long long)gridDim.x * BT : Tu;
+    const long long t0 = fold ? (long long)blockIdx.x * BT + threadIdx.x : (long long)blockIdx.x * 256 + threadIdx.x;
+    const bool active = fold ? (int)threadIdx.x < BT : t0 < Tu;
+    float cnt = 0.f, ref[4] = {0, 0, 0, 0}, sd[4] = {0, 0, 0, 0}, sq[4] = {0, 0, 0, 0};
+    if (active) {
+        long long i = t0;
+        for (; i + 3 * stride < items; i += 4 * stride) {                  // 4 loads in flight
+            float4 q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) q[u] = *(const float4*)(x + (i + u * stride) * 4);
+            if (cnt == 0.f) { ref[0] = q[0].x; ref[1] = q[0].y; ref[2] = q[0].z; ref[3] = q[0].w; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float d;
+                d = q[u].x - ref[0]; sd[0] += d; sq[0] = fmaf(d, d, sq[0]);
+                d = q[u].y - ref[1]; sd[1] += d; sq[1] = fmaf(d, d, sq[1]);
+                d = q[u].z - ref[2]; sd[2] += d; sq[2] = fmaf(d, d, sq[2]);
+                d = q[u].w - ref[3]; sd[3] += d; sq[3] = fmaf(d, d, sq[3]);
+            }
+            cnt += 4.f;
+        }
+        for (; i < items; i += stride) {
+            const float4 q = *(const float4*)(x + i * 4);
+            if (cnt == 0.f) { ref[0] = q.x; ref[1] = q.y; ref[2] = q.z; ref[3] = q.w; }
+            float d;
+            d = q.x - ref[0]; sd[0] += d; sq[0] = fmaf(d, d, sq[0]);
+            d = q.y - ref[1]; sd[1] += d; sq[1] = fmaf(d, d, sq[1]);
+            d = q.z - ref[2]; sd[2] += d; sq[2] = fmaf(d, d, sq[2]);
+            d = q.w - ref[3]; sd[3] += d; sq[3] = fmaf(d, d, sq[3]);
+            cnt += 1.f;
+        }
+    }
+    float mean[4], m2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        mean[j] = 0.f; m2[j] = 0.f;
+        if (cnt > 0.f) { mean[j] = ref[j] + sd[j] / cnt; m2[j] = fmaxf(sq[j] - sd[j] * sd[j] / cnt, 0.f); }
+    }
+    if (!fold) {                                                            // SoA [9][T], one partial per thread
+        part[t0] = cnt;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { part[(size_t)(1 + j) * T + t0] = mean[j]; part[(size_t)(5 + j) * T + t0] = m2[j]; }
+        return;
+    }
+    sh[0][threadIdx.x] = cnt;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sh[1 + j][threadIdx.x] = mean[j]; sh[5 + j][threadIdx.x] = m2[j]; }
+    __syncthreads();
+    if ((int)threadIdx.x < G4) {
+        for (int k = threadIdx.x + G4; k < BT; k += G4) {
+            const float nb = sh[0][k];
+            float na = cnt;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { na = cnt; bn_merge(na, mean[j], m2[j], nb, sh[1 + j][k], sh[5 + j][k]); }
+            cnt = na;
+        }
+        const size_t o = (size_t)blockIdx.x * G4 + threadIdx.x;
+        part[o] = cnt;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { part[(size_t)(1 + j) * T + o] = mean[j]; part[(size_t)(5 + j) * T + o] = m2[j]; }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* __restrict__ rm, float* __restrict__ rv, float* __restrict__ scale,
+                                                          float* __restrict__ shift, int G4, int Tu, int T, float eps, float momentum) {
+    __shared__ float sh[9][256];
+    const int g = blockIdx.x;
+    float n = 0.f, mean[4] = {0, 0, 0, 0}, m2[4] = {0, 0, 0, 0};
+    for (int t = g + threadIdx.x * G4; t < Tu; t += 256 * G4) {
+        const float nb = part[t];
+        float na = n;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { na = n; bn_merge(na, mean[j], m2[j], nb, part[(size_t)(1 + j) * T + t], part[(size_t)(5 + j) * T + t]); }
+        n = na;
+    }
+    sh[0][threadIdx.x] = n;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sh[1 + j][threadIdx.x] = mean[j]; sh[5 + j][threadIdx.x] = m2[j]; }
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            const float nb = sh[0][threadIdx.x + o];
+            float na = sh[0][threadIdx.x];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                na = sh[0][threadIdx.x];
+                bn_merge(na, sh[1 + j][threadIdx.x], sh[5 + j][threadIdx.x], nb, sh[1 + j][threadIdx.x + o], sh[5 + j][threadIdx.x + o]);
+            }
+            sh[0][threadIdx.x] = na;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) {
+        const int j = threadIdx.x, c = g * 4 + j;
+        const float cntf = sh[0][0], m = sh[1 + j][0], var = sh[5 + j][0] / cntf;
+        const float sc = gamma[c] / sqrtf(var + eps);
+        scale[c] = sc; shift[c] = beta[c] - m * sc;
+        if (rm) {
+            const float unbias = cntf > 1.f ? cntf / (cntf - 1.f) : 1.f;
+            rm[c] = (1.f - momentum) * rm[c] + momentum * m;
+            rv[c] = (1.f - momentum) * rv[c] + momentum * var * unbias;
+        }
+    }
+}
+
+extern "C" long long lp_bn_stats_workspace_bytes(long long P, int C) { return 9ll * bn_shape(P, C).T * (long long)sizeof(float); }
+
+extern "C" int lp_bn_stats(const float* y, const float* gamma, const float* beta, float* running_mean, float* running_var, float* scale,
+                           float* shift, float* workspace, long long P, int C, float eps, float momentum, void* stream) {
+    if (!y || !gamma || !beta || !scale || !shift || !workspace) return lp_set_error(LP_ERR_ARG, "lp_bn_stats: null pointer");
+    if ((C & 3) || P < 1 || (!running_mean != !running_var)) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_bn_stats: needs C % 4 == 0, P >= 1");
+    const int G4 = C >> 2;
+    const BnShape sp = bn_shape(P, C);
+    const int T = sp.T, Tu = sp.Tu;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_partial_kernel, dim3(sp.blocks), dim3(256), 0, st, y, workspace, P * G4, G4, sp.BT, Tu, T);
+    int rc = lp_check_launch("bn_partial");
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(G4), dim3(256), 0, st, workspace, gamma, beta, running_mean, running_var, scale, shift, G4, Tu, T,
+                       eps, momentum);
+    return lp_check_launch("bn_finalize");
 }

@@ -2,13 +2,38 @@
 
 The reference instantiates both from torchvision (embedders/unsupervised_pose_separate_embResNeXt_segmentation.py:26-28),
 which is an un-vendored dependency and absent from this image; these are restatements of the public architectures
-(He et al. / Xie et al. ResNeXt; Sandler et al. MobileNetV2) so that reference checkpoints load by key.  They run on
-stock PyTorch-ROCm ops: the embedder is the LAST row of the hot-path plan, not yet hand-written HIP."""
+(He et al. / Xie et al. ResNeXt; Sandler et al. MobileNetV2) so that reference checkpoints load by key.
+
+MobileNetV2 (the pose encoder) has a hand-written HIP forward for the calls made with autograd off -- the fine-tuning train step (the
+embedder is frozen and called under ``no_grad``, runners/holycow.py:178-182 of the reference) and ``drive.py``: 1x1 convs on
+``lp_conv16_fwd``, stem / depthwise / BatchNorm-ReLU6 / pooling on the kernels of csrc/mobilenet.hip, BatchNorm in either mode
+(batch statistics + running-stat update, or running statistics); parity: tests/test_mobilenet_hip.py.  It is selected with
+LP_EMBEDDER_HIP=1: measured inside a hipGraph it is still SLOWER than the stock PyTorch-ROCm layers (B=1 eval 0.90 ms vs 0.60 ms,
+B=8 train 2.05 ms vs 1.40 ms: the encoder is ~200 launches of a few microseconds each, and the MFMA conv kernel's fixed cost per
+launch is tuned for the generator's layers, not for 8x8x960 maps), so the default stays on the stock layers until the small-map
+path is competitive.  With autograd on (meta-training trains the embedder) and for the ResNeXt-50 identity encoder the layers
+are stock PyTorch-ROCm ops (last row of the hot-path plan)."""
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
 
 _PENDING_COUNTERS = []
+_HIP_FORWARD = [os.environ.get('LP_EMBEDDER_HIP', '0') == '1']       # set_hip_forward() / LP_EMBEDDER_HIP=1
+
+
+def set_hip_forward(on: bool):
+    """route MobileNetV2's no-grad forward through the HIP kernels (default: LP_EMBEDDER_HIP=1 in the environment)"""
+    _HIP_FORWARD[0] = bool(on)
+
+
+def _embedder_prec():
+    """Operand precision of the encoder's 1x1 convs.  52 BatchNorm-renormalised layers amplify operand rounding (fp16 operands: 6e-3 on
+    the pose embedding, bf16 hi+lo: 1e-5) and the whole encoder is ~0.3 GFLOP per frame, so the default here is the strict bf16x3
+    mode whatever LP_PREC says for the generator / critic / VGG convs; LP_EMBEDDER_PREC = f16 | bf16 | bf16x3 overrides."""
+    from latent_pose_reenactment_amd.nn import PREC_NAMES
+    return PREC_NAMES[os.environ.get('LP_EMBEDDER_PREC', 'bf16x3')]
 
 
 class _BatchNorm2d(nn.BatchNorm2d):
@@ -136,9 +161,94 @@ class MobileNetV2(nn.Module):
                 nn.init.zeros_(m.bias)
 
     def forward(self, x):
+        if _HIP_FORWARD[0] and x.is_cuda and not torch.is_grad_enabled() and x.dim() == 4 and x.shape[1] == 3 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 \
+                and x.shape[0] <= 64:
+            return self._forward_hip(x)
         x = self.features(x)
         _flush_bn_counters()
         return self.classifier(x.mean([2, 3]))
+
+    # ---- HIP forward (no autograd) ---------------------------------------------------------------------------------------------
+    def _pointwise_convs(self):
+        out = []
+        for blk in list(self.features)[1:-1]:
+            layers = list(blk.conv)
+            if len(layers) == 4:
+                out.append(layers[0][0])
+            out.append(layers[-2])
+        out.append(self.features[-1][0])
+        return out
+
+    def _hip_state(self, prec):
+        """16-bit packs of the 1x1 conv weights (ONE batched launch) and, for eval-mode BatchNorms, the (scale, shift) of the running
+        statistics; rebuilt when a weight / buffer changed (``_version``, or the fused optimizer's generation counter)."""
+        from latent_pose_reenactment_amd import hipops as ops
+        from latent_pose_reenactment_amd.optim import WEIGHTS_GENERATION
+        tens = self.__dict__.get('_hip_tensors')
+        if tens is None:
+            tens = self.__dict__['_hip_tensors'] = list(self.parameters()) + [b for b in self.buffers() if b.dtype == torch.float32]
+        key = (prec, WEIGHTS_GENERATION[0], self.features[0][1].training, sum(t._version for t in tens), tens[0].data_ptr())
+        st = self.__dict__.get('_hip_cache')
+        if st is not None and st[0] == key:
+            return st[1], st[2]
+        convs = self._pointwise_convs()
+        pb = self.__dict__.get('_hip_packbatch')
+        specs = [(c.weight.detach(), 0, False) for c in convs]
+        if pb is None or pb.prec != prec or pb.key != tuple((w.data_ptr(), m_, bool(k_)) for w, m_, k_ in specs):
+            pb = self.__dict__['_hip_packbatch'] = ops.PackBatch(specs, prec)      # buffers + descriptor table: allocated once
+        packs = dict(zip(convs, pb.update()))                                          # ONE launch (graph-capturable)
+        affines = {}
+        bns = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d) and not m.training]
+        if bns:
+            # eval mode: all BatchNorms folded to (scale, shift) by four multi-tensor ops
+            sc = torch._foreach_add([m.running_var for m in bns], bns[0].eps)
+            torch._foreach_rsqrt_(sc)
+            torch._foreach_mul_(sc, [m.weight.detach() for m in bns])
+            sh = torch._foreach_mul([m.running_mean for m in bns], sc)
+            sh = torch._foreach_sub([m.bias.detach() for m in bns], sh)
+            affines = {m: (a, b) for m, a, b in zip(bns, sc, sh)}
+        self.__dict__['_hip_cache'] = (key, packs, affines)
+        return packs, affines
+
+    def _forward_hip(self, x):
+        from latent_pose_reenactment_amd import hipops as ops
+        prec = _embedder_prec()
+        packs, affines = self._hip_state(prec)
+        counters = []
+
+        def bn(m, y):
+            if not m.training:
+                return affines[m]
+            if m.track_running_stats:
+                counters.append(m.num_batches_tracked)
+            return ops.bn_batch_affine(y, m.weight.detach(), m.bias.detach(), m.running_mean, m.running_var, m.momentum, m.eps)
+
+        feats = list(self.features)
+        x = x.contiguous().float()
+        y = ops.stem_conv_s2(x, feats[0][0].weight.detach())
+        pend = (y,) + tuple(bn(feats[0][1], y))          # raw conv output + the BatchNorm-ReLU6 its consumer applies while loading
+        cur = cur16 = None
+        for blk in feats[1:-1]:
+            layers = list(blk.conv)
+            if len(layers) == 4:
+                ye = ops.conv16(cur16, packs[layers[0][0]], ksize=1, prec=prec)
+                pend = (ye,) + tuple(bn(layers[0][1], ye))
+            dw, pw, pbn = layers[-3], layers[-2], layers[-1]
+            yd = ops.dwconv3x3(pend[0], dw[0].weight.detach(), dw[0].stride[0], pend[1], pend[2])
+            s, t = bn(dw[1], yd)
+            a = ops.act_pack(yd, pro=3, scale=s, shift=t, prec=prec)
+            yp = ops.conv16(a, packs[pw], ksize=1, prec=prec)
+            s, t = bn(pbn, yp)
+            cur, cur16 = ops.affine_res(yp, s, t, cur if blk.use_res else None, prec)
+        last = feats[-1]
+        yl = ops.conv16(cur16, packs[last[0]], ksize=1, prec=prec)
+        s, t = bn(last[1], yl)
+        pooled = ops.affine_relu6_mean(yl, s, t)
+        if counters:
+            torch._foreach_add_(counters, 1)
+        drop, fc = self.classifier[0], self.classifier[1]
+        pooled = F.dropout(pooled, drop.p, drop.training)
+        return ops.linear_fwd(pooled, fc.weight.detach(), fc.bias.detach(), None)
 
 
 def mobilenet_v2(num_classes=1000):

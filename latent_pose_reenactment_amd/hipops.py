@@ -137,7 +137,8 @@ def _alloc16(n, h, w, c, prec, device):
 
 def act_pack(x: Tensor, *, pro: int = 0, scale: Optional[Tensor] = None, shift: Optional[Tensor] = None, prec: int = PREC_BF16,
              grad: bool = False) -> Act16:
-    """x [N,H,W,C] fp32 -> operand planes of act(x): pro 0 identity | 1 relu(x*scale[n,c]+shift[n,c]) | 2 relu(x).
+    """x [N,H,W,C] fp32 -> operand planes of act(x): pro 0 identity | 1 relu(x*scale[n,c]+shift[n,c]) | 2 relu(x) |
+    3 relu6(x*scale[c]+shift[c]).
     ``grad``: x is a gradient (dY): in fp16 mode it is scaled by a power of two taken from its amax (two extra small launches) so
     that it sits in the fp16 normal range; the consumer gets 1/scale through ``Act16.inv``."""
     _chk(x, 'x')
@@ -306,8 +307,8 @@ def conv_wgrad(x: Tensor, dy: Tensor, *, ksize: int, upsample: bool = False, pro
     return conv_wgrad16(a, d, ksize=ksize, upsample=upsample, prec=prec, splits=splits, sn=sn, accum=accum, bias_grad=bias_grad)
 
 
-def linear_supported(b: int, k: int) -> bool:
-    return 1 <= b <= 64 and k % 4 == 0 and k <= 1024
+def linear_supported(b: int, k: int, fwd_only: bool = False) -> bool:
+    return 1 <= b <= 64 and k % 4 == 0 and k <= (2048 if fwd_only else 1024)
 
 
 def linear_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor], alpha: Optional[Tensor]) -> Tensor:
@@ -351,6 +352,63 @@ def grid_crop_bwd(dout: Tensor, boxes: Tensor, in_shape) -> Tensor:
     check(_lib.lib().lp_grid_crop_bwd(dout.data_ptr(), boxes.data_ptr(), dimg.data_ptr(), n, c, h, w, dout.shape[2], dout.shape[3], _stream()),
           'lp_grid_crop_bwd')
     return dimg
+
+
+# ---- MobileNetV2 pose encoder (forward): layers that are not dense contractions ------------------------------------------------
+def stem_conv_s2(x: Tensor, w: Tensor) -> Tensor:
+    """x [N,3,H,W] NCHW fp32, w [Cout,3,3,3] -> y [N,H/2,W/2,Cout] NHWC (3x3, stride 2, pad 1)"""
+    _chk(x, 'x'); _chk(w, 'w')
+    n, c, h, wd = x.shape
+    assert c == 3 and tuple(w.shape[1:]) == (3, 3, 3), (x.shape, w.shape)
+    y = torch.empty((n, h // 2, wd // 2, w.shape[0]), dtype=torch.float32, device=x.device)
+    check(_lib.lib().lp_stem_conv_s2(x.data_ptr(), w.data_ptr(), y.data_ptr(), n, h, wd, w.shape[0], _stream()), 'lp_stem_conv_s2')
+    return y
+
+
+def dwconv3x3(x: Tensor, w: Tensor, stride: int, in_scale: Optional[Tensor] = None, in_shift: Optional[Tensor] = None) -> Tensor:
+    """depthwise 3x3 (pad 1) of relu6(x*in_scale[c]+in_shift[c]) (or of x); x [N,H,W,C] NHWC, w [C,1,3,3]"""
+    _chk(x, 'x'); _chk(w, 'w')
+    n, h, wd, c = x.shape
+    assert w.numel() == c * 9
+    y = torch.empty((n, (h + stride - 1) // stride, (wd + stride - 1) // stride, c), dtype=torch.float32, device=x.device)
+    check(_lib.lib().lp_dwconv3x3_fwd(x.data_ptr(), w.data_ptr(), _p(in_scale), _p(in_shift), y.data_ptr(), n, h, wd, c, stride, _stream()),
+          'lp_dwconv3x3_fwd')
+    return y
+
+
+def affine_res(y: Tensor, scale: Tensor, shift: Tensor, res: Optional[Tensor] = None, prec: Optional[int] = None):
+    """x = y*scale[c]+shift[c] (+res), NHWC; with ``prec`` also the operand planes of x -> (x, Act16)"""
+    _chk(y, 'y')
+    n, h, w, c = y.shape
+    x = torch.empty_like(y)
+    hi = lo = None
+    if prec is not None:
+        hi, lo = _alloc16(n, h, w, c, prec, y.device)
+    check(_lib.lib().lp_affine_res(y.data_ptr(), scale.data_ptr(), shift.data_ptr(), _p(res), x.data_ptr(), _p(hi), _p(lo), n * h * w, c,
+                                   prec if prec is not None else 0, _stream()), 'lp_affine_res')
+    return x if prec is None else (x, Act16(hi, lo, c, None))
+
+
+def affine_relu6_mean(y: Tensor, scale: Tensor, shift: Tensor) -> Tensor:
+    _chk(y, 'y')
+    n, h, w, c = y.shape
+    out = torch.empty((n, c), dtype=torch.float32, device=y.device)
+    check(_lib.lib().lp_affine_relu6_mean(y.data_ptr(), scale.data_ptr(), shift.data_ptr(), out.data_ptr(), n, h * w, c, _stream()),
+          'lp_affine_relu6_mean')
+    return out
+
+
+def bn_batch_affine(y: Tensor, weight: Tensor, bias: Tensor, running_mean: Optional[Tensor], running_var: Optional[Tensor],
+                    momentum: float, eps: float) -> Tuple[Tensor, Tensor]:
+    """train-mode BatchNorm2d of y [N,H,W,C] as a per-channel (scale, shift), updating the running statistics in place"""
+    n, h, w, c = y.shape
+    _chk(y, 'y')
+    p = n * h * w
+    scale = torch.empty(2 * c, dtype=torch.float32, device=y.device)
+    ws = torch.empty(_lib.lib().lp_bn_stats_workspace_bytes(p, c) // 4, dtype=torch.float32, device=y.device)
+    check(_lib.lib().lp_bn_stats(y.data_ptr(), weight.data_ptr(), bias.data_ptr(), _p(running_mean), _p(running_var), scale.data_ptr(),
+                                 scale[c:].data_ptr(), ws.data_ptr(), p, c, eps, momentum, _stream()), 'lp_bn_stats')
+    return scale[:c], scale[c:]
 
 
 def sn_grad_apply(g: Tensor, w_orig: Tensor, u: Tensor, v: Tensor, sig: Tensor, accum: Optional[Tensor] = None) -> Optional[Tensor]:

@@ -1,0 +1,44 @@
+"""Pose-encoder (MobileNetV2) forward: HIP path vs the stock torch-ROCm layers, eager and inside a hipGraph.
+usage: python scripts/mobilenet_micro.py [B] [eval|train]"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from latent_pose_reenactment_amd.embedders.backbones import mobilenet_v2  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+mode = sys.argv[2] if len(sys.argv) > 2 else 'eval'
+net = mobilenet_v2(256).cuda().train(mode == 'train')
+x = torch.rand(B, 3, 256, 256, device='cuda') * 2 - 1
+
+
+def torch_path(t):
+    return net.classifier(net.features(t).mean([2, 3]))
+
+
+def timeit(fn, iters=50):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters * 1e3
+
+
+with torch.no_grad():
+    for name, f in (('hip', net), ('torch', torch_path)):
+        eager = timeit(lambda: f(x))
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            f(x)
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=s):
+                f(x)
+        graph = timeit(g.replay)
+        print(f'mobilenet_v2 B={B} {mode} {name}: eager {eager:.3f} ms, hipGraph {graph:.3f} ms')
