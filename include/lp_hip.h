@@ -63,12 +63,15 @@ int lp_amax_partial(const float* x, long long numel, float* part, void* stream);
  *   res [N][H>>res_shift][W>>res_shift][Cout]|NULL, alpha, alpha2: device scalars|NULL (=1; 1/sigma and 1/in_scale).  ksize 1|3.
  *   relu_mask16 [N][H][W][Co8]|NULL: 16-bit activation plane; y is zeroed where it is <= 0 -- the backward of the ReLU that produced
  *   the operand of the conv whose data gradient this launch computes (replaces a dx = dA * (x > 0) pass; blocks.py:71-73,84).
- *   out_hi/out_lo [N][H][W][Co8]|NULL: also emit the operand planes of (out_relu ? relu(y) : y) for the consumer conv. */
+ *   out_hi/out_lo [N][H][W][Co8]|NULL: also emit the operand planes of (out_relu ? relu(y) : y) for the consumer conv.
+ *   workspace (lp_conv16_fwd_workspace_bytes(); 0 = never needed) | NULL: split-K partial tiles for the layers whose output tiling
+ *   cannot fill the chip (4x4 .. 16x16 maps); without it those layers run unsplit. */
 int lp_conv16_fwd(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* w_hi, const uint16_t* w_lo, float* y,
                   const float* bias, const float* res, const float* alpha, const float* alpha2,
                   int N, int H, int W, int Cin, int Cout, int CinP, int CoutP,
                   int ksize, int upsample, int res_shift, int prec, const uint16_t* relu_mask16,
-                  uint16_t* out_hi, uint16_t* out_lo, int out_relu, void* stream);
+                  uint16_t* out_hi, uint16_t* out_lo, int out_relu, float* workspace, long long workspace_bytes, void* stream);
+long long lp_conv16_fwd_workspace_bytes(int N, int H, int W, int Cout, int ksize);
 
 /* Weight gradient: dw[co][ci][t] = out_scale * sum_{n,y,x} dy[n,y,x,co] * up2?(a)[n,y+dy_t,x+dx_t,ci]  (autograd of F.conv2d
  * w.r.t. weight, blocks.py:76-88) on operand planes: a = the planes the forward conv consumed, dy = lp_act_pack of the output

@@ -26,7 +26,8 @@ SIGNATURES = {
     'lp_act_pack': (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'lp_amax_blocks': (_i, []),
     'lp_amax_partial': (_i, [_vp, _ll, _vp, _vp]),
-    'lp_conv16_fwd': (_i, [_vp] * 9 + [_i] * 11 + [_vp, _vp, _vp, _i, _vp]),
+    'lp_conv16_fwd': (_i, [_vp] * 9 + [_i] * 11 + [_vp, _vp, _vp, _i, _vp, _ll, _vp]),
+    'lp_conv16_fwd_workspace_bytes': (_ll, [_i] * 5),
     'lp_conv_wgrad_workspace_bytes': (_ll, [_i, _i, _i, _i]),
     'lp_conv16_wgrad': (_i, [_vp] * 6 + [_i] * 9 + [_vp, _vp, _vp]),
     'lp_thin_conv_supported': (_i, [_i] * 4),

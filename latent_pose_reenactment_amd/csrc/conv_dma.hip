@@ -38,6 +38,7 @@ struct Conv16Params {
     const uint16_t* mask16;       // epilogue: y = 0 where this 16-bit activation plane [N][H][W][Co8] is <= 0 (fused ReLU backward)
     uint16_t* o_hi; uint16_t* o_lo;   // optional: 16-bit planes [N][H][W][Co8] of (o_relu ? relu(y) : y) for the consumer conv
     int o_relu;
+    float* part; long long part_bytes;      // split-K partial sums [ksplit][N*H*W][Cout] (caller's workspace)
     int N, H, W, Hin, Win, Cin, C8, Cout, Co8, CinP, CoutP;
     int res_shift;
     int lTH, lTW, lNB, tiles_x, tiles_y;
@@ -285,7 +286,7 @@ void conv_dma_kernel(Conv16Params p) {
     // ---- epilogue.  C layout of mfma 16x16: col = lane&15 (channel), row = (lane>>4)*4 + reg (tile row)
     float alpha = p.alpha ? *p.alpha : 1.f;
     if (p.alpha2) alpha *= *p.alpha2;
-    if (p.ksplit == 1 && (p.Cout & 3) == 0) {
+    if ((p.Cout & 3) == 0) {
         // Coalesced path: every wave transposes its (MR*16) x (NR*16) accumulator block through LDS (the staging buffers are dead
         // now) and writes whole pixel rows -- NR*64 contiguous bytes per pixel, 16 B per lane; bias, residual, mask likewise.
         constexpr int WR = MR * 16, WC = NR * 16, LDW = WC + 4;
@@ -313,6 +314,11 @@ void conv_dma_kernel(Conv16Params p) {
             const int n = n0 + nb, oyy = y0 + py, oxx = x0 + px;
             if (n < p.N && oyy < p.H && oxx < p.W && co < p.Cout) {
                 float4 v = *(const float4*)(tile + row * LDW + c4 * 4);
+                if (p.ksplit > 1) {        // split-K: the raw partial tile; splitk_reduce_kernel sums the slices and applies the epilogue
+                    const size_t pixs = (size_t)(n * p.H + oyy) * p.W + oxx;
+                    *(float4*)(p.part + ((size_t)blockIdx.z * p.N * p.H * p.W + pixs) * p.Cout + co) = v;
+                    continue;
+                }
                 v.x = fmaf(v.x, alpha, bv.x); v.y = fmaf(v.y, alpha, bv.y); v.z = fmaf(v.z, alpha, bv.z); v.w = fmaf(v.w, alpha, bv.w);
                 if (p.res) {
                     const float4 rv = *(const float4*)(p.res + ((size_t)(n * (p.H >> p.res_shift) + (oyy >> p.res_shift)) * (p.W >> p.res_shift)
@@ -360,23 +366,69 @@ void conv_dma_kernel(Conv16Params p) {
             for (int nr = 0; nr < NR; ++nr) {
                 const int co = co0 + wn * (NR * 16) + nr * 16 + (lane & 15);
                 if (co < p.Cout) {
-                    float v = acc[mr][nr][r] * alpha;
-                    if (p.ksplit == 1 || blockIdx.z == 0) {
-                        if (p.bias) v += p.bias[co];
-                        if (p.res) v += p.res[rpix + co];
+                    float v = acc[mr][nr][r] * alpha;      // (element-wise path: channel counts that are no multiple of 4; never split-K)
+                    if (p.bias) v += p.bias[co];
+                    if (p.res) v += p.res[rpix + co];
+                    if (p.mask16 && !((unsigned)(p.mask16[pixi * p.Co8 + co] - 1u) < 0x7fffu)) v = 0.f;
+                    p.y[pix + co] = v;
+                    if (p.o_hi) {
+                        const float q = p.o_relu ? fmaxf(v, 0.f) : v;
+                        const uint16_t h = lp_f32_to_op16<F16>(q);
+                        p.o_hi[pixi * p.Co8 + co] = h;
+                        if (SPLIT) p.o_lo[pixi * p.Co8 + co] = lp_f32_to_op16<false>(q - lp_op16_to_f32<false>(h));
                     }
-                    if (p.mask16 && !((unsigned)(p.mask16[pixi * p.Co8 + co] - 1u) < 0x7fffu)) v = 0.f;   // (0/1 mask: commutes with the split-K sum)
-                    if (p.ksplit == 1) {
-                        p.y[pix + co] = v;
-                        if (p.o_hi) {
-                            const float q = p.o_relu ? fmaxf(v, 0.f) : v;
-                            const uint16_t h = lp_f32_to_op16<F16>(q);
-                            p.o_hi[pixi * p.Co8 + co] = h;
-                            if (SPLIT) p.o_lo[pixi * p.Co8 + co] = lp_f32_to_op16<false>(q - lp_op16_to_f32<false>(h));
-                        }
-                    } else unsafeAtomicAdd(p.y + pix + co, v);       // y was zeroed by lp_conv16_fwd (hipMemsetAsync on the stream)
                 }
             }
+        }
+    }
+}
+
+// Split-K finish: y = alpha * sum_s part[s] + bias + res, ReLU mask, 16-bit planes of the consumer -- the whole epilogue of the conv,
+// once, on the summed tile (4 channels per thread; the slices are plain coalesced stores of the conv workgroups: no atomics, no
+// memset of y, and the planes need no extra pack pass).
+template <int PREC>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(Conv16Params p) {
+    constexpr bool SPLIT = (PREC == LP_PREC_BF16X3), F16 = (PREC == LP_PREC_F16);
+    const int C4 = p.Cout >> 2;
+    const size_t P = (size_t)p.N * p.H * p.W, items = P * C4, slice = P * p.Cout;
+    float alpha = p.alpha ? *p.alpha : 1.f;
+    if (p.alpha2) alpha *= *p.alpha2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < items; i += (size_t)gridDim.x * 256) {
+        const int co = (int)(i % C4) * 4;
+        const size_t pix = i / C4;
+        float4 v = *(const float4*)(p.part + i * 4);
+        for (int z = 1; z < p.ksplit; ++z) {
+            const float4 q = *(const float4*)(p.part + z * slice + i * 4);
+            v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+        }
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias) bv = *(const float4*)(p.bias + co);
+        v.x = fmaf(v.x, alpha, bv.x); v.y = fmaf(v.y, alpha, bv.y); v.z = fmaf(v.z, alpha, bv.z); v.w = fmaf(v.w, alpha, bv.w);
+        if (p.res) {
+            const int ox = (int)(pix % p.W); const size_t t = pix / p.W;
+            const int oy = (int)(t % p.H), n = (int)(t / p.H);
+            const float4 rv = *(const float4*)(p.res + ((size_t)(n * (p.H >> p.res_shift) + (oy >> p.res_shift)) * (p.W >> p.res_shift)
+                                                        + (ox >> p.res_shift)) * p.Cout + co);
+            v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+        }
+        if (p.mask16) {
+            const ushort4 mv = *(const ushort4*)(p.mask16 + pix * p.Co8 + co);
+            v.x = (mv.x - 1u) < 0x7fffu ? v.x : 0.f; v.y = (mv.y - 1u) < 0x7fffu ? v.y : 0.f;
+            v.z = (mv.z - 1u) < 0x7fffu ? v.z : 0.f; v.w = (mv.w - 1u) < 0x7fffu ? v.w : 0.f;
+        }
+        *(float4*)(p.y + pix * p.Cout + co) = v;
+        if (p.o_hi) {
+            float o[4] = {v.x, v.y, v.z, v.w};
+            ushort4 oh, ol;
+            uint16_t* ohp = (uint16_t*)&oh; uint16_t* olp = (uint16_t*)&ol;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float q = p.o_relu ? fmaxf(o[j], 0.f) : o[j];
+                ohp[j] = lp_f32_to_op16<F16>(q);
+                if (SPLIT) olp[j] = lp_f32_to_op16<false>(q - lp_op16_to_f32<false>(ohp[j]));
+            }
+            *(ushort4*)(p.o_hi + pix * p.Co8 + co) = oh;
+            if (SPLIT) *(ushort4*)(p.o_lo + pix * p.Co8 + co) = ol;
         }
     }
 }
@@ -449,17 +501,18 @@ static int launch_conv16(Conv16Params& p, hipStream_t stream) {
     if (lds < epi) lds = epi;
     if (lds > LDS_MAX) return lp_set_error(LP_ERR_UNSUPPORTED, "conv16 tile needs too much LDS");
     dim3 grid(pp ? (tiles + 1) / 2 : tiles, (p.Cout + BN - 1) / BN);
-    {   // split-K when the output tiling alone cannot fill the 256 CUs (4x4 ... 32x32 layers with K = 9*512)
+    {   // split-K when the output tiling alone cannot fill the 256 CUs (4x4 ... 16x16 layers with K = 9*512): grid.z slices of the
+        // contraction write partial tiles into the caller's workspace, splitk_reduce_kernel (launched by lp_conv16_fwd) finishes.
+        // 1x1 convs are not split: their whole contraction is 16 stages, less than the cost of a second launch.
         static const int max_split = getenv("LP_CONV_KSPLIT") ? atoi(getenv("LP_CONV_KSPLIT")) : 8;
         static const int split_wgs = getenv("LP_CONV_SPLIT_WGS") ? atoi(getenv("LP_CONV_SPLIT_WGS")) : 256;   // split while <= this many workgroups result
         const int wgs = grid.x * grid.y, nch = p.CinP / 32;
         int ks = 1;
-        while (ks < max_split && wgs * ks * 2 <= split_wgs && nch / (ks * 2) >= 2) ks *= 2;
+        if (KS == 3 && (p.Cout & 3) == 0 && p.part)
+            while (ks < max_split && wgs * ks * 2 <= split_wgs && nch / (ks * 2) >= 2 &&
+                   (long long)(ks * 2) * p.N * p.H * p.W * p.Cout * (long long)sizeof(float) <= p.part_bytes) ks *= 2;
         p.ksplit = ks;
         grid.z = ks;
-        if (ks > 1) { p.o_hi = nullptr; p.o_lo = nullptr; }      // partial sums: lp_conv16_fwd packs the finished y instead
-        if (ks > 1 && hipMemsetAsync(p.y, 0, (size_t)p.N * p.H * p.W * p.Cout * sizeof(float), stream) != hipSuccess)
-            return lp_set_error(LP_ERR_HIP, "hipMemsetAsync failed");
     }
     // (64-channel chunks -- CC = 64, twice the MFMAs between two barriers -- were measured 7-15 % SLOWER on the 64^2..256^2 layers: their
     //  146 KB of LDS leave one workgroup per CU, while the 72 KB of the 32-channel kernel let two ping-pong workgroups share a CU)
@@ -505,11 +558,21 @@ static int dispatch_conv16(Conv16Params& p, int ks, int ups, hipStream_t s) {
     return lp_set_error(LP_ERR_UNSUPPORTED, "unsupported conv configuration");
 }
 
+// upper bound of the split-K workspace: the split factor never exceeds 8 nor 256 / (workgroups of the largest tile, 256 x 128)
+extern "C" long long lp_conv16_fwd_workspace_bytes(int N, int H, int W, int Cout, int ksize) {
+    if (ksize != 3 || (Cout & 3)) return 0;
+    const long long P = (long long)N * H * W;
+    const long long wgs_lb = ((P + 255) / 256) * ((Cout + 127) / 128);
+    long long ks = 256 / wgs_lb; if (ks > 8) ks = 8;
+    if (ks < 2) return 0;
+    return ks * P * Cout * (long long)sizeof(float);
+}
+
 extern "C" int lp_conv16_fwd(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* w_hi, const uint16_t* w_lo, float* y,
                              const float* bias, const float* res, const float* alpha, const float* alpha2,
                              int N, int H, int W, int Cin, int Cout, int CinP, int CoutP,
                              int ksize, int upsample, int res_shift, int prec, const uint16_t* relu_mask16,
-                             uint16_t* out_hi, uint16_t* out_lo, int out_relu, void* stream) {
+                             uint16_t* out_hi, uint16_t* out_lo, int out_relu, float* workspace, long long workspace_bytes, void* stream) {
     if (!a_hi || !w_hi || !y) return lp_set_error(LP_ERR_ARG, "lp_conv16_fwd: null pointer");
     if (prec == LP_PREC_BF16X3 && (!w_lo || !a_lo)) return lp_set_error(LP_ERR_ARG, "lp_conv16_fwd: bf16x3 needs the lo planes");
     if (prec == LP_PREC_BF16X3 && out_hi && !out_lo) return lp_set_error(LP_ERR_ARG, "lp_conv16_fwd: bf16x3 needs out_lo");
@@ -518,7 +581,7 @@ extern "C" int lp_conv16_fwd(const uint16_t* a_hi, const uint16_t* a_lo, const u
     if (H < 2 || W < 2) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_conv16_fwd: H,W must be >= 2");
     Conv16Params p;
     p.a_hi = a_hi; p.a_lo = a_lo; p.w_hi = w_hi; p.w_lo = w_lo; p.y = y; p.bias = bias; p.res = res; p.alpha = alpha; p.alpha2 = alpha2;
-    p.mask16 = relu_mask16; p.o_relu = out_relu;
+    p.mask16 = relu_mask16; p.o_relu = out_relu; p.part = workspace; p.part_bytes = workspace ? workspace_bytes : 0;
     p.o_hi = (Cout & 7) ? nullptr : out_hi; p.o_lo = (Cout & 7) ? nullptr : out_lo;   // (pad channels: the pack pass writes them)
     p.N = N; p.H = H; p.W = W; p.Hin = upsample ? H / 2 : H; p.Win = upsample ? W / 2 : W;
     p.Cin = Cin; p.C8 = (Cin + 7) & ~7; p.Cout = Cout; p.Co8 = (Cout + 7) & ~7; p.CinP = CinP; p.CoutP = CoutP; p.res_shift = res_shift;
@@ -529,8 +592,17 @@ extern "C" int lp_conv16_fwd(const uint16_t* a_hi, const uint16_t* a_lo, const u
     else if (prec == LP_PREC_F16) rc = dispatch_conv16<LP_PREC_F16>(p, ksize, upsample, s);
     else return lp_set_error(LP_ERR_ARG, "lp_conv16_fwd: unknown precision mode");
     if (rc) return rc;
-    // the epilogue cannot emit the 16-bit planes from partial sums (split-K) or for channel counts it writes element-wise with
-    // padding channels: a bandwidth-bound pass over the finished y does it instead (same stream)
+    if (p.ksplit > 1) {
+        const long long items = (long long)N * H * W * (Cout >> 2);
+        long long blocks = (items + 255) / 256; if (blocks > 2048) blocks = 2048;
+        if (prec == LP_PREC_BF16) hipLaunchKernelGGL(splitk_reduce_kernel<LP_PREC_BF16>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+        else if (prec == LP_PREC_BF16X3) hipLaunchKernelGGL(splitk_reduce_kernel<LP_PREC_BF16X3>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(splitk_reduce_kernel<LP_PREC_F16>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+        rc = lp_check_launch("splitk_reduce");
+        if (rc) return rc;
+    }
+    // channel counts the epilogue writes element-wise (Cout % 8 != 0: padding channels) get their 16-bit planes from a
+    // bandwidth-bound pass over the finished y instead (same stream)
     if (out_hi && !p.o_hi)
         return lp_act_pack(y, nullptr, nullptr, out_relu ? 2 : 0, out_hi, out_lo, N, H * W, Cout, prec, nullptr, nullptr, nullptr, stream);
     return LP_OK;

@@ -180,11 +180,13 @@ def conv16(a: Act16, pack: WeightPack, *, ksize: int, upsample: bool = False, bi
     o_hi = o_lo = None
     if out16 is not None:
         o_hi, o_lo = _alloc16(n, h, w, cout, prec, y.device)
+    ws_bytes = _lib.lib().lp_conv16_fwd_workspace_bytes(n, h, w, cout, ksize)          # split-K partial tiles (small feature maps)
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=y.device) if ws_bytes else None
     with _Timed('conv_igemm', 2.0 * n * h * w * cout * cin * ksize * ksize, (n, h, w, cin, cout, ksize, int(upsample), 0)):
         check(_lib.lib().lp_conv16_fwd(a.hi.data_ptr(), _p(a.lo), pack.hi.data_ptr(), _p(pack.lo), y.data_ptr(), _p(bias), _p(res),
                                        _p(alpha), _p(a.inv), n, h, w, cin, cout, pack.cols_p, pack.rows_p, ksize, int(upsample),
                                        res_shift, prec, None if relu_mask is None else relu_mask.hi.data_ptr(), _p(o_hi), _p(o_lo),
-                                       int(bool(out16)), _stream()), 'lp_conv16_fwd')
+                                       int(bool(out16)), _p(ws), ws_bytes, _stream()), 'lp_conv16_fwd')
     if out16 is not None:
         return y, Act16(o_hi, o_lo, cout, None)
     return y

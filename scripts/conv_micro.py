@@ -9,6 +9,9 @@ SHAPES = [  # N, H, W, Cin, Cout, ks, ups
     (8, 4, 4, 512, 512, 3, 0), (8, 16, 16, 512, 512, 3, 0), (8, 32, 32, 512, 512, 3, 0), (8, 64, 64, 256, 256, 3, 0),
     (8, 128, 128, 128, 128, 3, 0), (8, 256, 256, 64, 64, 3, 0), (8, 256, 256, 128, 64, 3, 1), (8, 256, 256, 64, 128, 3, 0),
     (8, 64, 64, 512, 256, 3, 1), (8, 64, 64, 256, 128, 1, 0), (16, 128, 128, 128, 128, 3, 0), (16, 64, 64, 256, 256, 3, 0)]
+if os.environ.get('SHAPES') == 'small':      # the latency-bound layer classes (4x4 .. 16x16 maps, 1x1 skips)
+    SHAPES = [(8, 4, 4, 512, 512, 3, 0), (8, 8, 8, 512, 512, 3, 0), (8, 16, 16, 512, 512, 3, 0), (8, 8, 8, 512, 512, 1, 0),
+              (8, 16, 16, 512, 512, 1, 0), (8, 8, 8, 512, 512, 3, 1), (8, 32, 32, 512, 512, 3, 0)]
 prec = int(os.environ.get('PREC', '0'))
 REPS = int(os.environ.get('REPS', '20'))
 WHAT = os.environ.get('WHAT', 'conv,pack,wgrad').split(',')
