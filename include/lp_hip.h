@@ -77,11 +77,14 @@ long long lp_conv16_fwd_workspace_bytes(int N, int H, int W, int Cout, int ksize
  * w.r.t. weight, blocks.py:76-88) on operand planes: a = the planes the forward conv consumed, dy = lp_act_pack of the output
  * gradient.  Two launches: partial slabs over `splits` pixel ranges, then a reduction that also writes the reference
  * [Cout][Cin][k][k] layout.  workspace: lp_conv_wgrad_workspace_bytes().
- * dbias [Cout]|NULL: also emit out_scale * sum_{n,y,x} dy[n,y,x,co] (the kernel streams dy anyway).  out_scale: device scalar|NULL. */
+ * dbias [Cout]|NULL: also emit out_scale * sum_{n,y,x} dy[n,y,x,co] (the kernel streams dy anyway).  out_scale: device scalar|NULL.
+ * sn_w_orig [Cout][Cin][k][k] + sn_dot [lp_conv_wgrad_dot_blocks()] (both or neither): spectrally normalised layer -- the reduction
+ * also leaves per-block partial sums of <dw, W_orig> in sn_dot, which lp_sn_grad_apply(ndot = that count) consumes. */
 long long lp_conv_wgrad_workspace_bytes(int Cin, int Cout, int ksize, int splits);
 int lp_conv16_wgrad(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* dy_hi, const uint16_t* dy_lo, float* dw,
                     float* workspace, int N, int H, int W, int Cin, int Cout, int ksize, int upsample, int splits, int prec,
-                    float* dbias, const float* out_scale, void* stream);
+                    float* dbias, const float* out_scale, const float* sn_w_orig, float* sn_dot, void* stream);
+int lp_conv_wgrad_dot_blocks(int Cin, int Cout, int ksize);
 
 /* Thin-channel convs (<= 4 channels on one side: RGB -> 64 first convs of the critics / VGG stacks, the generator head's weight
  * gradient): bandwidth-bound fp32 VALU kernels on plain NHWC fp32 activations (no operand planes); weights from the same packs.
@@ -193,12 +196,13 @@ int lp_mt_ema(const void* table, int num_tensors, long long max_numel, float alp
  * always: u_out/v_out = the vectors used, sig_out = {sigma = u^T W v, 1/sigma}.  Five launches, row-/column-blocked over many workgroups.
  * (dot = scratch of 512 floats: per-block partial sums of <g, w_orig>, no memset needed)
  * lp_sn_grad_apply: g/sigma - (<g, w_orig>/sigma^2) u v^T (autograd of W/sigma with u, v constant), written in place on g, or
- * added to `accum` when that is non-NULL (fused accumulation into the parameter's .grad; g is then left untouched); dot = scratch. */
+ * added to `accum` when that is non-NULL (fused accumulation into the parameter's .grad; g is then left untouched).
+ * ndot = 0: dot = scratch of 512 floats, <g, w_orig> is taken here; ndot > 0: dot holds that many partial sums of <g, w_orig>. */
 int lp_sn_desc_bytes(void);
 int lp_sn_row_block(void);
 int lp_sn_power_iter(const void* table, int num_layers, int do_iter, int max_rows, int max_cols, void* stream);
-int lp_sn_grad_apply(float* g, const float* w_orig, const float* u, const float* v, const float* sig, float* dot, float* accum,
-                     int rows, int cols, void* stream);
+int lp_sn_grad_apply(float* g, const float* w_orig, const float* u, const float* v, const float* sig, float* dot, int ndot,
+                     float* accum, int rows, int cols, void* stream);
 
 #ifdef __cplusplus
 }

@@ -29,7 +29,8 @@ SIGNATURES = {
     'lp_conv16_fwd': (_i, [_vp] * 9 + [_i] * 11 + [_vp, _vp, _vp, _i, _vp, _ll, _vp]),
     'lp_conv16_fwd_workspace_bytes': (_ll, [_i] * 5),
     'lp_conv_wgrad_workspace_bytes': (_ll, [_i, _i, _i, _i]),
-    'lp_conv16_wgrad': (_i, [_vp] * 6 + [_i] * 9 + [_vp, _vp, _vp]),
+    'lp_conv16_wgrad': (_i, [_vp] * 6 + [_i] * 9 + [_vp, _vp, _vp, _vp, _vp]),
+    'lp_conv_wgrad_dot_blocks': (_i, [_i] * 3),
     'lp_thin_conv_supported': (_i, [_i] * 4),
     'lp_thin_conv_fwd': (_i, [_vp] * 6 + [_i] * 9 + [_vp]),
     'lp_thin_wgrad_supported': (_i, [_i] * 5),
@@ -65,7 +66,7 @@ SIGNATURES = {
     'lp_sn_desc_bytes': (_i, []),
     'lp_sn_power_iter': (_i, [_vp, _i, _i, _i, _i, _vp]),
     'lp_sn_row_block': (_i, []),
-    'lp_sn_grad_apply': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    'lp_sn_grad_apply': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp]),
 }
 
 _lib = None

@@ -301,11 +301,15 @@ __global__ __launch_bounds__(COB * 4) void conv_wgrad_kernel(WgradParams p) {
                 }
 }
 
-// dw[co][ci][tap] = sum_s part[s][tap][co][ci].  One thread per (tap, co, ci) with ci fastest -> every partial read is
-// coalesced; 8 independent accumulators keep 8 loads in flight per thread (the slabs are streamed once from HBM/L2).
+// dw[co][ci][tap] = sum_s part[s][tap][co][ci].  A thread owns 4 (tap, co, ci) triples 256 apart, ci fastest -> every partial read
+// is coalesced; 8 independent accumulators keep 8 loads in flight per thread (the slabs are streamed once from HBM/L2).
+// sn_w != NULL: the layer is spectrally normalised -- the block also leaves its share of <dw, W_orig> in sn_dot[blockIdx.x]
+// (lp_sn_grad_apply needs that inner product; taking it here saves a pass over dw and a launch).
+#define WRED_PER_BLOCK 1024
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int S, int T,
                                                            int Cout, int Cin, int CoP, int CiP, const float* __restrict__ bpart,
-                                                           float* __restrict__ dbias, int wblocks, const float* __restrict__ out_scale) {
+                                                           float* __restrict__ dbias, int wblocks, const float* __restrict__ out_scale,
+                                                           const float* __restrict__ sn_w, float* __restrict__ sn_dot) {
     const float osc = out_scale ? out_scale[0] : 1.f;          // 1 / (input scale of the fp16 dy operand)
     if ((int)blockIdx.x >= wblocks) {                 // trailing blocks: dbias[co] = sum_s bpart[s][co], 64 channels per block,
         __shared__ float red[4][64];                  // the splits dealt to 4 thread groups x 4 independent accumulators
@@ -325,26 +329,42 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         if (g == 0 && co < Cout) dbias[co] = ((red[0][c] + red[1][c]) + (red[2][c] + red[3][c])) * osc;
         return;
     }
-    int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= T * Cout * Cin) return;
-    int ci = idx % Cin, r = idx / Cin;
-    int co = r % Cout, t = r / Cout;
     const size_t slab = (size_t)T * CoP * CiP;
-    const float* p = part + ((size_t)t * CoP + co) * CiP + ci;
-    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    int k = 0;
-    for (; k + 8 <= S; k += 8) {
+    const int total = T * Cout * Cin;
+    float dsum = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) a[j] += p[(size_t)(k + j) * slab];
+    for (int j = 0; j < WRED_PER_BLOCK / 256; ++j) {
+        const int idx = blockIdx.x * WRED_PER_BLOCK + j * 256 + threadIdx.x;
+        if (idx < total) {
+            const int ci = idx % Cin, r = idx / Cin;
+            const int co = r % Cout, t = r / Cout;
+            const float* p = part + ((size_t)t * CoP + co) * CiP + ci;
+            float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            int k = 0;
+            for (; k + 8 <= S; k += 8) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) a[q] += p[(size_t)(k + q) * slab];
+            }
+            for (; k < S; ++k) a[0] += p[(size_t)k * slab];
+            const float val = (((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) * osc;
+            const size_t o = ((size_t)co * Cin + ci) * T + t;
+            dw[o] = val;
+            if (sn_w) dsum = fmaf(val, sn_w[o], dsum);
+        }
     }
-    for (; k < S; ++k) a[0] += p[(size_t)k * slab];
-    dw[((size_t)co * Cin + ci) * T + t] = (((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) * osc;
+    if (sn_w) {
+        __shared__ float dred[4];
+        for (int o = 32; o > 0; o >>= 1) dsum += __shfl_down(dsum, o, 64);
+        if ((threadIdx.x & 63) == 0) dred[threadIdx.x >> 6] = dsum;
+        __syncthreads();
+        if (threadIdx.x == 0) sn_dot[blockIdx.x] = (dred[0] + dred[1]) + (dred[2] + dred[3]);
+    }
 }
 
 static int ilog2_floor_w(int v) { int l = 0; while ((1 << (l + 1)) <= v) ++l; return l; }
 
 template <int KS, bool UPS, int PREC, int COB = 64>
-static int launch_wgrad(WgradParams& p, float* dw, float* dbias, const float* out_scale, hipStream_t stream) {
+static int launch_wgrad(WgradParams& p, float* dw, float* dbias, const float* out_scale, const float* sn_w, float* sn_dot, hipStream_t stream) {
     constexpr bool SPLIT = (PREC == LP_PREC_BF16X3);
     constexpr int SA = 64 * 2 + 16, SD = COB * 2 + 16;
     // 128-pixel tiles, row-major inside the patch; TW >= 4 so that 4 consecutive k are 4 consecutive x
@@ -376,13 +396,15 @@ static int launch_wgrad(WgradParams& p, float* dw, float* dbias, const float* ou
     int rc = lp_check_launch("conv_wgrad");
     if (rc) return rc;
     int total = KS * KS * p.Cout * p.Cin;
-    const int wblocks = (total + 255) / 256, bblocks = p.bpart ? (p.Cout + 63) / 64 : 0;
+    const int wblocks = (total + WRED_PER_BLOCK - 1) / WRED_PER_BLOCK, bblocks = p.bpart ? (p.Cout + 63) / 64 : 0;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wblocks + bblocks), dim3(256), 0, stream, p.part, dw, p.splits, KS * KS,
-                       p.Cout, p.Cin, p.CoP, p.CiP, p.bpart, dbias, wblocks, out_scale);
+                       p.Cout, p.Cin, p.CoP, p.CiP, p.bpart, dbias, wblocks, out_scale, sn_w, sn_dot);
     return lp_check_launch("wgrad_reduce");
 }
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+extern "C" int lp_conv_wgrad_dot_blocks(int Cin, int Cout, int ksize) { return (ksize * ksize * Cout * Cin + WRED_PER_BLOCK - 1) / WRED_PER_BLOCK; }
 
 extern "C" long long lp_conv_wgrad_workspace_bytes(int Cin, int Cout, int ksize, int splits) {
     // [splits][taps][CoP][CiP] weight-gradient slabs, then [splits][CoP] bias-gradient partials
@@ -390,22 +412,24 @@ extern "C" long long lp_conv_wgrad_workspace_bytes(int Cin, int Cout, int ksize,
 }
 
 template <int PREC>
-static int dispatch_wgrad(WgradParams& p, float* dw, float* dbias, const float* out_scale, int ksize, int upsample, hipStream_t s) {
+static int dispatch_wgrad(WgradParams& p, float* dw, float* dbias, const float* out_scale, const float* sn_w, float* sn_dot, int ksize,
+                          int upsample, hipStream_t s) {
     // 128 output channels per workgroup (8 waves) where the layer is wide enough; LP_WGRAD_COB = 64 | 128 overrides
     static const int cob_env = getenv("LP_WGRAD_COB") ? atoi(getenv("LP_WGRAD_COB")) : 0;
     const bool cob128 = cob_env ? (cob_env == 128) : true;      // measured: -9 % (bf16x3), -6 % (bf16) on the 64..512-channel layers
     if (cob128 && p.Cout >= 128 && ksize == 3)
-        return upsample ? launch_wgrad<3, true, PREC, 128>(p, dw, dbias, out_scale, s) : launch_wgrad<3, false, PREC, 128>(p, dw, dbias, out_scale, s);
-    if (ksize == 3 && !upsample) return launch_wgrad<3, false, PREC>(p, dw, dbias, out_scale, s);
-    if (ksize == 3 && upsample) return launch_wgrad<3, true, PREC>(p, dw, dbias, out_scale, s);
-    if (ksize == 1 && !upsample) return launch_wgrad<1, false, PREC>(p, dw, dbias, out_scale, s);
+        return upsample ? launch_wgrad<3, true, PREC, 128>(p, dw, dbias, out_scale, sn_w, sn_dot, s) : launch_wgrad<3, false, PREC, 128>(p, dw, dbias, out_scale, sn_w, sn_dot, s);
+    if (ksize == 3 && !upsample) return launch_wgrad<3, false, PREC>(p, dw, dbias, out_scale, sn_w, sn_dot, s);
+    if (ksize == 3 && upsample) return launch_wgrad<3, true, PREC>(p, dw, dbias, out_scale, sn_w, sn_dot, s);
+    if (ksize == 1 && !upsample) return launch_wgrad<1, false, PREC>(p, dw, dbias, out_scale, sn_w, sn_dot, s);
     return lp_set_error(LP_ERR_UNSUPPORTED, "lp_conv16_wgrad: unsupported configuration");
 }
 
 extern "C" int lp_conv16_wgrad(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* dy_hi, const uint16_t* dy_lo, float* dw,
                                float* workspace, int N, int H, int W, int Cin, int Cout, int ksize, int upsample, int splits, int prec,
-                               float* dbias, const float* out_scale, void* stream) {
+                               float* dbias, const float* out_scale, const float* sn_w_orig, float* sn_dot, void* stream) {
     if (!a_hi || !dy_hi || !dw || !workspace) return lp_set_error(LP_ERR_ARG, "lp_conv16_wgrad: null pointer");
+    if (!sn_w_orig != !sn_dot) return lp_set_error(LP_ERR_ARG, "lp_conv16_wgrad: sn_w_orig and sn_dot go together");
     if (prec == LP_PREC_BF16X3 && (!a_lo || !dy_lo)) return lp_set_error(LP_ERR_ARG, "lp_conv16_wgrad: bf16x3 needs the lo planes");
     if (splits < 1) return lp_set_error(LP_ERR_ARG, "lp_conv16_wgrad: splits must be >= 1");
     if (upsample && ((H | W) & 1)) return lp_set_error(LP_ERR_ARG, "lp_conv16_wgrad: upsampled dims must be even");
@@ -416,8 +440,8 @@ extern "C" int lp_conv16_wgrad(const uint16_t* a_hi, const uint16_t* a_lo, const
     p.splits = splits;
     p.bpart = dbias ? workspace + (size_t)splits * ksize * ksize * p.CoP * p.CiP : nullptr;
     hipStream_t s = (hipStream_t)stream;
-    if (prec == LP_PREC_BF16) return dispatch_wgrad<LP_PREC_BF16>(p, dw, dbias, out_scale, ksize, upsample, s);
-    if (prec == LP_PREC_BF16X3) return dispatch_wgrad<LP_PREC_BF16X3>(p, dw, dbias, out_scale, ksize, upsample, s);
-    if (prec == LP_PREC_F16) return dispatch_wgrad<LP_PREC_F16>(p, dw, dbias, out_scale, ksize, upsample, s);
+    if (prec == LP_PREC_BF16) return dispatch_wgrad<LP_PREC_BF16>(p, dw, dbias, out_scale, sn_w_orig, sn_dot, ksize, upsample, s);
+    if (prec == LP_PREC_BF16X3) return dispatch_wgrad<LP_PREC_BF16X3>(p, dw, dbias, out_scale, sn_w_orig, sn_dot, ksize, upsample, s);
+    if (prec == LP_PREC_F16) return dispatch_wgrad<LP_PREC_F16>(p, dw, dbias, out_scale, sn_w_orig, sn_dot, ksize, upsample, s);
     return lp_set_error(LP_ERR_ARG, "lp_conv16_wgrad: unknown precision");
 }

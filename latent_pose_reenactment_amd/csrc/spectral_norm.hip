@@ -209,24 +209,32 @@ __global__ __launch_bounds__(256) void sn_grad_apply_kernel(float* __restrict__ 
                                                             int C) {
     __shared__ float red[4];
     float d = 0.f;
-    for (int j = threadIdx.x; j < ndot; j += 256) d += dot[j];          // every block re-sums the (<= 512, L2-resident) partials
+    for (int j = threadIdx.x; j < ndot; j += 256) d += dot[j];          // every block re-sums the (L2-resident) partials
     d = block_sum_256(d, red);
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long long)R * C) return;
     const float alpha = sig[1];
     const float k = d * alpha * alpha;
-    int r = (int)(i / C), c = (int)(i % C);
-    const float val = fmaf(alpha, g[i], -k * u[r] * v[c]);
-    if (accum) accum[i] += val; else g[i] = val;
+    const long long total = (long long)R * C;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                                        // 4 elements per thread, 256 apart: 1 KiB runs per block
+        const long long i = (long long)blockIdx.x * 1024 + j * 256 + threadIdx.x;
+        if (i < total) {
+            const int r = (int)(i / C), c = (int)(i % C);
+            const float val = fmaf(alpha, g[i], -k * u[r] * v[c]);
+            if (accum) accum[i] += val; else g[i] = val;
+        }
+    }
 }
 
-extern "C" int lp_sn_grad_apply(float* g, const float* w_orig, const float* u, const float* v, const float* sig, float* dot,
+extern "C" int lp_sn_grad_apply(float* g, const float* w_orig, const float* u, const float* v, const float* sig, float* dot, int ndot,
                                 float* accum, int rows, int cols, void* stream) {
     if (!g || !w_orig || !u || !v || !sig || !dot) return lp_set_error(LP_ERR_ARG, "lp_sn_grad_apply: null pointer");
     long long total = (long long)rows * cols;
-    int db = (int)((total + 1023) / 1024); if (db > SN_DOT_BLOCKS) db = SN_DOT_BLOCKS; if (db < 1) db = 1;
-    hipLaunchKernelGGL(sn_dot_kernel, dim3(db), dim3(256), 0, (hipStream_t)stream, g, w_orig, dot, total);
-    hipLaunchKernelGGL(sn_grad_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, u, v, sig, dot,
+    int db = ndot;
+    if (ndot <= 0) {         // <g, w_orig> not supplied by the producer of g (lp_conv16_wgrad's sn_dot): take it here
+        db = (int)((total + 1023) / 1024); if (db > SN_DOT_BLOCKS) db = SN_DOT_BLOCKS; if (db < 1) db = 1;
+        hipLaunchKernelGGL(sn_dot_kernel, dim3(db), dim3(256), 0, (hipStream_t)stream, g, w_orig, dot, total);
+    }
+    hipLaunchKernelGGL(sn_grad_apply_kernel, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, g, u, v, sig, dot,
                        db, accum, rows, cols);
     return lp_check_launch("sn_grad_apply");
 }

@@ -251,22 +251,29 @@ def conv_wgrad16(a: Act16, dy: Act16, *, ksize: int, upsample: bool = False, pre
     ws = torch.empty(_lib.lib().lp_conv_wgrad_workspace_bytes(cin, cout, ksize, splits) // 4, dtype=torch.float32, device=dev)
     dw = torch.empty((cout, cin, ksize, ksize), dtype=torch.float32, device=dev)
     db = torch.empty(cout, dtype=torch.float32, device=dev) if bias_grad else None
+    dot, ndot = None, 0
+    if sn is not None:          # the reduction launch also takes <dw, W_orig> (per-block partials) for lp_sn_grad_apply
+        _chk(sn[0], 'w_orig')
+        ndot = _lib.lib().lp_conv_wgrad_dot_blocks(cin, cout, ksize)
+        dot = torch.empty(ndot, dtype=torch.float32, device=dev)
     with _Timed('conv_wgrad', 2.0 * n * h * w * cout * cin * ksize * ksize, (n, h, w, cin, cout, ksize, int(upsample), 0)):
         check(_lib.lib().lp_conv16_wgrad(a.hi.data_ptr(), _p(a.lo), dy.hi.data_ptr(), _p(dy.lo), dw.data_ptr(), ws.data_ptr(), n, h, w, cin,
-                                         cout, ksize, int(upsample), splits, prec, _p(db), _p(dy.inv), _stream()), 'lp_conv16_wgrad')
-    dw = _sn_finish(dw, sn, accum)
+                                         cout, ksize, int(upsample), splits, prec, _p(db), _p(dy.inv),
+                                         None if sn is None else sn[0].data_ptr(), _p(dot), _stream()), 'lp_conv16_wgrad')
+    dw = _sn_finish(dw, sn, accum, dot, ndot)
     return (dw, db) if bias_grad else dw
 
 
-def _sn_finish(dw, sn, accum):
+def _sn_finish(dw, sn, accum, dot=None, ndot=0):
     if sn is None:
         return dw
     w_orig, u, v, sig = sn
     cout = dw.shape[0]
-    dot = torch.empty(512, dtype=torch.float32, device=dw.device)      # per-block partials of <g, W>
+    if dot is None:
+        dot = torch.empty(512, dtype=torch.float32, device=dw.device)      # per-block partials of <g, W>, taken by lp_sn_grad_apply
     if accum is not None:
         assert accum.is_contiguous() and accum.dtype == torch.float32 and accum.numel() == dw.numel()
-    check(_lib.lib().lp_sn_grad_apply(dw.data_ptr(), w_orig.data_ptr(), u.data_ptr(), v.data_ptr(), sig.data_ptr(), dot.data_ptr(),
+    check(_lib.lib().lp_sn_grad_apply(dw.data_ptr(), w_orig.data_ptr(), u.data_ptr(), v.data_ptr(), sig.data_ptr(), dot.data_ptr(), ndot,
                                       _p(accum), cout, dw.numel() // cout, _stream()), 'lp_sn_grad_apply')
     return None if accum is not None else dw
 
@@ -422,7 +429,7 @@ def sn_grad_apply(g: Tensor, w_orig: Tensor, u: Tensor, v: Tensor, sig: Tensor, 
     dot = torch.empty(512, dtype=torch.float32, device=g.device)
     if accum is not None:
         assert accum.is_contiguous() and accum.dtype == torch.float32 and accum.numel() == g.numel()
-    check(_lib.lib().lp_sn_grad_apply(g.data_ptr(), w_orig.data_ptr(), u.data_ptr(), v.data_ptr(), sig.data_ptr(), dot.data_ptr(),
+    check(_lib.lib().lp_sn_grad_apply(g.data_ptr(), w_orig.data_ptr(), u.data_ptr(), v.data_ptr(), sig.data_ptr(), dot.data_ptr(), 0,
                                       _p(accum), rows, cols, _stream()), 'lp_sn_grad_apply')
     return None if accum is not None else g
 
