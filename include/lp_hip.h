@@ -48,12 +48,18 @@ int lp_pack_weights_batch(const void* table, int num_entries, long long total_ch
  * in the operand format of `prec` (bf16 | bf16 hi+lo | fp16, saturating).  Replaces, once per tensor, the instance_norm + mul +
  * add + relu chain of AdaptiveNorm2d/ReLU (generators/common/blocks.py:18-26,70-73) that the reference runs before every conv;
  * the planes feed lp_conv16_fwd (forward / dgrad) and lp_conv16_wgrad.  in_scale: device scalar|NULL.
- * fp16 gradient operands: amax_part = the lp_amax_blocks() block maxima of |x| written by lp_amax_partial (|NULL); the pack then
+ * fp16 gradient operands: amax_part = amax_count partial maxima of |x|, amax_stride floats apart (|NULL) -- the lp_amax_blocks()
+ * contiguous block maxima written by lp_amax_partial, or the lp_amax_slots() slots, lp_amax_slot_stride() floats apart, the kernel
+ * that produced x folded them into (the `amax_slots` argument of lp_conv16_fwd, lp_adain_relu_bwd, lp_sum2x2, lp_head_bwd,
+ * lp_avgpool2_bwd, lp_l1_bwd: a zeroed buffer of slots * stride floats); the pack then
  * scales by s = the power of two that puts amax(x) into [2^12, 2^13) and writes scale_out = {s, 1/s} (device, |NULL) for the
  * consumers (alpha2 of lp_conv16_fwd, out_scale of lp_conv16_wgrad). */
 int lp_act_pack(const float* x, const float* scale, const float* shift, int pro, uint16_t* hi, uint16_t* lo,
-                int N, int HW, int C, int prec, const float* in_scale, const float* amax_part, float* scale_out, void* stream);
+                int N, int HW, int C, int prec, const float* in_scale, const float* amax_part, int amax_count, int amax_stride,
+                float* scale_out, void* stream);
 int lp_amax_blocks(void);
+int lp_amax_slots(void);
+int lp_amax_slot_stride(void);
 int lp_amax_partial(const float* x, long long numel, float* part, void* stream);
 
 /* Fused conv on operand planes: y = alpha * alpha2 * conv_{k x k, pad k/2}( up2?(a), w ) + bias + res
@@ -70,7 +76,8 @@ int lp_conv16_fwd(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* w_
                   const float* bias, const float* res, const float* alpha, const float* alpha2,
                   int N, int H, int W, int Cin, int Cout, int CinP, int CoutP,
                   int ksize, int upsample, int res_shift, int prec, const uint16_t* relu_mask16,
-                  uint16_t* out_hi, uint16_t* out_lo, int out_relu, float* workspace, long long workspace_bytes, void* stream);
+                  uint16_t* out_hi, uint16_t* out_lo, int out_relu, float* workspace, long long workspace_bytes, float* amax_slots,
+                  void* stream);
 long long lp_conv16_fwd_workspace_bytes(int N, int H, int W, int Cout, int ksize);
 
 /* Weight gradient: dw[co][ci][t] = out_scale * sum_{n,y,x} dy[n,y,x,co] * up2?(a)[n,y+dy_t,x+dx_t,ci]  (autograd of F.conv2d
@@ -154,15 +161,15 @@ long long lp_adain_bwd_workspace_bytes(int N, int HW, int C);
 int lp_adain_relu_bwd(const float* dA, const float* x, const float* add, const float* gamma, int ab_stride,
                       const float* mean, const float* rstd, const float* scale, const float* shift,
                       float* dx, float* dgamma, float* dbeta, float* workspace,
-                      int N, int H, int W, int C, int upsample, void* stream);
+                      int N, int H, int W, int C, int upsample, float* amax_slots, void* stream);
 
 /* out[n,y,x,c] = sum of the 2x2 block of in[n,2y..2y+1,2x..2x+1,c]  (adjoint of nearest x2 upsampling, blocks.py:95). */
-int lp_sum2x2(const float* in, float* out, int N, int H, int W, int C, void* stream);
+int lp_sum2x2(const float* in, float* out, int N, int H, int W, int C, float* amax_slots, void* stream);
 
 /* Generator head (noBottleneck.py:86-88,170-181): t = tanh(z), rgb = t[:3]*0.75+0.5, segm = t[3]*0.5+0.5,
  * fake_rgbs = rgb*segm.  z/t NHWC [N][H][W][4]; fake_rgbs NCHW [N][3][H][W]; fake_segm NCHW [N][1][H][W]. */
 int lp_head_fwd(const float* z, float* t, float* fake_rgbs, float* fake_segm, int N, int H, int W, void* stream);
-int lp_head_bwd(const float* t, const float* d_rgbs, const float* d_segm, float* dz, int N, int H, int W, void* stream);
+int lp_head_bwd(const float* t, const float* d_rgbs, const float* d_segm, float* dz, int N, int H, int W, float* amax_slots, void* stream);
 
 /* ---- discriminator / perceptual-loss helpers (discriminators/no_landmarks.py:52-108, criterions/common/perceptual_loss.py) ---- */
 /* dx = dA * [x > 0]                       (autograd of nn.ReLU, blocks.py:71-73,84) */
@@ -170,7 +177,7 @@ int lp_relu_bwd(const float* dA, const float* x, float* dx, long long numel, voi
 /* y = AvgPool2d(2)(relu?(x)); x [N][2H][2W][C], y [N][H][W][C]   (nn.AvgPool2d, blocks.py:89-90; perceptual_loss.py:77) */
 int lp_avgpool2_fwd(const float* x, float* y, int N, int H, int W, int C, int relu_in, void* stream);
 /* dx [N][H][W][C] = 0.25 * dy[.., y>>1, x>>1, ..] * (relu_in ? [x>0] : 1); H, W = full-resolution dims */
-int lp_avgpool2_bwd(const float* dy, const float* x, float* dx, int N, int H, int W, int C, int relu_in, void* stream);
+int lp_avgpool2_bwd(const float* dy, const float* x, float* dx, int N, int H, int W, int C, int relu_in, float* amax_slots, void* stream);
 /* L1 taps: partial[lp_l1_partial_blocks()] block sums of |relu?(a) - relu?(b)| (F.l1_loss numerator; featmat.py:17, perceptual_loss.py:107);
  * backward: da = coef * grad_out[0] * sign(relu?(a) - relu?(b)) * (relu_in ? [a>0] : 1)  (+ add [numel]|NULL: the gradient that
  * reaches `a` from its other consumer -- the next conv / pool of the VGG stack -- summed here instead of by an autograd add) */
@@ -178,7 +185,7 @@ int lp_l1_partial_blocks(void);
 /* out|NULL: a second tiny launch writes out[0] = coef * sum(partial) (fixed order) -- the finished loss term. */
 int lp_l1_fwd(const float* a, const float* b, float* partial, long long numel, int relu_in, float coef, float* out, void* stream);
 int lp_l1_bwd(const float* a, const float* b, const float* grad_out, float coef, const float* add, float* da, long long numel, int relu_in,
-              void* stream);
+              float* amax_slots, void* stream);
 
 /* ---- fused multi-tensor optimizers + EMA (runners/holycow.py:34-41,99-109; utils/radam.py:29-95; torch.optim.Adam) ----
  * table: DEVICE array of {float* p; const float* g; float* m; float* v; long long n;} (lp_mt_desc_bytes() each), one per

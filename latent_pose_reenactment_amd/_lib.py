@@ -23,10 +23,12 @@ SIGNATURES = {
     'lp_pack_weights': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'lp_pack_desc_bytes': (_i, []),
     'lp_pack_weights_batch': (_i, [_vp, _i, _ll, _vp]),
-    'lp_act_pack': (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'lp_act_pack': (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
+    'lp_amax_slots': (_i, []),
+    'lp_amax_slot_stride': (_i, []),
     'lp_amax_blocks': (_i, []),
     'lp_amax_partial': (_i, [_vp, _ll, _vp, _vp]),
-    'lp_conv16_fwd': (_i, [_vp] * 9 + [_i] * 11 + [_vp, _vp, _vp, _i, _vp, _ll, _vp]),
+    'lp_conv16_fwd': (_i, [_vp] * 9 + [_i] * 11 + [_vp, _vp, _vp, _i, _vp, _ll, _vp, _vp]),
     'lp_conv16_fwd_workspace_bytes': (_ll, [_i] * 5),
     'lp_conv_wgrad_workspace_bytes': (_ll, [_i, _i, _i, _i]),
     'lp_conv16_wgrad': (_i, [_vp] * 6 + [_i] * 9 + [_vp, _vp, _vp, _vp, _vp]),
@@ -50,16 +52,16 @@ SIGNATURES = {
     'lp_instnorm_workspace_bytes': (_ll, [_i, _i, _i]),
     'lp_instnorm_stats': (_i, [_vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'lp_adain_bwd_workspace_bytes': (_ll, [_i, _i, _i]),
-    'lp_adain_relu_bwd': (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    'lp_sum2x2': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    'lp_adain_relu_bwd': (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    'lp_sum2x2': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'lp_head_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
-    'lp_head_bwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'lp_head_bwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     'lp_relu_bwd': (_i, [_vp, _vp, _vp, _ll, _vp]),
     'lp_avgpool2_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    'lp_avgpool2_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'lp_avgpool2_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     'lp_l1_partial_blocks': (_i, []),
     'lp_l1_fwd': (_i, [_vp, _vp, _vp, _ll, _i, _f, _vp, _vp]),
-    'lp_l1_bwd': (_i, [_vp, _vp, _vp, _f, _vp, _vp, _ll, _i, _vp]),
+    'lp_l1_bwd': (_i, [_vp, _vp, _vp, _f, _vp, _vp, _ll, _i, _vp, _vp]),
     'lp_mt_desc_bytes': (_i, []),
     'lp_mt_optimizer_step': (_i, [_vp, _i, _ll, _vp, _i, _f, _f, _f, _f, _vp]),
     'lp_mt_ema': (_i, [_vp, _i, _ll, _f, _i, _vp]),

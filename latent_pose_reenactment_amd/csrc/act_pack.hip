@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void act_pack_kernel(const float* __restrict__
                                                        const float* __restrict__ shift, int pro, uint16_t* __restrict__ hi,
                                                        uint16_t* __restrict__ lo, int HW, int C, int C8,
                                                        const float* __restrict__ in_scale, const float* __restrict__ amax_part,
-                                                       float* __restrict__ scale_out) {
+                                                       int amax_count, int amax_stride, float* __restrict__ scale_out) {
     constexpr bool SPLIT = (PREC == LP_PREC_BF16X3), F16 = (PREC == LP_PREC_F16);
     constexpr int U = 4;
     float isc = in_scale ? in_scale[0] : 1.f;
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void act_pack_kernel(const float* __restrict__
         // and derives the same power-of-two scale; block (0,0) publishes {s, 1/s} for the consumers of the planes
         __shared__ float sh[4];
         float m = 0.f;
-        for (int j = threadIdx.x; j < AMAX_BLOCKS; j += 256) m = fmaxf(m, amax_part[j]);
+        for (int j = threadIdx.x; j < amax_count; j += 256) m = fmaxf(m, amax_part[(size_t)j * amax_stride]);
         for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
         if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
         __syncthreads();
@@ -113,11 +113,12 @@ __global__ __launch_bounds__(256) void act_pack_kernel(const float* __restrict__
 }
 
 extern "C" int lp_act_pack(const float* x, const float* scale, const float* shift, int pro, uint16_t* hi, uint16_t* lo,
-                           int N, int HW, int C, int prec, const float* in_scale, const float* amax_part, float* scale_out,
-                           void* stream) {
+                           int N, int HW, int C, int prec, const float* in_scale, const float* amax_part, int amax_count,
+                           int amax_stride, float* scale_out, void* stream) {
     if (!x || !hi) return lp_set_error(LP_ERR_ARG, "lp_act_pack: null pointer");
     if ((pro == 1 || pro == 3) && (!scale || !shift)) return lp_set_error(LP_ERR_ARG, "lp_act_pack: pro=1|3 needs scale/shift");
     if (prec == LP_PREC_BF16X3 && !lo) return lp_set_error(LP_ERR_ARG, "lp_act_pack: bf16x3 needs the lo plane");
+    if (amax_part && (amax_count < 1 || amax_stride < 1)) return lp_set_error(LP_ERR_ARG, "lp_act_pack: amax_count / amax_stride must be >= 1 with amax_part");
     const int C8 = (C + 7) & ~7;
     const long long items = (long long)HW * (C8 >> 3);          // per image
     if (items == 0 || N == 0) return LP_OK;
@@ -126,7 +127,7 @@ extern "C" int lp_act_pack(const float* x, const float* scale, const float* shif
     const long long cap = (4096 + N - 1) / N; if (bx > cap) bx = cap; if (bx < 1) bx = 1;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)bx, (unsigned)N);
-#define LP_AP(P) hipLaunchKernelGGL(act_pack_kernel<P>, grid, dim3(256), 0, st, x, scale, shift, pro, hi, lo, HW, C, C8, in_scale, amax_part, scale_out)
+#define LP_AP(P) hipLaunchKernelGGL(act_pack_kernel<P>, grid, dim3(256), 0, st, x, scale, shift, pro, hi, lo, HW, C, C8, in_scale, amax_part, amax_count, amax_stride, scale_out)
     if (prec == LP_PREC_BF16) LP_AP(LP_PREC_BF16);
     else if (prec == LP_PREC_BF16X3) LP_AP(LP_PREC_BF16X3);
     else if (prec == LP_PREC_F16) LP_AP(LP_PREC_F16);
@@ -162,6 +163,8 @@ __global__ __launch_bounds__(256) void amax_partial_kernel(const float4* __restr
 }
 
 extern "C" int lp_amax_blocks(void) { return AMAX_BLOCKS; }
+extern "C" int lp_amax_slots(void) { return LP_AMAX_SLOTS; }
+extern "C" int lp_amax_slot_stride(void) { return LP_AMAX_STRIDE; }
 
 extern "C" int lp_amax_partial(const float* x, long long numel, float* part, void* stream) {
     if (!x || !part) return lp_set_error(LP_ERR_ARG, "lp_amax_partial: null pointer");

@@ -38,6 +38,7 @@ struct Conv16Params {
     const uint16_t* mask16;       // epilogue: y = 0 where this 16-bit activation plane [N][H][W][Co8] is <= 0 (fused ReLU backward)
     uint16_t* o_hi; uint16_t* o_lo;   // optional: 16-bit planes [N][H][W][Co8] of (o_relu ? relu(y) : y) for the consumer conv
     int o_relu;
+    float* amax;                            // LP_AMAX_SLOTS pre-zeroed floats | NULL: fold max|y| in (y will become an fp16 gradient operand)
     float* part; long long part_bytes;      // split-K partial sums [ksplit][N*H*W][Cout] (caller's workspace)
     int N, H, W, Hin, Win, Cin, C8, Cout, Co8, CinP, CoutP;
     int res_shift;
@@ -305,6 +306,7 @@ void conv_dma_kernel(Conv16Params p) {
         const int co = co0 + wn * WC + c4 * 4;
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p.bias && co < p.Cout) bv = *(const float4*)(p.bias + co);
+        float am = 0.f;
 #pragma unroll 4
         for (int r0 = 0; r0 < WR; r0 += RPP) {
             const int row = r0 + rsub;
@@ -332,6 +334,7 @@ void conv_dma_kernel(Conv16Params p) {
                     v.z = (mv.z - 1u) < 0x7fffu ? v.z : 0.f; v.w = (mv.w - 1u) < 0x7fffu ? v.w : 0.f;
                 }
                 *(float4*)(p.y + pix * p.Cout + co) = v;
+                am = lp_amax4(am, v);
                 if (p.o_hi) {
                     float o[4] = {v.x, v.y, v.z, v.w};
                     ushort4 oh, ol;
@@ -347,8 +350,10 @@ void conv_dma_kernel(Conv16Params p) {
                 }
             }
         }
+        if (p.amax && p.ksplit == 1) lp_amax_commit(am, p.amax, blockIdx.x + blockIdx.y * 7u);
         return;
     }
+    float am_s = 0.f;
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr) {
 #pragma unroll
@@ -371,6 +376,7 @@ void conv_dma_kernel(Conv16Params p) {
                     if (p.res) v += p.res[rpix + co];
                     if (p.mask16 && !((unsigned)(p.mask16[pixi * p.Co8 + co] - 1u) < 0x7fffu)) v = 0.f;
                     p.y[pix + co] = v;
+                    am_s = fmaxf(am_s, fabsf(v));
                     if (p.o_hi) {
                         const float q = p.o_relu ? fmaxf(v, 0.f) : v;
                         const uint16_t h = lp_f32_to_op16<F16>(q);
@@ -381,6 +387,7 @@ void conv_dma_kernel(Conv16Params p) {
             }
         }
     }
+    if (p.amax) lp_amax_commit(am_s, p.amax, blockIdx.x + blockIdx.y * 7u);
 }
 
 // Split-K finish: y = alpha * sum_s part[s] + bias + res, ReLU mask, 16-bit planes of the consumer -- the whole epilogue of the conv,
@@ -393,6 +400,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(Conv16Params p) {
     const size_t P = (size_t)p.N * p.H * p.W, items = P * C4, slice = P * p.Cout;
     float alpha = p.alpha ? *p.alpha : 1.f;
     if (p.alpha2) alpha *= *p.alpha2;
+    float am = 0.f;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < items; i += (size_t)gridDim.x * 256) {
         const int co = (int)(i % C4) * 4;
         const size_t pix = i / C4;
@@ -417,6 +425,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(Conv16Params p) {
             v.z = (mv.z - 1u) < 0x7fffu ? v.z : 0.f; v.w = (mv.w - 1u) < 0x7fffu ? v.w : 0.f;
         }
         *(float4*)(p.y + pix * p.Cout + co) = v;
+        am = lp_amax4(am, v);
         if (p.o_hi) {
             float o[4] = {v.x, v.y, v.z, v.w};
             ushort4 oh, ol;
@@ -431,6 +440,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(Conv16Params p) {
             if (SPLIT) *(ushort4*)(p.o_lo + pix * p.Co8 + co) = ol;
         }
     }
+    if (p.amax) lp_amax_commit(am, p.amax, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -572,7 +582,8 @@ extern "C" int lp_conv16_fwd(const uint16_t* a_hi, const uint16_t* a_lo, const u
                              const float* bias, const float* res, const float* alpha, const float* alpha2,
                              int N, int H, int W, int Cin, int Cout, int CinP, int CoutP,
                              int ksize, int upsample, int res_shift, int prec, const uint16_t* relu_mask16,
-                             uint16_t* out_hi, uint16_t* out_lo, int out_relu, float* workspace, long long workspace_bytes, void* stream) {
+                             uint16_t* out_hi, uint16_t* out_lo, int out_relu, float* workspace, long long workspace_bytes, float* amax_slots,
+                             void* stream) {
     if (!a_hi || !w_hi || !y) return lp_set_error(LP_ERR_ARG, "lp_conv16_fwd: null pointer");
     if (prec == LP_PREC_BF16X3 && (!w_lo || !a_lo)) return lp_set_error(LP_ERR_ARG, "lp_conv16_fwd: bf16x3 needs the lo planes");
     if (prec == LP_PREC_BF16X3 && out_hi && !out_lo) return lp_set_error(LP_ERR_ARG, "lp_conv16_fwd: bf16x3 needs out_lo");
@@ -581,7 +592,7 @@ extern "C" int lp_conv16_fwd(const uint16_t* a_hi, const uint16_t* a_lo, const u
     if (H < 2 || W < 2) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_conv16_fwd: H,W must be >= 2");
     Conv16Params p;
     p.a_hi = a_hi; p.a_lo = a_lo; p.w_hi = w_hi; p.w_lo = w_lo; p.y = y; p.bias = bias; p.res = res; p.alpha = alpha; p.alpha2 = alpha2;
-    p.mask16 = relu_mask16; p.o_relu = out_relu; p.part = workspace; p.part_bytes = workspace ? workspace_bytes : 0;
+    p.mask16 = relu_mask16; p.o_relu = out_relu; p.part = workspace; p.part_bytes = workspace ? workspace_bytes : 0; p.amax = amax_slots;
     p.o_hi = (Cout & 7) ? nullptr : out_hi; p.o_lo = (Cout & 7) ? nullptr : out_lo;   // (pad channels: the pack pass writes them)
     p.N = N; p.H = H; p.W = W; p.Hin = upsample ? H / 2 : H; p.Win = upsample ? W / 2 : W;
     p.Cin = Cin; p.C8 = (Cin + 7) & ~7; p.Cout = Cout; p.Co8 = (Cout + 7) & ~7; p.CinP = CinP; p.CoutP = CoutP; p.res_shift = res_shift;
@@ -604,6 +615,6 @@ extern "C" int lp_conv16_fwd(const uint16_t* a_hi, const uint16_t* a_lo, const u
     // channel counts the epilogue writes element-wise (Cout % 8 != 0: padding channels) get their 16-bit planes from a
     // bandwidth-bound pass over the finished y instead (same stream)
     if (out_hi && !p.o_hi)
-        return lp_act_pack(y, nullptr, nullptr, out_relu ? 2 : 0, out_hi, out_lo, N, H * W, Cout, prec, nullptr, nullptr, nullptr, stream);
+        return lp_act_pack(y, nullptr, nullptr, out_relu ? 2 : 0, out_hi, out_lo, N, H * W, Cout, prec, nullptr, nullptr, 0, 1, nullptr, stream);
     return LP_OK;
 }

@@ -247,10 +247,11 @@ __global__ void adain_bwd_finalize_kernel(const float* __restrict__ part, const 
 }
 
 __global__ void adain_bwd_apply_kernel(float* __restrict__ dx /* holds g */, const float* __restrict__ x, const float* __restrict__ add,
-                                       const float* __restrict__ coef, long long total4, int HW, int C) {
+                                       const float* __restrict__ coef, long long total4, int HW, int C, float* __restrict__ amax) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long stride = (long long)gridDim.x * blockDim.x;
     const int C4 = C >> 2;
+    float am = 0.f;
     for (; i < total4; i += stride) {
         int c = (int)(i % C4) * 4;
         int n = (int)(i / ((long long)C4 * HW));
@@ -262,7 +263,9 @@ __global__ void adain_bwd_apply_kernel(float* __restrict__ dx /* holds g */, con
         o.w = fmaf(cf[9], g.w, fmaf(cf[10], xv.w, cf[11]));
         if (add) { float4 a = ((const float4*)add)[i]; o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w; }
         ((float4*)dx)[i] = o;
+        am = lp_amax4(am, o);
     }
+    if (amax) lp_amax_commit(am, amax, blockIdx.x);
 }
 
 extern "C" long long lp_adain_bwd_workspace_bytes(int N, int HW, int C) {
@@ -272,7 +275,7 @@ extern "C" long long lp_adain_bwd_workspace_bytes(int N, int HW, int C) {
 
 extern "C" int lp_adain_relu_bwd(const float* dA, const float* x, const float* add, const float* gamma, int ab_stride, const float* mean,
                                  const float* rstd, const float* scale, const float* shift, float* dx, float* dgamma, float* dbeta,
-                                 float* workspace, int N, int H, int W, int C, int upsample, void* stream) {
+                                 float* workspace, int N, int H, int W, int C, int upsample, float* amax_slots, void* stream) {
     if (!dA || !x || !mean || !rstd || !scale || !shift || !dx || !workspace) return lp_set_error(LP_ERR_ARG, "lp_adain_relu_bwd: null pointer");
     if (C & 3) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_adain_relu_bwd: C must be a multiple of 4");
     const int HW = H * W;
@@ -290,17 +293,19 @@ extern "C" int lp_adain_relu_bwd(const float* dA, const float* x, const float* a
     if (rc) return rc;
     long long total4 = (long long)N * HW * C / 4;
     int blocks = (int)((total4 + 255) / 256); if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(adain_bwd_apply_kernel, dim3(blocks), dim3(256), 0, st, dx, x, add, coef, total4, HW, C);
+    hipLaunchKernelGGL(adain_bwd_apply_kernel, dim3(blocks), dim3(256), 0, st, dx, x, add, coef, total4, HW, C, amax_slots);
     return lp_check_launch("adain_bwd_apply");
 }
 
 // ------------------------------------------------------------------------------------------------------------------
 // 2x2 block sum (adjoint of nearest x2 upsampling)
 // ------------------------------------------------------------------------------------------------------------------
-__global__ void sum2x2_kernel(const float* __restrict__ in, float* __restrict__ out, long long total4, int H, int W, int C) {
+__global__ void sum2x2_kernel(const float* __restrict__ in, float* __restrict__ out, long long total4, int H, int W, int C,
+                              float* __restrict__ amax) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long stride = (long long)gridDim.x * blockDim.x;
     const int C4 = C >> 2;
+    float am = 0.f;
     for (; i < total4; i += stride) {
         int c = (int)(i % C4) * 4;
         long long pix = i / C4;
@@ -312,15 +317,17 @@ __global__ void sum2x2_kernel(const float* __restrict__ in, float* __restrict__ 
         o.x = (a0.x + a1.x) + (a2.x + a3.x); o.y = (a0.y + a1.y) + (a2.y + a3.y);
         o.z = (a0.z + a1.z) + (a2.z + a3.z); o.w = (a0.w + a1.w) + (a2.w + a3.w);
         ((float4*)out)[i] = o;
+        am = lp_amax4(am, o);
     }
+    if (amax) lp_amax_commit(am, amax, blockIdx.x);
 }
 
-extern "C" int lp_sum2x2(const float* in, float* out, int N, int H, int W, int C, void* stream) {
+extern "C" int lp_sum2x2(const float* in, float* out, int N, int H, int W, int C, float* amax_slots, void* stream) {
     if (!in || !out) return lp_set_error(LP_ERR_ARG, "lp_sum2x2: null pointer");
     if (C & 3) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_sum2x2: C must be a multiple of 4");
     long long total4 = (long long)N * H * W * C / 4;
     int blocks = (int)((total4 + 255) / 256); if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(sum2x2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, total4, H, W, C);
+    hipLaunchKernelGGL(sum2x2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, total4, H, W, C, amax_slots);
     return lp_check_launch("sum2x2");
 }
 
@@ -342,22 +349,26 @@ __global__ void head_fwd_kernel(const float* __restrict__ z, float* __restrict__
 }
 
 __global__ void head_bwd_kernel(const float* __restrict__ t, const float* __restrict__ d_rgbs, const float* __restrict__ d_segm,
-                                float* __restrict__ dz, int N, int HW) {
+                                float* __restrict__ dz, int N, int HW, float* __restrict__ amax) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long long)N * HW) return;
-    int n = (int)(i / HW), pix = (int)(i % HW);
-    float4 tv = ((const float4*)t)[i];
-    float sg = tv.w * 0.5f + 0.5f;
-    const float* dr = d_rgbs + (size_t)n * 3 * HW + pix;
-    float d0 = dr[0], d1 = dr[HW], d2 = dr[2 * (size_t)HW];
-    float dsg = d0 * (tv.x * 0.75f + 0.5f) + d1 * (tv.y * 0.75f + 0.5f) + d2 * (tv.z * 0.75f + 0.5f);
-    if (d_segm) dsg += d_segm[i];
-    float4 o;
-    o.x = d0 * sg * 0.75f * (1.f - tv.x * tv.x);
-    o.y = d1 * sg * 0.75f * (1.f - tv.y * tv.y);
-    o.z = d2 * sg * 0.75f * (1.f - tv.z * tv.z);
-    o.w = dsg * 0.5f * (1.f - tv.w * tv.w);
-    ((float4*)dz)[i] = o;
+    float am = 0.f;
+    if (i < (long long)N * HW) {
+        int n = (int)(i / HW), pix = (int)(i % HW);
+        float4 tv = ((const float4*)t)[i];
+        float sg = tv.w * 0.5f + 0.5f;
+        const float* dr = d_rgbs + (size_t)n * 3 * HW + pix;
+        float d0 = dr[0], d1 = dr[HW], d2 = dr[2 * (size_t)HW];
+        float dsg = d0 * (tv.x * 0.75f + 0.5f) + d1 * (tv.y * 0.75f + 0.5f) + d2 * (tv.z * 0.75f + 0.5f);
+        if (d_segm) dsg += d_segm[i];
+        float4 o;
+        o.x = d0 * sg * 0.75f * (1.f - tv.x * tv.x);
+        o.y = d1 * sg * 0.75f * (1.f - tv.y * tv.y);
+        o.z = d2 * sg * 0.75f * (1.f - tv.z * tv.z);
+        o.w = dsg * 0.5f * (1.f - tv.w * tv.w);
+        ((float4*)dz)[i] = o;
+        am = lp_amax4(0.f, o);
+    }
+    if (amax) lp_amax_commit(am, amax, blockIdx.x);       // (all lanes: the wave reduction is a cross-lane shuffle)
 }
 
 extern "C" int lp_head_fwd(const float* z, float* t, float* fake_rgbs, float* fake_segm, int N, int H, int W, void* stream) {
@@ -367,10 +378,11 @@ extern "C" int lp_head_fwd(const float* z, float* t, float* fake_rgbs, float* fa
     return lp_check_launch("head_fwd");
 }
 
-extern "C" int lp_head_bwd(const float* t, const float* d_rgbs, const float* d_segm, float* dz, int N, int H, int W, void* stream) {
+extern "C" int lp_head_bwd(const float* t, const float* d_rgbs, const float* d_segm, float* dz, int N, int H, int W, float* amax_slots,
+                           void* stream) {
     if (!t || !d_rgbs || !dz) return lp_set_error(LP_ERR_ARG, "lp_head_bwd: null pointer");
     long long total = (long long)N * H * W;
-    hipLaunchKernelGGL(head_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, t, d_rgbs, d_segm, dz, N, H * W);
+    hipLaunchKernelGGL(head_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, t, d_rgbs, d_segm, dz, N, H * W, amax_slots);
     return lp_check_launch("head_bwd");
 }
 
@@ -423,10 +435,11 @@ __global__ void avgpool2_fwd_kernel(const float* __restrict__ x, float* __restri
 
 // dx[n,y,x,c] = 0.25 * dy[n,y>>1,x>>1,c] * (relu_in ? [x>0] : 1).  H, W = INPUT (full-res) dims; one thread per 2x2 block.
 __global__ void avgpool2_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx, long long total4,
-                                    int H, int W, int C, int relu_in) {
+                                    int H, int W, int C, int relu_in, float* __restrict__ amax) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long stride = (long long)gridDim.x * blockDim.x;
     const int C4 = C >> 2, Ho = H >> 1, Wo = W >> 1;
+    float am = 0.f;
     for (; i < total4; i += stride) {
         int c = (int)(i % C4) * 4;
         long long pix = i / C4;
@@ -444,8 +457,10 @@ __global__ void avgpool2_bwd_kernel(const float* __restrict__ dy, const float* _
                 o.x = v.x > 0.f ? o.x : 0.f; o.y = v.y > 0.f ? o.y : 0.f; o.z = v.z > 0.f ? o.z : 0.f; o.w = v.w > 0.f ? o.w : 0.f;
             }
             *(float4*)(dx + base + offs[k]) = o;
+            am = lp_amax4(am, o);
         }
     }
+    if (amax) lp_amax_commit(am, amax, blockIdx.x);
 }
 
 extern "C" int lp_avgpool2_fwd(const float* x, float* y, int N, int H, int W, int C, int relu_in, void* stream) {
@@ -457,12 +472,13 @@ extern "C" int lp_avgpool2_fwd(const float* x, float* y, int N, int H, int W, in
     return lp_check_launch("avgpool2_fwd");
 }
 
-extern "C" int lp_avgpool2_bwd(const float* dy, const float* x, float* dx, int N, int H, int W, int C, int relu_in, void* stream) {
+extern "C" int lp_avgpool2_bwd(const float* dy, const float* x, float* dx, int N, int H, int W, int C, int relu_in, float* amax_slots,
+                               void* stream) {
     if (!dy || !dx || (relu_in && !x)) return lp_set_error(LP_ERR_ARG, "lp_avgpool2_bwd: null pointer");
     if ((C & 3) || (H & 1) || (W & 1)) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_avgpool2_bwd: C%4, H%2, W%2 must be 0");
     long long total4 = (long long)N * (H / 2) * (W / 2) * C / 4;
     int blocks = (int)((total4 + 255) / 256); if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, dx, total4, H, W, C, relu_in);
+    hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, dx, total4, H, W, C, relu_in, amax_slots);
     return lp_check_launch("avgpool2_bwd");
 }
 
@@ -501,10 +517,12 @@ __global__ __launch_bounds__(256) void l1_finalize_kernel(const float* __restric
 
 // da = coef * g[0] * sign(relu?(a) - relu?(b)) * (relu_in ? [a>0] : 1)  (+ add: the gradient arriving at `a` from its other consumer)
 __global__ void l1_bwd_kernel(const float4* __restrict__ a, const float4* __restrict__ b, const float* __restrict__ g, float coef,
-                              const float4* __restrict__ add, float4* __restrict__ da, long long total4, int relu_in) {
+                              const float4* __restrict__ add, float4* __restrict__ da, long long total4, int relu_in,
+                              float* __restrict__ amax) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long stride = (long long)gridDim.x * blockDim.x;
     const float k = coef * g[0];
+    float am = 0.f;
     for (; i < total4; i += stride) {
         float4 u = a[i], v = b[i], o;
         float ux = relu_in ? fmaxf(u.x, 0.f) : u.x, uy = relu_in ? fmaxf(u.y, 0.f) : u.y, uz = relu_in ? fmaxf(u.z, 0.f) : u.z,
@@ -516,7 +534,9 @@ __global__ void l1_bwd_kernel(const float4* __restrict__ a, const float4* __rest
         if (relu_in) { o.x = u.x > 0.f ? o.x : 0.f; o.y = u.y > 0.f ? o.y : 0.f; o.z = u.z > 0.f ? o.z : 0.f; o.w = u.w > 0.f ? o.w : 0.f; }
         if (add) { const float4 e = add[i]; o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w; }
         da[i] = o;
+        am = lp_amax4(am, o);
     }
+    if (amax) lp_amax_commit(am, amax, blockIdx.x);
 }
 
 #define L1_BLOCKS 1024
@@ -533,13 +553,13 @@ extern "C" int lp_l1_fwd(const float* a, const float* b, float* partial, long lo
 }
 
 extern "C" int lp_l1_bwd(const float* a, const float* b, const float* grad_out, float coef, const float* add, float* da, long long numel,
-                         int relu_in, void* stream) {
+                         int relu_in, float* amax_slots, void* stream) {
     if (!a || !b || !grad_out || !da) return lp_set_error(LP_ERR_ARG, "lp_l1_bwd: null pointer");
     if (numel & 3) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_l1_bwd: numel must be a multiple of 4");
     long long total4 = numel / 4;
     int blocks = (int)((total4 + 255) / 256); if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(l1_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)a, (const float4*)b, grad_out, coef,
-                       (const float4*)add, (float4*)da, total4, relu_in);
+                       (const float4*)add, (float4*)da, total4, relu_in, amax_slots);
     return lp_check_launch("l1_bwd");
 }
 

@@ -60,6 +60,25 @@ __device__ __forceinline__ void lp_glds16(const void* gsrc, unsigned lds_dst) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
+// Producer-side amax of a gradient tensor: kernels that WRITE a tensor which lp_act_pack will turn into fp16 gradient planes fold
+// max|v| of what they write into LP_AMAX_SLOTS pre-zeroed floats, LP_AMAX_STRIDE floats (one 128-B line, so the slots spread over
+// the L2 channels) apart: per wave one atomic max on the IEEE bit pattern (non-negative floats order like unsigned integers; the
+// result does not depend on the order of arrival), fire-and-forget.  lp_act_pack(amax_part =
+// slots, amax_count = LP_AMAX_SLOTS, amax_stride = LP_AMAX_STRIDE) then needs no separate pass over the tensor.  Call from every
+// lane of the wave.
+#define LP_AMAX_SLOTS 64
+#define LP_AMAX_STRIDE 32
+__device__ __forceinline__ float lp_amax4(float m, const float4& v) {
+    return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+}
+__device__ __forceinline__ void lp_amax_commit(float m, float* slots, unsigned key) {
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+    if ((threadIdx.x & 63) == 0) {
+        unsigned* s = (unsigned*)slots + ((key + (threadIdx.x >> 6)) & (LP_AMAX_SLOTS - 1)) * LP_AMAX_STRIDE;
+        if (m > 0.f) atomicMax(s, __float_as_uint(m));          // no return value: the wave does not wait for it
+    }
+}
+
 __device__ __forceinline__ void lp_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 template <int N> __device__ __forceinline__ void lp_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory"); }
 

@@ -135,6 +135,43 @@ def _alloc16(n, h, w, c, prec, device):
     return hi, lo
 
 
+FUSE_AMAX = os.environ.get('LP_FUSE_AMAX', '1') != '0'      # LP_FUSE_AMAX=0: every gradient operand gets its own amax pass (test knob)
+AMAX_STATS = {'fused': 0, 'pass': 0}
+
+
+class _AmaxSlots:
+    """Zeroed slot groups (lp_amax_slots() slots, lp_amax_slot_stride() floats apart) for the kernels that fold max|y| of a gradient tensor into their epilogue.
+    Handed out from one buffer zeroed by a single fill launch; under hipGraph capture the buffer (and its fill) belong to the
+    capture, so every replay starts from zeros."""
+
+    def __init__(self):
+        self.buf, self.pos, self.captured, self.n = None, 0, False, 0
+
+    def take(self, device):
+        if not self.n:
+            self.n = _lib.lib().lp_amax_slots() * _lib.lib().lp_amax_slot_stride()
+        capturing = torch.cuda.is_current_stream_capturing()
+        if (self.buf is None or self.pos + self.n > self.buf.numel() or self.buf.device != device or capturing != self.captured):
+            self.buf = torch.zeros(self.n * 256, dtype=torch.float32, device=device)
+            self.pos, self.captured = 0, capturing
+        s = self.buf[self.pos:self.pos + self.n]
+        self.pos += self.n
+        return s
+
+
+_AMAX_SLOTS = _AmaxSlots()
+
+
+def _amax_attach(out: Tensor, want: bool):
+    """slot group for a kernel about to write gradient tensor ``out`` (or None): remembered on the tensor object, together with its
+    version counter -- an in-place update (autograd accumulating a second gradient into it) invalidates the recorded maximum"""
+    if not (want and FUSE_AMAX):
+        return None
+    slots = _AMAX_SLOTS.take(out.device)
+    out._lp_amax = (slots, out._version)
+    return slots
+
+
 def act_pack(x: Tensor, *, pro: int = 0, scale: Optional[Tensor] = None, shift: Optional[Tensor] = None, prec: int = PREC_BF16,
              grad: bool = False) -> Act16:
     """x [N,H,W,C] fp32 -> operand planes of act(x): pro 0 identity | 1 relu(x*scale[n,c]+shift[n,c]) | 2 relu(x) |
@@ -145,22 +182,30 @@ def act_pack(x: Tensor, *, pro: int = 0, scale: Optional[Tensor] = None, shift: 
     n, h, w, c = x.shape
     hi, lo = _alloc16(n, h, w, c, prec, x.device)
     sc = part = None
+    npart, pstride = 0, 1
     if grad and prec == PREC_F16:
-        nb = _lib.lib().lp_amax_blocks()
-        buf = torch.empty(nb + 2, dtype=torch.float32, device=x.device)
-        part, sc = buf[:nb], buf[nb:]
-        check(_lib.lib().lp_amax_partial(x.data_ptr(), x.numel(), part.data_ptr(), _stream()), 'lp_amax_partial')
+        rec = getattr(x, '_lp_amax', None)
+        if rec is not None and rec[1] == x._version and FUSE_AMAX:
+            part, npart, pstride = rec[0], _lib.lib().lp_amax_slots(), _lib.lib().lp_amax_slot_stride()    # folded in by the kernel that wrote x
+            sc = torch.empty(2, dtype=torch.float32, device=x.device)
+            AMAX_STATS['fused'] += 1
+        else:
+            npart = _lib.lib().lp_amax_blocks()
+            buf = torch.empty(npart + 2, dtype=torch.float32, device=x.device)
+            part, sc = buf[:npart], buf[npart:]
+            check(_lib.lib().lp_amax_partial(x.data_ptr(), x.numel(), part.data_ptr(), _stream()), 'lp_amax_partial')
+            AMAX_STATS['pass'] += 1
     for t, nm in ((scale, 'scale'), (shift, 'shift')):
         if t is not None:
             _chk(t, nm)
-    check(_lib.lib().lp_act_pack(x.data_ptr(), _p(scale), _p(shift), pro, hi.data_ptr(), _p(lo), n, h * w, c, prec, None, _p(part), _p(sc),
-                                 _stream()), 'lp_act_pack')
+    check(_lib.lib().lp_act_pack(x.data_ptr(), _p(scale), _p(shift), pro, hi.data_ptr(), _p(lo), n, h * w, c, prec, None, _p(part), npart,
+                                 pstride, _p(sc), _stream()), 'lp_act_pack')
     return Act16(hi, lo, c, None if sc is None else sc[1:])
 
 
 def conv16(a: Act16, pack: WeightPack, *, ksize: int, upsample: bool = False, bias: Optional[Tensor] = None,
            res: Optional[Tensor] = None, res_shift: int = 0, alpha: Optional[Tensor] = None, prec: int = PREC_BF16,
-           relu_mask: Optional[Act16] = None, out16: Optional[int] = None):
+           relu_mask: Optional[Act16] = None, out16: Optional[int] = None, amax: bool = False):
     """y = alpha * conv(up2?(a), pack) + bias + res on operand planes; a [N,Hin,Win,C8] -> y [N,H,W,Cout] fp32.
     ``relu_mask``: operand planes [N,H,W,Co8] of the forward conv's input; y is zeroed where they are <= 0 (fused ReLU backward
     when this launch is a data gradient).  ``out16`` = 0 | 1: also return the operand planes of y (1: of relu(y)) -> (y, Act16)."""
@@ -180,13 +225,14 @@ def conv16(a: Act16, pack: WeightPack, *, ksize: int, upsample: bool = False, bi
     o_hi = o_lo = None
     if out16 is not None:
         o_hi, o_lo = _alloc16(n, h, w, cout, prec, y.device)
+    slots = _amax_attach(y, amax and prec == PREC_F16)       # y is a gradient that will be packed: max|y| from the epilogue
     ws_bytes = _lib.lib().lp_conv16_fwd_workspace_bytes(n, h, w, cout, ksize)          # split-K partial tiles (small feature maps)
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=y.device) if ws_bytes else None
     with _Timed('conv_igemm', 2.0 * n * h * w * cout * cin * ksize * ksize, (n, h, w, cin, cout, ksize, int(upsample), 0)):
         check(_lib.lib().lp_conv16_fwd(a.hi.data_ptr(), _p(a.lo), pack.hi.data_ptr(), _p(pack.lo), y.data_ptr(), _p(bias), _p(res),
                                        _p(alpha), _p(a.inv), n, h, w, cin, cout, pack.cols_p, pack.rows_p, ksize, int(upsample),
                                        res_shift, prec, None if relu_mask is None else relu_mask.hi.data_ptr(), _p(o_hi), _p(o_lo),
-                                       int(bool(out16)), _p(ws), ws_bytes, _stream()), 'lp_conv16_fwd')
+                                       int(bool(out16)), _p(ws), ws_bytes, _p(slots), _stream()), 'lp_conv16_fwd')
     if out16 is not None:
         return y, Act16(o_hi, o_lo, cout, None)
     return y
@@ -452,8 +498,9 @@ def instnorm_stats(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], e
 
 
 def adain_relu_bwd(dA: Tensor, x: Tensor, add: Optional[Tensor], gamma: Tensor, mean: Tensor, rstd: Tensor, scale: Tensor,
-                   shift: Tensor, dgamma: Tensor, dbeta: Tensor, upsample: bool) -> Tensor:
-    """Backward of relu(AdaIN(x)) (+x2 upsample).  dgamma/dbeta: [N,C] views into the projector-output gradient (written)."""
+                   shift: Tensor, dgamma: Tensor, dbeta: Tensor, upsample: bool, amax: bool = False) -> Tensor:
+    """Backward of relu(AdaIN(x)) (+x2 upsample).  dgamma/dbeta: [N,C] views into the projector-output gradient (written).
+    ``amax`` (here and below): the result will be packed as an fp16 gradient operand -- fold its max|.| into the kernel."""
     _chk(dA, 'dA'); _chk(x, 'x')
     n, h, w, c = x.shape
     assert dA.shape == (n, h << int(upsample), w << int(upsample), c), (dA.shape, x.shape)
@@ -463,15 +510,16 @@ def adain_relu_bwd(dA: Tensor, x: Tensor, add: Optional[Tensor], gamma: Tensor, 
     ws = torch.empty(_lib.lib().lp_adain_bwd_workspace_bytes(n, h * w, c) // 4, dtype=torch.float32, device=x.device)
     check(_lib.lib().lp_adain_relu_bwd(dA.data_ptr(), x.data_ptr(), _p(add), gamma.data_ptr(), gamma.stride(0), mean.data_ptr(),
                                        rstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), dx.data_ptr(), dgamma.data_ptr(),
-                                       dbeta.data_ptr(), ws.data_ptr(), n, h, w, c, int(upsample), _stream()), 'lp_adain_relu_bwd')
+                                       dbeta.data_ptr(), ws.data_ptr(), n, h, w, c, int(upsample), _p(_amax_attach(dx, amax)), _stream()),
+          'lp_adain_relu_bwd')
     return dx
 
 
-def sum2x2(x: Tensor) -> Tensor:
+def sum2x2(x: Tensor, amax: bool = False) -> Tensor:
     _chk(x, 'x')
     n, h2, w2, c = x.shape
     out = torch.empty((n, h2 // 2, w2 // 2, c), dtype=torch.float32, device=x.device)
-    check(_lib.lib().lp_sum2x2(x.data_ptr(), out.data_ptr(), n, h2 // 2, w2 // 2, c, _stream()), 'lp_sum2x2')
+    check(_lib.lib().lp_sum2x2(x.data_ptr(), out.data_ptr(), n, h2 // 2, w2 // 2, c, _p(_amax_attach(out, amax)), _stream()), 'lp_sum2x2')
     return out
 
 
@@ -487,13 +535,14 @@ def head_fwd(z: Tensor, want_t: bool = True) -> Tuple[Optional[Tensor], Tensor, 
     return t, rgbs, segm
 
 
-def head_bwd(t: Tensor, d_rgbs: Tensor, d_segm: Optional[Tensor]) -> Tensor:
+def head_bwd(t: Tensor, d_rgbs: Tensor, d_segm: Optional[Tensor], amax: bool = False) -> Tensor:
     _chk(t, 't'); _chk(d_rgbs, 'd_rgbs')
     n, h, w, _ = t.shape
     dz = torch.empty_like(t)
     if d_segm is not None:
         _chk(d_segm, 'd_segm')
-    check(_lib.lib().lp_head_bwd(t.data_ptr(), d_rgbs.data_ptr(), _p(d_segm), dz.data_ptr(), n, h, w, _stream()), 'lp_head_bwd')
+    check(_lib.lib().lp_head_bwd(t.data_ptr(), d_rgbs.data_ptr(), _p(d_segm), dz.data_ptr(), n, h, w, _p(_amax_attach(dz, amax)), _stream()),
+          'lp_head_bwd')
     return dz
 
 
@@ -512,11 +561,12 @@ def avgpool2_fwd(x: Tensor, relu_in: bool) -> Tensor:
     return y
 
 
-def avgpool2_bwd(dy: Tensor, x: Tensor, relu_in: bool) -> Tensor:
+def avgpool2_bwd(dy: Tensor, x: Tensor, relu_in: bool, amax: bool = False) -> Tensor:
     _chk(dy, 'dy'); _chk(x, 'x')
     n, h, w, c = x.shape
     dx = torch.empty_like(x)
-    check(_lib.lib().lp_avgpool2_bwd(dy.data_ptr(), x.data_ptr(), dx.data_ptr(), n, h, w, c, int(relu_in), _stream()), 'lp_avgpool2_bwd')
+    check(_lib.lib().lp_avgpool2_bwd(dy.data_ptr(), x.data_ptr(), dx.data_ptr(), n, h, w, c, int(relu_in), _p(_amax_attach(dx, amax)),
+                                     _stream()), 'lp_avgpool2_bwd')
     return dx
 
 
@@ -531,13 +581,13 @@ def l1_sum(a: Tensor, b: Tensor, relu_in: bool, coef: float = 1.0) -> Tensor:
     return out.reshape(())
 
 
-def l1_bwd(a: Tensor, b: Tensor, grad_out: Tensor, coef: float, relu_in: bool, add: Optional[Tensor] = None) -> Tensor:
+def l1_bwd(a: Tensor, b: Tensor, grad_out: Tensor, coef: float, relu_in: bool, add: Optional[Tensor] = None, amax: bool = False) -> Tensor:
     """gradient of coef * sum|relu?(a) - relu?(b)| w.r.t. a, times grad_out; ``add`` (same shape) is summed in"""
     _chk(a, 'a'); _chk(b, 'b')
     if add is not None:
         _chk(add, 'add'); assert add.shape == a.shape
     g = grad_out.reshape(1).contiguous().float()
     da = torch.empty_like(a)
-    check(_lib.lib().lp_l1_bwd(a.data_ptr(), b.data_ptr(), g.data_ptr(), float(coef), _p(add), da.data_ptr(), a.numel(), int(relu_in), _stream()),
-          'lp_l1_bwd')
+    check(_lib.lib().lp_l1_bwd(a.data_ptr(), b.data_ptr(), g.data_ptr(), float(coef), _p(add), da.data_ptr(), a.numel(), int(relu_in),
+                               _p(_amax_attach(da, amax)), _stream()), 'lp_l1_bwd')
     return da

@@ -392,6 +392,7 @@ class _DecoderFunction(torch.autograd.Function):
     def backward(ctx, d_rgbs, d_segm):
         cfg = ctx.cfg
         blocks, prec = cfg['blocks'], cfg['prec']
+        f16 = prec == PREC_F16          # gradient tensors become fp16 operands: their producers fold max|.| in (no amax pass)
         sn = cfg['sn']
         affine, wl = ctx.affine, ctx.weights
         params = ctx.params
@@ -406,7 +407,7 @@ class _DecoderFunction(torch.autograd.Function):
 
         x, sth, oh, t, ah = ctx.head
         ch = blocks[-1][1]
-        dz = ops.head_bwd(t, d_rgbs.contiguous(), None if d_segm is None else d_segm.contiguous())
+        dz = ops.head_bwd(t, d_rgbs.contiguous(), None if d_segm is None else d_segm.contiguous(), amax=f16)
         wi = len(wl) - 2
         if ops.thin_wgrad_supported(ch, dz.shape[3], 3, 1, dz.shape[2]):
             grads[wi], grads[wi + 1] = ops.thin_wgrad(x, dz, ksize=3, pro=1, scale=sth[2], shift=sth[3], sn=snw(wi),
@@ -421,7 +422,7 @@ class _DecoderFunction(torch.autograd.Function):
         pT = tpack(wi, small_k=True)
         dA = ops.conv(dz, pT, ksize=3, alpha=sn[wi][2][1:], prec=prec, grad=True)
         g, dg, db = slices(oh, ch)
-        dx = ops.adain_relu_bwd(dA, x, None, g, sth[0], sth[1], sth[2], sth[3], dg, db, False)
+        dx = ops.adain_relu_bwd(dA, x, None, g, sth[0], sth[1], sth[2], sth[3], dg, db, False, amax=f16)
         dbg = cfg.get('debug')
         if dbg is not None:
             dbg['dz'] = dz; dbg['dA_head'] = dA; dbg[f'dx{len(blocks)}'] = dx
@@ -437,11 +438,11 @@ class _DecoderFunction(torch.autograd.Function):
             grads[wi + 1] = ops.conv_wgrad16(a1, d16, ksize=3, prec=prec, sn=snw(wi + 1), accum=_accum_target(params[wi + 1]))
             dA1 = ops.conv16(d16, tpack(wi + 1), ksize=3, alpha=sn[wi + 1][2][1:], prec=prec)
             g, dg, db = slices(o1, cout)
-            dh1 = ops.adain_relu_bwd(dA1, h1, None, g, st1[0], st1[1], st1[2], st1[3], dg, db, False)
+            dh1 = ops.adain_relu_bwd(dA1, h1, None, g, st1[0], st1[1], st1[2], st1[3], dg, db, False, amax=f16)
             # skip branch: out += up2(conv1x1(x) + b)
             if has_skip:
                 if up:
-                    ds = ops.sum2x2(d_out)
+                    ds = ops.sum2x2(d_out, amax=f16)
                     ds16 = ops.act_pack(ds, prec=prec, grad=True)
                 else:
                     ds16 = d16
@@ -455,7 +456,7 @@ class _DecoderFunction(torch.autograd.Function):
             grads[wi] = ops.conv_wgrad16(a0, dh16, ksize=3, upsample=up, prec=prec, sn=snw(wi), accum=_accum_target(params[wi]))
             dA0 = ops.conv16(dh16, tpack(wi), ksize=3, alpha=sn[wi][2][1:], prec=prec)
             g, dg, db = slices(o0, cin)
-            dx = ops.adain_relu_bwd(dA0, x, dx_skip, g, st0[0], st0[1], st0[2], st0[3], dg, db, up)
+            dx = ops.adain_relu_bwd(dA0, x, dx_skip, g, st0[0], st0[1], st0[2], st0[3], dg, db, up, amax=f16 and bi > 0)
             if dbg is not None:
                 dbg[f'dx{bi}'] = dx; dbg[f'dh1_{bi}'] = dh1; dbg[f'dxskip{bi}'] = dx_skip
         d_const = dx.sum(dim=0, keepdim=True).permute(0, 3, 1, 2).contiguous()
@@ -731,7 +732,7 @@ class ConvFn(torch.autograd.Function):
                 dx = ops.thin_conv(dy, packT, ksize=ksize, alpha=alpha, prec=prec)
             else:
                 # pro == 2: the forward applied ReLU to x first -> dx = dA * (x > 0), fused into the dgrad launch's epilogue
-                dx = ops.conv16(dy16(), packT, ksize=ksize, alpha=alpha, prec=prec, relu_mask=a16 if pro == 2 else None)
+                dx = ops.conv16(dy16(), packT, ksize=ksize, alpha=alpha, prec=prec, relu_mask=a16 if pro == 2 else None, amax=True)
         want_db = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             kw = dict(ksize=ksize, sn=None if sn is None else (wd,) + tuple(sn),
@@ -773,7 +774,7 @@ class AvgPool2Fn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
-        return ops.avgpool2_bwd(dy.contiguous(), x, ctx.relu_in), None
+        return ops.avgpool2_bwd(dy.contiguous(), x, ctx.relu_in, amax=default_prec() == PREC_F16), None
 
 
 class L1Fn(torch.autograd.Function):
@@ -789,7 +790,7 @@ class L1Fn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         a, b = ctx.saved_tensors
-        return ops.l1_bwd(a, b, g, 1.0 / a.numel(), ctx.relu_in), None, None
+        return ops.l1_bwd(a, b, g, 1.0 / a.numel(), ctx.relu_in, amax=default_prec() == PREC_F16), None, None
 
 
 def hip_l1(a, b, relu_in=False):
@@ -814,7 +815,7 @@ class L1TapFn(torch.autograd.Function):
         if g_loss is None:
             return g_next, None, None
         add = None if g_next is None else g_next.contiguous()
-        return ops.l1_bwd(a, b, g_loss, 1.0 / a.numel(), ctx.relu_in, add=add), None, None
+        return ops.l1_bwd(a, b, g_loss, 1.0 / a.numel(), ctx.relu_in, add=add, amax=default_prec() == PREC_F16), None, None
 
 
 def hip_l1_tap(a, b, relu_in=False):

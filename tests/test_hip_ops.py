@@ -281,3 +281,58 @@ def test_grid_crop_fwd_bwd(case):
     torch.cuda.synchronize()
     report(f'grid_crop fwd{case}', rel(out, ref), 1e-5)
     report(f'grid_crop bwd{case}', rel(dimg, img.grad), 1e-5)
+
+
+def test_producer_side_amax_matches_the_amax_pass():
+    """fp16 gradient operands: max|x| folded into the producing kernel's epilogue (conv data gradient incl. split-K, AdaIN backward,
+    avg-pool backward, L1 backward, 2x2 sum) gives the same scale and the same planes as the separate amax pass; an in-place
+    update of the tensor invalidates the recorded maximum (version counter)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(31)
+    prec = 2
+
+    def packs_equal(t):
+        assert getattr(t, '_lp_amax', None) is not None
+        before = dict(ops.AMAX_STATS)
+        a = ops.act_pack(t, prec=prec, grad=True)
+        assert ops.AMAX_STATS['fused'] == before['fused'] + 1, 'recorded maximum not used'
+        ops.FUSE_AMAX = False
+        try:
+            b = ops.act_pack(t, prec=prec, grad=True)
+        finally:
+            ops.FUSE_AMAX = True
+        assert torch.equal(a.inv, b.inv) and torch.equal(a.hi, b.hi)
+
+    for (n, h, w, cin, cout) in [(2, 4, 4, 512, 512), (2, 32, 32, 128, 64), (1, 16, 16, 64, 6)]:       # split-K, coalesced, element-wise epilogues
+        dy = (torch.randn(n, h, w, cout, generator=g) * 1e-4).cuda()
+        wt = (torch.randn(cout, cin, 3, 3, generator=g) * 0.05).cuda()
+        d16 = ops.act_pack(dy, prec=prec, grad=True)
+        dx = ops.conv16(d16, ops.pack_weights(wt, 1, prec), ksize=3, prec=prec, amax=True)
+        packs_equal(dx)
+    x = (torch.randn(2, 16, 16, 64, generator=g) * 3e-5).cuda()
+    packs_equal(ops.avgpool2_bwd(torch.randn(2, 8, 8, 64, generator=g).cuda() * 1e-3, x, True, amax=True))
+    packs_equal(ops.sum2x2(x, amax=True))
+    packs_equal(ops.l1_bwd(x, x.flip(0), torch.tensor(2e-3).cuda(), 1.0 / x.numel(), True, add=x * 0.1, amax=True))
+    t = ops.sum2x2(x, amax=True)
+    t.mul_(64.0)                               # in-place: the recorded maximum is stale now
+    before = dict(ops.AMAX_STATS)
+    a = ops.act_pack(t, prec=prec, grad=True)
+    assert ops.AMAX_STATS['pass'] == before['pass'] + 1
+    ref = t.double().cpu()
+    back = a.hi.view(torch.float16).double().cpu() * float(a.inv[0])
+    assert rel(back, ref) < 1e-3
+
+
+def test_recorded_amax_survives_autograd():
+    """the maximum recorded by a data-gradient launch is found again by the next layer's backward (same tensor object through the
+    autograd engine): a conv -> relu -> conv chain packs its inner gradient without an amax pass"""
+    ops = _ops()
+    from latent_pose_reenactment_amd.nn import hip_conv
+    g = torch.Generator().manual_seed(32)
+    x = torch.randn(2, 16, 16, 64, generator=g).cuda().requires_grad_(True)
+    w1 = (torch.randn(64, 64, 3, 3, generator=g) * 0.05).cuda().requires_grad_(True)
+    w2 = (torch.randn(64, 64, 3, 3, generator=g) * 0.05).cuda().requires_grad_(True)
+    y = hip_conv(hip_conv(x, w1, ksize=3, prec=2), w2, ksize=3, pro=2, prec=2)
+    before = dict(ops.AMAX_STATS)
+    y.square().sum().backward()
+    assert ops.AMAX_STATS['fused'] - before['fused'] >= 1, ops.AMAX_STATS
