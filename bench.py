@@ -6,7 +6,7 @@ Workload at N=1 = BASELINE.json configs[1]: the fine-tuning step of configs/fine
 256x256, synthetic VoxCeleb2-shaped batch, random-init weights (no network for datasets/checkpoints).  One "step" =
 runners/holycow.py:230-257: E(pose) -> G -> D x3 -> criterions -> G backward/step -> D backward/step -> EMA.
 The generator, the discriminator, the VGG19/VGGFace criterions, RAdam, EMA and the spectral-norm power iterations run on the
-hand-written gfx950 kernels of liblp_hip.so; only the MobileNetV2 pose encoder (forward only in fine-tuning) is stock torch-ROCm.  For N>1 the same per-GPU step runs data
+hand-written gfx950 kernels of liblp_hip.so; including the MobileNetV2 pose encoder (forward only in fine-tuning; csrc/mobilenet.hip).  For N>1 the same per-GPU step runs data
 parallel with the RCCL gradient all-reduce of latent_pose_reenactment_amd.parallel (weak scaling).
 
 Prints ONE JSON line on rank 0 (see README/DESIGN for the field definitions)."""
@@ -265,7 +265,7 @@ def drive_fps(args, frames=60):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
     return {'value': round(frames / dt, 2), 'unit': 'frames/s', 'ms_per_frame': round(dt / frames * 1e3, 3), 'batch': 1,
-            'launch_mode': mode, 'note': 'drive.py:84-88 loop (MobileNetV2 pose encoder on torch-ROCm + HIP generator, eval mode, '
+            'launch_mode': mode, 'note': 'drive.py:84-88 loop (MobileNetV2 pose encoder + generator on the HIP kernels, eval mode, '
                                           'bf16 weight packs cached), frames resident in HBM'}
 
 
@@ -451,9 +451,9 @@ def main():
                       'f16': 'f16 (IEEE fp16 MFMA operands incl. power-of-two scaled gradient operands, fp32 accumulate, fp32 activations/weights/optimizer)'}[a.prec],
             'data': 'synthetic VoxCeleb2-shaped batch, random-init weights (VGG weights seeded He-normal)',
             'config': {'workload': {'finetune_step': 'finetuning-base.yaml step (configs[1]): G, D, VGG19/VGGFace criterions, RAdam, EMA, spectral '
-                                                     'norm on hand-written gfx950 kernels; MobileNetV2 pose encoder on torch-ROCm',
+                                                     'norm and the MobileNetV2 pose encoder on hand-written gfx950 kernels',
                                     'metatrain_step': 'default.yaml meta-training step (configs[2]): ResNeXt50 identity encoder over 8 frames + '
-                                                      'MobileNetV2 pose encoder (torch-ROCm), G, D with the 98000x512 label embedding, '
+                                                      'MobileNetV2 pose encoder (both trained here: torch-ROCm autograd), G, D with the 98000x512 label embedding, '
                                                       'VGG19/VGGFace/featmat/adversarial/dis_embed/dice criterions, Adam, EMA (gfx950 kernels)',
                                     'generator': 'generator forward+backward only (HIP kernels)'}[a.workload],
                        'image_size': a.image_size, 'per_gpu_batch': a.batch, 'global_batch': a.batch * world,

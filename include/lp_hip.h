@@ -123,8 +123,9 @@ int lp_grid_crop_fwd(const float* images, const float* boxes, float* out, int N,
 int lp_grid_crop_bwd(const float* dout, const float* boxes, float* dimages, int N, int C, int H, int W, int Ho, int Wo, void* stream);
 
 /* MobileNetV2 pose encoder, forward (embedders/unsupervised_pose_separate_embResNeXt_segmentation.py:26-28,56-58 = torchvision
- * mobilenet_v2(num_classes)): the layers that are not dense contractions; the 1x1 convs are lp_conv16_fwd (ksize 1) on planes
- * written by lp_act_pack (pro 3 = ReLU6 of a per-channel affine) or lp_affine_res.  BatchNorm enters as per-channel
+ * mobilenet_v2(num_classes)), fp32: stem, depthwise and pointwise convs with the producer's BatchNorm (+ ReLU6, + residual) applied
+ * while the input is loaded and the BatchNorm statistics of the output folded into the same launch.  (lp_affine_res / lp_act_pack
+ * pro 3 + lp_conv16_fwd is the alternative MFMA route for the 1x1 convs.)  BatchNorm enters as per-channel
  * (scale, shift): running statistics in eval mode; lp_bn_stats in train mode.
  *   lp_stem_conv_s2:  x [N][3][H][W] NCHW fp32, w [Cout][3][3][3] -> y [N][H/2][W/2][Cout]   (3x3, stride 2, pad 1, no bias)
  *   lp_dwconv3x3_fwd: depthwise 3x3 pad 1 stride 1|2 on relu6(x*in_scale[c]+in_shift[c]) (in_scale NULL: on x), w [C][3][3]
@@ -140,6 +141,20 @@ int lp_affine_res(const float* y, const float* scale, const float* shift, const 
                   long long P, int C, int prec, void* stream);
 int lp_affine_relu6_mean(const float* y, const float* scale, const float* shift, float* out, int N, int HW, int C, void* stream);
 long long lp_bn_stats_workspace_bytes(long long P, int C);
+/*   lp_pwconv_fwd:    1x1 conv on the VALU in fp32 (the encoder's layers are launch- and bandwidth-bound, not MFMA work):
+ *                     y [P][N] = a w^T, a = (in_relu6 ? relu6 : id)(x*in_scale[k]+in_shift[k]) (+ in_res [P][K]); w [N][K] (nn.Conv2d
+ *                     layout); in_scale/in_shift|NULL (both or neither); x_out|NULL: `a` written back (the block input a later
+ *                     residual needs); stats_part|NULL: 9 * lp_pwconv_stat_rows(P, K, N) * N/4 floats, BatchNorm partials of y
+ *   lp_dwconv3x3_stats_fwd: lp_dwconv3x3_fwd + the BatchNorm partials of its output (9 * lp_dwconv_stat_rows() * C/4 floats)
+ *   lp_bn_finalize:   (scale, shift) + running-statistics update from `rows` partials per channel group */
+int lp_pwconv_stat_rows(long long P, int K, int N);
+int lp_pwconv_fwd(const float* x, const float* w, float* y, const float* in_scale, const float* in_shift, int in_relu6,
+                  const float* in_res, float* x_out, float* stats_part, long long P, int K, int N, void* stream);
+int lp_dwconv_stat_rows(int N, int H, int W, int C, int stride);
+int lp_dwconv3x3_stats_fwd(const float* x, const float* w, const float* in_scale, const float* in_shift, float* y, float* stats_part,
+                           int N, int H, int W, int C, int stride, void* stream);
+int lp_bn_finalize(const float* stats_part, int rows, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                   float* scale, float* shift, int C, float eps, float momentum, void* stream);
 int lp_bn_stats(const float* y, const float* gamma, const float* beta, float* running_mean, float* running_var, float* scale,
                 float* shift, float* workspace, long long P, int C, float eps, float momentum, void* stream);
 

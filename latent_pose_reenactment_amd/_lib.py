@@ -48,6 +48,11 @@ SIGNATURES = {
     'lp_affine_res': (_i, [_vp] * 7 + [_ll, _i, _i, _vp]),
     'lp_affine_relu6_mean': (_i, [_vp] * 4 + [_i, _i, _i, _vp]),
     'lp_bn_stats_workspace_bytes': (_ll, [_ll, _i]),
+    'lp_pwconv_stat_rows': (_i, [_ll, _i, _i]),
+    'lp_pwconv_fwd': (_i, [_vp] * 5 + [_i, _vp, _vp, _vp, _ll, _i, _i, _vp]),
+    'lp_dwconv_stat_rows': (_i, [_i] * 5),
+    'lp_dwconv3x3_stats_fwd': (_i, [_vp] * 6 + [_i] * 5 + [_vp]),
+    'lp_bn_finalize': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _f, _vp]),
     'lp_bn_stats': (_i, [_vp] * 8 + [_ll, _i, _f, _f, _vp]),
     'lp_instnorm_workspace_bytes': (_ll, [_i, _i, _i]),
     'lp_instnorm_stats': (_i, [_vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),

@@ -278,45 +278,62 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
     }
 }
 
+// merge of two partials of one channel GROUP: the four channels share their count, so the two quotients are taken once
+struct BnAcc { float n, mean[4], m2[4]; };
+__device__ __forceinline__ void bn_merge4(BnAcc& a, float nb, const float* mb, const float* qb) {
+    if (nb == 0.f) return;
+    if (a.n == 0.f) { a.n = nb; for (int j = 0; j < 4; ++j) { a.mean[j] = mb[j]; a.m2[j] = qb[j]; } return; }
+    const float n = a.n + nb, inv = 1.f / n, fb = nb * inv, fab = a.n * fb;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float d = mb[j] - a.mean[j];
+        a.mean[j] = fmaf(d, fb, a.mean[j]);
+        a.m2[j] += qb[j] + d * d * fab;
+    }
+    a.n = n;
+}
+
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float* __restrict__ rm, float* __restrict__ rv, float* __restrict__ scale,
                                                           float* __restrict__ shift, int G4, int Tu, int T, float eps, float momentum) {
-    __shared__ float sh[9][256];
+    __shared__ float sh[4][9];
     const int g = blockIdx.x;
-    float n = 0.f, mean[4] = {0, 0, 0, 0}, m2[4] = {0, 0, 0, 0};
+    BnAcc a; a.n = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { a.mean[j] = 0.f; a.m2[j] = 0.f; }
     for (int t = g + threadIdx.x * G4; t < Tu; t += 256 * G4) {
-        const float nb = part[t];
-        float na = n;
+        float mb[4], qb[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { na = n; bn_merge(na, mean[j], m2[j], nb, part[(size_t)(1 + j) * T + t], part[(size_t)(5 + j) * T + t]); }
-        n = na;
+        for (int j = 0; j < 4; ++j) { mb[j] = part[(size_t)(1 + j) * T + t]; qb[j] = part[(size_t)(5 + j) * T + t]; }
+        bn_merge4(a, part[t], mb, qb);
     }
-    sh[0][threadIdx.x] = n;
+    for (int o = 32; o > 0; o >>= 1) {                                            // wave reduction by shuffles
+        const float nb = __shfl_down(a.n, o, 64);
+        float mb[4], qb[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { sh[1 + j][threadIdx.x] = mean[j]; sh[5 + j][threadIdx.x] = m2[j]; }
+        for (int j = 0; j < 4; ++j) { mb[j] = __shfl_down(a.mean[j], o, 64); qb[j] = __shfl_down(a.m2[j], o, 64); }
+        bn_merge4(a, nb, mb, qb);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        float* d = sh[threadIdx.x >> 6];
+        d[0] = a.n;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { d[1 + j] = a.mean[j]; d[5 + j] = a.m2[j]; }
+    }
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o) {
-            const float nb = sh[0][threadIdx.x + o];
-            float na = sh[0][threadIdx.x];
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) bn_merge4(a, sh[w][0], &sh[w][1], &sh[w][5]);
+        const float unbias = a.n > 1.f ? a.n / (a.n - 1.f) : 1.f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                na = sh[0][threadIdx.x];
-                bn_merge(na, sh[1 + j][threadIdx.x], sh[5 + j][threadIdx.x], nb, sh[1 + j][threadIdx.x + o], sh[5 + j][threadIdx.x + o]);
+        for (int j = 0; j < 4; ++j) {
+            const int c = g * 4 + j;
+            const float var = a.m2[j] / a.n;
+            const float sc = gamma[c] / sqrtf(var + eps);
+            scale[c] = sc; shift[c] = beta[c] - a.mean[j] * sc;
+            if (rm) {
+                rm[c] = (1.f - momentum) * rm[c] + momentum * a.mean[j];
+                rv[c] = (1.f - momentum) * rv[c] + momentum * var * unbias;
             }
-            sh[0][threadIdx.x] = na;
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x < 4) {
-        const int j = threadIdx.x, c = g * 4 + j;
-        const float cntf = sh[0][0], m = sh[1 + j][0], var = sh[5 + j][0] / cntf;
-        const float sc = gamma[c] / sqrtf(var + eps);
-        scale[c] = sc; shift[c] = beta[c] - m * sc;
-        if (rm) {
-            const float unbias = cntf > 1.f ? cntf / (cntf - 1.f) : 1.f;
-            rm[c] = (1.f - momentum) * rm[c] + momentum * m;
-            rv[c] = (1.f - momentum) * rv[c] + momentum * var * unbias;
         }
     }
 }
@@ -336,5 +353,302 @@ extern "C" int lp_bn_stats(const float* y, const float* gamma, const float* beta
     if (rc) return rc;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(G4), dim3(256), 0, st, workspace, gamma, beta, running_mean, running_var, scale, shift, G4, Tu, T,
                        eps, momentum);
+    return lp_check_launch("bn_finalize");
+}
+
+// ---- pointwise (1x1) conv of the encoder on the VALU, fp32 ---------------------------------------------------------------------
+// y[p][n] = sum_k a[p][k] * w[n][k],   a = in_relu6 ? relu6(x*in_scale[k]+in_shift[k]) : x*in_scale[k]+in_shift[k] (+ in_res[p][k])
+// The encoder is ~0.3 GFLOP per frame spread over 35 such layers with 64 .. 131072 positions: launch-, latency- and bandwidth-bound,
+// not MFMA work.  A 64 x 64 output tile per workgroup (4 x 4 per thread), k in chunks of 16 through LDS; the producer's BatchNorm
+// (+ ReLU6, + the block's residual) is applied while the A tile is loaded, and the tile column 0 workgroups can write that
+// activated input back (x_out: the block input a later residual add needs).  stats: per-(tile row, channel) count / mean / M2 of
+// the raw outputs, in the partial layout of bn_finalize_kernel -- train-mode BatchNorm then costs one small finalize launch.
+#define PW_BM 64
+#define PW_BN 64
+#define PW_BK 16
+struct PwParams {
+    const float* x; const float* w; float* y;
+    const float* in_scale; const float* in_shift; const float* in_res; float* x_out;
+    float* part;
+    int P, K, N, in_relu6;
+};
+
+__global__ __launch_bounds__(256) void pwconv_kernel(PwParams p) {
+    __shared__ __attribute__((aligned(16))) float sm[PW_BM * (PW_BN + 4)];        // As | Bs during the k loop, the output tile afterwards
+    float* As = sm;                                                               // [PW_BK][PW_BM + 4]
+    float* Bs = sm + PW_BK * (PW_BM + 4);                                         // [PW_BK][PW_BN + 4]
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int p0 = blockIdx.x * PW_BM, n0 = blockIdx.y * PW_BN;
+    const int lr = tid >> 2, lk = (tid & 3) * 4;                                   // this thread's (row, k quad) of both tile loads
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    const bool arow = (p0 + lr) < p.P, brow = (n0 + lr) < p.N;
+    // the global loads of chunk c+1 are issued before the FMAs of chunk c (registers), so their latency hides behind the arithmetic
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto gload = [&](int k0) {
+        const int k = k0 + lk;
+        a = make_float4(0.f, 0.f, 0.f, 0.f); b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (arow && k < p.K) a = *(const float4*)(p.x + (size_t)(p0 + lr) * p.K + k);
+        if (brow && k < p.K) b = *(const float4*)(p.w + (size_t)(n0 + lr) * p.K + k);
+    };
+    gload(0);
+    for (int k0 = 0; k0 < p.K; k0 += PW_BK) {
+        const int k = k0 + lk;
+        if (arow && k < p.K) {
+            const size_t off = (size_t)(p0 + lr) * p.K + k;
+            if (p.in_scale) {
+                const float4 s = *(const float4*)(p.in_scale + k), t = *(const float4*)(p.in_shift + k);
+                a.x = fmaf(a.x, s.x, t.x); a.y = fmaf(a.y, s.y, t.y); a.z = fmaf(a.z, s.z, t.z); a.w = fmaf(a.w, s.w, t.w);
+            }
+            if (p.in_relu6) { a.x = fminf(fmaxf(a.x, 0.f), 6.f); a.y = fminf(fmaxf(a.y, 0.f), 6.f); a.z = fminf(fmaxf(a.z, 0.f), 6.f); a.w = fminf(fmaxf(a.w, 0.f), 6.f); }
+            if (p.in_res) { const float4 r = *(const float4*)(p.in_res + off); a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w; }
+            if (p.x_out && blockIdx.y == 0) *(float4*)(p.x_out + off) = a;
+        }
+        __syncthreads();                                                           // previous chunk fully consumed
+        As[(lk + 0) * (PW_BM + 4) + lr] = a.x; As[(lk + 1) * (PW_BM + 4) + lr] = a.y; As[(lk + 2) * (PW_BM + 4) + lr] = a.z; As[(lk + 3) * (PW_BM + 4) + lr] = a.w;
+        Bs[(lk + 0) * (PW_BN + 4) + lr] = b.x; Bs[(lk + 1) * (PW_BN + 4) + lr] = b.y; Bs[(lk + 2) * (PW_BN + 4) + lr] = b.z; Bs[(lk + 3) * (PW_BN + 4) + lr] = b.w;
+        __syncthreads();
+        if (k0 + PW_BK < p.K) gload(k0 + PW_BK);
+#pragma unroll
+        for (int kk = 0; kk < PW_BK; ++kk) {
+            const float4 av = *(const float4*)(As + kk * (PW_BM + 4) + ty * 4), bv = *(const float4*)(Bs + kk * (PW_BN + 4) + tx * 4);
+            const float am[4] = {av.x, av.y, av.z, av.w}, bn[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(am[i], bn[j], acc[i][j]);
+        }
+    }
+    __syncthreads();
+    float* Ct = sm;                                                                // [PW_BM][PW_BN + 4]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *(float4*)(Ct + (ty * 4 + i) * (PW_BN + 4) + tx * 4) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {                                               // coalesced rows: 16 float4 per position
+        const int idx = tid + it * 256, row = idx >> 4, c4 = (idx & 15) * 4;
+        if (p0 + row < p.P && n0 + c4 < p.N) *(float4*)(p.y + (size_t)(p0 + row) * p.N + n0 + c4) = *(const float4*)(Ct + row * (PW_BN + 4) + c4);
+    }
+    if (p.part) {
+        // channel c of the tile: 4 threads (q) take 16 positions each (mean, then M2 around it), thread q == 0 merges them
+        __shared__ float st[3][4][64];
+        const int c = tid & 63, q = tid >> 6;
+        float cnt = 0.f, s = 0.f;
+        for (int i = 0; i < 16; ++i) { const int row = q * 16 + i; if (p0 + row < p.P) { s += Ct[row * (PW_BN + 4) + c]; cnt += 1.f; } }
+        const float mean = cnt > 0.f ? s / cnt : 0.f;
+        float m2 = 0.f;
+        for (int i = 0; i < 16; ++i) { const int row = q * 16 + i; if (p0 + row < p.P) { const float d = Ct[row * (PW_BN + 4) + c] - mean; m2 = fmaf(d, d, m2); } }
+        st[0][q][c] = cnt; st[1][q][c] = mean; st[2][q][c] = m2;
+        __syncthreads();
+        if (q == 0 && n0 + c < p.N) {
+            float na = st[0][0][c], ma = st[1][0][c], qa = st[2][0][c];
+            for (int r = 1; r < 4; ++r) bn_merge(na, ma, qa, st[0][r][c], st[1][r][c], st[2][r][c]);
+            const int G4 = p.N >> 2, T = gridDim.x * G4;
+            const size_t o = (size_t)blockIdx.x * G4 + ((n0 + c) >> 2);
+            const int j = c & 3;
+            if (j == 0) p.part[o] = na;
+            p.part[(size_t)(1 + j) * T + o] = ma;
+            p.part[(size_t)(5 + j) * T + o] = qa;
+        }
+    }
+}
+
+// Few positions (<= PW_ROWS_MAXP: the 16x16 / 8x8 maps of the late blocks): a 64 x 64 tile grid would be a handful of workgroups, each
+// walking the whole contraction alone.  Here a workgroup takes 8 positions (their activated inputs staged in LDS) and each of its waves
+// one output channel at a time, the lanes splitting the contraction in float4 steps and reducing by shuffles -- the weight rows stream
+// from L2 once per 8 positions, and the grid is (N / 4 channels) x (P / 8 position tiles) workgroups.
+#define PW_RT 8
+#define PW_ROWS_MAXP 2048
+#define PW_ROWS_MAXK 2048
+__global__ __launch_bounds__(256) void pwconv_rows_kernel(PwParams p) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];                     // [PW_RT][K]
+    const int r0 = blockIdx.y * PW_RT, rt = min(PW_RT, p.P - r0);
+    const int K4 = p.K >> 2;
+    for (int i = threadIdx.x; i < rt * K4; i += 256) {
+        const int r = i / K4, k = (i - r * K4) * 4;
+        const size_t off = (size_t)(r0 + r) * p.K + k;
+        float4 a = *(const float4*)(p.x + off);
+        if (p.in_scale) {
+            const float4 s = *(const float4*)(p.in_scale + k), t = *(const float4*)(p.in_shift + k);
+            a.x = fmaf(a.x, s.x, t.x); a.y = fmaf(a.y, s.y, t.y); a.z = fmaf(a.z, s.z, t.z); a.w = fmaf(a.w, s.w, t.w);
+        }
+        if (p.in_relu6) { a.x = fminf(fmaxf(a.x, 0.f), 6.f); a.y = fminf(fmaxf(a.y, 0.f), 6.f); a.z = fminf(fmaxf(a.z, 0.f), 6.f); a.w = fminf(fmaxf(a.w, 0.f), 6.f); }
+        if (p.in_res) { const float4 r4 = *(const float4*)(p.in_res + off); a.x += r4.x; a.y += r4.y; a.z += r4.z; a.w += r4.w; }
+        if (p.x_out && blockIdx.x == 0) *(float4*)(p.x_out + off) = a;
+        *(float4*)(xs + r * p.K + k) = a;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int n = blockIdx.x * 4 + wave; n < p.N; n += gridDim.x * 4) {
+        float acc[PW_RT];
+#pragma unroll
+        for (int b = 0; b < PW_RT; ++b) acc[b] = 0.f;
+        const float* wr = p.w + (size_t)n * p.K;
+        for (int k = lane * 4; k < p.K; k += 256) {
+            const float4 wv = *(const float4*)(wr + k);
+#pragma unroll
+            for (int b = 0; b < PW_RT; ++b) {
+                if (b < rt) {
+                    const float4 xv = *(const float4*)(xs + b * p.K + k);
+                    acc[b] = fmaf(wv.x, xv.x, fmaf(wv.y, xv.y, fmaf(wv.z, xv.z, fmaf(wv.w, xv.w, acc[b]))));
+                }
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < PW_RT; ++b)
+            for (int o = 32; o > 0; o >>= 1) acc[b] += __shfl_down(acc[b], o, 64);
+        if (lane == 0) {
+            float s = 0.f;
+            for (int b = 0; b < rt; ++b) { p.y[(size_t)(r0 + b) * p.N + n] = acc[b]; s += acc[b]; }
+            if (p.part) {
+                const float mean = s / (float)rt;
+                float m2 = 0.f;
+                for (int b = 0; b < rt; ++b) { const float d = acc[b] - mean; m2 = fmaf(d, d, m2); }
+                const int G4 = p.N >> 2, T = gridDim.y * G4, j = n & 3;
+                const size_t o = (size_t)blockIdx.y * G4 + (n >> 2);
+                if (j == 0) p.part[o] = (float)rt;
+                p.part[(size_t)(1 + j) * T + o] = mean;
+                p.part[(size_t)(5 + j) * T + o] = m2;
+            }
+        }
+    }
+}
+
+static bool pw_use_rows(long long P, int K, int N) {
+    return P <= PW_ROWS_MAXP && K <= PW_ROWS_MAXK && ((P + PW_BM - 1) / PW_BM) * ((N + PW_BN - 1) / PW_BN) < 96;
+}
+
+extern "C" int lp_pwconv_stat_rows(long long P, int K, int N) {
+    return pw_use_rows(P, K, N) ? (int)((P + PW_RT - 1) / PW_RT) : (int)((P + PW_BM - 1) / PW_BM);
+}
+
+extern "C" int lp_pwconv_fwd(const float* x, const float* w, float* y, const float* in_scale, const float* in_shift, int in_relu6,
+                             const float* in_res, float* x_out, float* stats_part, long long P, int K, int N, void* stream) {
+    if (!x || !w || !y) return lp_set_error(LP_ERR_ARG, "lp_pwconv_fwd: null pointer");
+    if ((K & 3) || (N & 3) || P < 1 || (!in_scale != !in_shift)) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_pwconv_fwd: needs K % 4 == 0, N % 4 == 0");
+    PwParams p;
+    p.x = x; p.w = w; p.y = y; p.in_scale = in_scale; p.in_shift = in_shift; p.in_res = in_res; p.x_out = x_out; p.part = stats_part;
+    p.P = (int)P; p.K = K; p.N = N; p.in_relu6 = in_relu6;
+    if (pw_use_rows(P, K, N)) {
+        const int tiles = (int)((P + PW_RT - 1) / PW_RT);
+        int bx = (N + 3) / 4; if (bx > 512) bx = 512;      // (fewer, fatter workgroups were measured slower: a wave's channel loop is latency bound)
+        dim3 grid((unsigned)bx, (unsigned)tiles);
+        hipLaunchKernelGGL(pwconv_rows_kernel, grid, dim3(256), (size_t)PW_RT * K * sizeof(float), (hipStream_t)stream, p);
+        return lp_check_launch("pwconv_rows");
+    }
+    dim3 grid((unsigned)((P + PW_BM - 1) / PW_BM), (unsigned)((N + PW_BN - 1) / PW_BN));
+    hipLaunchKernelGGL(pwconv_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    return lp_check_launch("pwconv_fwd");
+}
+
+// ---- depthwise 3x3 with the BatchNorm statistics of its output folded in (train mode) -----------------------------------------------
+// Same arithmetic as dwconv3x3_kernel; the item loop has the shape of bn_partial_kernel (a thread keeps one group of 4 channels), so
+// the count / mean / M2 partials of the outputs come out of the same pass.
+__global__ __launch_bounds__(256) void dwconv3x3_stats_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ sc,
+                                                              const float* __restrict__ sh, float* __restrict__ y, float* __restrict__ part,
+                                                              int N, int H, int W, int C, int stride, int BT, int T) {
+    __shared__ float shm[9][256];
+    const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride, G4 = C >> 2;
+    const long long items = (long long)N * Ho * Wo * G4, step = (long long)gridDim.x * BT;
+    float cnt = 0.f, ref[4] = {0, 0, 0, 0}, sd[4] = {0, 0, 0, 0}, sq[4] = {0, 0, 0, 0};
+    if ((int)threadIdx.x < BT) {
+        const int g = threadIdx.x % G4, c = g * 4;
+        float4 s = make_float4(1.f, 1.f, 1.f, 1.f), t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (sc) { s = *(const float4*)(sc + c); t = *(const float4*)(sh + c); }
+        float wk[9][4];
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wk[k][j] = w[(c + j) * 9 + k];
+        for (long long i = (long long)blockIdx.x * BT + threadIdx.x; i < items; i += step) {
+            long long pix = i / G4;
+            const int xo = (int)(pix % Wo); pix /= Wo;
+            const int yo = (int)(pix % Ho); const int n = (int)(pix / Ho);
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int iy = yo * stride + ky - 1, ix = xo * stride + kx - 1;
+                    if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                        float4 v = *(const float4*)(x + (((size_t)n * H + iy) * W + ix) * C + c);
+                        if (sc) {
+                            v.x = fminf(fmaxf(fmaf(v.x, s.x, t.x), 0.f), 6.f); v.y = fminf(fmaxf(fmaf(v.y, s.y, t.y), 0.f), 6.f);
+                            v.z = fminf(fmaxf(fmaf(v.z, s.z, t.z), 0.f), 6.f); v.w = fminf(fmaxf(fmaf(v.w, s.w, t.w), 0.f), 6.f);
+                        }
+                        const int k = ky * 3 + kx;
+                        acc.x = fmaf(v.x, wk[k][0], acc.x); acc.y = fmaf(v.y, wk[k][1], acc.y);
+                        acc.z = fmaf(v.z, wk[k][2], acc.z); acc.w = fmaf(v.w, wk[k][3], acc.w);
+                    }
+                }
+            *(float4*)(y + (((size_t)n * Ho + yo) * Wo + xo) * C + c) = acc;
+            if (cnt == 0.f) { ref[0] = acc.x; ref[1] = acc.y; ref[2] = acc.z; ref[3] = acc.w; }
+            float d;
+            d = acc.x - ref[0]; sd[0] += d; sq[0] = fmaf(d, d, sq[0]);
+            d = acc.y - ref[1]; sd[1] += d; sq[1] = fmaf(d, d, sq[1]);
+            d = acc.z - ref[2]; sd[2] += d; sq[2] = fmaf(d, d, sq[2]);
+            d = acc.w - ref[3]; sd[3] += d; sq[3] = fmaf(d, d, sq[3]);
+            cnt += 1.f;
+        }
+    }
+    float mean[4], m2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        mean[j] = 0.f; m2[j] = 0.f;
+        if (cnt > 0.f) { mean[j] = ref[j] + sd[j] / cnt; m2[j] = fmaxf(sq[j] - sd[j] * sd[j] / cnt, 0.f); }
+    }
+    shm[0][threadIdx.x] = cnt;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { shm[1 + j][threadIdx.x] = mean[j]; shm[5 + j][threadIdx.x] = m2[j]; }
+    __syncthreads();
+    if ((int)threadIdx.x < G4) {
+        for (int k = threadIdx.x + G4; k < BT; k += G4) {
+            const float nb = shm[0][k];
+            float na = cnt;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { na = cnt; bn_merge(na, mean[j], m2[j], nb, shm[1 + j][k], shm[5 + j][k]); }
+            cnt = na;
+        }
+        const size_t o = (size_t)blockIdx.x * G4 + threadIdx.x;
+        part[o] = cnt;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { part[(size_t)(1 + j) * T + o] = mean[j]; part[(size_t)(5 + j) * T + o] = m2[j]; }
+    }
+}
+
+static int dw_stat_blocks(long long items, int G4) {
+    const int BT = 256 - 256 % G4;
+    long long nb = (items + 4ll * BT - 1) / (4ll * BT);
+    return (int)(nb > 1024 ? 1024 : (nb < 1 ? 1 : nb));
+}
+
+extern "C" int lp_dwconv_stat_rows(int N, int H, int W, int C, int stride) {
+    if ((C & 3) || (C >> 2) > 256) return 0;
+    return dw_stat_blocks((long long)N * ((H + stride - 1) / stride) * ((W + stride - 1) / stride) * (C >> 2), C >> 2);
+}
+
+extern "C" int lp_dwconv3x3_stats_fwd(const float* x, const float* w, const float* in_scale, const float* in_shift, float* y, float* stats_part,
+                                      int N, int H, int W, int C, int stride, void* stream) {
+    if (!x || !w || !y || !stats_part) return lp_set_error(LP_ERR_ARG, "lp_dwconv3x3_stats_fwd: null pointer");
+    if ((C & 3) || (C >> 2) > 256 || (stride != 1 && stride != 2) || (!in_scale != !in_shift))
+        return lp_set_error(LP_ERR_UNSUPPORTED, "lp_dwconv3x3_stats_fwd: needs C % 4 == 0, C <= 1024, stride 1|2");
+    const int G4 = C >> 2, BT = 256 - 256 % G4;
+    const int blocks = lp_dwconv_stat_rows(N, H, W, C, stride);
+    hipLaunchKernelGGL(dwconv3x3_stats_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, w, in_scale, in_shift, y, stats_part, N, H, W, C,
+                       stride, BT, blocks * G4);
+    return lp_check_launch("dwconv3x3_stats_fwd");
+}
+
+// BatchNorm (scale, shift) + running-statistics update from `rows` partials per channel group (lp_pwconv_fwd / lp_dwconv3x3_stats_fwd)
+extern "C" int lp_bn_finalize(const float* stats_part, int rows, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                              float* scale, float* shift, int C, float eps, float momentum, void* stream) {
+    if (!stats_part || !gamma || !beta || !scale || !shift) return lp_set_error(LP_ERR_ARG, "lp_bn_finalize: null pointer");
+    if ((C & 3) || rows < 1 || (!running_mean != !running_var)) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_bn_finalize: needs C % 4 == 0, rows >= 1");
+    const int G4 = C >> 2, T = rows * G4;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(G4), dim3(256), 0, (hipStream_t)stream, stats_part, gamma, beta, running_mean, running_var, scale,
+                       shift, G4, T, T, eps, momentum);
     return lp_check_launch("bn_finalize");
 }

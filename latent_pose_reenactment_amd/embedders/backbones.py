@@ -4,15 +4,12 @@ The reference instantiates both from torchvision (embedders/unsupervised_pose_se
 which is an un-vendored dependency and absent from this image; these are restatements of the public architectures
 (He et al. / Xie et al. ResNeXt; Sandler et al. MobileNetV2) so that reference checkpoints load by key.
 
-MobileNetV2 (the pose encoder) has a hand-written HIP forward for the calls made with autograd off -- the fine-tuning train step (the
-embedder is frozen and called under ``no_grad``, runners/holycow.py:178-182 of the reference) and ``drive.py``: 1x1 convs on
-``lp_conv16_fwd``, stem / depthwise / BatchNorm-ReLU6 / pooling on the kernels of csrc/mobilenet.hip, BatchNorm in either mode
-(batch statistics + running-stat update, or running statistics); parity: tests/test_mobilenet_hip.py.  It is selected with
-LP_EMBEDDER_HIP=1: measured inside a hipGraph it is still SLOWER than the stock PyTorch-ROCm layers (B=1 eval 0.90 ms vs 0.60 ms,
-B=8 train 2.05 ms vs 1.40 ms: the encoder is ~200 launches of a few microseconds each, and the MFMA conv kernel's fixed cost per
-launch is tuned for the generator's layers, not for 8x8x960 maps), so the default stays on the stock layers until the small-map
-path is competitive.  With autograd on (meta-training trains the embedder) and for the ResNeXt-50 identity encoder the layers
-are stock PyTorch-ROCm ops (last row of the hot-path plan)."""
+MobileNetV2 (the pose encoder) has a hand-written HIP forward (fp32) for the calls made with autograd off -- the fine-tuning train
+step (the embedder is frozen and called under ``no_grad``, runners/holycow.py:178-182 of the reference) and ``drive.py``: stem,
+depthwise and 1x1 convs, BatchNorm in either mode (batch statistics + running-stat update folded into the conv launches, or running
+statistics), ReLU6, residual adds, pooling and the classifier on the kernels of csrc/mobilenet.hip; parity:
+tests/test_mobilenet_hip.py.  LP_EMBEDDER_HIP=0 selects the stock PyTorch-ROCm layers instead.  With autograd on (meta-training
+trains the embedder) and for the ResNeXt-50 identity encoder the layers are stock PyTorch-ROCm ops (last row of the hot-path plan)."""
 import os
 
 import torch
@@ -20,20 +17,12 @@ import torch.nn.functional as F
 from torch import nn
 
 _PENDING_COUNTERS = []
-_HIP_FORWARD = [os.environ.get('LP_EMBEDDER_HIP', '0') == '1']       # set_hip_forward() / LP_EMBEDDER_HIP=1
+_HIP_FORWARD = [os.environ.get('LP_EMBEDDER_HIP', '1') != '0']       # set_hip_forward() / LP_EMBEDDER_HIP=0
 
 
 def set_hip_forward(on: bool):
-    """route MobileNetV2's no-grad forward through the HIP kernels (default: LP_EMBEDDER_HIP=1 in the environment)"""
+    """route MobileNetV2's no-grad forward through the HIP kernels (default on; LP_EMBEDDER_HIP=0 in the environment turns it off)"""
     _HIP_FORWARD[0] = bool(on)
-
-
-def _embedder_prec():
-    """Operand precision of the encoder's 1x1 convs.  52 BatchNorm-renormalised layers amplify operand rounding (fp16 operands: 6e-3 on
-    the pose embedding, bf16 hi+lo: 1e-5) and the whole encoder is ~0.3 GFLOP per frame, so the default here is the strict bf16x3
-    mode whatever LP_PREC says for the generator / critic / VGG convs; LP_EMBEDDER_PREC = f16 | bf16 | bf16x3 overrides."""
-    from latent_pose_reenactment_amd.nn import PREC_NAMES
-    return PREC_NAMES[os.environ.get('LP_EMBEDDER_PREC', 'bf16x3')]
 
 
 class _BatchNorm2d(nn.BatchNorm2d):
@@ -169,80 +158,77 @@ class MobileNetV2(nn.Module):
         return self.classifier(x.mean([2, 3]))
 
     # ---- HIP forward (no autograd) ---------------------------------------------------------------------------------------------
-    def _pointwise_convs(self):
-        out = []
-        for blk in list(self.features)[1:-1]:
-            layers = list(blk.conv)
-            if len(layers) == 4:
-                out.append(layers[0][0])
-            out.append(layers[-2])
-        out.append(self.features[-1][0])
-        return out
-
-    def _hip_state(self, prec):
-        """16-bit packs of the 1x1 conv weights (ONE batched launch) and, for eval-mode BatchNorms, the (scale, shift) of the running
-        statistics; rebuilt when a weight / buffer changed (``_version``, or the fused optimizer's generation counter)."""
-        from latent_pose_reenactment_amd import hipops as ops
+    def _eval_affines(self):
+        """eval mode: every BatchNorm folded to a per-channel (scale, shift) by four multi-tensor ops, cached until a weight or
+        buffer changes (``_version``, or the generation counter of the fused optimizer / EMA kernels)"""
         from latent_pose_reenactment_amd.optim import WEIGHTS_GENERATION
         tens = self.__dict__.get('_hip_tensors')
         if tens is None:
-            tens = self.__dict__['_hip_tensors'] = list(self.parameters()) + [b for b in self.buffers() if b.dtype == torch.float32]
-        key = (prec, WEIGHTS_GENERATION[0], self.features[0][1].training, sum(t._version for t in tens), tens[0].data_ptr())
+            tens = self.__dict__['_hip_tensors'] = [t for m in self.modules() if isinstance(m, nn.BatchNorm2d)
+                                                    for t in (m.weight, m.bias, m.running_mean, m.running_var)]
+        key = (WEIGHTS_GENERATION[0], sum(t._version for t in tens), tens[0].data_ptr())
         st = self.__dict__.get('_hip_cache')
         if st is not None and st[0] == key:
-            return st[1], st[2]
-        convs = self._pointwise_convs()
-        pb = self.__dict__.get('_hip_packbatch')
-        specs = [(c.weight.detach(), 0, False) for c in convs]
-        if pb is None or pb.prec != prec or pb.key != tuple((w.data_ptr(), m_, bool(k_)) for w, m_, k_ in specs):
-            pb = self.__dict__['_hip_packbatch'] = ops.PackBatch(specs, prec)      # buffers + descriptor table: allocated once
-        packs = dict(zip(convs, pb.update()))                                          # ONE launch (graph-capturable)
-        affines = {}
-        bns = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d) and not m.training]
-        if bns:
-            # eval mode: all BatchNorms folded to (scale, shift) by four multi-tensor ops
-            sc = torch._foreach_add([m.running_var for m in bns], bns[0].eps)
-            torch._foreach_rsqrt_(sc)
-            torch._foreach_mul_(sc, [m.weight.detach() for m in bns])
-            sh = torch._foreach_mul([m.running_mean for m in bns], sc)
-            sh = torch._foreach_sub([m.bias.detach() for m in bns], sh)
-            affines = {m: (a, b) for m, a, b in zip(bns, sc, sh)}
-        self.__dict__['_hip_cache'] = (key, packs, affines)
-        return packs, affines
+            return st[1]
+        bns = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
+        sc = torch._foreach_add([m.running_var for m in bns], bns[0].eps)
+        torch._foreach_rsqrt_(sc)
+        torch._foreach_mul_(sc, [m.weight.detach() for m in bns])
+        sh = torch._foreach_mul([m.running_mean for m in bns], sc)
+        sh = torch._foreach_sub([m.bias.detach() for m in bns], sh)
+        affines = {m: (a_, b_) for m, a_, b_ in zip(bns, sc, sh)}
+        self.__dict__['_hip_cache'] = (key, affines)
+        return affines
 
     def _forward_hip(self, x):
+        """fp32 throughout.  A conv launch leaves its RAW output; the BatchNorm that follows is a per-channel (scale, shift) which
+        the NEXT launch applies while it loads that tensor (with ReLU6, or with the block's residual add).  Train mode: the conv
+        launch also leaves the statistics partials of its output and lp_bn_finalize turns them into (scale, shift) and the
+        running-statistics update -- two launches per conv + BatchNorm (+ ReLU6 / residual); eval mode: one."""
         from latent_pose_reenactment_amd import hipops as ops
-        prec = _embedder_prec()
-        packs, affines = self._hip_state(prec)
+        feats = list(self.features)
+        train = feats[0][1].training
+        affines = None if train else self._eval_affines()
         counters = []
 
-        def bn(m, y):
-            if not m.training:
+        def bn(m, stats):
+            if not train:
                 return affines[m]
             if m.track_running_stats:
                 counters.append(m.num_batches_tracked)
-            return ops.bn_batch_affine(y, m.weight.detach(), m.bias.detach(), m.running_mean, m.running_var, m.momentum, m.eps)
+            return ops.bn_finalize(stats, m.weight.detach(), m.bias.detach(), m.running_mean, m.running_var, m.momentum, m.eps)
 
-        feats = list(self.features)
         x = x.contiguous().float()
         y = ops.stem_conv_s2(x, feats[0][0].weight.detach())
-        pend = (y,) + tuple(bn(feats[0][1], y))          # raw conv output + the BatchNorm-ReLU6 its consumer applies while loading
-        cur = cur16 = None
+        if train:
+            if feats[0][1].track_running_stats:
+                counters.append(feats[0][1].num_batches_tracked)
+            m0 = feats[0][1]
+            aff = ops.bn_batch_affine(y, m0.weight.detach(), m0.bias.detach(), m0.running_mean, m0.running_var, m0.momentum, m0.eps)
+        else:
+            aff = affines[feats[0][1]]
+        pend = (y, aff)                                  # raw conv output + the BatchNorm-ReLU6 its consumer applies while loading
+        cur = None                                       # block input: (raw project output, its BatchNorm (scale, shift), residual | None)
         for blk in feats[1:-1]:
             layers = list(blk.conv)
+            res = None
             if len(layers) == 4:
-                ye = ops.conv16(cur16, packs[layers[0][0]], ksize=1, prec=prec)
-                pend = (ye,) + tuple(bn(layers[0][1], ye))
+                raw, (s, t), r = cur
+                ye, xin, st = ops.pwconv(raw, layers[0][0].weight.detach(), in_scale=s, in_shift=t, in_res=r, want_x=blk.use_res, stats=train)
+                pend = (ye, bn(layers[0][1], st))
+                res = xin                                # x = BN(raw) + r, written back by the expand launch when the block adds it later
             dw, pw, pbn = layers[-3], layers[-2], layers[-1]
-            yd = ops.dwconv3x3(pend[0], dw[0].weight.detach(), dw[0].stride[0], pend[1], pend[2])
-            s, t = bn(dw[1], yd)
-            a = ops.act_pack(yd, pro=3, scale=s, shift=t, prec=prec)
-            yp = ops.conv16(a, packs[pw], ksize=1, prec=prec)
-            s, t = bn(pbn, yp)
-            cur, cur16 = ops.affine_res(yp, s, t, cur if blk.use_res else None, prec)
+            if train:
+                yd, st = ops.dwconv3x3_stats(pend[0], dw[0].weight.detach(), dw[0].stride[0], pend[1][0], pend[1][1])
+            else:
+                yd, st = ops.dwconv3x3(pend[0], dw[0].weight.detach(), dw[0].stride[0], pend[1][0], pend[1][1]), None
+            s, t = bn(dw[1], st)
+            yp, _, st = ops.pwconv(yd, pw.weight.detach(), in_scale=s, in_shift=t, in_relu6=True, stats=train)
+            cur = (yp, bn(pbn, st), res if blk.use_res else None)
         last = feats[-1]
-        yl = ops.conv16(cur16, packs[last[0]], ksize=1, prec=prec)
-        s, t = bn(last[1], yl)
+        raw, (s, t), r = cur
+        yl, _, st = ops.pwconv(raw, last[0].weight.detach(), in_scale=s, in_shift=t, in_res=r, stats=train)
+        s, t = bn(last[1], st)
         pooled = ops.affine_relu6_mean(yl, s, t)
         if counters:
             torch._foreach_add_(counters, 1)

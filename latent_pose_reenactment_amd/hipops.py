@@ -431,6 +431,52 @@ def dwconv3x3(x: Tensor, w: Tensor, stride: int, in_scale: Optional[Tensor] = No
     return y
 
 
+def pwconv(x: Tensor, w: Tensor, *, in_scale: Optional[Tensor] = None, in_shift: Optional[Tensor] = None, in_relu6: bool = False,
+           in_res: Optional[Tensor] = None, want_x: bool = False, stats: bool = False):
+    """fp32 1x1 conv y = a w^T on NHWC x, a = (relu6?)(x*in_scale+in_shift) (+ in_res).  -> (y, a | None, stats | None);
+    ``stats`` = (partials, rows) for ``bn_finalize``"""
+    _chk(x, 'x'); _chk(w, 'w')
+    n, h, wd, k = x.shape
+    cout = w.shape[0]
+    assert w.numel() == cout * k
+    pcount = n * h * wd
+    y = torch.empty((n, h, wd, cout), dtype=torch.float32, device=x.device)
+    xo = torch.empty_like(x) if want_x else None
+    part, rows = None, 0
+    if stats:
+        rows = _lib.lib().lp_pwconv_stat_rows(pcount, k, cout)
+        part = torch.empty(9 * rows * (cout // 4), dtype=torch.float32, device=x.device)
+    if in_res is not None:
+        _chk(in_res, 'in_res'); assert in_res.shape == x.shape
+    check(_lib.lib().lp_pwconv_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), _p(in_scale), _p(in_shift), int(in_relu6), _p(in_res), _p(xo),
+                                   _p(part), pcount, k, cout, _stream()), 'lp_pwconv_fwd')
+    return y, xo, ((part, rows) if stats else None)
+
+
+def dwconv3x3_stats(x: Tensor, w: Tensor, stride: int, in_scale: Optional[Tensor] = None, in_shift: Optional[Tensor] = None):
+    """``dwconv3x3`` that also returns the BatchNorm partials of its output: (y, (partials, rows))"""
+    _chk(x, 'x'); _chk(w, 'w')
+    n, h, wd, c = x.shape
+    rows = _lib.lib().lp_dwconv_stat_rows(n, h, wd, c, stride)
+    assert rows > 0, c
+    y = torch.empty((n, (h + stride - 1) // stride, (wd + stride - 1) // stride, c), dtype=torch.float32, device=x.device)
+    part = torch.empty(9 * rows * (c // 4), dtype=torch.float32, device=x.device)
+    check(_lib.lib().lp_dwconv3x3_stats_fwd(x.data_ptr(), w.data_ptr(), _p(in_scale), _p(in_shift), y.data_ptr(), part.data_ptr(), n, h, wd, c,
+                                            stride, _stream()), 'lp_dwconv3x3_stats_fwd')
+    return y, (part, rows)
+
+
+def bn_finalize(stats, weight: Tensor, bias: Tensor, running_mean: Optional[Tensor], running_var: Optional[Tensor], momentum: float,
+                eps: float) -> Tuple[Tensor, Tensor]:
+    """train-mode BatchNorm (scale, shift) from the partials a conv launch left behind; updates the running statistics in place"""
+    part, rows = stats
+    c = weight.numel()
+    out = torch.empty(2 * c, dtype=torch.float32, device=weight.device)
+    check(_lib.lib().lp_bn_finalize(part.data_ptr(), rows, weight.data_ptr(), bias.data_ptr(), _p(running_mean), _p(running_var), out.data_ptr(),
+                                    out[c:].data_ptr(), c, eps, momentum, _stream()), 'lp_bn_finalize')
+    return out[:c], out[c:]
+
+
 def affine_res(y: Tensor, scale: Tensor, shift: Tensor, res: Optional[Tensor] = None, prec: Optional[int] = None):
     """x = y*scale[c]+shift[c] (+res), NHWC; with ``prec`` also the operand planes of x -> (x, Act16)"""
     _chk(y, 'y')

@@ -1,4 +1,4 @@
-"""GPU parity of the MobileNetV2 pose encoder's HIP forward (csrc/mobilenet.hip + lp_conv16_fwd for the 1x1 convs) against fp64
+"""GPU parity of the MobileNetV2 pose encoder's HIP forward (csrc/mobilenet.hip, fp32) against fp64
 torch on the CPU: the kernels one by one, then ``mobilenet_v2(256)`` whole, in eval mode (running statistics: drive.py) and in
 train mode (batch statistics + running-stat update: the fine-tuning step calls the frozen embedder under no_grad in train mode).
 Reference: embedders/unsupervised_pose_separate_embResNeXt_segmentation.py:26-28,56-58 (torchvision mobilenet_v2)."""
@@ -134,11 +134,69 @@ def _randomise_bn(net, seed):
         net.classifier[1].bias.normal_(0, 0.1, generator=g)
 
 
+@pytest.mark.parametrize('case', [(2, 16, 16, 24, 144, False, False), (3, 8, 8, 96, 24, True, False), (1, 7, 5, 960, 160, True, False),
+                                  (2, 32, 32, 16, 96, False, True), (8, 8, 8, 320, 1280, False, True), (4, 32, 32, 32, 192, False, True),
+                                  (5, 30, 30, 96, 24, True, False)])
+def test_pwconv_with_fused_batchnorm(case):
+    """1x1 conv with the producer's BatchNorm (+ReLU6 / +residual) applied on load, the activated input written back, and the
+    train-mode BatchNorm of the OUTPUT (scale, shift, running statistics) from the partials the same launch leaves"""
+    ops = _ops()
+    n, h, w, k, cout, relu6, with_res = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(n, h, w, k, generator=g, dtype=torch.float64) * 2
+    r = torch.randn(n, h, w, k, generator=g, dtype=torch.float64)
+    sc = torch.rand(k, generator=g, dtype=torch.float64) + 0.5
+    sh = torch.randn(k, generator=g, dtype=torch.float64)
+    wt = torch.randn(cout, k, 1, 1, generator=g, dtype=torch.float64) / k ** 0.5
+    a = x * sc + sh
+    if relu6:
+        a = a.clamp(0, 6)
+    if with_res:
+        a = a + r
+    ref = torch.einsum('nhwk,ok->nhwo', a, wt[:, :, 0, 0])
+    bn = torch.nn.BatchNorm2d(cout).double().train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(cout, generator=g) + 0.5); bn.bias.copy_(torch.randn(cout, generator=g) * 0.3)
+        bn.running_mean.copy_(torch.randn(cout, generator=g)); bn.running_var.copy_(torch.rand(cout, generator=g) + 0.5)
+    rm, rv = bn.running_mean.clone().float().cuda(), bn.running_var.clone().float().cuda()
+    ref_bn = bn(ref.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+    y, xo, st = ops.pwconv(x.float().cuda(), wt.float().cuda(), in_scale=sc.float().cuda(), in_shift=sh.float().cuda(), in_relu6=relu6,
+                           in_res=r.float().cuda() if with_res else None, want_x=True, stats=True)
+    assert rel(y, ref) < 2e-6 and rel(xo, a) < 1e-6
+    s, t = ops.bn_finalize(st, bn.weight.float().cuda(), bn.bias.float().cuda(), rm, rv, bn.momentum, bn.eps)
+    assert rel(y * s + t, ref_bn) < 1e-5
+    assert rel(rm, bn.running_mean) < 1e-5 and rel(rv, bn.running_var) < 1e-5
+    y2, xo2, st2 = ops.pwconv(x.float().cuda(), wt.float().cuda())
+    assert xo2 is None and st2 is None and rel(y2, torch.einsum('nhwk,ok->nhwo', x, wt[:, :, 0, 0])) < 2e-6
+
+
+@pytest.mark.parametrize('case', [(2, 32, 32, 96, 2), (3, 15, 9, 24, 1), (1, 7, 7, 960, 1), (8, 16, 16, 144, 2)])
+def test_dwconv3x3_with_batchnorm_statistics(case):
+    ops = _ops()
+    n, h, w, c, stride = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(n, c, h, w, generator=g, dtype=torch.float64) * 3
+    wt = torch.randn(c, 1, 3, 3, generator=g, dtype=torch.float64)
+    sc = torch.randn(c, generator=g, dtype=torch.float64)
+    sh = torch.randn(c, generator=g, dtype=torch.float64)
+    a = torch.clamp(x * sc[None, :, None, None] + sh[None, :, None, None], 0, 6)
+    ref = F.conv2d(a, wt, None, stride, 1, groups=c)
+    bn = torch.nn.BatchNorm2d(c).double().train()
+    rm, rv = bn.running_mean.clone().float().cuda(), bn.running_var.clone().float().cuda()
+    ref_bn = nhwc(bn(ref))
+    y, st = ops.dwconv3x3_stats(nhwc(x).float().cuda(), wt.float().cuda(), stride, sc.float().cuda(), sh.float().cuda())
+    assert rel(y, nhwc(ref)) < 2e-6
+    s, t = ops.bn_finalize(st, bn.weight.float().cuda(), bn.bias.float().cuda(), rm, rv, bn.momentum, bn.eps)
+    assert rel(y * s + t, ref_bn) < 1e-5
+    assert rel(rm, bn.running_mean) < 1e-5 and rel(rv, bn.running_var) < 1e-5
+
+
 @pytest.mark.parametrize('mode', ['eval', 'train'])
-@pytest.mark.parametrize('prec', ['bf16x3', 'f16'])
-def test_mobilenet_v2_forward(prec, mode, monkeypatch):
-    """mobilenet_v2(256) on a [4, 3, 256, 256] batch: the HIP forward (taken under no_grad) vs the fp64 CPU module"""
-    monkeypatch.setenv('LP_EMBEDDER_PREC', prec)
+@pytest.mark.parametrize('batch', [1, 4])
+def test_mobilenet_v2_forward(batch, mode):
+    """mobilenet_v2(256) on a [B, 3, 256, 256] batch: the HIP forward (taken under no_grad) vs the fp64 CPU module"""
+    if batch == 1 and mode == 'train':
+        pytest.skip('the late 8x8 maps of one frame are too few positions for batch statistics to be a meaningful comparison')
     from latent_pose_reenactment_amd.embedders.backbones import mobilenet_v2
     torch.manual_seed(0)
     net = mobilenet_v2(256)
@@ -146,7 +204,7 @@ def test_mobilenet_v2_forward(prec, mode, monkeypatch):
     net.classifier[0].p = 0.0                      # the dropout mask is random: not comparable
     ref_net = copy.deepcopy(net).double()
     dev_net = copy.deepcopy(net).cuda()
-    x = torch.rand(4, 3, 256, 256, generator=torch.Generator().manual_seed(8), dtype=torch.float64) * 2 - 1
+    x = torch.rand(batch, 3, 256, 256, generator=torch.Generator().manual_seed(8), dtype=torch.float64) * 2 - 1
     for m in (ref_net, dev_net):
         m.train(mode == 'train')
     with torch.no_grad():
@@ -159,9 +217,9 @@ def test_mobilenet_v2_forward(prec, mode, monkeypatch):
             ref = ref_net(x * 0.5)
             got = dev_net((x * 0.5).float().cuda())
     assert calls, 'the HIP forward was not taken'
-    tol = {'bf16x3': 1e-4, 'f16': 1e-2}[prec]      # fp16 operands through 52 renormalised layers: why the encoder defaults to bf16x3
+    tol = 1e-4
     err = rel(got, ref)
-    print(f'[parity] mobilenet_v2 {mode} {prec}: rel-L2 {err:.3e} (tol {tol:.0e})')
+    print(f'[parity] mobilenet_v2 {mode} B={batch}: rel-L2 {err:.3e} (tol {tol:.0e})')
     assert err < tol
     if mode == 'train':
         for (k, a), (_, b) in zip(dev_net.state_dict().items(), ref_net.state_dict().items()):
@@ -171,9 +229,8 @@ def test_mobilenet_v2_forward(prec, mode, monkeypatch):
                 assert int(a) == int(b) == 2, k
 
 
-def test_mobilenet_v2_pack_cache_follows_weights(monkeypatch):
-    """the 16-bit packs / folded BatchNorm are cached between frames; loading a state dict must invalidate them"""
-    monkeypatch.setenv('LP_EMBEDDER_PREC', 'bf16x3')
+def test_mobilenet_v2_folded_batchnorm_cache_follows_weights():
+    """the folded BatchNorm (scale, shift) are cached between frames; loading a state dict must invalidate them"""
     from latent_pose_reenactment_amd.embedders.backbones import mobilenet_v2
     torch.manual_seed(1)
     a, b = mobilenet_v2(64), mobilenet_v2(64)
