@@ -6,8 +6,9 @@ Workload at N=1 = BASELINE.json configs[1]: the fine-tuning step of configs/fine
 256x256, synthetic VoxCeleb2-shaped batch, random-init weights (no network for datasets/checkpoints).  One "step" =
 runners/holycow.py:230-257: E(pose) -> G -> D x3 -> criterions -> G backward/step -> D backward/step -> EMA.
 The generator, the discriminator, the VGG19/VGGFace criterions, RAdam, EMA and the spectral-norm power iterations run on the
-hand-written gfx950 kernels of liblp_hip.so; including the MobileNetV2 pose encoder (forward only in fine-tuning; csrc/mobilenet.hip).  For N>1 the same per-GPU step runs data
-parallel with the RCCL gradient all-reduce of latent_pose_reenactment_amd.parallel (weak scaling).
+hand-written gfx950 kernels of liblp_hip.so, and so does the MobileNetV2 pose encoder (forward only in fine-tuning; csrc/mobilenet.hip).
+For N>1 the default workload is the meta-training step (configs[2]: the configuration the reference runs data parallel), each rank on
+its own batch with the RCCL gradient all-reduce of latent_pose_reenactment_amd.parallel (weak scaling).
 
 Prints ONE JSON line on rank 0 (see README/DESIGN for the field definitions)."""
 import argparse
