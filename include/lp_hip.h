@@ -94,13 +94,17 @@ int lp_conv16_wgrad(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* 
 int lp_conv_wgrad_dot_blocks(int Cin, int Cout, int ksize);
 
 /* Thin-channel convs (<= 4 channels on one side: RGB -> 64 first convs of the critics / VGG stacks, the generator head's weight
- * gradient): bandwidth-bound fp32 VALU kernels on plain NHWC fp32 activations (no operand planes); weights from the same packs.
- *   lp_thin_conv_fwd:  y = alpha * conv(x, w) + bias for Cin <= 4, Cout % 64 == 0 (lp_thin_conv_supported).
+ * gradient): bandwidth-bound kernels on plain NHWC fp32 activations (no input operand planes); weights from the same packs.
+ *   lp_thin_conv_fwd:  y = alpha * conv(x, w) + bias for Cin <= 4, Cout % 64 == 0 (lp_thin_conv_supported).  fp32 VALU kernel; the
+ *                      RGB 3x3 case in the fp16 / bf16 modes (lp_thin_conv_emits_planes: Cin 3, W % 16 == 0) runs as one MFMA k-step
+ *                      per output block and can also write out_hi [N][H][W][Cout] = the operand planes of (out_relu ? relu(y) : y).
  *   lp_thin_wgrad:     dw (and dbias when lp_thin_wgrad_has_dbias) for Cin <= 4 (pro 0) or Cout <= 4 (3x3; the AdaIN/ReLU prologue
  *                      pro/scale/shift of the wide input is applied on the fly); workspace as lp_conv_wgrad_workspace_bytes(). */
 int lp_thin_conv_supported(int Cin, int Cout, int ksize, int W);
 int lp_thin_conv_fwd(const float* x, const uint16_t* w_hi, const uint16_t* w_lo, float* y, const float* bias, const float* alpha,
-                     int N, int H, int W, int Cin, int Cout, int CinP, int CoutP, int ksize, int prec, void* stream);
+                     int N, int H, int W, int Cin, int Cout, int CinP, int CoutP, int ksize, int prec, uint16_t* out_hi, int out_relu,
+                     void* stream);
+int lp_thin_conv_emits_planes(int Cin, int Cout, int ksize, int W, int prec);
 int lp_thin_wgrad_supported(int Cin, int Cout, int ksize, int pro, int W);
 int lp_thin_wgrad_has_dbias(int Cin, int Cout);
 int lp_thin_wgrad(const float* x, const float* dy, float* dw, float* workspace, const float* scale, const float* shift,

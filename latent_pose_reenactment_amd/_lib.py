@@ -34,7 +34,8 @@ SIGNATURES = {
     'lp_conv16_wgrad': (_i, [_vp] * 6 + [_i] * 9 + [_vp, _vp, _vp, _vp, _vp]),
     'lp_conv_wgrad_dot_blocks': (_i, [_i] * 3),
     'lp_thin_conv_supported': (_i, [_i] * 4),
-    'lp_thin_conv_fwd': (_i, [_vp] * 6 + [_i] * 9 + [_vp]),
+    'lp_thin_conv_fwd': (_i, [_vp] * 6 + [_i] * 9 + [_vp, _i, _vp]),
+    'lp_thin_conv_emits_planes': (_i, [_i] * 5),
     'lp_thin_wgrad_supported': (_i, [_i] * 5),
     'lp_thin_wgrad_has_dbias': (_i, [_i] * 2),
     'lp_thin_wgrad': (_i, [_vp] * 6 + [_i] * 8 + [_vp, _vp]),

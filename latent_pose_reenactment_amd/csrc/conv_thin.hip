@@ -273,6 +273,106 @@ __global__ __launch_bounds__(256) void conv_thin_fwd_kernel(ThinFwdParams p) {
     }
 }
 
+// RGB -> 64 3x3 on the matrix cores (fp16 / bf16 operand modes): the whole contraction is 27 MACs per output = ONE 16x16x32 MFMA
+// k-step.  k = 3 * tap + channel (27 used, 5 zero); a wave takes 16 consecutive pixels of an image row as the M side and 64 output
+// channels as 4 N tiles.  A fragment: 8 u16 LDS reads per lane from the fp16/bf16 halo rows (one 8-byte word per pixel); B fragments:
+// gathered once per workgroup from the 16-bit weight pack.  The fp32 VALU kernel above spends 27 FMAs per output per lane (31 us of
+// pure VALU time on a 8 x 256 x 256 image against 25 us of output writes); this one is bound by the writes.  The 16 x 64 block goes
+// through LDS so that a pixel's 64 channels leave as one 256-byte run, together with the optional operand planes of (relu?)(y)
+// for the next conv (saves that layer's lp_act_pack pass over y).
+struct RgbMfmaParams {
+    const float* x; const uint16_t* w_hi; float* y; const float* bias; const float* alpha; uint16_t* o_hi;
+    int N, H, W, Cout, CinP, CoutP, o_relu;
+};
+
+template <bool F16>
+__global__ __launch_bounds__(256) void conv_rgb_mfma_kernel(RgbMfmaParams p) {
+    constexpr int RB = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+    const int RW = p.W + 2;
+    uint16_t* halo = (uint16_t*)smraw;                                             // [RB + 2][RW][4] 16-bit
+    float* tbase = (float*)(smraw + (((size_t)(RB + 2) * RW * 8 + 15) & ~(size_t)15));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* T = tbase + wave * (16 * 68);                                            // this wave's 16 x 64 output block (+4 pad)
+    const int co0 = blockIdx.y * 64;
+    const int kg = lane >> 4, m = lane & 15;
+    // per-lane k slice kk = kg*8 + j -> (tap, channel) -> halo offset (in 16-bit units) relative to (row r, pixel x0 + m)
+    int aoff[8];
+    s16x8_t bfrag[4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int kk = kg * 8 + j, t = kk / 3, c = kk - t * 3;
+        aoff[j] = kk < 27 ? ((t / 3) * RW + (t % 3)) * 4 + c : -1;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int co = co0 + nt * 16 + m;
+            bfrag[nt][j] = kk < 27 ? (short)p.w_hi[((size_t)t * p.CoutP + co) * p.CinP + c] : (short)0;
+        }
+    }
+    const float alpha = p.alpha ? *p.alpha : 1.f;
+    const int pq = lane >> 2, cq = (lane & 3) * 16;                                  // store phase: pixel of the block, first of 16 channels
+    float bias16[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) bias16[j] = p.bias ? p.bias[co0 + cq + j] : 0.f;
+    const int gpi = (p.H + RB - 1) / RB, segs = p.W >> 4;
+    for (int grp = blockIdx.x; grp < p.N * gpi; grp += gridDim.x) {
+        const int n = grp / gpi, y0 = (grp % gpi) * RB;
+        __syncthreads();
+        for (int i = tid; i < (RB + 2) * RW; i += 256) {
+            const int r = i / RW, hx = i - r * RW;
+            const int iy = y0 + r - 1, ix = hx - 1;
+            ushort4 v = make_ushort4(0, 0, 0, 0);
+            if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+                const float* src = p.x + ((size_t)(n * p.H + iy) * p.W + ix) * 3;
+                v.x = lp_f32_to_op16<F16>(src[0]); v.y = lp_f32_to_op16<F16>(src[1]); v.z = lp_f32_to_op16<F16>(src[2]);
+            }
+            *(ushort4*)(halo + (size_t)i * 4) = v;
+        }
+        __syncthreads();
+        const int nrow = min(RB, p.H - y0);
+        for (int sgi = wave; sgi < nrow * segs; sgi += 4) {
+            const int r = sgi / segs, x0 = (sgi - r * segs) << 4;
+            const uint16_t* hb = halo + ((size_t)r * RW + x0 + m) * 4;
+            s16x8_t a;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] = aoff[j] >= 0 ? (short)hb[aoff[j]] : (short)0;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                f32x4_t acc = mfma16t<F16>(a, bfrag[nt], (f32x4_t){0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+                for (int q = 0; q < 4; ++q) T[(kg * 4 + q) * 68 + nt * 16 + m] = acc[q];      // C: row = (lane>>4)*4 + q (pixel), col = lane&15
+            }
+            // (wave-private block: the LDS writes above are ordered before the reads below by the compiler's lgkmcnt wait)
+            const size_t pix = (size_t)(n * p.H + y0 + r) * p.W + x0 + pq;
+            float* dst = p.y + pix * p.Cout + co0 + cq;
+            float o[16];
+#pragma unroll
+            for (int j4 = 0; j4 < 4; ++j4) {
+                const float4 v = *(const float4*)(T + pq * 68 + cq + j4 * 4);
+                o[j4 * 4 + 0] = fmaf(v.x, alpha, bias16[j4 * 4 + 0]); o[j4 * 4 + 1] = fmaf(v.y, alpha, bias16[j4 * 4 + 1]);
+                o[j4 * 4 + 2] = fmaf(v.z, alpha, bias16[j4 * 4 + 2]); o[j4 * 4 + 3] = fmaf(v.w, alpha, bias16[j4 * 4 + 3]);
+                *(float4*)(dst + j4 * 4) = make_float4(o[j4 * 4], o[j4 * 4 + 1], o[j4 * 4 + 2], o[j4 * 4 + 3]);
+            }
+            if (p.o_hi) {
+                s16x8_t h0, h1;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    h0[j] = (short)lp_f32_to_op16<F16>(p.o_relu ? fmaxf(o[j], 0.f) : o[j]);
+                    h1[j] = (short)lp_f32_to_op16<F16>(p.o_relu ? fmaxf(o[8 + j], 0.f) : o[8 + j]);
+                }
+                uint16_t* od = p.o_hi + pix * p.Cout + co0 + cq;
+                *(s16x8_t*)od = h0; *(s16x8_t*)(od + 8) = h1;
+            }
+        }
+    }
+}
+
+static bool rgb_mfma_ok(int Cin, int Cout, int ksize, int W, int prec) {
+    static const int env = getenv("LP_THIN_MFMA") ? atoi(getenv("LP_THIN_MFMA")) : 1;       // LP_THIN_MFMA=0: fp32 VALU kernel always
+    return env && Cin == 3 && ksize == 3 && (Cout % 64) == 0 && (W % 16) == 0 && prec != LP_PREC_BF16X3 &&
+           (size_t)6 * (W + 2) * 8 + 16 + 4 * 16 * 68 * 4 <= 64 * 1024;
+}
+
 bool lp_conv_thin_fwd_supported(int Cin, int Cout, int ksize, int upsample, int pro, bool has_res, int W) {
     return Cin <= 4 && (Cout % 64) == 0 && !upsample && pro == 0 && !has_res && (ksize == 1 || ksize == 3) &&
            (size_t)(4 + 2) * (W + 2) * 16 <= 64 * 1024;
@@ -299,10 +399,25 @@ extern "C" int lp_thin_conv_supported(int Cin, int Cout, int ksize, int W) {
     return lp_conv_thin_fwd_supported(Cin, Cout, ksize, 0, 0, false, W) ? 1 : 0;
 }
 
+extern "C" int lp_thin_conv_emits_planes(int Cin, int Cout, int ksize, int W, int prec) { return rgb_mfma_ok(Cin, Cout, ksize, W, prec) ? 1 : 0; }
+
 extern "C" int lp_thin_conv_fwd(const float* x, const uint16_t* w_hi, const uint16_t* w_lo, float* y, const float* bias, const float* alpha,
-                                int N, int H, int W, int Cin, int Cout, int CinP, int CoutP, int ksize, int prec, void* stream) {
+                                int N, int H, int W, int Cin, int Cout, int CinP, int CoutP, int ksize, int prec, uint16_t* out_hi,
+                                int out_relu, void* stream) {
     if (!x || !w_hi || !y) return lp_set_error(LP_ERR_ARG, "lp_thin_conv_fwd: null pointer");
     if (!lp_conv_thin_fwd_supported(Cin, Cout, ksize, 0, 0, false, W)) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_thin_conv_fwd: unsupported shape");
+    if (rgb_mfma_ok(Cin, Cout, ksize, W, prec)) {
+        RgbMfmaParams q;
+        q.x = x; q.w_hi = w_hi; q.y = y; q.bias = bias; q.alpha = alpha; q.o_hi = out_hi; q.o_relu = out_relu;
+        q.N = N; q.H = H; q.W = W; q.Cout = Cout; q.CinP = CinP; q.CoutP = CoutP;
+        int G = N * ((H + 3) / 4); if (G > 2048) G = 2048;
+        const size_t lds = (((size_t)6 * (W + 2) * 8 + 15) & ~(size_t)15) + (size_t)4 * 16 * 68 * sizeof(float);
+        dim3 grid(G, Cout / 64);
+        if (prec == LP_PREC_F16) hipLaunchKernelGGL(conv_rgb_mfma_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, q);
+        else hipLaunchKernelGGL(conv_rgb_mfma_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, q);
+        return lp_check_launch("conv_rgb_mfma");
+    }
+    if (out_hi) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_thin_conv_fwd: operand planes are only emitted where lp_thin_conv_emits_planes() says so");
     return lp_conv_thin_fwd(x, w_hi, prec == LP_PREC_BF16X3 ? w_lo : nullptr, y, bias, alpha, N, H, W, Cin, Cout, CinP, CoutP, ksize,
                             prec == LP_PREC_F16, (hipStream_t)stream);
 }

@@ -239,6 +239,7 @@ def conv16(a: Act16, pack: WeightPack, *, ksize: int, upsample: bool = False, bi
 
 
 _THIN = os.environ.get('LP_THIN', '1') != '0'      # LP_THIN=0: thin-channel layers through the MFMA kernels (test knob)
+_THIN_MFMA = os.environ.get('LP_THIN_MFMA', '1') != '0'
 
 
 def thin_conv_supported(cin: int, cout: int, ksize: int, w: int) -> bool:
@@ -246,16 +247,25 @@ def thin_conv_supported(cin: int, cout: int, ksize: int, w: int) -> bool:
 
 
 def thin_conv(x: Tensor, pack: WeightPack, *, ksize: int, bias: Optional[Tensor] = None, alpha: Optional[Tensor] = None,
-              prec: int = PREC_BF16) -> Tensor:
-    """conv with <= 4 input channels (RGB -> 64, dz -> 64): fp32 VALU kernel on the plain NHWC tensor (no operand planes)"""
+              prec: int = PREC_BF16, out16: Optional[int] = None):
+    """conv with <= 4 input channels (RGB -> 64, dz -> 64) on the plain NHWC tensor (no input operand planes): fp32 VALU kernel, or --
+    RGB 3x3 in the fp16 / bf16 modes -- one MFMA k-step per output block.  ``out16`` = 0 | 1: also return the operand planes of y
+    (1: of relu(y)) -> (y, Act16); written by the same launch where the MFMA kernel runs, by a pack pass otherwise."""
     _chk(x, 'x')
     n, h, w, cin = x.shape
     cout = pack.rows
     y = torch.empty((n, h, w, cout), dtype=torch.float32, device=x.device)
+    fused = out16 is not None and bool(_lib.lib().lp_thin_conv_emits_planes(cin, cout, ksize, w, prec)) and _THIN_MFMA
+    o_hi = torch.empty((n, h, w, cout), dtype=torch.int16, device=x.device) if fused else None
     with _Timed('conv_thin', 2.0 * n * h * w * cout * cin * ksize * ksize, (n, h, w, cin, cout, ksize, 0, 0)):
         check(_lib.lib().lp_thin_conv_fwd(x.data_ptr(), pack.hi.data_ptr(), _p(pack.lo), y.data_ptr(), _p(bias), _p(alpha), n, h, w, cin,
-                                          cout, pack.cols_p, pack.rows_p, ksize, prec, _stream()), 'lp_thin_conv_fwd')
-    return y
+                                          cout, pack.cols_p, pack.rows_p, ksize, prec, _p(o_hi), int(bool(out16)), _stream()),
+              'lp_thin_conv_fwd')
+    if out16 is None:
+        return y
+    if fused:
+        return y, Act16(o_hi, None, cout, None)
+    return y, act_pack(y, pro=2 if out16 else 0, prec=prec)
 
 
 def conv(x: Tensor, pack: WeightPack, *, ksize: int, upsample: bool = False, pro: int = 0, scale: Optional[Tensor] = None,

@@ -680,9 +680,10 @@ class ConvFn(torch.autograd.Function):
         thin_w = need_w and ops.thin_wgrad_supported(cin, cout, ksize, pro, width)       # the weight gradient will want fp32 x
         a16 = x16
         if a16 is None and pro == 0 and res is None and ops.thin_conv_supported(cin, cout, ksize, width):
-            y = ops.thin_conv(x, pack, ksize=ksize, bias=bd, alpha=alpha, prec=prec)
+            y = ops.thin_conv(x, pack, ksize=ksize, bias=bd, alpha=alpha, prec=prec, out16=None if emit is None else emit[0])
             if emit is not None:
-                emit[1].append(ops.act_pack(y, pro=2 if emit[0] else 0, prec=prec))
+                y, o16 = y
+                emit[1].append(o16)
                 if emit[0]:
                     tape_relu(lambda: emit[1][-1].hi[..., :cout] > 0, True)
         else:
