@@ -301,11 +301,13 @@ __global__ __launch_bounds__(COB * 4) void conv_wgrad_kernel(WgradParams p) {
                 }
 }
 
-// dw[co][ci][tap] = sum_s part[s][tap][co][ci].  A thread owns 4 (tap, co, ci) triples 256 apart, ci fastest -> every partial read
-// is coalesced; 8 independent accumulators keep 8 loads in flight per thread (the slabs are streamed once from HBM/L2).
+// dw[co][ci][tap] = sum_s part[s][tap][co][ci].  A block owns one output channel and WRED_CI input channels: the slabs are read with
+// ci fastest (coalesced 4-byte lanes, 8 independent accumulators keep 8 loads in flight per thread; the slabs are streamed once
+// from HBM/L2), the sums cross an LDS tile [ci][tap], and the block's WRED_CI * T outputs -- one contiguous run of the reference
+// [Cout][Cin][k][k] layout -- leave as coalesced stores (a direct write is a 36-byte stride per lane: 8x write amplification).
 // sn_w != NULL: the layer is spectrally normalised -- the block also leaves its share of <dw, W_orig> in sn_dot[blockIdx.x]
 // (lp_sn_grad_apply needs that inner product; taking it here saves a pass over dw and a launch).
-#define WRED_PER_BLOCK 1024
+#define WRED_CI 128
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int S, int T,
                                                            int Cout, int Cin, int CoP, int CiP, const float* __restrict__ bpart,
                                                            float* __restrict__ dbias, int wblocks, const float* __restrict__ out_scale,
@@ -329,16 +331,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         if (g == 0 && co < Cout) dbias[co] = ((red[0][c] + red[1][c]) + (red[2][c] + red[3][c])) * osc;
         return;
     }
+    __shared__ float tile[WRED_CI * 9];
+    const int cib = (Cin + WRED_CI - 1) / WRED_CI;
+    const int co = blockIdx.x / cib, ci0 = (blockIdx.x - co * cib) * WRED_CI;
+    const int nci = min(WRED_CI, Cin - ci0), nel = nci * T;
     const size_t slab = (size_t)T * CoP * CiP;
-    const int total = T * Cout * Cin;
-    float dsum = 0.f;
-#pragma unroll
-    for (int j = 0; j < WRED_PER_BLOCK / 256; ++j) {
-        const int idx = blockIdx.x * WRED_PER_BLOCK + j * 256 + threadIdx.x;
-        if (idx < total) {
-            const int ci = idx % Cin, r = idx / Cin;
-            const int co = r % Cout, t = r / Cout;
-            const float* p = part + ((size_t)t * CoP + co) * CiP + ci;
+    for (int e = threadIdx.x; e < T * WRED_CI; e += 256) {
+        const int t = e / WRED_CI, ci = e - t * WRED_CI;
+        if (ci < nci) {
+            const float* p = part + ((size_t)t * CoP + co) * CiP + ci0 + ci;
             float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             int k = 0;
             for (; k + 8 <= S; k += 8) {
@@ -346,11 +347,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
                 for (int q = 0; q < 8; ++q) a[q] += p[(size_t)(k + q) * slab];
             }
             for (; k < S; ++k) a[0] += p[(size_t)k * slab];
-            const float val = (((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) * osc;
-            const size_t o = ((size_t)co * Cin + ci) * T + t;
-            dw[o] = val;
-            if (sn_w) dsum = fmaf(val, sn_w[o], dsum);
+            tile[ci * T + t] = (((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) * osc;
         }
+    }
+    __syncthreads();
+    const size_t obase = ((size_t)co * Cin + ci0) * T;
+    float dsum = 0.f;
+    for (int e = threadIdx.x; e < nel; e += 256) {
+        const float val = tile[e];
+        dw[obase + e] = val;
+        if (sn_w) dsum = fmaf(val, sn_w[obase + e], dsum);
     }
     if (sn_w) {
         __shared__ float dred[4];
@@ -396,7 +402,8 @@ static int launch_wgrad(WgradParams& p, float* dw, float* dbias, const float* ou
     int rc = lp_check_launch("conv_wgrad");
     if (rc) return rc;
     int total = KS * KS * p.Cout * p.Cin;
-    const int wblocks = (total + WRED_PER_BLOCK - 1) / WRED_PER_BLOCK, bblocks = p.bpart ? (p.Cout + 63) / 64 : 0;
+    const int wblocks = p.Cout * ((p.Cin + WRED_CI - 1) / WRED_CI), bblocks = p.bpart ? (p.Cout + 63) / 64 : 0;
+    (void)total;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wblocks + bblocks), dim3(256), 0, stream, p.part, dw, p.splits, KS * KS,
                        p.Cout, p.Cin, p.CoP, p.CiP, p.bpart, dbias, wblocks, out_scale, sn_w, sn_dot);
     return lp_check_launch("wgrad_reduce");
@@ -404,7 +411,7 @@ static int launch_wgrad(WgradParams& p, float* dw, float* dbias, const float* ou
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-extern "C" int lp_conv_wgrad_dot_blocks(int Cin, int Cout, int ksize) { return (ksize * ksize * Cout * Cin + WRED_PER_BLOCK - 1) / WRED_PER_BLOCK; }
+extern "C" int lp_conv_wgrad_dot_blocks(int Cin, int Cout, int ksize) { (void)ksize; return Cout * ((Cin + WRED_CI - 1) / WRED_CI); }
 
 extern "C" long long lp_conv_wgrad_workspace_bytes(int Cin, int Cout, int ksize, int splits) {
     // [splits][taps][CoP][CiP] weight-gradient slabs, then [splits][CoP] bias-gradient partials
