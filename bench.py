@@ -422,8 +422,15 @@ def main():
             try:
                 pm = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc_conv_dma.json')))
                 entry['traffic'] = pm.get('hbm_bytes_per_launch')
-                entry['traffic_note'] = ('mean HBM bytes per conv_dma_kernel launch over the generator-only step (profiles/r02_pmc_conv_dma.json: '
-                                         '(2 x FETCH_SIZE + WRITE_SIZE) x 1024, separate rocprofv3 --pmc passes); per-shape values: '
+                # algorithmic bytes of the SAME population (the 12 layer classes of scripts/conv_micro.py, N tiles of 128 channels):
+                micro = [(8, 4, 4, 512, 512, 3, 0), (8, 16, 16, 512, 512, 3, 0), (8, 32, 32, 512, 512, 3, 0), (8, 64, 64, 256, 256, 3, 0),
+                         (8, 128, 128, 128, 128, 3, 0), (8, 256, 256, 64, 64, 3, 0), (8, 256, 256, 128, 64, 3, 1), (8, 256, 256, 64, 128, 3, 0),
+                         (8, 64, 64, 512, 256, 3, 1), (8, 64, 64, 256, 128, 1, 0), (16, 128, 128, 128, 128, 3, 0), (16, 64, 64, 256, 256, 3, 0)]
+                alg = sum(2 * n_ * (h_ >> u_) * (w_ >> u_) * ci_ * ((co_ + 127) // 128) + 2 * k_ * k_ * ci_ * co_ + 4 * n_ * h_ * w_ * co_
+                          for n_, h_, w_, ci_, co_, k_, u_ in micro) / len(micro)
+                entry['traffic_note'] = ('mean HBM bytes per conv_dma_kernel launch over the per-layer micro-benchmark (scripts/conv_micro.py, 12 layer '
+                                         'classes; profiles/r02_pmc_conv_dma.json: (2 x FETCH_SIZE + WRITE_SIZE) x 1024, separate rocprofv3 --pmc '
+                                         f'passes); algorithmic bytes of the same 12 launches: {alg / 1e6:.1f} MB mean; per-shape values: '
                                          'profiles/r02_pmc_conv_micro_f16.csv; MFMA busy fraction from SQ_VALU_MFMA_BUSY_CYCLES: '
                                          f"{pm.get('mfma_busy_fraction')}")
             except Exception:

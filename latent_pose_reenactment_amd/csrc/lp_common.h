@@ -28,20 +28,6 @@ template <bool F16> __device__ __forceinline__ uint16_t lp_f32_to_op16(float v) 
     return __builtin_bit_cast(uint16_t, (__bf16)v);
 }
 
-// fp32 -> (hi, lo) bf16 split of 8 values; lo only computed when SPLIT
-template <bool SPLIT>
-__device__ __forceinline__ void cvt8(const float (&v)[8], s16x8_t& hi, s16x8_t& lo) {
-    bf16x8_t h, l;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        __bf16 hh = (__bf16)v[j];
-        h[j] = hh;
-        if (SPLIT) l[j] = (__bf16)(v[j] - (float)hh);
-    }
-    hi = __builtin_bit_cast(s16x8_t, h);
-    if (SPLIT) lo = __builtin_bit_cast(s16x8_t, l);
-}
-
 __device__ __forceinline__ f32x4_t mfma16(s16x8_t a, s16x8_t b, f32x4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
@@ -116,59 +102,3 @@ __device__ __forceinline__ void tile_lin_decode(int kpix, int lTH, int lTW, int&
     nb = kpix >> (lTW + lTH);
 }
 
-// Stage the activated input halo of one tile into LDS as bf16 (hi[,lo]) rows of `CC` channels, row stride SA bytes.
-//   x      : NHWC fp32 [N][Hin][Win][Cin] (pre-activation)
-//   pro    : 0 none, 1 relu(x*scale[n,c]+shift[n,c]) (AdaIN), 2 relu(x)
-//   halo   : NBv images x HH x HW pixels, origin (oy, ox) in input coordinates; out-of-image pixels are ZERO
-//            (zero padding is applied after the activation, blocks.py:76-88 conv padding=1).
-template <int CC, bool SPLIT, int NT = 256>
-__device__ __forceinline__ void stage_act_halo(unsigned char* __restrict__ lds_hi, unsigned char* __restrict__ lds_lo, int SA,
-                                               const float* __restrict__ x, const float* __restrict__ scale,
-                                               const float* __restrict__ shift, int pro, int N, int Hin, int Win, int Cin,
-                                               int n0, int NBv, int HH, int HW, int oy, int ox, int c0, int tid) {
-    constexpr int CG = CC / 8;
-    const int items = NBv * HH * HW * CG;
-    const bool vec_ok = (Cin & 3) == 0;
-    for (int i = tid; i < items; i += NT) {
-        int cg = i % CG, hp = i / CG;
-        int hx = hp % HW, t2 = hp / HW;
-        int hy = t2 % HH, nb = t2 / HH;
-        int n = n0 + nb, iy = oy + hy, ix = ox + hx, c = c0 + cg * 8;
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = 0.f;
-        bool inb = (n < N) && (iy >= 0) && (iy < Hin) && (ix >= 0) && (ix < Win) && (c < Cin);
-        if (inb) {
-            const float* src = x + ((size_t)(n * Hin + iy) * Win + ix) * Cin + c;
-            if (vec_ok && c + 8 <= Cin) {
-                float4 p0 = *(const float4*)src, p1 = *(const float4*)(src + 4);
-                v[0] = p0.x; v[1] = p0.y; v[2] = p0.z; v[3] = p0.w; v[4] = p1.x; v[5] = p1.y; v[6] = p1.z; v[7] = p1.w;
-                if (pro == 1) {
-                    const float* sp = scale + (size_t)n * Cin + c; const float* tp = shift + (size_t)n * Cin + c;
-                    float4 s0 = *(const float4*)sp, s1 = *(const float4*)(sp + 4), t0 = *(const float4*)tp, t1 = *(const float4*)(tp + 4);
-                    v[0] = fmaxf(fmaf(v[0], s0.x, t0.x), 0.f); v[1] = fmaxf(fmaf(v[1], s0.y, t0.y), 0.f);
-                    v[2] = fmaxf(fmaf(v[2], s0.z, t0.z), 0.f); v[3] = fmaxf(fmaf(v[3], s0.w, t0.w), 0.f);
-                    v[4] = fmaxf(fmaf(v[4], s1.x, t1.x), 0.f); v[5] = fmaxf(fmaf(v[5], s1.y, t1.y), 0.f);
-                    v[6] = fmaxf(fmaf(v[6], s1.z, t1.z), 0.f); v[7] = fmaxf(fmaf(v[7], s1.w, t1.w), 0.f);
-                } else if (pro == 2) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    if (c + j < Cin) {
-                        float q = src[j];
-                        if (pro == 1) q = fmaxf(fmaf(q, scale[(size_t)n * Cin + c + j], shift[(size_t)n * Cin + c + j]), 0.f);
-                        else if (pro == 2) q = fmaxf(q, 0.f);
-                        v[j] = q;
-                    }
-                }
-            }
-        }
-        s16x8_t hi, lo;
-        cvt8<SPLIT>(v, hi, lo);
-        *(s16x8_t*)(lds_hi + (size_t)hp * SA + cg * 16) = hi;
-        if (SPLIT) *(s16x8_t*)(lds_lo + (size_t)hp * SA + cg * 16) = lo;
-    }
-}

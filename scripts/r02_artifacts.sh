@@ -32,6 +32,12 @@ python scripts/pmc_summary.py $O/${R}_pmc_gen_*/*counter_collection.csv > $O/${R
 python scripts/pmc_summary.py $O/${R}_pmc_micro_*/*counter_collection.csv > $O/${R}_pmc_conv_micro_f16.csv 2>> $O/${R}_pmc_summary.err
 python scripts/pmc_summary.py --json conv_dma_kernel $O/${R}_pmc_micro_*/*counter_collection.csv > $O/${R}_pmc_conv_dma.json 2>> $O/${R}_pmc_summary.err
 python scripts/pmc_summary.py --json conv_dma_kernel $O/${R}_pmc_gen_*/*counter_collection.csv > $O/${R}_pmc_conv_dma_generator_step_mfma.json 2>> $O/${R}_pmc_summary.err
+timeout 120 python scripts/mobilenet_micro.py 1 eval > $O/${R}_mobilenet_micro.txt 2>&1
+timeout 120 python scripts/mobilenet_micro.py 8 train >> $O/${R}_mobilenet_micro.txt 2>&1
+# functional run of the N > 1 bench path (two gloo ranks sharing the box's single GPU: NOT a performance number)
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 6 --warmup 2 --backend gloo > $O/${R}_bench_dp2_gloo_one_gpu_functional.json 2> $O/${R}_bench_dp2.err
+# CPU baseline exactly as BASELINE.md section 3 (>= 3 warm-up + >= 10 timed steps, all-core and 1-thread rows)
+timeout 900 python bench.py --steps 20 --warmup 5 --no-also --cpu-baseline-full > $O/${R}_bench_cpu_baseline_full.json 2> $O/${R}_bench_cpu_baseline_full.err
 PREC=2 timeout 120 python scripts/conv_micro.py > $O/${R}_conv_micro_f16.txt 2>&1
 PREC=1 timeout 120 python scripts/conv_micro.py > $O/${R}_conv_micro_bf16x3.txt 2>&1
 cat $O/${R}_bench_f16.json | cut -c1-1500

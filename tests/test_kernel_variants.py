@@ -1,6 +1,6 @@
 """Every tile / schedule variant of the HIP kernels must pass the same per-op parity tests, not only the variant the default
 heuristics pick for the (small) test shapes.  The variant knobs are read once per process (static env lookups in
-csrc/conv_dma.hip, conv_wgrad.hip; LP_THIN in hipops.py), so each setting runs tests/test_hip_ops.py in a fresh interpreter."""
+csrc/conv_dma.hip, conv_wgrad.hip, conv_thin.hip; LP_THIN in hipops.py), so each setting runs tests/test_hip_ops.py in a fresh interpreter."""
 import os
 import subprocess
 import sys
@@ -18,6 +18,7 @@ VARIANTS = [
     {'LP_CONV_NBUF': '2', 'LP_CONV_SPLIT_WGS': '512'},   # no ring; deeper split-K
     {'LP_WGRAD_COB': '64'},                     # 64-output-channel wgrad workgroups only
     {'LP_THIN': '0'},                           # thin-channel layers through the MFMA kernels (3- / 4-channel operand planes)
+    {'LP_THIN_MFMA': '0'},                      # RGB -> 64 convs on the fp32 VALU kernel in every precision mode
 ]
 
 
