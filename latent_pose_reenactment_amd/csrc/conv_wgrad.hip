@@ -301,6 +301,27 @@ __global__ __launch_bounds__(COB * 4) void conv_wgrad_kernel(WgradParams p) {
                 }
 }
 
+// trailing blocks of both reductions: dbias[co] = sum_s bpart[s][co], 64 channels per block, the splits dealt to 4 thread groups x 4
+// independent accumulators
+__device__ __forceinline__ void wred_bias_block(const float* __restrict__ bpart, float* __restrict__ dbias, int S, int Cout, int CoP, int blk,
+                                                float osc) {
+    __shared__ float red[4][64];
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int co = blk * 64 + c;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (co < Cout) {
+        int k = g;
+        for (; k + 12 < S; k += 16) {
+            a0 += bpart[(size_t)k * CoP + co]; a1 += bpart[(size_t)(k + 4) * CoP + co];
+            a2 += bpart[(size_t)(k + 8) * CoP + co]; a3 += bpart[(size_t)(k + 12) * CoP + co];
+        }
+        for (; k < S; k += 4) a0 += bpart[(size_t)k * CoP + co];
+    }
+    red[g][c] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (g == 0 && co < Cout) dbias[co] = ((red[0][c] + red[1][c]) + (red[2][c] + red[3][c])) * osc;
+}
+
 // dw[co][ci][tap] = sum_s part[s][tap][co][ci].  A block owns one output channel and WRED_CI input channels: the slabs are read with
 // ci fastest (coalesced 4-byte lanes, 8 independent accumulators keep 8 loads in flight per thread; the slabs are streamed once
 // from HBM/L2), the sums cross an LDS tile [ci][tap], and the block's WRED_CI * T outputs -- one contiguous run of the reference
@@ -313,24 +334,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
                                                            float* __restrict__ dbias, int wblocks, const float* __restrict__ out_scale,
                                                            const float* __restrict__ sn_w, float* __restrict__ sn_dot) {
     const float osc = out_scale ? out_scale[0] : 1.f;          // 1 / (input scale of the fp16 dy operand)
-    if ((int)blockIdx.x >= wblocks) {                 // trailing blocks: dbias[co] = sum_s bpart[s][co], 64 channels per block,
-        __shared__ float red[4][64];                  // the splits dealt to 4 thread groups x 4 independent accumulators
-        const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
-        const int co = (blockIdx.x - wblocks) * 64 + c;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        if (co < Cout) {
-            int k = g;
-            for (; k + 12 < S; k += 16) {
-                a0 += bpart[(size_t)k * CoP + co]; a1 += bpart[(size_t)(k + 4) * CoP + co];
-                a2 += bpart[(size_t)(k + 8) * CoP + co]; a3 += bpart[(size_t)(k + 12) * CoP + co];
-            }
-            for (; k < S; k += 4) a0 += bpart[(size_t)k * CoP + co];
-        }
-        red[g][c] = (a0 + a1) + (a2 + a3);
-        __syncthreads();
-        if (g == 0 && co < Cout) dbias[co] = ((red[0][c] + red[1][c]) + (red[2][c] + red[3][c])) * osc;
-        return;
-    }
+    if ((int)blockIdx.x >= wblocks) { wred_bias_block(bpart, dbias, S, Cout, CoP, blockIdx.x - wblocks, osc); return; }
     __shared__ float tile[WRED_CI * 9];
     const int cib = (Cin + WRED_CI - 1) / WRED_CI;
     const int co = blockIdx.x / cib, ci0 = (blockIdx.x - co * cib) * WRED_CI;
@@ -365,6 +369,48 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         __syncthreads();
         if (threadIdx.x == 0) sn_dot[blockIdx.x] = (dred[0] + dred[1]) + (dred[2] + dred[3]);
     }
+}
+
+// Small layers (few weights, many pixel splits: 64 x 64 x 9 weights summed over up to 512 slabs): one thread per (tap, co, ci) so that
+// the grid is as wide as the layer allows; the strided 4-byte stores do not matter at these sizes.
+__global__ __launch_bounds__(256) void wgrad_reduce_flat_kernel(const float* __restrict__ part, float* __restrict__ dw, int S, int T, int Cout,
+                                                                int Cin, int CoP, int CiP, const float* __restrict__ bpart,
+                                                                float* __restrict__ dbias, int wblocks, const float* __restrict__ out_scale,
+                                                                const float* __restrict__ sn_w, float* __restrict__ sn_dot) {
+    const float osc = out_scale ? out_scale[0] : 1.f;
+    if ((int)blockIdx.x >= wblocks) { wred_bias_block(bpart, dbias, S, Cout, CoP, blockIdx.x - wblocks, osc); return; }
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    float dsum = 0.f;
+    if (idx < T * Cout * Cin) {
+        const int ci = idx % Cin, r = idx / Cin;
+        const int co = r % Cout, t = r / Cout;
+        const size_t slab = (size_t)T * CoP * CiP;
+        const float* p = part + ((size_t)t * CoP + co) * CiP + ci;
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int k = 0;
+        for (; k + 8 <= S; k += 8) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a[q] += p[(size_t)(k + q) * slab];
+        }
+        for (; k < S; ++k) a[0] += p[(size_t)k * slab];
+        const float val = (((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) * osc;
+        const size_t o = ((size_t)co * Cin + ci) * T + t;
+        dw[o] = val;
+        if (sn_w) dsum = val * sn_w[o];
+    }
+    if (sn_w) {
+        __shared__ float dred[4];
+        for (int o = 32; o > 0; o >>= 1) dsum += __shfl_down(dsum, o, 64);
+        if ((threadIdx.x & 63) == 0) dred[threadIdx.x >> 6] = dsum;
+        __syncthreads();
+        if (threadIdx.x == 0) sn_dot[blockIdx.x] = (dred[0] + dred[1]) + (dred[2] + dred[3]);
+    }
+}
+
+// which reduction a layer gets, and with it the number of <dw, W_orig> partials
+static bool wred_tiled(int Cin, int Cout) { return Cout * ((Cin + WRED_CI - 1) / WRED_CI) >= 512; }
+static int wred_blocks(int Cin, int Cout, int T) {
+    return wred_tiled(Cin, Cout) ? Cout * ((Cin + WRED_CI - 1) / WRED_CI) : (T * Cout * Cin + 255) / 256;
 }
 
 static int ilog2_floor_w(int v) { int l = 0; while ((1 << (l + 1)) <= v) ++l; return l; }
@@ -402,16 +448,23 @@ static int launch_wgrad(WgradParams& p, float* dw, float* dbias, const float* ou
     int rc = lp_check_launch("conv_wgrad");
     if (rc) return rc;
     int total = KS * KS * p.Cout * p.Cin;
-    const int wblocks = p.Cout * ((p.Cin + WRED_CI - 1) / WRED_CI), bblocks = p.bpart ? (p.Cout + 63) / 64 : 0;
     (void)total;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wblocks + bblocks), dim3(256), 0, stream, p.part, dw, p.splits, KS * KS,
-                       p.Cout, p.Cin, p.CoP, p.CiP, p.bpart, dbias, wblocks, out_scale, sn_w, sn_dot);
+    const int bblocks = p.bpart ? (p.Cout + 63) / 64 : 0;
+    if (wred_tiled(p.Cin, p.Cout)) {
+        const int wblocks = wred_blocks(p.Cin, p.Cout, KS * KS);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wblocks + bblocks), dim3(256), 0, stream, p.part, dw, p.splits, KS * KS,
+                           p.Cout, p.Cin, p.CoP, p.CiP, p.bpart, dbias, wblocks, out_scale, sn_w, sn_dot);
+    } else {
+        const int wblocks = wred_blocks(p.Cin, p.Cout, KS * KS);
+        hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3(wblocks + bblocks), dim3(256), 0, stream, p.part, dw, p.splits, KS * KS, p.Cout, p.Cin,
+                           p.CoP, p.CiP, p.bpart, dbias, wblocks, out_scale, sn_w, sn_dot);
+    }
     return lp_check_launch("wgrad_reduce");
 }
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-extern "C" int lp_conv_wgrad_dot_blocks(int Cin, int Cout, int ksize) { (void)ksize; return Cout * ((Cin + WRED_CI - 1) / WRED_CI); }
+extern "C" int lp_conv_wgrad_dot_blocks(int Cin, int Cout, int ksize) { return wred_blocks(Cin, Cout, ksize * ksize); }
 
 extern "C" long long lp_conv_wgrad_workspace_bytes(int Cin, int Cout, int ksize, int splits) {
     // [splits][taps][CoP][CiP] weight-gradient slabs, then [splits][CoP] bias-gradient partials
