@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import math
 import os
+import weakref
 from typing import List, Optional, Tuple
 
 import torch
@@ -118,17 +119,22 @@ class SNBatch:
     """One-launch spectral normalisation of many ``SNWeight`` layers (lp_sn_power_iter): in train mode each layer's (u, v)
     buffers take one power-iteration step in place, and for every layer the call yields ``(u_used, v_used, sig)`` with
     ``sig = [sigma, 1/sigma]`` (device tensors).  ``1/sigma`` becomes the conv kernels' epilogue scale, so ``W / sigma`` is never
-    materialised; backward uses the saved (u, v).  Outputs rotate over a few static buffer sets (a discriminator runs three
-    passes per step, each needing its own copies until its backward is done; static addresses keep hipGraph capture valid)."""
+    materialised; backward uses the saved (u, v).  Outputs rotate over static buffer sets (a discriminator runs three passes per
+    step, each needing its own copies until its backward is done; static addresses keep hipGraph capture valid).  A set is reused
+    only when the autograd graph of the pass it served is gone: every grad-mode update hands out a fresh view object of the first
+    layer's sigma, which the consumers keep in their saved state, and the set stays reserved while that object is alive; if all
+    sets are reserved (more forward passes than ``SETS`` before a backward: gradient accumulation, two discriminator evaluations)
+    another set is allocated instead of silently overwriting one."""
     SETS = 4
 
     def __init__(self, layers):
         self.layers = list(layers)
         self.sets = None
+        self.live = []
         self.key = None
         self.next = 0
 
-    def _build(self):
+    def _new_set(self):
         import struct
         from . import _lib
         assert _lib.lib().lp_sn_desc_bytes() == 72
@@ -137,27 +143,30 @@ class SNBatch:
         rows = [l.weight_orig.shape[0] for l in self.layers]
         cols = [l.weight_orig[0].numel() for l in self.layers]
         self.max_rows, self.max_cols = max(rows), max(cols)
-        self.sets = []
-        for _ in range(self.SETS):
-            sig = torch.zeros(len(self.layers), 2, dtype=torch.float32, device=dev)
-            al = lambda n: (n + 3) // 4 * 4                 # 16-byte aligned slices: the mat-vec kernels use 16-B loads
-            uo = torch.zeros(sum(al(r) for r in rows), dtype=torch.float32, device=dev)
-            vo = torch.zeros(sum(al(c) for c in cols), dtype=torch.float32, device=dev)
-            need = [al(((r + rb - 1) // rb) * c + r + (c + 63) // 64) for r, c in zip(rows, cols)]
-            scratch = torch.zeros(sum(need), dtype=torch.float32, device=dev)
-            blob = bytearray()
-            states = []
-            ro = co = so = 0
-            for i, l in enumerate(self.layers):
-                w, u, v = l.weight_orig.data, l.weight_u, l.weight_v
-                assert w.is_contiguous() and w.dtype == torch.float32
-                ui, vi, si, pi = uo[ro:ro + rows[i]], vo[co:co + cols[i]], sig[i], scratch[so:so + need[i]]
-                blob += struct.pack('<QQQQQQQiifi', w.data_ptr(), u.data_ptr(), v.data_ptr(), ui.data_ptr(), vi.data_ptr(), si.data_ptr(),
-                                    pi.data_ptr(), rows[i], cols[i], float(l.eps), 0)
-                states.append((ui, vi, si))
-                ro += al(rows[i]); co += al(cols[i]); so += need[i]
-            table = torch.frombuffer(blob, dtype=torch.uint8).clone().to(dev)
-            self.sets.append((table, states, (sig, uo, vo, scratch)))
+        sig = torch.zeros(len(self.layers), 2, dtype=torch.float32, device=dev)
+        al = lambda n: (n + 3) // 4 * 4                 # 16-byte aligned slices: the mat-vec kernels use 16-B loads
+        uo = torch.zeros(sum(al(r) for r in rows), dtype=torch.float32, device=dev)
+        vo = torch.zeros(sum(al(c) for c in cols), dtype=torch.float32, device=dev)
+        need = [al(((r + rb - 1) // rb) * c + r + (c + 63) // 64) for r, c in zip(rows, cols)]
+        scratch = torch.zeros(sum(need), dtype=torch.float32, device=dev)
+        blob = bytearray()
+        states = []
+        ro = co = so = 0
+        for i, l in enumerate(self.layers):
+            w, u, v = l.weight_orig.data, l.weight_u, l.weight_v
+            assert w.is_contiguous() and w.dtype == torch.float32
+            ui, vi, si, pi = uo[ro:ro + rows[i]], vo[co:co + cols[i]], sig[i], scratch[so:so + need[i]]
+            blob += struct.pack('<QQQQQQQiifi', w.data_ptr(), u.data_ptr(), v.data_ptr(), ui.data_ptr(), vi.data_ptr(), si.data_ptr(),
+                                pi.data_ptr(), rows[i], cols[i], float(l.eps), 0)
+            states.append((ui, vi, si))
+            ro += al(rows[i]); co += al(cols[i]); so += need[i]
+        table = torch.frombuffer(blob, dtype=torch.uint8).clone().to(dev)
+        return (table, states, (sig, uo, vo, scratch))
+
+    def _build(self):
+        self.sets = [self._new_set() for _ in range(self.SETS)]
+        self.live = [None] * self.SETS
+        self.next = 0
 
     def update(self, training: bool):
         from . import _lib
@@ -165,10 +174,29 @@ class SNBatch:
         if self.sets is None or key != self.key:
             self._build()
             self.key = key
-        table, states, _ = self.sets[self.next]
-        self.next = (self.next + 1) % self.SETS
+        idx = None
+        for _ in range(len(self.sets)):
+            cand = self.next
+            self.next = (self.next + 1) % len(self.sets)
+            ref = self.live[cand]
+            if ref is None or ref() is None:
+                idx = cand
+                break
+        if idx is None:                                  # every set still serves a pass whose backward has not run
+            self.sets.append(self._new_set())
+            self.live.append(None)
+            idx = len(self.sets) - 1
+            self.next = 0
+        table, states, bufs = self.sets[idx]
         _lib.check(_lib.lib().lp_sn_power_iter(table.data_ptr(), len(self.layers), int(training), self.max_rows, self.max_cols,
                                                torch.cuda.current_stream().cuda_stream), 'lp_sn_power_iter')
+        if torch.is_grad_enabled():
+            u0, v0, _ = states[0]
+            token = bufs[0][0]                           # a NEW view object of layer 0's [sigma, 1/sigma]: alive as long as a consumer's
+            self.live[idx] = weakref.ref(token)          # saved state is, i.e. until the pass's autograd graph is released
+            states = [(u0, v0, token)] + states[1:]
+        else:
+            self.live[idx] = None
         return states
 
 

@@ -121,7 +121,18 @@ class _FusedBase(Optimizer):
 
 
 class FusedRAdam(_FusedBase):
+    """utils/radam.py:29-95 (degenerated_to_sgd=True) as one launch per parameter group.  Differences from the reference class, all
+    outside what its training loop does: every parameter of a group that requires grad is stepped on every call with ONE shared
+    step counter (the reference skips a parameter whose ``.grad`` is None; here a gradient view always exists and is zero after
+    ``zero_grad``, so such a parameter would still move on its momentum); ``state_dict()`` carries the reference's per-group
+    ``buffer`` cache (unused here) so that the state loads into the reference's RAdam."""
     KIND = 0
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, **ignored):
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, **ignored)
+        for group in self.param_groups:
+            group.setdefault('buffer', [[None, None, None] for _ in range(10)])
+        self.defaults.setdefault('buffer', [[None, None, None] for _ in range(10)])
 
 
 class FusedAdam(_FusedBase):

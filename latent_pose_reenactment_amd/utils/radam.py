@@ -12,7 +12,11 @@ class RAdam(Optimizer):
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1):
             raise ValueError('invalid RAdam hyper-parameter')
         self.degenerated_to_sgd = degenerated_to_sgd
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        # ``buffer``: the reference keeps a 10-entry (step, N_sma, step_size) cache in every param group (utils/radam.py:22-23,63-80)
+        # and indexes it in step(); it is emitted here (unused: the rectification is recomputed) so that an optimizer state
+        # written by this class loads into the reference's RAdam.
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
+                                      buffer=[[None, None, None] for _ in range(10)]))
 
     @staticmethod
     def rectification(step, beta1, beta2, degenerated_to_sgd=True):

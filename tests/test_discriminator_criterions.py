@@ -115,3 +115,35 @@ def test_perceptual_and_vggface_vs_reference_golden(monkeypatch):
     print(f'[parity] perceptual: loss_vgg19 {e1:.2e} grad {g1:.2e} | loss_vggface {e2:.2e} grad {g2:.2e}')
     assert e1 < 1e-4 and e2 < 1e-4 and g1 < 5e-3 and g2 < 5e-3
     assert rel(crop_and_resize(real, boxes), z['crop32']) < 1e-5
+
+
+@pytest.mark.gpu
+def test_spectral_norm_state_survives_many_forwards_before_backward(monkeypatch):
+    """The (u, v, 1/sigma) a pass used live in rotating static buffer sets until its backward has run.  Three discriminator
+    evaluations (9 passes) before ONE backward need more than the four initial sets: the ring must grow instead of overwriting a
+    pass's state -- gradients equal those of evaluate-then-backward done one at a time."""
+    import copy
+    monkeypatch.setenv('LP_PREC', 'bf16x3')
+    z = load('discriminator_small.npz')
+    D0 = make_dis(z)
+    D0.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in z.items() if k.startswith('sd.')}, strict=True)
+    g = torch.Generator().manual_seed(3)
+    batches = [dict(fake=torch.from_numpy(z['fake']) + 0.1 * i * torch.randn(z['fake'].shape, generator=g),
+                    real=torch.from_numpy(z['real']) + 0.1 * i * torch.randn(z['real'].shape, generator=g)) for i in range(3)]
+
+    def loss_of(D, b):
+        dd = dict(fake_rgbs=b['fake'].cuda(), target_rgbs=b['real'].cuda(), label=torch.from_numpy(z['label']).cuda())
+        D(dd)
+        return dd['fake_score_D'].square().mean() + dd['real_score'].square().mean() + sum(f.square().mean() for f in dd['real_features'])
+
+    Da, Db = copy.deepcopy(D0).cuda().train(), copy.deepcopy(D0).cuda().train()
+    sum(loss_of(Da, b) for b in batches).backward()              # A: all forwards first, one backward
+    for b in batches:                                            # B: one at a time (gradients accumulate)
+        loss_of(Db, b).backward()
+    worst = 0.0
+    for (k, pa), (_, pb) in zip(Da.named_parameters(), Db.named_parameters()):
+        if pb.grad is not None and float(pb.grad.abs().max()) > 0:
+            worst = max(worst, rel(pa.grad, pb.grad.cpu()))
+    assert worst < 1e-4, worst
+    for (k, ba), (_, bb) in zip(Da.named_buffers(), Db.named_buffers()):
+        assert torch.equal(ba, bb), k                            # the power iteration itself advanced identically

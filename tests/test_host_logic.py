@@ -135,3 +135,20 @@ def test_grad_reducer_two_rank_gloo(tmp_path):
                               stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=180)[0] for p in procs]
     assert all('REDUCER_OK' in o for o in outs), outs
+
+
+def test_radam_state_loads_into_a_reference_style_radam():
+    """the reference's RAdam indexes ``group['buffer'][step % 10]`` in step() (utils/radam.py:63): an optimizer state written here must
+    carry that per-group cache, for the restated RAdam and for the fused one (whose state_dict needs no GPU)"""
+    import torch
+    from latent_pose_reenactment_amd.optim import FusedRAdam
+    from latent_pose_reenactment_amd.utils.radam import RAdam
+    for cls in (RAdam, FusedRAdam):
+        p = torch.nn.Parameter(torch.zeros(3))
+        sd = cls([p], lr=5e-4, betas=(0.0, 0.999), eps=1e-5).state_dict()
+        buf = sd['param_groups'][0]['buffer']
+        assert len(buf) == 10 and all(len(b) == 3 for b in buf), cls
+    # and a state with the cache (as the reference writes it) loads back
+    opt = RAdam([torch.nn.Parameter(torch.zeros(3))])
+    opt.load_state_dict(sd)
+    assert 'buffer' in opt.param_groups[0]
