@@ -23,6 +23,8 @@ SIGNATURES = {
     'lp_pack_weights': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'lp_pack_desc_bytes': (_i, []),
     'lp_pack_weights_batch': (_i, [_vp, _i, _ll, _vp]),
+    'lp_pack_pair_desc_bytes': (_i, []),
+    'lp_pack_weights_pairs': (_i, [_vp, _i, _ll, _vp]),
     'lp_act_pack': (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
     'lp_amax_slots': (_i, []),
     'lp_amax_slot_stride': (_i, []),

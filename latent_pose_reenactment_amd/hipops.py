@@ -82,18 +82,19 @@ def pack_weights(w: Tensor, mode: int, prec: int, small_k: bool = False) -> Weig
 
 
 class PackBatch:
-    """16-bit packs of MANY conv weights, refreshed by ONE launch (lp_pack_weights_batch).  ``specs`` = [(w, mode, small_k)];
-    the pack buffers and the device descriptor table are allocated once (static addresses: hipGraph friendly); ``update()``
-    re-packs all entries from the current weight values and returns the list of WeightPacks (same order as ``specs``)."""
+    """16-bit packs of MANY conv weights, refreshed by one or two launches.  ``specs`` = [(w, mode, small_k)]; the pack buffers and
+    the device descriptor tables are allocated once (static addresses: hipGraph friendly); ``update()`` re-packs all entries from
+    the current weight values and returns the list of WeightPacks (same order as ``specs``).  A weight that appears in both
+    orientations (training: forward + data-gradient pack) is handled by lp_pack_weights_pairs -- one coalesced read of W through an
+    LDS tile for both packs; the rest by lp_pack_weights_batch."""
 
     def __init__(self, specs, prec: int):
         import struct
-        assert _lib.lib().lp_pack_desc_bytes() == 56
+        assert _lib.lib().lp_pack_desc_bytes() == 56 and _lib.lib().lp_pack_pair_desc_bytes() == 80
         self.prec = prec
         self.key = tuple((w.data_ptr(), mode, bool(sk)) for w, mode, sk in specs)
         self.packs = []
-        blob = bytearray()
-        self.chunks = 0
+        geo = []
         for w, mode, small_k in specs:
             _chk(w, 'w')
             cout, cin = w.shape[0], w.shape[1]
@@ -104,13 +105,42 @@ class PackBatch:
             hi = torch.empty((taps, rows_p, cols_p), dtype=torch.int16, device=w.device)
             lo = torch.empty_like(hi) if prec == PREC_BF16X3 else None
             self.packs.append(WeightPack(hi, lo, rows, cols, rows_p, cols_p, taps))
-            blob += struct.pack('<QQQiiiiiiii', w.data_ptr(), hi.data_ptr(), 0 if lo is None else lo.data_ptr(), cout, cin, taps, rows_p,
-                                cols_p, mode, self.chunks, _f16(prec))
-            self.chunks += (taps * rows_p * cols_p + 1023) // 1024
-        self.table = torch.frombuffer(blob, dtype=torch.uint8).clone().to(specs[0][0].device)
+            geo.append((w, mode, cout, cin, taps))
+        by_w = {}
+        for i, (w, mode, *_rest) in enumerate(geo):
+            by_w.setdefault(w.data_ptr(), {}).setdefault(mode, i)
+        paired = {}
+        for ptr, modes in by_w.items():
+            if 0 in modes and 1 in modes and geo[modes[0]][4] in (1, 9):
+                paired[modes[0]] = modes[1]
+        in_pair = set(paired) | set(paired.values())
+        blob, pblob = bytearray(), bytearray()
+        self.chunks = self.tiles = self.nsingle = self.npair = 0
+        lop = lambda pk: 0 if pk.lo is None else pk.lo.data_ptr()
+        for i, (w, mode, cout, cin, taps) in enumerate(geo):
+            pk = self.packs[i]
+            if i in paired:
+                pk1 = self.packs[paired[i]]
+                tco = (max(pk.rows_p, pk1.cols_p) + 31) // 32
+                tci = (max(pk.cols_p, pk1.rows_p) + 31) // 32
+                pblob += struct.pack('<QQQQQiiiiiiiiii', w.data_ptr(), pk.hi.data_ptr(), lop(pk), pk1.hi.data_ptr(), lop(pk1), cout, cin, taps,
+                                     pk.rows_p, pk.cols_p, pk1.rows_p, pk1.cols_p, self.tiles, tci, _f16(prec))
+                self.tiles += tco * tci
+                self.npair += 1
+            elif i not in in_pair:
+                blob += struct.pack('<QQQiiiiiiii', w.data_ptr(), pk.hi.data_ptr(), lop(pk), cout, cin, taps, pk.rows_p, pk.cols_p, mode,
+                                    self.chunks, _f16(prec))
+                self.chunks += (taps * pk.rows_p * pk.cols_p + 1023) // 1024
+                self.nsingle += 1
+        dev = specs[0][0].device
+        self.table = torch.frombuffer(blob, dtype=torch.uint8).clone().to(dev) if self.nsingle else None
+        self.ptable = torch.frombuffer(pblob, dtype=torch.uint8).clone().to(dev) if self.npair else None
 
     def update(self):
-        check(_lib.lib().lp_pack_weights_batch(self.table.data_ptr(), len(self.packs), self.chunks, _stream()), 'lp_pack_weights_batch')
+        if self.npair:
+            check(_lib.lib().lp_pack_weights_pairs(self.ptable.data_ptr(), self.npair, self.tiles, _stream()), 'lp_pack_weights_pairs')
+        if self.nsingle:
+            check(_lib.lib().lp_pack_weights_batch(self.table.data_ptr(), self.nsingle, self.chunks, _stream()), 'lp_pack_weights_batch')
         return self.packs
 
 

@@ -58,11 +58,12 @@ def test_abi_version_and_error_string():
 
 def test_descriptor_struct_sizes_match_the_python_packers():
     """the device descriptor tables are packed with struct.pack on the host (nn.SNBatch '<QQQQQQQiifi', optim._build_table,
-    hipops.PackBatch '<QQQiiiiiiii'): their byte sizes must equal the C structs'"""
+    hipops.PackBatch '<QQQiiiiiiii' / '<QQQQQiiiiiiiiii'): their byte sizes must equal the C structs'"""
     import struct
     from latent_pose_reenactment_amd import _lib
     l = _lib.lib()
     assert l.lp_sn_desc_bytes() == struct.calcsize('<QQQQQQQiifi') == 72
     assert l.lp_pack_desc_bytes() == struct.calcsize('<QQQiiiiiiii') == 56
+    assert l.lp_pack_pair_desc_bytes() == struct.calcsize('<QQQQQiiiiiiiiii') == 80
     assert l.lp_mt_desc_bytes() == struct.calcsize('<QQQQq') == 40
     assert l.lp_sn_row_block() == 32 and l.lp_l1_partial_blocks() == 1024

@@ -336,3 +336,27 @@ def test_recorded_amax_survives_autograd():
     before = dict(ops.AMAX_STATS)
     y.square().sum().backward()
     assert ops.AMAX_STATS['fused'] - before['fused'] >= 1, ops.AMAX_STATS
+
+
+@pytest.mark.parametrize('prec', [1, 2])
+def test_pack_batch_pairs_equal_single_packs(prec):
+    """PackBatch packs a weight that is needed in both orientations with lp_pack_weights_pairs (one read of W through an LDS tile):
+    bit-identical to lp_pack_weights, padding included, for 3x3 / 1x1 kernels, odd channel counts and the small-k padding"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(41)
+    shapes = [(64, 64, 3), (128, 512, 3), (24, 16, 1), (4, 64, 3), (70, 130, 3), (512, 256, 1)]
+    ws = [torch.randn(co, ci, k, k, generator=g).cuda() for co, ci, k in shapes]
+    extra = torch.randn(32, 8, 3, 3, generator=g).cuda()           # forward pack only: goes through the per-element kernel
+    specs = [(w, 0, False) for w in ws] + [(extra, 0, True)] + [(w, 1, w.shape[0] <= 32 and w.shape[2] == 3) for w in ws]
+    pb = ops.PackBatch(specs, prec)
+    assert pb.npair == len(ws) and pb.nsingle == 1
+    for pk in pb.packs:                                            # poison: padding must be written too
+        pk.hi.fill_(0x7fff)
+        if pk.lo is not None:
+            pk.lo.fill_(0x7fff)
+    got = pb.update()
+    for (w, mode, sk), pk in zip(specs, got):
+        ref = ops.pack_weights(w, mode, prec, small_k=sk)
+        assert pk.hi.shape == ref.hi.shape and torch.equal(pk.hi, ref.hi), (tuple(w.shape), mode)
+        if prec == 1:
+            assert torch.equal(pk.lo, ref.lo), (tuple(w.shape), mode)
