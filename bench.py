@@ -376,24 +376,29 @@ def main():
             # the N = 1 point of THIS workload (`--gpus 1` defaults to the fine-tuning step, which the reference never runs multi-GPU):
             # every rank repeats the timed loop with the gradient exchange removed -- one GPU's throughput on the same step and batch
             red, tm.reducer = tm.reducer, None
-            try:
-                nsolo = min(a.steps, 50)
+            nsolo = min(a.steps, 50)
+            t_local, err = 0.0, None
+            try:      # no collective inside: a rank that fails here must not leave the others waiting in one
                 step1 = eager_step if a.eager else holycow.GraphedTrainStep(tm, opt_G, opt_D, args, data, target, warmup_steps=2)
                 for _ in range(3):
                     step1()
-                sync()
+                torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 for _ in range(nsolo):
                     step1()
-                sync()
-                t = torch.tensor([time.perf_counter() - t1], device=device, dtype=torch.float64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                solo = {'value': round(a.batch * nsolo / t.item(), 3), 'unit': 'images/s', 'n_gpus': 1, 'steps': nsolo,
-                        'ms_per_step': round(t.item() / nsolo * 1e3, 3),
+                torch.cuda.synchronize()
+                t_local = time.perf_counter() - t1
+            except Exception as ex:
+                err = repr(ex)
+            t = torch.tensor([t_local, 0.0 if err is None else 1.0], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            if t[1].item() > 0:
+                solo = {'error': err or 'failed on another rank'}
+            else:
+                solo = {'value': round(a.batch * nsolo / t[0].item(), 3), 'unit': 'images/s', 'n_gpus': 1, 'steps': nsolo,
+                        'ms_per_step': round(t[0].item() / nsolo * 1e3, 3),
                         'note': 'same workload and per-GPU batch with the gradient exchange removed, timed on every rank at once (max over ranks): '
                                 'the single-GPU point of this curve'}
-            except Exception as ex:
-                solo = {'error': repr(ex)}
             tm.reducer = red
 
     # live roofline of the dominant kernel family (HIP events recorded on the launch stream inside the timed region)
