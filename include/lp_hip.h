@@ -41,13 +41,13 @@ int lp_pack_weights(const float* w, uint16_t* hi, uint16_t* lo, int Cout, int Ci
  * The grid is flat over 1024-element chunks: chunk0 = sum of ceil(T*RowsP*ColsP/1024) of the preceding entries (ascending),
  * total_chunks = that sum over all entries. */
 int lp_pack_desc_bytes(void);
+int lp_pack_weights_batch(const void* table, int num_entries, long long total_chunks, void* stream);
 /* Forward AND data-gradient pack of a conv weight (T = 1 | 9) from one coalesced read.  table: DEVICE array of {const float* w;
  * uint16_t* hi0, *lo0 (forward pack, rows RowsP0 x cols ColsP0), *hi1, *lo1 (data-gradient pack, RowsP1 x ColsP1); int Cout, Cin, T,
  * RowsP0, ColsP0, RowsP1, ColsP1, tile0, tiles_ci, f16;} (lp_pack_pair_desc_bytes() each); an entry owns the 32 x 32 tiles
  * [tile0, tile0 + tiles_co * tiles_ci) with tiles_co = ceil(max(RowsP0, ColsP1) / 32), tiles_ci = ceil(max(ColsP0, RowsP1) / 32). */
 int lp_pack_pair_desc_bytes(void);
 int lp_pack_weights_pairs(const void* table, int num_entries, long long total_tiles, void* stream);
-int lp_pack_weights_batch(const void* table, int num_entries, long long total_chunks, void* stream);
 
 /* Operand planes of a conv input: hi (, lo) [N*HW][C8] 16-bit, C8 = C rounded up to 8 (pad channels zero), holding
  *   act(x) * in_scale,  act: pro 0 identity | 1 relu(x*scale[n,c]+shift[n,c]) | 2 relu(x) | 3 relu6(x*scale[c]+shift[c])
