@@ -207,10 +207,13 @@ int lp_avgpool2_bwd(const float* dy, const float* x, float* dx, int N, int H, in
  * backward: da = coef * grad_out[0] * sign(relu?(a) - relu?(b)) * (relu_in ? [a>0] : 1)  (+ add [numel]|NULL: the gradient that
  * reaches `a` from its other consumer -- the next conv / pool of the VGG stack -- summed here instead of by an autograd add) */
 int lp_l1_partial_blocks(void);
-/* out|NULL: a second tiny launch writes out[0] = coef * sum(partial) (fixed order) -- the finished loss term. */
-int lp_l1_fwd(const float* a, const float* b, float* partial, long long numel, int relu_in, float coef, float* out, void* stream);
+/* out|NULL: a second tiny launch writes out[0] = coef * sum(partial) (fixed order) -- the finished loss term.
+ * sign_out [numel] int8|NULL: the forward also leaves sign(relu?(a) - relu?(b)) * (relu_in ? [a > 0] : 1); lp_l1_bwd(sign = that) then
+ * reads one byte per element instead of a and b again (a, b may be NULL). */
+int lp_l1_fwd(const float* a, const float* b, float* partial, long long numel, int relu_in, float coef, float* out, int8_t* sign_out,
+              void* stream);
 int lp_l1_bwd(const float* a, const float* b, const float* grad_out, float coef, const float* add, float* da, long long numel, int relu_in,
-              float* amax_slots, void* stream);
+              const int8_t* sign, float* amax_slots, void* stream);
 
 /* ---- fused multi-tensor optimizers + EMA (runners/holycow.py:34-41,99-109; utils/radam.py:29-95; torch.optim.Adam) ----
  * table: DEVICE array of {float* p; const float* g; float* m; float* v; long long n;} (lp_mt_desc_bytes() each), one per

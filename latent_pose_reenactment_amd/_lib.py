@@ -68,8 +68,8 @@ SIGNATURES = {
     'lp_avgpool2_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'lp_avgpool2_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     'lp_l1_partial_blocks': (_i, []),
-    'lp_l1_fwd': (_i, [_vp, _vp, _vp, _ll, _i, _f, _vp, _vp]),
-    'lp_l1_bwd': (_i, [_vp, _vp, _vp, _f, _vp, _vp, _ll, _i, _vp, _vp]),
+    'lp_l1_fwd': (_i, [_vp, _vp, _vp, _ll, _i, _f, _vp, _vp, _vp]),
+    'lp_l1_bwd': (_i, [_vp, _vp, _vp, _f, _vp, _vp, _ll, _i, _vp, _vp, _vp]),
     'lp_mt_desc_bytes': (_i, []),
     'lp_mt_optimizer_step': (_i, [_vp, _i, _ll, _vp, _i, _f, _f, _f, _f, _vp]),
     'lp_mt_ema': (_i, [_vp, _i, _ll, _f, _i, _vp]),

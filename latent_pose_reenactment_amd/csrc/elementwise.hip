@@ -537,8 +537,10 @@ extern "C" int lp_avgpool2_bwd(const float* dy, const float* x, float* dx, int N
 }
 
 // partial[b] = sum over this block's elements of |relu?(a) - relu?(b)|   (criterions/common/perceptual_loss.py:104-108 L1 taps)
+// sgn != NULL: also the backward's sign pattern, one int8 per element: sign(relu?(a) - relu?(b)) * (relu_in ? [a > 0] : 1) -- the backward
+// then reads 1 byte per element instead of a and b again (8 bytes).
 __global__ __launch_bounds__(256) void l1_partial_kernel(const float4* __restrict__ a, const float4* __restrict__ b,
-                                                         float* __restrict__ part, long long total4, int relu_in) {
+                                                         float* __restrict__ part, long long total4, int relu_in, char4* __restrict__ sgn) {
     __shared__ float sh[4];
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -550,6 +552,14 @@ __global__ __launch_bounds__(256) void l1_partial_kernel(const float4* __restric
             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
         s += (fabsf(u.x - v.x) + fabsf(u.y - v.y)) + (fabsf(u.z - v.z) + fabsf(u.w - v.w));
+        if (sgn) {      // (with relu_in, u == 0 wherever a <= 0: then u > v is false and u < v needs the mask)
+            char4 q;
+            q.x = (char)((u.x > v.x) - ((u.x < v.x) && (!relu_in || u.x > 0.f)));
+            q.y = (char)((u.y > v.y) - ((u.y < v.y) && (!relu_in || u.y > 0.f)));
+            q.z = (char)((u.z > v.z) - ((u.z < v.z) && (!relu_in || u.z > 0.f)));
+            q.w = (char)((u.w > v.w) - ((u.w < v.w) && (!relu_in || u.w > 0.f)));
+            sgn[i] = q;
+        }
     }
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
@@ -593,25 +603,47 @@ __global__ void l1_bwd_kernel(const float4* __restrict__ a, const float4* __rest
     if (amax) lp_amax_commit(am, amax, blockIdx.x);
 }
 
+// the same from the sign pattern the forward launch left: da = coef * g[0] * sgn (+ add)
+__global__ void l1_bwd_sgn_kernel(const char4* __restrict__ sgn, const float* __restrict__ g, float coef, const float4* __restrict__ add,
+                                  float4* __restrict__ da, long long total4, float* __restrict__ amax) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const float k = coef * g[0];
+    float am = 0.f;
+    for (; i < total4; i += stride) {
+        const char4 q = sgn[i];
+        float4 o = make_float4(k * (float)q.x, k * (float)q.y, k * (float)q.z, k * (float)q.w);
+        if (add) { const float4 e = add[i]; o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w; }
+        da[i] = o;
+        am = lp_amax4(am, o);
+    }
+    if (amax) lp_amax_commit(am, amax, blockIdx.x);
+}
+
 #define L1_BLOCKS 1024
 extern "C" int lp_l1_partial_blocks(void) { return L1_BLOCKS; }
 
 extern "C" int lp_l1_fwd(const float* a, const float* b, float* partial, long long numel, int relu_in, float coef, float* out,
-                         void* stream) {
+                         int8_t* sign_out, void* stream) {
     if (!a || !b || !partial) return lp_set_error(LP_ERR_ARG, "lp_l1_fwd: null pointer");
     if (numel & 3) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_l1_fwd: numel must be a multiple of 4");
     hipLaunchKernelGGL(l1_partial_kernel, dim3(L1_BLOCKS), dim3(256), 0, (hipStream_t)stream, (const float4*)a, (const float4*)b, partial,
-                       numel / 4, relu_in);
+                       numel / 4, relu_in, (char4*)sign_out);
     if (out) hipLaunchKernelGGL(l1_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, L1_BLOCKS, coef, out);
     return lp_check_launch("l1_fwd");
 }
 
 extern "C" int lp_l1_bwd(const float* a, const float* b, const float* grad_out, float coef, const float* add, float* da, long long numel,
-                         int relu_in, float* amax_slots, void* stream) {
-    if (!a || !b || !grad_out || !da) return lp_set_error(LP_ERR_ARG, "lp_l1_bwd: null pointer");
+                         int relu_in, const int8_t* sign, float* amax_slots, void* stream) {
+    if ((!sign && (!a || !b)) || !grad_out || !da) return lp_set_error(LP_ERR_ARG, "lp_l1_bwd: null pointer");
     if (numel & 3) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_l1_bwd: numel must be a multiple of 4");
     long long total4 = numel / 4;
     int blocks = (int)((total4 + 255) / 256); if (blocks > 8192) blocks = 8192;
+    if (sign) {
+        hipLaunchKernelGGL(l1_bwd_sgn_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const char4*)sign, grad_out, coef, (const float4*)add,
+                           (float4*)da, total4, amax_slots);
+        return lp_check_launch("l1_bwd_sgn");
+    }
     hipLaunchKernelGGL(l1_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)a, (const float4*)b, grad_out, coef,
                        (const float4*)add, (float4*)da, total4, relu_in, amax_slots);
     return lp_check_launch("l1_bwd");

@@ -656,24 +656,31 @@ def avgpool2_bwd(dy: Tensor, x: Tensor, relu_in: bool, amax: bool = False) -> Te
     return dx
 
 
-def l1_sum(a: Tensor, b: Tensor, relu_in: bool, coef: float = 1.0) -> Tensor:
-    """coef * sum |relu?(a) - relu?(b)| as a 0-d tensor (block partials + a one-block finalize launch)"""
+def l1_sum(a: Tensor, b: Tensor, relu_in: bool, coef: float = 1.0, want_sign: bool = False):
+    """coef * sum |relu?(a) - relu?(b)| as a 0-d tensor (block partials + a one-block finalize launch).  ``want_sign``: -> (term, sgn)
+    with sgn int8 [numel] = the sign pattern the backward needs (``l1_bwd(sign=...)`` then does not read a and b again)"""
     _chk(a, 'a'); _chk(b, 'b')
     assert a.shape == b.shape
     buf = torch.empty(_lib.lib().lp_l1_partial_blocks() + 1, dtype=torch.float32, device=a.device)
     out = buf[-1:]
-    check(_lib.lib().lp_l1_fwd(a.data_ptr(), b.data_ptr(), buf.data_ptr(), a.numel(), int(relu_in), float(coef), out.data_ptr(),
+    sgn = torch.empty(a.numel(), dtype=torch.int8, device=a.device) if want_sign else None
+    check(_lib.lib().lp_l1_fwd(a.data_ptr(), b.data_ptr(), buf.data_ptr(), a.numel(), int(relu_in), float(coef), out.data_ptr(), _p(sgn),
                                _stream()), 'lp_l1_fwd')
-    return out.reshape(())
+    return (out.reshape(()), sgn) if want_sign else out.reshape(())
 
 
-def l1_bwd(a: Tensor, b: Tensor, grad_out: Tensor, coef: float, relu_in: bool, add: Optional[Tensor] = None, amax: bool = False) -> Tensor:
-    """gradient of coef * sum|relu?(a) - relu?(b)| w.r.t. a, times grad_out; ``add`` (same shape) is summed in"""
-    _chk(a, 'a'); _chk(b, 'b')
+def l1_bwd(a: Optional[Tensor], b: Optional[Tensor], grad_out: Tensor, coef: float, relu_in: bool, add: Optional[Tensor] = None,
+           amax: bool = False, sign: Optional[Tensor] = None, shape=None) -> Tensor:
+    """gradient of coef * sum|relu?(a) - relu?(b)| w.r.t. a, times grad_out; ``add`` (same shape) is summed in.  ``sign`` (from
+    ``l1_sum(want_sign=True)``) replaces a and b; ``shape`` is then the shape of the result"""
+    if sign is None:
+        _chk(a, 'a'); _chk(b, 'b')
+        shape = a.shape
     if add is not None:
-        _chk(add, 'add'); assert add.shape == a.shape
+        _chk(add, 'add'); assert tuple(add.shape) == tuple(shape)
     g = grad_out.reshape(1).contiguous().float()
-    da = torch.empty_like(a)
-    check(_lib.lib().lp_l1_bwd(a.data_ptr(), b.data_ptr(), g.data_ptr(), float(coef), _p(add), da.data_ptr(), a.numel(), int(relu_in),
+    da = torch.empty(tuple(shape), dtype=torch.float32, device=g.device)
+    check(_lib.lib().lp_l1_bwd(_p(a), _p(b), g.data_ptr(), float(coef), _p(add), da.data_ptr(), da.numel(), int(relu_in), _p(sign),
                                _p(_amax_attach(da, amax)), _stream()), 'lp_l1_bwd')
     return da
+

@@ -812,14 +812,15 @@ class L1Fn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, a, b, relu_in):
-        ctx.save_for_backward(a, b)
-        ctx.relu_in = relu_in
-        return ops.l1_sum(a, b, relu_in, 1.0 / a.numel())
+        if not ctx.needs_input_grad[0]:
+            return ops.l1_sum(a, b, relu_in, 1.0 / a.numel())
+        term, ctx.sgn = ops.l1_sum(a, b, relu_in, 1.0 / a.numel(), want_sign=True)      # the backward reads the 1-byte sign pattern,
+        ctx.shape = tuple(a.shape)                                                        # not a and b again
+        return term
 
     @staticmethod
     def backward(ctx, g):
-        a, b = ctx.saved_tensors
-        return ops.l1_bwd(a, b, g, 1.0 / a.numel(), ctx.relu_in, amax=default_prec() == PREC_F16), None, None
+        return ops.l1_bwd(None, None, g, 1.0 / ctx.sgn.numel(), False, sign=ctx.sgn, shape=ctx.shape, amax=default_prec() == PREC_F16), None, None
 
 
 def hip_l1(a, b, relu_in=False):
@@ -834,17 +835,19 @@ class L1TapFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, a, b, relu_in):
-        ctx.save_for_backward(a, b)
-        ctx.relu_in = relu_in
-        return a.view_as(a), ops.l1_sum(a, b, relu_in, 1.0 / a.numel())
+        if not ctx.needs_input_grad[0]:
+            return a.view_as(a), ops.l1_sum(a, b, relu_in, 1.0 / a.numel())
+        term, ctx.sgn = ops.l1_sum(a, b, relu_in, 1.0 / a.numel(), want_sign=True)
+        ctx.shape = tuple(a.shape)
+        return a.view_as(a), term
 
     @staticmethod
     def backward(ctx, g_next, g_loss):
-        a, b = ctx.saved_tensors
         if g_loss is None:
             return g_next, None, None
         add = None if g_next is None else g_next.contiguous()
-        return ops.l1_bwd(a, b, g_loss, 1.0 / a.numel(), ctx.relu_in, add=add, amax=default_prec() == PREC_F16), None, None
+        return ops.l1_bwd(None, None, g_loss, 1.0 / ctx.sgn.numel(), False, add=add, sign=ctx.sgn, shape=ctx.shape,
+                          amax=default_prec() == PREC_F16), None, None
 
 
 def hip_l1_tap(a, b, relu_in=False):

@@ -360,3 +360,21 @@ def test_pack_batch_pairs_equal_single_packs(prec):
         assert pk.hi.shape == ref.hi.shape and torch.equal(pk.hi, ref.hi), (tuple(w.shape), mode)
         if prec == 1:
             assert torch.equal(pk.lo, ref.lo), (tuple(w.shape), mode)
+
+
+@pytest.mark.parametrize('relu_in', [False, True])
+def test_l1_backward_from_the_saved_sign_pattern(relu_in):
+    """the L1 forward can leave its 1-byte sign pattern; the backward from it equals the backward that re-reads a and b"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(51)
+    a = torch.randn(2, 16, 16, 64, generator=g).cuda()
+    b = torch.randn(2, 16, 16, 64, generator=g).cuda()
+    a[0, 0, 0, :8] = b[0, 0, 0, :8]                                 # exact ties -> zero gradient
+    add = torch.randn(2, 16, 16, 64, generator=g).cuda()
+    go = torch.tensor(0.37).cuda()
+    term, sgn = ops.l1_sum(a, b, relu_in, 1.0 / a.numel(), want_sign=True)
+    assert torch.equal(term, ops.l1_sum(a, b, relu_in, 1.0 / a.numel()))
+    ref = ops.l1_bwd(a, b, go, 1.0 / a.numel(), relu_in, add=add)
+    got = ops.l1_bwd(None, None, go, 1.0 / a.numel(), False, add=add, sign=sgn, shape=a.shape)
+    assert torch.equal(got, ref)
+    assert torch.equal(ops.l1_bwd(None, None, go, 2.0, False, sign=sgn, shape=a.shape), ops.l1_bwd(a, b, go, 2.0, relu_in))
