@@ -199,8 +199,9 @@ int lp_head_bwd(const float* t, const float* d_rgbs, const float* d_segm, float*
 /* ---- discriminator / perceptual-loss helpers (discriminators/no_landmarks.py:52-108, criterions/common/perceptual_loss.py) ---- */
 /* dx = dA * [x > 0]                       (autograd of nn.ReLU, blocks.py:71-73,84) */
 int lp_relu_bwd(const float* dA, const float* x, float* dx, long long numel, void* stream);
-/* y = AvgPool2d(2)(relu?(x)); x [N][2H][2W][C], y [N][H][W][C]   (nn.AvgPool2d, blocks.py:89-90; perceptual_loss.py:77) */
-int lp_avgpool2_fwd(const float* x, float* y, int N, int H, int W, int C, int relu_in, void* stream);
+/* y = AvgPool2d(2)(relu?(x)); x [N][2H][2W][C], y [N][H][W][C]   (nn.AvgPool2d, blocks.py:89-90; perceptual_loss.py:77);
+ * out_hi [N][H][W][C]|NULL (C % 8 == 0, prec bf16 | fp16): also the operand planes of y for the conv that follows */
+int lp_avgpool2_fwd(const float* x, float* y, int N, int H, int W, int C, int relu_in, uint16_t* out_hi, int prec, void* stream);
 /* dx [N][H][W][C] = 0.25 * dy[.., y>>1, x>>1, ..] * (relu_in ? [x>0] : 1); H, W = full-resolution dims */
 int lp_avgpool2_bwd(const float* dy, const float* x, float* dx, int N, int H, int W, int C, int relu_in, float* amax_slots, void* stream);
 /* L1 taps: partial[lp_l1_partial_blocks()] block sums of |relu?(a) - relu?(b)| (F.l1_loss numerator; featmat.py:17, perceptual_loss.py:107);

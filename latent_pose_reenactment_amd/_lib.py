@@ -65,7 +65,7 @@ SIGNATURES = {
     'lp_head_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'lp_head_bwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     'lp_relu_bwd': (_i, [_vp, _vp, _vp, _ll, _vp]),
-    'lp_avgpool2_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'lp_avgpool2_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     'lp_avgpool2_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     'lp_l1_partial_blocks': (_i, []),
     'lp_l1_fwd': (_i, [_vp, _vp, _vp, _ll, _i, _f, _vp, _vp, _vp]),

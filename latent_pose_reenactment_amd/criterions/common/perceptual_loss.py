@@ -109,7 +109,10 @@ class PerceptualLoss(nn.Module):
                     cur, term = hip_l1_tap(cur, targets[len(taps)], relu_in=True)
                     taps.append(term)
             else:
-                cur = AvgPool2Fn.apply(cur, pending_relu)
+                # pool -> conv: the pool launch also writes the next conv's operand planes (one-plane precision modes)
+                holder = [] if (prec != lpnn.PREC_BF16X3 and i + 1 < n_layers and isinstance(self.model[i + 1], nn.Conv2d)) else None
+                cur = AvgPool2Fn.apply(cur, pending_relu, None if holder is None else (prec, holder))
+                cur16 = holder[0] if holder else None
                 pending_relu = False
         return taps
 
@@ -122,7 +125,6 @@ class PerceptualLoss(nn.Module):
         with torch.no_grad():
             ft = self.normalize_inputs((target.detach() + 1) / 2)
             taps_t = self._features(ft, packs, prec, [])
-        loss = 0
-        for term in self._features(fi, packs, prec, [], targets=taps_t):
-            loss = loss + term
+        terms = self._features(fi, packs, prec, [], targets=taps_t)
+        loss = torch.stack(terms).sum() if len(terms) > 1 else terms[0]     # (one cat + one sum instead of a chain of scalar adds)
         return loss * self.weight

@@ -1,4 +1,5 @@
 """Feature matching over the discriminator's feature maps (reference API: criterions/featmat.py:4-29)."""
+import torch
 import torch.nn.functional as F
 from torch import nn
 
@@ -27,5 +28,6 @@ class Criterion(nn.Module):
             if f.is_cuda and f.dim() == 4 and f.numel() % 4 == 0:
                 return hip_l1(f.permute(0, 2, 3, 1).contiguous(), r.detach().permute(0, 2, 3, 1).contiguous())
             return F.l1_loss(f, r.detach())
-        total = sum(l1(f, r) for f, r in zip(fake, real))
+        terms = [l1(f, r) for f, r in zip(fake, real)]
+        total = torch.stack(terms).sum() if len(terms) > 1 else terms[0]
         return {'feature_matching': total / len(fake) * self.fm_weight}

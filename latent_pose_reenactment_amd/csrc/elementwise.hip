@@ -463,7 +463,9 @@ extern "C" int lp_relu_bwd(const float* dA, const float* x, float* dx, long long
 }
 
 // y[n,Y,X,c] = 0.25 * sum_{2x2} act(x[n,2Y+i,2X+j,c]),  act = relu if relu_in else identity.  H, W = OUTPUT dims.
-__global__ void avgpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long total4, int H, int W, int C, int relu_in) {
+// o16 != NULL (C % 8 == 0): also the 16-bit operand planes [N][H][W][C] of y for the conv that follows (fp16 when f16, else bf16)
+__global__ void avgpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long total4, int H, int W, int C, int relu_in,
+                                    uint16_t* __restrict__ o16, int f16) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long stride = (long long)gridDim.x * blockDim.x;
     const int C4 = C >> 2;
@@ -484,6 +486,12 @@ __global__ void avgpool2_fwd_kernel(const float* __restrict__ x, float* __restri
         o.x = 0.25f * ((a0.x + a1.x) + (a2.x + a3.x)); o.y = 0.25f * ((a0.y + a1.y) + (a2.y + a3.y));
         o.z = 0.25f * ((a0.z + a1.z) + (a2.z + a3.z)); o.w = 0.25f * ((a0.w + a1.w) + (a2.w + a3.w));
         ((float4*)y)[i] = o;
+        if (o16) {
+            ushort4 h;
+            if (f16) { h.x = lp_f32_to_op16<true>(o.x); h.y = lp_f32_to_op16<true>(o.y); h.z = lp_f32_to_op16<true>(o.z); h.w = lp_f32_to_op16<true>(o.w); }
+            else { h.x = lp_f32_to_op16<false>(o.x); h.y = lp_f32_to_op16<false>(o.y); h.z = lp_f32_to_op16<false>(o.z); h.w = lp_f32_to_op16<false>(o.w); }
+            ((ushort4*)o16)[i] = h;
+        }
     }
 }
 
@@ -517,12 +525,14 @@ __global__ void avgpool2_bwd_kernel(const float* __restrict__ dy, const float* _
     if (amax) lp_amax_commit(am, amax, blockIdx.x);
 }
 
-extern "C" int lp_avgpool2_fwd(const float* x, float* y, int N, int H, int W, int C, int relu_in, void* stream) {
+extern "C" int lp_avgpool2_fwd(const float* x, float* y, int N, int H, int W, int C, int relu_in, uint16_t* out_hi, int prec, void* stream) {
+    if (out_hi && ((C & 7) || prec == LP_PREC_BF16X3)) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_avgpool2_fwd: planes need C % 8 == 0 and a one-plane precision mode");
     if (!x || !y) return lp_set_error(LP_ERR_ARG, "lp_avgpool2_fwd: null pointer");
     if (C & 3) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_avgpool2_fwd: C must be a multiple of 4");
     long long total4 = (long long)N * H * W * C / 4;
     int blocks = (int)((total4 + 255) / 256); if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(avgpool2_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, total4, H, W, C, relu_in);
+    hipLaunchKernelGGL(avgpool2_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, total4, H, W, C, relu_in, out_hi,
+                       prec == LP_PREC_F16 ? 1 : 0);
     return lp_check_launch("avgpool2_fwd");
 }
 

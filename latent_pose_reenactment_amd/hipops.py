@@ -639,12 +639,18 @@ def relu_bwd(dA: Tensor, x: Tensor) -> Tensor:
     return dx
 
 
-def avgpool2_fwd(x: Tensor, relu_in: bool) -> Tensor:
+def avgpool2_fwd(x: Tensor, relu_in: bool, out16_prec: Optional[int] = None):
+    """AvgPool2d(2) of relu?(x).  ``out16_prec`` (PREC_F16 | PREC_BF16, C % 8 == 0): also the operand planes of y -> (y, Act16)"""
     _chk(x, 'x')
     n, h2, w2, c = x.shape
     y = torch.empty((n, h2 // 2, w2 // 2, c), dtype=torch.float32, device=x.device)
-    check(_lib.lib().lp_avgpool2_fwd(x.data_ptr(), y.data_ptr(), n, h2 // 2, w2 // 2, c, int(relu_in), _stream()), 'lp_avgpool2_fwd')
-    return y
+    fused = out16_prec is not None and out16_prec != PREC_BF16X3 and c % 8 == 0
+    o_hi = torch.empty((n, h2 // 2, w2 // 2, c), dtype=torch.int16, device=x.device) if fused else None
+    check(_lib.lib().lp_avgpool2_fwd(x.data_ptr(), y.data_ptr(), n, h2 // 2, w2 // 2, c, int(relu_in), _p(o_hi),
+                                     out16_prec if fused else 0, _stream()), 'lp_avgpool2_fwd')
+    if out16_prec is None:
+        return y
+    return y, (Act16(o_hi, None, c, None) if fused else act_pack(y, pro=0, prec=out16_prec))
 
 
 def avgpool2_bwd(dy: Tensor, x: Tensor, relu_in: bool, amax: bool = False) -> Tensor:

@@ -795,15 +795,20 @@ class AvgPool2Fn(torch.autograd.Function):
     """AvgPool2d(2) of relu?(x), NHWC (blocks.py:89-90 / perceptual_loss.py:77 with the preceding ReLU fused)."""
 
     @staticmethod
-    def forward(ctx, x, relu_in):
+    def forward(ctx, x, relu_in, emit=None):
+        """``emit`` = (prec, holder list): the pool launch also writes the operand planes of y for the conv that follows"""
         ctx.save_for_backward(x)
         ctx.relu_in = relu_in
-        return ops.avgpool2_fwd(x, relu_in)
+        if emit is None:
+            return ops.avgpool2_fwd(x, relu_in)
+        y, o16 = ops.avgpool2_fwd(x, relu_in, out16_prec=emit[0])
+        emit[1].append(o16)
+        return y
 
     @staticmethod
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
-        return ops.avgpool2_bwd(dy.contiguous(), x, ctx.relu_in, amax=default_prec() == PREC_F16), None
+        return ops.avgpool2_bwd(dy.contiguous(), x, ctx.relu_in, amax=default_prec() == PREC_F16), None, None
 
 
 class L1Fn(torch.autograd.Function):
