@@ -90,13 +90,14 @@ long long lp_conv16_fwd_workspace_bytes(int N, int H, int W, int Cout, int ksize
  * w.r.t. weight, blocks.py:76-88) on operand planes: a = the planes the forward conv consumed, dy = lp_act_pack of the output
  * gradient.  Two launches: partial slabs over `splits` pixel ranges, then a reduction that also writes the reference
  * [Cout][Cin][k][k] layout.  workspace: lp_conv_wgrad_workspace_bytes().
- * dbias [Cout]|NULL: also emit out_scale * sum_{n,y,x} dy[n,y,x,co] (the kernel streams dy anyway).  out_scale: device scalar|NULL.
+ * dbias [Cout]|NULL: also emit out_scale * sum_{n,y,x} dy[n,y,x,co] (the kernel streams dy anyway); dbias_accumulate: ADD it to dbias
+ * (the parameter's .grad) instead of storing.  out_scale: device scalar|NULL.
  * sn_w_orig [Cout][Cin][k][k] + sn_dot [lp_conv_wgrad_dot_blocks()] (both or neither): spectrally normalised layer -- the reduction
  * also leaves per-block partial sums of <dw, W_orig> in sn_dot, which lp_sn_grad_apply(ndot = that count) consumes. */
 long long lp_conv_wgrad_workspace_bytes(int Cin, int Cout, int ksize, int splits);
 int lp_conv16_wgrad(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* dy_hi, const uint16_t* dy_lo, float* dw,
                     float* workspace, int N, int H, int W, int Cin, int Cout, int ksize, int upsample, int splits, int prec,
-                    float* dbias, const float* out_scale, const float* sn_w_orig, float* sn_dot, void* stream);
+                    float* dbias, int dbias_accumulate, const float* out_scale, const float* sn_w_orig, float* sn_dot, void* stream);
 int lp_conv_wgrad_dot_blocks(int Cin, int Cout, int ksize);
 
 /* Thin-channel convs (<= 4 channels on one side: RGB -> 64 first convs of the critics / VGG stacks, the generator head's weight

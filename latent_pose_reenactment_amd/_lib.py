@@ -33,7 +33,7 @@ SIGNATURES = {
     'lp_conv16_fwd': (_i, [_vp] * 9 + [_i] * 11 + [_vp, _vp, _vp, _i, _vp, _ll, _vp, _vp]),
     'lp_conv16_fwd_workspace_bytes': (_ll, [_i] * 5),
     'lp_conv_wgrad_workspace_bytes': (_ll, [_i, _i, _i, _i]),
-    'lp_conv16_wgrad': (_i, [_vp] * 6 + [_i] * 9 + [_vp, _vp, _vp, _vp, _vp]),
+    'lp_conv16_wgrad': (_i, [_vp] * 6 + [_i] * 9 + [_vp, _i, _vp, _vp, _vp, _vp]),
     'lp_conv_wgrad_dot_blocks': (_i, [_i] * 3),
     'lp_thin_conv_supported': (_i, [_i] * 4),
     'lp_thin_conv_fwd': (_i, [_vp] * 6 + [_i] * 9 + [_vp, _i, _vp]),

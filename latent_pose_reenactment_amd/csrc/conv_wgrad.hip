@@ -20,6 +20,7 @@ struct WgradParams {
     int N, H, W, Hin, Win, Cin, Cout, C8, Co8, CoP, CiP;
     int splits, num_tiles;
     int lTH, lTW, lNB, tiles_x, tiles_y;
+    int db_acc;            // add the bias gradient to dbias instead of storing it
 };
 
 // zero-masked 16-byte load of 8 consecutive 16-bit channels
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(COB * 4) void conv_wgrad_kernel(WgradParams p) {
 // trailing blocks of both reductions: dbias[co] = sum_s bpart[s][co], 64 channels per block, the splits dealt to 4 thread groups x 4
 // independent accumulators
 __device__ __forceinline__ void wred_bias_block(const float* __restrict__ bpart, float* __restrict__ dbias, int S, int Cout, int CoP, int blk,
-                                                float osc) {
+                                                float osc, int accumulate) {
     __shared__ float red[4][64];
     const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int co = blk * 64 + c;
@@ -319,7 +320,10 @@ __device__ __forceinline__ void wred_bias_block(const float* __restrict__ bpart,
     }
     red[g][c] = (a0 + a1) + (a2 + a3);
     __syncthreads();
-    if (g == 0 && co < Cout) dbias[co] = ((red[0][c] + red[1][c]) + (red[2][c] + red[3][c])) * osc;
+    if (g == 0 && co < Cout) {
+        const float v = ((red[0][c] + red[1][c]) + (red[2][c] + red[3][c])) * osc;
+        dbias[co] = accumulate ? dbias[co] + v : v;          // accumulate: dbias is the parameter's .grad (fused gradient accumulation)
+    }
 }
 
 // dw[co][ci][tap] = sum_s part[s][tap][co][ci].  A block owns one output channel and WRED_CI input channels: the slabs are read with
@@ -332,9 +336,9 @@ __device__ __forceinline__ void wred_bias_block(const float* __restrict__ bpart,
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int S, int T,
                                                            int Cout, int Cin, int CoP, int CiP, const float* __restrict__ bpart,
                                                            float* __restrict__ dbias, int wblocks, const float* __restrict__ out_scale,
-                                                           const float* __restrict__ sn_w, float* __restrict__ sn_dot) {
+                                                           const float* __restrict__ sn_w, float* __restrict__ sn_dot, int db_acc) {
     const float osc = out_scale ? out_scale[0] : 1.f;          // 1 / (input scale of the fp16 dy operand)
-    if ((int)blockIdx.x >= wblocks) { wred_bias_block(bpart, dbias, S, Cout, CoP, blockIdx.x - wblocks, osc); return; }
+    if ((int)blockIdx.x >= wblocks) { wred_bias_block(bpart, dbias, S, Cout, CoP, blockIdx.x - wblocks, osc, db_acc); return; }
     __shared__ float tile[WRED_CI * 9];
     const int cib = (Cin + WRED_CI - 1) / WRED_CI;
     const int co = blockIdx.x / cib, ci0 = (blockIdx.x - co * cib) * WRED_CI;
@@ -376,9 +380,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 __global__ __launch_bounds__(256) void wgrad_reduce_flat_kernel(const float* __restrict__ part, float* __restrict__ dw, int S, int T, int Cout,
                                                                 int Cin, int CoP, int CiP, const float* __restrict__ bpart,
                                                                 float* __restrict__ dbias, int wblocks, const float* __restrict__ out_scale,
-                                                                const float* __restrict__ sn_w, float* __restrict__ sn_dot) {
+                                                                const float* __restrict__ sn_w, float* __restrict__ sn_dot, int db_acc) {
     const float osc = out_scale ? out_scale[0] : 1.f;
-    if ((int)blockIdx.x >= wblocks) { wred_bias_block(bpart, dbias, S, Cout, CoP, blockIdx.x - wblocks, osc); return; }
+    if ((int)blockIdx.x >= wblocks) { wred_bias_block(bpart, dbias, S, Cout, CoP, blockIdx.x - wblocks, osc, db_acc); return; }
     const int idx = blockIdx.x * 256 + threadIdx.x;
     float dsum = 0.f;
     if (idx < T * Cout * Cin) {
@@ -453,11 +457,11 @@ static int launch_wgrad(WgradParams& p, float* dw, float* dbias, const float* ou
     if (wred_tiled(p.Cin, p.Cout)) {
         const int wblocks = wred_blocks(p.Cin, p.Cout, KS * KS);
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wblocks + bblocks), dim3(256), 0, stream, p.part, dw, p.splits, KS * KS,
-                           p.Cout, p.Cin, p.CoP, p.CiP, p.bpart, dbias, wblocks, out_scale, sn_w, sn_dot);
+                           p.Cout, p.Cin, p.CoP, p.CiP, p.bpart, dbias, wblocks, out_scale, sn_w, sn_dot, p.db_acc);
     } else {
         const int wblocks = wred_blocks(p.Cin, p.Cout, KS * KS);
         hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3(wblocks + bblocks), dim3(256), 0, stream, p.part, dw, p.splits, KS * KS, p.Cout, p.Cin,
-                           p.CoP, p.CiP, p.bpart, dbias, wblocks, out_scale, sn_w, sn_dot);
+                           p.CoP, p.CiP, p.bpart, dbias, wblocks, out_scale, sn_w, sn_dot, p.db_acc);
     }
     return lp_check_launch("wgrad_reduce");
 }
@@ -487,7 +491,8 @@ static int dispatch_wgrad(WgradParams& p, float* dw, float* dbias, const float* 
 
 extern "C" int lp_conv16_wgrad(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* dy_hi, const uint16_t* dy_lo, float* dw,
                                float* workspace, int N, int H, int W, int Cin, int Cout, int ksize, int upsample, int splits, int prec,
-                               float* dbias, const float* out_scale, const float* sn_w_orig, float* sn_dot, void* stream) {
+                               float* dbias, int dbias_accumulate, const float* out_scale, const float* sn_w_orig, float* sn_dot,
+                               void* stream) {
     if (!a_hi || !dy_hi || !dw || !workspace) return lp_set_error(LP_ERR_ARG, "lp_conv16_wgrad: null pointer");
     if (!sn_w_orig != !sn_dot) return lp_set_error(LP_ERR_ARG, "lp_conv16_wgrad: sn_w_orig and sn_dot go together");
     if (prec == LP_PREC_BF16X3 && (!a_lo || !dy_lo)) return lp_set_error(LP_ERR_ARG, "lp_conv16_wgrad: bf16x3 needs the lo planes");
@@ -497,7 +502,7 @@ extern "C" int lp_conv16_wgrad(const uint16_t* a_hi, const uint16_t* a_lo, const
     p.a_hi = a_hi; p.a_lo = a_lo; p.d_hi = dy_hi; p.d_lo = dy_lo; p.part = workspace;
     p.N = N; p.H = H; p.W = W; p.Hin = upsample ? H / 2 : H; p.Win = upsample ? W / 2 : W;
     p.Cin = Cin; p.Cout = Cout; p.C8 = (Cin + 7) & ~7; p.Co8 = (Cout + 7) & ~7; p.CoP = round_up(Cout, 64); p.CiP = round_up(Cin, 64);
-    p.splits = splits;
+    p.splits = splits; p.db_acc = dbias_accumulate;
     p.bpart = dbias ? workspace + (size_t)splits * ksize * ksize * p.CoP * p.CiP : nullptr;
     hipStream_t s = (hipStream_t)stream;
     if (prec == LP_PREC_BF16) return dispatch_wgrad<LP_PREC_BF16>(p, dw, dbias, out_scale, sn_w_orig, sn_dot, ksize, upsample, s);

@@ -322,12 +322,13 @@ def default_splits(n, h, w, cin, cout):
 
 
 def conv_wgrad16(a: Act16, dy: Act16, *, ksize: int, upsample: bool = False, prec: int = PREC_BF16, splits: Optional[int] = None,
-                 sn=None, accum: Optional[Tensor] = None, bias_grad: bool = False):
+                 sn=None, accum: Optional[Tensor] = None, bias_grad: bool = False, bias_accum: Optional[Tensor] = None):
     """dw [Cout,Cin,k,k] = sum_pixels dy (x) up2?(a) (shifted by tap) on operand planes (a = what the forward conv consumed).
     ``sn`` = (w_orig, u, v, sig): the layer is spectrally normalised (forward used alpha = 1/sigma in the conv epilogue); the
     returned gradient is then w.r.t. W_orig: dw/sigma - <dw, W_orig>/sigma^2 u v^T.
     ``accum`` (with ``sn``): add that gradient to this tensor (the parameter's .grad) instead and return None.
-    ``bias_grad``: return ``(dw, db)`` with db [Cout] = sum_pixels dy, produced by the same launch (the kernel streams dy anyway)."""
+    ``bias_grad``: return ``(dw, db)`` with db [Cout] = sum_pixels dy, produced by the same launch (the kernel streams dy anyway);
+    ``bias_accum`` (the bias parameter's .grad): the launch adds db to it instead and db is returned as None."""
     n, h, w = dy.nhw
     cout, cin = dy.c, a.c
     assert a.nhw == ((n, h // 2, w // 2) if upsample else (n, h, w)), (a.hi.shape, dy.hi.shape, upsample)
@@ -336,7 +337,13 @@ def conv_wgrad16(a: Act16, dy: Act16, *, ksize: int, upsample: bool = False, pre
         splits = default_splits(n, h, w, cin, cout)
     ws = torch.empty(_lib.lib().lp_conv_wgrad_workspace_bytes(cin, cout, ksize, splits) // 4, dtype=torch.float32, device=dev)
     dw = torch.empty((cout, cin, ksize, ksize), dtype=torch.float32, device=dev)
-    db = torch.empty(cout, dtype=torch.float32, device=dev) if bias_grad else None
+    db = None
+    if bias_grad:
+        if bias_accum is not None:
+            assert bias_accum.is_contiguous() and bias_accum.dtype == torch.float32 and bias_accum.numel() == cout
+            db = bias_accum
+        else:
+            db = torch.empty(cout, dtype=torch.float32, device=dev)
     dot, ndot = None, 0
     if sn is not None:          # the reduction launch also takes <dw, W_orig> (per-block partials) for lp_sn_grad_apply
         _chk(sn[0], 'w_orig')
@@ -344,10 +351,10 @@ def conv_wgrad16(a: Act16, dy: Act16, *, ksize: int, upsample: bool = False, pre
         dot = torch.empty(ndot, dtype=torch.float32, device=dev)
     with _Timed('conv_wgrad', 2.0 * n * h * w * cout * cin * ksize * ksize, (n, h, w, cin, cout, ksize, int(upsample), 0)):
         check(_lib.lib().lp_conv16_wgrad(a.hi.data_ptr(), _p(a.lo), dy.hi.data_ptr(), _p(dy.lo), dw.data_ptr(), ws.data_ptr(), n, h, w, cin,
-                                         cout, ksize, int(upsample), splits, prec, _p(db), _p(dy.inv),
+                                         cout, ksize, int(upsample), splits, prec, _p(db), int(bias_grad and bias_accum is not None), _p(dy.inv),
                                          None if sn is None else sn[0].data_ptr(), _p(dot), _stream()), 'lp_conv16_wgrad')
     dw = _sn_finish(dw, sn, accum, dot, ndot)
-    return (dw, db) if bias_grad else dw
+    return (dw, None if bias_accum is not None else db) if bias_grad else dw
 
 
 def _sn_finish(dw, sn, accum, dot=None, ndot=0):

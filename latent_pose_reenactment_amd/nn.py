@@ -475,7 +475,8 @@ class _DecoderFunction(torch.autograd.Function):
                 else:
                     ds16 = d16
                 grads[wi + 2], grads[wi + 3] = ops.conv_wgrad16(xs, ds16, ksize=1, prec=prec, sn=snw(wi + 2),
-                                                                accum=_accum_target(params[wi + 2]), bias_grad=True)
+                                                                accum=_accum_target(params[wi + 2]), bias_grad=True,
+                                                                bias_accum=_accum_target(params[wi + 3]))
                 dx_skip = ops.conv16(ds16, tpack(wi + 2), ksize=1, alpha=sn[wi + 2][2][1:], prec=prec)
             else:
                 dx_skip = d_out
@@ -731,6 +732,7 @@ class ConvFn(torch.autograd.Function):
         ctx.a16 = a16 if ((need_w and not thin_w) or pro == 2) else None
         ctx.wd = wd
         ctx.w_param = w if (sn is not None and w.requires_grad and w.is_leaf) else None
+        ctx.b_param = bias if (bias is not None and bias.requires_grad and bias.is_leaf) else None
         ctx.cfg = (ksize, pro, prec, packs, bias is not None, res is not None, sn)
         return y
 
@@ -768,8 +770,9 @@ class ConvFn(torch.autograd.Function):
                       accum=None if ctx.w_param is None else _accum_target(ctx.w_param), bias_grad=want_db)
             if x is not None:
                 dw = ops.thin_wgrad(x, dy, pro=pro, **kw)
-            else:
-                dw = ops.conv_wgrad16(a16, dy16(), prec=prec, **kw)
+            else:      # (fused accumulation: the reduce launch adds the bias gradient straight into the bias parameter's .grad)
+                dw = ops.conv_wgrad16(a16, dy16(), prec=prec, bias_accum=_accum_target(ctx.b_param) if (want_db and ctx.b_param is not None) else None,
+                                      **kw)
             if want_db:
                 dw, db = dw
         elif want_db:
