@@ -21,7 +21,8 @@
 // Ping-pong (PP): the workgroup has two 4-wave groups on adjacent M tiles sharing the weight stages; each stage slot has two
 // phases separated by workgroup barriers: group 0 multiplies while group 1 issues its share of the DMA, then they swap, so
 // every SIMD always has one wave in its MFMA phase while the other wave's DMA issue (~60-100 cycles per 1 KiB piece) runs
-// beside it.  Small feature maps: split-K over gridDim.z (fp32 atomics onto a zeroed y) and 8-wave groups.
+// beside it.  Small feature maps: split-K over gridDim.z (partial tiles into a caller workspace, finished by splitk_reduce_kernel)
+// and 8-wave groups.
 //
 // Precision modes (MFMA 16x16x32, fp32 accumulate): bf16 | f16 operands, 1 MFMA per k-step; bf16x3 = hi+lo split, 3 MFMAs.
 #include "lp_common.h"
