@@ -267,7 +267,7 @@ def drive_fps(args, frames=60):
         dt = time.perf_counter() - t0
     return {'value': round(frames / dt, 2), 'unit': 'frames/s', 'ms_per_frame': round(dt / frames * 1e3, 3), 'batch': 1,
             'launch_mode': mode, 'note': 'drive.py:84-88 loop (MobileNetV2 pose encoder + generator on the HIP kernels, eval mode, '
-                                          'bf16 weight packs cached), frames resident in HBM'}
+                                          '16-bit weight packs cached), frames resident in HBM'}
 
 
 def main():
