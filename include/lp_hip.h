@@ -50,7 +50,8 @@ int lp_pack_pair_desc_bytes(void);
 int lp_pack_weights_pairs(const void* table, int num_entries, long long total_tiles, void* stream);
 
 /* Operand planes of a conv input: hi (, lo) [N*HW][C8] 16-bit, C8 = C rounded up to 8 (pad channels zero), holding
- *   act(x) * in_scale,  act: pro 0 identity | 1 relu(x*scale[n,c]+shift[n,c]) | 2 relu(x) | 3 relu6(x*scale[c]+shift[c])
+ *   act(x) * in_scale,  act: pro 0 identity | 1 relu(x*scale[n,c]+shift[n,c]) | 2 relu(x) | 3 relu6(x*scale[c]+shift[c]) |
+ *                            4 relu(x*scale[c]+shift[c]) | 5 x*scale[c]+shift[c]   (3..5: BatchNorm folded to a per-channel affine)
  * in the operand format of `prec` (bf16 | bf16 hi+lo | fp16, saturating).  Replaces, once per tensor, the instance_norm + mul +
  * add + relu chain of AdaptiveNorm2d/ReLU (generators/common/blocks.py:18-26,70-73) that the reference runs before every conv;
  * the planes feed lp_conv16_fwd (forward / dgrad) and lp_conv16_wgrad.  in_scale: device scalar|NULL.
@@ -188,6 +189,60 @@ int lp_adain_relu_bwd(const float* dA, const float* x, const float* add, const f
                       const float* mean, const float* rstd, const float* scale, const float* shift,
                       float* dx, float* dgamma, float* dbeta, float* workspace,
                       int N, int H, int W, int C, int upsample, float* amax_slots, void* stream);
+
+/* Generalisation used by the embedder's BatchNorm layers (a train-mode BatchNorm over [P][C] is this with N = 1, H*W = P, ab_stride = C):
+ *   mask_mode 0: g = dA * [0 < x*scale+shift < act_hi]  (ReLU: act_hi <= 0 or huge; ReLU6: 6);  1: g = dA (no activation);
+ *             2: g = dA * [mask_src > 0]  (the ReLU sits behind a residual add; mask_src [N][H][W][C] = the block output)
+ *   g_copy [N][H][W][C]|NULL: also receives g (the identity branch's gradient);  frozen_stats = 1: mean/rstd are constants
+ *   (eval-mode BatchNorm on running statistics): dx = gamma*rstd*g. */
+int lp_norm_act_bwd(const float* dA, const float* x, const float* add, const float* gamma, int ab_stride,
+                    const float* mean, const float* rstd, const float* scale, const float* shift,
+                    float* dx, float* dgamma, float* dbeta, float* workspace,
+                    int N, int H, int W, int C, int upsample, int mask_mode, const float* mask_src, float* g_copy, float act_hi,
+                    int frozen_stats, float* amax_slots, void* stream);
+
+/* Train-mode nn.BatchNorm2d statistics of y [P][C] (torchvision resnext50_32x4d / mobilenet_v2 layers of
+ * embedders/unsupervised_pose_separate_embResNeXt_segmentation.py:26-28): mean, rstd = 1/sqrt(biased var + eps), scale = gamma*rstd,
+ * shift = beta - mean*scale, all [C]; running_mean/running_var|NULL updated with `momentum` (unbiased variance).
+ * workspace: lp_bn_train_stats_workspace_bytes(P, C). */
+long long lp_bn_train_stats_workspace_bytes(long long P, int C);
+int lp_bn_train_stats(const float* y, const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                      float* running_var, float* mean, float* rstd, float* scale, float* shift, float* workspace,
+                      long long P, int C, void* stream);
+
+/* ---- ResNeXt-50 32x4d identity encoder (embedders/unsupervised_pose_separate_embResNeXt_segmentation.py:26,37-54) ----
+ * The contractions reuse lp_conv16_fwd / lp_conv16_wgrad (1x1 convs on flattened pixels, the 7x7/2 stem on its im2col rows, the
+ * classifier); the entries below are the grouped 3x3 conv and the bandwidth-bound layers around the contractions.
+ *   lp_gconv16_fwd:   3x3, pad 1, stride 1 conv with C/group_size groups as a block-diagonal conv over aligned 64-channel blocks
+ *                     (group_size | 64); a [N][H][W][C] operand planes, weights from lp_pack_grouped ([9][CP][64]), y fp32; with the
+ *                     mode-1 pack and a = dY: the data gradient.  alpha2 as lp_conv16_fwd (1/scale of an fp16 gradient operand).
+ *   lp_gconv16_wgrad: dw [C][group_size][3][3]; workspace lp_gconv_wgrad_workspace_bytes(C, splits)
+ *   lp_pack_grouped:  w [C][group_size][3][3] -> hi(, lo) [9][CP][64]; mode 0 forward, 1 data gradient (flipped, transposed)
+ *   lp_im2col_planes: x [N][C][H][W] fp32 NCHW -> operand rows [N*Ho*Wo][K8], K = C*k*k in nn.Conv2d weight order (zero padding)
+ *   lp_bn_relu_maxpool_fwd: out [N][Ho][Wo][C] = MaxPool2d(3,2,1)(relu(y*scale[c]+shift[c])), hi/lo|NULL its operand planes,
+ *                     idx|NULL [N][Ho][Wo][C] bytes = window position of the maximum;  lp_maxpool_bwd: dA [N][H][W][C] from d_out + idx
+ *   lp_bn_add_act:    out = (relu?)(y*scale[c]+shift[c] + (res | res*res_scale[c]+res_shift[c] | 0)) over [P][C], + operand planes
+ *   lp_subsample2 / lp_zero_stuff2: out[n,i,j] = in[n,2i,2j] / its adjoint on [N][H][W][row_bytes] tensors (H, W = FULL-resolution dims;
+ *                     fp32 NHWC or operand planes: row_bytes % 16 == 0);  lp_add_strided2: d[n,2i,2j,:] += s[n,i,j,:] (fp32)
+ *   lp_spatial_mean_fwd/bwd: AdaptiveAvgPool2d(1) */
+int lp_gconv16_fwd(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* w_hi, const uint16_t* w_lo, float* y, const float* alpha2,
+                   int N, int H, int W, int C, int CP, int prec, float* amax_slots, void* stream);
+long long lp_gconv_wgrad_workspace_bytes(int C, int splits);
+int lp_gconv16_wgrad(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* dy_hi, const uint16_t* dy_lo, float* dw, float* workspace,
+                     int N, int H, int W, int C, int group_size, int splits, int prec, const float* out_scale, void* stream);
+int lp_pack_grouped(const float* w, uint16_t* hi, uint16_t* lo, int C, int group_size, int CP, int mode, int f16, void* stream);
+int lp_im2col_planes(const float* x, uint16_t* hi, uint16_t* lo, int N, int C, int H, int W, int ksize, int stride, int pad, int prec,
+                     void* stream);
+int lp_bn_relu_maxpool_fwd(const float* y, const float* scale, const float* shift, float* out, uint16_t* hi, uint16_t* lo,
+                           unsigned char* idx, int N, int H, int W, int C, int prec, void* stream);
+int lp_maxpool_bwd(const float* dout, const unsigned char* idx, float* dA, int N, int H, int W, int C, void* stream);
+int lp_bn_add_act(const float* y, const float* scale, const float* shift, const float* res, const float* res_scale, const float* res_shift,
+                  float* out, uint16_t* hi, uint16_t* lo, long long P, int C, int relu, int prec, void* stream);
+int lp_subsample2(const void* in, void* out, int N, int H, int W, int row_bytes, void* stream);
+int lp_zero_stuff2(const void* in, void* out, int N, int H, int W, int row_bytes, void* stream);
+int lp_add_strided2(float* d, const float* s, int N, int H, int W, int C, void* stream);
+int lp_spatial_mean_fwd(const float* x, float* out, int N, int HW, int C, void* stream);
+int lp_spatial_mean_bwd(const float* g, float* dx, int N, int HW, int C, void* stream);
 
 /* out[n,y,x,c] = sum of the 2x2 block of in[n,2y..2y+1,2x..2x+1,c]  (adjoint of nearest x2 upsampling, blocks.py:95). */
 int lp_sum2x2(const float* in, float* out, int N, int H, int W, int C, float* amax_slots, void* stream);

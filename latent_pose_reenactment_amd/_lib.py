@@ -61,6 +61,22 @@ SIGNATURES = {
     'lp_instnorm_stats': (_i, [_vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'lp_adain_bwd_workspace_bytes': (_ll, [_i, _i, _i]),
     'lp_adain_relu_bwd': (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    'lp_norm_act_bwd': (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp]),
+    'lp_bn_train_stats_workspace_bytes': (_ll, [_ll, _i]),
+    'lp_bn_train_stats': (_i, [_vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _vp]),
+    'lp_gconv16_fwd': (_i, [_vp] * 6 + [_i] * 6 + [_vp, _vp]),
+    'lp_gconv_wgrad_workspace_bytes': (_ll, [_i, _i]),
+    'lp_gconv16_wgrad': (_i, [_vp] * 6 + [_i] * 7 + [_vp, _vp]),
+    'lp_pack_grouped': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'lp_im2col_planes': (_i, [_vp, _vp, _vp] + [_i] * 8 + [_vp]),
+    'lp_bn_relu_maxpool_fwd': (_i, [_vp] * 7 + [_i] * 5 + [_vp]),
+    'lp_maxpool_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'lp_bn_add_act': (_i, [_vp] * 9 + [_ll, _i, _i, _i, _vp]),
+    'lp_subsample2': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    'lp_zero_stuff2': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    'lp_add_strided2': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    'lp_spatial_mean_fwd': (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    'lp_spatial_mean_bwd': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'lp_sum2x2': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'lp_head_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'lp_head_bwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),

@@ -1,6 +1,7 @@
 // Operand packing for conv_dma.hip / conv_wgrad.hip (gfx950): the activated input of a conv is written ONCE as 16-bit planes
 //   hi[p][c] (, lo[p][c])  =  split( act( x[p][c] ) * in_scale ),   [N*HW][C8] with C8 = C rounded up to 8 (pad channels = 0)
-// act = identity | relu(x*scale[n,c]+shift[n,c]) (AdaIN + ReLU, generators/common/blocks.py:18-26,70-73) | relu(x).
+// act = identity | relu(x*scale[n,c]+shift[n,c]) (AdaIN + ReLU, generators/common/blocks.py:18-26,70-73) | relu(x) | relu6 / relu /
+// identity of a per-channel BatchNorm affine x*scale[c]+shift[c] (the embedder's conv -> BatchNorm -> ReLU chains).
 // Bandwidth-bound: 4 B read, 2 B (bf16 / f16) or 4 B (bf16x3: hi + lo) written per element; every thread converts 8 channels of
 // one pixel (two 16-B loads, one 16-B store per plane).  fp16 gradients are scaled by a power of two taken from the tensor's
 // amax (lp_amax_scale) so that they sit in the fp16 normal range; the consumer multiplies its result by 1/in_scale.
@@ -53,9 +54,9 @@ __global__ __launch_bounds__(256) void act_pack_kernel(const float* __restrict__
     const unsigned stride = gridDim.x * 256u;
     const int n = blockIdx.y;
     const bool vec = (C & 3) == 0;
-    const float lo_clamp = (pro != 0) ? 0.f : -3.0e38f;
-    const float hi_clamp = (pro == 3) ? 6.f : 3.0e38f;          // pro 3 = ReLU6 of a per-channel (batch-norm) affine
-    const bool aff = (pro == 1 || pro == 3);
+    const float lo_clamp = (pro != 0 && pro != 5) ? 0.f : -3.0e38f;
+    const float hi_clamp = (pro == 3) ? 6.f : 3.0e38f;          // pro 3 = ReLU6, 4 = ReLU, 5 = identity of a per-channel (batch-norm) affine
+    const bool aff = (pro == 1 || pro >= 3);
     const size_t aoff = (pro == 1) ? (size_t)n * C : 0;
     const float* xn = x + (size_t)n * HW * C;
     uint16_t* hn = hi + (size_t)n * HW * C8;
@@ -116,7 +117,8 @@ extern "C" int lp_act_pack(const float* x, const float* scale, const float* shif
                            int N, int HW, int C, int prec, const float* in_scale, const float* amax_part, int amax_count,
                            int amax_stride, float* scale_out, void* stream) {
     if (!x || !hi) return lp_set_error(LP_ERR_ARG, "lp_act_pack: null pointer");
-    if ((pro == 1 || pro == 3) && (!scale || !shift)) return lp_set_error(LP_ERR_ARG, "lp_act_pack: pro=1|3 needs scale/shift");
+    if (pro < 0 || pro > 5) return lp_set_error(LP_ERR_ARG, "lp_act_pack: pro must be 0..5");
+    if ((pro == 1 || pro >= 3) && (!scale || !shift)) return lp_set_error(LP_ERR_ARG, "lp_act_pack: pro=1|3|4|5 needs scale/shift");
     if (prec == LP_PREC_BF16X3 && !lo) return lp_set_error(LP_ERR_ARG, "lp_act_pack: bf16x3 needs the lo plane");
     if (amax_part && (amax_count < 1 || amax_stride < 1)) return lp_set_error(LP_ERR_ARG, "lp_act_pack: amax_count / amax_stride must be >= 1 with amax_part");
     const int C8 = (C + 7) & ~7;

@@ -47,6 +47,8 @@ struct Conv16Params {
     int hit;                      // halo DMA instructions per wave and chunk
     int a_dbuf;                   // single-group schedule: halo double buffered (1) or one buffer + an extra barrier per chunk (0)
     int ksplit;
+    int grouped;                  // block-diagonal (grouped) conv: the workgroup's 64 output channels only see input channels co0 .. co0+63;
+                                  // the weight image then has 64 columns (CinP = 64) and the activation channel offset is co0
 };
 
 template <int KS, bool UPS, int WM, int WN, int MR, int NR, int PREC, bool PP, int NBUF = 2, int CC = 32>
@@ -138,7 +140,7 @@ void conv_dma_kernel(Conv16Params p) {
     }
     const uint16_t* zero16 = (const uint16_t*)lp_zero_page;
     auto issue_a = [&](int chunk, unsigned char* Hbuf) {
-        const int c0 = chunk * CC;
+        const int c0 = chunk * CC + (p.grouped ? co0 : 0);
         const bool cok = (c0 + a_g8) < p.C8;
         const unsigned dst = (unsigned)(uintptr_t)Hbuf;
 #pragma unroll
@@ -315,7 +317,7 @@ void conv_dma_kernel(Conv16Params p) {
             int nb, py, px;
             tile_row_linear(m, p.lTH, p.lTW, nb, py, px);
             const int n = n0 + nb, oyy = y0 + py, oxx = x0 + px;
-            if (n < p.N && oyy < p.H && oxx < p.W && co < p.Cout) {
+            if (nb < NBv && n < p.N && oyy < p.H && oxx < p.W && co < p.Cout) {
                 float4 v = *(const float4*)(tile + row * LDW + c4 * 4);
                 if (p.ksplit > 1) {        // split-K: the raw partial tile; splitk_reduce_kernel sums the slices and applies the epilogue
                     const size_t pixs = (size_t)(n * p.H + oyy) * p.W + oxx;
@@ -363,7 +365,7 @@ void conv_dma_kernel(Conv16Params p) {
             int nb, py, px;
             tile_row_linear(m, p.lTH, p.lTW, nb, py, px);
             const int n = n0 + nb, oyy = y0 + py, oxx = x0 + px;
-            if (n >= p.N || oyy >= p.H || oxx >= p.W) continue;
+            if (nb >= NBv || n >= p.N || oyy >= p.H || oxx >= p.W) continue;
             const size_t pixi = (size_t)(n * p.H + oyy) * p.W + oxx;
             const size_t pix = pixi * p.Cout;
             size_t rpix = 0;
@@ -522,6 +524,10 @@ static int launch_conv16(Conv16Params& p, hipStream_t stream) {
         if (KS == 3 && (p.Cout & 3) == 0 && p.part)
             while (ks < max_split && wgs * ks * 2 <= split_wgs && nch / (ks * 2) >= 2 &&
                    (long long)(ks * 2) * p.N * p.H * p.W * p.Cout * (long long)sizeof(float) <= p.part_bytes) ks *= 2;
+        // every slice must own at least one chunk: the kernel gives slice z the chunks [z*per, (z+1)*per) with per = ceil(nch/ks), and
+        // splitk_reduce_kernel sums ALL ks slices of the (uninitialised) workspace -- e.g. 18 chunks (Cin 576) over 8 slices would
+        // leave slices 6 and 7 unwritten.  Shrink ks to the fixed point of ks = ceil(nch / ceil(nch / ks)).
+        for (;;) { const int per = (nch + ks - 1) / ks, k2 = (nch + per - 1) / per; if (k2 == ks) break; ks = k2; }
         p.ksplit = ks;
         grid.z = ks;
     }
@@ -597,6 +603,7 @@ extern "C" int lp_conv16_fwd(const uint16_t* a_hi, const uint16_t* a_lo, const u
     p.o_hi = (Cout & 7) ? nullptr : out_hi; p.o_lo = (Cout & 7) ? nullptr : out_lo;   // (pad channels: the pack pass writes them)
     p.N = N; p.H = H; p.W = W; p.Hin = upsample ? H / 2 : H; p.Win = upsample ? W / 2 : W;
     p.Cin = Cin; p.C8 = (Cin + 7) & ~7; p.Cout = Cout; p.Co8 = (Cout + 7) & ~7; p.CinP = CinP; p.CoutP = CoutP; p.res_shift = res_shift;
+    p.grouped = 0;
     hipStream_t s = (hipStream_t)stream;
     int rc;
     if (prec == LP_PREC_BF16) rc = dispatch_conv16<LP_PREC_BF16>(p, ksize, upsample, s);
@@ -618,4 +625,29 @@ extern "C" int lp_conv16_fwd(const uint16_t* a_hi, const uint16_t* a_lo, const u
     if (out_hi && !p.o_hi)
         return lp_act_pack(y, nullptr, nullptr, out_relu ? 2 : 0, out_hi, out_lo, N, H * W, Cout, prec, nullptr, nullptr, 0, 1, nullptr, stream);
     return LP_OK;
+}
+
+// Grouped 3x3 conv (ResNeXt conv2, embedders/unsupervised_pose_separate_embResNeXt_segmentation.py:26 = torchvision resnext50_32x4d:
+// 32 groups of 4 / 8 / 16 / 32 channels) as a BLOCK-DIAGONAL dense conv: every group lies inside one aligned 64-channel block, so the
+// workgroup that owns output channels [co0, co0 + 64) contracts over input channels [co0, co0 + 64) only -- two 32-channel chunks of the
+// same LDS-DMA / MFMA pipeline, with a weight image [9][CP][64] whose off-group entries are zero (lp_pack_grouped).  The matrix pipe
+// does 64 / group-size times the algorithmic work, which is irrelevant: the layer is bound by its activation traffic (2 B read +
+// 4 B written per element).  Stride 2 and the data gradient of stride 2 are expressed by the caller (full-resolution conv +
+// lp_subsample2 / lp_zero_stuff2_16).  With the mode-1 pack and a = dY this is the data-gradient kernel.
+extern "C" int lp_gconv16_fwd(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* w_hi, const uint16_t* w_lo, float* y,
+                              const float* alpha2, int N, int H, int W, int C, int CP, int prec, float* amax_slots, void* stream) {
+    if (!a_hi || !w_hi || !y) return lp_set_error(LP_ERR_ARG, "lp_gconv16_fwd: null pointer");
+    if (prec == LP_PREC_BF16X3 && (!w_lo || !a_lo)) return lp_set_error(LP_ERR_ARG, "lp_gconv16_fwd: bf16x3 needs the lo planes");
+    if ((C & 63) || CP % 128 || CP < C) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_gconv16_fwd: C must be a multiple of 64, CP of 128");
+    if (H < 2 || W < 2) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_gconv16_fwd: H,W must be >= 2");
+    Conv16Params p;
+    p.a_hi = a_hi; p.a_lo = a_lo; p.w_hi = w_hi; p.w_lo = w_lo; p.y = y; p.bias = nullptr; p.res = nullptr; p.alpha = nullptr; p.alpha2 = alpha2;
+    p.mask16 = nullptr; p.o_relu = 0; p.part = nullptr; p.part_bytes = 0; p.amax = amax_slots; p.o_hi = nullptr; p.o_lo = nullptr;
+    p.N = N; p.H = H; p.W = W; p.Hin = H; p.Win = W;
+    p.Cin = C; p.C8 = C; p.Cout = C; p.Co8 = C; p.CinP = 64; p.CoutP = CP; p.res_shift = 0; p.grouped = 1;
+    hipStream_t s = (hipStream_t)stream;
+    if (prec == LP_PREC_BF16) return launch_conv16<3, false, 4, 1, 4, 4, LP_PREC_BF16>(p, s);
+    if (prec == LP_PREC_BF16X3) return launch_conv16<3, false, 4, 1, 4, 4, LP_PREC_BF16X3>(p, s);
+    if (prec == LP_PREC_F16) return launch_conv16<3, false, 4, 1, 4, 4, LP_PREC_F16>(p, s);
+    return lp_set_error(LP_ERR_ARG, "lp_gconv16_fwd: unknown precision mode");
 }

@@ -21,6 +21,8 @@ struct WgradParams {
     int splits, num_tiles;
     int lTH, lTW, lNB, tiles_x, tiles_y;
     int db_acc;            // add the bias gradient to dbias instead of storing it
+    int diag;              // block-diagonal (grouped conv): the workgroup of output channels [co0, co0+64) only pairs with input channels
+                           // [co0, co0+64); slab layout [split][tap][CoP][64] (column = ci - co0)
 };
 
 // zero-masked 16-byte load of 8 consecutive 16-bit channels
@@ -52,7 +54,7 @@ __global__ __launch_bounds__(COB * 4) void conv_wgrad_kernel(WgradParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int mh = wave >> 1, nh = wave & 1;       // wave -> 32(co) x 32(ci) sub-block
     const int TH = 1 << p.lTH, TW = 1 << p.lTW, NBv = 1 << p.lNB;
-    const int co0 = blockIdx.y * COB, ci0 = blockIdx.z * 64;
+    const int co0 = blockIdx.y * COB, ci0 = p.diag ? co0 : blockIdx.z * 64;
 
     int HH, HW;
     if (KS == 1) { HH = TH; HW = TW; } else if (UPS) { HH = (TH >> 1) + 2; HW = (TW >> 1) + 2; } else { HH = TH + 2; HW = TW + 2; }
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(COB * 4) void conv_wgrad_kernel(WgradParams p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     int co = co0 + mh * 32 + mf * 16 + (lane >> 4) * 4 + r;
-                    int ci = ci0 + nh * 32 + nf * 16 + (lane & 15);
+                    int ci = (p.diag ? 0 : ci0) + nh * 32 + nf * 16 + (lane & 15);
                     if (COB == 64 || co < p.CoP) p.part[(((size_t)blockIdx.x * T + tap) * p.CoP + co) * p.CiP + ci] = acc[tap][mf][nf][r];
                 }
 }
@@ -447,10 +449,11 @@ static int launch_wgrad(WgradParams& p, float* dw, float* dbias, const float* ou
             return lp_set_error(LP_ERR_HIP, "hipFuncSetAttribute failed");
         attr_dev = dev;
     }
-    dim3 grid(p.splits, (p.CoP + COB - 1) / COB, p.CiP / 64);
+    dim3 grid(p.splits, (p.CoP + COB - 1) / COB, p.diag ? 1 : p.CiP / 64);
     hipLaunchKernelGGL(kern, grid, dim3(COB * 4), lds, stream, p);
     int rc = lp_check_launch("conv_wgrad");
     if (rc) return rc;
+    if (p.diag) return LP_OK;                              // the grouped reduction is launched by lp_gconv16_wgrad
     int total = KS * KS * p.Cout * p.Cin;
     (void)total;
     const int bblocks = p.bpart ? (p.Cout + 63) / 64 : 0;
@@ -502,11 +505,57 @@ extern "C" int lp_conv16_wgrad(const uint16_t* a_hi, const uint16_t* a_lo, const
     p.a_hi = a_hi; p.a_lo = a_lo; p.d_hi = dy_hi; p.d_lo = dy_lo; p.part = workspace;
     p.N = N; p.H = H; p.W = W; p.Hin = upsample ? H / 2 : H; p.Win = upsample ? W / 2 : W;
     p.Cin = Cin; p.Cout = Cout; p.C8 = (Cin + 7) & ~7; p.Co8 = (Cout + 7) & ~7; p.CoP = round_up(Cout, 64); p.CiP = round_up(Cin, 64);
-    p.splits = splits; p.db_acc = dbias_accumulate;
+    p.splits = splits; p.db_acc = dbias_accumulate; p.diag = 0;
     p.bpart = dbias ? workspace + (size_t)splits * ksize * ksize * p.CoP * p.CiP : nullptr;
     hipStream_t s = (hipStream_t)stream;
     if (prec == LP_PREC_BF16) return dispatch_wgrad<LP_PREC_BF16>(p, dw, dbias, out_scale, sn_w_orig, sn_dot, ksize, upsample, s);
     if (prec == LP_PREC_BF16X3) return dispatch_wgrad<LP_PREC_BF16X3>(p, dw, dbias, out_scale, sn_w_orig, sn_dot, ksize, upsample, s);
     if (prec == LP_PREC_F16) return dispatch_wgrad<LP_PREC_F16>(p, dw, dbias, out_scale, sn_w_orig, sn_dot, ksize, upsample, s);
     return lp_set_error(LP_ERR_ARG, "lp_conv16_wgrad: unknown precision");
+}
+
+// ---- grouped 3x3 conv (ResNeXt conv2): weight gradient of the block-diagonal formulation (see lp_gconv16_fwd) --------------------
+// conv_wgrad_kernel with diag = 1 leaves slabs [split][9][C][64] (row = output channel, column = input channel inside the row's aligned
+// 64-channel block); the reduction keeps the group's own columns: dw[co][j][t] = osc * sum_s slab[s][t][co][(co % 64) / cg * cg + j].
+__global__ __launch_bounds__(256) void gconv_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int S, int C, int cg,
+                                                                  const float* __restrict__ out_scale) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;                 // (co, t, j), j fastest: neighbouring lanes read neighbouring columns
+    if (idx >= C * 9 * cg) return;
+    const int j = idx % cg, r = idx / cg;
+    const int t = r % 9, co = r / 9;
+    const size_t slab = (size_t)9 * C * 64;
+    const float* p = part + ((size_t)t * C + co) * 64 + ((co & 63) / cg) * cg + j;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    for (; k + 4 <= S; k += 4) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q] += p[(size_t)(k + q) * slab];
+    }
+    for (; k < S; ++k) a[0] += p[(size_t)k * slab];
+    dw[((size_t)co * cg + j) * 9 + t] = ((a[0] + a[1]) + (a[2] + a[3])) * (out_scale ? out_scale[0] : 1.f);
+}
+
+extern "C" long long lp_gconv_wgrad_workspace_bytes(int C, int splits) { return (long long)splits * 9 * C * 64 * 4; }
+
+extern "C" int lp_gconv16_wgrad(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* dy_hi, const uint16_t* dy_lo, float* dw,
+                                float* workspace, int N, int H, int W, int C, int group_size, int splits, int prec,
+                                const float* out_scale, void* stream) {
+    if (!a_hi || !dy_hi || !dw || !workspace) return lp_set_error(LP_ERR_ARG, "lp_gconv16_wgrad: null pointer");
+    if (prec == LP_PREC_BF16X3 && (!a_lo || !dy_lo)) return lp_set_error(LP_ERR_ARG, "lp_gconv16_wgrad: bf16x3 needs the lo planes");
+    if ((C & 63) || group_size < 1 || 64 % group_size || splits < 1) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_gconv16_wgrad: C % 64 == 0, group size dividing 64");
+    WgradParams p;
+    p.a_hi = a_hi; p.a_lo = a_lo; p.d_hi = dy_hi; p.d_lo = dy_lo; p.part = workspace;
+    p.N = N; p.H = H; p.W = W; p.Hin = H; p.Win = W;
+    p.Cin = C; p.Cout = C; p.C8 = C; p.Co8 = C; p.CoP = C; p.CiP = 64;
+    p.splits = splits; p.db_acc = 0; p.diag = 1; p.bpart = nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if (prec == LP_PREC_BF16) rc = launch_wgrad<3, false, LP_PREC_BF16>(p, dw, nullptr, out_scale, nullptr, nullptr, s);
+    else if (prec == LP_PREC_BF16X3) rc = launch_wgrad<3, false, LP_PREC_BF16X3>(p, dw, nullptr, out_scale, nullptr, nullptr, s);
+    else if (prec == LP_PREC_F16) rc = launch_wgrad<3, false, LP_PREC_F16>(p, dw, nullptr, out_scale, nullptr, nullptr, s);
+    else return lp_set_error(LP_ERR_ARG, "lp_gconv16_wgrad: unknown precision");
+    if (rc) return rc;
+    const int total = C * 9 * group_size;
+    hipLaunchKernelGGL(gconv_wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, workspace, dw, p.splits, C, group_size, out_scale);
+    return lp_check_launch("gconv_wgrad_reduce");
 }

@@ -190,7 +190,8 @@ __global__ __launch_bounds__(256) void instnorm_partial_kernel(const float* __re
 
 __global__ void instnorm_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma, const float* __restrict__ beta,
                                          int ab_stride, float eps, float* __restrict__ mean, float* __restrict__ rstd,
-                                         float* __restrict__ scale, float* __restrict__ shift, int N, int C, int S) {
+                                         float* __restrict__ scale, float* __restrict__ shift, int N, int C, int S,
+                                         float* __restrict__ run_mean = nullptr, float* __restrict__ run_var = nullptr, float momentum = 0.f) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= N * C) return;
     int n = idx / C, c = idx % C;
@@ -206,6 +207,11 @@ __global__ void instnorm_finalize_kernel(const float* __restrict__ part, const f
     float var = (float)(qa / na);
     float m = (float)ma, r = 1.0f / sqrtf(var + eps);
     mean[idx] = m; rstd[idx] = r;
+    if (run_mean) {        // nn.BatchNorm2d: running_mean / running_var (UNBIASED batch variance) <- (1 - momentum) * old + momentum * batch
+        const float unb = na > 1 ? (float)(qa / (na - 1)) : var;
+        run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * m;
+        run_var[c] = (1.f - momentum) * run_var[c] + momentum * unb;
+    }
     if (scale) {
         float g = gamma ? gamma[(size_t)n * ab_stride + c] : 1.f, b = beta ? beta[(size_t)n * ab_stride + c] : 0.f;
         float sc = r * g;
@@ -231,16 +237,41 @@ extern "C" int lp_instnorm_stats(const float* x, const float* gamma, const float
     return lp_check_launch("instnorm_finalize");
 }
 
+// train-mode nn.BatchNorm2d over y [P][C]: batch statistics (biased variance for the normalisation), scale = gamma*rstd,
+// shift = beta - mean*scale, and the momentum update of the running statistics -- the instance-norm kernels with N = 1, HW = P.
+extern "C" long long lp_bn_train_stats_workspace_bytes(long long P, int C) { return lp_instnorm_workspace_bytes(1, (int)P, C); }
+
+extern "C" int lp_bn_train_stats(const float* y, const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                                 float* running_var, float* mean, float* rstd, float* scale, float* shift, float* workspace,
+                                 long long P, int C, void* stream) {
+    if (!y || !gamma || !beta || !mean || !rstd || !scale || !shift || !workspace) return lp_set_error(LP_ERR_ARG, "lp_bn_train_stats: null pointer");
+    if (!running_mean != !running_var) return lp_set_error(LP_ERR_ARG, "lp_bn_train_stats: running_mean and running_var go together");
+    if (P < 1 || P >= (1ll << 30)) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_bn_train_stats: 1 <= P < 2^30");
+    const int HW = (int)P;
+    const int S = (HW + STAT_SPLIT_PIX - 1) / STAT_SPLIT_PIX;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(instnorm_partial_kernel, dim3(S, (C + 63) / 64, 1), dim3(256), 0, st, y, workspace, HW, C, S);
+    int rc = lp_check_launch("bn_stats_partial");
+    if (rc) return rc;
+    hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, workspace, gamma, beta, C, eps, mean, rstd, scale, shift,
+                       1, C, S, running_mean, running_var, momentum);
+    return lp_check_launch("bn_stats_finalize");
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // backward of relu(AdaIN(x)) [+ x2 nearest upsample]
 //   pass 1: g = sum2x2?(dA) * mask  -> written into dx (as temporary), partial sums S1 = sum g, S2 = sum g*xhat
 //   pass 2: coefficients; pass 3: dx = ca*g + cb*x + cc (+ add)
 // ------------------------------------------------------------------------------------------------------------------
+// mask_mode 0: the activation's own pattern 0 < x*scale+shift < act_hi (ReLU: act_hi = inf; ReLU6: 6);  1: no mask (a plain norm);
+// 2: mask_src > 0 (the ReLU sits behind a residual add: mask_src = the block output).  g_copy (|NULL): the masked gradient g is also
+// written there (the identity branch of the residual block receives exactly that).
 __global__ __launch_bounds__(256) void adain_bwd_partial_kernel(const float* __restrict__ dA, const float* __restrict__ x,
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
                                                                 float* __restrict__ g_out, float* __restrict__ part, int H, int W, int C,
-                                                                int ups, int S) {
+                                                                int ups, int S, int mask_mode = 0, const float* __restrict__ mask_src = nullptr,
+                                                                float* __restrict__ g_copy = nullptr, float act_hi = 3.0e38f) {
     __shared__ float sh[2][16][64];
     const int n = blockIdx.z, cb = blockIdx.y, s = blockIdx.x;
     const int cq = threadIdx.x & 15, pl = threadIdx.x >> 4;
@@ -262,9 +293,16 @@ __global__ __launch_bounds__(256) void adain_bwd_partial_kernel(const float* __r
                 g.x = (a0.x + a1.x) + (a2.x + a3.x); g.y = (a0.y + a1.y) + (a2.y + a3.y);
                 g.z = (a0.z + a1.z) + (a2.z + a3.z); g.w = (a0.w + a1.w) + (a2.w + a3.w);
             } else g = *(const float4*)(dA + ((size_t)n * HW + pix) * C + c);
-            g.x = fmaf(xv.x, sc.x, sf.x) > 0.f ? g.x : 0.f; g.y = fmaf(xv.y, sc.y, sf.y) > 0.f ? g.y : 0.f;
-            g.z = fmaf(xv.z, sc.z, sf.z) > 0.f ? g.z : 0.f; g.w = fmaf(xv.w, sc.w, sf.w) > 0.f ? g.w : 0.f;
+            if (mask_mode == 0) {
+                const float a0 = fmaf(xv.x, sc.x, sf.x), a1 = fmaf(xv.y, sc.y, sf.y), a2 = fmaf(xv.z, sc.z, sf.z), a3 = fmaf(xv.w, sc.w, sf.w);
+                g.x = (a0 > 0.f && a0 < act_hi) ? g.x : 0.f; g.y = (a1 > 0.f && a1 < act_hi) ? g.y : 0.f;
+                g.z = (a2 > 0.f && a2 < act_hi) ? g.z : 0.f; g.w = (a3 > 0.f && a3 < act_hi) ? g.w : 0.f;
+            } else if (mask_mode == 2) {
+                const float4 mk = *(const float4*)(mask_src + ((size_t)n * HW + pix) * C + c);
+                g.x = mk.x > 0.f ? g.x : 0.f; g.y = mk.y > 0.f ? g.y : 0.f; g.z = mk.z > 0.f ? g.z : 0.f; g.w = mk.w > 0.f ? g.w : 0.f;
+            }
             *(float4*)(g_out + ((size_t)n * HW + pix) * C + c) = g;
+            if (g_copy) *(float4*)(g_copy + ((size_t)n * HW + pix) * C + c) = g;
             s1[0] += g.x; s1[1] += g.y; s1[2] += g.z; s1[3] += g.w;
             s2[0] += g.x * ((xv.x - mu.x) * rs.x); s2[1] += g.y * ((xv.y - mu.y) * rs.y);
             s2[2] += g.z * ((xv.z - mu.z) * rs.z); s2[3] += g.w * ((xv.w - mu.w) * rs.w);
@@ -283,7 +321,8 @@ __global__ __launch_bounds__(256) void adain_bwd_partial_kernel(const float* __r
 
 __global__ void adain_bwd_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma, int ab_stride,
                                           const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dgamma,
-                                          float* __restrict__ dbeta, float* __restrict__ coef, int N, int C, int S, float inv_hw) {
+                                          float* __restrict__ dbeta, float* __restrict__ coef, int N, int C, int S, float inv_hw,
+                                          int frozen = 0) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= N * C) return;
     int n = idx / C, c = idx % C;
@@ -295,8 +334,8 @@ __global__ void adain_bwd_finalize_kernel(const float* __restrict__ part, const 
     float g = gamma ? gamma[(size_t)n * ab_stride + c] : 1.f;
     float r = rstd[idx], m = mean[idx];
     float ca = g * r;
-    float cb = -ca * r * S2 * inv_hw;
-    float cc = -ca * S1 * inv_hw - cb * m;
+    float cb = frozen ? 0.f : -ca * r * S2 * inv_hw;          // frozen: the statistics are constants (running statistics, eval mode)
+    float cc = frozen ? 0.f : -ca * S1 * inv_hw - cb * m;
     coef[(size_t)idx * 3 + 0] = ca; coef[(size_t)idx * 3 + 1] = cb; coef[(size_t)idx * 3 + 2] = cc;
 }
 
@@ -330,19 +369,29 @@ extern "C" long long lp_adain_bwd_workspace_bytes(int N, int HW, int C) {
 extern "C" int lp_adain_relu_bwd(const float* dA, const float* x, const float* add, const float* gamma, int ab_stride, const float* mean,
                                  const float* rstd, const float* scale, const float* shift, float* dx, float* dgamma, float* dbeta,
                                  float* workspace, int N, int H, int W, int C, int upsample, float* amax_slots, void* stream) {
-    if (!dA || !x || !mean || !rstd || !scale || !shift || !dx || !workspace) return lp_set_error(LP_ERR_ARG, "lp_adain_relu_bwd: null pointer");
-    if (C & 3) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_adain_relu_bwd: C must be a multiple of 4");
+    return lp_norm_act_bwd(dA, x, add, gamma, ab_stride, mean, rstd, scale, shift, dx, dgamma, dbeta, workspace, N, H, W, C, upsample, 0,
+                           nullptr, nullptr, 0.f, 0, amax_slots, stream);
+}
+
+extern "C" int lp_norm_act_bwd(const float* dA, const float* x, const float* add, const float* gamma, int ab_stride, const float* mean,
+                               const float* rstd, const float* scale, const float* shift, float* dx, float* dgamma, float* dbeta,
+                               float* workspace, int N, int H, int W, int C, int upsample, int mask_mode, const float* mask_src,
+                               float* g_copy, float act_hi, int frozen_stats, float* amax_slots, void* stream) {
+    if (!dA || !x || !mean || !rstd || !scale || !shift || !dx || !workspace) return lp_set_error(LP_ERR_ARG, "lp_norm_act_bwd: null pointer");
+    if (C & 3) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_norm_act_bwd: C must be a multiple of 4");
+    if (mask_mode < 0 || mask_mode > 2 || (mask_mode == 2 && !mask_src)) return lp_set_error(LP_ERR_ARG, "lp_norm_act_bwd: bad mask mode");
+    if ((long long)H * W >= (1ll << 30)) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_norm_act_bwd: H*W < 2^30");
     const int HW = H * W;
     int S = (HW + STAT_SPLIT_PIX - 1) / STAT_SPLIT_PIX;
     float* part = workspace;
     float* coef = workspace + (size_t)N * S * C * 2;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(adain_bwd_partial_kernel, dim3(S, (C + 63) / 64, N), dim3(256), 0, st, dA, x, mean, rstd, scale, shift, dx, part,
-                       H, W, C, upsample, S);
+                       H, W, C, upsample, S, mask_mode, mask_src, g_copy, act_hi > 0.f ? act_hi : 3.0e38f);
     int rc = lp_check_launch("adain_bwd_partial");
     if (rc) return rc;
     hipLaunchKernelGGL(adain_bwd_finalize_kernel, dim3(cdiv((long long)N * C, 256)), dim3(256), 0, st, part, gamma, ab_stride, mean, rstd,
-                       dgamma, dbeta, coef, N, C, S, 1.0f / (float)HW);
+                       dgamma, dbeta, coef, N, C, S, 1.0f / (float)HW, frozen_stats);
     rc = lp_check_launch("adain_bwd_finalize");
     if (rc) return rc;
     long long total4 = (long long)N * HW * C / 4;

@@ -22,9 +22,10 @@ template <bool F16> __device__ __forceinline__ float lp_op16_to_f32(uint16_t b) 
     if (F16) return (float)__builtin_bit_cast(_Float16, b);
     return __uint_as_float((unsigned)b << 16);
 }
-// fp32 -> 16-bit operand (hi) and residual (lo, bf16x3 only); fp16 saturates instead of overflowing to inf
+// fp32 -> 16-bit operand (hi) and residual (lo, bf16x3 only); fp16 saturates finite values instead of overflowing to inf (a NaN
+// propagates: a diverging run must not be masked at the operand)
 template <bool F16> __device__ __forceinline__ uint16_t lp_f32_to_op16(float v) {
-    if (F16) { v = fminf(fmaxf(v, -65504.f), 65504.f); return __builtin_bit_cast(uint16_t, (_Float16)v); }
+    if (F16) { const float c = fminf(fmaxf(v, -65504.f), 65504.f); v = (v != v) ? v : c; return __builtin_bit_cast(uint16_t, (_Float16)v); }   // NaN stays NaN
     return __builtin_bit_cast(uint16_t, (__bf16)v);
 }
 

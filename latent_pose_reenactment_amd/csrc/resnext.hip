@@ -1,0 +1,385 @@
+// Layers around the contractions of the ResNeXt-50 32x4d identity encoder (embedders/unsupervised_pose_separate_embResNeXt_segmentation.py:
+// 26-28,37-54 = torchvision resnext50_32x4d(num_classes=512)) for gfx950 -- all bandwidth-bound, one pass each:
+//   * lp_im2col_planes     7x7 / stride 2 stem as a 1x1 contraction: the 147 taps of every output pixel as one 16-bit operand row
+//   * lp_bn_relu_maxpool   BatchNorm affine + ReLU + MaxPool2d(3, 2, 1) forward (fp32 + operand planes + 1-byte argmax), backward
+//   * lp_bn_add_act        BatchNorm affine of the block output + identity / BatchNorm'ed downsample branch + ReLU (+ operand planes)
+//   * lp_subsample2 / lp_zero_stuff2 / lp_add_strided2   stride-2 plumbing (pick / adjoint of pick) on fp32 tensors and operand planes
+//   * lp_spatial_mean      AdaptiveAvgPool2d(1) forward / backward
+//   * lp_pack_grouped      weight image of the block-diagonal grouped 3x3 conv (lp_gconv16_fwd)
+// The contractions themselves (1x1 convs, the grouped 3x3, the stem on its im2col rows, the classifier) run on conv_dma.hip /
+// conv_wgrad.hip; the BatchNorm statistics and BatchNorm backward on the instance-norm kernels of elementwise.hip (a BatchNorm over
+// [P][C] is an instance norm with one "image" of P pixels).
+#include "lp_common.h"
+#include "lp_hip.h"
+#include "lp_internal.h"
+
+static inline unsigned grid_for(long long items, int cap = 16384) {
+    long long b = (items + 255) / 256;
+    return (unsigned)(b > cap ? cap : (b < 1 ? 1 : b));
+}
+
+template <bool F16, bool SPLIT>
+__device__ __forceinline__ void store_op8(const float (&v)[8], uint16_t* hi, uint16_t* lo, size_t off8) {
+    s16x8_t h, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint16_t hb = lp_f32_to_op16<F16>(v[j]);
+        h[j] = (short)hb;
+        if (SPLIT) l[j] = (short)lp_f32_to_op16<false>(v[j] - lp_op16_to_f32<false>(hb));
+    }
+    *(s16x8_t*)(hi + off8) = h;
+    if (SPLIT) *(s16x8_t*)(lo + off8) = l;
+}
+
+// ---- im2col rows as operand planes -----------------------------------------------------------------------------------------------
+// x [N][C][H][W] fp32 (NCHW, what the dataloader delivers) -> rows [N*Ho*Wo][K8], K = C*KS*KS, k = (c*KS + ky)*KS + kx (the order of
+// nn.Conv2d's weight.view(Cout, -1)), zero padding, pad columns zero.  One thread per (pixel, 8 consecutive k): the row of a pixel is
+// K8*2 contiguous bytes, so a wave writes whole rows (coalesced); the gathers hit L1/L2 (every input value is read KS*KS/stride^2 times).
+template <int PREC>
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo,
+                                                     long long items, int C, int H, int W, int Ho, int Wo, int KS, int stride, int pad,
+                                                     int K, int G) {
+    constexpr bool SPLIT = (PREC == LP_PREC_BF16X3), F16 = (PREC == LP_PREC_F16);
+    const int KK = KS * KS;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < items; i += (long long)gridDim.x * 256) {
+        const int g = (int)(i % G);
+        const long long pix = i / G;
+        const int ox = (int)(pix % Wo);
+        const long long t = pix / Wo;
+        const int oy = (int)(t % Ho), n = (int)(t / Ho);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = g * 8 + j;
+            float q = 0.f;
+            if (k < K) {
+                const int c = k / KK, r = k - c * KK;
+                const int ky = r / KS, kx = r - ky * KS;
+                const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) q = x[(((size_t)n * C + c) * H + iy) * W + ix];
+            }
+            v[j] = q;
+        }
+        store_op8<F16, SPLIT>(v, hi, lo, (size_t)i * 8);
+    }
+}
+
+extern "C" int lp_im2col_planes(const float* x, uint16_t* hi, uint16_t* lo, int N, int C, int H, int W, int ksize, int stride, int pad,
+                                int prec, void* stream) {
+    if (!x || !hi) return lp_set_error(LP_ERR_ARG, "lp_im2col_planes: null pointer");
+    if (prec == LP_PREC_BF16X3 && !lo) return lp_set_error(LP_ERR_ARG, "lp_im2col_planes: bf16x3 needs the lo plane");
+    if (ksize < 1 || stride < 1 || pad < 0) return lp_set_error(LP_ERR_ARG, "lp_im2col_planes: bad geometry");
+    const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
+    const int K = C * ksize * ksize, G = (K + 7) / 8;
+    const long long items = (long long)N * Ho * Wo * G;
+    if (items <= 0) return LP_OK;
+    hipStream_t st = (hipStream_t)stream;
+#define LP_I2C(P) hipLaunchKernelGGL(im2col_kernel<P>, dim3(grid_for(items, 65536)), dim3(256), 0, st, x, hi, lo, items, C, H, W, Ho, Wo, ksize, stride, pad, K, G)
+    if (prec == LP_PREC_BF16) LP_I2C(LP_PREC_BF16);
+    else if (prec == LP_PREC_BF16X3) LP_I2C(LP_PREC_BF16X3);
+    else if (prec == LP_PREC_F16) LP_I2C(LP_PREC_F16);
+    else return lp_set_error(LP_ERR_ARG, "lp_im2col_planes: unknown precision mode");
+#undef LP_I2C
+    return lp_check_launch("im2col_planes");
+}
+
+// ---- BatchNorm affine + ReLU + MaxPool2d(kernel 3, stride 2, padding 1) -----------------------------------------------------------
+// y [N][H][W][C] raw conv output -> out [N][Ho][Wo][C] = max over the window of relu(y*scale[c]+shift[c]) (padding = -inf, i.e. ignored),
+// the operand planes of out, and idx = position 0..8 (ky*3+kx) of the first maximum in row-major scan order (torch's tie rule).
+template <int PREC>
+__global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const float* __restrict__ y, const float* __restrict__ sc, const float* __restrict__ sh,
+                                                              float* __restrict__ out, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo,
+                                                              unsigned char* __restrict__ idx, long long items, int H, int W, int Ho, int Wo, int C) {
+    constexpr bool SPLIT = (PREC == LP_PREC_BF16X3), F16 = (PREC == LP_PREC_F16);
+    const int C4 = C >> 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < items; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C4) * 4;
+        const long long pix = i / C4;
+        const int ox = (int)(pix % Wo);
+        const long long t = pix / Wo;
+        const int oy = (int)(t % Ho), n = (int)(t / Ho);
+        const float4 s = *(const float4*)(sc + c), b = *(const float4*)(sh + c);
+        float m[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+        int am[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = 2 * oy - 1 + ky;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = 2 * ox - 1 + kx;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                    const float4 q = *(const float4*)(y + (((size_t)n * H + iy) * W + ix) * C + c);
+                    const float a0 = fmaxf(fmaf(q.x, s.x, b.x), 0.f), a1 = fmaxf(fmaf(q.y, s.y, b.y), 0.f);
+                    const float a2 = fmaxf(fmaf(q.z, s.z, b.z), 0.f), a3 = fmaxf(fmaf(q.w, s.w, b.w), 0.f);
+                    const int k = ky * 3 + kx;
+                    if (a0 > m[0]) { m[0] = a0; am[0] = k; }
+                    if (a1 > m[1]) { m[1] = a1; am[1] = k; }
+                    if (a2 > m[2]) { m[2] = a2; am[2] = k; }
+                    if (a3 > m[3]) { m[3] = a3; am[3] = k; }
+                }
+            }
+        }
+        *(float4*)(out + (size_t)i * 4) = make_float4(m[0], m[1], m[2], m[3]);
+        if (idx) *(uchar4*)(idx + (size_t)i * 4) = make_uchar4((unsigned char)am[0], (unsigned char)am[1], (unsigned char)am[2], (unsigned char)am[3]);
+        if (hi) {
+            ushort4 h, l;
+            uint16_t* hp = (uint16_t*)&h; uint16_t* lp = (uint16_t*)&l;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                hp[j] = lp_f32_to_op16<F16>(m[j]);
+                if (SPLIT) lp[j] = lp_f32_to_op16<false>(m[j] - lp_op16_to_f32<false>(hp[j]));
+            }
+            *(ushort4*)(hi + (size_t)i * 4) = h;
+            if (SPLIT) *(ushort4*)(lo + (size_t)i * 4) = l;
+        }
+    }
+}
+
+extern "C" int lp_bn_relu_maxpool_fwd(const float* y, const float* scale, const float* shift, float* out, uint16_t* hi, uint16_t* lo,
+                                      unsigned char* idx, int N, int H, int W, int C, int prec, void* stream) {
+    if (!y || !scale || !shift || !out) return lp_set_error(LP_ERR_ARG, "lp_bn_relu_maxpool_fwd: null pointer");
+    if ((C & 7) || H < 2 || W < 2) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_bn_relu_maxpool_fwd: C % 8 == 0, H, W >= 2");
+    if (hi && prec == LP_PREC_BF16X3 && !lo) return lp_set_error(LP_ERR_ARG, "lp_bn_relu_maxpool_fwd: bf16x3 planes need lo");
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long long items = (long long)N * Ho * Wo * (C >> 2);
+    hipStream_t st = (hipStream_t)stream;
+#define LP_MP(P) hipLaunchKernelGGL(bn_relu_maxpool_kernel<P>, dim3(grid_for(items, 65536)), dim3(256), 0, st, y, scale, shift, out, hi, lo, idx, items, H, W, Ho, Wo, C)
+    if (prec == LP_PREC_BF16) LP_MP(LP_PREC_BF16);
+    else if (prec == LP_PREC_BF16X3) LP_MP(LP_PREC_BF16X3);
+    else if (prec == LP_PREC_F16) LP_MP(LP_PREC_F16);
+    else return lp_set_error(LP_ERR_ARG, "lp_bn_relu_maxpool_fwd: unknown precision mode");
+#undef LP_MP
+    return lp_check_launch("bn_relu_maxpool");
+}
+
+// dA [N][H][W][C] (gradient w.r.t. relu(bn(y)), the maxpool input) = sum over the <= 4 windows containing the pixel of d_out where the
+// window's recorded argmax is this pixel.  A gather: no atomics, every element written exactly once.
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dout, const unsigned char* __restrict__ idx, float* __restrict__ dA,
+                                                          long long items, int H, int W, int Ho, int Wo, int C) {
+    const int C4 = C >> 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < items; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C4) * 4;
+        const long long pix = i / C4;
+        const int ix = (int)(pix % W);
+        const long long t = pix / W;
+        const int iy = (int)(t % H), n = (int)(t / H);
+        // windows oy with 2*oy-1 <= iy <= 2*oy+1: iy even -> oy = iy/2 (ky 1); iy odd -> oy = (iy-1)/2 (ky 2) and (iy+1)/2 (ky 0)
+        const int oy0 = iy >> 1, ky0 = (iy & 1) ? 2 : 1, ny = (iy & 1) ? 2 : 1;
+        const int ox0 = ix >> 1, kx0 = (ix & 1) ? 2 : 1, nx = (ix & 1) ? 2 : 1;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int p = 0; p < ny; ++p) {
+            const int oy = oy0 + p, ky = p ? 0 : ky0;
+            if (oy >= Ho) continue;
+            for (int q = 0; q < nx; ++q) {
+                const int ox = ox0 + q, kx = q ? 0 : kx0;
+                if (ox >= Wo) continue;
+                const size_t o = (((size_t)n * Ho + oy) * Wo + ox) * C + c;
+                const uchar4 id = *(const uchar4*)(idx + o);
+                const float4 d = *(const float4*)(dout + o);
+                const int k = ky * 3 + kx;
+                a.x += (id.x == k) ? d.x : 0.f; a.y += (id.y == k) ? d.y : 0.f;
+                a.z += (id.z == k) ? d.z : 0.f; a.w += (id.w == k) ? d.w : 0.f;
+            }
+        }
+        *(float4*)(dA + (size_t)i * 4) = a;
+    }
+}
+
+extern "C" int lp_maxpool_bwd(const float* dout, const unsigned char* idx, float* dA, int N, int H, int W, int C, void* stream) {
+    if (!dout || !idx || !dA) return lp_set_error(LP_ERR_ARG, "lp_maxpool_bwd: null pointer");
+    if (C & 3) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_maxpool_bwd: C % 4 == 0");
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long long items = (long long)N * H * W * (C >> 2);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(items, 65536)), dim3(256), 0, (hipStream_t)stream, dout, idx, dA, items, H, W, Ho, Wo, C);
+    return lp_check_launch("maxpool_bwd");
+}
+
+// ---- block output: out = act( y*scale[c]+shift[c] + r ),  r = res | res*rscale[c]+rshift[c] | 0;  act = ReLU | identity -------------
+template <int PREC>
+__global__ __launch_bounds__(256) void bn_add_act_kernel(const float* __restrict__ y, const float* __restrict__ sc, const float* __restrict__ sh,
+                                                         const float* __restrict__ res, const float* __restrict__ rsc, const float* __restrict__ rsh,
+                                                         float* __restrict__ out, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo,
+                                                         long long items, int C, int relu) {
+    constexpr bool SPLIT = (PREC == LP_PREC_BF16X3), F16 = (PREC == LP_PREC_F16);
+    const int G = C >> 3;
+    const float floor_v = relu ? 0.f : -3.0e38f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < items; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % G) * 8;
+        const float4 p0 = *(const float4*)(y + i * 8), p1 = *(const float4*)(y + i * 8 + 4);
+        float v[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], sc[c + j], sh[c + j]);
+        if (res) {
+            const float4 r0 = *(const float4*)(res + i * 8), r1 = *(const float4*)(res + i * 8 + 4);
+            float r[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+            if (rsc) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r[j] = fmaf(r[j], rsc[c + j], rsh[c + j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += r[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], floor_v);
+        *(float4*)(out + i * 8) = make_float4(v[0], v[1], v[2], v[3]);
+        *(float4*)(out + i * 8 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        if (hi) store_op8<F16, SPLIT>(v, hi, lo, (size_t)i * 8);
+    }
+}
+
+extern "C" int lp_bn_add_act(const float* y, const float* scale, const float* shift, const float* res, const float* res_scale,
+                             const float* res_shift, float* out, uint16_t* hi, uint16_t* lo, long long P, int C, int relu, int prec,
+                             void* stream) {
+    if (!y || !scale || !shift || !out) return lp_set_error(LP_ERR_ARG, "lp_bn_add_act: null pointer");
+    if (!res_scale != !res_shift || (res_scale && !res)) return lp_set_error(LP_ERR_ARG, "lp_bn_add_act: res_scale/res_shift go together and need res");
+    if (C & 7) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_bn_add_act: C must be a multiple of 8");
+    if (hi && prec == LP_PREC_BF16X3 && !lo) return lp_set_error(LP_ERR_ARG, "lp_bn_add_act: bf16x3 planes need lo");
+    const long long items = P * (C >> 3);
+    if (items == 0) return LP_OK;
+    hipStream_t st = (hipStream_t)stream;
+#define LP_BA(Q) hipLaunchKernelGGL(bn_add_act_kernel<Q>, dim3(grid_for(items)), dim3(256), 0, st, y, scale, shift, res, res_scale, res_shift, out, hi, lo, items, C, relu)
+    if (prec == LP_PREC_BF16) LP_BA(LP_PREC_BF16);
+    else if (prec == LP_PREC_BF16X3) LP_BA(LP_PREC_BF16X3);
+    else if (prec == LP_PREC_F16) LP_BA(LP_PREC_F16);
+    else return lp_set_error(LP_ERR_ARG, "lp_bn_add_act: unknown precision mode");
+#undef LP_BA
+    return lp_check_launch("bn_add_act");
+}
+
+// ---- stride-2 plumbing on [N][H][W][row of `units` 16-byte pieces] tensors (fp32 NHWC: units = C/4; operand planes: units = C8/8) ----
+// subsample: out[n,i,j] = in[n,2i,2j]  (what a stride-2 1x1 conv reads; the stride-2 3x3 conv output picked from the stride-1 result)
+__global__ __launch_bounds__(256) void subsample2_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, long long items, int Ho, int Wo,
+                                                         int H, int W, int units) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < items; i += (long long)gridDim.x * 256) {
+        const int u = (int)(i % units);
+        const long long pix = i / units;
+        const int ox = (int)(pix % Wo);
+        const long long t = pix / Wo;
+        const int oy = (int)(t % Ho), n = (int)(t / Ho);
+        out[i] = in[(((size_t)n * H + 2 * oy) * W + 2 * ox) * units + u];
+    }
+}
+// zero stuffing (adjoint of subsample): out[n,y,x] = (y, x both even) ? in[n,y/2,x/2] : 0 -- out is [N][H][W], in [N][ceil(H/2)][ceil(W/2)]
+__global__ __launch_bounds__(256) void zero_stuff2_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, long long items, int Hi, int Wi,
+                                                          int H, int W, int units) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < items; i += (long long)gridDim.x * 256) {
+        const int u = (int)(i % units);
+        const long long pix = i / units;
+        const int x = (int)(pix % W);
+        const long long t = pix / W;
+        const int y = (int)(t % H), n = (int)(t / H);
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (!((x | y) & 1)) v = in[(((size_t)n * Hi + (y >> 1)) * Wi + (x >> 1)) * units + u];
+        out[i] = v;
+    }
+}
+// d[n,2i,2j,:] += s[n,i,j,:]  (fp32; adjoint of the pick inside a sum: the stride-2 downsample branch's data gradient joins the main one)
+__global__ __launch_bounds__(256) void add_strided2_kernel(float4* __restrict__ d, const float4* __restrict__ s, long long items, int Hs, int Ws,
+                                                           int H, int W, int C4) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < items; i += (long long)gridDim.x * 256) {
+        const int u = (int)(i % C4);
+        const long long pix = i / C4;
+        const int ox = (int)(pix % Ws);
+        const long long t = pix / Ws;
+        const int oy = (int)(t % Hs), n = (int)(t / Hs);
+        const size_t o = (((size_t)n * H + 2 * oy) * W + 2 * ox) * C4 + u;
+        float4 a = d[o];
+        const float4 b = s[i];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        d[o] = a;
+    }
+}
+
+extern "C" int lp_subsample2(const void* in, void* out, int N, int H, int W, int row_bytes, void* stream) {
+    if (!in || !out) return lp_set_error(LP_ERR_ARG, "lp_subsample2: null pointer");
+    if (row_bytes & 15) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_subsample2: rows must be multiples of 16 bytes");
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2, units = row_bytes >> 4;
+    const long long items = (long long)N * Ho * Wo * units;
+    if (items == 0) return LP_OK;
+    hipLaunchKernelGGL(subsample2_kernel, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, (const uint4*)in, (uint4*)out, items, Ho, Wo, H, W, units);
+    return lp_check_launch("subsample2");
+}
+extern "C" int lp_zero_stuff2(const void* in, void* out, int N, int H, int W, int row_bytes, void* stream) {
+    if (!in || !out) return lp_set_error(LP_ERR_ARG, "lp_zero_stuff2: null pointer");
+    if (row_bytes & 15) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_zero_stuff2: rows must be multiples of 16 bytes");
+    const int Hi = (H + 1) / 2, Wi = (W + 1) / 2, units = row_bytes >> 4;
+    const long long items = (long long)N * H * W * units;
+    if (items == 0) return LP_OK;
+    hipLaunchKernelGGL(zero_stuff2_kernel, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, (const uint4*)in, (uint4*)out, items, Hi, Wi, H, W, units);
+    return lp_check_launch("zero_stuff2");
+}
+extern "C" int lp_add_strided2(float* d, const float* s, int N, int H, int W, int C, void* stream) {
+    if (!d || !s) return lp_set_error(LP_ERR_ARG, "lp_add_strided2: null pointer");
+    if (C & 3) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_add_strided2: C % 4 == 0");
+    const int Hs = (H + 1) / 2, Ws = (W + 1) / 2;
+    const long long items = (long long)N * Hs * Ws * (C >> 2);
+    if (items == 0) return LP_OK;
+    hipLaunchKernelGGL(add_strided2_kernel, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, (float4*)d, (const float4*)s, items, Hs, Ws, H, W, C >> 2);
+    return lp_check_launch("add_strided2");
+}
+
+// ---- AdaptiveAvgPool2d(1): out[n][c] = mean over HW of x[n][p][c];  backward: dx[n][p][c] = g[n][c] / HW -----------------------------
+__global__ __launch_bounds__(256) void spatial_mean_kernel(const float* __restrict__ x, float* __restrict__ out, int HW, int C) {
+    __shared__ float red[4][64];
+    const int n = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
+    float a = 0.f;
+    if (c < C) for (int p = pl; p < HW; p += 4) a += x[((size_t)n * HW + p) * C + c];
+    red[pl][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (pl == 0 && c < C) out[(size_t)n * C + c] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x])) / (float)HW;
+}
+__global__ __launch_bounds__(256) void spatial_mean_bwd_kernel(const float4* __restrict__ g, float4* __restrict__ dx, long long items, int HW, int C4, float inv) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < items; i += (long long)gridDim.x * 256) {
+        const int u = (int)(i % C4);
+        const long long n = i / ((long long)C4 * HW);
+        const float4 v = g[n * C4 + u];
+        dx[i] = make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
+    }
+}
+extern "C" int lp_spatial_mean_fwd(const float* x, float* out, int N, int HW, int C, void* stream) {
+    if (!x || !out) return lp_set_error(LP_ERR_ARG, "lp_spatial_mean_fwd: null pointer");
+    hipLaunchKernelGGL(spatial_mean_kernel, dim3((C + 63) / 64, N), dim3(256), 0, (hipStream_t)stream, x, out, HW, C);
+    return lp_check_launch("spatial_mean");
+}
+extern "C" int lp_spatial_mean_bwd(const float* g, float* dx, int N, int HW, int C, void* stream) {
+    if (!g || !dx) return lp_set_error(LP_ERR_ARG, "lp_spatial_mean_bwd: null pointer");
+    if (C & 3) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_spatial_mean_bwd: C % 4 == 0");
+    const long long items = (long long)N * HW * (C >> 2);
+    if (items == 0) return LP_OK;
+    hipLaunchKernelGGL(spatial_mean_bwd_kernel, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, (const float4*)g, (float4*)dx, items, HW, C >> 2,
+                       1.0f / (float)HW);
+    return lp_check_launch("spatial_mean_bwd");
+}
+
+// ---- weight image of the block-diagonal grouped 3x3 conv -------------------------------------------------------------------------
+// w [C][cg][9] (nn.Conv2d(C, C, 3, groups = C/cg) layout).  mode 0 (forward):  out[t][co][cl]   = w[co][ci % cg][t]   for ci = 64*(co/64) + cl
+// in co's group, else 0;  mode 1 (data gradient): out[8-t][ci][cl] = w[co][ci % cg][t] for co = 64*(ci/64) + cl in ci's group, else 0.
+// Rows padded to CP (zero).
+__global__ __launch_bounds__(256) void pack_grouped_kernel(const float* __restrict__ w, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo,
+                                                           int C, int cg, int CP, int mode, int f16, long long total) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int cl = (int)(i & 63);
+        const long long r = i >> 6;
+        const int row = (int)(r % CP), t = (int)(r / CP);
+        float v = 0.f;
+        if (row < C) {
+            const int other = (row & ~63) + cl;              // the channel of the OTHER side (input for mode 0, output for mode 1)
+            if (other < C && other / cg == row / cg) {
+                const int co = mode ? other : row, ci = mode ? row : other;
+                const int ts = mode ? 8 - t : t;
+                v = w[((size_t)co * cg + (ci % cg)) * 9 + ts];
+            }
+        }
+        uint16_t hb;
+        if (f16) hb = lp_f32_to_op16<true>(v); else hb = lp_f32_to_op16<false>(v);
+        hi[i] = hb;
+        if (lo) lo[i] = lp_f32_to_op16<false>(v - lp_op16_to_f32<false>(hb));
+    }
+}
+extern "C" int lp_pack_grouped(const float* w, uint16_t* hi, uint16_t* lo, int C, int group_size, int CP, int mode, int f16, void* stream) {
+    if (!w || !hi) return lp_set_error(LP_ERR_ARG, "lp_pack_grouped: null pointer");
+    if ((C & 63) || group_size < 1 || 64 % group_size || CP < C) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_pack_grouped: C % 64 == 0, group size dividing 64");
+    const long long total = 9ll * CP * 64;
+    hipLaunchKernelGGL(pack_grouped_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, w, hi, f16 ? nullptr : lo, C, group_size, CP, mode, f16, total);
+    return lp_check_launch("pack_grouped");
+}

@@ -95,10 +95,93 @@ class ResNeXt(nn.Module):
         return nn.Sequential(*seq)
 
     def forward(self, x):
+        from . import resnext_hip
+        if _HIP_FORWARD[0] and x.is_cuda and x.dim() == 4 and x.shape[1] == 3 and resnext_hip.supported(x.shape[0], x.shape[2], x.shape[3]):
+            return self._forward_hip(x)
+        if _HIP_FORWARD[0] and x.is_cuda and not self.__dict__.get('_warned_stock'):
+            self.__dict__['_warned_stock'] = True
+            import logging
+            logging.getLogger('embedder').warning('ResNeXt: input %s is outside the HIP path\'s geometry (see resnext_hip.supported); '
+                                                  'running the stock PyTorch-ROCm layers', tuple(x.shape))
         x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         _flush_bn_counters()
         return self.fc(torch.flatten(self.avgpool(x), 1))
+
+    # ---- HIP path (forward and backward): embedders/resnext_hip.py -----------------------------------------------------------------
+    @property
+    def prec(self):
+        """MFMA operand mode of the encoder's contractions: LP_PREC_E (f16 | bf16x3 | bf16) or the global LP_PREC"""
+        from latent_pose_reenactment_amd.nn import PREC_NAMES, default_prec
+        name = os.environ.get('LP_PREC_E')
+        return PREC_NAMES[name] if name else default_prec()
+
+    def _hip_structure(self):
+        if self.__dict__.get('_hip_param_names') is None:
+            self.__dict__['_hip_param_names'] = [k for k, _ in self.named_parameters()]
+            self.__dict__['_hip_bn'] = {k: m for k, m in self.named_modules() if isinstance(m, nn.BatchNorm2d)}
+            blocks = []
+            for li in range(1, 5):
+                for bi, blk in enumerate(getattr(self, f'layer{li}')):
+                    blocks.append((f'layer{li}.{bi}', blk.conv1.in_channels, blk.conv2.in_channels, blk.conv3.out_channels,
+                                   blk.conv2.stride[0], blk.downsample is not None))
+            self.__dict__['_hip_blocks'] = blocks
+
+    def _hip_packs(self, par, need_grad):
+        """16-bit weight packs: name -> (forward pack, data-gradient pack | None).  The dense contractions (1x1 convs, the stem viewed as
+        [64][147], the classifier) are re-packed by one batched launch per orientation set (static buffers: hipGraph friendly); the
+        grouped 3x3 weights by lp_pack_grouped.  Without autograd and in eval mode the packs are cached until a weight changes."""
+        from latent_pose_reenactment_amd import hipops as ops
+        from latent_pose_reenactment_amd.optim import WEIGHTS_GENERATION
+        prec = self.prec
+        dense = [k for k in self._hip_param_names
+                 if k == 'conv1.weight' or k == 'fc.weight' or (par[k].dim() == 4 and par[k].shape[2] == 1)]      # stem, classifier, 1x1 convs
+        grouped = [k for k in self._hip_param_names if par[k].dim() == 4 and par[k].shape[2] == 3]                 # the 16 grouped 3x3 convs
+        cacheable = not need_grad and not self.training
+        key = (prec, need_grad, WEIGHTS_GENERATION[0]) + tuple((par[k].data_ptr(), par[k]._version) for k in dense + grouped)
+        cache = self.__dict__.get('_hip_pack_cache')
+        if cacheable and cache is not None and cache[0] == key:
+            return cache[1]
+
+        def w2d(k):
+            w = par[k].detach()
+            return w.view(w.shape[0], -1) if k == 'conv1.weight' else w
+        specs = [(w2d(k), 0, False) for k in dense]
+        if need_grad:
+            specs += [(w2d(k), 1, False) for k in dense if k != 'conv1.weight']
+        pb = self.__dict__.get('_hip_pb')
+        pkey = tuple((w.data_ptr(), m, bool(sk)) for w, m, sk in specs)
+        if pb is None or pb.prec != prec or pb.key != pkey:
+            pb = ops.PackBatch(specs, prec)
+            self.__dict__['_hip_pb'] = pb
+        allp = pb.update()
+        packs = {k: [allp[i], None] for i, k in enumerate(dense)}
+        if need_grad:
+            for j, k in enumerate(k_ for k_ in dense if k_ != 'conv1.weight'):
+                packs[k][1] = allp[len(dense) + j]
+        for k in grouped:
+            w = par[k].detach().contiguous()
+            packs[k] = [ops.pack_grouped(w, 0, prec), ops.pack_grouped(w, 1, prec) if need_grad else None]
+        if cacheable:
+            self.__dict__['_hip_pack_cache'] = (key, packs)
+        return packs
+
+    def _hip_eval_affines(self, par):
+        """eval mode: every BatchNorm as (mean, rstd, scale, shift) from its running statistics (five multi-tensor ops for all layers)"""
+        from .resnext_hip import _BN
+        names = list(self._hip_bn)
+        bns = [self._hip_bn[k] for k in names]
+        rstd = torch._foreach_add([m.running_var for m in bns], bns[0].eps)
+        torch._foreach_rsqrt_(rstd)
+        sc = torch._foreach_mul(rstd, [par[k + '.weight'].detach() for k in names])
+        sh = torch._foreach_mul([m.running_mean for m in bns], sc)
+        sh = torch._foreach_sub([par[k + '.bias'].detach() for k in names], sh)
+        return {k: _BN(m.running_mean, r, a_, b_) for k, m, r, a_, b_ in zip(names, bns, rstd, sc, sh)}
+
+    def _forward_hip(self, x):
+        from .resnext_hip import ResNeXtFunction
+        self._hip_structure()
+        return ResNeXtFunction.apply(self, x, *[p for _, p in self.named_parameters()])
 
 
 def resnext50_32x4d(num_classes=1000):

@@ -1,0 +1,189 @@
+"""ResNeXt-50 32x4d identity encoder on the gfx950 kernels: forward AND backward as ONE ``torch.autograd.Function`` -- the reference's
+``torchvision.models.resnext50_32x4d(num_classes=512)`` call (embedders/unsupervised_pose_separate_embResNeXt_segmentation.py:26,37-54),
+trained in meta-training (runners/holycow.py:34-41 puts the embedder's parameters into optimizer_G).
+
+Data flow (NHWC fp32 activations, 16-bit operand planes for every contraction, as in the generator):
+  stem     7x7/2 conv = lp_im2col_planes (147 taps per output pixel as one operand row) + the 1x1 contraction kernel;
+           BatchNorm + ReLU + MaxPool(3,2,1) in one pass (lp_bn_relu_maxpool_fwd, 1-byte argmax for the backward)
+  block    conv1 1x1 -> BN -> ReLU -> grouped 3x3 (stride 1|2) -> BN -> ReLU -> conv3 1x1 -> BN -> (+ identity | BN(downsample 1x1)) -> ReLU
+           1x1 convs:   lp_conv16_fwd / lp_conv16_wgrad on the pixels flattened to one "image" (a 1x1 conv ignores the spatial structure)
+           grouped 3x3: lp_gconv16_fwd / lp_gconv16_wgrad (block-diagonal over aligned 64-channel blocks); stride 2 = full-resolution conv +
+                        lp_subsample2, its gradients through lp_zero_stuff2 (3 of the 16 blocks)
+           BatchNorm:   train mode: lp_bn_train_stats (batch statistics + running-statistics update) -> per-channel (scale, shift) which
+                        lp_act_pack (pro 4) applies with the ReLU while it writes the next conv's operand planes; the block output's
+                        BN + residual + ReLU is lp_bn_add_act.  Backward: lp_norm_act_bwd (the AdaIN backward kernels with one "image").
+  head     AdaptiveAvgPool2d(1) (lp_spatial_mean) + the classifier as a 1x1 contraction over the N frames.
+Every raw conv output is kept in fp32 (BatchNorm statistics and backward read it); the saved operand planes are what the weight
+gradients multiply.  Nothing here is a torch op except views and allocation."""
+import torch
+
+from latent_pose_reenactment_amd import hipops as ops
+from latent_pose_reenactment_amd._lib import PREC_F16
+
+
+class _BN:
+    """per-layer BatchNorm state of one pass: (mean, rstd, scale, shift) [C]"""
+    __slots__ = ('mean', 'rstd', 'scale', 'shift')
+
+    def __init__(self, mean, rstd, scale, shift):
+        self.mean, self.rstd, self.scale, self.shift = mean, rstd, scale, shift
+
+
+def supported(n: int, h: int, w: int) -> bool:
+    """geometry the kernels cover: the last stage's grouped 3x3 (input H/16 x W/16) needs a >= 4 wide map (weight-gradient tiles are
+    >= 4 pixels wide), the classifier contraction N % 4 == 0 and N >= 8.  The 256 x 256 x (B x 8 frames) workload and the 128 x 128
+    test sizes qualify; smaller toy sizes run the stock layers (backbones.ResNeXt.forward)."""
+    return h % 32 == 0 and w % 32 == 0 and h >= 64 and w >= 64 and n % 4 == 0 and n >= 8
+
+
+def _conv1x1(a16, pack, prec, bias=None, res=None, amax=False):
+    """1x1 contraction on flattened pixels: a16 [..., C8] planes -> y [P, Cout] fp32"""
+    fa = ops.flat16(a16)
+    _, h, w, _ = fa.hi.shape
+    if res is not None:
+        res = res.view(1, h, w, -1)
+    y = ops.conv16(fa, pack, ksize=1, bias=bias, res=res, prec=prec, amax=amax)
+    return y
+
+
+def _wgrad1x1(a16, d16, prec, bias_grad=False):
+    return ops.conv_wgrad16(ops.flat16(a16), ops.flat16(d16), ksize=1, prec=prec, bias_grad=bias_grad)
+
+
+class ResNeXtFunction(torch.autograd.Function):
+    """inputs: the module (structure, buffers), frames x [N,3,H,W] NCHW fp32, then the parameters in ``net.parameters()`` order.
+    output: logits [N, num_classes]."""
+
+    @staticmethod
+    def forward(ctx, net, x, *params):
+        prec = net.prec
+        train = net.training
+        need_grad = any(ctx.needs_input_grad[2:])
+        par = dict(zip(net._hip_param_names, params))
+        packs = net._hip_packs(par, need_grad)
+        bn_eval = None if train else net._hip_eval_affines(par)
+        counters = []
+
+        def bn(y, name):
+            m = net._hip_bn[name]
+            if not train:
+                return bn_eval[name]
+            if m.track_running_stats:
+                counters.append(m.num_batches_tracked)
+            st = ops.bn_train_stats(y, par[name + '.weight'].detach(), par[name + '.bias'].detach(), m.running_mean, m.running_var,
+                                    m.momentum, m.eps)
+            return _BN(*st)
+
+        n, _, hin, win = x.shape
+        x = x.detach().contiguous()
+        if x.dtype not in (torch.float32, torch.float64):      # (fp64 only reaches the CPU emulation of the tests)
+            x = x.float()
+        # ---- stem
+        cols = ops.im2col_planes(x, 7, 2, 3, prec)                               # [N, H/2, W/2, 152]
+        h0, w0 = cols.hi.shape[1], cols.hi.shape[2]
+        y0 = _conv1x1(cols, packs['conv1.weight'][0], prec).view(n, h0, w0, 64)
+        st0 = bn(y0, 'bn1')
+        out, out16, idx = ops.bn_relu_maxpool(y0, st0.scale, st0.shift, prec, want_idx=need_grad)
+        saved_blocks = []
+        # ---- bottleneck blocks
+        for bname, cin, width, cout, stride, down in net._hip_blocks:
+            xin, xin16 = out, out16
+            _, h, w, _ = xin.shape
+            y1 = _conv1x1(xin16, packs[bname + '.conv1.weight'][0], prec).view(n, h, w, width)
+            st1 = bn(y1, bname + '.bn1')
+            a1 = ops.act_pack(y1, pro=4, scale=st1.scale, shift=st1.shift, prec=prec)
+            y2 = ops.gconv16(a1, packs[bname + '.conv2.weight'][0], prec=prec)
+            if stride == 2:
+                y2 = ops.subsample2(y2)
+            ho, wo = y2.shape[1], y2.shape[2]
+            st2 = bn(y2, bname + '.bn2')
+            a2 = ops.act_pack(y2, pro=4, scale=st2.scale, shift=st2.shift, prec=prec)
+            y3 = _conv1x1(a2, packs[bname + '.conv3.weight'][0], prec).view(n, ho, wo, cout)
+            st3 = bn(y3, bname + '.bn3')
+            xd16 = yd = std = None
+            if down:
+                xd16 = ops.subsample2_16(xin16) if stride == 2 else xin16
+                yd = _conv1x1(xd16, packs[bname + '.downsample.0.weight'][0], prec).view(n, ho, wo, cout)
+                std = bn(yd, bname + '.downsample.1')
+                out, out16 = ops.bn_add_act(y3, st3.scale, st3.shift, yd, std.scale, std.shift, relu=True, prec=prec)
+            else:
+                out, out16 = ops.bn_add_act(y3, st3.scale, st3.shift, xin, relu=True, prec=prec)
+            if need_grad:
+                saved_blocks.append((xin16, y1, st1, a1, y2, st2, a2, y3, st3, xd16, yd, std, out, (h, w, ho, wo)))
+        # ---- head
+        _, hl, wl, cl = out.shape
+        pooled = ops.spatial_mean(out)                                            # [N, 2048]
+        fh, fw = ops.flat_hw(n)
+        p16 = ops.act_pack(pooled.view(1, fh, fw, cl), pro=0, prec=prec)
+        logits = ops.conv16(p16, packs['fc.weight'][0], ksize=1, bias=par['fc.bias'].detach().contiguous(), prec=prec).view(n, -1)
+        if counters:
+            torch._foreach_add_(counters, 1)
+        if need_grad:
+            ctx.net, ctx.par, ctx.packs, ctx.train = net, par, packs, train
+            ctx.stem = (cols, y0, st0, idx, (h0, w0))
+            ctx.blocks = saved_blocks
+            ctx.head = (p16, (hl, wl, cl), (fh, fw))
+            ctx.n = n
+        return logits
+
+    @staticmethod
+    def backward(ctx, d_logits):
+        net, par, packs, train = ctx.net, ctx.par, ctx.packs, ctx.train
+        prec = net.prec
+        f16 = prec == PREC_F16
+        frozen = not train
+        n = ctx.n
+        grads = {}
+
+        def bn_bwd(dA, y, st, name, **kw):
+            dx, dg, db, g = ops.norm_act_bwd(dA, y, par[name + '.weight'].detach(), st.mean, st.rstd, st.scale, st.shift, frozen=frozen,
+                                             amax=f16, **kw)
+            grads[name + '.weight'], grads[name + '.bias'] = dg, db
+            return dx, g
+
+        # ---- head
+        p16, (hl, wl, cl), (fh, fw) = ctx.head
+        dl16 = ops.act_pack(d_logits.contiguous().view(1, fh, fw, -1), prec=prec, grad=True)
+        dw, db = ops.conv_wgrad16(p16, dl16, ksize=1, prec=prec, bias_grad=True)
+        grads['fc.weight'], grads['fc.bias'] = dw.view(par['fc.weight'].shape), db
+        d_pooled = ops.conv16(dl16, packs['fc.weight'][1], ksize=1, prec=prec).view(n, cl)
+        d_out = ops.spatial_mean_bwd(d_pooled, hl, wl)                            # [N, hl, wl, 2048]
+        # ---- blocks, last to first
+        for (bname, cin, width, cout, stride, down), sv in zip(reversed(net._hip_blocks), reversed(ctx.blocks)):
+            xin16, y1, st1, a1, y2, st2, a2, y3, st3, xd16, yd, std, out, (h, w, ho, wo) = sv
+            # out = relu(bn3(y3) + skip): g = d_out * [out > 0] reaches bn3 and the skip branch alike
+            dy3, g = bn_bwd(d_out, y3, st3, bname + '.bn3', mask_mode=2, mask_src=out, want_g=True)
+            d16 = ops.act_pack(dy3, prec=prec, grad=True)
+            grads[bname + '.conv3.weight'] = _wgrad1x1(a2, d16, prec).view(par[bname + '.conv3.weight'].shape)
+            dA2 = _conv1x1(d16, packs[bname + '.conv3.weight'][1], prec).view(n, ho, wo, width)
+            dy2, _ = bn_bwd(dA2, y2, st2, bname + '.bn2')
+            d16 = ops.act_pack(dy2, prec=prec, grad=True)
+            if stride == 2:
+                d16 = ops.zero_stuff2_16(d16, h, w)                               # adjoint of the subsample of the full-resolution conv
+            cg = par[bname + '.conv2.weight'].shape[1]
+            grads[bname + '.conv2.weight'] = ops.gconv_wgrad16(a1, d16, cg, prec=prec)
+            dA1 = ops.gconv16(d16, packs[bname + '.conv2.weight'][1], prec=prec)
+            dy1, _ = bn_bwd(dA1, y1, st1, bname + '.bn1')
+            d16 = ops.act_pack(dy1, prec=prec, grad=True)
+            grads[bname + '.conv1.weight'] = _wgrad1x1(xin16, d16, prec).view(par[bname + '.conv1.weight'].shape)
+            if down:
+                dyd, _ = bn_bwd(g, yd, std, bname + '.downsample.1', mask_mode=1)
+                dd16 = ops.act_pack(dyd, prec=prec, grad=True)
+                grads[bname + '.downsample.0.weight'] = _wgrad1x1(xd16, dd16, prec).view(par[bname + '.downsample.0.weight'].shape)
+                d_xd = _conv1x1(dd16, packs[bname + '.downsample.0.weight'][1], prec)          # [P', cin]
+                if stride == 2:
+                    d_xin = _conv1x1(d16, packs[bname + '.conv1.weight'][1], prec).view(n, h, w, cin)
+                    ops.add_strided2(d_xin, d_xd.view(n, ho, wo, cin))
+                else:
+                    d_xin = _conv1x1(d16, packs[bname + '.conv1.weight'][1], prec, res=d_xd).view(n, h, w, cin)
+            else:
+                d_xin = _conv1x1(d16, packs[bname + '.conv1.weight'][1], prec, res=g).view(n, h, w, cin)
+            d_out = d_xin
+        # ---- stem
+        cols, y0, st0, idx, (h0, w0) = ctx.stem
+        dA0 = ops.maxpool_bwd(d_out, idx, h0, w0)
+        dy0, _ = bn_bwd(dA0, y0, st0, 'bn1')
+        d16 = ops.act_pack(dy0, prec=prec, grad=True)
+        grads['conv1.weight'] = _wgrad1x1(cols, d16, prec).view(par['conv1.weight'].shape)
+        ctx.blocks = ctx.stem = ctx.head = None
+        return (None, None) + tuple(grads.get(k) for k in net._hip_param_names)

@@ -697,3 +697,196 @@ def l1_bwd(a: Optional[Tensor], b: Optional[Tensor], grad_out: Tensor, coef: flo
                                _p(_amax_attach(da, amax)), _stream()), 'lp_l1_bwd')
     return da
 
+
+
+# ---- ResNeXt-50 identity encoder: BatchNorm statistics / backward, grouped 3x3 conv, stem, pooling (csrc/resnext.hip) -------------
+def flat_hw(p: int) -> Tuple[int, int]:
+    """(H, W) factorisation of P pixels for the 1x1 contractions (they do not care about the spatial structure): the widest W in
+    {16, 8, 4} with H >= 2"""
+    for w in (16, 8, 4):
+        if p % w == 0 and p // w >= 2:
+            return p // w, w
+    raise ValueError(f'{p} pixels cannot be arranged as H x W with W in (16, 8, 4), H >= 2')
+
+
+def flat16(a: Act16) -> Act16:
+    """the same operand planes viewed as ONE image of P = N*H*W pixels (for 1x1 convs)"""
+    c8 = a.hi.shape[-1]
+    p = a.hi.numel() // c8
+    h, w = flat_hw(p)
+    return Act16(a.hi.view(1, h, w, c8), None if a.lo is None else a.lo.view(1, h, w, c8), a.c, a.inv)
+
+
+def bn_train_stats(y: Tensor, gamma: Tensor, beta: Tensor, running_mean: Optional[Tensor], running_var: Optional[Tensor], momentum: float,
+                   eps: float):
+    """train-mode BatchNorm2d statistics of y [..., C] -> (mean, rstd, scale, shift) [C]; running statistics updated in place"""
+    _chk(y, 'y')
+    c = y.shape[-1]
+    p = y.numel() // c
+    out = torch.empty(4, c, dtype=torch.float32, device=y.device)
+    ws = torch.empty(_lib.lib().lp_bn_train_stats_workspace_bytes(p, c) // 4, dtype=torch.float32, device=y.device)
+    check(_lib.lib().lp_bn_train_stats(y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps, momentum, _p(running_mean), _p(running_var),
+                                       out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), ws.data_ptr(), p, c, _stream()),
+          'lp_bn_train_stats')
+    return out[0], out[1], out[2], out[3]
+
+
+def norm_act_bwd(dA: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, scale: Tensor, shift: Tensor, *, mask_mode: int = 0,
+                 mask_src: Optional[Tensor] = None, want_g: bool = False, act_hi: float = 0.0, frozen: bool = False, amax: bool = False):
+    """backward of act(BatchNorm(x)) over x [..., C] treated as [P][C] (per-channel statistics [C]):
+    -> (dx, dgamma [C], dbeta [C], g | None).  mask_mode 0: act = ReLU (act_hi = 6: ReLU6) of the layer's own affine; 1: no activation;
+    2: ReLU pattern taken from ``mask_src`` (the residual block's output).  ``want_g``: also return the masked incoming gradient."""
+    _chk(dA, 'dA'); _chk(x, 'x')
+    c = x.shape[-1]
+    p = x.numel() // c
+    assert dA.shape == x.shape, (dA.shape, x.shape)
+    dx = torch.empty_like(x)
+    dgb = torch.empty(2, c, dtype=torch.float32, device=x.device)
+    g = torch.empty_like(x) if want_g else None
+    ws = torch.empty(_lib.lib().lp_adain_bwd_workspace_bytes(1, p, c) // 4, dtype=torch.float32, device=x.device)
+    if mask_src is not None:
+        _chk(mask_src, 'mask_src'); assert mask_src.shape == x.shape
+    check(_lib.lib().lp_norm_act_bwd(dA.data_ptr(), x.data_ptr(), None, gamma.data_ptr(), c, mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(),
+                                     shift.data_ptr(), dx.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(), ws.data_ptr(), 1, p, 1, c, 0,
+                                     mask_mode, _p(mask_src), _p(g), float(act_hi), int(frozen), _p(_amax_attach(dx, amax)), _stream()),
+          'lp_norm_act_bwd')
+    return dx, dgb[0], dgb[1], g
+
+
+def pack_grouped(w: Tensor, mode: int, prec: int) -> WeightPack:
+    """w [C, cg, 3, 3] (grouped conv, C/cg groups) -> the [9][CP][64] image of the block-diagonal formulation (lp_gconv16_fwd)"""
+    _chk(w, 'w')
+    c, cg = w.shape[0], w.shape[1]
+    cp = _round_up(c, 128)
+    hi = torch.empty((9, cp, 64), dtype=torch.int16, device=w.device)
+    lo = torch.empty_like(hi) if prec == PREC_BF16X3 else None
+    check(_lib.lib().lp_pack_grouped(w.data_ptr(), hi.data_ptr(), _p(lo), c, cg, cp, mode, _f16(prec), _stream()), 'lp_pack_grouped')
+    return WeightPack(hi, lo, c, 64, cp, 64, 9)
+
+
+def gconv16(a: Act16, pack: WeightPack, *, prec: int, amax: bool = False) -> Tensor:
+    """grouped 3x3 conv (pad 1, stride 1) on operand planes a [N,H,W,C] -> y [N,H,W,C] fp32; with the mode-1 pack: the data gradient"""
+    n, h, w = a.nhw
+    c = a.c
+    assert c == pack.rows and a.hi.shape[3] == c, (a.hi.shape, pack.rows)
+    y = torch.empty((n, h, w, c), dtype=torch.float32, device=a.hi.device)
+    slots = _amax_attach(y, amax and prec == PREC_F16)
+    with _Timed('gconv', 2.0 * n * h * w * c * 64 * 9, (n, h, w, c, c, 3, 0, 0)):
+        check(_lib.lib().lp_gconv16_fwd(a.hi.data_ptr(), _p(a.lo), pack.hi.data_ptr(), _p(pack.lo), y.data_ptr(), _p(a.inv), n, h, w, c,
+                                        pack.rows_p, prec, _p(slots), _stream()), 'lp_gconv16_fwd')
+    return y
+
+
+def gconv_wgrad16(a: Act16, dy: Act16, group_size: int, *, prec: int, splits: Optional[int] = None) -> Tensor:
+    """weight gradient [C, cg, 3, 3] of the grouped 3x3 conv (a = the planes the forward consumed, dy = packed output gradient)"""
+    n, h, w = dy.nhw
+    c = dy.c
+    assert a.nhw == dy.nhw and a.c == c
+    if splits is None:
+        splits = max(1, min(512 // max(1, c // 64), (n * h * w + 127) // 128))
+    ws = torch.empty(_lib.lib().lp_gconv_wgrad_workspace_bytes(c, splits) // 4, dtype=torch.float32, device=dy.hi.device)
+    dw = torch.empty((c, group_size, 3, 3), dtype=torch.float32, device=dy.hi.device)
+    with _Timed('gconv_wgrad', 2.0 * n * h * w * c * 64 * 9, (n, h, w, c, c, 3, 0, 0)):
+        check(_lib.lib().lp_gconv16_wgrad(a.hi.data_ptr(), _p(a.lo), dy.hi.data_ptr(), _p(dy.lo), dw.data_ptr(), ws.data_ptr(), n, h, w, c,
+                                          group_size, splits, prec, _p(dy.inv), _stream()), 'lp_gconv16_wgrad')
+    return dw
+
+
+def im2col_planes(x: Tensor, ksize: int, stride: int, pad: int, prec: int) -> Act16:
+    """x [N,C,H,W] NCHW fp32 -> operand rows [N,Ho,Wo,K8] (K = C*k*k in nn.Conv2d weight order): a k x k conv becomes a 1x1 contraction"""
+    _chk(x, 'x')
+    n, c, h, w = x.shape
+    ho, wo = (h + 2 * pad - ksize) // stride + 1, (w + 2 * pad - ksize) // stride + 1
+    k = c * ksize * ksize
+    hi, lo = _alloc16(n, ho, wo, k, prec, x.device)
+    check(_lib.lib().lp_im2col_planes(x.data_ptr(), hi.data_ptr(), _p(lo), n, c, h, w, ksize, stride, pad, prec, _stream()), 'lp_im2col_planes')
+    return Act16(hi, lo, k, None)
+
+
+def bn_relu_maxpool(y: Tensor, scale: Tensor, shift: Tensor, prec: int, want_idx: bool = True):
+    """MaxPool2d(3, 2, 1)(relu(y*scale[c]+shift[c])), y [N,H,W,C] -> (out fp32, its operand planes, argmax bytes | None)"""
+    _chk(y, 'y')
+    n, h, w, c = y.shape
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    out = torch.empty((n, ho, wo, c), dtype=torch.float32, device=y.device)
+    hi, lo = _alloc16(n, ho, wo, c, prec, y.device)
+    idx = torch.empty((n, ho, wo, c), dtype=torch.uint8, device=y.device) if want_idx else None
+    check(_lib.lib().lp_bn_relu_maxpool_fwd(y.data_ptr(), scale.data_ptr(), shift.data_ptr(), out.data_ptr(), hi.data_ptr(), _p(lo), _p(idx),
+                                            n, h, w, c, prec, _stream()), 'lp_bn_relu_maxpool_fwd')
+    return out, Act16(hi, lo, c, None), idx
+
+
+def maxpool_bwd(dout: Tensor, idx: Tensor, h: int, w: int) -> Tensor:
+    _chk(dout, 'dout')
+    n, ho, wo, c = dout.shape
+    dA = torch.empty((n, h, w, c), dtype=torch.float32, device=dout.device)
+    check(_lib.lib().lp_maxpool_bwd(dout.data_ptr(), idx.data_ptr(), dA.data_ptr(), n, h, w, c, _stream()), 'lp_maxpool_bwd')
+    return dA
+
+
+def bn_add_act(y: Tensor, scale: Tensor, shift: Tensor, res: Optional[Tensor] = None, res_scale: Optional[Tensor] = None,
+               res_shift: Optional[Tensor] = None, relu: bool = True, prec: Optional[int] = None):
+    """out = relu?(y*scale[c]+shift[c] + (res | res*res_scale[c]+res_shift[c])) over [..., C]; with ``prec`` -> (out, Act16)"""
+    _chk(y, 'y')
+    c = y.shape[-1]
+    p = y.numel() // c
+    out = torch.empty_like(y)
+    hi = lo = None
+    if prec is not None:
+        hi = torch.empty(y.shape, dtype=torch.int16, device=y.device)
+        lo = torch.empty_like(hi) if prec == PREC_BF16X3 else None
+    if res is not None:
+        _chk(res, 'res'); assert res.shape == y.shape, (res.shape, y.shape)
+    check(_lib.lib().lp_bn_add_act(y.data_ptr(), scale.data_ptr(), shift.data_ptr(), _p(res), _p(res_scale), _p(res_shift), out.data_ptr(),
+                                   _p(hi), _p(lo), p, c, int(relu), prec if prec is not None else 0, _stream()), 'lp_bn_add_act')
+    return out if prec is None else (out, Act16(hi, lo, c, None))
+
+
+def subsample2(x: Tensor) -> Tensor:
+    """x [N,H,W,C] -> x[:, ::2, ::2] contiguous (fp32 or int16 planes with C*itemsize % 16 == 0)"""
+    n, h, w, c = x.shape
+    assert x.is_contiguous()
+    out = torch.empty((n, (h + 1) // 2, (w + 1) // 2, c), dtype=x.dtype, device=x.device)
+    check(_lib.lib().lp_subsample2(x.data_ptr(), out.data_ptr(), n, h, w, c * x.element_size(), _stream()), 'lp_subsample2')
+    return out
+
+
+def subsample2_16(a: Act16) -> Act16:
+    return Act16(subsample2(a.hi), None if a.lo is None else subsample2(a.lo), a.c, a.inv)
+
+
+def zero_stuff2_16(a: Act16, h: int, w: int) -> Act16:
+    """adjoint of ``subsample2`` on operand planes: [N,ceil(h/2),ceil(w/2),C8] -> [N,h,w,C8], zeros at the odd positions"""
+    n, hs, ws_, c8 = a.hi.shape
+    assert hs == (h + 1) // 2 and ws_ == (w + 1) // 2
+
+    def one(t):
+        out = torch.empty((n, h, w, c8), dtype=t.dtype, device=t.device)
+        check(_lib.lib().lp_zero_stuff2(t.data_ptr(), out.data_ptr(), n, h, w, c8 * t.element_size(), _stream()), 'lp_zero_stuff2')
+        return out
+    return Act16(one(a.hi), None if a.lo is None else one(a.lo), a.c, a.inv)
+
+
+def add_strided2(d: Tensor, s: Tensor) -> Tensor:
+    """d[:, ::2, ::2] += s, in place (fp32 NHWC)"""
+    _chk(d, 'd'); _chk(s, 's')
+    n, h, w, c = d.shape
+    assert s.shape == (n, (h + 1) // 2, (w + 1) // 2, c)
+    check(_lib.lib().lp_add_strided2(d.data_ptr(), s.data_ptr(), n, h, w, c, _stream()), 'lp_add_strided2')
+    return d
+
+
+def spatial_mean(x: Tensor) -> Tensor:
+    _chk(x, 'x')
+    n, h, w, c = x.shape
+    out = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    check(_lib.lib().lp_spatial_mean_fwd(x.data_ptr(), out.data_ptr(), n, h * w, c, _stream()), 'lp_spatial_mean_fwd')
+    return out
+
+
+def spatial_mean_bwd(g: Tensor, h: int, w: int) -> Tensor:
+    _chk(g, 'g')
+    n, c = g.shape
+    dx = torch.empty((n, h, w, c), dtype=torch.float32, device=g.device)
+    check(_lib.lib().lp_spatial_mean_bwd(g.data_ptr(), dx.data_ptr(), n, h * w, c, _stream()), 'lp_spatial_mean_bwd')
+    return dx

@@ -802,6 +802,7 @@ class AvgPool2Fn(torch.autograd.Function):
         """``emit`` = (prec, holder list): the pool launch also writes the operand planes of y for the conv that follows"""
         ctx.save_for_backward(x)
         ctx.relu_in = relu_in
+        ctx.f16 = (default_prec() if emit is None else emit[0]) == PREC_F16      # the mode of the module that owns this pool
         if emit is None:
             return ops.avgpool2_fwd(x, relu_in)
         y, o16 = ops.avgpool2_fwd(x, relu_in, out16_prec=emit[0])
@@ -811,7 +812,7 @@ class AvgPool2Fn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
-        return ops.avgpool2_bwd(dy.contiguous(), x, ctx.relu_in, amax=default_prec() == PREC_F16), None, None
+        return ops.avgpool2_bwd(dy.contiguous(), x, ctx.relu_in, amax=ctx.f16), None, None
 
 
 class L1Fn(torch.autograd.Function):
@@ -824,11 +825,12 @@ class L1Fn(torch.autograd.Function):
             return ops.l1_sum(a, b, relu_in, 1.0 / a.numel())
         term, ctx.sgn = ops.l1_sum(a, b, relu_in, 1.0 / a.numel(), want_sign=True)      # the backward reads the 1-byte sign pattern,
         ctx.shape = tuple(a.shape)                                                        # not a and b again
+        ctx.f16 = default_prec() == PREC_F16
         return term
 
     @staticmethod
     def backward(ctx, g):
-        return ops.l1_bwd(None, None, g, 1.0 / ctx.sgn.numel(), False, sign=ctx.sgn, shape=ctx.shape, amax=default_prec() == PREC_F16), None, None
+        return ops.l1_bwd(None, None, g, 1.0 / ctx.sgn.numel(), False, sign=ctx.sgn, shape=ctx.shape, amax=ctx.f16), None, None
 
 
 def hip_l1(a, b, relu_in=False):
@@ -847,6 +849,7 @@ class L1TapFn(torch.autograd.Function):
             return a.view_as(a), ops.l1_sum(a, b, relu_in, 1.0 / a.numel())
         term, ctx.sgn = ops.l1_sum(a, b, relu_in, 1.0 / a.numel(), want_sign=True)
         ctx.shape = tuple(a.shape)
+        ctx.f16 = default_prec() == PREC_F16
         return a.view_as(a), term
 
     @staticmethod
@@ -855,7 +858,7 @@ class L1TapFn(torch.autograd.Function):
             return g_next, None, None
         add = None if g_next is None else g_next.contiguous()
         return ops.l1_bwd(None, None, g_loss, 1.0 / ctx.sgn.numel(), False, add=add, sign=ctx.sgn, shape=ctx.shape,
-                          amax=default_prec() == PREC_F16), None, None
+                          amax=ctx.f16), None, None
 
 
 def hip_l1_tap(a, b, relu_in=False):

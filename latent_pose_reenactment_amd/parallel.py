@@ -20,6 +20,23 @@ import torch
 import torch.distributed as dist
 
 
+def flat_broadcast(tensors, src: int = 0):
+    """broadcast many tensors from ``src`` with one collective per (dtype, device): gather into a flat buffer, broadcast, scatter
+    back with a multi-tensor copy"""
+    groups = {}
+    for t in tensors:
+        groups.setdefault((t.dtype, t.device), []).append(t)
+    with torch.no_grad():
+        for ts in groups.values():
+            flat = torch.cat([t.reshape(-1) for t in ts])
+            dist.broadcast(flat, src)
+            views, off = [], 0
+            for t in ts:
+                views.append(flat[off:off + t.numel()].view_as(t))
+                off += t.numel()
+            torch._foreach_copy_(ts, views)
+
+
 class _Bucket:
     def __init__(self, params: Iterable[torch.nn.Parameter], optimizer=None):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
@@ -104,10 +121,17 @@ class GradReducer:
         self.g_bucket = _Bucket(g_side, optimizer_G)
         self.d_bucket = _Bucket(training_module.discriminator.parameters(), optimizer_D)
         self.discriminator = training_module.discriminator
+        self._checked_b = None
         if broadcast:        # apex Reducer broadcasts rank 0's parameters at construction
-            with torch.no_grad():
-                for t in training_module.parameters():      # parameters only, like apex (buffers/EMA stay rank-local)
-                    dist.broadcast(t, 0)
+            # ONE flat collective per dtype instead of one per tensor (hundreds of tiny broadcasts).  Parameters only, like apex
+            # (buffers / EMA stay rank-local) -- plus the (u, v) power-iteration buffers of the label embedding: the row-sparse
+            # exchange below rebuilds the rank-1 term of its gradient from THIS rank's u, v, which is only the averaged gradient if
+            # every rank holds the same vectors (same start + identical weights after every all-reduce => they stay identical).
+            tensors = [t.data for t in training_module.parameters()]
+            emb = getattr(training_module.discriminator, 'embed', None)
+            if emb is not None and hasattr(emb, 'weight_u'):
+                tensors += [emb.weight_u, emb.weight_v]
+            flat_broadcast(tensors, 0)
 
     def reduce_generator_side(self, async_op: bool = False):
         self.g_bucket.start(self.world_size, async_op)
@@ -121,19 +145,34 @@ class GradReducer:
             self.d_bucket.start(self.world_size, async_op)
             return
         (off, n), (label, rows, coef, u, v) = sparse
-        self.d_bucket.start(self.world_size, True, skip=(off, n))
-        # row-sparse exchange of the label-embedding gradient: one small all-reduce of a zero-padded [world, B*E + B + 1] buffer
         b, e = rows.shape
-        mine = torch.cat([rows.reshape(-1), label.to(rows.dtype), coef.reshape(1)])
-        buf = torch.zeros(self.world_size, mine.numel(), dtype=rows.dtype, device=rows.device)
-        buf[dist.get_rank()] = mine
+        if self._checked_b != b:
+            # the exchange buffers are [world, B * E + 1]: every rank must bring the same B (a ragged last batch would mis-size the
+            # collective and hang).  Checked once per batch size; unequal sizes fall back to the dense all-reduce.
+            mm = torch.tensor([b, -b], dtype=torch.int64, device=rows.device)
+            dist.all_reduce(mm, op=dist.ReduceOp.MAX)
+            self._equal_b = bool(mm[0].item() == b and -mm[1].item() == b)
+            self._checked_b = b
+        if not self._equal_b:
+            self.d_bucket.start(self.world_size, async_op)
+            return
+        self.d_bucket.start(self.world_size, True, skip=(off, n))
+        # row-sparse exchange of the label-embedding gradient: one small all-reduce of a zero-padded fp32 [world, B*E + 1] buffer
+        # (gradient rows + rank-1 coefficient) and one of an int64 [world, B] buffer (the labels: exact for any label value)
+        rank = dist.get_rank()
+        buf = torch.zeros(self.world_size, b * e + 1, dtype=rows.dtype, device=rows.device)
+        buf[rank, :b * e] = rows.reshape(-1)
+        buf[rank, b * e] = coef.reshape(())
+        lab = torch.zeros(self.world_size, b, dtype=torch.int64, device=rows.device)
+        lab[rank] = label.to(torch.int64)
         dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        dist.all_reduce(lab, op=dist.ReduceOp.SUM)
         grad = self.d_bucket.arena[off:off + n].view(-1, e)
         inv = 1.0 / self.world_size
         grad.zero_()
         grad.addmm_((u * (-(buf[:, -1].sum() * inv)))[:, None], v[None, :])
         for r in range(self.world_size):                              # fixed order: every rank rebuilds the same bits
-            grad.index_add_(0, buf[r, b * e:b * e + b].round().long(), buf[r, :b * e].view(b, e) * inv)
+            grad.index_add_(0, lab[r], buf[r, :b * e].view(b, e) * inv)
         if not async_op:
             self.d_bucket.finish(self.world_size)
 

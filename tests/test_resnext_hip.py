@@ -1,0 +1,307 @@
+"""GPU parity of the ResNeXt-50 identity encoder's HIP path (E1; embedders/unsupervised_pose_separate_embResNeXt_segmentation.py:26,37-54):
+  * every new kernel against its plain-torch fp64 restatement (tests/emu_ops.py) on the same inputs;
+  * the whole network, forward AND backward, train- and eval-mode BatchNorm, against the stock nn.Module in fp64 on the same device.
+Tolerances (rel-L2): bf16x3 3e-5 per op (fp32-class), f16 1e-3 per op (2^-12 operands); whole network: stated per test."""
+import copy
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'latent_pose_reenactment_amd'))
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+pytestmark = pytest.mark.gpu
+
+TOL = {0: 1e-2, 1: 3e-5, 2: 1e-3}
+
+
+def _ops():
+    from latent_pose_reenactment_amd import hipops
+    return hipops
+
+
+def rel(a, b):
+    a = a.detach().double().cpu(); b = b.detach().double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def report(name, err, tol):
+    print(f'[parity] {name}: rel-L2 {err:.3e} (tol {tol:.0e})')
+    assert err < tol, f'{name}: rel-L2 {err:.3e} >= {tol}'
+
+
+def decode(a, prec):
+    """operand planes -> fp64 values (x 1/scale for scaled fp16 gradient operands)"""
+    if prec == 2:
+        v = a.hi.view(torch.float16).double()
+    else:
+        v = a.hi.view(torch.bfloat16).double()
+        if prec == 1:
+            v = v + a.lo.view(torch.bfloat16).double()
+    if a.inv is not None:
+        v = v * a.inv.double()
+    return v[..., :a.c]
+
+
+def e16(t):
+    import emu_ops
+    return emu_ops.Act16(t, None, t.shape[-1], None)
+
+
+@pytest.mark.parametrize('prec', [1, 2])
+def test_im2col_stem_rows(prec):
+    import emu_ops
+    ops = _ops()
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(3, 3, 40, 56, generator=g).cuda()
+    a = ops.im2col_planes(x, 7, 2, 3, prec)
+    ref = emu_ops.im2col_planes(x.double(), 7, 2, 3, prec)
+    assert a.hi.shape == (3, 20, 28, 152) and a.c == 147
+    report(f'im2col 7x7/2 prec{prec}', rel(decode(a, prec), ref.hi), 3e-6 if prec == 1 else 3e-4)
+    pad = a.hi[..., 147:]
+    assert int(pad.abs().max()) == 0
+
+
+@pytest.mark.parametrize('p,c', [(4096, 64), (1000, 256), (64, 2048), (70000, 128)])
+def test_bn_train_stats(p, c):
+    import emu_ops
+    ops = _ops()
+    g = torch.Generator().manual_seed(p + c)
+    y = (torch.randn(p, c, generator=g) * torch.rand(c, generator=g) * 3 + torch.randn(c, generator=g) * 5).cuda()
+    gamma, beta = (torch.rand(c, generator=g) + 0.5).cuda(), torch.randn(c, generator=g).cuda()
+    rm, rv = torch.randn(c, generator=g).cuda(), (torch.rand(c, generator=g) + 0.5).cuda()
+    rm_ref, rv_ref = rm.double().clone(), rv.double().clone()
+    out = ops.bn_train_stats(y, gamma, beta, rm, rv, 0.1, 1e-5)
+    ref = emu_ops.bn_train_stats(y.double(), gamma.double(), beta.double(), rm_ref, rv_ref, 0.1, 1e-5)
+    for nm, a, b in zip(('mean', 'rstd', 'scale', 'shift'), out, ref):
+        report(f'bn_train_stats[{p}x{c}].{nm}', rel(a, b), 5e-6)
+    report('running_mean', rel(rm, rm_ref), 1e-6)
+    report('running_var', rel(rv, rv_ref), 5e-6)
+
+
+@pytest.mark.parametrize('mode', ['relu', 'relu6', 'none', 'src', 'frozen'])
+def test_norm_act_bwd_modes(mode):
+    import emu_ops
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    n, h, w, c = 4, 12, 20, 64
+    x = torch.randn(n, h, w, c, generator=g).cuda()
+    dA = torch.randn(n, h, w, c, generator=g).cuda()
+    src = torch.randn(n, h, w, c, generator=g).cuda()
+    gamma, beta = (torch.rand(c, generator=g) + 0.5).cuda(), (torch.randn(c, generator=g) * 0.3).cuda()
+    mean, rstd, scale, shift = emu_ops.bn_train_stats(x.double(), gamma.double(), beta.double(), None, None, 0.1, 1e-5)
+    if mode == 'relu6':
+        scale, shift = scale * 4, shift * 4 + 2          # so that the upper clamp is active for a good share of the elements
+    st32 = [t.float().contiguous() for t in (mean, rstd, scale, shift)]
+    kw = dict(mask_mode={'relu': 0, 'relu6': 0, 'none': 1, 'src': 2, 'frozen': 0}[mode], mask_src=src if mode == 'src' else None,
+              want_g=mode == 'src', act_hi=6.0 if mode == 'relu6' else 0.0, frozen=mode == 'frozen')
+    dx, dg, db, gm = ops.norm_act_bwd(dA, x, gamma, *st32, amax=True, **kw)
+    kw64 = dict(kw, mask_src=None if kw['mask_src'] is None else src.double())
+    rdx, rdg, rdb, rg = emu_ops.norm_act_bwd(dA.double(), x.double(), gamma.double(), mean, rstd, scale, shift, **kw64)
+    report(f'norm_act_bwd[{mode}].dx', rel(dx, rdx), 2e-5)
+    report(f'norm_act_bwd[{mode}].dgamma', rel(dg, rdg), 2e-5)
+    report(f'norm_act_bwd[{mode}].dbeta', rel(db, rdb), 2e-5)
+    if gm is not None:
+        report(f'norm_act_bwd[{mode}].g', rel(gm, rg), 1e-7)
+    slots, ver = dx._lp_amax
+    assert abs(float(slots.max()) - float(dx.abs().max())) <= 1e-6 * float(dx.abs().max())
+
+
+GCASES = [(2, 16, 16, 128, 4), (8, 8, 8, 1024, 32), (3, 12, 20, 256, 8), (1, 32, 32, 512, 16), (8, 4, 4, 1024, 32)]
+
+
+@pytest.mark.parametrize('prec', [1, 2])
+@pytest.mark.parametrize('case', GCASES)
+def test_grouped_conv_fwd_dgrad_wgrad(case, prec):
+    import emu_ops
+    ops = _ops()
+    n, h, w, c, cg = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(n, h, w, c, generator=g).cuda()
+    wt = (torch.randn(c, cg, 3, 3, generator=g) / (cg * 9) ** 0.5).cuda()
+    dy = (torch.randn(n, h, w, c, generator=g) * 1e-3).cuda()
+    a = ops.act_pack(x, pro=0, prec=prec)
+    y = ops.gconv16(a, ops.pack_grouped(wt, 0, prec), prec=prec)
+    ry = emu_ops.gconv16(e16(x.double()), emu_ops.Pack(wt.double(), 0))
+    report(f'gconv fwd {case} prec{prec}', rel(y, ry), TOL[prec])
+    d16 = ops.act_pack(dy, prec=prec, grad=True)
+    dx = ops.gconv16(d16, ops.pack_grouped(wt, 1, prec), prec=prec)
+    rdx = emu_ops.gconv16(e16(dy.double()), emu_ops.Pack(wt.double(), 1))
+    report(f'gconv dgrad {case} prec{prec}', rel(dx, rdx), TOL[prec])
+    dw = ops.gconv_wgrad16(a, d16, cg, prec=prec)
+    rdw = emu_ops.gconv_wgrad16(e16(x.double()), e16(dy.double()), cg)
+    report(f'gconv wgrad {case} prec{prec}', rel(dw, rdw), TOL[prec])
+
+
+@pytest.mark.parametrize('prec', [1, 2])
+def test_grouped_conv_stride2_via_subsample_and_zero_stuffing(prec):
+    """the stride-2 grouped conv (first block of layer2..4): full-resolution conv + pick; gradients through zero stuffing"""
+    import torch.nn.functional as F
+    ops = _ops()
+    n, h, w, c, cg = 2, 16, 16, 256, 8
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(n, h, w, c, generator=g).cuda()
+    wt = (torch.randn(c, cg, 3, 3, generator=g) / (cg * 9) ** 0.5).cuda()
+    dy = torch.randn(n, h // 2, w // 2, c, generator=g).cuda()
+    xr = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    wr = wt.double().requires_grad_(True)
+    yr = F.conv2d(xr, wr, stride=2, padding=1, groups=c // cg)
+    (yr * dy.double().permute(0, 3, 1, 2)).sum().backward()
+    a = ops.act_pack(x, pro=0, prec=prec)
+    y = ops.subsample2(ops.gconv16(a, ops.pack_grouped(wt, 0, prec), prec=prec))
+    report(f'gconv stride 2 fwd prec{prec}', rel(y, yr.permute(0, 2, 3, 1)), TOL[prec])
+    d16 = ops.zero_stuff2_16(ops.act_pack(dy, prec=prec, grad=True), h, w)
+    dx = ops.gconv16(d16, ops.pack_grouped(wt, 1, prec), prec=prec)
+    report(f'gconv stride 2 dgrad prec{prec}', rel(dx, xr.grad.permute(0, 2, 3, 1)), TOL[prec])
+    dw = ops.gconv_wgrad16(a, d16, cg, prec=prec)
+    report(f'gconv stride 2 wgrad prec{prec}', rel(dw, wr.grad), TOL[prec])
+
+
+@pytest.mark.parametrize('prec', [1, 2])
+def test_bn_relu_maxpool_fwd_bwd(prec):
+    import emu_ops
+    ops = _ops()
+    g = torch.Generator().manual_seed(2)
+    n, h, w, c = 3, 22, 30, 64
+    y = torch.randn(n, h, w, c, generator=g).cuda()
+    sc, sh = (torch.rand(c, generator=g) + 0.5).cuda(), (torch.randn(c, generator=g) * 0.3).cuda()
+    out, o16, idx = ops.bn_relu_maxpool(y, sc, sh, prec)
+    rout, _, ridx = emu_ops.bn_relu_maxpool(y.double(), sc.double(), sh.double(), prec)
+    report('maxpool fwd', rel(out, rout), 1e-6)
+    report('maxpool planes', rel(decode(o16, prec), rout), 3e-6 if prec == 1 else 3e-4)
+    d = torch.randn(out.shape, generator=g).cuda()
+    dA = ops.maxpool_bwd(d, idx, h, w)
+    rdA = emu_ops.maxpool_bwd(d.double(), ridx, h, w)
+    # ties at 0 (all-negative windows after the ReLU) may pick different positions; their gradient is zeroed by the ReLU backward anyway
+    act = torch.relu(y.double() * sc.double() + sh.double()) > 0
+    report('maxpool bwd (on active units)', rel(dA * act, rdA * act), 1e-6)
+
+
+@pytest.mark.parametrize('prec', [1, 2])
+@pytest.mark.parametrize('variant', ['identity', 'downsample', 'plain'])
+def test_bn_add_act(variant, prec):
+    import emu_ops
+    ops = _ops()
+    g = torch.Generator().manual_seed(4)
+    shp = (2, 9, 7, 256)
+    y, res = torch.randn(shp, generator=g).cuda(), torch.randn(shp, generator=g).cuda()
+    v = [(torch.rand(256, generator=g) + 0.5).cuda() if i % 2 == 0 else torch.randn(256, generator=g).cuda() for i in range(4)]
+    args = dict(identity=(res, None, None), downsample=(res, v[2], v[3]), plain=(None, None, None))[variant]
+    out, o16 = ops.bn_add_act(y, v[0], v[1], *args, relu=variant != 'plain', prec=prec)
+    rout = emu_ops.bn_add_act(y.double(), v[0].double(), v[1].double(), *[None if t is None else t.double() for t in args], relu=variant != 'plain')
+    report(f'bn_add_act[{variant}]', rel(out, rout), 1e-6)
+    report(f'bn_add_act[{variant}] planes', rel(decode(o16, prec), rout), 3e-6 if prec == 1 else 3e-4)
+
+
+def test_stride2_plumbing_and_pooling():
+    import emu_ops
+    ops = _ops()
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(3, 10, 14, 64, generator=g).cuda()
+    assert torch.equal(ops.subsample2(x), x[:, ::2, ::2].contiguous())
+    a = ops.act_pack(x, pro=0, prec=1)
+    s = ops.subsample2_16(a)
+    assert torch.equal(s.hi, a.hi[:, ::2, ::2].contiguous()) and torch.equal(s.lo, a.lo[:, ::2, ::2].contiguous())
+    z = ops.zero_stuff2_16(s, 10, 14)
+    ref = torch.zeros_like(a.hi); ref[:, ::2, ::2] = s.hi
+    assert torch.equal(z.hi, ref)
+    d = torch.randn(3, 10, 14, 64, generator=g).cuda()
+    sm = torch.randn(3, 5, 7, 64, generator=g).cuda()
+    want = d.clone(); want[:, ::2, ::2] += sm
+    assert torch.equal(ops.add_strided2(d, sm), want)
+    report('spatial_mean', rel(ops.spatial_mean(x), x.double().mean(dim=(1, 2))), 1e-6)
+    gm = torch.randn(3, 64, generator=g).cuda()
+    report('spatial_mean_bwd', rel(ops.spatial_mean_bwd(gm, 10, 14), emu_ops.spatial_mean_bwd(gm.double(), 10, 14)), 1e-6)
+
+
+@pytest.mark.parametrize('prec', [1, 2])
+def test_bn_relu_pack_and_flat_1x1_contraction(prec):
+    """conv -> BN -> ReLU -> conv as the embedder runs it: lp_act_pack pro 4 on a per-channel affine, then the 1x1 contraction on the
+    pixels flattened to one image, its data gradient with a residual, and its weight gradient"""
+    import emu_ops
+    ops = _ops()
+    g = torch.Generator().manual_seed(8)
+    n, h, w, cin, cout = 8, 8, 8, 256, 128
+    y = torch.randn(n, h, w, cin, generator=g).cuda()
+    sc, sh = (torch.rand(cin, generator=g) + 0.5).cuda(), (torch.randn(cin, generator=g) * 0.3).cuda()
+    wt = (torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5).cuda()
+    a = ops.act_pack(y, pro=4, scale=sc, shift=sh, prec=prec)
+    ra = emu_ops.act_pack(y.double(), pro=4, scale=sc.double(), shift=sh.double())
+    report('act_pack pro 4', rel(decode(a, prec), ra.hi), 3e-6 if prec == 1 else 3e-4)
+    a5 = ops.act_pack(y, pro=5, scale=sc, shift=sh, prec=prec)
+    report('act_pack pro 5', rel(decode(a5, prec), y.double() * sc.double() + sh.double()), 3e-6 if prec == 1 else 3e-4)
+    fa = ops.flat16(a)
+    assert fa.hi.shape == (1, 32, 16, cin)
+    out = ops.conv16(fa, ops.pack_weights(wt, 0, prec), ksize=1, prec=prec).view(n, h, w, cout)
+    rout = emu_ops.conv16(ra, emu_ops.Pack(wt.double(), 0), ksize=1)
+    report('flat 1x1 fwd', rel(out, rout), TOL[prec])
+    dy = (torch.randn(n, h, w, cout, generator=g) * 1e-2).cuda()
+    res = torch.randn(n, h, w, cin, generator=g).cuda() * 1e-2
+    d16 = ops.act_pack(dy, prec=prec, grad=True)
+    dx = ops.conv16(ops.flat16(d16), ops.pack_weights(wt, 1, prec), ksize=1, res=res.view(1, 32, 16, cin), prec=prec).view(n, h, w, cin)
+    rdx = emu_ops.conv16(e16(dy.double()), emu_ops.Pack(wt.double(), 1), ksize=1, res=res.double())
+    report('flat 1x1 dgrad + res', rel(dx, rdx), TOL[prec])
+    dw = ops.conv_wgrad16(fa, ops.flat16(d16), ksize=1, prec=prec)
+    report('flat 1x1 wgrad', rel(dw, emu_ops.conv_wgrad16(ra, e16(dy.double()), ksize=1)), TOL[prec])
+
+
+def _nets(num_classes, seed):
+    from embedders.backbones import resnext50_32x4d
+    torch.manual_seed(seed)
+    m = resnext50_32x4d(num_classes)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.weight.data.uniform_(0.5, 1.5); mod.bias.data.uniform_(-0.3, 0.3)
+            mod.running_mean.uniform_(-0.2, 0.2); mod.running_var.uniform_(0.5, 1.5)
+    return m.cuda(), copy.deepcopy(m).double().cuda()
+
+
+@pytest.mark.parametrize('prec_name,train,size', [('bf16x3', True, 128), ('bf16x3', False, 64), ('f16', True, 128), ('f16', False, 128)])
+def test_resnext50_forward_backward_vs_fp64(monkeypatch, prec_name, train, size):
+    """whole network through the HIP path vs the stock layers in fp64 (same device): logits, EVERY parameter gradient, BatchNorm buffers.
+    bf16x3 is held to fp32-class figures; f16 (2^-12 operands through 53 renormalised layers) to its measured class -- both printed."""
+    from embedders import backbones
+    monkeypatch.setenv('LP_PREC_E', prec_name)
+    m, ref = _nets(32, 7)
+    m.train(train); ref.train(train)
+    x = torch.rand(8, 3, size, size, device='cuda')
+    r = torch.randn(8, 32, device='cuda')
+    y = m(x)
+    assert m.__dict__.get('_hip_param_names') is not None, 'the HIP path did not run'
+    (y * r).sum().backward()
+    backbones.set_hip_forward(False)
+    try:
+        yr = ref(x.double())
+        (yr * r.double()).sum().backward()
+    finally:
+        backbones.set_hip_forward(True)
+    errs = {k: rel(p.grad, q.grad) for (k, p), (_, q) in zip(m.named_parameters(), ref.named_parameters())}
+    berr = {k: rel(b.double(), q) for (k, b), (_, q) in zip(m.named_buffers(), ref.named_buffers()) if b.dtype.is_floating_point}
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    e_out, e_g, e_b = rel(y, yr), max(errs.values()), max(berr.values())
+    tot = (sum((p.grad.double().cpu() - q.grad.cpu()).norm() ** 2 for p, q in zip(m.parameters(), ref.parameters())) /
+           sum(q.grad.cpu().norm() ** 2 for q in ref.parameters())) ** 0.5
+    print(f'[parity] resnext50 {prec_name} train={train} {size}px: logits {e_out:.2e}, all-gradients {float(tot):.2e}, worst tensor {e_g:.2e}, '
+          f'buffers {e_b:.2e}; worst: {[(k, f"{v:.1e}") for k, v in worst]}')
+    tol_out, tol_g = (2e-5, 2e-4) if prec_name == 'bf16x3' else (3e-3, 2e-2)
+    assert e_out < tol_out and float(tot) < tol_g and e_b < (1e-5 if prec_name == 'bf16x3' else 1e-3), (e_out, float(tot), e_b)
+    for (k, b), (_, q) in zip(m.named_buffers(), ref.named_buffers()):
+        if not b.dtype.is_floating_point:
+            assert int(b) == int(q), k
+
+
+def test_embedder_plugin_uses_hip_identity_encoder(monkeypatch):
+    """the plugin call site (get_identity_embedding: B x K frames -> embeds) reaches the HIP function, and the frame mean is differentiable"""
+    import argparse
+    from embedders.unsupervised_pose_separate_embResNeXt_segmentation import Wrapper as EW
+    monkeypatch.setenv('LP_PREC_E', 'bf16x3')
+    torch.manual_seed(0)
+    E = EW.get_net(argparse.Namespace(embed_channels=16, pose_embedding_size=8, average_function='sum', device='cuda')).train()
+    d = {'enc_rgbs': torch.rand(2, 4, 3, 64, 64, device='cuda')}
+    E.get_identity_embedding(d)
+    assert d['embeds'].shape == (2, 16) and d['embeds_elemwise'].shape == (2, 4, 16)
+    d['embeds'].sum().backward()
+    assert E.identity_encoder.__dict__.get('_hip_param_names') is not None
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in E.identity_encoder.parameters())
