@@ -170,6 +170,16 @@ int lp_bn_finalize(const float* stats_part, int rows, const float* gamma, const 
 int lp_bn_stats(const float* y, const float* gamma, const float* beta, float* running_mean, float* running_var, float* scale,
                 float* shift, float* workspace, long long P, int C, float eps, float momentum, void* stream);
 
+/* MobileNetV2 backward (meta-training trains the pose encoder, runners/holycow.py:34-41): the depthwise 3x3 conv's data gradient
+ * w.r.t. its activated input (da [N][H][W][C] from dy [N][Ho][Wo][C]) and weight gradient dw [C][3][3] (the activation
+ * relu6(x*in_scale[c]+in_shift[c]) of the raw input x is recomputed on load, in_scale NULL: identity);
+ * workspace: lp_dwconv3x3_wgrad_workspace_bytes(C).  The 1x1 convs, BatchNorm and ReLU6 backward run on lp_conv16_fwd /
+ * lp_conv16_wgrad / lp_norm_act_bwd (act_hi = 6). */
+int lp_dwconv3x3_dgrad(const float* dy, const float* w, float* da, int N, int H, int W, int C, int stride, void* stream);
+long long lp_dwconv3x3_wgrad_workspace_bytes(int C);
+int lp_dwconv3x3_wgrad(const float* x, const float* in_scale, const float* in_shift, const float* dy, float* dw, float* workspace,
+                       int N, int H, int W, int C, int stride, void* stream);
+
 /* Instance-norm statistics of x [N][H*W][C] and the AdaIN scale/shift derived from them (blocks.py:18-26):
  *   mean/rstd [N][C] (biased variance, eps), scale = rstd*gamma, shift = beta - mean*scale.
  * gamma/beta [N][C] with row stride `ab_stride` floats (they are slices of the projector output, noBottleneck.py:108-125).
@@ -271,6 +281,22 @@ int lp_l1_fwd(const float* a, const float* b, float* partial, long long numel, i
               void* stream);
 int lp_l1_bwd(const float* a, const float* b, const float* grad_out, float coef, const float* add, float* da, long long numel, int relu_in,
               const int8_t* sign, float* amax_slots, void* stream);
+
+/* Loss reductions.  lp_reduce_dice (criterions/dice.py:20-39): fake [B][Cf][HW], real [B][Cr][HW] NCHW, Cf = 1 (broadcast over real's
+ * channels -- the reference's 1-vs-3 channel quirk: overlap and sum r^2 over B x Cr, sum f^2 over B x 1) or Cf = Cr;
+ * out[0] = -log(sum 2 f r / (sum f^2 + sum r^2)) * weight; partial = lp_dice_partial_blocks() * 3 floats; sums[2] = {overlap, energy}
+ * kept for lp_reduce_dice_bwd: dfake = -weight * grad_out[0] * (2 sum_c r / overlap - 2 f / energy).
+ * lp_reduce_hinge (criterions/adversarial.py:34-57, gan_type 'gan'): out[0] = loss_G = -mean(fake_g),
+ * out[1] = loss_D = mean(relu(1 - real)) + mean(relu(1 + fake_d)) over B scores; backward writes the non-NULL ones of
+ * d_real, d_fake_d (need grad_D), d_fake_g (needs grad_G). */
+int lp_dice_partial_blocks(void);
+int lp_reduce_dice(const float* fake, const float* real, float* partial, float* out, float* sums, int B, int Cf, int Cr, int HW,
+                   float weight, void* stream);
+int lp_reduce_dice_bwd(const float* fake, const float* real, const float* sums, const float* grad_out, float* dfake, int B, int Cf,
+                       int Cr, int HW, float weight, void* stream);
+int lp_reduce_hinge(const float* real, const float* fake_d, const float* fake_g, float* out, int B, void* stream);
+int lp_reduce_hinge_bwd(const float* real, const float* fake_d, const float* grad_G, const float* grad_D, float* d_real,
+                        float* d_fake_d, float* d_fake_g, int B, void* stream);
 
 /* ---- fused multi-tensor optimizers + EMA (runners/holycow.py:34-41,99-109; utils/radam.py:29-95; torch.optim.Adam) ----
  * table: DEVICE array of {float* p; const float* g; float* m; float* v; long long n;} (lp_mt_desc_bytes() each), one per

@@ -77,6 +77,9 @@ SIGNATURES = {
     'lp_add_strided2': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'lp_spatial_mean_fwd': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'lp_spatial_mean_bwd': (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    'lp_dwconv3x3_dgrad': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'lp_dwconv3x3_wgrad_workspace_bytes': (_ll, [_i]),
+    'lp_dwconv3x3_wgrad': (_i, [_vp] * 6 + [_i] * 5 + [_vp]),
     'lp_sum2x2': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'lp_head_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'lp_head_bwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
@@ -86,6 +89,11 @@ SIGNATURES = {
     'lp_l1_partial_blocks': (_i, []),
     'lp_l1_fwd': (_i, [_vp, _vp, _vp, _ll, _i, _f, _vp, _vp, _vp]),
     'lp_l1_bwd': (_i, [_vp, _vp, _vp, _f, _vp, _vp, _ll, _i, _vp, _vp, _vp]),
+    'lp_dice_partial_blocks': (_i, []),
+    'lp_reduce_dice': (_i, [_vp] * 5 + [_i] * 4 + [_f, _vp]),
+    'lp_reduce_dice_bwd': (_i, [_vp] * 5 + [_i] * 4 + [_f, _vp]),
+    'lp_reduce_hinge': (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
+    'lp_reduce_hinge_bwd': (_i, [_vp] * 7 + [_i, _vp]),
     'lp_mt_desc_bytes': (_i, []),
     'lp_mt_optimizer_step': (_i, [_vp, _i, _ll, _vp, _i, _f, _f, _f, _f, _vp]),
     'lp_mt_ema': (_i, [_vp, _i, _ll, _f, _i, _vp]),

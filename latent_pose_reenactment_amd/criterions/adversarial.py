@@ -29,6 +29,10 @@ class Criterion(nn.Module):
 
     def forward(self, data_dict):
         real = data_dict['real_score']
+        fd, fg = data_dict['fake_score_D'], data_dict['fake_score_G']
+        if self.gan_type == 'gan' and real.is_cuda and real.dtype == torch.float32 and real.shape == fd.shape == fg.shape:
+            loss_G, loss_D = HingeFn.apply(real, fd, fg)          # lp_reduce_hinge: one launch for both losses (+ one for the backward)
+            return {'adversarial_G': loss_G}, {'adversarial_D': loss_D}
         real_pred, fake_pred_D = self._preds(real, data_dict['fake_score_D'])
         _, fake_pred_G = self._preds(real, data_dict['fake_score_G'])
         loss_D = torch.relu(1. - real_pred).mean() + torch.relu(1. + fake_pred_D).mean()
@@ -37,3 +41,36 @@ class Criterion(nn.Module):
         else:
             loss_G = torch.relu(1. + real_pred).mean() + torch.relu(1. - fake_pred_G).mean()
         return {'adversarial_G': loss_G}, {'adversarial_D': loss_D}
+
+
+class HingeFn(torch.autograd.Function):
+    """(loss_G, loss_D) = (-mean(fake_G), mean(relu(1 - real)) + mean(relu(1 + fake_D))) over the B critic scores --
+    criterions/adversarial.py:41-52 of the reference, gan_type 'gan'."""
+
+    @staticmethod
+    def forward(ctx, real, fake_d, fake_g):
+        from latent_pose_reenactment_amd import _lib
+        r, fd, fg = (t.detach().contiguous().reshape(-1) for t in (real, fake_d, fake_g))
+        out = torch.empty(2, dtype=torch.float32, device=r.device)
+        _lib.check(_lib.lib().lp_reduce_hinge(r.data_ptr(), fd.data_ptr(), fg.data_ptr(), out.data_ptr(), r.numel(),
+                                              torch.cuda.current_stream().cuda_stream), 'lp_reduce_hinge')
+        ctx.save_for_backward(r, fd)
+        ctx.shape = real.shape
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, gG, gD):
+        from latent_pose_reenactment_amd import _lib
+        r, fd = ctx.saved_tensors
+        n = r.numel()
+        need = ctx.needs_input_grad
+        zero = None
+        if gG is None or gD is None:
+            zero = torch.zeros(1, dtype=torch.float32, device=r.device)
+        g1 = (gG if gG is not None else zero).reshape(1).contiguous().float()
+        g2 = (gD if gD is not None else zero).reshape(1).contiguous().float()
+        outs = [torch.empty(n, dtype=torch.float32, device=r.device) if nd else None for nd in need]
+        p = lambda t: None if t is None else t.data_ptr()
+        _lib.check(_lib.lib().lp_reduce_hinge_bwd(r.data_ptr(), fd.data_ptr(), g1.data_ptr(), g2.data_ptr(), p(outs[0]), p(outs[1]), p(outs[2]), n,
+                                                  torch.cuda.current_stream().cuda_stream), 'lp_reduce_hinge_bwd')
+        return tuple(None if o is None else o.view(ctx.shape) for o in outs)

@@ -486,6 +486,9 @@ static int dispatch_wgrad(WgradParams& p, float* dw, float* dbias, const float* 
     const bool cob128 = cob_env ? (cob_env == 128) : true;      // measured: -9 % (bf16x3), -6 % (bf16) on the 64..512-channel layers
     if (cob128 && p.Cout >= 128 && ksize == 3)
         return upsample ? launch_wgrad<3, true, PREC, 128>(p, dw, dbias, out_scale, sn_w, sn_dot, s) : launch_wgrad<3, false, PREC, 128>(p, dw, dbias, out_scale, sn_w, sn_dot, s);
+    static const int cob1_env = getenv("LP_WGRAD_COB1") ? atoi(getenv("LP_WGRAD_COB1")) : 0;        // 1x1 layers: 64 | 128 forces
+    if ((cob1_env ? cob1_env == 128 : true) && p.Cout >= 128 && ksize == 1 && !upsample)
+        return launch_wgrad<1, false, PREC, 128>(p, dw, dbias, out_scale, sn_w, sn_dot, s);
     if (ksize == 3 && !upsample) return launch_wgrad<3, false, PREC>(p, dw, dbias, out_scale, sn_w, sn_dot, s);
     if (ksize == 3 && upsample) return launch_wgrad<3, true, PREC>(p, dw, dbias, out_scale, sn_w, sn_dot, s);
     if (ksize == 1 && !upsample) return launch_wgrad<1, false, PREC>(p, dw, dbias, out_scale, sn_w, sn_dot, s);

@@ -188,15 +188,16 @@ __global__ __launch_bounds__(256) void instnorm_partial_kernel(const float* __re
     }
 }
 
-__global__ void instnorm_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma, const float* __restrict__ beta,
+// one WAVE per (n, c): the lanes split the S partials (a BatchNorm over 10^6 positions has 1024 of them), merge pairwise in fp64
+__global__ __launch_bounds__(256) void instnorm_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma, const float* __restrict__ beta,
                                          int ab_stride, float eps, float* __restrict__ mean, float* __restrict__ rstd,
                                          float* __restrict__ scale, float* __restrict__ shift, int N, int C, int S,
                                          float* __restrict__ run_mean = nullptr, float* __restrict__ run_var = nullptr, float momentum = 0.f) {
-    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (idx >= N * C) return;
     int n = idx / C, c = idx % C;
     double na = 0, ma = 0, qa = 0;
-    for (int s = 0; s < S; ++s) {
+    for (int s = lane; s < S; s += 64) {
         const float* q = part + (((size_t)n * S + s) * C + c) * 3;
         double nb = q[0], mb = q[1], qb = q[2];
         if (nb == 0) continue;
@@ -204,6 +205,14 @@ __global__ void instnorm_finalize_kernel(const float* __restrict__ part, const f
         double nn = na + nb, d = mb - ma;
         ma += d * (nb / nn); qa += qb + d * d * (na * nb / nn); na = nn;
     }
+    for (int o = 32; o > 0; o >>= 1) {
+        const double nb = __shfl_down(na, o, 64), mb = __shfl_down(ma, o, 64), qb = __shfl_down(qa, o, 64);
+        if (nb != 0) {
+            if (na == 0) { na = nb; ma = mb; qa = qb; }
+            else { double nn = na + nb, d = mb - ma; ma += d * (nb / nn); qa += qb + d * d * (na * nb / nn); na = nn; }
+        }
+    }
+    if (lane != 0) return;
     float var = (float)(qa / na);
     float m = (float)ma, r = 1.0f / sqrtf(var + eps);
     mean[idx] = m; rstd[idx] = r;
@@ -232,7 +241,7 @@ extern "C" int lp_instnorm_stats(const float* x, const float* gamma, const float
     hipLaunchKernelGGL(instnorm_partial_kernel, dim3(S, (C + 63) / 64, N), dim3(256), 0, st, x, workspace, HW, C, S);
     int rc = lp_check_launch("instnorm_partial");
     if (rc) return rc;
-    hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(cdiv((long long)N * C, 256)), dim3(256), 0, st, workspace, gamma, beta, ab_stride,
+    hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(cdiv((long long)N * C, 4)), dim3(256), 0, st, workspace, gamma, beta, ab_stride,
                        eps, mean, rstd, scale, shift, N, C, S);
     return lp_check_launch("instnorm_finalize");
 }
@@ -253,7 +262,7 @@ extern "C" int lp_bn_train_stats(const float* y, const float* gamma, const float
     hipLaunchKernelGGL(instnorm_partial_kernel, dim3(S, (C + 63) / 64, 1), dim3(256), 0, st, y, workspace, HW, C, S);
     int rc = lp_check_launch("bn_stats_partial");
     if (rc) return rc;
-    hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, workspace, gamma, beta, C, eps, mean, rstd, scale, shift,
+    hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, workspace, gamma, beta, C, eps, mean, rstd, scale, shift,
                        1, C, S, running_mean, running_var, momentum);
     return lp_check_launch("bn_stats_finalize");
 }
@@ -319,15 +328,17 @@ __global__ __launch_bounds__(256) void adain_bwd_partial_kernel(const float* __r
     }
 }
 
-__global__ void adain_bwd_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma, int ab_stride,
+__global__ __launch_bounds__(256) void adain_bwd_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma, int ab_stride,
                                           const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dgamma,
                                           float* __restrict__ dbeta, float* __restrict__ coef, int N, int C, int S, float inv_hw,
                                           int frozen = 0) {
-    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;          // one wave per (n, c)
     if (idx >= N * C) return;
     int n = idx / C, c = idx % C;
     double a1 = 0, a2 = 0;
-    for (int s = 0; s < S; ++s) { const float* q = part + (((size_t)n * S + s) * C + c) * 2; a1 += q[0]; a2 += q[1]; }
+    for (int s = lane; s < S; s += 64) { const float* q = part + (((size_t)n * S + s) * C + c) * 2; a1 += q[0]; a2 += q[1]; }
+    for (int o = 32; o > 0; o >>= 1) { a1 += __shfl_down(a1, o, 64); a2 += __shfl_down(a2, o, 64); }
+    if (lane != 0) return;
     float S1 = (float)a1, S2 = (float)a2;
     if (dgamma) dgamma[(size_t)n * ab_stride + c] = S2;
     if (dbeta) dbeta[(size_t)n * ab_stride + c] = S1;
@@ -390,7 +401,7 @@ extern "C" int lp_norm_act_bwd(const float* dA, const float* x, const float* add
                        H, W, C, upsample, S, mask_mode, mask_src, g_copy, act_hi > 0.f ? act_hi : 3.0e38f);
     int rc = lp_check_launch("adain_bwd_partial");
     if (rc) return rc;
-    hipLaunchKernelGGL(adain_bwd_finalize_kernel, dim3(cdiv((long long)N * C, 256)), dim3(256), 0, st, part, gamma, ab_stride, mean, rstd,
+    hipLaunchKernelGGL(adain_bwd_finalize_kernel, dim3(cdiv((long long)N * C, 4)), dim3(256), 0, st, part, gamma, ab_stride, mean, rstd,
                        dgamma, dbeta, coef, N, C, S, 1.0f / (float)HW, frozen_stats);
     rc = lp_check_launch("adain_bwd_finalize");
     if (rc) return rc;
@@ -799,4 +810,119 @@ extern "C" int lp_mt_ema(const void* table, int num_tensors, long long max_numel
     int bx = (int)((max_numel + 2047) / 2048); if (bx < 1) bx = 1; if (bx > 1024) bx = 1024;
     hipLaunchKernelGGL(mt_ema_kernel, dim3(bx, num_tensors), dim3(256), 0, (hipStream_t)stream, (const MtDesc*)table, alpha, copy_only);
     return lp_check_launch("mt_ema");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Loss reductions (criterions/dice.py:20-39, criterions/adversarial.py:34-57)
+// ------------------------------------------------------------------------------------------------------------------
+// Dice: fake [B][Cf][HW], real [B][Cr][HW] (NCHW), Cf = 1 (broadcast over real's channels: the reference's 1-vs-3 channel quirk) or
+// Cf = Cr.  overlap = sum 2*f*r over the BROADCAST shape, energy = sum f^2 (over fake's own elements) + sum r^2;
+// loss = -log(overlap / energy) * weight.  Pass 1: DICE_BLOCKS block partials (3 sums each); pass 2: one block finishes, writes the
+// loss and keeps {overlap, energy} for the backward:  d loss / d f = -weight * (2 * sum_c r / overlap - 2 f / energy) * grad_out.
+#define DICE_BLOCKS 256
+__global__ __launch_bounds__(256) void dice_partial_kernel(const float* __restrict__ fake, const float* __restrict__ real, float* __restrict__ part,
+                                                           int B, int Cf, int Cr, int HW) {
+    __shared__ float sh[3][4];
+    float ov = 0.f, ef = 0.f, er = 0.f;
+    const long long total = (long long)B * HW;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int b = (int)(i / HW), p = (int)(i % HW);
+        for (int c = 0; c < Cr; ++c) {
+            const float r = real[((size_t)b * Cr + c) * HW + p];
+            const float f = fake[((size_t)b * Cf + (Cf == 1 ? 0 : c)) * HW + p];
+            ov = fmaf(2.f * f, r, ov); er = fmaf(r, r, er);
+            if (Cf != 1 || c == 0) ef = fmaf(f, f, ef);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { ov += __shfl_down(ov, o, 64); ef += __shfl_down(ef, o, 64); er += __shfl_down(er, o, 64); }
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = ov; sh[1][threadIdx.x >> 6] = ef; sh[2][threadIdx.x >> 6] = er; }
+    __syncthreads();
+    if (threadIdx.x < 3) part[blockIdx.x * 3 + threadIdx.x] = (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]);
+}
+__global__ __launch_bounds__(64) void dice_finalize_kernel(const float* __restrict__ part, int nblocks, float weight, float* __restrict__ out,
+                                                           float* __restrict__ sums) {
+    double ov = 0, ef = 0, er = 0;
+    for (int b = threadIdx.x; b < nblocks; b += 64) { ov += part[b * 3]; ef += part[b * 3 + 1]; er += part[b * 3 + 2]; }
+    for (int o = 32; o > 0; o >>= 1) { ov += __shfl_down(ov, o, 64); ef += __shfl_down(ef, o, 64); er += __shfl_down(er, o, 64); }
+    if (threadIdx.x == 0) {
+        const float o_ = (float)ov, e_ = (float)(ef + er);
+        sums[0] = o_; sums[1] = e_;
+        out[0] = -logf(o_ / e_) * weight;
+    }
+}
+__global__ __launch_bounds__(256) void dice_bwd_kernel(const float* __restrict__ fake, const float* __restrict__ real, const float* __restrict__ sums,
+                                                       const float* __restrict__ gout, float weight, float* __restrict__ dfake, int B, int Cf,
+                                                       int Cr, int HW) {
+    const float io = 1.f / sums[0], ie = 1.f / sums[1], g = -weight * gout[0];
+    const long long total = (long long)B * HW;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int b = (int)(i / HW), p = (int)(i % HW);
+        if (Cf == 1) {
+            float rs = 0.f;
+            for (int c = 0; c < Cr; ++c) rs += real[((size_t)b * Cr + c) * HW + p];
+            const float f = fake[(size_t)b * HW + p];
+            dfake[(size_t)b * HW + p] = g * (2.f * rs * io - 2.f * f * ie);
+        } else {
+            for (int c = 0; c < Cr; ++c) {
+                const size_t o = ((size_t)b * Cr + c) * HW + p;
+                dfake[o] = g * (2.f * real[o] * io - 2.f * fake[o] * ie);
+            }
+        }
+    }
+}
+
+extern "C" int lp_dice_partial_blocks(void) { return DICE_BLOCKS; }
+
+extern "C" int lp_reduce_dice(const float* fake, const float* real, float* partial, float* out, float* sums, int B, int Cf, int Cr, int HW,
+                              float weight, void* stream) {
+    if (!fake || !real || !partial || !out || !sums) return lp_set_error(LP_ERR_ARG, "lp_reduce_dice: null pointer");
+    if (Cf != 1 && Cf != Cr) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_reduce_dice: fake must have 1 channel or as many as real");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(dice_partial_kernel, dim3(DICE_BLOCKS), dim3(256), 0, st, fake, real, partial, B, Cf, Cr, HW);
+    int rc = lp_check_launch("dice_partial");
+    if (rc) return rc;
+    hipLaunchKernelGGL(dice_finalize_kernel, dim3(1), dim3(64), 0, st, partial, DICE_BLOCKS, weight, out, sums);
+    return lp_check_launch("dice_finalize");
+}
+
+extern "C" int lp_reduce_dice_bwd(const float* fake, const float* real, const float* sums, const float* grad_out, float* dfake, int B, int Cf,
+                                  int Cr, int HW, float weight, void* stream) {
+    if (!fake || !real || !sums || !grad_out || !dfake) return lp_set_error(LP_ERR_ARG, "lp_reduce_dice_bwd: null pointer");
+    if (Cf != 1 && Cf != Cr) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_reduce_dice_bwd: fake must have 1 channel or as many as real");
+    const long long total = (long long)B * HW;
+    long long blocks = (total + 255) / 256; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(dice_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, fake, real, sums, grad_out, weight, dfake, B, Cf, Cr, HW);
+    return lp_check_launch("dice_bwd");
+}
+
+// Hinge GAN losses on B critic scores (gan_type 'gan'): out[0] = loss_G = -mean(fake_G); out[1] = loss_D = mean(relu(1 - real)) +
+// mean(relu(1 + fake_D)).  Backward: d_fake_G = -gG / B;  d_real = -gD / B * [1 - real > 0];  d_fake_D = gD / B * [1 + fake_D > 0].
+__global__ __launch_bounds__(64) void hinge_fwd_kernel(const float* __restrict__ real, const float* __restrict__ fake_d, const float* __restrict__ fake_g,
+                                                       float* __restrict__ out, int B) {
+    float g = 0.f, d = 0.f;
+    for (int i = threadIdx.x; i < B; i += 64) { g -= fake_g[i]; d += fmaxf(1.f - real[i], 0.f) + fmaxf(1.f + fake_d[i], 0.f); }
+    for (int o = 32; o > 0; o >>= 1) { g += __shfl_down(g, o, 64); d += __shfl_down(d, o, 64); }
+    if (threadIdx.x == 0) { out[0] = g / (float)B; out[1] = d / (float)B; }
+}
+__global__ __launch_bounds__(64) void hinge_bwd_kernel(const float* __restrict__ real, const float* __restrict__ fake_d, const float* __restrict__ gG,
+                                                       const float* __restrict__ gD, float* __restrict__ d_real, float* __restrict__ d_fake_d,
+                                                       float* __restrict__ d_fake_g, int B) {
+    const float ib = 1.f / (float)B;
+    for (int i = threadIdx.x; i < B; i += 64) {
+        if (d_fake_g) d_fake_g[i] = -gG[0] * ib;
+        if (d_real) d_real[i] = (1.f - real[i] > 0.f) ? -gD[0] * ib : 0.f;
+        if (d_fake_d) d_fake_d[i] = (1.f + fake_d[i] > 0.f) ? gD[0] * ib : 0.f;
+    }
+}
+extern "C" int lp_reduce_hinge(const float* real, const float* fake_d, const float* fake_g, float* out, int B, void* stream) {
+    if (!real || !fake_d || !fake_g || !out || B < 1) return lp_set_error(LP_ERR_ARG, "lp_reduce_hinge: null pointer");
+    hipLaunchKernelGGL(hinge_fwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, real, fake_d, fake_g, out, B);
+    return lp_check_launch("hinge_fwd");
+}
+extern "C" int lp_reduce_hinge_bwd(const float* real, const float* fake_d, const float* grad_G, const float* grad_D, float* d_real,
+                                   float* d_fake_d, float* d_fake_g, int B, void* stream) {
+    if (!real || !fake_d || B < 1) return lp_set_error(LP_ERR_ARG, "lp_reduce_hinge_bwd: null pointer");
+    if ((d_fake_g && !grad_G) || ((d_real || d_fake_d) && !grad_D)) return lp_set_error(LP_ERR_ARG, "lp_reduce_hinge_bwd: missing upstream gradient");
+    hipLaunchKernelGGL(hinge_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, real, fake_d, grad_G, grad_D, d_real, d_fake_d, d_fake_g, B);
+    return lp_check_launch("hinge_bwd");
 }

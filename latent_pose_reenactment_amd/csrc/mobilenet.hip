@@ -652,3 +652,142 @@ extern "C" int lp_bn_finalize(const float* stats_part, int rows, const float* ga
                        shift, G4, T, T, eps, momentum);
     return lp_check_launch("bn_finalize");
 }
+
+// ---- depthwise 3x3 backward (meta-training trains the pose encoder: runners/holycow.py:34-41) -----------------------------------------
+// Data gradient w.r.t. the ACTIVATED input a = act(x) (the BatchNorm + ReLU6 backward that follows is lp_norm_act_bwd on the raw x):
+//   da[n,iy,ix,c] = sum_{ky,kx} dy[n,yo,xo,c] * w[c][ky][kx]   over the outputs with yo*stride + ky - 1 = iy, xo*stride + kx - 1 = ix
+// a gather (every element written once, no atomics), 4 channels per thread.
+__global__ __launch_bounds__(256) void dwconv3x3_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ da,
+                                                              int N, int H, int W, int C, int stride) {
+    const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride, C4 = C >> 2;
+    const long long total = (long long)N * H * W * C4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C4) * 4;
+        long long pix = i / C4;
+        const int ix = (int)(pix % W); pix /= W;
+        const int iy = (int)(pix % H); const int n = (int)(pix / H);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int ty = iy + 1 - ky;
+            if (ty < 0 || (stride == 2 && (ty & 1))) continue;
+            const int yo = ty / stride;
+            if (yo >= Ho) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int tx = ix + 1 - kx;
+                if (tx < 0 || (stride == 2 && (tx & 1))) continue;
+                const int xo = tx / stride;
+                if (xo >= Wo) continue;
+                const float4 d = *(const float4*)(dy + (((size_t)n * Ho + yo) * Wo + xo) * C + c);
+                const int k = ky * 3 + kx;
+                acc.x = fmaf(d.x, w[(c + 0) * 9 + k], acc.x); acc.y = fmaf(d.y, w[(c + 1) * 9 + k], acc.y);
+                acc.z = fmaf(d.z, w[(c + 2) * 9 + k], acc.z); acc.w = fmaf(d.w, w[(c + 3) * 9 + k], acc.w);
+            }
+        }
+        *(float4*)(da + (size_t)i * 4) = acc;
+    }
+}
+
+extern "C" int lp_dwconv3x3_dgrad(const float* dy, const float* w, float* da, int N, int H, int W, int C, int stride, void* stream) {
+    if (!dy || !w || !da) return lp_set_error(LP_ERR_ARG, "lp_dwconv3x3_dgrad: null pointer");
+    if ((C & 3) || (stride != 1 && stride != 2)) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_dwconv3x3_dgrad: needs C % 4 == 0, stride 1|2");
+    const long long total = (long long)N * H * W * (C / 4);
+    long long blocks = (total + 255) / 256; if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(dwconv3x3_dgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, w, da, N, H, W, C, stride);
+    return lp_check_launch("dwconv3x3_dgrad");
+}
+
+// Weight gradient: dw[c][k] = sum_{n,yo,xo} dy[n,yo,xo,c] * act(x)[n, yo*s+ky-1, xo*s+kx-1, c],  act = clamp(x*sc[c]+sh[c], 0, 6) | identity
+// (recomputed from the raw input while it is loaded, as in the forward).  Pass 1: the grid's thread count per block is trimmed to a
+// multiple of the C/4 channel quads (C/4 <= 256), so a thread meets the same 4 channels on every step and keeps 9 x 4 partial sums in
+// registers; the block folds its threads per quad through LDS -> part[block][9][C].  Pass 2: fixed-order sum over the blocks.
+#define DWW_MAXB 512
+__global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ sh,
+                                                              const float* __restrict__ dy, float* __restrict__ part, int N, int H, int W, int C,
+                                                              int stride, int BT) {
+    __shared__ float red[36][256];
+    const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride, C4 = C >> 2;
+    const long long total = (long long)N * Ho * Wo * C4;
+    float acc[9][4];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[k][j] = 0.f;
+    const bool active = (int)threadIdx.x < BT;
+    if (active) {
+        const int c = ((int)threadIdx.x % C4) * 4;                      // BT % C4 == 0 and the grid stride is a multiple of C4: fixed quad
+        float4 s = make_float4(1.f, 1.f, 1.f, 1.f), t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (sc) { s = *(const float4*)(sc + c); t = *(const float4*)(sh + c); }
+        for (long long i = (long long)blockIdx.x * BT + threadIdx.x; i < total; i += (long long)gridDim.x * BT) {
+            long long pix = i / C4;
+            const int xo = (int)(pix % Wo); pix /= Wo;
+            const int yo = (int)(pix % Ho); const int n = (int)(pix / Ho);
+            const float4 d = *(const float4*)(dy + (size_t)i * 4);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int iy = yo * stride + ky - 1, ix = xo * stride + kx - 1;
+                    if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                        float4 v = *(const float4*)(x + (((size_t)n * H + iy) * W + ix) * C + c);
+                        if (sc) {
+                            v.x = fminf(fmaxf(fmaf(v.x, s.x, t.x), 0.f), 6.f); v.y = fminf(fmaxf(fmaf(v.y, s.y, t.y), 0.f), 6.f);
+                            v.z = fminf(fmaxf(fmaf(v.z, s.z, t.z), 0.f), 6.f); v.w = fminf(fmaxf(fmaf(v.w, s.w, t.w), 0.f), 6.f);
+                        }
+                        const int k = ky * 3 + kx;
+                        acc[k][0] = fmaf(d.x, v.x, acc[k][0]); acc[k][1] = fmaf(d.y, v.y, acc[k][1]);
+                        acc[k][2] = fmaf(d.z, v.z, acc[k][2]); acc[k][3] = fmaf(d.w, v.w, acc[k][3]);
+                    }
+                }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[k * 4 + j][threadIdx.x] = acc[k][j];
+    __syncthreads();
+    // fold the BT / C4 threads of every quad: thread q < C4 sums entries q, q + C4, ... for its 36 values
+    if ((int)threadIdx.x < C4) {
+        for (int e = 0; e < 36; ++e) {
+            float a = 0.f;
+            for (int r = threadIdx.x; r < BT; r += C4) a += red[e][r];
+            const int k = e >> 2, j = e & 3;
+            part[((size_t)blockIdx.x * 9 + k) * C + threadIdx.x * 4 + j] = a;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void dwconv3x3_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int blocks, int C) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;                    // (k, c), c fastest: coalesced reads of the partials
+    if (idx >= 9 * C) return;
+    const int c = idx % C, k = idx / C;
+    float a0 = 0.f, a1 = 0.f;
+    int b = 0;
+    for (; b + 1 < blocks; b += 2) { a0 += part[((size_t)b * 9 + k) * C + c]; a1 += part[((size_t)(b + 1) * 9 + k) * C + c]; }
+    if (b < blocks) a0 += part[((size_t)b * 9 + k) * C + c];
+    dw[(size_t)c * 9 + k] = a0 + a1;
+}
+
+static int dww_blocks(long long total, int BT) {
+    long long nb = (total + 8ll * BT - 1) / (8ll * BT);
+    return (int)(nb > DWW_MAXB ? DWW_MAXB : (nb < 1 ? 1 : nb));
+}
+
+extern "C" long long lp_dwconv3x3_wgrad_workspace_bytes(int C) { return (long long)DWW_MAXB * 9 * C * (long long)sizeof(float); }
+
+extern "C" int lp_dwconv3x3_wgrad(const float* x, const float* in_scale, const float* in_shift, const float* dy, float* dw, float* workspace,
+                                  int N, int H, int W, int C, int stride, void* stream) {
+    if (!x || !dy || !dw || !workspace) return lp_set_error(LP_ERR_ARG, "lp_dwconv3x3_wgrad: null pointer");
+    if ((C & 3) || C > 1024 || (stride != 1 && stride != 2) || (!in_scale != !in_shift))
+        return lp_set_error(LP_ERR_UNSUPPORTED, "lp_dwconv3x3_wgrad: needs C % 4 == 0, C <= 1024, stride 1|2");
+    const int C4 = C >> 2, BT = 256 - 256 % C4;
+    const long long total = (long long)N * ((H + stride - 1) / stride) * ((W + stride - 1) / stride) * C4;
+    const int blocks = dww_blocks(total, BT);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(dwconv3x3_wgrad_kernel, dim3(blocks), dim3(256), 0, st, x, in_scale, in_shift, dy, workspace, N, H, W, C, stride, BT);
+    int rc = lp_check_launch("dwconv3x3_wgrad");
+    if (rc) return rc;
+    hipLaunchKernelGGL(dwconv3x3_wgrad_reduce_kernel, dim3((9 * C + 255) / 256), dim3(256), 0, st, workspace, dw, blocks, C);
+    return lp_check_launch("dwconv3x3_wgrad_reduce");
+}

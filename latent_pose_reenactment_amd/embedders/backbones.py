@@ -233,23 +233,89 @@ class MobileNetV2(nn.Module):
                 nn.init.zeros_(m.bias)
 
     def forward(self, x):
-        if _HIP_FORWARD[0] and x.is_cuda and not torch.is_grad_enabled() and x.dim() == 4 and x.shape[1] == 3 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 \
-                and x.shape[0] <= 64:
-            return self._forward_hip(x)
+        hip = _HIP_FORWARD[0] and x.is_cuda and x.dim() == 4 and x.shape[1] == 3
+        if hip and not torch.is_grad_enabled() and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and x.shape[0] <= 64:
+            return self._forward_hip(x)                      # fused fp32 forward (fine-tuning step, drive.py)
+        if hip and torch.is_grad_enabled():
+            from . import mobilenet_hip
+            if mobilenet_hip.supported(x.shape[0], x.shape[2], x.shape[3]):
+                return self._forward_hip_train(x)            # autograd on (meta-training): forward + backward on the HIP kernels
+            if not self.__dict__.get('_warned_stock'):
+                self.__dict__['_warned_stock'] = True
+                import logging
+                logging.getLogger('embedder').warning('MobileNetV2: input %s is outside the HIP training path\'s geometry (see '
+                                                      'mobilenet_hip.supported); running the stock PyTorch-ROCm layers', tuple(x.shape))
         x = self.features(x)
         _flush_bn_counters()
         return self.classifier(x.mean([2, 3]))
+
+    # ---- HIP training path (forward + backward): embedders/mobilenet_hip.py --------------------------------------------------------
+    def _hip_train_structure(self):
+        if self.__dict__.get('_hip_feature_param_names') is None:
+            self.__dict__['_hip_feature_param_names'] = [k for k, _ in self.features.named_parameters()]
+            self.__dict__['_hip_feature_bn'] = {k: m for k, m in self.features.named_modules() if isinstance(m, nn.BatchNorm2d)}
+
+    def _hip_train_packs(self, par, need_grad):
+        """bf16x3 packs of the dense contractions (stem viewed as [32][27], every 1x1 conv): name -> [forward, data-gradient | None];
+        one batched launch per call in training, cached for no-grad eval calls"""
+        from latent_pose_reenactment_amd import hipops as ops
+        from latent_pose_reenactment_amd.optim import WEIGHTS_GENERATION
+        from .mobilenet_hip import PREC
+        dense = [k for k in self._hip_feature_param_names if k == '0.0.weight' or (par[k].dim() == 4 and par[k].shape[2] == 1)]
+        cacheable = not need_grad and not self.training
+        key = (need_grad, WEIGHTS_GENERATION[0]) + tuple((par[k].data_ptr(), par[k]._version) for k in dense)
+        cache = self.__dict__.get('_hip_train_pack_cache')
+        if cacheable and cache is not None and cache[0] == key:
+            return cache[1]
+
+        def w2d(k):
+            w = par[k].detach()
+            return w.view(w.shape[0], -1) if k == '0.0.weight' else w
+        specs = [(w2d(k), 0, False) for k in dense]
+        if need_grad:
+            specs += [(w2d(k), 1, False) for k in dense if k != '0.0.weight']
+        pb = self.__dict__.get('_hip_train_pb')
+        pkey = tuple((w.data_ptr(), m, bool(sk)) for w, m, sk in specs)
+        if pb is None or pb.key != pkey:
+            pb = ops.PackBatch(specs, PREC)
+            self.__dict__['_hip_train_pb'] = pb
+        allp = pb.update()
+        packs = {k: [allp[i], None] for i, k in enumerate(dense)}
+        if need_grad:
+            for j, k in enumerate(k_ for k_ in dense if k_ != '0.0.weight'):
+                packs[k][1] = allp[len(dense) + j]
+        if cacheable:
+            self.__dict__['_hip_train_pack_cache'] = (key, packs)
+        return packs
+
+    def _hip_eval_bn(self, par):
+        from .resnext_hip import _BN
+        names = list(self._hip_feature_bn)
+        bns = [self._hip_feature_bn[k] for k in names]
+        rstd = torch._foreach_add([m.running_var for m in bns], bns[0].eps)
+        torch._foreach_rsqrt_(rstd)
+        sc = torch._foreach_mul(rstd, [par[k + '.weight'].detach() for k in names])
+        sh = torch._foreach_mul([m.running_mean for m in bns], sc)
+        sh = torch._foreach_sub([par[k + '.bias'].detach() for k in names], sh)
+        return {k: _BN(m.running_mean, r, a_, b_) for k, m, r, a_, b_ in zip(names, bns, rstd, sc, sh)}
+
+    def _forward_hip_train(self, x):
+        from .mobilenet_hip import LinearRowsFunction, MobileNetFeaturesFunction
+        self._hip_train_structure()
+        pooled = MobileNetFeaturesFunction.apply(self, x, *[p for _, p in self.features.named_parameters()])
+        drop, fc = self.classifier[0], self.classifier[1]
+        pooled = F.dropout(pooled, drop.p, drop.training)
+        return LinearRowsFunction.apply(pooled, fc.weight, fc.bias)
 
     # ---- HIP forward (no autograd) ---------------------------------------------------------------------------------------------
     def _eval_affines(self):
         """eval mode: every BatchNorm folded to a per-channel (scale, shift) by four multi-tensor ops, cached until a weight or
         buffer changes (``_version``, or the generation counter of the fused optimizer / EMA kernels)"""
         from latent_pose_reenactment_amd.optim import WEIGHTS_GENERATION
-        tens = self.__dict__.get('_hip_tensors')
-        if tens is None:
-            tens = self.__dict__['_hip_tensors'] = [t for m in self.modules() if isinstance(m, nn.BatchNorm2d)
-                                                    for t in (m.weight, m.bias, m.running_mean, m.running_var)]
-        key = (WEIGHTS_GENERATION[0], sum(t._version for t in tens), tens[0].data_ptr())
+        # (the tensor OBJECTS are re-collected on every call: Module._apply -- .to / .cuda / .float -- replaces buffers, and a key built
+        #  from stale objects would miss later in-place updates of the new ones)
+        tens = [t for m in self.modules() if isinstance(m, nn.BatchNorm2d) for t in (m.weight, m.bias, m.running_mean, m.running_var)]
+        key = (WEIGHTS_GENERATION[0], sum(t._version for t in tens), tuple(t.data_ptr() for t in tens[:8]))
         st = self.__dict__.get('_hip_cache')
         if st is not None and st[0] == key:
             return st[1]

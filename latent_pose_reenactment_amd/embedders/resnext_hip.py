@@ -30,10 +30,10 @@ class _BN:
 
 
 def supported(n: int, h: int, w: int) -> bool:
-    """geometry the kernels cover: the last stage's grouped 3x3 (input H/16 x W/16) needs a >= 4 wide map (weight-gradient tiles are
-    >= 4 pixels wide), the classifier contraction N % 4 == 0 and N >= 8.  The 256 x 256 x (B x 8 frames) workload and the 128 x 128
-    test sizes qualify; smaller toy sizes run the stock layers (backbones.ResNeXt.forward)."""
-    return h % 32 == 0 and w % 32 == 0 and h >= 64 and w >= 64 and n % 4 == 0 and n >= 8
+    """geometry the kernels cover: the last stage's grouped 3x3 convs (maps of H/32 x W/32) need >= 4 wide maps (weight-gradient tiles
+    are >= 4 pixels wide), the classifier contraction N % 4 == 0 and N >= 8.  The 256 x 256 x (B x 8 frames) workload and the 128 x 128
+    test size qualify; smaller toy sizes run the stock layers (backbones.ResNeXt.forward)."""
+    return h % 32 == 0 and w % 32 == 0 and h >= 128 and w >= 128 and n % 4 == 0 and n >= 8
 
 
 def _conv1x1(a16, pack, prec, bias=None, res=None, amax=False):
@@ -119,6 +119,7 @@ class ResNeXtFunction(torch.autograd.Function):
         if counters:
             torch._foreach_add_(counters, 1)
         if need_grad:
+            ctx.params = params
             ctx.net, ctx.par, ctx.packs, ctx.train = net, par, packs, train
             ctx.stem = (cols, y0, st0, idx, (h0, w0))
             ctx.blocks = saved_blocks
@@ -186,4 +187,5 @@ class ResNeXtFunction(torch.autograd.Function):
         d16 = ops.act_pack(dy0, prec=prec, grad=True)
         grads['conv1.weight'] = _wgrad1x1(cols, d16, prec).view(par['conv1.weight'].shape)
         ctx.blocks = ctx.stem = ctx.head = None
-        return (None, None) + tuple(grads.get(k) for k in net._hip_param_names)
+        from latent_pose_reenactment_amd.nn import fused_accumulate
+        return (None, None) + tuple(fused_accumulate(ctx.params, [grads.get(k) for k in net._hip_param_names]))

@@ -890,3 +890,25 @@ def spatial_mean_bwd(g: Tensor, h: int, w: int) -> Tensor:
     dx = torch.empty((n, h, w, c), dtype=torch.float32, device=g.device)
     check(_lib.lib().lp_spatial_mean_bwd(g.data_ptr(), dx.data_ptr(), n, h * w, c, _stream()), 'lp_spatial_mean_bwd')
     return dx
+
+
+# ---- MobileNetV2 backward: depthwise 3x3 ------------------------------------------------------------------------------------------
+def dwconv3x3_dgrad(dy: Tensor, w: Tensor, h: int, wd: int, stride: int) -> Tensor:
+    """gradient w.r.t. the activated input of ``dwconv3x3`` ([N,h,wd,C]) from dy [N,ceil(h/s),ceil(wd/s),C]"""
+    _chk(dy, 'dy'); _chk(w, 'w')
+    n, ho, wo, c = dy.shape
+    assert ho == (h + stride - 1) // stride and wo == (wd + stride - 1) // stride and w.numel() == c * 9
+    da = torch.empty((n, h, wd, c), dtype=torch.float32, device=dy.device)
+    check(_lib.lib().lp_dwconv3x3_dgrad(dy.data_ptr(), w.data_ptr(), da.data_ptr(), n, h, wd, c, stride, _stream()), 'lp_dwconv3x3_dgrad')
+    return da
+
+
+def dwconv3x3_wgrad(x: Tensor, dy: Tensor, stride: int, in_scale: Optional[Tensor] = None, in_shift: Optional[Tensor] = None) -> Tensor:
+    """weight gradient [C,1,3,3] of ``dwconv3x3`` (x = its raw input, activation relu6(x*in_scale+in_shift) recomputed on load)"""
+    _chk(x, 'x'); _chk(dy, 'dy')
+    n, h, wd, c = x.shape
+    dw = torch.empty((c, 1, 3, 3), dtype=torch.float32, device=x.device)
+    ws = torch.empty(_lib.lib().lp_dwconv3x3_wgrad_workspace_bytes(c) // 4, dtype=torch.float32, device=x.device)
+    check(_lib.lib().lp_dwconv3x3_wgrad(x.data_ptr(), _p(in_scale), _p(in_shift), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), n, h, wd, c,
+                                        stride, _stream()), 'lp_dwconv3x3_wgrad')
+    return dw

@@ -115,6 +115,27 @@ def _accum_target(w):
     return g if (g is not None and g.is_contiguous() and g.dtype == torch.float32 and g.shape == w.shape) else None
 
 
+def fused_accumulate(params, grads):
+    """For autograd.Functions that produce the gradients of MANY parameters at once (the embedder backbones): inside
+    ``fused_grad_accumulation`` the gradients of all leaf parameters whose ``.grad`` exists are added to it by ONE multi-tensor add
+    (instead of one AccumulateGrad launch per parameter) and autograd receives None for them.  -> the list to return from backward."""
+    out = list(grads)
+    if not _FUSED_ACCUM[0]:
+        return out
+    tgt, src = [], []
+    for i, (p, g) in enumerate(zip(params, grads)):
+        if g is None:
+            continue
+        t = _accum_target(p)
+        if t is not None:
+            tgt.append(t)
+            src.append(g.reshape(t.shape) if g.shape != t.shape else g)
+            out[i] = None
+    if tgt:
+        torch._foreach_add_(tgt, src)
+    return out
+
+
 class SNBatch:
     """One-launch spectral normalisation of many ``SNWeight`` layers (lp_sn_power_iter): in train mode each layer's (u, v)
     buffers take one power-iteration step in place, and for every layer the call yields ``(u_used, v_used, sig)`` with

@@ -197,3 +197,28 @@ def spatial_mean(x):
 def spatial_mean_bwd(g, h, w):
     n, c = g.shape
     return (g / (h * w))[:, None, None, :].expand(n, h, w, c).contiguous()
+
+
+# ---- MobileNetV2 pieces ---------------------------------------------------------------------------------------------------------
+def dwconv3x3(x, w, stride, in_scale=None, in_shift=None):
+    a = x if in_scale is None else torch.clamp(x * in_scale + in_shift, 0, 6)
+    c = x.shape[-1]
+    y = F.conv2d(a.permute(0, 3, 1, 2), w.reshape(c, 1, 3, 3), stride=stride, padding=1, groups=c)
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+def dwconv3x3_dgrad(dy, w, h, wd, stride):
+    c = dy.shape[-1]
+    x = torch.zeros(dy.shape[0], c, h, wd, dtype=dy.dtype, device=dy.device)
+    da = torch.nn.grad.conv2d_input(x.shape, w.reshape(c, 1, 3, 3), dy.permute(0, 3, 1, 2), stride=stride, padding=1, groups=c)
+    return da.permute(0, 2, 3, 1).contiguous()
+
+
+def dwconv3x3_wgrad(x, dy, stride, in_scale=None, in_shift=None):
+    a = x if in_scale is None else torch.clamp(x * in_scale + in_shift, 0, 6)
+    c = x.shape[-1]
+    return torch.nn.grad.conv2d_weight(a.permute(0, 3, 1, 2), (c, 1, 3, 3), dy.permute(0, 3, 1, 2), stride=stride, padding=1, groups=c)
+
+
+def affine_relu6_mean(y, scale, shift):
+    return torch.clamp(y * scale + shift, 0, 6).mean(dim=(1, 2))

@@ -1,0 +1,108 @@
+"""GPU parity of the MobileNetV2 pose encoder's TRAINING path (E2: autograd on, meta-training; embedders/mobilenet_hip.py):
+the depthwise backward kernels against their fp64 restatements, the classifier Function against F.linear, and the whole network
+(forward + every parameter gradient + BatchNorm buffers) against the stock layers in fp64, calibrated by the stock fp32 layers."""
+import copy
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'latent_pose_reenactment_amd'))
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a = a.detach().double().cpu(); b = b.detach().double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def report(name, err, tol):
+    print(f'[parity] {name}: rel-L2 {err:.3e} (tol {tol:.0e})')
+    assert err < tol, f'{name}: rel-L2 {err:.3e} >= {tol}'
+
+
+@pytest.mark.parametrize('case', [(2, 16, 16, 96, 1, True), (2, 16, 16, 144, 2, True), (3, 9, 13, 32, 1, False), (8, 8, 8, 960, 1, True),
+                                  (2, 14, 10, 384, 2, True)])
+def test_depthwise_backward(case):
+    import emu_ops
+    from latent_pose_reenactment_amd import hipops as ops
+    n, h, w, c, stride, aff = case
+    g = torch.Generator().manual_seed(sum(case[:5]))
+    x = torch.randn(n, h, w, c, generator=g).cuda()
+    wt = (torch.randn(c, 1, 3, 3, generator=g) / 3).cuda()
+    sc = (torch.rand(c, generator=g) * 3 + 0.5).cuda() if aff else None
+    sh = (torch.randn(c, generator=g) + 1).cuda() if aff else None
+    ho, wo = (h + stride - 1) // stride, (w + stride - 1) // stride
+    dy = torch.randn(n, ho, wo, c, generator=g).cuda()
+    d64 = lambda t: None if t is None else t.double()
+    y = ops.dwconv3x3(x, wt, stride, sc, sh)
+    report(f'dwconv fwd {case}', rel(y, emu_ops.dwconv3x3(x.double(), wt.double(), stride, d64(sc), d64(sh))), 1e-6)
+    da = ops.dwconv3x3_dgrad(dy, wt, h, w, stride)
+    report(f'dwconv dgrad {case}', rel(da, emu_ops.dwconv3x3_dgrad(dy.double(), wt.double(), h, w, stride)), 1e-6)
+    dw = ops.dwconv3x3_wgrad(x, dy, stride, sc, sh)
+    report(f'dwconv wgrad {case}', rel(dw, emu_ops.dwconv3x3_wgrad(x.double(), dy.double(), stride, d64(sc), d64(sh))), 3e-6)
+
+
+def test_linear_rows_function():
+    from embedders.mobilenet_hip import LinearRowsFunction
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(8, 1280, generator=g).cuda().requires_grad_(True)
+    w = (torch.randn(256, 1280, generator=g) * 0.02).cuda().requires_grad_(True)
+    b = torch.randn(256, generator=g).cuda().requires_grad_(True)
+    r = torch.randn(8, 256, generator=g).cuda()
+    y = LinearRowsFunction.apply(x, w, b)
+    (y * r).sum().backward()
+    xr, wr, br = (t.detach().double().requires_grad_(True) for t in (x, w, b))
+    yr = F.linear(xr, wr, br)
+    (yr * r.double()).sum().backward()
+    for nm, a, bb in (('y', y, yr), ('dx', x.grad, xr.grad), ('dw', w.grad, wr.grad), ('db', b.grad, br.grad)):
+        report(f'linear_rows.{nm}', rel(a, bb), 3e-5)
+
+
+def _nets(seed):
+    from embedders.backbones import mobilenet_v2
+    torch.manual_seed(seed)
+    m = mobilenet_v2(256)
+    m.classifier[0].p = 0.0                      # Dropout off on both sides (its random mask is not part of parity)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.weight.data.uniform_(0.5, 1.5); mod.bias.data.uniform_(-0.3, 0.3)
+            mod.running_mean.uniform_(-0.2, 0.2); mod.running_var.uniform_(0.5, 1.5)
+    return m.cuda(), copy.deepcopy(m).double().cuda()
+
+
+@pytest.mark.parametrize('train,size', [(True, 128), (False, 128), (True, 256)])
+def test_mobilenet_v2_forward_backward_vs_fp64(train, size):
+    from embedders import backbones
+    from test_resnext_hip import _grad_err, structured_frames
+    m, ref = _nets(11)
+    m32 = copy.deepcopy(m)
+    for net in (m, ref, m32):
+        net.train(train)
+    x = structured_frames(8, size, 5).cuda()
+    r = torch.randn(8, 256, device='cuda')
+    y = m(x)
+    assert m.__dict__.get('_hip_feature_param_names') is not None, 'the HIP training path did not run'
+    (y * r).sum().backward()
+    backbones.set_hip_forward(False)
+    try:
+        yr = ref(x.double())
+        (yr * r.double()).sum().backward()
+        y32 = m32(x)
+        (y32 * r).sum().backward()
+    finally:
+        backbones.set_hip_forward(True)
+    e_out, c_out = rel(y, yr), rel(y32, yr)
+    tot, c_tot = _grad_err(list(m.parameters()), list(ref.parameters())), _grad_err(list(m32.parameters()), list(ref.parameters()))
+    e_b = max(rel(b.double(), q) for (k, b), (_, q) in zip(m.named_buffers(), ref.named_buffers()) if b.dtype.is_floating_point)
+    print(f'[parity] mobilenet_v2 train={train} {size}px (bf16x3 contractions): pose vector {e_out:.2e}, all-gradients {tot:.2e}, buffers {e_b:.2e} '
+          f'| stock fp32 layers vs fp64: {c_out:.2e}, {c_tot:.2e}')
+    assert e_out < max(3 * c_out, 3e-5) and tot < max(3 * c_tot, 3e-4) and e_b < 1e-4, (e_out, tot, e_b, c_out, c_tot)
+    for (k, b), (_, q) in zip(m.named_buffers(), ref.named_buffers()):
+        if not b.dtype.is_floating_point:
+            assert int(b) == int(q), k
+    assert all(p.grad is not None for p in m.parameters())
