@@ -1,14 +1,15 @@
 #!/usr/bin/env python3
 """bench.py -- train-step images/s at 256x256, per-GPU bs=8 (BASELINE.json metric), on N MI355X GPUs.
 
-Workload at N=1 = BASELINE.json configs[1]: the fine-tuning step of configs/finetuning-base.yaml
-(criterions adversarial, featmat, idt_embed, perceptual, dice; RAdam lr_gen 5e-4 / lr_dis 8e-4; EMA 0.972), bs=8,
-256x256, synthetic VoxCeleb2-shaped batch, random-init weights (no network for datasets/checkpoints).  One "step" =
-runners/holycow.py:230-257: E(pose) -> G -> D x3 -> criterions -> G backward/step -> D backward/step -> EMA.
-The generator, the discriminator, the VGG19/VGGFace criterions, RAdam, EMA and the spectral-norm power iterations run on the
-hand-written gfx950 kernels of liblp_hip.so, and so does the MobileNetV2 pose encoder (forward only in fine-tuning; csrc/mobilenet.hip).
-For N>1 the default workload is the meta-training step (configs[2]: the configuration the reference runs data parallel), each rank on
-its own batch with the RCCL gradient all-reduce of latent_pose_reenactment_amd.parallel (weak scaling).
+ONE workload for every N (so that 1/2/4/8-GPU values form a scaling curve): the META-TRAINING step of configs/default.yaml (BASELINE
+configs[2] -- the configuration the reference runs data parallel): ResNeXt-50 identity encoder over 8 frames per sample + MobileNetV2 pose
+encoder (both trained), G, D with the 98000 x 512 label embedding, criterions idt_embed, perceptual, adversarial, featmat, dis_embed,
+dice, Adam, EMA; bs 8 per GPU, 256 x 256, synthetic VoxCeleb2-shaped batch, random-init weights (no network for datasets/checkpoints).
+One "step" = runners/holycow.py:230-257: E -> G -> D x3 -> criterions -> G backward/[all-reduce]/step -> D backward/[all-reduce]/step -> EMA,
+every layer of it on the hand-written gfx950 kernels of liblp_hip.so.  N > 1: each rank on its own batch, RCCL gradient all-reduce of
+latent_pose_reenactment_amd.parallel (weak scaling).
+`--workload finetune_step` = BASELINE configs[1] (finetuning-base.yaml; the reference refuses multi-GPU fine-tuning): at N = 1 the
+default run also measures it in a child process and reports it under "finetune_step".
 
 Prints ONE JSON line on rank 0 (see README/DESIGN for the field definitions)."""
 import argparse
@@ -26,6 +27,22 @@ import torch.distributed as dist  # noqa: E402
 
 GEN_FWD_GFLOP_PER_IMAGE = 60.72      # SURVEY 8d / BASELINE.md: dense 2*MAC, as executed by the reference
 MFMA_BF16_PEAK_TFLOPS = 2500.0       # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+# dense 2*MAC per image of the other nets (ResNeXt-50 / MobileNetV2 per FRAME, from the layer shapes at 256 x 256)
+DIS_GFLOP, VGG19_GFLOP, VGGFACE_GFLOP, RESNEXT_GFLOP_PER_FRAME, MOBILENET_GFLOP_PER_FRAME = 30.97, 47.34, 40.09, 11.0, 0.8
+
+
+def step_algorithmic_tflop(workload, batch, frames=8):
+    """useful dense FLOPs of one training step as THIS path executes it (fwd = 1, data gradient = 1, weight gradient = 1 per layer):
+    G fwd + both gradients; D: the fake pass of the G loss (fwd + dgrad, its weight gradients are never consumed), the detached fake and
+    the real pass of the D loss (fwd + both gradients each); VGG19 / VGGFace: fake fwd + dgrad, real fwd; meta-training adds the encoders
+    (fwd + both gradients).  The reference's step also computes D weight gradients in the G backward and discards them (holycow.py:247)."""
+    per_img = 3 * GEN_FWD_GFLOP_PER_IMAGE
+    if workload == 'generator':
+        return per_img * batch / 1e3
+    per_img += (2 + 3 + 3) * DIS_GFLOP + 3 * VGG19_GFLOP + 3 * VGGFACE_GFLOP
+    if workload == 'metatrain_step':
+        per_img += 3 * (RESNEXT_GFLOP_PER_FRAME * frames + MOBILENET_GFLOP_PER_FRAME)
+    return per_img * batch / 1e3
 
 
 def make_args(image_size, batch_size, device, num_gpus, rank, prec_name, finetune=True):
@@ -83,6 +100,80 @@ def synthetic_batch(args, per_gpu_batch, seed):
     target = {'real_segm': torch.stack([t['real_segm'] for t in targets]).to(args.device),
               'label': torch.tensor([t['label'] for t in targets], device=args.device)}
     return data, target
+
+
+def _cpu_step_metatrain(args, sample_batch):
+    """-> a callable running ONE meta-training step (configs/default.yaml) of `sample_batch` samples on the CPU: ResNeXt-50 over the
+    8 encoder frames + MobileNetV2 (the torchvision-compatible restatements of embedders/backbones.py, stock torch-CPU layers, train
+    mode) -> oracle generator -> oracle discriminator x3 with the 98000 x 512 label embedding -> VGGFace / VGG19 / adversarial /
+    featmat / dis_embed / dice -> loss_G.backward -> Adam(G + E) -> loss_D.backward -> Adam(D) -> EMA(G + E)."""
+    import copy
+    from oracle import lp_oracle as O
+    from generators.vector_pose_unsupervised_segmentation_noBottleneck import Wrapper as GW
+    from discriminators.no_landmarks import Wrapper as DW
+    from embedders.backbones import mobilenet_v2, resnext50_32x4d
+    from criterions.common.perceptual_loss import PerceptualLoss
+    from dataloaders.synthetic_voxceleb2 import make_sample
+    a = copy.copy(args)
+    a.device = 'cpu'
+    torch.manual_seed(0)
+    G, D = GW.get_net(a), DW.get_net(a)
+    idt_net, pose_net = resnext50_32x4d(a.embed_channels).train(), mobilenet_v2(a.pose_embedding_size).train()
+    vgg19 = PerceptualLoss(a.perc_weight, '/nonexistent', 'caffe', synthetic_seed=1234).model.state_dict()
+    vggf = PerceptualLoss(a.idt_embed_weight, '/nonexistent', 'face', synthetic_seed=1235).model.state_dict()
+
+    def as_sd(module):
+        sd = {k: v.detach().clone() for k, v in module.state_dict().items()}
+        params = [k for k, _ in module.named_parameters()]
+        for k in params:
+            sd[k].requires_grad_(True)
+        return sd, params
+    sdG, pG = as_sd(G)
+    sdD, pD = as_sd(D)
+    e_params = list(idt_net.parameters()) + list(pose_net.parameters())
+    ema = {k: sdG[k].detach().clone() for k in pG}
+    ema_e = [p.detach().clone() for p in e_params]
+    mom = {id(sd): {k: (torch.zeros_like(sd[k]), torch.zeros_like(sd[k])) for k in ps} for sd, ps in ((sdG, pG), (sdD, pD))}
+    mom_e = [(torch.zeros_like(p), torch.zeros_like(p)) for p in e_params]
+    data, target = zip(*[make_sample(i, a.image_size, a.n_frames_for_encoder, a.num_labels, False, 7) for i in range(sample_batch)])
+    enc = torch.stack([d['enc_rgbs'] for d in data])                      # B x K x 3 x S x S
+    pose_in = torch.stack([d['pose_input_rgbs'][0] for d in data])
+    tgt = torch.stack([d['target_rgbs'][0] for d in data])
+    real_segm = torch.stack([t['real_segm'] for t in target])
+    label = torch.tensor([t['label'] for t in target], dtype=torch.long)
+    step_no = [0]
+
+    def one():
+        step_no[0] += 1
+        b, k = enc.shape[:2]
+        per_frame = idt_net(enc.reshape(b * k, *enc.shape[2:])).view(b, k, -1)
+        embeds = per_frame.mean(1)
+        pose = pose_net(pose_in)
+        rgb, segm = O.generator_forward(sdG, embeds, pose, num_channels=64, max_num_channels=512, image_size=a.image_size, train=True)
+        out = O.discriminator_forward(sdD, rgb, tgt, label, image_size=a.image_size, dis_num_blocks=7, train=True, embed_eps=O.SN_EPS_CONV)
+        lg, ld = O.adversarial_gan(out['fake_score_G'], out['fake_score_D'], out['real_score'])
+        loss_G = lg + O.feature_matching(out['fake_features'], out['real_features']) \
+            + O.perceptual_loss(vggf, O.crop_and_resize_fixed(rgb), O.crop_and_resize_fixed(tgt), a.idt_embed_weight, O.VGG16_CFG) \
+            + O.perceptual_loss(vgg19, rgb, tgt, a.perc_weight, O.VGG19_CFG) + O.dice(segm, real_segm) \
+            + O.dis_embed(per_frame, out['real_embedding'], a.dis_embed_weight)
+        gs = torch.autograd.grad(loss_G, [sdG[k] for k in pG] + e_params, retain_graph=True, allow_unused=True)
+        with torch.no_grad():
+            for k, g in zip(pG, gs):
+                if g is not None:
+                    O.adam_step(sdG[k], g, *mom[id(sdG)][k], step_no[0], a.lr_gen, 0.0, 0.999, 1e-5)
+            for p_, g, m_ in zip(e_params, gs[len(pG):], mom_e):
+                if g is not None:
+                    O.adam_step(p_, g, *m_, step_no[0], a.lr_gen, 0.0, 0.999, 1e-5)
+        gD = torch.autograd.grad(ld, [sdD[k] for k in pD], allow_unused=True)
+        with torch.no_grad():
+            for k, g in zip(pD, gD):
+                if g is not None:
+                    O.adam_step(sdD[k], g, *mom[id(sdD)][k], step_no[0], a.lr_dis, 0.0, 0.999, 1e-5)
+            for k in pG:
+                O.ema_update(ema[k], sdG[k], 0.999)
+            for av, p_ in zip(ema_e, e_params):
+                O.ema_update(av, p_.detach(), 0.999)
+    return one
 
 
 def _cpu_step(args, sample_batch):
@@ -186,40 +277,44 @@ def _median_time(fn, warm, reps, budget_s):
 def cpu_worker(spec):
     """child process of cpu_baseline: `threads,batch,warm,reps,budget,image_size` -> one JSON line {"t": median seconds per step, "n": timed steps}
     (its own process so that OMP_NUM_THREADS / torch.set_num_threads take effect before any CPU kernel has run)"""
-    threads, batch, warm, reps, budget, image_size = [int(float(v)) for v in spec.split(',')]
+    threads, batch, warm, reps, budget, image_size, meta = [int(float(v)) for v in spec.split(',')]
     torch.set_num_threads(threads)
-    args = make_args(image_size, 8, 'cpu', 1, 0, 'bf16x3')
-    t, n = _median_time(_cpu_step(args, batch), warm, reps, budget)
+    args = make_args(image_size, 8, 'cpu', 1, 0, 'bf16x3', finetune=not meta)
+    t, n = _median_time((_cpu_step_metatrain if meta else _cpu_step)(args, batch), warm, reps, budget)
     print(json.dumps({'t': t, 'n': n, 'threads': torch.get_num_threads()}))
 
 
-def cpu_baseline(args, full=False):
-    """The CPU path timed on this box's host cores: the oracle -- the parity-pinned fp32 torch-CPU restatement of
-    the reference -- running the SAME fine-tuning step on the SAME kind of synthetic batch, each row in its own process.
-      all-core row : bs = 8 (the GPU workload's batch), every physical core, median of the timed steps;
-      1-thread row : how the reference configures itself (OMP_NUM_THREADS=1, torch.set_num_threads(1): train.py:2, utils/utils.py:19),
-                     bs = 1 sample of the same step.
+def cpu_baseline(args, full=False, workload='metatrain_step'):
+    """The CPU path timed on this box's host cores: the parity-pinned fp32 torch-CPU restatement of the reference
+    (oracle/lp_oracle.py; for the encoders the torchvision-compatible stock layers) running the SAME training step on the SAME kind of
+    synthetic batch, each row in its own process.
+      all-core row : every physical core (torch.set_num_threads(physical cores)); meta-training: a bounded sample of 2 samples per step
+                     (16 encoder frames; a full bs = 8 step is ~8 TFLOP of fp32 CPU work); fine-tuning: the full bs = 8 batch;
+      1-thread row : how the reference configures itself (OMP_NUM_THREADS=1, torch.set_num_threads(1): train.py:2, utils/utils.py:19), 1 sample.
     Default = a bounded sample (1 warm-up + up to 3 timed all-core steps, 1 + up to 2 one-thread steps: 1-2 minutes);
     --cpu-baseline-full runs the >= 3 warm-up + >= 10 timed protocol."""
     import subprocess
     model, cores, logical = _cpu_info()
-    use = min(cores, 64)       # torch-CPU oversubscribes badly beyond the physical cores
+    use = cores                 # all physical cores (the SMT siblings add nothing to torch-CPU GEMMs)
     warm, reps = (3, 10) if full else (1, 3)
+    meta = int(workload == 'metatrain_step')
+    name = 'meta-training' if meta else 'fine-tuning'
+    ab = 2 if meta else 8
 
     def run(threads, batch, w, r, budget):
         env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
-        out = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-worker', f'{threads},{batch},{w},{r},{budget},{args.image_size}'],
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-worker', f'{threads},{batch},{w},{r},{budget},{args.image_size},{meta}'],
                              env=env, capture_output=True, text=True, timeout=budget * 4 + 900)
         return json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
-    a = run(use, 8, warm, reps, 600 if full else 45)
+    a = run(use, ab, warm, reps, 600 if full else 45)
     o = run(1, 1, warm if full else 1, reps if full else 2, 900 if full else 40)
-    return {'value': round(8 / a['t'], 4), 'unit': 'images/s', 'cores': use, 'kind': 'port', 'cpu_model': model, 'physical_cores': cores,
-            'logical_cpus': logical,
+    return {'value': round(ab / a['t'], 4), 'unit': 'images/s', 'cores': use, 'kind': 'port', 'cpu_model': model, 'physical_cores': cores,
+            'logical_cpus': logical, 'workload': workload,
             'one_thread': {'value': round(1 / o['t'], 4), 'unit': 'images/s', 'cores': 1,
-                           'sample': f"median of {o['n']} fine-tuning step(s) of 1 image at {args.image_size}x{args.image_size}, OMP_NUM_THREADS=1 / "
+                           'sample': f"median of {o['n']} {name} step(s) of 1 sample at {args.image_size}x{args.image_size}, OMP_NUM_THREADS=1 / "
                                      f"torch.set_num_threads(1): {o['t']:.2f} s per step"},
-            'sample': f"median of {a['n']} fine-tuning step(s) of the bs=8 batch at {args.image_size}x{args.image_size} through oracle/lp_oracle.py "
-                      f"(torch CPU fp32, {use} threads = physical cores of {model}); {a['t']:.2f} s per step"
+            'sample': f"median of {a['n']} {name} step(s) of {ab} samples at {args.image_size}x{args.image_size} through oracle/lp_oracle.py "
+                      f"(+ the stock torch-CPU encoder layers; torch CPU fp32, {use} threads = all physical cores of {model}); {a['t']:.2f} s per step"
                       + ('' if full else '; bounded sample -- the >= 3 + >= 10 protocol is `bench.py --cpu-baseline-full` (profiles/)')}
 
 
@@ -283,8 +378,9 @@ def main():
     ap.add_argument('--generator', default='vector_pose_unsupervised_segmentation_noBottleneck', choices=['vector_pose_unsupervised_segmentation_noBottleneck', 'FSTH_plus'],
                     help='generator plugin of --workload generator (FSTH_plus with --image_size 512 --batch 4 = BASELINE configs[4])')
     ap.add_argument('--workload', default=None, choices=['finetune_step', 'metatrain_step', 'generator'],
-                    help='default: finetune_step at --gpus 1 (BASELINE configs[1]; the reference refuses multi-GPU fine-tuning), '
-                         'metatrain_step at --gpus > 1 (configs[2], default.yaml: the configuration that IS trained data-parallel)')
+                    help='default: metatrain_step for EVERY --gpus value (configs[2], default.yaml: the configuration that is trained data-parallel; one '
+                         'workload so that the 1/2/4/8-GPU values form a scaling curve).  finetune_step = BASELINE configs[1] (single GPU in the '
+                         'reference); the default N = 1 run also reports it under "finetune_step"')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-also', action='store_true', help='skip the side measurement of the strict bf16x3 mode')
     ap.add_argument('--eager', action='store_true', help='do not capture the step into hipGraphs')
@@ -308,8 +404,9 @@ def main():
         dist.init_process_group(backend=a.backend, init_method='env://')
     assert world == a.gpus, f'--gpus {a.gpus} but WORLD_SIZE={world}'
 
+    default_run = a.workload is None
     if a.workload is None:
-        a.workload = 'finetune_step' if world == 1 else 'metatrain_step'
+        a.workload = 'metatrain_step'
     finetune = a.workload != 'metatrain_step'
     args = make_args(a.image_size, a.batch, device, world, rank, a.prec, finetune=finetune)
     args.generator = a.generator
@@ -373,7 +470,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
         if a.workload != 'generator':
-            # the N = 1 point of THIS workload (`--gpus 1` defaults to the fine-tuning step, which the reference never runs multi-GPU):
+            # the N = 1 point of THIS workload measured inside the same job (a cross-check of the driver's separate --gpus 1 run):
             # every rank repeats the timed loop with the gradient exchange removed -- one GPU's throughput on the same step and batch
             red, tm.reducer = tm.reducer, None
             nsolo = min(a.steps, 50)
@@ -425,7 +522,11 @@ def main():
             # HBM bytes per launch of this kernel family from the committed PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs of
             # `bench.py --workload generator` under rocprofv3, scripts/r02_artifacts.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md)
             try:
-                pm = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc_conv_dma.json')))
+                pm_path = os.path.join(ROOT, 'profiles', 'r03_pmc_conv_dma_step.json')
+                step_pop = os.path.exists(pm_path)
+                if not step_pop:
+                    pm_path = os.path.join(ROOT, 'profiles', 'r02_pmc_conv_dma.json')
+                pm = json.load(open(pm_path))
                 entry['traffic'] = pm.get('hbm_bytes_per_launch')
                 # algorithmic bytes of the SAME population (the 12 layer classes of scripts/conv_micro.py, N tiles of 128 channels):
                 micro = [(8, 4, 4, 512, 512, 3, 0), (8, 16, 16, 512, 512, 3, 0), (8, 32, 32, 512, 512, 3, 0), (8, 64, 64, 256, 256, 3, 0),
@@ -433,7 +534,13 @@ def main():
                          (8, 64, 64, 512, 256, 3, 1), (8, 64, 64, 256, 128, 1, 0), (16, 128, 128, 128, 128, 3, 0), (16, 64, 64, 256, 256, 3, 0)]
                 alg = sum(2 * n_ * (h_ >> u_) * (w_ >> u_) * ci_ * ((co_ + 127) // 128) + 2 * k_ * k_ * ci_ * co_ + 4 * n_ * h_ * w_ * co_
                           for n_, h_, w_, ci_, co_, k_, u_ in micro) / len(micro)
-                entry['traffic_note'] = ('mean HBM bytes per conv_dma_kernel launch over the per-layer micro-benchmark (scripts/conv_micro.py, 12 layer '
+                if step_pop:
+                    entry['traffic_note'] = ('mean HBM bytes per conv_dma_kernel launch over the launch population of one generator fwd+bwd step '
+                                             '(profiles/r03_pmc_conv_dma_step.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of '
+                                             '`bench.py --workload generator`, kernel filter conv_dma; (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per '
+                                             f"MI355X_MICROARCH.md); MFMA busy fraction from SQ_VALU_MFMA_BUSY_CYCLES: {pm.get('mfma_busy_fraction')}")
+                else:
+                  entry['traffic_note'] = ('mean HBM bytes per conv_dma_kernel launch over the per-layer micro-benchmark (scripts/conv_micro.py, 12 layer '
                                          'classes; profiles/r02_pmc_conv_dma.json: (2 x FETCH_SIZE + WRITE_SIZE) x 1024, separate rocprofv3 --pmc '
                                          f'passes); algorithmic bytes of the same 12 launches: {alg / 1e6:.1f} MB mean; per-shape values: '
                                          'profiles/r02_pmc_conv_micro_f16.csv; MFMA busy fraction from SQ_VALU_MFMA_BUSY_CYCLES: '
@@ -466,14 +573,19 @@ def main():
             'config': {'workload': {'finetune_step': 'finetuning-base.yaml step (configs[1]): G, D, VGG19/VGGFace criterions, RAdam, EMA, spectral '
                                                      'norm and the MobileNetV2 pose encoder on hand-written gfx950 kernels',
                                     'metatrain_step': 'default.yaml meta-training step (configs[2]): ResNeXt50 identity encoder over 8 frames + '
-                                                      'MobileNetV2 pose encoder (both trained here: torch-ROCm autograd), G, D with the 98000x512 label embedding, '
-                                                      'VGG19/VGGFace/featmat/adversarial/dis_embed/dice criterions, Adam, EMA (gfx950 kernels)',
+                                                      'MobileNetV2 pose encoder (both trained, forward + backward on hand-written gfx950 kernels), G, D with '
+                                                      'the 98000x512 label embedding, VGG19/VGGFace/featmat/adversarial/dis_embed/dice criterions, Adam, EMA',
                                     'generator': 'generator forward+backward only (HIP kernels)'}[a.workload],
                        'image_size': a.image_size, 'per_gpu_batch': a.batch, 'global_batch': a.batch * world,
                        'parallelism': f'dp{world}', 'precision_mode': a.prec,
                        'launch_mode': mode if a.workload != 'generator' else 'eager'},
             'roofline': roof,
         }
+        # whole-step MFMA utilisation: the number the 0.60 target of BASELINE.json is about (useful dense FLOPs of the step / time / peak)
+        tf = step_algorithmic_tflop(a.workload, a.batch, args.n_frames_for_encoder) * world
+        out['step_mfma_utilisation'] = {'algorithmic_tflop_per_step': round(tf, 3), 'achieved_tflops': round(tf / (dt / a.steps), 1),
+                                        'frac_of_bf16_peak': round(tf / (dt / a.steps) / (MFMA_BF16_PEAK_TFLOPS * world), 4),
+                                        'note': 'useful dense 2*MAC of one step as executed (step_algorithmic_tflop) / ms_per_step / (2.5 PF x n_gpus)'}
         out.update(extra)
         if solo is not None:
             out['single_gpu_same_workload'] = solo
@@ -482,21 +594,35 @@ def main():
                 out['drive'] = drive_fps(args)
             except Exception as ex:
                 out['drive'] = {'error': repr(ex)}
-        if world == 1 and a.prec == 'f16' and a.workload == 'finetune_step' and not a.no_also:
-            # the strict-parity mode (bf16x3: 3 MFMAs per MAC, fp32-class results) measured by the same script in a child process
+        def child(extra_args, timeout=600):
+            import subprocess
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), '--steps', '20', '--warmup', '5', '--no-cpu-baseline', '--no-also'] + extra_args,
+                               capture_output=True, text=True, timeout=timeout)
+            return json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+        if world == 1 and a.prec == 'f16' and a.workload in ('finetune_step', 'metatrain_step') and not a.no_also:
+            # the strict-parity mode (bf16x3: 3 MFMAs per MAC, fp32-class results) of the SAME workload, measured by the same script in a
+            # child process.  Parity status of the two modes: the f16 headline meets the 1e-3 OUTPUT gate of BASELINE.json; the full
+            # SURVEY 8(d) gate (outputs, losses AND every parameter gradient within 1e-3) is met in bf16x3 only.
             try:
-                import subprocess
-                r = subprocess.run([sys.executable, os.path.abspath(__file__), '--prec', 'bf16x3', '--steps', '20', '--warmup', '5',
-                                    '--no-cpu-baseline', '--no-also'], capture_output=True, text=True, timeout=600)
-                j = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+                j = child(['--prec', 'bf16x3', '--workload', a.workload])
                 out['strict_mode_bf16x3'] = {'value': j['value'], 'unit': j['unit'], 'ms_per_step': j['ms_per_step'],
                                              'roofline_frac': (j.get('roofline') or {}).get('frac'),
-                                             'parity': 'outputs 2.5e-6, tie-masked gradients 2.7e-5 from the fp32 CPU path (tests/test_full_size_parity.py)'}
+                                             'parity': 'meets the full SURVEY 8(d) gate: outputs 2.5e-6, tie-masked gradients <= 2.4e-4 from the fp32 '
+                                                       'CPU path (tests/test_full_size_parity.py); the f16 headline meets the 1e-3 output gate '
+                                                       '(1.7e-4) but its gradients are 4e-4 .. 9e-3'}
             except Exception as ex:
                 out['strict_mode_bf16x3'] = {'error': repr(ex)}
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and default_run and not a.no_also:
+            # BASELINE configs[1] (fine-tuning step, single GPU in the reference) beside the scaling workload
             try:
-                out['cpu_baseline'] = cpu_baseline(args, full=a.cpu_baseline_full)
+                j = child(['--prec', a.prec, '--workload', 'finetune_step'])
+                out['finetune_step'] = {k: j.get(k) for k in ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'roofline', 'step_mfma_utilisation')}
+                out['finetune_step']['config'] = j.get('config')
+            except Exception as ex:
+                out['finetune_step'] = {'error': repr(ex)}
+        if world == 1 and not a.no_cpu_baseline and a.workload != 'generator':
+            try:
+                out['cpu_baseline'] = cpu_baseline(args, full=a.cpu_baseline_full, workload=a.workload)
             except Exception as ex:      # never lose the GPU line because of the baseline leg
                 out['cpu_baseline'] = {'error': repr(ex)}
         print(json.dumps(out))

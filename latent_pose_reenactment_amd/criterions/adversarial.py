@@ -56,6 +56,9 @@ class HingeFn(torch.autograd.Function):
                                               torch.cuda.current_stream().cuda_stream), 'lp_reduce_hinge')
         ctx.save_for_backward(r, fd)
         ctx.shape = real.shape
+        # the two losses are backpropagated separately (loss_G.backward, then loss_D.backward: holycow.py:239-250): an output whose
+        # gradient is absent must arrive as None -- a materialised zero would be propagated through the whole generator/embedder graph
+        ctx.set_materialize_grads(False)
         return out[0], out[1]
 
     @staticmethod
@@ -63,14 +66,14 @@ class HingeFn(torch.autograd.Function):
         from latent_pose_reenactment_amd import _lib
         r, fd = ctx.saved_tensors
         n = r.numel()
-        need = ctx.needs_input_grad
-        zero = None
-        if gG is None or gD is None:
-            zero = torch.zeros(1, dtype=torch.float32, device=r.device)
-        g1 = (gG if gG is not None else zero).reshape(1).contiguous().float()
-        g2 = (gD if gD is not None else zero).reshape(1).contiguous().float()
+        # input i is reached only through the loss whose gradient is present: real, fake_d <- loss_D; fake_g <- loss_G
+        need = [ctx.needs_input_grad[0] and gD is not None, ctx.needs_input_grad[1] and gD is not None, ctx.needs_input_grad[2] and gG is not None]
+        if not any(need):
+            return None, None, None
+        g1 = None if gG is None else gG.reshape(1).contiguous().float()
+        g2 = None if gD is None else gD.reshape(1).contiguous().float()
         outs = [torch.empty(n, dtype=torch.float32, device=r.device) if nd else None for nd in need]
         p = lambda t: None if t is None else t.data_ptr()
-        _lib.check(_lib.lib().lp_reduce_hinge_bwd(r.data_ptr(), fd.data_ptr(), g1.data_ptr(), g2.data_ptr(), p(outs[0]), p(outs[1]), p(outs[2]), n,
+        _lib.check(_lib.lib().lp_reduce_hinge_bwd(r.data_ptr(), fd.data_ptr(), p(g1), p(g2), p(outs[0]), p(outs[1]), p(outs[2]), n,
                                                   torch.cuda.current_stream().cuda_stream), 'lp_reduce_hinge_bwd')
         return tuple(None if o is None else o.view(ctx.shape) for o in outs)

@@ -761,7 +761,7 @@ def pack_grouped(w: Tensor, mode: int, prec: int) -> WeightPack:
     hi = torch.empty((9, cp, 64), dtype=torch.int16, device=w.device)
     lo = torch.empty_like(hi) if prec == PREC_BF16X3 else None
     check(_lib.lib().lp_pack_grouped(w.data_ptr(), hi.data_ptr(), _p(lo), c, cg, cp, mode, _f16(prec), _stream()), 'lp_pack_grouped')
-    return WeightPack(hi, lo, c, 64, cp, 64, 9)
+    return WeightPack(hi, lo, c, cg, cp, 64, 9)          # cols = the group size (logical contraction width per output channel)
 
 
 def gconv16(a: Act16, pack: WeightPack, *, prec: int, amax: bool = False) -> Tensor:
@@ -771,7 +771,7 @@ def gconv16(a: Act16, pack: WeightPack, *, prec: int, amax: bool = False) -> Ten
     assert c == pack.rows and a.hi.shape[3] == c, (a.hi.shape, pack.rows)
     y = torch.empty((n, h, w, c), dtype=torch.float32, device=a.hi.device)
     slots = _amax_attach(y, amax and prec == PREC_F16)
-    with _Timed('gconv', 2.0 * n * h * w * c * 64 * 9, (n, h, w, c, c, 3, 0, 0)):
+    with _Timed('gconv', 2.0 * n * h * w * c * pack.cols * 9, (n, h, w, pack.cols, c, 3, 0, 0)):
         check(_lib.lib().lp_gconv16_fwd(a.hi.data_ptr(), _p(a.lo), pack.hi.data_ptr(), _p(pack.lo), y.data_ptr(), _p(a.inv), n, h, w, c,
                                         pack.rows_p, prec, _p(slots), _stream()), 'lp_gconv16_fwd')
     return y
@@ -786,7 +786,7 @@ def gconv_wgrad16(a: Act16, dy: Act16, group_size: int, *, prec: int, splits: Op
         splits = max(1, min(512 // max(1, c // 64), (n * h * w + 127) // 128))
     ws = torch.empty(_lib.lib().lp_gconv_wgrad_workspace_bytes(c, splits) // 4, dtype=torch.float32, device=dy.hi.device)
     dw = torch.empty((c, group_size, 3, 3), dtype=torch.float32, device=dy.hi.device)
-    with _Timed('gconv_wgrad', 2.0 * n * h * w * c * 64 * 9, (n, h, w, c, c, 3, 0, 0)):
+    with _Timed('gconv_wgrad', 2.0 * n * h * w * c * group_size * 9, (n, h, w, group_size, c, 3, 0, 0)):
         check(_lib.lib().lp_gconv16_wgrad(a.hi.data_ptr(), _p(a.lo), dy.hi.data_ptr(), _p(dy.lo), dw.data_ptr(), ws.data_ptr(), n, h, w, c,
                                           group_size, splits, prec, _p(dy.inv), _stream()), 'lp_gconv16_wgrad')
     return dw

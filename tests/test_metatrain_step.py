@@ -90,3 +90,60 @@ def test_metatrain_iteration_matches_reference_run_epoch(monkeypatch):
     # state tensors: Adam moves every element by ~lr, so a wrong sign on a ~0-gradient element is lr-sized: absolute gate on states
     bad = {k: v for k, v in errs.items() if v >= (5e-3 if k.startswith('E.grad') else 2e-4 if k.startswith('loss.') or k in ('embeds', 'pose_embedding') else 2e-3)}
     assert not bad, bad
+
+
+def test_metatrain_step_hip_embedder_vs_stock_layers(monkeypatch):
+    """One meta-training iteration with BOTH encoders in train mode (BatchNorm batch statistics, as the reference holds them) through the
+    HIP encoders (embedders/resnext_hip.py, mobilenet_hip.py) vs the same step through the stock PyTorch-ROCm layers: identical
+    initial state and batch; embeddings, every loss, the BatchNorm buffers after the step.  (Dropout p = 0 on both sides.)"""
+    monkeypatch.setenv('LP_PREC', 'bf16x3')
+    monkeypatch.setenv('LP_PREC_E', 'bf16x3')
+    import copy
+    from generators.vector_pose_unsupervised_segmentation_noBottleneck import Wrapper as GW
+    from embedders.unsupervised_pose_separate_embResNeXt_segmentation import Wrapper as EW
+    from embedders import backbones
+    from discriminators.no_landmarks import Wrapper as DW
+    from criterions import adversarial, featmat, dice, dis_embed
+    from runners import holycow
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from test_resnext_hip import structured_frames
+    a = argparse.Namespace(image_size=128, num_channels=4, max_num_channels=16, embed_channels=8, pose_embedding_size=4, in_channels=3,
+                           out_channels=3, num_labels=5, dis_num_blocks=5, gen_padding='zero', norm_layer='in', gen_constant_input_size=4,
+                           gen_num_residual_blocks=2, dis_padding='zero', device='cuda', optimizer='Adam', lr_gen=5e-5, lr_dis=2e-4,
+                           beta1=0.0, finetune=False, num_gpus=1, average_function='sum')
+    torch.manual_seed(META_SEED)
+    E0, G0, D0 = EW.get_net(a), GW.get_net(a), DW.get_net(a)
+    E0.pose_encoder.classifier[0].p = 0.0
+    b = 8
+    data = {'enc_rgbs': structured_frames(b, 128, 1).view(b, 1, 3, 128, 128).cuda(), 'pose_input_rgbs': structured_frames(b, 128, 2).view(b, 1, 3, 128, 128).cuda(),
+            'target_rgbs': structured_frames(b, 128, 3).view(b, 1, 3, 128, 128).cuda()}
+    target = {'real_segm': (structured_frames(b, 128, 4).view(b, 1, 3, 128, 128)[:, :, :1].expand(b, 1, 3, 128, 128) > 0.5).float().contiguous().cuda(),
+              'label': torch.arange(b).cuda() % 5}
+    results = {}
+    for mode in ('hip', 'stock'):
+        backbones.set_hip_forward(mode == 'hip')
+        try:
+            E, G, D = copy.deepcopy(E0), copy.deepcopy(G0), copy.deepcopy(D0)
+            crits = [adversarial.Criterion('gan'), featmat.Criterion(10.0), dis_embed.Criterion(1e-2), dice.Criterion(1.0)]
+            tm = holycow.TrainingModule(E, G, D, crits, [], {})
+            opt_G = holycow.get_optimizer(tm.embedder, tm.generator, a)
+            opt_D = DW.get_optimizer(tm.discriminator, a)
+            tm.train()
+            all_data, lG, lD = holycow.train_step(tm, data, target, opt_G, opt_D, a)
+            torch.cuda.synchronize()
+            if mode == 'hip':
+                assert E.identity_encoder.__dict__.get('_hip_param_names') is not None and E.pose_encoder.__dict__.get('_hip_feature_param_names') is not None
+            results[mode] = dict(embeds=all_data['embeds'].detach().clone(), pose=all_data['pose_embedding'].detach().clone(),
+                                 losses={k: v.detach().clone() for k, v in {**lG, **lD}.items()},
+                                 buffers={k: v.detach().clone() for k, v in E.state_dict().items() if 'running' in k or 'tracked' in k},
+                                 egrad=torch.cat([p.grad.reshape(-1) for p in E.parameters()]).clone())
+        finally:
+            backbones.set_hip_forward(True)
+    h, s_ = results['hip'], results['stock']
+    errs = {'embeds': rel(h['embeds'], s_['embeds'].cpu()), 'pose': rel(h['pose'], s_['pose'].cpu())}
+    errs.update({'loss.' + k: rel(h['losses'][k], s_['losses'][k].cpu()) for k in h['losses']})
+    errs['buffers'] = max(rel(h['buffers'][k].double(), s_['buffers'][k].double().cpu()) for k in h['buffers'])
+    cos = float((h['egrad'].double() * s_['egrad'].double()).sum() / (h['egrad'].double().norm() * s_['egrad'].double().norm()))
+    print('[parity] meta-train step, train-mode encoders, HIP vs stock layers:', {k: f'{v:.2e}' for k, v in errs.items()}, f'encoder-gradient cosine {cos:.4f}')
+    assert all(v < 2e-3 for v in errs.values()), errs
+    assert cos > 0.9, cos
