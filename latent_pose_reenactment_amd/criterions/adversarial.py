@@ -31,8 +31,7 @@ class Criterion(nn.Module):
         real = data_dict['real_score']
         fd, fg = data_dict['fake_score_D'], data_dict['fake_score_G']
         if self.gan_type == 'gan' and real.is_cuda and real.dtype == torch.float32 and real.shape == fd.shape == fg.shape:
-            loss_G, loss_D = HingeFn.apply(real, fd, fg)          # lp_reduce_hinge: one launch for both losses (+ one for the backward)
-            return {'adversarial_G': loss_G}, {'adversarial_D': loss_D}
+            return {'adversarial_G': HingeGFn.apply(fg)}, {'adversarial_D': HingeDFn.apply(real, fd)}      # lp_reduce_hinge (+ _bwd)
         real_pred, fake_pred_D = self._preds(real, data_dict['fake_score_D'])
         _, fake_pred_G = self._preds(real, data_dict['fake_score_G'])
         loss_D = torch.relu(1. - real_pred).mean() + torch.relu(1. + fake_pred_D).mean()
@@ -43,37 +42,57 @@ class Criterion(nn.Module):
         return {'adversarial_G': loss_G}, {'adversarial_D': loss_D}
 
 
-class HingeFn(torch.autograd.Function):
-    """(loss_G, loss_D) = (-mean(fake_G), mean(relu(1 - real)) + mean(relu(1 + fake_D))) over the B critic scores --
-    criterions/adversarial.py:41-52 of the reference, gan_type 'gan'."""
+class HingeDFn(torch.autograd.Function):
+    """loss_D = mean(relu(1 - real)) + mean(relu(1 + fake_D)) over the B critic scores (criterions/adversarial.py:41-44 of the reference,
+    gan_type 'gan'): lp_reduce_hinge / lp_reduce_hinge_bwd.  loss_G and loss_D are SEPARATE autograd nodes on purpose: a joint node would
+    make the whole generator/embedder graph reachable from loss_D (the engine walks edges even when a gradient is undefined, and every
+    Python Function on the way would materialise zeros and run its backward)."""
 
     @staticmethod
-    def forward(ctx, real, fake_d, fake_g):
+    def forward(ctx, real, fake_d):
         from latent_pose_reenactment_amd import _lib
-        r, fd, fg = (t.detach().contiguous().reshape(-1) for t in (real, fake_d, fake_g))
+        r, fd = (t.detach().contiguous().reshape(-1) for t in (real, fake_d))
         out = torch.empty(2, dtype=torch.float32, device=r.device)
-        _lib.check(_lib.lib().lp_reduce_hinge(r.data_ptr(), fd.data_ptr(), fg.data_ptr(), out.data_ptr(), r.numel(),
+        _lib.check(_lib.lib().lp_reduce_hinge(r.data_ptr(), fd.data_ptr(), fd.data_ptr(), out.data_ptr(), r.numel(),
                                               torch.cuda.current_stream().cuda_stream), 'lp_reduce_hinge')
         ctx.save_for_backward(r, fd)
         ctx.shape = real.shape
-        # the two losses are backpropagated separately (loss_G.backward, then loss_D.backward: holycow.py:239-250): an output whose
-        # gradient is absent must arrive as None -- a materialised zero would be propagated through the whole generator/embedder graph
-        ctx.set_materialize_grads(False)
-        return out[0], out[1]
+        return out[1]
 
     @staticmethod
-    def backward(ctx, gG, gD):
+    def backward(ctx, gD):
         from latent_pose_reenactment_amd import _lib
         r, fd = ctx.saved_tensors
         n = r.numel()
-        # input i is reached only through the loss whose gradient is present: real, fake_d <- loss_D; fake_g <- loss_G
-        need = [ctx.needs_input_grad[0] and gD is not None, ctx.needs_input_grad[1] and gD is not None, ctx.needs_input_grad[2] and gG is not None]
-        if not any(need):
-            return None, None, None
-        g1 = None if gG is None else gG.reshape(1).contiguous().float()
-        g2 = None if gD is None else gD.reshape(1).contiguous().float()
-        outs = [torch.empty(n, dtype=torch.float32, device=r.device) if nd else None for nd in need]
+        g = gD.reshape(1).contiguous().float()
+        outs = [torch.empty(n, dtype=torch.float32, device=r.device) if nd else None for nd in ctx.needs_input_grad]
         p = lambda t: None if t is None else t.data_ptr()
-        _lib.check(_lib.lib().lp_reduce_hinge_bwd(r.data_ptr(), fd.data_ptr(), p(g1), p(g2), p(outs[0]), p(outs[1]), p(outs[2]), n,
+        _lib.check(_lib.lib().lp_reduce_hinge_bwd(r.data_ptr(), fd.data_ptr(), None, g.data_ptr(), p(outs[0]), p(outs[1]), None, n,
                                                   torch.cuda.current_stream().cuda_stream), 'lp_reduce_hinge_bwd')
         return tuple(None if o is None else o.view(ctx.shape) for o in outs)
+
+
+class HingeGFn(torch.autograd.Function):
+    """loss_G = -mean(fake_G) (criterions/adversarial.py:46-47 of the reference)"""
+
+    @staticmethod
+    def forward(ctx, fake_g):
+        from latent_pose_reenactment_amd import _lib
+        fg = fake_g.detach().contiguous().reshape(-1)
+        out = torch.empty(2, dtype=torch.float32, device=fg.device)
+        _lib.check(_lib.lib().lp_reduce_hinge(fg.data_ptr(), fg.data_ptr(), fg.data_ptr(), out.data_ptr(), fg.numel(),
+                                              torch.cuda.current_stream().cuda_stream), 'lp_reduce_hinge')
+        ctx.save_for_backward(fg)
+        ctx.shape = fake_g.shape
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, gG):
+        from latent_pose_reenactment_amd import _lib
+        (fg,) = ctx.saved_tensors
+        n = fg.numel()
+        g = gG.reshape(1).contiguous().float()
+        d = torch.empty(n, dtype=torch.float32, device=fg.device)
+        _lib.check(_lib.lib().lp_reduce_hinge_bwd(fg.data_ptr(), fg.data_ptr(), g.data_ptr(), None, None, None, d.data_ptr(), n,
+                                                  torch.cuda.current_stream().cuda_stream), 'lp_reduce_hinge_bwd')
+        return d.view(ctx.shape)

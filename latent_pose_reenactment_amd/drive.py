@@ -49,12 +49,18 @@ def load_for_inference(checkpoint_path, data_root, device):
     return embedder, generator, saved_args
 
 
-def drive_frame(embedder, generator, data_dict):
-    """one iteration of the hot loop (drive.py:84-88) -> uint8 HWC frame grid (driver | result)"""
+def drive_frames(embedder, generator, data_dict):
+    """one iteration of the hot loop (drive.py:84-88) on a batch of B >= 1 driving frames -> uint8 [B, H, 2W, 3] frame grids
+    (driver | result), left ON THE DEVICE: the caller gathers a whole sequence and crosses PCIe once (no per-frame host sync)"""
     embedder.get_pose_embedding(data_dict)
     generator(data_dict)
-    to_u8 = lambda img: img.permute(1, 2, 0).clamp(0, 1).mul(255).byte()
-    return torch.cat((to_u8(data_dict['pose_input_rgbs'][0, 0]), to_u8(data_dict['fake_rgbs'][0])), dim=1)
+    to_u8 = lambda img: img.permute(0, 2, 3, 1).clamp(0, 1).mul(255).byte()
+    return torch.cat((to_u8(data_dict['pose_input_rgbs'][:, 0]), to_u8(data_dict['fake_rgbs'])), dim=2)
+
+
+def drive_frame(embedder, generator, data_dict):
+    """single-frame form (B = 1) -> uint8 HWC frame grid"""
+    return drive_frames(embedder, generator, data_dict)[0]
 
 
 def main():
@@ -66,11 +72,13 @@ def main():
     ap.add_argument('data_root', type=Path)
     ap.add_argument('--images_paths', type=Path, nargs='+')
     ap.add_argument('--destination', type=Path, required=True)
+    ap.add_argument('--batch_size', type=int, default=1, help='driving frames per generator call (the reference drives one frame at a time)')
     args = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit('drive.py needs the MI355X: the generator has no CPU fallback')
     device = 'cuda:0'
     embedder, generator, saved_args = load_for_inference(args.checkpoint_path, args.data_root, device)
+    saved_args.batch_size = max(1, args.batch_size)
     from dataloaders.dataloader import Dataloader
     for driver in args.images_paths:
         saved_args.val_split_path = driver
@@ -80,9 +88,10 @@ def main():
         frames = []
         for data_dict, _ in loader:
             utils.dict_to_device(data_dict, device)
-            frames.append(drive_frame(embedder, generator, data_dict).cpu().numpy())
-        np.save(out, np.stack(frames))
-        logger.info(f'wrote {len(frames)} frames to {out}')
+            frames.append(drive_frames(embedder, generator, data_dict))       # uint8 on the device: nothing waits for the GPU here
+        video = torch.cat(frames).cpu().numpy()                             # one device-to-host transfer (and sync) per sequence
+        np.save(out, video)
+        logger.info(f'wrote {len(video)} frames to {out}')
 
 
 if __name__ == '__main__':

@@ -228,6 +228,10 @@ def run_epoch(dataloader, training_module, optimizer_G, optimizer_D, epoch, args
         if optimizer_D:
             optimizer_D.zero_grad()
     use_graph = phase == 'train' and getattr(args, 'hip_graph', False) and str(args.device).startswith('cuda')
+    if phase == 'train' and str(args.device).startswith('cuda') and getattr(args, 'prefetch_to_device', True):
+        # pinned, double-buffered H2D on a side stream, one batch ahead of the computing step (dataloaders/prefetch.py)
+        from latent_pose_reenactment_amd.dataloaders.prefetch import DevicePrefetcher
+        dataloader = DevicePrefetcher(dataloader, args.device)
     log_every = max(1, int(getattr(args, 'log_frequency_loss', 1)))
     end = time.time()
     for it, (data_dict, target_dict) in enumerate(dataloader):

@@ -73,3 +73,21 @@ def test_drive_frame_on_reference_written_checkpoint(monkeypatch):
         want = rgb[0].permute(1, 2, 0).clamp(0, 1).mul(255).byte()
         diff = (out[:, 32:].cpu().int() - want.int()).abs()
         assert diff.max().item() <= 1 and (diff > 0).float().mean().item() < 0.02, (diff.max().item(), (diff > 0).float().mean().item())
+
+
+@pytest.mark.gpu
+def test_drive_batch_of_frames_equals_single_frames(monkeypatch):
+    """drive loop with B > 1 driving frames per generator call: same frames as B single-frame calls, results stay on the device"""
+    monkeypatch.setenv('LP_PREC', 'bf16x3')
+    _register()
+    import drive
+    torch.set_grad_enabled(True)
+    with torch.no_grad():
+        E, G, _ = drive.load_for_inference(CKPT, '/nonexistent', 'cuda:0')
+        g = torch.Generator().manual_seed(4)
+        frames = torch.rand(3, 1, 3, 32, 32, generator=g).cuda()
+        batch = drive.drive_frames(E, G, {'pose_input_rgbs': frames})
+        assert batch.is_cuda and batch.shape == (3, 32, 64, 3) and batch.dtype == torch.uint8
+        for i in range(3):
+            one = drive.drive_frame(E, G, {'pose_input_rgbs': frames[i:i + 1]})
+            assert (batch[i].int() - one.int()).abs().max().item() <= 1

@@ -95,15 +95,16 @@ class TM(torch.nn.Module):
         super().__init__()
         s.embedder = torch.nn.Linear(3, 2); s.generator = torch.nn.Linear(4, 3); s.discriminator = torch.nn.Linear(5, 1)
 tm = TM()
-if rank == 1:
-    for p in tm.parameters(): p.data.add_(1.0)            # will be overwritten by the rank-0 broadcast
+if rank >= 1:
+    for p in tm.parameters(): p.data.add_(float(rank))            # will be overwritten by the rank-0 broadcast
 red = GradReducer(tm, finetune=False)
 for p in tm.parameters(): p.grad = torch.full_like(p, float(rank + 1))
 red.reduce_generator_side(async_op=True); red.wait_generator_side()
-ok = all(torch.allclose(p.grad, torch.full_like(p, 1.5)) for p in list(tm.generator.parameters()) + list(tm.embedder.parameters()))
+W = dist.get_world_size(); mean = (W + 1) / 2
+ok = all(torch.allclose(p.grad, torch.full_like(p, mean)) for p in list(tm.generator.parameters()) + list(tm.embedder.parameters()))
 ok &= all(torch.allclose(p.grad, torch.full_like(p, float(rank + 1))) for p in tm.discriminator.parameters())   # untouched so far
 red.reduce_discriminator_side()
-ok &= all(torch.allclose(p.grad, torch.full_like(p, 1.5)) for p in tm.discriminator.parameters())
+ok &= all(torch.allclose(p.grad, torch.full_like(p, mean)) for p in tm.discriminator.parameters())
 # arena path: a (stand-in) fused optimizer owning one flat gradient buffer per side is reduced in place
 class Arena:
     def __init__(s, params):
@@ -117,23 +118,60 @@ oG, oD = Arena(list(tm.generator.parameters()) + list(tm.embedder.parameters()))
 red2 = GradReducer(tm, finetune=False, broadcast=False, optimizer_G=oG, optimizer_D=oD)
 oG.flat.fill_(float(rank + 1)); oD.flat.fill_(float(10 * (rank + 1)))
 red2.reduce_generator_side(async_op=True); red2.wait_generator_side(); red2.reduce_discriminator_side()
-ok &= bool(torch.allclose(oG.flat, torch.full_like(oG.flat, 1.5))) and bool(torch.allclose(oD.flat, torch.full_like(oD.flat, 15.0)))
-ok &= all(torch.allclose(p.grad, torch.full_like(p, 1.5)) for p in tm.generator.parameters())
+ok &= bool(torch.allclose(oG.flat, torch.full_like(oG.flat, mean))) and bool(torch.allclose(oD.flat, torch.full_like(oD.flat, 10 * mean)))
+ok &= all(torch.allclose(p.grad, torch.full_like(p, mean)) for p in tm.generator.parameters())
 w = [p.detach().clone() for p in tm.parameters()]
-gathered = [None, None]; dist.all_gather_object(gathered, [t.tolist() for t in w])
-ok &= gathered[0] == gathered[1]                            # parameters identical after the broadcast
+gathered = [None] * W; dist.all_gather_object(gathered, [t.tolist() for t in w])
+ok &= all(g_ == gathered[0] for g_ in gathered)                            # parameters identical after the broadcast
+# row-sparse label-embedding exchange (meta-training): every rank publishes (labels, B gradient rows, rank-1 coefficient); the rebuilt
+# gradient must equal the average of the ranks' dense gradients  rows-scatter - coef * u v^T  -- also for labels above 2^24 (int64 exchange)
+class SNW(torch.nn.Module):
+    def __init__(s, n, e):
+        super().__init__()
+        s.weight_orig = torch.nn.Parameter(torch.randn(n, e)); s.register_buffer('weight_u', torch.randn(n)); s.register_buffer('weight_v', torch.randn(e))
+class Dis(torch.nn.Module):
+    def __init__(s):
+        super().__init__()
+        s.lin = torch.nn.Linear(5, 1); s.embed = SNW(5000, 6)
+class TM2(torch.nn.Module):
+    def __init__(s):
+        super().__init__()
+        s.embedder = torch.nn.Linear(3, 2); s.generator = torch.nn.Linear(4, 3); s.discriminator = Dis()
+torch.manual_seed(1 + rank)                                  # different (u, v) per rank: the constructor's broadcast must unify them
+tm2 = TM2()
+oD2 = Arena(tm2.discriminator.parameters())
+red3 = GradReducer(tm2, finetune=False, optimizer_D=oD2)
+u, v = tm2.discriminator.embed.weight_u, tm2.discriminator.embed.weight_v
+gu = [None] * W; dist.all_gather_object(gu, (u.tolist(), v.tolist()))
+ok &= all(g_ == gu[0] for g_ in gu)
+g = torch.Generator().manual_seed(100 + rank)
+B, E = 3, 6
+label = torch.randint(0, 5000, (B,), generator=g); rows = torch.randn(B, E, generator=g); coef = torch.randn((), generator=g)
+dense = torch.zeros(5000, E); dense.index_add_(0, label, rows); dense.addmm_((u * (-coef))[:, None], v[None, :])
+oD2.flat.fill_(float(rank + 1))
+emb_grad = tm2.discriminator.embed.weight_orig.grad
+emb_grad.fill_(float('nan'))                              # the sparse path must REBUILD this slice from the published parts (a dense all-reduce would keep NaN)
+tm2.discriminator._embed_parts = {'parts': (label, rows, coef, u, v)}
+red3.reduce_discriminator_side()
+alld = [None] * W; dist.all_gather_object(alld, dense.tolist())
+want = sum(torch.tensor(d_) for d_ in alld) / W
+ok &= bool(torch.allclose(emb_grad, want, atol=1e-5))
+ok &= all(torch.allclose(p.grad, torch.full_like(p, mean)) for p in tm2.discriminator.lin.parameters())
 print('REDUCER_OK' if ok else 'REDUCER_FAIL', flush=True)
 dist.destroy_process_group()
 '''
 
 
-def test_grad_reducer_two_rank_gloo(tmp_path):
+@pytest.mark.parametrize('world', [2, 4])
+def test_grad_reducer_gloo(tmp_path, world):
+    """parallel.GradReducer on 2 and 4 gloo ranks: ONE flat start-up broadcast (parameters + the label embedding's power-iteration
+    vectors), per-side mean all-reduce (tensor list and flat-arena paths), the row-sparse label-embedding exchange with int64 labels"""
     script = tmp_path / 'worker.py'
     script.write_text(REDUCER_WORKER)
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', WORLD_SIZE='2')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29533 + world), WORLD_SIZE=str(world))
     procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
-                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
-    outs = [p.communicate(timeout=180)[0] for p in procs]
+                              stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
     assert all('REDUCER_OK' in o for o in outs), outs
 
 

@@ -317,8 +317,14 @@ def test_resnext_forward_backward_vs_fp64(monkeypatch, prec_name, train, depth):
           f'| stock fp32 layers vs fp64: logits {c_out:.2e}, all-gradients {c_tot:.2e}')
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
     if depth == 'shallow':
-        tol_out, tol_g, tol_b = (3e-5, 1e-3, 1e-5) if prec_name == 'bf16x3' else (2e-3, 3e-2, 1e-3)
-        assert e_out < tol_out and tot < max(tol_g, 3 * c_tot) and e_b < tol_b, (e_out, tot, e_b, c_out, c_tot)
+        # gates = 2-3x what a CPU emulation of the SAME operand rounding predicts for this net and input (fp64 arithmetic, operands of every
+        # contraction rounded to hi+lo bf16 / to fp16 with the power-of-two gradient scale: scripts/embedder_rounding_study.py):
+        #   bf16x3: eval 6.7e-6 / 3.0e-4, train 3.6e-5 / 1.5e-2;   f16: eval 4.9e-4 / 1.7e-3, train 3.0e-3 / 1.3e-1   (logits / all gradients)
+        # i.e. the kernels reproduce the arithmetic they are specified to do; what is left is the conditioning of train-mode BatchNorm + ReLU
+        # at random initialisation (the stock fp32 layers are 3e-3 off in the gradients on the same problem).
+        tol = {('bf16x3', False): (2e-5, 1e-3, 1e-6), ('bf16x3', True): (1.5e-4, 5e-2, 3e-5),
+               ('f16', False): (1.5e-3, 8e-3, 1e-6), ('f16', True): (1e-2, 0.3, 2e-3)}[(prec_name, train)]
+        assert e_out < tol[0] and tot < tol[1] and e_b < tol[2], (e_out, tot, e_b, c_out, c_tot)
     elif prec_name == 'bf16x3':
         assert e_out < max(50 * c_out, 2e-5) and tot < max(10 * c_tot, 1e-3) and e_b < 1e-3, (e_out, tot, e_b, c_out, c_tot)
     else:
