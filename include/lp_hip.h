@@ -86,6 +86,22 @@ int lp_conv16_fwd(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* w_
                   uint16_t* out_hi, uint16_t* out_lo, int out_relu, float* workspace, long long workspace_bytes, float* amax_slots,
                   void* stream);
 long long lp_conv16_fwd_workspace_bytes(int N, int H, int W, int Cout, int ksize);
+/* lp_conv16_fwd with two more outputs options (blocks.py:18-26: the instance norm that follows every generator conv; the BatchNorm of the
+ * embedder convs):  y may be NULL when out_hi is given and Cout % 8 == 0 (16-bit activation residency: no fp32 store);
+ * stats [rows][Cout][3] (capacity stats_capacity_floats >= lp_conv16_stats_floats()) | NULL: {count, mean, M2} of the written values per
+ * (64-pixel row block, channel) from the conv epilogue -- no extra pass over y; *stats_rows (HOST int) = row blocks per image, or 0 when
+ * the geometry is not covered (maps under 64 pixels, ragged tiles, split-K): then run lp_instnorm_stats / lp_bn_train_stats on y.
+ * lp_norm_stats_finalize merges them: mean, rstd, scale = gamma*rstd, shift = beta - mean*scale per (n, c) (+ BatchNorm running stats, N = 1). */
+int lp_conv16_fwd_stats(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* w_hi, const uint16_t* w_lo, float* y,
+                        const float* bias, const float* res, const float* alpha, const float* alpha2,
+                        int N, int H, int W, int Cin, int Cout, int CinP, int CoutP,
+                        int ksize, int upsample, int res_shift, int prec, const uint16_t* relu_mask16,
+                        uint16_t* out_hi, uint16_t* out_lo, int out_relu, float* workspace, long long workspace_bytes, float* amax_slots,
+                        float* stats, long long stats_capacity_floats, int* stats_rows, void* stream);
+long long lp_conv16_stats_floats(int N, int H, int W, int Cout);
+int lp_norm_stats_finalize(const float* part, int S, const float* gamma, const float* beta, int ab_stride, float eps, float momentum,
+                           float* running_mean, float* running_var, float* mean, float* rstd, float* scale, float* shift,
+                           int N, int C, void* stream);
 
 /* Weight gradient: dw[co][ci][t] = out_scale * sum_{n,y,x} dy[n,y,x,co] * up2?(a)[n,y+dy_t,x+dx_t,ci]  (autograd of F.conv2d
  * w.r.t. weight, blocks.py:76-88) on operand planes: a = the planes the forward conv consumed, dy = lp_act_pack of the output
@@ -237,6 +253,9 @@ int lp_bn_train_stats(const float* y, const float* gamma, const float* beta, flo
  *   lp_spatial_mean_fwd/bwd: AdaptiveAvgPool2d(1) */
 int lp_gconv16_fwd(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* w_hi, const uint16_t* w_lo, float* y, const float* alpha2,
                    int N, int H, int W, int C, int CP, int prec, float* amax_slots, void* stream);
+int lp_gconv16_fwd_stats(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* w_hi, const uint16_t* w_lo, float* y, const float* alpha2,
+                         int N, int H, int W, int C, int CP, int prec, float* amax_slots, float* stats, long long stats_capacity_floats,
+                         int* stats_rows, void* stream);
 long long lp_gconv_wgrad_workspace_bytes(int C, int splits);
 int lp_gconv16_wgrad(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* dy_hi, const uint16_t* dy_lo, float* dw, float* workspace,
                      int N, int H, int W, int C, int group_size, int splits, int prec, const float* out_scale, void* stream);

@@ -47,6 +47,11 @@ struct Conv16Params {
     int hit;                      // halo DMA instructions per wave and chunk
     int a_dbuf;                   // single-group schedule: halo double buffered (1) or one buffer + an extra barrier per chunk (0)
     int ksplit;
+    float* stats;                 // NULL | per-(row block, channel) {count, mean, M2} of the values this launch writes: [rows][Cout][3], row block
+                                  // = (tile index * WM + wave row) -- what lp_norm_stats_finalize merges (instance / batch norm of y with no
+                                  // extra pass over it).  Host-checked: every wave's rows lie in one image, tiles cover the images exactly.
+    long long stats_cap;          // (host) capacity of `stats` in floats
+    int stats_rows;               // (host, out) partial rows per image the launch wrote (0: none -- geometry not covered, caller runs the stats pass)
     int grouped;                  // block-diagonal (grouped) conv: the workgroup's 64 output channels only see input channels co0 .. co0+63;
                                   // the weight image then has 64 columns (CinP = 64) and the activation channel offset is co0
 };
@@ -310,6 +315,7 @@ void conv_dma_kernel(Conv16Params p) {
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p.bias && co < p.Cout) bv = *(const float4*)(p.bias + co);
         float am = 0.f;
+        float st_n = 0.f, st_ref[4] = {0.f, 0.f, 0.f, 0.f}, st_d[4] = {0.f, 0.f, 0.f, 0.f}, st_q[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
         for (int r0 = 0; r0 < WR; r0 += RPP) {
             const int row = r0 + rsub;
@@ -336,8 +342,15 @@ void conv_dma_kernel(Conv16Params p) {
                     v.x = (mv.x - 1u) < 0x7fffu ? v.x : 0.f; v.y = (mv.y - 1u) < 0x7fffu ? v.y : 0.f;
                     v.z = (mv.z - 1u) < 0x7fffu ? v.z : 0.f; v.w = (mv.w - 1u) < 0x7fffu ? v.w : 0.f;
                 }
-                *(float4*)(p.y + pix * p.Cout + co) = v;
+                if (p.y) *(float4*)(p.y + pix * p.Cout + co) = v;
                 am = lp_amax4(am, v);
+                if (p.stats) {                     // shifted sums (reference = the lane's first value): no cancellation at large |mean| / std
+                    const float o4[4] = {v.x, v.y, v.z, v.w};
+                    if (st_n == 0.f) { st_ref[0] = v.x; st_ref[1] = v.y; st_ref[2] = v.z; st_ref[3] = v.w; }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const float d = o4[j] - st_ref[j]; st_d[j] += d; st_q[j] = fmaf(d, d, st_q[j]); }
+                    st_n += 1.f;
+                }
                 if (p.o_hi) {
                     float o[4] = {v.x, v.y, v.z, v.w};
                     ushort4 oh, ol;
@@ -354,6 +367,36 @@ void conv_dma_kernel(Conv16Params p) {
             }
         }
         if (p.amax && p.ksplit == 1) lp_amax_commit(am, p.amax, blockIdx.x + blockIdx.y * 7u);
+        if (p.stats && p.ksplit == 1) {
+            // lane -> (count, mean, M2) of its 4 channels over its rows; the RPP lanes that share the channel quad (lane bits above C4)
+            // merge pairwise (Chan et al.); rsub == 0 writes the wave's partial: row block = tile * WM + wm
+            float mean[4], m2[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                mean[j] = 0.f; m2[j] = 0.f;
+                if (st_n > 0.f) { mean[j] = st_ref[j] + st_d[j] / st_n; m2[j] = fmaxf(st_q[j] - st_d[j] * st_d[j] / st_n, 0.f); }
+            }
+#pragma unroll
+            for (int o = C4; o < 64; o <<= 1) {
+                const float nb_ = __shfl_xor(st_n, o, 64);
+                float mb[4], qb[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { mb[j] = __shfl_xor(mean[j], o, 64); qb[j] = __shfl_xor(m2[j], o, 64); }
+                const float nn = st_n + nb_;
+                if (nn > 0.f) {
+                    const float fb = nb_ / nn, fab = st_n * fb;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const float d = mb[j] - mean[j]; mean[j] = fmaf(d, fb, mean[j]); m2[j] += qb[j] + d * d * fab; }
+                }
+                st_n = nn;
+            }
+            if (rsub == 0 && co < p.Cout) {
+                const int t_ = PP ? (int)blockIdx.x * 2 + grp : (int)blockIdx.x;
+                float* o = p.stats + ((size_t)(t_ * WM + wm) * p.Cout + co) * 3;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { o[j * 3 + 0] = st_n; o[j * 3 + 1] = mean[j]; o[j * 3 + 2] = m2[j]; }
+            }
+        }
         return;
     }
     float am_s = 0.f;
@@ -378,7 +421,7 @@ void conv_dma_kernel(Conv16Params p) {
                     if (p.bias) v += p.bias[co];
                     if (p.res) v += p.res[rpix + co];
                     if (p.mask16 && !((unsigned)(p.mask16[pixi * p.Co8 + co] - 1u) < 0x7fffu)) v = 0.f;
-                    p.y[pix + co] = v;
+                    if (p.y) p.y[pix + co] = v;
                     am_s = fmaxf(am_s, fabsf(v));
                     if (p.o_hi) {
                         const float q = p.o_relu ? fmaxf(v, 0.f) : v;
@@ -427,7 +470,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(Conv16Params p) {
             v.x = (mv.x - 1u) < 0x7fffu ? v.x : 0.f; v.y = (mv.y - 1u) < 0x7fffu ? v.y : 0.f;
             v.z = (mv.z - 1u) < 0x7fffu ? v.z : 0.f; v.w = (mv.w - 1u) < 0x7fffu ? v.w : 0.f;
         }
-        *(float4*)(p.y + pix * p.Cout + co) = v;
+        if (p.y) *(float4*)(p.y + pix * p.Cout + co) = v;
         am = lp_amax4(am, v);
         if (p.o_hi) {
             float o[4] = {v.x, v.y, v.z, v.w};
@@ -531,6 +574,16 @@ static int launch_conv16(Conv16Params& p, hipStream_t stream) {
         p.ksplit = ks;
         grid.z = ks;
     }
+    p.stats_rows = 0;
+    if (p.stats) {
+        // fused norm statistics need: full tiles (every wave's MR*16 rows inside ONE image, tiles covering the images exactly, image-major
+        // row-block order), the coalesced epilogue (Cout % 4 == 0), no split-K (its finish kernel has no statistics), room in the buffer
+        constexpr int WR = MR * 16;
+        const long long rows = (long long)(pp ? 2 * ((tiles + 1) / 2) : tiles) * WM;
+        const bool ok = (NBv * TH * TW == BM) && (TH * TW >= WR) && (p.H % TH == 0) && (p.W % TW == 0) && ((p.Cout & 3) == 0) && p.ksplit == 1 &&
+                        rows * p.Cout * 3 <= p.stats_cap;
+        if (ok) p.stats_rows = (p.H * p.W) / WR; else p.stats = nullptr;
+    }
     // (64-channel chunks -- CC = 64, twice the MFMAs between two barriers -- were measured 7-15 % SLOWER on the 64^2..256^2 layers: their
     //  146 KB of LDS leave one workgroup per CU, while the 72 KB of the 32-channel kernel let two ping-pong workgroups share a CU)
     if constexpr (pp_ok) { if (pp) return launch_v<KS, UPS, WM, WN, MR, NR, PREC, true>(p, lds, grid, stream); }
@@ -591,7 +644,25 @@ extern "C" int lp_conv16_fwd(const uint16_t* a_hi, const uint16_t* a_lo, const u
                              int ksize, int upsample, int res_shift, int prec, const uint16_t* relu_mask16,
                              uint16_t* out_hi, uint16_t* out_lo, int out_relu, float* workspace, long long workspace_bytes, float* amax_slots,
                              void* stream) {
-    if (!a_hi || !w_hi || !y) return lp_set_error(LP_ERR_ARG, "lp_conv16_fwd: null pointer");
+    if (!y) return lp_set_error(LP_ERR_ARG, "lp_conv16_fwd: null pointer");
+    return lp_conv16_fwd_stats(a_hi, a_lo, w_hi, w_lo, y, bias, res, alpha, alpha2, N, H, W, Cin, Cout, CinP, CoutP, ksize, upsample, res_shift, prec,
+                               relu_mask16, out_hi, out_lo, out_relu, workspace, workspace_bytes, amax_slots, nullptr, 0, nullptr, stream);
+}
+
+// lp_conv16_fwd + (a) y may be NULL when the operand planes out_hi (, out_lo) are requested and Cout % 8 == 0 (the consumer only reads the
+// planes: no fp32 store); (b) stats [rows][Cout][3] | NULL: {count, mean, M2} of the written values per (row block, channel), merged by
+// lp_norm_stats_finalize -- *stats_rows (HOST int, out) = partial rows per image, 0 when this geometry is not covered (small / ragged
+// maps, split-K) and the caller has to run lp_instnorm_stats / lp_bn_train_stats on y instead.
+extern "C" int lp_conv16_fwd_stats(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* w_hi, const uint16_t* w_lo, float* y,
+                                   const float* bias, const float* res, const float* alpha, const float* alpha2,
+                                   int N, int H, int W, int Cin, int Cout, int CinP, int CoutP,
+                                   int ksize, int upsample, int res_shift, int prec, const uint16_t* relu_mask16,
+                                   uint16_t* out_hi, uint16_t* out_lo, int out_relu, float* workspace, long long workspace_bytes, float* amax_slots,
+                                   float* stats, long long stats_capacity_floats, int* stats_rows, void* stream) {
+    if (stats_rows) *stats_rows = 0;
+    if (!a_hi || !w_hi) return lp_set_error(LP_ERR_ARG, "lp_conv16_fwd: null pointer");
+    if (!y && (!out_hi || (Cout & 7))) return lp_set_error(LP_ERR_ARG, "lp_conv16_fwd: y may only be NULL when out_hi is given and Cout % 8 == 0");
+    if (stats && !stats_rows) return lp_set_error(LP_ERR_ARG, "lp_conv16_fwd: stats needs stats_rows");
     if (prec == LP_PREC_BF16X3 && (!w_lo || !a_lo)) return lp_set_error(LP_ERR_ARG, "lp_conv16_fwd: bf16x3 needs the lo planes");
     if (prec == LP_PREC_BF16X3 && out_hi && !out_lo) return lp_set_error(LP_ERR_ARG, "lp_conv16_fwd: bf16x3 needs out_lo");
     if (upsample && ((H | W) & 1)) return lp_set_error(LP_ERR_ARG, "lp_conv16_fwd: upsampled output dims must be even");
@@ -603,7 +674,7 @@ extern "C" int lp_conv16_fwd(const uint16_t* a_hi, const uint16_t* a_lo, const u
     p.o_hi = (Cout & 7) ? nullptr : out_hi; p.o_lo = (Cout & 7) ? nullptr : out_lo;   // (pad channels: the pack pass writes them)
     p.N = N; p.H = H; p.W = W; p.Hin = upsample ? H / 2 : H; p.Win = upsample ? W / 2 : W;
     p.Cin = Cin; p.C8 = (Cin + 7) & ~7; p.Cout = Cout; p.Co8 = (Cout + 7) & ~7; p.CinP = CinP; p.CoutP = CoutP; p.res_shift = res_shift;
-    p.grouped = 0;
+    p.grouped = 0; p.stats = stats; p.stats_cap = stats ? stats_capacity_floats : 0; p.stats_rows = 0;
     hipStream_t s = (hipStream_t)stream;
     int rc;
     if (prec == LP_PREC_BF16) rc = dispatch_conv16<LP_PREC_BF16>(p, ksize, upsample, s);
@@ -620,6 +691,7 @@ extern "C" int lp_conv16_fwd(const uint16_t* a_hi, const uint16_t* a_lo, const u
         rc = lp_check_launch("splitk_reduce");
         if (rc) return rc;
     }
+    if (stats_rows) *stats_rows = p.stats_rows;
     // channel counts the epilogue writes element-wise (Cout % 8 != 0: padding channels) get their 16-bit planes from a
     // bandwidth-bound pass over the finished y instead (same stream)
     if (out_hi && !p.o_hi)
@@ -636,6 +708,14 @@ extern "C" int lp_conv16_fwd(const uint16_t* a_hi, const uint16_t* a_lo, const u
 // lp_subsample2 / lp_zero_stuff2_16).  With the mode-1 pack and a = dY this is the data-gradient kernel.
 extern "C" int lp_gconv16_fwd(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* w_hi, const uint16_t* w_lo, float* y,
                               const float* alpha2, int N, int H, int W, int C, int CP, int prec, float* amax_slots, void* stream) {
+    return lp_gconv16_fwd_stats(a_hi, a_lo, w_hi, w_lo, y, alpha2, N, H, W, C, CP, prec, amax_slots, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int lp_gconv16_fwd_stats(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* w_hi, const uint16_t* w_lo, float* y,
+                                    const float* alpha2, int N, int H, int W, int C, int CP, int prec, float* amax_slots,
+                                    float* stats, long long stats_capacity_floats, int* stats_rows, void* stream) {
+    if (stats_rows) *stats_rows = 0;
+    if (stats && !stats_rows) return lp_set_error(LP_ERR_ARG, "lp_gconv16_fwd: stats needs stats_rows");
     if (!a_hi || !w_hi || !y) return lp_set_error(LP_ERR_ARG, "lp_gconv16_fwd: null pointer");
     if (prec == LP_PREC_BF16X3 && (!w_lo || !a_lo)) return lp_set_error(LP_ERR_ARG, "lp_gconv16_fwd: bf16x3 needs the lo planes");
     if ((C & 63) || CP % 128 || CP < C) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_gconv16_fwd: C must be a multiple of 64, CP of 128");
@@ -645,9 +725,19 @@ extern "C" int lp_gconv16_fwd(const uint16_t* a_hi, const uint16_t* a_lo, const 
     p.mask16 = nullptr; p.o_relu = 0; p.part = nullptr; p.part_bytes = 0; p.amax = amax_slots; p.o_hi = nullptr; p.o_lo = nullptr;
     p.N = N; p.H = H; p.W = W; p.Hin = H; p.Win = W;
     p.Cin = C; p.C8 = C; p.Cout = C; p.Co8 = C; p.CinP = 64; p.CoutP = CP; p.res_shift = 0; p.grouped = 1;
+    p.stats = stats; p.stats_cap = stats ? stats_capacity_floats : 0; p.stats_rows = 0;
     hipStream_t s = (hipStream_t)stream;
-    if (prec == LP_PREC_BF16) return launch_conv16<3, false, 4, 1, 4, 4, LP_PREC_BF16>(p, s);
-    if (prec == LP_PREC_BF16X3) return launch_conv16<3, false, 4, 1, 4, 4, LP_PREC_BF16X3>(p, s);
-    if (prec == LP_PREC_F16) return launch_conv16<3, false, 4, 1, 4, 4, LP_PREC_F16>(p, s);
-    return lp_set_error(LP_ERR_ARG, "lp_gconv16_fwd: unknown precision mode");
+    int rc;
+    if (prec == LP_PREC_BF16) rc = launch_conv16<3, false, 4, 1, 4, 4, LP_PREC_BF16>(p, s);
+    else if (prec == LP_PREC_BF16X3) rc = launch_conv16<3, false, 4, 1, 4, 4, LP_PREC_BF16X3>(p, s);
+    else if (prec == LP_PREC_F16) rc = launch_conv16<3, false, 4, 1, 4, 4, LP_PREC_F16>(p, s);
+    else return lp_set_error(LP_ERR_ARG, "lp_gconv16_fwd: unknown precision mode");
+    if (stats_rows) *stats_rows = p.stats_rows;
+    return rc;
+}
+
+// upper bound of the statistics buffer of lp_conv16_fwd_stats / lp_gconv16_fwd_stats in floats: one row block per 64 output pixels
+// (+ one tile of slack for the paired ping-pong grid) x Cout x 3
+extern "C" long long lp_conv16_stats_floats(int N, int H, int W, int Cout) {
+    return ((long long)N * H * W / 64 + 16) * Cout * 3;
 }

@@ -246,6 +246,19 @@ extern "C" int lp_instnorm_stats(const float* x, const float* gamma, const float
     return lp_check_launch("instnorm_finalize");
 }
 
+// Finish of the statistics a conv launch left behind (lp_conv16_fwd_stats): part [N][S][C][3] = {count, mean, M2} per (row block, channel)
+// -> mean, rstd (biased variance), scale = gamma*rstd, shift = beta - mean*scale per (n, c); N = 1 with running_mean/var: a train-mode
+// BatchNorm (momentum update, unbiased variance).  gamma/beta [N][C] with row stride ab_stride.
+extern "C" int lp_norm_stats_finalize(const float* part, int S, const float* gamma, const float* beta, int ab_stride, float eps, float momentum,
+                                      float* running_mean, float* running_var, float* mean, float* rstd, float* scale, float* shift,
+                                      int N, int C, void* stream) {
+    if (!part || !mean || !rstd || S < 1) return lp_set_error(LP_ERR_ARG, "lp_norm_stats_finalize: null pointer");
+    if (!running_mean != !running_var || (running_mean && N != 1)) return lp_set_error(LP_ERR_ARG, "lp_norm_stats_finalize: running statistics need N == 1");
+    hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(cdiv((long long)N * C, 4)), dim3(256), 0, (hipStream_t)stream, part, gamma, beta, ab_stride,
+                       eps, mean, rstd, scale, shift, N, C, S, running_mean, running_var, momentum);
+    return lp_check_launch("norm_stats_finalize");
+}
+
 // train-mode nn.BatchNorm2d over y [P][C]: batch statistics (biased variance for the normalisation), scale = gamma*rstd,
 // shift = beta - mean*scale, and the momentum update of the running statistics -- the instance-norm kernels with N = 1, HW = P.
 extern "C" long long lp_bn_train_stats_workspace_bytes(long long P, int C) { return lp_instnorm_workspace_bytes(1, (int)P, C); }

@@ -17,7 +17,7 @@ import torch
 
 from latent_pose_reenactment_amd import hipops as ops
 from latent_pose_reenactment_amd._lib import PREC_BF16X3
-from .resnext_hip import _BN, _conv1x1, _wgrad1x1
+from .resnext_hip import _BN, _conv1x1, _wgrad1x1, bn_state
 
 PREC = PREC_BF16X3
 
@@ -42,13 +42,10 @@ class MobileNetFeaturesFunction(torch.autograd.Function):
         bn_eval = None if train else net._hip_eval_bn(par)
         counters = []
 
-        def bn(y, name, m):
+        def bn(y, name, m, st=None):
             if not train:
                 return bn_eval[name]
-            if m.track_running_stats:
-                counters.append(m.num_batches_tracked)
-            return _BN(*ops.bn_train_stats(y, par[name + '.weight'].detach(), par[name + '.bias'].detach(), m.running_mean, m.running_var,
-                                           m.momentum, m.eps))
+            return bn_state(y, st, par[name + '.weight'].detach(), par[name + '.bias'].detach(), m, counters)
 
         n = x.shape[0]
         x = x.detach().contiguous()
@@ -57,8 +54,9 @@ class MobileNetFeaturesFunction(torch.autograd.Function):
         cols = ops.im2col_planes(x, 3, 2, 1, PREC)                                 # [N, H/2, W/2, 32] (27 taps + pad)
         h0, w0 = cols.hi.shape[1], cols.hi.shape[2]
         c0 = par['0.0.weight'].shape[0]
-        y0 = _conv1x1(cols, packs['0.0.weight'][0], PREC).view(n, h0, w0, c0)
-        st0 = bn(y0, '0.1', feats[0][1])
+        y0, cs = _conv1x1(cols, packs['0.0.weight'][0], PREC, stats=True)
+        y0 = y0.view(n, h0, w0, c0)
+        st0 = bn(y0, '0.1', feats[0][1], cs)
         raw, st_raw = y0, st0              # the tensor the next depthwise conv loads: raw conv output + its BN (ReLU6 applied on load)
         xact = x16 = None                  # block input (fp32, post-BN) and its operand planes
         saved = []
@@ -70,8 +68,9 @@ class MobileNetFeaturesFunction(torch.autograd.Function):
             if expand:
                 _, h, w, _ = xact.shape
                 hid = layers[0][0].out_channels
-                ye = _conv1x1(x16, packs[pre + '.0.0.weight'][0], PREC).view(n, h, w, hid)
-                ste = bn(ye, pre + '.0.1', layers[0][1])
+                ye, cs = _conv1x1(x16, packs[pre + '.0.0.weight'][0], PREC, stats=True)
+                ye = ye.view(n, h, w, hid)
+                ste = bn(ye, pre + '.0.1', layers[0][1], cs)
                 raw, st_raw = ye, ste
             dwi = 1 if expand else 0
             dw = layers[dwi][0]
@@ -83,8 +82,9 @@ class MobileNetFeaturesFunction(torch.autograd.Function):
             ad = ops.act_pack(yd, pro=3, scale=std.scale, shift=std.shift, prec=PREC)
             ho, wo = yd.shape[1], yd.shape[2]
             oup = layers[dwi + 1].out_channels
-            yp = _conv1x1(ad, packs[f'{pre}.{dwi + 1}.weight'][0], PREC).view(n, ho, wo, oup)
-            stp = bn(yp, f'{pre}.{dwi + 2}', layers[dwi + 2])
+            yp, cs = _conv1x1(ad, packs[f'{pre}.{dwi + 1}.weight'][0], PREC, stats=True)
+            yp = yp.view(n, ho, wo, oup)
+            stp = bn(yp, f'{pre}.{dwi + 2}', layers[dwi + 2], cs)
             xact, x16 = ops.bn_add_act(yp, stp.scale, stp.shift, xact if blk.use_res else None, relu=False, prec=PREC)
             rec.update(raw=raw, st_raw=st_raw, wd=wd, stride=stride, yd=yd, std=std, ad=ad, yp=yp, stp=stp, pre=pre, dwi=dwi,
                        dims=(hin, win, ho, wo))
@@ -93,8 +93,9 @@ class MobileNetFeaturesFunction(torch.autograd.Function):
         last = feats[-1]
         li = len(feats) - 1
         _, hl, wl, _ = xact.shape
-        yl = _conv1x1(x16, packs[f'{li}.0.weight'][0], PREC).view(n, hl, wl, last[0].out_channels)
-        stl = bn(yl, f'{li}.1', last[1])
+        yl, cs = _conv1x1(x16, packs[f'{li}.0.weight'][0], PREC, stats=True)
+        yl = yl.view(n, hl, wl, last[0].out_channels)
+        stl = bn(yl, f'{li}.1', last[1], cs)
         pooled = ops.affine_relu6_mean(yl, stl.scale, stl.shift)
         if counters:
             torch._foreach_add_(counters, 1)

@@ -36,14 +36,24 @@ def supported(n: int, h: int, w: int) -> bool:
     return h % 32 == 0 and w % 32 == 0 and h >= 128 and w >= 128 and n % 4 == 0 and n >= 8
 
 
-def _conv1x1(a16, pack, prec, bias=None, res=None, amax=False):
-    """1x1 contraction on flattened pixels: a16 [..., C8] planes -> y [P, Cout] fp32"""
+def _conv1x1(a16, pack, prec, bias=None, res=None, amax=False, stats=False):
+    """1x1 contraction on flattened pixels: a16 [..., C8] planes -> y [P, Cout] fp32 (``stats``: -> (y, ConvStats | None): the BatchNorm
+    partials of y over all P pixels, written by the conv epilogue)"""
     fa = ops.flat16(a16)
     _, h, w, _ = fa.hi.shape
     if res is not None:
         res = res.view(1, h, w, -1)
-    y = ops.conv16(fa, pack, ksize=1, bias=bias, res=res, prec=prec, amax=amax)
-    return y
+    return ops.conv16(fa, pack, ksize=1, bias=bias, res=res, prec=prec, amax=amax, stats=stats)
+
+
+def bn_state(y, st, gamma, beta, m, counters):
+    """train-mode BatchNorm of a conv output: from the partials the conv epilogue left (``st``: no pass over y), else lp_bn_train_stats"""
+    if m.track_running_stats:
+        counters.append(m.num_batches_tracked)
+    rm, rv = (m.running_mean, m.running_var) if m.track_running_stats else (None, None)
+    if st is not None:
+        return _BN(*ops.norm_stats_finalize(st, 1, y.shape[-1], gamma, beta, m.eps, running_mean=rm, running_var=rv, momentum=m.momentum))
+    return _BN(*ops.bn_train_stats(y, gamma, beta, rm, rv, m.momentum, m.eps))
 
 
 def _wgrad1x1(a16, d16, prec, bias_grad=False):
@@ -64,15 +74,10 @@ class ResNeXtFunction(torch.autograd.Function):
         bn_eval = None if train else net._hip_eval_affines(par)
         counters = []
 
-        def bn(y, name):
-            m = net._hip_bn[name]
+        def bn(y, name, st=None):
             if not train:
                 return bn_eval[name]
-            if m.track_running_stats:
-                counters.append(m.num_batches_tracked)
-            st = ops.bn_train_stats(y, par[name + '.weight'].detach(), par[name + '.bias'].detach(), m.running_mean, m.running_var,
-                                    m.momentum, m.eps)
-            return _BN(*st)
+            return bn_state(y, st, par[name + '.weight'].detach(), par[name + '.bias'].detach(), net._hip_bn[name], counters)
 
         n, _, hin, win = x.shape
         x = x.detach().contiguous()
@@ -81,30 +86,35 @@ class ResNeXtFunction(torch.autograd.Function):
         # ---- stem
         cols = ops.im2col_planes(x, 7, 2, 3, prec)                               # [N, H/2, W/2, 152]
         h0, w0 = cols.hi.shape[1], cols.hi.shape[2]
-        y0 = _conv1x1(cols, packs['conv1.weight'][0], prec).view(n, h0, w0, 64)
-        st0 = bn(y0, 'bn1')
+        y0, cs = _conv1x1(cols, packs['conv1.weight'][0], prec, stats=True)
+        y0 = y0.view(n, h0, w0, 64)
+        st0 = bn(y0, 'bn1', cs)
         out, out16, idx = ops.bn_relu_maxpool(y0, st0.scale, st0.shift, prec, want_idx=need_grad)
         saved_blocks = []
         # ---- bottleneck blocks
         for bname, cin, width, cout, stride, down in net._hip_blocks:
             xin, xin16 = out, out16
             _, h, w, _ = xin.shape
-            y1 = _conv1x1(xin16, packs[bname + '.conv1.weight'][0], prec).view(n, h, w, width)
-            st1 = bn(y1, bname + '.bn1')
+            y1, cs = _conv1x1(xin16, packs[bname + '.conv1.weight'][0], prec, stats=True)
+            y1 = y1.view(n, h, w, width)
+            st1 = bn(y1, bname + '.bn1', cs)
             a1 = ops.act_pack(y1, pro=4, scale=st1.scale, shift=st1.shift, prec=prec)
-            y2 = ops.gconv16(a1, packs[bname + '.conv2.weight'][0], prec=prec)
-            if stride == 2:
-                y2 = ops.subsample2(y2)
+            if stride == 1:
+                y2, cs = ops.gconv16(a1, packs[bname + '.conv2.weight'][0], prec=prec, stats=True)
+            else:       # (the statistics of the strided output: one pass over the quarter-size tensor)
+                y2, cs = ops.subsample2(ops.gconv16(a1, packs[bname + '.conv2.weight'][0], prec=prec)), None
             ho, wo = y2.shape[1], y2.shape[2]
-            st2 = bn(y2, bname + '.bn2')
+            st2 = bn(y2, bname + '.bn2', cs)
             a2 = ops.act_pack(y2, pro=4, scale=st2.scale, shift=st2.shift, prec=prec)
-            y3 = _conv1x1(a2, packs[bname + '.conv3.weight'][0], prec).view(n, ho, wo, cout)
-            st3 = bn(y3, bname + '.bn3')
+            y3, cs = _conv1x1(a2, packs[bname + '.conv3.weight'][0], prec, stats=True)
+            y3 = y3.view(n, ho, wo, cout)
+            st3 = bn(y3, bname + '.bn3', cs)
             xd16 = yd = std = None
             if down:
                 xd16 = ops.subsample2_16(xin16) if stride == 2 else xin16
-                yd = _conv1x1(xd16, packs[bname + '.downsample.0.weight'][0], prec).view(n, ho, wo, cout)
-                std = bn(yd, bname + '.downsample.1')
+                yd, cs = _conv1x1(xd16, packs[bname + '.downsample.0.weight'][0], prec, stats=True)
+                yd = yd.view(n, ho, wo, cout)
+                std = bn(yd, bname + '.downsample.1', cs)
                 out, out16 = ops.bn_add_act(y3, st3.scale, st3.shift, yd, std.scale, std.shift, relu=True, prec=prec)
             else:
                 out, out16 = ops.bn_add_act(y3, st3.scale, st3.shift, xin, relu=True, prec=prec)

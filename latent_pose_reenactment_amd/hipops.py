@@ -233,39 +233,59 @@ def act_pack(x: Tensor, *, pro: int = 0, scale: Optional[Tensor] = None, shift: 
     return Act16(hi, lo, c, None if sc is None else sc[1:])
 
 
+class ConvStats(NamedTuple):
+    """{count, mean, M2} partials a conv epilogue left behind: ``part`` [rows, Cout, 3] floats, ``rows`` partial rows per image"""
+    part: Tensor
+    rows: int
+
+
 def conv16(a: Act16, pack: WeightPack, *, ksize: int, upsample: bool = False, bias: Optional[Tensor] = None,
            res: Optional[Tensor] = None, res_shift: int = 0, alpha: Optional[Tensor] = None, prec: int = PREC_BF16,
-           relu_mask: Optional[Act16] = None, out16: Optional[int] = None, amax: bool = False):
+           relu_mask: Optional[Act16] = None, out16: Optional[int] = None, amax: bool = False, stats: bool = False, want_y: bool = True):
     """y = alpha * conv(up2?(a), pack) + bias + res on operand planes; a [N,Hin,Win,C8] -> y [N,H,W,Cout] fp32.
     ``relu_mask``: operand planes [N,H,W,Co8] of the forward conv's input; y is zeroed where they are <= 0 (fused ReLU backward
-    when this launch is a data gradient).  ``out16`` = 0 | 1: also return the operand planes of y (1: of relu(y)) -> (y, Act16)."""
+    when this launch is a data gradient).  ``out16`` = 0 | 1: also return the operand planes of y (1: of relu(y)) -> (y, Act16).
+    ``stats``: the epilogue also leaves the norm-statistics partials of y -> (..., ConvStats | None) appended (None: geometry not covered
+    by the fused path -- run ``instnorm_stats`` / ``bn_train_stats`` on y).  ``want_y=False`` (with ``out16`` and Cout % 8 == 0): no fp32 y
+    is written, y is returned as None."""
     n, hin, win = a.nhw
     cin = a.c
     assert cin == pack.cols and pack.taps == ksize * ksize, (a.hi.shape, a.c, pack.rows, pack.cols, pack.taps)
     h, w = (hin * 2, win * 2) if upsample else (hin, win)
     cout = pack.rows
-    y = torch.empty((n, h, w, cout), dtype=torch.float32, device=a.hi.device)
+    dev = a.hi.device
+    if not want_y:
+        assert out16 is not None and cout % 8 == 0 and not amax, 'want_y=False needs out16 and Cout % 8 == 0'
+    y = torch.empty((n, h, w, cout), dtype=torch.float32, device=dev) if want_y else None
     for t, nm in ((bias, 'bias'), (res, 'res')):
         if t is not None:
             _chk(t, nm)
     if res is not None:
-        assert res.shape == (n, h >> res_shift, w >> res_shift, cout), (res.shape, y.shape, res_shift)
+        assert res.shape == (n, h >> res_shift, w >> res_shift, cout), (res.shape, (n, h, w, cout), res_shift)
     if relu_mask is not None:
         assert relu_mask.hi.shape == (n, h, w, _round_up(cout, 8)), (relu_mask.hi.shape, (n, h, w, cout))
     o_hi = o_lo = None
     if out16 is not None:
-        o_hi, o_lo = _alloc16(n, h, w, cout, prec, y.device)
-    slots = _amax_attach(y, amax and prec == PREC_F16)       # y is a gradient that will be packed: max|y| from the epilogue
+        o_hi, o_lo = _alloc16(n, h, w, cout, prec, dev)
+    slots = _amax_attach(y, amax and prec == PREC_F16) if y is not None else None       # y is a gradient that will be packed: max|y| from the epilogue
     ws_bytes = _lib.lib().lp_conv16_fwd_workspace_bytes(n, h, w, cout, ksize)          # split-K partial tiles (small feature maps)
-    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=y.device) if ws_bytes else None
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev) if ws_bytes else None
+    st_buf, st_rows, st_cap = None, None, 0
+    if stats:
+        import ctypes
+        st_cap = _lib.lib().lp_conv16_stats_floats(n, h, w, cout)
+        st_buf = torch.empty(st_cap, dtype=torch.float32, device=dev)
+        st_rows = ctypes.c_int(0)
     with _Timed('conv_igemm', 2.0 * n * h * w * cout * cin * ksize * ksize, (n, h, w, cin, cout, ksize, int(upsample), 0)):
-        check(_lib.lib().lp_conv16_fwd(a.hi.data_ptr(), _p(a.lo), pack.hi.data_ptr(), _p(pack.lo), y.data_ptr(), _p(bias), _p(res),
-                                       _p(alpha), _p(a.inv), n, h, w, cin, cout, pack.cols_p, pack.rows_p, ksize, int(upsample),
-                                       res_shift, prec, None if relu_mask is None else relu_mask.hi.data_ptr(), _p(o_hi), _p(o_lo),
-                                       int(bool(out16)), _p(ws), ws_bytes, _p(slots), _stream()), 'lp_conv16_fwd')
-    if out16 is not None:
-        return y, Act16(o_hi, o_lo, cout, None)
-    return y
+        check(_lib.lib().lp_conv16_fwd_stats(a.hi.data_ptr(), _p(a.lo), pack.hi.data_ptr(), _p(pack.lo), _p(y), _p(bias), _p(res),
+                                             _p(alpha), _p(a.inv), n, h, w, cin, cout, pack.cols_p, pack.rows_p, ksize, int(upsample),
+                                             res_shift, prec, None if relu_mask is None else relu_mask.hi.data_ptr(), _p(o_hi), _p(o_lo),
+                                             int(bool(out16)), _p(ws), ws_bytes, _p(slots), _p(st_buf), st_cap,
+                                             None if st_rows is None else ctypes.addressof(st_rows), _stream()), 'lp_conv16_fwd')
+    out = (y,) if out16 is None else (y, Act16(o_hi, o_lo, cout, None))
+    if stats:
+        out = out + ((ConvStats(st_buf, st_rows.value) if st_rows.value > 0 else None),)
+    return out[0] if len(out) == 1 else out
 
 
 _THIN = os.environ.get('LP_THIN', '1') != '0'      # LP_THIN=0: thin-channel layers through the MFMA kernels (test knob)
@@ -764,17 +784,47 @@ def pack_grouped(w: Tensor, mode: int, prec: int) -> WeightPack:
     return WeightPack(hi, lo, c, cg, cp, 64, 9)          # cols = the group size (logical contraction width per output channel)
 
 
-def gconv16(a: Act16, pack: WeightPack, *, prec: int, amax: bool = False) -> Tensor:
-    """grouped 3x3 conv (pad 1, stride 1) on operand planes a [N,H,W,C] -> y [N,H,W,C] fp32; with the mode-1 pack: the data gradient"""
+def gconv16(a: Act16, pack: WeightPack, *, prec: int, amax: bool = False, stats: bool = False):
+    """grouped 3x3 conv (pad 1, stride 1) on operand planes a [N,H,W,C] -> y [N,H,W,C] fp32; with the mode-1 pack: the data gradient.
+    ``stats``: -> (y, ConvStats | None) as ``conv16``"""
     n, h, w = a.nhw
     c = a.c
     assert c == pack.rows and a.hi.shape[3] == c, (a.hi.shape, pack.rows)
     y = torch.empty((n, h, w, c), dtype=torch.float32, device=a.hi.device)
     slots = _amax_attach(y, amax and prec == PREC_F16)
+    st_buf, st_rows, st_cap = None, None, 0
+    if stats:
+        import ctypes
+        st_cap = _lib.lib().lp_conv16_stats_floats(n, h, w, c)
+        st_buf = torch.empty(st_cap, dtype=torch.float32, device=y.device)
+        st_rows = ctypes.c_int(0)
     with _Timed('gconv', 2.0 * n * h * w * c * pack.cols * 9, (n, h, w, pack.cols, c, 3, 0, 0)):
-        check(_lib.lib().lp_gconv16_fwd(a.hi.data_ptr(), _p(a.lo), pack.hi.data_ptr(), _p(pack.lo), y.data_ptr(), _p(a.inv), n, h, w, c,
-                                        pack.rows_p, prec, _p(slots), _stream()), 'lp_gconv16_fwd')
+        check(_lib.lib().lp_gconv16_fwd_stats(a.hi.data_ptr(), _p(a.lo), pack.hi.data_ptr(), _p(pack.lo), y.data_ptr(), _p(a.inv), n, h, w, c,
+                                              pack.rows_p, prec, _p(slots), _p(st_buf), st_cap, None if st_rows is None else ctypes.addressof(st_rows),
+                                              _stream()), 'lp_gconv16_fwd')
+    if stats:
+        return y, (ConvStats(st_buf, st_rows.value) if st_rows.value > 0 else None)
     return y
+
+
+def norm_stats_finalize(st: ConvStats, n: int, c: int, gamma: Optional[Tensor], beta: Optional[Tensor], eps: float, *,
+                        running_mean: Optional[Tensor] = None, running_var: Optional[Tensor] = None, momentum: float = 0.0):
+    """(mean, rstd, scale, shift) [n, c] from the partials a conv epilogue wrote (``ConvStats``).  gamma/beta: [n, c] views (row stride
+    free) or [c] (n == 1).  n == 1 with running statistics = train-mode BatchNorm."""
+    dev = st.part.device
+    out = torch.empty(4, n, c, dtype=torch.float32, device=dev)
+    ab_stride = 0
+    if gamma is not None:
+        assert gamma.stride(-1) == 1 and beta.stride(-1) == 1
+        ab_stride = gamma.stride(0) if gamma.dim() == 2 else c
+        if beta.dim() == 2:
+            assert beta.stride(0) == ab_stride
+    check(_lib.lib().lp_norm_stats_finalize(st.part.data_ptr(), st.rows, _p(gamma), _p(beta), ab_stride, eps, momentum, _p(running_mean),
+                                            _p(running_var), out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), n, c,
+                                            _stream()), 'lp_norm_stats_finalize')
+    if n == 1 and (gamma is None or gamma.dim() == 1):
+        return out[0, 0], out[1, 0], out[2, 0], out[3, 0]
+    return out[0], out[1], out[2], out[3]
 
 
 def gconv_wgrad16(a: Act16, dy: Act16, group_size: int, *, prec: int, splits: Optional[int] = None) -> Tensor:

@@ -385,6 +385,13 @@ class _DecoderFunction(torch.autograd.Function):
             off += 2 * c
             return gamma, beta, o
 
+        def in_stats(t, cs, gamma, beta):
+            # instance-norm statistics of a conv output: from the {count, mean, M2} partials its epilogue left (no pass over the tensor),
+            # else -- maps under 64 pixels, split-K launches, the constant input -- by the two-launch statistics kernel
+            if cs is not None:
+                return ops.norm_stats_finalize(cs, t.shape[0], t.shape[3], gamma, beta, ADAIN_EPS)
+            return ops.instnorm_stats(t, gamma, beta, ADAIN_EPS)
+        x_cs = None
         for (cin, cout, up) in blocks:
             w1, w2 = wl[wi], wl[wi + 1]
             wi += 2
@@ -393,11 +400,11 @@ class _DecoderFunction(torch.autograd.Function):
             g1, b1, o1 = aff(cout)
             # AdaIN + ReLU are applied ONCE per tensor while it is packed to the conv's 16-bit operand planes (the same planes feed
             # the weight gradient in backward); the convs themselves stage their operands by LDS-DMA only
-            st0 = ops.instnorm_stats(x, g0, b0, ADAIN_EPS)
+            st0 = in_stats(x, x_cs, g0, b0)
             a0 = ops.act_pack(x, pro=1, scale=st0[2], shift=st0[3], prec=prec)
             p1 = fpack(wi - 2, w1)
-            h1 = ops.conv16(a0, p1, ksize=3, upsample=up, alpha=sn[wi - 2][2][1:], prec=prec)
-            st1 = ops.instnorm_stats(h1, g1, b1, ADAIN_EPS)
+            h1, cs1 = ops.conv16(a0, p1, ksize=3, upsample=up, alpha=sn[wi - 2][2][1:], prec=prec, stats=True)
+            st1 = in_stats(h1, cs1, g1, b1)
             a1 = ops.act_pack(h1, pro=1, scale=st1[2], shift=st1[3], prec=prec)
             xs = None
             if has_skip:
@@ -411,7 +418,7 @@ class _DecoderFunction(torch.autograd.Function):
                 s, rs = x, 0
             i2 = wi - (3 if has_skip else 1)
             p2 = fpack(i2, w2)
-            out = ops.conv16(a1, p2, ksize=3, res=s, res_shift=rs, alpha=sn[i2][2][1:], prec=prec)
+            out, x_cs = ops.conv16(a1, p2, ksize=3, res=s, res_shift=rs, alpha=sn[i2][2][1:], prec=prec, stats=True)
             if need_grad:
                 saved.append((x, h1, st0, st1, o0, o1, a0, a1, xs))
             if cfg.get('debug') is not None:      # activation patterns of the AdaIN+ReLU sites (tie-masked parity checks)
@@ -419,7 +426,7 @@ class _DecoderFunction(torch.autograd.Function):
             x = out
         ch = blocks[-1][1]
         gh, bh, oh = aff(ch)
-        sth = ops.instnorm_stats(x, gh, bh, ADAIN_EPS)
+        sth = in_stats(x, x_cs, gh, bh)
         wh, bhd = wl[wi], wl[wi + 1]
         ph = fpack(wi, wh)
         ah = ops.act_pack(x, pro=1, scale=sth[2], shift=sth[3], prec=prec)

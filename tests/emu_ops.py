@@ -67,7 +67,13 @@ def act_pack(x, *, pro=0, scale=None, shift=None, prec=0, grad=False):
     return Act16(v, None, x.shape[-1], None)
 
 
-def conv16(a, pack, *, ksize, upsample=False, bias=None, res=None, res_shift=0, alpha=None, prec=0, relu_mask=None, out16=None, amax=False):
+class ConvStats(NamedTuple):
+    part: torch.Tensor          # (emulation: the conv output itself)
+    rows: int
+
+
+def conv16(a, pack, *, ksize, upsample=False, bias=None, res=None, res_shift=0, alpha=None, prec=0, relu_mask=None, out16=None, amax=False,
+           stats=False, want_y=True):
     assert ksize == 1 and not upsample
     w = pack.w.reshape(pack.w.shape[0], -1)                       # [Cout, Cin]
     x = a.hi[..., :a.c]
@@ -76,7 +82,12 @@ def conv16(a, pack, *, ksize, upsample=False, bias=None, res=None, res_shift=0, 
         y = y + bias
     if res is not None:
         y = y + res
-    return y
+    return (y, ConvStats(y, 1)) if stats else y
+
+
+def norm_stats_finalize(st, n, c, gamma, beta, eps, *, running_mean=None, running_var=None, momentum=0.0):
+    assert n == 1
+    return bn_train_stats(st.part, gamma, beta, running_mean, running_var, momentum, eps)
 
 
 def conv_wgrad16(a, dy, *, ksize, upsample=False, prec=0, splits=None, sn=None, accum=None, bias_grad=False, bias_accum=None):
@@ -87,12 +98,13 @@ def conv_wgrad16(a, dy, *, ksize, upsample=False, prec=0, splits=None, sn=None, 
     return (dw, d.sum(0)) if bias_grad else dw
 
 
-def gconv16(a, pack, *, prec=0, amax=False):
+def gconv16(a, pack, *, prec=0, amax=False, stats=False):
     w = pack.w
     groups = a.c // w.shape[1]
     x = a.hi.permute(0, 3, 1, 2)
     y = F.conv2d(x, w, padding=1, groups=groups) if pack.mode == 0 else F.conv_transpose2d(x, w, padding=1, groups=groups)
-    return y.permute(0, 2, 3, 1).contiguous()
+    y = y.permute(0, 2, 3, 1).contiguous()
+    return (y, ConvStats(y, 1)) if stats else y
 
 
 def gconv_wgrad16(a, dy, group_size, *, prec=0, splits=None):

@@ -114,6 +114,9 @@ def test_metatrain_step_hip_embedder_vs_stock_layers(monkeypatch):
     torch.manual_seed(META_SEED)
     E0, G0, D0 = EW.get_net(a), GW.get_net(a), DW.get_net(a)
     E0.pose_encoder.classifier[0].p = 0.0
+    for mod in E0.modules():       # non-trivial BatchNorm affines: with the default beta = 0 a linear-bottleneck output has an exactly-zero batch
+        if isinstance(mod, torch.nn.BatchNorm2d):      # mean, so the next layer's running_mean is pure rounding noise on both sides
+            mod.weight.data.uniform_(0.5, 1.5); mod.bias.data.uniform_(-0.3, 0.3)
     b = 8
     data = {'enc_rgbs': structured_frames(b, 128, 1).view(b, 1, 3, 128, 128).cuda(), 'pose_input_rgbs': structured_frames(b, 128, 2).view(b, 1, 3, 128, 128).cuda(),
             'target_rgbs': structured_frames(b, 128, 3).view(b, 1, 3, 128, 128).cuda()}
