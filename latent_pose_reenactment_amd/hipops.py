@@ -237,6 +237,7 @@ class ConvStats(NamedTuple):
     """{count, mean, M2} partials a conv epilogue left behind: ``part`` [rows, Cout, 3] floats, ``rows`` partial rows per image"""
     part: Tensor
     rows: int
+    images: int = 1         # images of the launch: a BatchNorm over all of them merges rows * images partials per channel
 
 
 def conv16(a: Act16, pack: WeightPack, *, ksize: int, upsample: bool = False, bias: Optional[Tensor] = None,
@@ -284,7 +285,7 @@ def conv16(a: Act16, pack: WeightPack, *, ksize: int, upsample: bool = False, bi
                                              None if st_rows is None else ctypes.addressof(st_rows), _stream()), 'lp_conv16_fwd')
     out = (y,) if out16 is None else (y, Act16(o_hi, o_lo, cout, None))
     if stats:
-        out = out + ((ConvStats(st_buf, st_rows.value) if st_rows.value > 0 else None),)
+        out = out + ((ConvStats(st_buf, st_rows.value, n) if st_rows.value > 0 else None),)
     return out[0] if len(out) == 1 else out
 
 
@@ -336,9 +337,17 @@ def conv(x: Tensor, pack: WeightPack, *, ksize: int, upsample: bool = False, pro
     return conv16(a, pack, ksize=ksize, upsample=upsample, bias=bias, res=res, res_shift=res_shift, alpha=alpha, prec=prec, relu_mask=m16)
 
 
-def default_splits(n, h, w, cin, cout):
+def default_splits(n, h, w, cin, cout, ksize=3):
+    """pixel-range splits of the weight-gradient launch.  3x3: ~2 workgroups per CU in total (9 taps of MFMA work per staged tile).
+    1x1: a staged 128-pixel tile feeds ONE tap, so the per-tile load -> LDS -> MFMA latency (~4 us) is exposed unless several
+    workgroups share a CU: ~4 per CU, every workgroup still walking >= 4 tiles (the embedder's 1024 x 2048 layers ran 1 workgroup per
+    CU over 32 tiles: 125 us for 17 GFLOP)."""
+    tiles = (n * h * w + 127) // 128
+    if ksize == 1:
+        blocks = (_round_up(cout, 128) // 128 if cout >= 128 else 1) * (_round_up(cin, 64) // 64)
+        return max(1, min(1024 // blocks, tiles // 4))
     blocks = _round_up(cout, 64) // 64 * (_round_up(cin, 64) // 64)
-    return max(1, min(512 // blocks, (n * h * w + 127) // 128))     # ~2 workgroups per CU in total
+    return max(1, min(512 // blocks, tiles))
 
 
 def conv_wgrad16(a: Act16, dy: Act16, *, ksize: int, upsample: bool = False, prec: int = PREC_BF16, splits: Optional[int] = None,
@@ -354,7 +363,7 @@ def conv_wgrad16(a: Act16, dy: Act16, *, ksize: int, upsample: bool = False, pre
     assert a.nhw == ((n, h // 2, w // 2) if upsample else (n, h, w)), (a.hi.shape, dy.hi.shape, upsample)
     dev = dy.hi.device
     if splits is None:
-        splits = default_splits(n, h, w, cin, cout)
+        splits = default_splits(n, h, w, cin, cout, ksize)
     ws = torch.empty(_lib.lib().lp_conv_wgrad_workspace_bytes(cin, cout, ksize, splits) // 4, dtype=torch.float32, device=dev)
     dw = torch.empty((cout, cin, ksize, ksize), dtype=torch.float32, device=dev)
     db = None
@@ -803,7 +812,7 @@ def gconv16(a: Act16, pack: WeightPack, *, prec: int, amax: bool = False, stats:
                                               pack.rows_p, prec, _p(slots), _p(st_buf), st_cap, None if st_rows is None else ctypes.addressof(st_rows),
                                               _stream()), 'lp_gconv16_fwd')
     if stats:
-        return y, (ConvStats(st_buf, st_rows.value) if st_rows.value > 0 else None)
+        return y, (ConvStats(st_buf, st_rows.value, n) if st_rows.value > 0 else None)
     return y
 
 
@@ -819,7 +828,9 @@ def norm_stats_finalize(st: ConvStats, n: int, c: int, gamma: Optional[Tensor], 
         ab_stride = gamma.stride(0) if gamma.dim() == 2 else c
         if beta.dim() == 2:
             assert beta.stride(0) == ab_stride
-    check(_lib.lib().lp_norm_stats_finalize(st.part.data_ptr(), st.rows, _p(gamma), _p(beta), ab_stride, eps, momentum, _p(running_mean),
+    assert n == st.images or n == 1, (n, st.images)
+    rows = st.rows if n == st.images else st.rows * st.images       # n == 1 over several images: a BatchNorm over all pixels
+    check(_lib.lib().lp_norm_stats_finalize(st.part.data_ptr(), rows, _p(gamma), _p(beta), ab_stride, eps, momentum, _p(running_mean),
                                             _p(running_var), out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), n, c,
                                             _stream()), 'lp_norm_stats_finalize')
     if n == 1 and (gamma is None or gamma.dim() == 1):

@@ -63,7 +63,7 @@ def test_flat_1x1_and_grouped_batchnorm_statistics(prec):
     gamma, beta = (torch.rand(cout, generator=g) + 0.5).cuda(), torch.randn(cout, generator=g).cuda()
     a = ops.act_pack(x, pro=0, prec=prec)
     y, cs = ops.conv16(ops.flat16(a), ops.pack_weights(wt, 0, prec), ksize=1, prec=prec, stats=True)
-    assert cs is not None and cs.rows == n * h * w // 64
+    assert cs is not None and cs.rows == n * h * w // 64 and cs.images == 1
     rm, rv = torch.zeros(cout).cuda(), torch.ones(cout).cuda()
     rm2, rv2 = rm.clone(), rv.clone()
     got = ops.norm_stats_finalize(cs, 1, cout, gamma, beta, 1e-5, running_mean=rm, running_var=rv, momentum=0.1)
@@ -78,7 +78,7 @@ def test_flat_1x1_and_grouped_batchnorm_statistics(prec):
     wg = (torch.randn(c, cg, 3, 3, generator=g) / (cg * 9) ** 0.5).cuda()
     ag = ops.act_pack(xg, pro=0, prec=prec)
     yg, csg = ops.gconv16(ag, ops.pack_grouped(wg, 0, prec), prec=prec, stats=True)
-    assert csg is not None
+    assert csg is not None and csg.rows == 4 and csg.images == 4
     gam, bet = torch.ones(c).cuda(), torch.zeros(c).cuda()
     got = ops.norm_stats_finalize(csg, 1, c, gam, bet, 1e-5)
     want = ops.bn_train_stats(yg, gam, bet, None, None, 0.1, 1e-5)
