@@ -270,6 +270,15 @@ int lp_bn_add_act(const float* y, const float* scale, const float* shift, const 
 int lp_subsample2(const void* in, void* out, int N, int H, int W, int row_bytes, void* stream);
 int lp_zero_stuff2(const void* in, void* out, int N, int H, int W, int row_bytes, void* stream);
 int lp_add_strided2(float* d, const float* s, int N, int H, int W, int C, void* stream);
+/*   lp_bn_bwd16:      backward of act(BatchNorm(x)) over x [P][C] written STRAIGHT to the operand planes of dy (hi [, lo]) that the weight /
+ *                     data gradient contractions consume -- no fp32 dy, no masked-gradient temporary: out_scale[2] = {s, 1/s} (fp16 mode: the power
+ *                     of two taken from a per-channel bound of |dy|; 1 otherwise) goes to alpha2 / out_scale of the consumers; dgamma, dbeta [C];
+ *                     mask modes / act_hi / frozen_stats as lp_norm_act_bwd; g_out [P][C]|NULL: the masked incoming gradient in fp32 (the
+ *                     identity branch of a residual block); workspace lp_bn_bwd16_workspace_bytes(P, C) */
+long long lp_bn_bwd16_workspace_bytes(long long P, int C);
+int lp_bn_bwd16(const float* dA, const float* x, const float* mask_src, const float* gamma, const float* mean, const float* rstd,
+                const float* scale, const float* shift, uint16_t* out_hi, uint16_t* out_lo, float* out_scale, float* dgamma, float* dbeta,
+                float* workspace, long long P, int C, int mask_mode, float act_hi, int frozen_stats, int prec, float* g_out, void* stream);
 int lp_spatial_mean_fwd(const float* x, float* out, int N, int HW, int C, void* stream);
 int lp_spatial_mean_bwd(const float* g, float* dx, int N, int HW, int C, void* stream);
 

@@ -79,6 +79,8 @@ SIGNATURES = {
     'lp_subsample2': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'lp_zero_stuff2': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'lp_add_strided2': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    'lp_bn_bwd16_workspace_bytes': (_ll, [_ll, _i]),
+    'lp_bn_bwd16': (_i, [_vp] * 14 + [_ll, _i, _i, _f, _i, _i, _vp, _vp]),
     'lp_spatial_mean_fwd': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'lp_spatial_mean_bwd': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'lp_dwconv3x3_dgrad': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -383,3 +383,180 @@ extern "C" int lp_pack_grouped(const float* w, uint16_t* hi, uint16_t* lo, int C
     hipLaunchKernelGGL(pack_grouped_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, w, hi, f16 ? nullptr : lo, C, group_size, CP, mode, f16, total);
     return lp_check_launch("pack_grouped");
 }
+
+// ---- BatchNorm (+ activation) backward straight to operand planes ------------------------------------------------------------------
+// The embedder's conv -> BatchNorm -> ReLU chains only ever consume the BatchNorm input gradient dy as the 16-bit operand of the weight /
+// data gradient contractions, so it is never written in fp32:
+//   pass 1 (partial):  per (pixel split, channel)  S1 = sum g, S2 = sum g*xhat, max|g|, max|xhat|     g = dA * activation mask (recomputed, not stored)
+//   pass 2 (finalize): dgamma = S2, dbeta = S1, coefficients of dy = ca*g + cb*x + cc, and a per-channel BOUND of |dy|
+//                      (|ca| * (max|g| + |S1|/P + max|xhat| * |S2|/P)) from which the fp16 gradient scale is taken (a power of two putting the
+//                      bound into [2^12, 2^13): the true amax is at most the bound, so the scaled planes cannot overflow)
+//   pass 3 (apply):    recomputes g from dA and the mask, writes dy * s as operand planes (hi [, lo]); block 0 publishes {s, 1/s}
+// 8 B read in pass 1 and 8 B read + 2 B written in pass 3 per element (fp16 mode), against 30 B for partial + apply + lp_act_pack on fp32 dy.
+// mask modes as lp_norm_act_bwd: 0 own activation 0 < x*scale+shift < act_hi, 1 none, 2 mask_src > 0.
+#define BNB_SPLIT_PIX 1024
+__global__ __launch_bounds__(256) void bn_bwd16_partial_kernel(const float* __restrict__ dA, const float* __restrict__ x, const float* __restrict__ mask_src,
+                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                               const float* __restrict__ scale, const float* __restrict__ shift,
+                                                               float* __restrict__ part, long long P, int C, int mask_mode, float act_hi) {
+    __shared__ float sh[4][16][64];
+    const int cb = blockIdx.y, s = blockIdx.x;
+    const int cq = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int c = cb * 64 + cq * 4;
+    const long long p0 = (long long)s * BNB_SPLIT_PIX, p1 = min(P, p0 + BNB_SPLIT_PIX);
+    float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0}, gm[4] = {0, 0, 0, 0}, xm[4] = {0, 0, 0, 0};
+    if (c < C) {
+        const float4 mu = *(const float4*)(mean + c), rs = *(const float4*)(rstd + c);
+        const float4 sc = *(const float4*)(scale + c), sf = *(const float4*)(shift + c);
+        const float m4[4] = {mu.x, mu.y, mu.z, mu.w}, r4[4] = {rs.x, rs.y, rs.z, rs.w}, a4[4] = {sc.x, sc.y, sc.z, sc.w}, b4[4] = {sf.x, sf.y, sf.z, sf.w};
+        for (long long pix = p0 + pl; pix < p1; pix += 16) {
+            const float4 xv = *(const float4*)(x + pix * C + c), gv = *(const float4*)(dA + pix * C + c);
+            float xs[4] = {xv.x, xv.y, xv.z, xv.w}, g[4] = {gv.x, gv.y, gv.z, gv.w};
+            if (mask_mode == 2) {
+                const float4 mk = *(const float4*)(mask_src + pix * C + c);
+                const float k4[4] = {mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) g[j] = k4[j] > 0.f ? g[j] : 0.f;
+            } else if (mask_mode == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const float a = fmaf(xs[j], a4[j], b4[j]); g[j] = (a > 0.f && a < act_hi) ? g[j] : 0.f; }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xh = (xs[j] - m4[j]) * r4[j];
+                s1[j] += g[j]; s2[j] = fmaf(g[j], xh, s2[j]);
+                gm[j] = fmaxf(gm[j], fabsf(g[j])); xm[j] = fmaxf(xm[j], fabsf(xh));
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sh[0][pl][cq * 4 + j] = s1[j]; sh[1][pl][cq * 4 + j] = s2[j]; sh[2][pl][cq * 4 + j] = gm[j]; sh[3][pl][cq * 4 + j] = xm[j]; }
+    __syncthreads();
+    {
+        const int which = threadIdx.x >> 6, ch = threadIdx.x & 63;
+        float a = 0.f;
+        if (which < 2) { for (int k = 0; k < 16; ++k) a += sh[which][k][ch]; }
+        else { for (int k = 0; k < 16; ++k) a = fmaxf(a, sh[which][k][ch]); }
+        const int cg = cb * 64 + ch;
+        if (cg < C) part[((size_t)s * C + cg) * 4 + which] = a;
+    }
+}
+
+// one wave per channel: merges the S partials; coef[c] = {ca, cb, cc}, bound[c] >= max|dy| of the channel
+__global__ __launch_bounds__(256) void bn_bwd16_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                float* __restrict__ coef, float* __restrict__ bound, int C, int S, float inv_p, int frozen) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= C) return;
+    double a1 = 0, a2 = 0;
+    float gm = 0.f, xm = 0.f;
+    for (int s = lane; s < S; s += 64) {
+        const float* q = part + ((size_t)s * C + c) * 4;
+        a1 += q[0]; a2 += q[1]; gm = fmaxf(gm, q[2]); xm = fmaxf(xm, q[3]);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        a1 += __shfl_down(a1, o, 64); a2 += __shfl_down(a2, o, 64);
+        gm = fmaxf(gm, __shfl_down(gm, o, 64)); xm = fmaxf(xm, __shfl_down(xm, o, 64));
+    }
+    if (lane != 0) return;
+    const float S1 = (float)a1, S2 = (float)a2;
+    dgamma[c] = S2; dbeta[c] = S1;
+    const float r = rstd[c], m = mean[c], ca = gamma[c] * r;
+    const float cb = frozen ? 0.f : -ca * r * S2 * inv_p;
+    const float cc = frozen ? 0.f : -ca * S1 * inv_p - cb * m;
+    coef[c * 3 + 0] = ca; coef[c * 3 + 1] = cb; coef[c * 3 + 2] = cc;
+    bound[c] = frozen ? fabsf(ca) * gm : fabsf(ca) * (gm + fabsf(S1) * inv_p + xm * fabsf(S2) * inv_p);
+}
+
+template <int PREC>
+__global__ __launch_bounds__(256) void bn_bwd16_apply_kernel(const float* __restrict__ dA, const float* __restrict__ x, const float* __restrict__ mask_src,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ coef,
+                                                             const float* __restrict__ bound, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo,
+                                                             float* __restrict__ out_scale, long long items, int C, int mask_mode, float act_hi,
+                                                             float* __restrict__ g_out) {
+    constexpr bool SPLIT = (PREC == LP_PREC_BF16X3), F16 = (PREC == LP_PREC_F16);
+    float sc_out = 1.f;
+    if (F16) {       // every block derives the same power-of-two scale from the per-channel bounds (C floats, L2 resident)
+        __shared__ float shm[4];
+        float m = 0.f;
+        for (int j = threadIdx.x; j < C; j += 256) m = fmaxf(m, bound[j]);
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+        if ((threadIdx.x & 63) == 0) shm[threadIdx.x >> 6] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(shm[0], shm[1]), fmaxf(shm[2], shm[3]));
+        float inv = 1.f;
+        if (m > 0.f && m < 3.0e38f) {
+            int e;
+            (void)frexpf(m, &e);
+            int k = 13 - e;
+            k = k > 100 ? 100 : (k < -100 ? -100 : k);
+            sc_out = ldexpf(1.f, k); inv = ldexpf(1.f, -k);
+        }
+        if (out_scale && blockIdx.x == 0 && threadIdx.x == 0) { out_scale[0] = sc_out; out_scale[1] = inv; }
+    } else if (out_scale && blockIdx.x == 0 && threadIdx.x == 0) { out_scale[0] = 1.f; out_scale[1] = 1.f; }
+    const int G = C >> 3;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < items; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % G) * 8;
+        const float4 g0 = *(const float4*)(dA + i * 8), g1 = *(const float4*)(dA + i * 8 + 4);
+        const float4 x0 = *(const float4*)(x + i * 8), x1 = *(const float4*)(x + i * 8 + 4);
+        float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+        if (mask_mode == 2) {
+            const float4 m0 = *(const float4*)(mask_src + i * 8), m1 = *(const float4*)(mask_src + i * 8 + 4);
+            const float k8[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[j] = k8[j] > 0.f ? g[j] : 0.f;
+        } else if (mask_mode == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float a = fmaf(xs[j], scale[c + j], shift[c + j]); g[j] = (a > 0.f && a < act_hi) ? g[j] : 0.f; }
+        }
+        if (g_out) {          // the masked incoming gradient itself: what the identity branch of a residual block receives
+            *(float4*)(g_out + i * 8) = make_float4(g[0], g[1], g[2], g[3]);
+            *(float4*)(g_out + i * 8 + 4) = make_float4(g[4], g[5], g[6], g[7]);
+        }
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float* cf = coef + (c + j) * 3;
+            v[j] = fmaf(cf[0], g[j], fmaf(cf[1], xs[j], cf[2])) * sc_out;
+        }
+        store_op8<F16, SPLIT>(v, hi, lo, (size_t)i * 8);
+    }
+}
+
+extern "C" long long lp_bn_bwd16_workspace_bytes(long long P, int C) {
+    const long long S = (P + BNB_SPLIT_PIX - 1) / BNB_SPLIT_PIX;
+    return (S * C * 4 + (long long)C * 4) * (long long)sizeof(float);
+}
+
+extern "C" int lp_bn_bwd16(const float* dA, const float* x, const float* mask_src, const float* gamma, const float* mean, const float* rstd,
+                           const float* scale, const float* shift, uint16_t* out_hi, uint16_t* out_lo, float* out_scale, float* dgamma,
+                           float* dbeta, float* workspace, long long P, int C, int mask_mode, float act_hi, int frozen_stats, int prec,
+                           float* g_out, void* stream) {
+    if (!dA || !x || !gamma || !mean || !rstd || !scale || !shift || !out_hi || !out_scale || !dgamma || !dbeta || !workspace)
+        return lp_set_error(LP_ERR_ARG, "lp_bn_bwd16: null pointer");
+    if (C & 7) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_bn_bwd16: C must be a multiple of 8");
+    if (mask_mode < 0 || mask_mode > 2 || (mask_mode == 2 && !mask_src)) return lp_set_error(LP_ERR_ARG, "lp_bn_bwd16: bad mask mode");
+    if (prec == LP_PREC_BF16X3 && !out_lo) return lp_set_error(LP_ERR_ARG, "lp_bn_bwd16: bf16x3 needs the lo plane");
+    if (P < 1) return LP_OK;
+    const int S = (int)((P + BNB_SPLIT_PIX - 1) / BNB_SPLIT_PIX);
+    float* part = workspace;
+    float* coef = workspace + (size_t)S * C * 4;
+    float* bound = coef + (size_t)C * 3;
+    const float hi_ = act_hi > 0.f ? act_hi : 3.0e38f;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_bwd16_partial_kernel, dim3(S, (C + 63) / 64), dim3(256), 0, st, dA, x, mask_src, mean, rstd, scale, shift, part, P, C, mask_mode, hi_);
+    int rc = lp_check_launch("bn_bwd16_partial");
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_bwd16_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, gamma, mean, rstd, dgamma, dbeta, coef, bound, C, S,
+                       1.0f / (float)P, frozen_stats);
+    rc = lp_check_launch("bn_bwd16_finalize");
+    if (rc) return rc;
+    const long long items = P * (C >> 3);
+#define LP_BB(Q) hipLaunchKernelGGL(bn_bwd16_apply_kernel<Q>, dim3(grid_for(items, 8192)), dim3(256), 0, st, dA, x, mask_src, scale, shift, coef, bound, out_hi, out_lo, out_scale, items, C, mask_mode, hi_, g_out)
+    if (prec == LP_PREC_BF16) LP_BB(LP_PREC_BF16);
+    else if (prec == LP_PREC_BF16X3) LP_BB(LP_PREC_BF16X3);
+    else if (prec == LP_PREC_F16) LP_BB(LP_PREC_F16);
+    else return lp_set_error(LP_ERR_ARG, "lp_bn_bwd16: unknown precision mode");
+#undef LP_BB
+    return lp_check_launch("bn_bwd16_apply");
+}

@@ -1,16 +1,22 @@
-"""Input side of the training loop on MI355X: pinned, double-buffered host-to-device copies on a side stream, one batch ahead of the
+"""Input side of the training loop on MI355X: pinned, triple-buffered host-to-device copies on a side stream, one batch ahead of the
 step that is computing (the reference relies on DataLoader(pin_memory=True) + its prefetching subclass and a blocking
 ``dict_to_device`` at the top of every iteration: dataloaders/dataloader.py:24-50, runners/holycow.py:233-236).
 
 ``DevicePrefetcher(loader, device)`` wraps any iterable of ``(data_dict, target_dict)`` host batches (the plugin dataloader contract) and
 yields the same dicts with their tensors in DEVICE staging buffers:
-  * batch k+1 is staged while step k computes: host tensors -> a pinned slot (plain memcpy) -> the slot's device buffers by an async copy
-    on ``copy_stream``; an event orders the consumer's stream behind the copy (no host synchronisation on the hot path);
-  * two slots: before slot s is refilled (batch k+2) the copy stream waits for everything the compute stream had enqueued up to that
-    moment -- step k, the last reader of slot s -- and the host waits for the slot's previous H2D before overwriting its pinned memory.
-A batch is 18.9 MB per step in meta-training (8 x (8 + 1 + 1 + 3/3) frames of 3 x 256 x 256 fp32): ~0.3 ms at PCIe Gen5 rates, hidden
-behind a 40+ ms step.  The hipGraph step copies the staging tensors into its static inputs (device-to-device, ~10 us)."""
+  * batch k+1 is staged while step k computes: host tensors -> a pinned slot (plain memcpy; skipped when the loader already delivers pinned
+    tensors) -> the slot's device buffers by an async copy on ``copy_stream``;
+  * NO device-side dependency between the copy stream and the compute stream: measured on MI355X (profiles/README.md, r03 input path), an
+    H2D copy running beside the captured step costs nothing (+0.07 ms for 25 MB), while every cross-stream event wait placed between
+    graph replays costs ~1 ms per step.  Ordering is kept on the HOST instead, with events that are already complete in steady state:
+      - a batch is handed out only after its H2D event completed (issued a whole step earlier);
+      - three slots: slot s is refilled for batch k+3 only after a marker recorded on the compute stream behind step k -- the last reader
+        of slot s -- completed (recorded when batch k+2 was staged), so the host never runs more than two steps ahead of the device.
+A meta-training batch is 69 MB per step (8 x (8 + 1 + 1 + 1) frames of 3 x 256 x 256 fp32), a fine-tuning batch 25 MB: 1.6 / 0.55 ms at the
+44 GB/s measured, hidden behind a 50 / 22 ms step.  The hipGraph step copies the staging tensors into its static inputs (device-to-device, ~10 us)."""
 import torch
+
+SLOTS = 3
 
 
 class DevicePrefetcher:
@@ -18,54 +24,66 @@ class DevicePrefetcher:
         self.loader = loader
         self.device = torch.device(device)
         self.copy_stream = torch.cuda.Stream(device=self.device)
-        self.slots = [None, None]          # per slot: {'pinned': {...}, 'dev': {...}, 'event': cuda event of the last H2D}
+        self.slots = [None] * SLOTS        # per slot: {'pinned': {...}, 'dev': {...}, 'reader_done': event | None}
+        self.markers = []                  # (batch index the marker covers, event): everything enqueued on the compute stream so far
 
     def __len__(self):
         return len(self.loader)
 
-    def _buffers(self, slot, key, t):
+    def _buffers(self, slot, key, t, need_pin):
         s = self.slots[slot]
-        buf = s['pinned'].get(key)
-        if buf is None or buf.shape != t.shape or buf.dtype != t.dtype:
-            s['pinned'][key] = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        dev = s['dev'].get(key)
+        if dev is None or dev.shape != t.shape or dev.dtype != t.dtype:
             s['dev'][key] = torch.empty(t.shape, dtype=t.dtype, device=self.device)
-        return s['pinned'][key], s['dev'][key]
+            s['pinned'].pop(key, None)
+        pin = None
+        if need_pin:
+            pin = s['pinned'].get(key)
+            if pin is None or pin.shape != t.shape or pin.dtype != t.dtype:
+                pin = s['pinned'][key] = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        return pin, s['dev'][key]
 
-    def _stage(self, batch, slot):
+    def _stage(self, batch, index):
+        slot = index % SLOTS
         if self.slots[slot] is None:
-            self.slots[slot] = {'pinned': {}, 'dev': {}, 'event': None}
+            self.slots[slot] = {'pinned': {}, 'dev': {}, 'reader_done': None}
         s = self.slots[slot]
-        if s['event'] is not None:
-            s['event'].synchronize()                                   # the pinned slot's previous H2D is done (it was issued a step ago)
-        # the device buffers of this slot were last read by work already enqueued on the consumer's stream: let the copy wait for it
-        self.copy_stream.wait_stream(torch.cuda.current_stream(self.device))
+        # marker: all compute-stream work enqueued up to now, i.e. every step up to batch index - 2 (batch index - 1 has not been handed out yet)
+        mk = torch.cuda.Event()
+        mk.record(torch.cuda.current_stream(self.device))
+        self.markers.append((index - 2, mk))
+        # the last reader of this slot was the step of batch index - SLOTS: wait (on the host) for a marker that covers it
+        while self.markers and self.markers[0][0] < index - SLOTS:
+            self.markers.pop(0)
+        if self.markers and self.markers[0][0] >= index - SLOTS and index >= SLOTS:
+            self.markers[0][1].synchronize()
         out = []
         with torch.cuda.stream(self.copy_stream):
             for di, d in enumerate(batch):
                 o = {}
                 for k, v in d.items():
                     if torch.is_tensor(v) and not v.is_cuda:
-                        pin, dev = self._buffers(slot, (di, k), v)
-                        pin.copy_(v)                                    # host memcpy into pinned memory
-                        dev.copy_(pin, non_blocking=True)               # async H2D on the copy stream
+                        pin, dev = self._buffers(slot, (di, k), v, need_pin=not v.is_pinned())
+                        if pin is not None:
+                            pin.copy_(v)                                # host memcpy into pinned memory
+                            v = pin
+                        dev.copy_(v, non_blocking=True)                 # async H2D on the copy stream (pinned source)
                         o[k] = dev
                     else:
                         o[k] = v
                 out.append(o)
             ev = torch.cuda.Event()
             ev.record(self.copy_stream)
-        s['event'] = ev
         return tuple(out), ev
 
     def __iter__(self):
-        pending, slot = None, 0
-        for batch in self.loader:
-            staged = self._stage(batch, slot)
-            slot ^= 1
+        pending = None
+        for index, batch in enumerate(self.loader):
+            staged = self._stage(batch, index)
             if pending is not None:
-                torch.cuda.current_stream(self.device).wait_event(pending[1])
+                pending[1].synchronize()           # host-side: this H2D was issued a whole step ago
                 yield pending[0]
             pending = staged
         if pending is not None:
-            torch.cuda.current_stream(self.device).wait_event(pending[1])
+            pending[1].synchronize()
             yield pending[0]

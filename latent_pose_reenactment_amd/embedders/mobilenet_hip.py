@@ -118,12 +118,16 @@ class MobileNetFeaturesFunction(torch.autograd.Function):
             grads[name + '.weight'], grads[name + '.bias'] = dg, db
             return dx
 
+        def bn_bwd16(dA, y, st, name, **kw):          # straight to the operand planes of dy (consumed only by gradient contractions)
+            d16, dg, db, _ = ops.bn_bwd16(dA, y, par[name + '.weight'].detach(), st.mean, st.rstd, st.scale, st.shift, prec=PREC, frozen=frozen, **kw)
+            grads[name + '.weight'], grads[name + '.bias'] = dg, db
+            return d16
+
         def wshape(k):
             return par[k].shape
         x16, yl, stl, li, (hl, wl) = ctx.last
         dAl = ops.spatial_mean_bwd(d_pooled.contiguous(), hl, wl)
-        dyl = bn_bwd(dAl, yl, stl, f'{li}.1', act_hi=6.0)
-        d16 = ops.act_pack(dyl, prec=PREC, grad=True)
+        d16 = bn_bwd16(dAl, yl, stl, f'{li}.1', act_hi=6.0)
         grads[f'{li}.0.weight'] = _wgrad1x1(x16, d16, PREC).view(wshape(f'{li}.0.weight'))
         d_out = _conv1x1(d16, packs[f'{li}.0.weight'][1], PREC).view(n, hl, wl, -1)
         dA_raw = None
@@ -131,8 +135,7 @@ class MobileNetFeaturesFunction(torch.autograd.Function):
             pre, dwi = rec['pre'], rec['dwi']
             hin, win, ho, wo = rec['dims']
             # block output = BN(project) (+ block input): a linear BatchNorm
-            dyp = bn_bwd(d_out, rec['yp'], rec['stp'], f'{pre}.{dwi + 2}', mask_mode=1)
-            d16 = ops.act_pack(dyp, prec=PREC, grad=True)
+            d16 = bn_bwd16(d_out, rec['yp'], rec['stp'], f'{pre}.{dwi + 2}', mask_mode=1)
             kp = f'{pre}.{dwi + 1}.weight'
             grads[kp] = _wgrad1x1(rec['ad'], d16, PREC).view(wshape(kp))
             dAd = _conv1x1(d16, packs[kp][1], PREC).view(rec['yd'].shape)
@@ -141,15 +144,13 @@ class MobileNetFeaturesFunction(torch.autograd.Function):
             grads[f'{pre}.{dwi}.0.weight'] = ops.dwconv3x3_wgrad(raw, dyd, rec['stride'], st_raw.scale, st_raw.shift)
             dA_raw = ops.dwconv3x3_dgrad(dyd, rec['wd'], hin, win, rec['stride'])          # w.r.t. relu6(BN(raw))
             if rec['expand']:
-                dye = bn_bwd(dA_raw, raw, st_raw, f'{pre}.0.1', act_hi=6.0)
-                de16 = ops.act_pack(dye, prec=PREC, grad=True)
+                de16 = bn_bwd16(dA_raw, raw, st_raw, f'{pre}.0.1', act_hi=6.0)
                 ke = f'{pre}.0.0.weight'
                 grads[ke] = _wgrad1x1(rec['x16'], de16, PREC).view(wshape(ke))
                 d_out = _conv1x1(de16, packs[ke][1], PREC, res=d_out if rec['res'] else None).view(n, hin, win, -1)
         # the first block has no expand conv: its depthwise input is the stem output
         cols, y0, st0, (h0, w0) = ctx.stem
-        dy0 = bn_bwd(dA_raw, y0, st0, '0.1', act_hi=6.0)
-        d16 = ops.act_pack(dy0, prec=PREC, grad=True)
+        d16 = bn_bwd16(dA_raw, y0, st0, '0.1', act_hi=6.0)
         grads['0.0.weight'] = _wgrad1x1(cols, d16, PREC).view(wshape('0.0.weight'))
         ctx.saved = ctx.stem = ctx.last = None
         from latent_pose_reenactment_amd.nn import fused_accumulate

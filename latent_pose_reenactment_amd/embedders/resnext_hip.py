@@ -141,16 +141,15 @@ class ResNeXtFunction(torch.autograd.Function):
     def backward(ctx, d_logits):
         net, par, packs, train = ctx.net, ctx.par, ctx.packs, ctx.train
         prec = net.prec
-        f16 = prec == PREC_F16
         frozen = not train
         n = ctx.n
         grads = {}
 
         def bn_bwd(dA, y, st, name, **kw):
-            dx, dg, db, g = ops.norm_act_bwd(dA, y, par[name + '.weight'].detach(), st.mean, st.rstd, st.scale, st.shift, frozen=frozen,
-                                             amax=f16, **kw)
+            # BatchNorm (+ ReLU) backward straight to the operand planes of dy: the only consumers are the two gradient contractions
+            d16, dg, db, g = ops.bn_bwd16(dA, y, par[name + '.weight'].detach(), st.mean, st.rstd, st.scale, st.shift, prec=prec, frozen=frozen, **kw)
             grads[name + '.weight'], grads[name + '.bias'] = dg, db
-            return dx, g
+            return d16, g
 
         # ---- head
         p16, (hl, wl, cl), (fh, fw) = ctx.head
@@ -163,23 +162,19 @@ class ResNeXtFunction(torch.autograd.Function):
         for (bname, cin, width, cout, stride, down), sv in zip(reversed(net._hip_blocks), reversed(ctx.blocks)):
             xin16, y1, st1, a1, y2, st2, a2, y3, st3, xd16, yd, std, out, (h, w, ho, wo) = sv
             # out = relu(bn3(y3) + skip): g = d_out * [out > 0] reaches bn3 and the skip branch alike
-            dy3, g = bn_bwd(d_out, y3, st3, bname + '.bn3', mask_mode=2, mask_src=out, want_g=True)
-            d16 = ops.act_pack(dy3, prec=prec, grad=True)
+            d16, g = bn_bwd(d_out, y3, st3, bname + '.bn3', mask_mode=2, mask_src=out, want_g=not down)
             grads[bname + '.conv3.weight'] = _wgrad1x1(a2, d16, prec).view(par[bname + '.conv3.weight'].shape)
             dA2 = _conv1x1(d16, packs[bname + '.conv3.weight'][1], prec).view(n, ho, wo, width)
-            dy2, _ = bn_bwd(dA2, y2, st2, bname + '.bn2')
-            d16 = ops.act_pack(dy2, prec=prec, grad=True)
+            d16, _ = bn_bwd(dA2, y2, st2, bname + '.bn2')
             if stride == 2:
                 d16 = ops.zero_stuff2_16(d16, h, w)                               # adjoint of the subsample of the full-resolution conv
             cg = par[bname + '.conv2.weight'].shape[1]
             grads[bname + '.conv2.weight'] = ops.gconv_wgrad16(a1, d16, cg, prec=prec)
             dA1 = ops.gconv16(d16, packs[bname + '.conv2.weight'][1], prec=prec)
-            dy1, _ = bn_bwd(dA1, y1, st1, bname + '.bn1')
-            d16 = ops.act_pack(dy1, prec=prec, grad=True)
+            d16, _ = bn_bwd(dA1, y1, st1, bname + '.bn1')
             grads[bname + '.conv1.weight'] = _wgrad1x1(xin16, d16, prec).view(par[bname + '.conv1.weight'].shape)
             if down:
-                dyd, _ = bn_bwd(g, yd, std, bname + '.downsample.1', mask_mode=1)
-                dd16 = ops.act_pack(dyd, prec=prec, grad=True)
+                dd16, _ = bn_bwd(d_out, yd, std, bname + '.downsample.1', mask_mode=2, mask_src=out)      # same ReLU pattern as bn3: out > 0
                 grads[bname + '.downsample.0.weight'] = _wgrad1x1(xd16, dd16, prec).view(par[bname + '.downsample.0.weight'].shape)
                 d_xd = _conv1x1(dd16, packs[bname + '.downsample.0.weight'][1], prec)          # [P', cin]
                 if stride == 2:
@@ -193,8 +188,7 @@ class ResNeXtFunction(torch.autograd.Function):
         # ---- stem
         cols, y0, st0, idx, (h0, w0) = ctx.stem
         dA0 = ops.maxpool_bwd(d_out, idx, h0, w0)
-        dy0, _ = bn_bwd(dA0, y0, st0, 'bn1')
-        d16 = ops.act_pack(dy0, prec=prec, grad=True)
+        d16, _ = bn_bwd(dA0, y0, st0, 'bn1')
         grads['conv1.weight'] = _wgrad1x1(cols, d16, prec).view(par['conv1.weight'].shape)
         ctx.blocks = ctx.stem = ctx.head = None
         from latent_pose_reenactment_amd.nn import fused_accumulate

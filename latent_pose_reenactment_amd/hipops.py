@@ -973,3 +973,26 @@ def dwconv3x3_wgrad(x: Tensor, dy: Tensor, stride: int, in_scale: Optional[Tenso
     check(_lib.lib().lp_dwconv3x3_wgrad(x.data_ptr(), _p(in_scale), _p(in_shift), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), n, h, wd, c,
                                         stride, _stream()), 'lp_dwconv3x3_wgrad')
     return dw
+
+
+def bn_bwd16(dA: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, scale: Tensor, shift: Tensor, *, prec: int, mask_mode: int = 0,
+             mask_src: Optional[Tensor] = None, want_g: bool = False, act_hi: float = 0.0, frozen: bool = False):
+    """backward of act(BatchNorm(x)) over x [..., C] written straight to the OPERAND PLANES of dy (what the weight / data gradient
+    contractions consume): -> (Act16 of dy, dgamma [C], dbeta [C], g | None).  No fp32 dy, no masked-gradient temporary; in fp16 mode the
+    planes carry the power-of-two scale of lp_bn_bwd16 (``Act16.inv``).  Arguments as ``norm_act_bwd``."""
+    _chk(dA, 'dA'); _chk(x, 'x')
+    c = x.shape[-1]
+    p = x.numel() // c
+    assert dA.shape == x.shape and c % 8 == 0, (dA.shape, x.shape)
+    hi = torch.empty(x.shape, dtype=torch.int16, device=x.device)
+    lo = torch.empty_like(hi) if prec == PREC_BF16X3 else None
+    small = torch.empty(2 + 2 * c, dtype=torch.float32, device=x.device)
+    sc, dg, db = small[:2], small[2:2 + c], small[2 + c:]
+    g = torch.empty_like(x) if want_g else None
+    ws = torch.empty(_lib.lib().lp_bn_bwd16_workspace_bytes(p, c) // 4, dtype=torch.float32, device=x.device)
+    if mask_src is not None:
+        _chk(mask_src, 'mask_src'); assert mask_src.shape == x.shape
+    check(_lib.lib().lp_bn_bwd16(dA.data_ptr(), x.data_ptr(), _p(mask_src), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(),
+                                 shift.data_ptr(), hi.data_ptr(), _p(lo), sc.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), p, c,
+                                 mask_mode, float(act_hi), int(frozen), prec, _p(g), _stream()), 'lp_bn_bwd16')
+    return Act16(hi, lo, c, sc[1:] if prec == PREC_F16 else None), dg, db, g

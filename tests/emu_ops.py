@@ -234,3 +234,9 @@ def dwconv3x3_wgrad(x, dy, stride, in_scale=None, in_shift=None):
 
 def affine_relu6_mean(y, scale, shift):
     return torch.clamp(y * scale + shift, 0, 6).mean(dim=(1, 2))
+
+
+def bn_bwd16(dA, x, gamma, mean, rstd, scale, shift, *, prec=0, mask_mode=0, mask_src=None, want_g=False, act_hi=0.0, frozen=False):
+    dx, dg, db, g = norm_act_bwd(dA, x, gamma, mean, rstd, scale, shift, mask_mode=mask_mode, mask_src=mask_src, want_g=want_g, act_hi=act_hi,
+                                 frozen=frozen)
+    return Act16(dx, None, x.shape[-1], None), dg, db, g

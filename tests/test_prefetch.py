@@ -17,7 +17,8 @@ pytestmark = pytest.mark.gpu
 def test_prefetcher_delivers_every_batch_while_the_device_is_busy():
     from latent_pose_reenactment_amd.dataloaders.prefetch import DevicePrefetcher
     g = torch.Generator().manual_seed(0)
-    batches = [({'x': torch.randn(4, 3, 256, 256, generator=g), 'tag': k}, {'label': torch.arange(4) + k}) for k in range(7)]
+    batches = [({'x': torch.randn(4, 3, 256, 256, generator=g), 'tag': k}, {'label': torch.arange(4) + k}) for k in range(9)]
+    batches[3][0]['x'] = batches[3][0]['x'].pin_memory()          # a loader that already delivers pinned tensors: copied from in place
     big = torch.randn(4096, 4096, device='cuda')
     got = []
     for data, target in DevicePrefetcher(batches, 'cuda'):

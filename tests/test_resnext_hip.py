@@ -109,6 +109,38 @@ def test_norm_act_bwd_modes(mode):
     assert abs(float(slots.max()) - float(dx.abs().max())) <= 1e-6 * float(dx.abs().max())
 
 
+@pytest.mark.parametrize('prec', [1, 2])
+@pytest.mark.parametrize('mode', ['relu', 'relu6', 'none', 'src', 'frozen'])
+def test_bn_bwd_straight_to_operand_planes(mode, prec):
+    """lp_bn_bwd16: dy never exists in fp32 -- the planes (x 1/scale in fp16 mode) must equal the fp64 dy to operand precision, and the
+    fp16 scale (taken from a per-channel BOUND of |dy|) must leave the largest element inside the fp16 range with >= 2^-3 of headroom used"""
+    import emu_ops
+    ops = _ops()
+    g = torch.Generator().manual_seed(15)
+    n, h, w, c = 4, 12, 20, 128
+    x = torch.randn(n, h, w, c, generator=g).cuda()
+    dA = (torch.randn(n, h, w, c, generator=g) * 1e-4).cuda()
+    src = torch.randn(n, h, w, c, generator=g).cuda()
+    gamma, beta = (torch.rand(c, generator=g) + 0.5).cuda(), (torch.randn(c, generator=g) * 0.3).cuda()
+    mean, rstd, scale, shift = emu_ops.bn_train_stats(x.double(), gamma.double(), beta.double(), None, None, 0.1, 1e-5)
+    if mode == 'relu6':
+        scale, shift = scale * 4, shift * 4 + 2
+    st32 = [t.float().contiguous() for t in (mean, rstd, scale, shift)]
+    kw = dict(mask_mode={'relu': 0, 'relu6': 0, 'none': 1, 'src': 2, 'frozen': 0}[mode], mask_src=src if mode == 'src' else None,
+              want_g=mode == 'src', act_hi=6.0 if mode == 'relu6' else 0.0, frozen=mode == 'frozen')
+    d16, dg, db, gm = ops.bn_bwd16(dA, x, gamma, *st32, prec=prec, **kw)
+    kw64 = dict(kw, mask_src=None if kw['mask_src'] is None else src.double())
+    rdx, rdg, rdb, rg = emu_ops.norm_act_bwd(dA.double(), x.double(), gamma.double(), mean, rstd, scale, shift, **kw64)
+    report(f'bn_bwd16[{mode}] prec{prec} planes', rel(decode(d16, prec), rdx), 3e-6 if prec == 1 else 4e-4)
+    report(f'bn_bwd16[{mode}] dgamma', rel(dg, rdg), 2e-5)
+    report(f'bn_bwd16[{mode}] dbeta', rel(db, rdb), 2e-5)
+    if gm is not None:
+        report(f'bn_bwd16[{mode}] g', rel(gm, rg), 1e-7)
+    if prec == 2:
+        top = d16.hi.view(torch.float16).float().abs().max().item()
+        assert 2.0 ** 9 <= top < 2.0 ** 13.01, top         # bound >= amax (no overflow) and within 2^4 of it (no needless underflow)
+
+
 GCASES = [(2, 16, 16, 128, 4), (8, 8, 8, 1024, 32), (3, 12, 20, 256, 8), (1, 32, 32, 512, 16), (8, 4, 4, 1024, 32)]
 
 
