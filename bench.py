@@ -295,7 +295,9 @@ def cpu_baseline(args, full=False, workload='metatrain_step'):
     --cpu-baseline-full runs the >= 3 warm-up + >= 10 timed protocol."""
     import subprocess
     model, cores, logical = _cpu_info()
-    use = cores                 # all physical cores (the SMT siblings add nothing to torch-CPU GEMMs)
+    # torch-CPU on this 2-socket box is SLOWER on all 128 physical cores than on the 64 of one socket (measured: meta-training sample
+    # 21.1 s/step on 128 threads; the fine-tuning step 19.2 s on 64): the all-core row uses min(physical cores, 64) threads and says so
+    use = min(cores, 64)
     warm, reps = (3, 10) if full else (1, 3)
     meta = int(workload == 'metatrain_step')
     name = 'meta-training' if meta else 'fine-tuning'
@@ -314,7 +316,8 @@ def cpu_baseline(args, full=False, workload='metatrain_step'):
                            'sample': f"median of {o['n']} {name} step(s) of 1 sample at {args.image_size}x{args.image_size}, OMP_NUM_THREADS=1 / "
                                      f"torch.set_num_threads(1): {o['t']:.2f} s per step"},
             'sample': f"median of {a['n']} {name} step(s) of {ab} samples at {args.image_size}x{args.image_size} through oracle/lp_oracle.py "
-                      f"(+ the stock torch-CPU encoder layers; torch CPU fp32, {use} threads = all physical cores of {model}); {a['t']:.2f} s per step"
+                      f"(+ the stock torch-CPU encoder layers; torch CPU fp32, {use} threads on a host with {cores} physical cores ({model}): more threads "
+                      f"run slower, NUMA); {a['t']:.2f} s per step"
                       + ('' if full else '; bounded sample -- the >= 3 + >= 10 protocol is `bench.py --cpu-baseline-full` (profiles/)')}
 
 
@@ -382,7 +385,8 @@ def main():
                          'workload so that the 1/2/4/8-GPU values form a scaling curve).  finetune_step = BASELINE configs[1] (single GPU in the '
                          'reference); the default N = 1 run also reports it under "finetune_step"')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-also', action='store_true', help='skip the side measurement of the strict bf16x3 mode')
+    ap.add_argument('--no-also', action='store_true', help='skip the side measurements (strict bf16x3 mode, fine-tuning step)')
+    ap.add_argument('--no-drive', action='store_true', help='skip the drive.py frame-loop measurement (PMC passes: keeps the launch population to the step)')
     ap.add_argument('--eager', action='store_true', help='do not capture the step into hipGraphs')
     ap.add_argument('--shapes', default=None, help='write the per-shape conv / wgrad timing table of the instrumented steps (CSV)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only for functional tests)')
@@ -501,11 +505,15 @@ def main():
     # live roofline of the dominant kernel family (HIP events recorded on the launch stream inside the timed region)
     agg = {}
     shapes = {}
-    for kind, flops, e0, e1, tag in prof:
+    agg_bytes = {}
+    for kind, flops, e0, e1, tag, nbytes in prof:
         sd = shapes.setdefault((kind, tag), [0.0, 0.0, 0])
         sd[0] += flops; sd[1] += e0.elapsed_time(e1) * 1e-3; sd[2] += 1
         d = agg.setdefault(kind, [0.0, 0.0, 0])
         d[0] += flops; d[1] += e0.elapsed_time(e1) * 1e-3; d[2] += 1
+        agg_bytes[kind] = agg_bytes.get(kind, 0.0) + nbytes
+    HBM_KINDS = ('conv1x1', 'wgrad1x1', 'gconv', 'gconv_wgrad')      # the embedder's contractions: bound by their activation traffic, not by MFMA
+    HBM_PEAK_GBS = 8000.0
     roof = None
     extra = {}
     for kind, (fl, sec, cnt) in agg.items():
@@ -518,6 +526,14 @@ def main():
                  'mfma_per_algorithmic_flop': 3 if a.prec == 'bf16x3' else 1,
                  'mfma_work_tflops': round(ach * (3 if a.prec == 'bf16x3' else 1), 2),
                  'traffic_note': None}
+        if kind in HBM_KINDS and sec > 0:
+            gbs = agg_bytes.get(kind, 0.0) / sec / 1e9
+            entry.update({'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4),
+                          'algorithmic_mb_per_launch': round(agg_bytes.get(kind, 0.0) / max(cnt, 1) / 1e6, 2), 'algorithmic_tflops': round(ach, 1),
+                          'traffic_note': 'algorithmic bytes: operand planes read once + weights + the fp32 (and plane) outputs written once; '
+                                          'priced against the 8 TB/s HBM3E peak (6.3 TB/s is what a streaming copy reaches on this chip)'})
+            for k_ in ('mfma_per_algorithmic_flop', 'mfma_work_tflops', 'algorithmic_gflop_per_launch'):
+                entry.pop(k_, None)
         if kind == 'conv_igemm':
             # HBM bytes per launch of this kernel family from the committed PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs of
             # `bench.py --workload generator` under rocprofv3, scripts/r02_artifacts.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md)
@@ -589,7 +605,7 @@ def main():
         out.update(extra)
         if solo is not None:
             out['single_gpu_same_workload'] = solo
-        if world == 1:
+        if world == 1 and not a.no_drive:
             try:
                 out['drive'] = drive_fps(args)
             except Exception as ex:

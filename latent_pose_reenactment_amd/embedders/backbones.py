@@ -95,9 +95,10 @@ class ResNeXt(nn.Module):
         return nn.Sequential(*seq)
 
     def forward(self, x):
-        from . import resnext_hip
-        if _HIP_FORWARD[0] and x.is_cuda and x.dim() == 4 and x.shape[1] == 3 and resnext_hip.supported(x.shape[0], x.shape[2], x.shape[3]):
-            return self._forward_hip(x)
+        if _HIP_FORWARD[0] and x.is_cuda and x.dim() == 4 and x.shape[1] == 3:
+            from . import resnext_hip
+            if resnext_hip.supported(x.shape[0], x.shape[2], x.shape[3]):
+                return self._forward_hip(x)
         if _HIP_FORWARD[0] and x.is_cuda and not self.__dict__.get('_warned_stock'):
             self.__dict__['_warned_stock'] = True
             import logging

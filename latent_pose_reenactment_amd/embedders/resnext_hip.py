@@ -43,7 +43,7 @@ def _conv1x1(a16, pack, prec, bias=None, res=None, amax=False, stats=False):
     _, h, w, _ = fa.hi.shape
     if res is not None:
         res = res.view(1, h, w, -1)
-    return ops.conv16(fa, pack, ksize=1, bias=bias, res=res, prec=prec, amax=amax, stats=stats)
+    return ops.conv16(fa, pack, ksize=1, bias=bias, res=res, prec=prec, amax=amax, stats=stats, kind='conv1x1')
 
 
 def bn_state(y, st, gamma, beta, m, counters):
@@ -57,7 +57,7 @@ def bn_state(y, st, gamma, beta, m, counters):
 
 
 def _wgrad1x1(a16, d16, prec, bias_grad=False):
-    return ops.conv_wgrad16(ops.flat16(a16), ops.flat16(d16), ksize=1, prec=prec, bias_grad=bias_grad)
+    return ops.conv_wgrad16(ops.flat16(a16), ops.flat16(d16), ksize=1, prec=prec, bias_grad=bias_grad, kind='wgrad1x1')
 
 
 class ResNeXtFunction(torch.autograd.Function):

@@ -22,8 +22,8 @@ PROFILE = None
 
 
 class _Timed:
-    def __init__(self, kind, flops, tag=None):
-        self.kind, self.flops, self.tag = kind, flops, tag
+    def __init__(self, kind, flops, tag=None, nbytes=0.0):
+        self.kind, self.flops, self.tag, self.nbytes = kind, flops, tag, nbytes
 
     def __enter__(self):
         if PROFILE is not None:
@@ -35,7 +35,7 @@ class _Timed:
     def __exit__(self, *exc):
         if PROFILE is not None:
             self.e1.record()
-            PROFILE.append((self.kind, self.flops, self.e0, self.e1, self.tag))
+            PROFILE.append((self.kind, self.flops, self.e0, self.e1, self.tag, self.nbytes))
 
 
 def _p(t: Optional[Tensor]):
@@ -242,7 +242,8 @@ class ConvStats(NamedTuple):
 
 def conv16(a: Act16, pack: WeightPack, *, ksize: int, upsample: bool = False, bias: Optional[Tensor] = None,
            res: Optional[Tensor] = None, res_shift: int = 0, alpha: Optional[Tensor] = None, prec: int = PREC_BF16,
-           relu_mask: Optional[Act16] = None, out16: Optional[int] = None, amax: bool = False, stats: bool = False, want_y: bool = True):
+           relu_mask: Optional[Act16] = None, out16: Optional[int] = None, amax: bool = False, stats: bool = False, want_y: bool = True,
+           kind: str = 'conv_igemm'):
     """y = alpha * conv(up2?(a), pack) + bias + res on operand planes; a [N,Hin,Win,C8] -> y [N,H,W,Cout] fp32.
     ``relu_mask``: operand planes [N,H,W,Co8] of the forward conv's input; y is zeroed where they are <= 0 (fused ReLU backward
     when this launch is a data gradient).  ``out16`` = 0 | 1: also return the operand planes of y (1: of relu(y)) -> (y, Act16).
@@ -277,7 +278,10 @@ def conv16(a: Act16, pack: WeightPack, *, ksize: int, upsample: bool = False, bi
         st_cap = _lib.lib().lp_conv16_stats_floats(n, h, w, cout)
         st_buf = torch.empty(st_cap, dtype=torch.float32, device=dev)
         st_rows = ctypes.c_int(0)
-    with _Timed('conv_igemm', 2.0 * n * h * w * cout * cin * ksize * ksize, (n, h, w, cin, cout, ksize, int(upsample), 0)):
+    pl = 4 if prec == PREC_BF16X3 else 2              # bytes per operand-plane element
+    nbytes = n * hin * win * a.hi.shape[3] * pl + pack.hi.numel() * pl + n * h * w * cout * ((4 if want_y else 0) + (pl if out16 is not None else 0)) \
+        + (n * (h >> res_shift) * (w >> res_shift) * cout * 4 if res is not None else 0)
+    with _Timed(kind, 2.0 * n * h * w * cout * cin * ksize * ksize, (n, h, w, cin, cout, ksize, int(upsample), 0), nbytes):
         check(_lib.lib().lp_conv16_fwd_stats(a.hi.data_ptr(), _p(a.lo), pack.hi.data_ptr(), _p(pack.lo), _p(y), _p(bias), _p(res),
                                              _p(alpha), _p(a.inv), n, h, w, cin, cout, pack.cols_p, pack.rows_p, ksize, int(upsample),
                                              res_shift, prec, None if relu_mask is None else relu_mask.hi.data_ptr(), _p(o_hi), _p(o_lo),
@@ -351,7 +355,7 @@ def default_splits(n, h, w, cin, cout, ksize=3):
 
 
 def conv_wgrad16(a: Act16, dy: Act16, *, ksize: int, upsample: bool = False, prec: int = PREC_BF16, splits: Optional[int] = None,
-                 sn=None, accum: Optional[Tensor] = None, bias_grad: bool = False, bias_accum: Optional[Tensor] = None):
+                 sn=None, accum: Optional[Tensor] = None, bias_grad: bool = False, bias_accum: Optional[Tensor] = None, kind: str = 'conv_wgrad'):
     """dw [Cout,Cin,k,k] = sum_pixels dy (x) up2?(a) (shifted by tap) on operand planes (a = what the forward conv consumed).
     ``sn`` = (w_orig, u, v, sig): the layer is spectrally normalised (forward used alpha = 1/sigma in the conv epilogue); the
     returned gradient is then w.r.t. W_orig: dw/sigma - <dw, W_orig>/sigma^2 u v^T.
@@ -378,7 +382,9 @@ def conv_wgrad16(a: Act16, dy: Act16, *, ksize: int, upsample: bool = False, pre
         _chk(sn[0], 'w_orig')
         ndot = _lib.lib().lp_conv_wgrad_dot_blocks(cin, cout, ksize)
         dot = torch.empty(ndot, dtype=torch.float32, device=dev)
-    with _Timed('conv_wgrad', 2.0 * n * h * w * cout * cin * ksize * ksize, (n, h, w, cin, cout, ksize, int(upsample), 0)):
+    pl = 4 if prec == PREC_BF16X3 else 2
+    nbytes = (a.hi.numel() + dy.hi.numel()) * pl + cout * cin * ksize * ksize * 4
+    with _Timed(kind, 2.0 * n * h * w * cout * cin * ksize * ksize, (n, h, w, cin, cout, ksize, int(upsample), 0), nbytes):
         check(_lib.lib().lp_conv16_wgrad(a.hi.data_ptr(), _p(a.lo), dy.hi.data_ptr(), _p(dy.lo), dw.data_ptr(), ws.data_ptr(), n, h, w, cin,
                                          cout, ksize, int(upsample), splits, prec, _p(db), int(bias_grad and bias_accum is not None), _p(dy.inv),
                                          None if sn is None else sn[0].data_ptr(), _p(dot), _stream()), 'lp_conv16_wgrad')
@@ -807,7 +813,8 @@ def gconv16(a: Act16, pack: WeightPack, *, prec: int, amax: bool = False, stats:
         st_cap = _lib.lib().lp_conv16_stats_floats(n, h, w, c)
         st_buf = torch.empty(st_cap, dtype=torch.float32, device=y.device)
         st_rows = ctypes.c_int(0)
-    with _Timed('gconv', 2.0 * n * h * w * c * pack.cols * 9, (n, h, w, pack.cols, c, 3, 0, 0)):
+    pl = 4 if prec == PREC_BF16X3 else 2
+    with _Timed('gconv', 2.0 * n * h * w * c * pack.cols * 9, (n, h, w, pack.cols, c, 3, 0, 0), n * h * w * c * (pl + 4) + pack.hi.numel() * pl):
         check(_lib.lib().lp_gconv16_fwd_stats(a.hi.data_ptr(), _p(a.lo), pack.hi.data_ptr(), _p(pack.lo), y.data_ptr(), _p(a.inv), n, h, w, c,
                                               pack.rows_p, prec, _p(slots), _p(st_buf), st_cap, None if st_rows is None else ctypes.addressof(st_rows),
                                               _stream()), 'lp_gconv16_fwd')
@@ -847,7 +854,8 @@ def gconv_wgrad16(a: Act16, dy: Act16, group_size: int, *, prec: int, splits: Op
         splits = max(1, min(512 // max(1, c // 64), (n * h * w + 127) // 128))
     ws = torch.empty(_lib.lib().lp_gconv_wgrad_workspace_bytes(c, splits) // 4, dtype=torch.float32, device=dy.hi.device)
     dw = torch.empty((c, group_size, 3, 3), dtype=torch.float32, device=dy.hi.device)
-    with _Timed('gconv_wgrad', 2.0 * n * h * w * c * group_size * 9, (n, h, w, group_size, c, 3, 0, 0)):
+    pl = 4 if prec == PREC_BF16X3 else 2
+    with _Timed('gconv_wgrad', 2.0 * n * h * w * c * group_size * 9, (n, h, w, group_size, c, 3, 0, 0), 2 * n * h * w * c * pl):
         check(_lib.lib().lp_gconv16_wgrad(a.hi.data_ptr(), _p(a.lo), dy.hi.data_ptr(), _p(dy.lo), dw.data_ptr(), ws.data_ptr(), n, h, w, c,
                                           group_size, splits, prec, _p(dy.inv), _stream()), 'lp_gconv16_wgrad')
     return dw

@@ -20,7 +20,7 @@ cp $O/${R}_prof_ft/${R}_kernel_stats.csv $O/${R}_finetune_step_f16_kernel_stats.
 rm -f $O/${R}_prof_ft/${R}_kernel_trace.csv
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_WAVE_CYCLES"; do
   tag=$(echo $c | tr ' ' '+')
-  timeout 300 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "conv_dma_kernel" --output-format csv -d $O/${R}_pmc_gen_$tag -o ${R} -- python bench.py --workload generator --steps 2 --warmup 1 --no-cpu-baseline > $O/${R}_pmc_gen_$tag.log 2>&1
+  timeout 300 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "conv_dma_kernel" --output-format csv -d $O/${R}_pmc_gen_$tag -o ${R} -- python bench.py --workload generator --steps 2 --warmup 1 --no-cpu-baseline --no-drive > $O/${R}_pmc_gen_$tag.log 2>&1
   echo "pmc $tag rc=$?" >> $O/summary.txt
   rm -f $O/${R}_pmc_gen_$tag/${R}_kernel_trace.csv
 done

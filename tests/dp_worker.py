@@ -14,6 +14,9 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'latent_pose_reenactment_amd'))
 
 
+ORDER = []
+
+
 def small_args(world, rank, num_labels):
     return argparse.Namespace(image_size=32, num_channels=4, max_num_channels=16, embed_channels=8, pose_embedding_size=4, in_channels=3,
                               out_channels=3, num_labels=num_labels, dis_num_blocks=5, gen_padding='zero', norm_layer='in',
@@ -67,14 +70,39 @@ def run(world, rank, mode, total, num_labels, steps, out_path):
         # INSIDE a capture would be re-initialised by every replay), then the captured step replayed for the rest
         holycow.train_step(tm, data, target, opt_G, opt_D, a)
         step = holycow.GraphedTrainStep(tm, opt_G, opt_D, a, data, target, warmup_steps=0)
+        if world > 1:
+            # order log of the re-cut step: graph replays and collectives as the host issues them (the test asserts that the generator-side
+            # all-reduce is issued ASYNCHRONOUSLY before the discriminator-backward graph and waited for only before optimizer_G's graph)
+            class _Logged:
+                def __init__(self, name, g):
+                    self.name, self.g = name, g
+
+                def replay(self):
+                    ORDER.append(self.name)
+                    self.g.replay()
+            for nm in ('g1', 'g2a', 'g2b', 'g3'):
+                setattr(step, nm, _Logged(nm, getattr(step, nm)))
+            orig_ar, orig_wait = dist.all_reduce, step.reducer.wait_generator_side
+            n_g = opt_G.ensure_flat(0).numel()
+
+            def logged_all_reduce(t, *args, **kw):
+                ORDER.append(('all_reduce', 'G' if t.numel() == n_g else 'D-side', bool(kw.get('async_op', False))))
+                return orig_ar(t, *args, **kw)
+
+            def logged_wait():
+                ORDER.append('wait_G')
+                return orig_wait()
+            dist.all_reduce = logged_all_reduce
+            step.reducer.wait_generator_side = logged_wait
         for _ in range(steps - 1):
+            del ORDER[:]
             step()
     else:
         for _ in range(steps):
             holycow.train_step(tm, data, target, opt_G, opt_D, a)
     torch.cuda.synchronize()
     if rank == 0:
-        torch.save({'gradG': opt_G.ensure_flat(0).cpu(), 'gradD': opt_D.ensure_flat(0).cpu(),
+        torch.save({'order': list(ORDER), 'gradG': opt_G.ensure_flat(0).cpu(), 'gradD': opt_D.ensure_flat(0).cpu(),
                     'G': {k: v.cpu() for k, v in tm.generator.state_dict().items()},
                     'D': {k: v.cpu() for k, v in tm.discriminator.state_dict().items()}}, out_path)
 

@@ -73,7 +73,7 @@ class ConvStats(NamedTuple):
 
 
 def conv16(a, pack, *, ksize, upsample=False, bias=None, res=None, res_shift=0, alpha=None, prec=0, relu_mask=None, out16=None, amax=False,
-           stats=False, want_y=True):
+           stats=False, want_y=True, kind=None):
     assert ksize == 1 and not upsample
     w = pack.w.reshape(pack.w.shape[0], -1)                       # [Cout, Cin]
     x = a.hi[..., :a.c]
@@ -90,7 +90,7 @@ def norm_stats_finalize(st, n, c, gamma, beta, eps, *, running_mean=None, runnin
     return bn_train_stats(st.part, gamma, beta, running_mean, running_var, momentum, eps)
 
 
-def conv_wgrad16(a, dy, *, ksize, upsample=False, prec=0, splits=None, sn=None, accum=None, bias_grad=False, bias_accum=None):
+def conv_wgrad16(a, dy, *, ksize, upsample=False, prec=0, splits=None, sn=None, accum=None, bias_grad=False, bias_accum=None, kind=None):
     assert ksize == 1
     x = a.hi[..., :a.c].reshape(-1, a.c)
     d = dy.hi[..., :dy.c].reshape(-1, dy.c)

@@ -475,7 +475,7 @@ def _install_backbones():
 META_SEED = 21
 
 
-def make_metatrain_step():
+def make_metatrain_step(train_bn=False):
     """runners/holycow.run_epoch for ONE batch of the META-TRAINING configuration (configs/default.yaml: criterions idt_embed,
     perceptual, adversarial, featmat, dis_embed, dice; Adam; embedder parameters in optimizer_G; many labels), reduced size, with
     the reference's own TrainingModule / get_optimizer / Embedder.  torchvision is absent, so the reference's embedder receives this
@@ -501,7 +501,13 @@ def make_metatrain_step():
     opt_G = ref_runner.get_optimizer(tm.embedder, tm.generator, args)
     opt_D = ref_dis.Wrapper.get_optimizer(tm.discriminator, args)
     tm.train()
-    tm.embedder.eval()
+    if train_bn:
+        # second fixture: BOTH encoders in train mode, as the reference holds them (BatchNorm on batch statistics, running statistics
+        # updated); the only change is Dropout p = 0 in the MobileNetV2 classifier on both sides (its mask is RNG-stream dependent)
+        tm.embedder.pose_encoder.classifier[0].p = 0.0
+        tm.running_averages['embedder'].pose_encoder.classifier[0].p = 0.0
+    else:
+        tm.embedder.eval()
     for nm, mod in (('G', tm.generator), ('D', tm.discriminator)):
         out.update(sd_np(mod, f'init.{nm}.'))
     g = torch.Generator().manual_seed(5)
@@ -547,8 +553,13 @@ def make_metatrain_step():
         gr = p_.grad if p_.grad is not None else torch.zeros_like(p_)
         summ.append([float(gr.double().norm()), float((gr.double() * r.double()).sum())])
     out['E.grad_summary'] = np.array(summ)
-    np.savez_compressed(os.path.join(OUT, 'metatrain_step_small.npz'), **out)
-    print('metatrain_step_small.npz', len(out), 'arrays; losses', {k: float(v) for k, v in out.items() if k.startswith('loss.')})
+    if train_bn:      # the BatchNorm running statistics after the step (momentum update from the batch statistics), as a checksum per buffer
+        out['E.buffer_norms'] = np.array([float(b.double().norm()) for k, b in tm.embedder.named_buffers() if 'running' in k])
+        # keep the fixture small: the generator / discriminator states are pinned by the eval-mode fixture already
+        out = {k: v for k, v in out.items() if not (k.startswith('after.') and ('.weight_orig' in k or 'weight_u' in k or 'weight_v' in k) and v.size > 4096)}
+    name = 'metatrain_step_trainbn_small.npz' if train_bn else 'metatrain_step_small.npz'
+    np.savez_compressed(os.path.join(OUT, name), **out)
+    print(name, len(out), 'arrays; losses', {k: float(v) for k, v in out.items() if k.startswith('loss.')})
 
 
 def make_checkpoint():
@@ -646,6 +657,9 @@ def make_fsth_plus():
 
 if __name__ == '__main__':
     torch.set_num_threads(1)
-    which = sys.argv[1:] or ['ops', 'generator', 'discriminator', 'perceptual', 'train_step', 'metatrain_step', 'checkpoint', 'fsth_plus']
+    which = sys.argv[1:] or ['ops', 'generator', 'discriminator', 'perceptual', 'train_step', 'metatrain_step', 'metatrain_step_trainbn', 'checkpoint', 'fsth_plus']
     for w in which:
-        globals()['make_' + w]()
+        if w == 'metatrain_step_trainbn':
+            make_metatrain_step(train_bn=True)
+        else:
+            globals()['make_' + w]()
