@@ -208,12 +208,9 @@ void conv_dma_kernel(Conv16Params p) {
             }
         };
         fetch(0, 0);
-        // ping-pong: the SIMD's other wave is issuing LDS-DMA (scalar M0 moves, address VALU, the loads) beside these MFMAs -- a role split,
-        // which is where a raised priority for the matrix wave pays (cdna_hip_programming.md T5); LP_CONV_PRIO=0 builds without it (A/B)
-#ifndef LP_CONV_PRIO
-#define LP_CONV_PRIO 1
-#endif
-        if (PP && LP_CONV_PRIO) __builtin_amdgcn_s_setprio(1);
+        // (measured null, round 3: s_setprio(1) around this MFMA cluster of the ping-pong kernel -- the SIMD's other wave issues LDS-DMA
+        //  beside it -- changes the 12 layer classes of scripts/conv_micro.py by -2 .. +2 %; two ping-pong workgroups per CU at <= 128
+        //  VGPRs (LP_PP_MINW=4) run 1.3 - 1.7x slower: profiles/r03_conv_dma_variants.md)
 #pragma unroll
         for (int st = 0; st < STEPS; ++st) {
             const int cur = st & 1;
@@ -229,7 +226,6 @@ void conv_dma_kernel(Conv16Params p) {
                     acc[mr][nr] = mfma16t<F16>(fa[cur][mr], fb[cur][nr], acc[mr][nr]);
                 }
         }
-        if (PP && LP_CONV_PRIO) __builtin_amdgcn_s_setprio(0);
     };
 
     const int nch_total = p.CinP / CC;

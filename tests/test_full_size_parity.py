@@ -50,6 +50,7 @@ def test_generator_256_vs_oracle(prec, tol_out, tol_grad):
     torch.cuda.synchronize()
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     sd_u = {k: v.detach().clone() for k, v in sd.items()}         # (the power iteration updates u, v in place: one copy per oracle run)
+    sd_c = {k: v.detach().clone() for k, v in sd.items()}
 
     def oracle_grads(state, relu_masks):
         for k, v in state.items():
@@ -71,7 +72,7 @@ def test_generator_256_vs_oracle(prec, tol_out, tol_grad):
     # calibration of the tie effect itself: the SAME fp32 oracle against an fp64 run of it (true ReLUs on both sides).  Its gradients
     # already differ by the floor that ReLU ties put under any pair of correct implementations; the HIP path's UNTIED error is compared
     # with that floor (printed), the tie-masked comparison below removes it.
-    sd64 = {k: (v.detach().double().clone().requires_grad_(v.requires_grad) if v.dtype.is_floating_point else v.clone()) for k, v in sd_u.items()}
+    sd64 = {k: (v.detach().double().clone().requires_grad_(sd[k].requires_grad) if v.dtype.is_floating_point else v.clone()) for k, v in sd_c.items()}
     e64, p64 = e.double().requires_grad_(True), p.double().requires_grad_(True)
     rgb64, segm64 = O.generator_forward(sd64, e64, p64, num_channels=64, max_num_channels=512, image_size=256, train=True)
     ((rgb64 * r1.double()).sum() + (segm64 * r2.double()).sum()).backward()
