@@ -524,25 +524,27 @@ static int launch_v(Conv16Params& p, size_t lds, dim3 grid, hipStream_t stream) 
     return lp_check_launch("conv_dma");
 }
 
-template <int KS, bool UPS, int WM, int WN, int MR, int NR, int PREC>
+template <int KS, bool UPS, int WM, int WN, int MR, int NR, int PREC, int CC = 32>
 static int launch_conv16(Conv16Params& p, hipStream_t stream) {
     constexpr int BM = WM * MR * 16, BN = WN * NR * 16, NWAVE = WM * WN;
     constexpr bool SPLIT = (PREC == LP_PREC_BF16X3);
-    constexpr size_t B_BUF = (size_t)KS * BN * 64 * (SPLIT ? 2 : 1);
+    constexpr int ROWB = CC * 2, RPI = 64 / (CC / 8);                    // bytes per halo pixel / weight row of a chunk; rows per 1 KiB DMA piece
+    constexpr size_t B_BUF = (size_t)KS * BN * ROWB * (SPLIT ? 2 : 1);
     constexpr size_t LDS_MAX = 160 * 1024;
-    constexpr int AIT = (BM == 128) ? (NWAVE == 8 ? 3 : 5) : 6;
+    constexpr int AIT = ((BM == 128) ? (NWAVE == 8 ? 3 : 5) : 6) * (CC / 32) - (CC == 64 ? 1 : 0);
+    if (p.CinP % CC) return lp_set_error(LP_ERR_ARG, "conv16: padded input channels must be a multiple of the chunk size");
     choose_tile(BM, p.N, p.H, p.W, &p.lTH, &p.lTW, &p.lNB);
     int HH, HW, halo_px;
     for (;;) {       // fewer images per tile until the halo fits the per-wave descriptor budget (tiny feature maps)
         const int TH = 1 << p.lTH, TW = 1 << p.lTW, NBv = 1 << p.lNB;
         if (KS == 1) { HH = TH; HW = TW; } else if (UPS) { HH = TH / 2 + 2; HW = TW / 2 + 2; } else { HH = TH + 2; HW = TW + 2; }
         halo_px = NBv * HH * HW;
-        if ((halo_px + 15) / 16 <= AIT * NWAVE || p.lNB == 0) break;
+        if ((halo_px + RPI - 1) / RPI <= AIT * NWAVE || p.lNB == 0) break;
         --p.lNB;
     }
     const int TH = 1 << p.lTH, TW = 1 << p.lTW, NBv = 1 << p.lNB;
     p.tiles_x = (p.W + TW - 1) / TW; p.tiles_y = (p.H + TH - 1) / TH;
-    const int NH = (halo_px + 15) / 16;
+    const int NH = (halo_px + RPI - 1) / RPI;
     p.hit = (NH + NWAVE - 1) / NWAVE;
     if (p.hit > AIT) return lp_set_error(LP_ERR_UNSUPPORTED, "conv16: halo exceeds the DMA descriptor budget");
     const size_t a_buf = (size_t)p.hit * NWAVE * 1024 * (SPLIT ? 2 : 1);
@@ -565,7 +567,7 @@ static int launch_conv16(Conv16Params& p, hipStream_t stream) {
         // 1x1 convs are not split: their whole contraction is 16 stages, less than the cost of a second launch.
         static const int max_split = getenv("LP_CONV_KSPLIT") ? atoi(getenv("LP_CONV_KSPLIT")) : 8;
         static const int split_wgs = getenv("LP_CONV_SPLIT_WGS") ? atoi(getenv("LP_CONV_SPLIT_WGS")) : 256;   // split while <= this many workgroups result
-        const int wgs = grid.x * grid.y, nch = p.CinP / 32;
+        const int wgs = grid.x * grid.y, nch = p.CinP / CC;
         int ks = 1;
         if (KS == 3 && (p.Cout & 3) == 0 && p.part)
             while (ks < max_split && wgs * ks * 2 <= split_wgs && nch / (ks * 2) >= 2 &&
@@ -589,18 +591,18 @@ static int launch_conv16(Conv16Params& p, hipStream_t stream) {
     }
     // (64-channel chunks -- CC = 64, twice the MFMAs between two barriers -- were measured 7-15 % SLOWER on the 64^2..256^2 layers: their
     //  146 KB of LDS leave one workgroup per CU, while the 72 KB of the 32-channel kernel let two ping-pong workgroups share a CU)
-    if constexpr (pp_ok) { if (pp) return launch_v<KS, UPS, WM, WN, MR, NR, PREC, true>(p, lds, grid, stream); }
+    if constexpr (pp_ok) { if (pp) return launch_v<KS, UPS, WM, WN, MR, NR, PREC, true, 2, CC>(p, lds, grid, stream); }
     // 3-deep weight ring when the grid gives each CU at most ~one workgroup (its LDS would exclude a second one anyway) and it fits
-    constexpr int NQ = KS * BN * 64 / 1024;
+    constexpr int NQ = KS * BN * ROWB / 1024;
     constexpr bool ring_ok = (NQ % NWAVE == 0);
     static const int nbuf_env = getenv("LP_CONV_NBUF") ? atoi(getenv("LP_CONV_NBUF")) : 0;      // 2 | 3 forces
     if constexpr (ring_ok) {
         const size_t lds3 = lds_halo + 3 * B_BUF;
         const long long total_wgs = (long long)grid.x * grid.y * grid.z;
         const bool ring = (nbuf_env ? nbuf_env == 3 : total_wgs <= 320) && lds3 <= LDS_MAX;
-        if (ring) return launch_v<KS, UPS, WM, WN, MR, NR, PREC, false, 3>(p, lds3 > epi ? lds3 : epi, grid, stream);
+        if (ring) return launch_v<KS, UPS, WM, WN, MR, NR, PREC, false, 3, CC>(p, lds3 > epi ? lds3 : epi, grid, stream);
     }
-    return launch_v<KS, UPS, WM, WN, MR, NR, PREC, false>(p, lds, grid, stream);
+    return launch_v<KS, UPS, WM, WN, MR, NR, PREC, false, 2, CC>(p, lds, grid, stream);
 }
 
 template <int PREC>
@@ -625,6 +627,16 @@ static int dispatch_conv16(Conv16Params& p, int ks, int ups, hipStream_t s) {
         return launch_conv16<3, true, 2, 2, 4, 4, PREC>(p, s);
     }
     if (ks == 1 && !ups) {
+        // 1x1: one tap per chunk, so a 32-channel stage is 16 MFMAs per wave between two barriers.  With >= 512 input channels and single-plane
+        // operands the stage is a 64-channel chunk (32 MFMAs, half the barriers): +3..12% on the embedder's K >= 512 layers, nothing below
+        // (those are bound by the fp32 output store), and SLOWER with bf16x3's doubled planes (LDS per workgroup doubles again, occupancy
+        // drops) -- profiles/r03_conv1x1_cc64.txt.  LP_CONV_CC1 = 32 | 64 forces.
+        static const int cc_env = getenv("LP_CONV_CC1") ? atoi(getenv("LP_CONV_CC1")) : 0;
+        const bool cc64 = (cc_env ? cc_env == 64 : (p.Cin >= 512 && PREC != LP_PREC_BF16X3)) && (p.CinP % 64 == 0);
+        if (cc64) {
+            if (p.Cout <= 64 && big_img) return launch_conv16<1, false, 4, 1, 4, 4, PREC, 64>(p, s);
+            return launch_conv16<1, false, 2, 2, 4, 4, PREC, 64>(p, s);
+        }
         if (p.Cout <= 64 && big_img) return launch_conv16<1, false, 4, 1, 4, 4, PREC>(p, s);
         return launch_conv16<1, false, 2, 2, 4, 4, PREC>(p, s);
     }

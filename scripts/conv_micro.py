@@ -12,6 +12,10 @@ SHAPES = [  # N, H, W, Cin, Cout, ks, ups
 if os.environ.get('SHAPES') == 'small':      # the latency-bound layer classes (4x4 .. 16x16 maps, 1x1 skips)
     SHAPES = [(8, 4, 4, 512, 512, 3, 0), (8, 8, 8, 512, 512, 3, 0), (8, 16, 16, 512, 512, 3, 0), (8, 8, 8, 512, 512, 1, 0),
               (8, 16, 16, 512, 512, 1, 0), (8, 8, 8, 512, 512, 3, 1), (8, 32, 32, 512, 512, 3, 0)]
+if os.environ.get('SHAPES') == '1x1':        # the embedder's pointwise layers on flattened pixels (ResNeXt-50 32x4d, 64 frames of 256 px)
+    SHAPES = [(1, p // 16, 16, ci, co, 1, 0) for p, ci, co in
+              [(262144, 64, 128), (262144, 128, 256), (262144, 256, 128), (65536, 256, 512), (65536, 512, 256), (16384, 512, 1024),
+               (16384, 1024, 512), (4096, 1024, 2048), (4096, 2048, 1024)]]
 prec = int(os.environ.get('PREC', '0'))
 REPS = int(os.environ.get('REPS', '20'))
 WHAT = os.environ.get('WHAT', 'conv,pack,wgrad').split(',')
