@@ -139,7 +139,7 @@ extern "C" int lp_pack_weights(const float* w, uint16_t* hi, uint16_t* lo, int C
 //            merged with Chan's parallel-variance formula (no E[x^2]-E[x]^2 cancellation).
 //   stage 2: one thread per (n,c) merges the splits in fp64 and emits mean, rstd, scale, shift.
 // ------------------------------------------------------------------------------------------------------------------
-#define STAT_SPLIT_PIX 1024   // pixels per stage-1 block (256^2 x 64ch x 8 images -> 4096 blocks)
+// pixels per stage-1 block: lp_stat_split_pix (lp_common.h) -- 1024 for the 256^2 maps (4096 blocks), down to 64 for the small ones
 
 __device__ __forceinline__ void chan_merge(float& n_a, float& mean_a, float& m2_a, float n_b, float mean_b, float m2_b) {
     if (n_b == 0.f) return;
@@ -151,16 +151,17 @@ __device__ __forceinline__ void chan_merge(float& n_a, float& mean_a, float& m2_
 }
 
 __global__ __launch_bounds__(256) void instnorm_partial_kernel(const float* __restrict__ x, float* __restrict__ part, int HW, int C,
-                                                               int S) {
+                                                               int S, int PB) {
     __shared__ float sh[3][16][64];
     const int n = blockIdx.z, cb = blockIdx.y, s = blockIdx.x;
     const int cq = threadIdx.x & 15, pl = threadIdx.x >> 4;
     const int c = cb * 64 + cq * 4;
-    const int p0 = s * STAT_SPLIT_PIX, p1 = min(HW, p0 + STAT_SPLIT_PIX);
+    const int p0 = s * PB, p1 = min(HW, p0 + PB);
     float cnt = 0.f, ref[4] = {0, 0, 0, 0}, sd[4] = {0, 0, 0, 0}, sq[4] = {0, 0, 0, 0};
     if (c < C) {
         const float* base = x + (size_t)n * HW * C + c;
         const bool vec = (C & 3) == 0;
+#pragma unroll 4
         for (int pix = p0 + pl; pix < p1; pix += 16) {
             float v[4] = {0, 0, 0, 0};
             if (vec) { float4 q = *(const float4*)(base + (size_t)pix * C); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
@@ -229,16 +230,18 @@ __global__ __launch_bounds__(256) void instnorm_finalize_kernel(const float* __r
 }
 
 extern "C" long long lp_instnorm_workspace_bytes(int N, int HW, int C) {
-    long long S = (HW + STAT_SPLIT_PIX - 1) / STAT_SPLIT_PIX;
+    const int PB = lp_stat_split_pix(N, HW, C);
+    long long S = (HW + PB - 1) / PB;
     return (long long)N * S * C * 3 * 4;
 }
 
 extern "C" int lp_instnorm_stats(const float* x, const float* gamma, const float* beta, int ab_stride, float eps, float* mean,
                                  float* rstd, float* scale, float* shift, float* workspace, int N, int HW, int C, void* stream) {
     if (!x || !mean || !rstd || !workspace) return lp_set_error(LP_ERR_ARG, "lp_instnorm_stats: null pointer");
-    int S = (HW + STAT_SPLIT_PIX - 1) / STAT_SPLIT_PIX;
+    const int PB = lp_stat_split_pix(N, HW, C);
+    int S = (HW + PB - 1) / PB;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(instnorm_partial_kernel, dim3(S, (C + 63) / 64, N), dim3(256), 0, st, x, workspace, HW, C, S);
+    hipLaunchKernelGGL(instnorm_partial_kernel, dim3(S, (C + 63) / 64, N), dim3(256), 0, st, x, workspace, HW, C, S, PB);
     int rc = lp_check_launch("instnorm_partial");
     if (rc) return rc;
     hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(cdiv((long long)N * C, 4)), dim3(256), 0, st, workspace, gamma, beta, ab_stride,
@@ -270,9 +273,10 @@ extern "C" int lp_bn_train_stats(const float* y, const float* gamma, const float
     if (!running_mean != !running_var) return lp_set_error(LP_ERR_ARG, "lp_bn_train_stats: running_mean and running_var go together");
     if (P < 1 || P >= (1ll << 30)) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_bn_train_stats: 1 <= P < 2^30");
     const int HW = (int)P;
-    const int S = (HW + STAT_SPLIT_PIX - 1) / STAT_SPLIT_PIX;
+    const int PB = lp_stat_split_pix(1, HW, C);
+    const int S = (HW + PB - 1) / PB;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(instnorm_partial_kernel, dim3(S, (C + 63) / 64, 1), dim3(256), 0, st, y, workspace, HW, C, S);
+    hipLaunchKernelGGL(instnorm_partial_kernel, dim3(S, (C + 63) / 64, 1), dim3(256), 0, st, y, workspace, HW, C, S, PB);
     int rc = lp_check_launch("bn_stats_partial");
     if (rc) return rc;
     hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, workspace, gamma, beta, C, eps, mean, rstd, scale, shift,
@@ -292,18 +296,19 @@ __global__ __launch_bounds__(256) void adain_bwd_partial_kernel(const float* __r
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
                                                                 float* __restrict__ g_out, float* __restrict__ part, int H, int W, int C,
-                                                                int ups, int S, int mask_mode = 0, const float* __restrict__ mask_src = nullptr,
+                                                                int ups, int S, int PB, int mask_mode = 0, const float* __restrict__ mask_src = nullptr,
                                                                 float* __restrict__ g_copy = nullptr, float act_hi = 3.0e38f) {
     __shared__ float sh[2][16][64];
     const int n = blockIdx.z, cb = blockIdx.y, s = blockIdx.x;
     const int cq = threadIdx.x & 15, pl = threadIdx.x >> 4;
     const int c = cb * 64 + cq * 4;
     const int HW = H * W;
-    const int p0 = s * STAT_SPLIT_PIX, p1 = min(HW, p0 + STAT_SPLIT_PIX);
+    const int p0 = s * PB, p1 = min(HW, p0 + PB);
     float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
     if (c < C) {                                       // C % 4 == 0 required (checked on host)
         float4 mu = *(const float4*)(mean + (size_t)n * C + c), rs = *(const float4*)(rstd + (size_t)n * C + c);
         float4 sc = *(const float4*)(scale + (size_t)n * C + c), sf = *(const float4*)(shift + (size_t)n * C + c);
+#pragma unroll 2
         for (int pix = p0 + pl; pix < p1; pix += 16) {
             float4 xv = *(const float4*)(x + ((size_t)n * HW + pix) * C + c);
             float4 g;
@@ -386,7 +391,8 @@ __global__ void adain_bwd_apply_kernel(float* __restrict__ dx /* holds g */, con
 }
 
 extern "C" long long lp_adain_bwd_workspace_bytes(int N, int HW, int C) {
-    long long S = (HW + STAT_SPLIT_PIX - 1) / STAT_SPLIT_PIX;
+    const int PB = lp_stat_split_pix(N, HW, C);
+    long long S = (HW + PB - 1) / PB;
     return (long long)N * S * C * 2 * 4 + (long long)N * C * 3 * 4;
 }
 
@@ -406,12 +412,13 @@ extern "C" int lp_norm_act_bwd(const float* dA, const float* x, const float* add
     if (mask_mode < 0 || mask_mode > 2 || (mask_mode == 2 && !mask_src)) return lp_set_error(LP_ERR_ARG, "lp_norm_act_bwd: bad mask mode");
     if ((long long)H * W >= (1ll << 30)) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_norm_act_bwd: H*W < 2^30");
     const int HW = H * W;
-    int S = (HW + STAT_SPLIT_PIX - 1) / STAT_SPLIT_PIX;
+    const int PB = lp_stat_split_pix(N, HW, C);
+    int S = (HW + PB - 1) / PB;
     float* part = workspace;
     float* coef = workspace + (size_t)N * S * C * 2;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(adain_bwd_partial_kernel, dim3(S, (C + 63) / 64, N), dim3(256), 0, st, dA, x, mean, rstd, scale, shift, dx, part,
-                       H, W, C, upsample, S, mask_mode, mask_src, g_copy, act_hi > 0.f ? act_hi : 3.0e38f);
+                       H, W, C, upsample, S, PB, mask_mode, mask_src, g_copy, act_hi > 0.f ? act_hi : 3.0e38f);
     int rc = lp_check_launch("adain_bwd_partial");
     if (rc) return rc;
     hipLaunchKernelGGL(adain_bwd_finalize_kernel, dim3(cdiv((long long)N * C, 4)), dim3(256), 0, st, part, gamma, ab_stride, mean, rstd,

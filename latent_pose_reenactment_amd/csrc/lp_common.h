@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;     // 8 x 16-bit lanes = one MFMA 16x16x32 A/B fragment
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
@@ -103,3 +104,18 @@ __device__ __forceinline__ void tile_lin_decode(int kpix, int lTH, int lTW, int&
     nb = kpix >> (lTW + lTH);
 }
 
+
+// Pixels per stage-1 workgroup of the per-channel reductions (norm statistics, norm-backward sums): a workgroup covers 64 channels x
+// `pix` pixels of one image.  1024 pixels where that already gives >= 2048 workgroups (the 256^2 maps); fewer for the smaller tensors
+// (multiples of 16, >= 64) so that the launch still covers the 256 CUs -- the embedder's 8 x 64 x 64 x 256 BatchNorm had 128 workgroups
+// of 64 serial iterations at the fixed split (profiles/r03_bn_bwd16_micro.txt).
+static inline int lp_stat_split_pix(long long images, long long HW, int C) {
+    static const bool fixed = getenv("LP_STAT_SPLIT_FIXED") != nullptr;       // A/B knob: the fixed 1024-pixel split of rounds 1-2
+    if (fixed) return 1024;
+    const long long cb = (C + 63) / 64;
+    long long pb = images * HW * cb / 2048;
+    pb = pb / 16 * 16;
+    if (pb < 64) pb = 64;
+    if (pb > 1024) pb = 1024;
+    return (int)pb;
+}

@@ -394,21 +394,21 @@ extern "C" int lp_pack_grouped(const float* w, uint16_t* hi, uint16_t* lo, int C
 //   pass 3 (apply):    recomputes g from dA and the mask, writes dy * s as operand planes (hi [, lo]); block 0 publishes {s, 1/s}
 // 8 B read in pass 1 and 8 B read + 2 B written in pass 3 per element (fp16 mode), against 30 B for partial + apply + lp_act_pack on fp32 dy.
 // mask modes as lp_norm_act_bwd: 0 own activation 0 < x*scale+shift < act_hi, 1 none, 2 mask_src > 0.
-#define BNB_SPLIT_PIX 1024
 __global__ __launch_bounds__(256) void bn_bwd16_partial_kernel(const float* __restrict__ dA, const float* __restrict__ x, const float* __restrict__ mask_src,
                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                const float* __restrict__ scale, const float* __restrict__ shift,
-                                                               float* __restrict__ part, long long P, int C, int mask_mode, float act_hi) {
+                                                               float* __restrict__ part, long long P, int C, int mask_mode, float act_hi, int PB) {
     __shared__ float sh[4][16][64];
     const int cb = blockIdx.y, s = blockIdx.x;
     const int cq = threadIdx.x & 15, pl = threadIdx.x >> 4;
     const int c = cb * 64 + cq * 4;
-    const long long p0 = (long long)s * BNB_SPLIT_PIX, p1 = min(P, p0 + BNB_SPLIT_PIX);
+    const long long p0 = (long long)s * PB, p1 = min(P, p0 + PB);
     float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0}, gm[4] = {0, 0, 0, 0}, xm[4] = {0, 0, 0, 0};
     if (c < C) {
         const float4 mu = *(const float4*)(mean + c), rs = *(const float4*)(rstd + c);
         const float4 sc = *(const float4*)(scale + c), sf = *(const float4*)(shift + c);
         const float m4[4] = {mu.x, mu.y, mu.z, mu.w}, r4[4] = {rs.x, rs.y, rs.z, rs.w}, a4[4] = {sc.x, sc.y, sc.z, sc.w}, b4[4] = {sf.x, sf.y, sf.z, sf.w};
+#pragma unroll 4
         for (long long pix = p0 + pl; pix < p1; pix += 16) {
             const float4 xv = *(const float4*)(x + pix * C + c), gv = *(const float4*)(dA + pix * C + c);
             float xs[4] = {xv.x, xv.y, xv.z, xv.w}, g[4] = {gv.x, gv.y, gv.z, gv.w};
@@ -523,8 +523,80 @@ __global__ __launch_bounds__(256) void bn_bwd16_apply_kernel(const float* __rest
     }
 }
 
+// pass 3 for C/8 <= 256 channel groups (every layer of the two encoders): a thread keeps ONE group of 8 channels -- its 40 coefficients
+// (ca, cb, cc, scale, shift) are loaded once as float4s -- and walks the pixels of its block (256 / (C/8) pixels per iteration, the
+// lanes of a pixel contiguous: coalesced 32 B per lane).  The one-item-per-thread form above re-reads 40 scalars per 8 elements.
+template <int PREC>
+__global__ __launch_bounds__(256) void bn_bwd16_apply_rows_kernel(const float* __restrict__ dA, const float* __restrict__ x, const float* __restrict__ mask_src,
+                                                                  const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ coef,
+                                                                  const float* __restrict__ bound, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo,
+                                                                  float* __restrict__ out_scale, long long P, int C, int rows, int PB, int mask_mode, float act_hi,
+                                                                  float* __restrict__ g_out) {
+    constexpr bool SPLIT = (PREC == LP_PREC_BF16X3), F16 = (PREC == LP_PREC_F16);
+    float sc_out = 1.f;
+    if (F16) {
+        __shared__ float shm[4];
+        float m = 0.f;
+        for (int j = threadIdx.x; j < C; j += 256) m = fmaxf(m, bound[j]);
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+        if ((threadIdx.x & 63) == 0) shm[threadIdx.x >> 6] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(shm[0], shm[1]), fmaxf(shm[2], shm[3]));
+        float inv = 1.f;
+        if (m > 0.f && m < 3.0e38f) {
+            int e;
+            (void)frexpf(m, &e);
+            int k = 13 - e;
+            k = k > 100 ? 100 : (k < -100 ? -100 : k);
+            sc_out = ldexpf(1.f, k); inv = ldexpf(1.f, -k);
+        }
+        if (out_scale && blockIdx.x == 0 && threadIdx.x == 0) { out_scale[0] = sc_out; out_scale[1] = inv; }
+    } else if (out_scale && blockIdx.x == 0 && threadIdx.x == 0) { out_scale[0] = 1.f; out_scale[1] = 1.f; }
+    const int G = C >> 3;
+    const int cg = threadIdx.x % G, r = threadIdx.x / G;
+    if (r >= rows) return;
+    const int c = cg * 8;
+    float cf[24], a8[8], b8[8];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) { const float4 q = *(const float4*)(coef + (size_t)c * 3 + j * 4); cf[j * 4] = q.x; cf[j * 4 + 1] = q.y; cf[j * 4 + 2] = q.z; cf[j * 4 + 3] = q.w; }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float4 q = *(const float4*)(scale + c + j * 4), t = *(const float4*)(shift + c + j * 4);
+        a8[j * 4] = q.x; a8[j * 4 + 1] = q.y; a8[j * 4 + 2] = q.z; a8[j * 4 + 3] = q.w;
+        b8[j * 4] = t.x; b8[j * 4 + 1] = t.y; b8[j * 4 + 2] = t.z; b8[j * 4 + 3] = t.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { cf[j * 3] *= sc_out; cf[j * 3 + 1] *= sc_out; cf[j * 3 + 2] *= sc_out; }      // power of two: exact
+    const long long p0 = (long long)blockIdx.x * PB, p1 = min(P, p0 + PB);
+#pragma unroll 2
+    for (long long pix = p0 + r; pix < p1; pix += rows) {
+        const size_t off = (size_t)pix * C + c;
+        const float4 g0 = *(const float4*)(dA + off), g1 = *(const float4*)(dA + off + 4);
+        const float4 x0 = *(const float4*)(x + off), x1 = *(const float4*)(x + off + 4);
+        float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+        if (mask_mode == 2) {
+            const float4 m0 = *(const float4*)(mask_src + off), m1 = *(const float4*)(mask_src + off + 4);
+            const float k8[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[j] = k8[j] > 0.f ? g[j] : 0.f;
+        } else if (mask_mode == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float a = fmaf(xs[j], a8[j], b8[j]); g[j] = (a > 0.f && a < act_hi) ? g[j] : 0.f; }
+        }
+        if (g_out) {
+            *(float4*)(g_out + off) = make_float4(g[0], g[1], g[2], g[3]);
+            *(float4*)(g_out + off + 4) = make_float4(g[4], g[5], g[6], g[7]);
+        }
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaf(cf[j * 3], g[j], fmaf(cf[j * 3 + 1], xs[j], cf[j * 3 + 2]));
+        store_op8<F16, SPLIT>(v, hi, lo, off);
+    }
+}
+
 extern "C" long long lp_bn_bwd16_workspace_bytes(long long P, int C) {
-    const long long S = (P + BNB_SPLIT_PIX - 1) / BNB_SPLIT_PIX;
+    const int PB = lp_stat_split_pix(1, P, C);
+    const long long S = (P + PB - 1) / PB;
     return (S * C * 4 + (long long)C * 4) * (long long)sizeof(float);
 }
 
@@ -538,13 +610,14 @@ extern "C" int lp_bn_bwd16(const float* dA, const float* x, const float* mask_sr
     if (mask_mode < 0 || mask_mode > 2 || (mask_mode == 2 && !mask_src)) return lp_set_error(LP_ERR_ARG, "lp_bn_bwd16: bad mask mode");
     if (prec == LP_PREC_BF16X3 && !out_lo) return lp_set_error(LP_ERR_ARG, "lp_bn_bwd16: bf16x3 needs the lo plane");
     if (P < 1) return LP_OK;
-    const int S = (int)((P + BNB_SPLIT_PIX - 1) / BNB_SPLIT_PIX);
+    const int PB = lp_stat_split_pix(1, P, C);
+    const int S = (int)((P + PB - 1) / PB);
     float* part = workspace;
     float* coef = workspace + (size_t)S * C * 4;
     float* bound = coef + (size_t)C * 3;
     const float hi_ = act_hi > 0.f ? act_hi : 3.0e38f;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_bwd16_partial_kernel, dim3(S, (C + 63) / 64), dim3(256), 0, st, dA, x, mask_src, mean, rstd, scale, shift, part, P, C, mask_mode, hi_);
+    hipLaunchKernelGGL(bn_bwd16_partial_kernel, dim3(S, (C + 63) / 64), dim3(256), 0, st, dA, x, mask_src, mean, rstd, scale, shift, part, P, C, mask_mode, hi_, PB);
     int rc = lp_check_launch("bn_bwd16_partial");
     if (rc) return rc;
     hipLaunchKernelGGL(bn_bwd16_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, gamma, mean, rstd, dgamma, dbeta, coef, bound, C, S,
@@ -552,6 +625,22 @@ extern "C" int lp_bn_bwd16(const float* dA, const float* x, const float* mask_sr
     rc = lp_check_launch("bn_bwd16_finalize");
     if (rc) return rc;
     const long long items = P * (C >> 3);
+    const int G = C >> 3;
+    static const bool one_item = getenv("LP_BNB_ITEMS") != nullptr;          // A/B knob: the one-item-per-thread form
+    if (G <= 256 && !one_item) {
+        const int rows = 256 / G;
+        long long ppb = (P + 4095) / 4096;                                   // <= 4096 workgroups, >= 4 pixel rows per thread where P allows
+        if (ppb < 4ll * rows) ppb = 4ll * rows;
+        ppb = (ppb + rows - 1) / rows * rows;
+        const unsigned grid = (unsigned)((P + ppb - 1) / ppb);
+#define LP_BR(Q) hipLaunchKernelGGL(bn_bwd16_apply_rows_kernel<Q>, dim3(grid), dim3(256), 0, st, dA, x, mask_src, scale, shift, coef, bound, out_hi, out_lo, out_scale, P, C, rows, (int)ppb, mask_mode, hi_, g_out)
+        if (prec == LP_PREC_BF16) LP_BR(LP_PREC_BF16);
+        else if (prec == LP_PREC_BF16X3) LP_BR(LP_PREC_BF16X3);
+        else if (prec == LP_PREC_F16) LP_BR(LP_PREC_F16);
+        else return lp_set_error(LP_ERR_ARG, "lp_bn_bwd16: unknown precision mode");
+#undef LP_BR
+        return lp_check_launch("bn_bwd16_apply");
+    }
 #define LP_BB(Q) hipLaunchKernelGGL(bn_bwd16_apply_kernel<Q>, dim3(grid_for(items, 8192)), dim3(256), 0, st, dA, x, mask_src, scale, shift, coef, bound, out_hi, out_lo, out_scale, items, C, mask_mode, hi_, g_out)
     if (prec == LP_PREC_BF16) LP_BB(LP_PREC_BF16);
     else if (prec == LP_PREC_BF16X3) LP_BB(LP_PREC_BF16X3);
