@@ -469,6 +469,196 @@ static int launch_wgrad(WgradParams& p, float* dw, float* dbias, const float* ou
     return lp_check_launch("wgrad_reduce");
 }
 
+
+// ---- 1x1 weight gradient ("pixel contraction"): dw[co][ci] = sum_p dy[p][co] * a[p][ci] ------------------------------------------------
+// The embedder's pointwise layers have one tap per staged tile, i.e. 1/9 of the MFMA work per staged byte of the 3x3 case: the
+// load -> register -> LDS -> barrier -> MFMA cycle of conv_wgrad_kernel leaves them at ~0.9 TB/s of operand traffic (0.11 of HBM peak,
+// profiles/r03_bench_f16.json roofline_wgrad1x1).  This kernel is the same contraction as a K-major GEMM built for that regime:
+//   * a workgroup (4 waves, 2 x 2) owns a 128(co) x 128(ci) block of dw and a contiguous range of 64-pixel stages (split-K over pixels);
+//     a wave keeps 64 x 64 (4 x 4 MFMA 16x16x32 tiles) -> 85 MFMA flops per staged byte against 43 for the 128 x 64 workgroup tile;
+//   * both operand tiles [64 pixels][128 channels] go global -> LDS by DMA (16 B per lane, no registers), double buffered: the DMA of stage
+//     s+1 is in flight while stage s multiplies, one barrier per stage;
+//   * rows are 256 B = one LDS bank period, so the 32-byte units of a row are XOR-swizzled with (pixel & 7): the DMA lane that fills slot k'
+//     of row r fetches chunk k' ^ ((r & 7) << 1); the transposing fragment reads (ds_read_b64_tr_b16: 4 pixels x 16 channels per 16-lane
+//     group) then touch 8 distinct units per 8 pixels;
+//   * XCD-aware block order: the 8 hardware queues take consecutive block ids, so block b = (j, x = b & 7) works on split (j / tiles) * 8 + x
+//     and tile j % tiles -- all tiles that read the same pixel range run on the SAME XCD (one L2) next to each other in dispatch order, so
+//     the operand re-reads (dy once per ci tile, a once per co tile) are L2 hits, not HBM reads.
+// Output: the [split][CoP][CiP] fp32 slabs of the common reduction (wgrad_reduce_*: fp16 scale, spectral-norm dot, accumulation).
+// Layers that want the bias gradient (column sums of dy) keep conv_wgrad_kernel: its staging passes dy through registers.
+struct W1Params {
+    const uint16_t* a_hi; const uint16_t* a_lo; const uint16_t* d_hi; const uint16_t* d_lo; float* part;
+    long long P;
+    int C8, Co8, CoP, CiP, splits, tiles_co, tiles_ci, nstage, xcd_map;
+};
+static __device__ __attribute__((aligned(64))) unsigned int w1_zero_page[16];      // what out-of-range DMA lanes read
+
+template <int PREC>
+__global__ __launch_bounds__(256) void wgrad1x1_kernel(W1Params p) {
+    constexpr bool SPLIT = (PREC == LP_PREC_BF16X3), F16 = (PREC == LP_PREC_F16);
+    constexpr int KP = 64;                                  // pixels per stage
+    constexpr int TILE_B = KP * 256;                        // one [64][128] 16-bit tile
+    constexpr int STAGE_B = TILE_B * (SPLIT ? 4 : 2);       // D_hi | A_hi [| D_lo | A_lo]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mh = wave >> 1, nh = wave & 1;
+    const int ntile = p.tiles_co * p.tiles_ci;
+    int tile, split;
+    if (p.xcd_map) { const int x = blockIdx.x & 7, j = blockIdx.x >> 3; tile = j % ntile; split = (j / ntile) * 8 + x; }
+    else { tile = blockIdx.x % ntile; split = blockIdx.x / ntile; }
+    const int co0 = (tile / p.tiles_ci) * 128, ci0 = (tile % p.tiles_ci) * 128;
+    const int per = (p.nstage + p.splits - 1) / p.splits;
+    const int s_beg = split * per, s_end = min(p.nstage, s_beg + per);
+
+    // DMA descriptors: piece q = i*4 + wave covers rows 4q .. 4q+3 of a tile; lane -> row 4q + lane/16, slot lane%16
+    int d_rel[4], a_rel[4], row_[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (i * 4 + wave) * 4 + (lane >> 4);
+        const int chunk = (lane & 15) ^ ((row & 7) << 1);
+        const int dch = co0 + chunk * 8, ach = ci0 + chunk * 8;
+        row_[i] = row;
+        d_rel[i] = dch < p.Co8 ? row * p.Co8 + dch : -1;
+        a_rel[i] = ach < p.C8 ? row * p.C8 + ach : -1;
+    }
+    const uint16_t* zero16 = (const uint16_t*)w1_zero_page;
+    auto issue = [&](int stage, int buf) {
+        const long long pix0 = (long long)stage * KP;
+        const unsigned dst = (unsigned)(uintptr_t)(smem + buf * STAGE_B);
+        const size_t dbase = (size_t)pix0 * p.Co8, abase = (size_t)pix0 * p.C8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool pok = pix0 + row_[i] < p.P;
+            const bool dok = pok && d_rel[i] >= 0, aok = pok && a_rel[i] >= 0;
+            const unsigned o = dst + (unsigned)((i * 4 + wave) * 1024);
+            lp_glds16(dok ? p.d_hi + dbase + d_rel[i] : zero16, o);
+            lp_glds16(aok ? p.a_hi + abase + a_rel[i] : zero16, o + TILE_B);
+            if (SPLIT) {
+                lp_glds16(dok ? p.d_lo + dbase + d_rel[i] : zero16, o + 2 * TILE_B);
+                lp_glds16(aok ? p.a_lo + abase + a_rel[i] : zero16, o + 3 * TILE_B);
+            }
+        }
+    };
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // source-lane role of the transposing reads (see the header of this file): pixel G*4 + sj of the 16-pixel half, channels 4*sq .. 4*sq+3
+    const int G = lane >> 4, sj = (lane & 15) >> 2, sq = lane & 3;
+    const int kpl = G * 4 + sj;                            // 0..15; the four halves of a stage are kpl + 16 h
+    const int sw = (kpl & 7) << 1;                         // (pixel & 7) is the same for all halves
+    int d_off[4], a_off[4];                                // byte offset inside a row of this lane's 8-byte piece, per fragment
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        d_off[f] = (((mh * 8 + f * 2 + (sq >> 1)) ^ sw) << 4) + (sq & 1) * 8;
+        a_off[f] = (((nh * 8 + f * 2 + (sq >> 1)) ^ sw) << 4) + (sq & 1) * 8;
+    }
+    auto compute = [&](int buf) {
+        const unsigned char* D_hi = smem + buf * STAGE_B;
+        const unsigned char* A_hi = D_hi + TILE_B;
+        s16x8_t fa[2][4], fb[2][4], fal[2][4], fbl[2][4];
+        auto fetch = [&](int ks, int set) {
+            const int r0 = (ks * 32 + kpl) * 256, r1 = r0 + 16 * 256;
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const s16x4_t v0 = tr_read(D_hi + r0 + d_off[f]), v1 = tr_read(D_hi + r1 + d_off[f]);
+                fa[set][f] = (s16x8_t){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                const s16x4_t w0 = tr_read(A_hi + r0 + a_off[f]), w1 = tr_read(A_hi + r1 + a_off[f]);
+                fb[set][f] = (s16x8_t){w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
+                if (SPLIT) {
+                    const s16x4_t x0 = tr_read(D_hi + 2 * TILE_B + r0 + d_off[f]), x1 = tr_read(D_hi + 2 * TILE_B + r1 + d_off[f]);
+                    fal[set][f] = (s16x8_t){x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+                    const s16x4_t y0 = tr_read(A_hi + 2 * TILE_B + r0 + a_off[f]), y1 = tr_read(A_hi + 2 * TILE_B + r1 + a_off[f]);
+                    fbl[set][f] = (s16x8_t){y0[0], y0[1], y0[2], y0[3], y1[0], y1[1], y1[2], y1[3]};
+                }
+            }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < KP / 32; ++ks) {
+            const int cur = ks & 1;
+            if (ks + 1 < KP / 32) fetch(ks + 1, cur ^ 1);
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+                for (int nf = 0; nf < 4; ++nf) {
+                    if (SPLIT) {
+                        acc[mf][nf] = mfma16(fal[cur][mf], fb[cur][nf], acc[mf][nf]);
+                        acc[mf][nf] = mfma16(fa[cur][mf], fbl[cur][nf], acc[mf][nf]);
+                    }
+                    acc[mf][nf] = mfma16t<F16>(fa[cur][mf], fb[cur][nf], acc[mf][nf]);
+                }
+        }
+    };
+
+    if (s_beg < s_end) issue(s_beg, 0);
+    for (int s = s_beg; s < s_end; ++s) {
+        const int buf = (s - s_beg) & 1;
+        lp_wait_vm0();
+        __syncthreads();                    // stage s has landed for every wave; everyone is done with the other buffer
+        if (s + 1 < s_end) issue(s + 1, buf ^ 1);
+        compute(buf);
+    }
+    // C layout of the 16x16 MFMA: row (co) = (lane >> 4) * 4 + r, column (ci) = lane & 15
+    float* slab = p.part + (size_t)split * p.CoP * p.CiP;
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + mh * 64 + mf * 16 + (lane >> 4) * 4 + r;
+                const int ci = ci0 + nh * 64 + nf * 16 + (lane & 15);
+                if (co < p.CoP && ci < p.CiP) slab[(size_t)co * p.CiP + ci] = acc[mf][nf][r];
+            }
+}
+
+static int launch_wreduce(const WgradParams& p, int T, float* dw, float* dbias, const float* out_scale, const float* sn_w, float* sn_dot,
+                          hipStream_t stream) {
+    const int bblocks = p.bpart ? (p.Cout + 63) / 64 : 0;
+    const int wblocks = wred_blocks(p.Cin, p.Cout, T);
+    if (wred_tiled(p.Cin, p.Cout))
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wblocks + bblocks), dim3(256), 0, stream, p.part, dw, p.splits, T, p.Cout, p.Cin, p.CoP, p.CiP,
+                           p.bpart, dbias, wblocks, out_scale, sn_w, sn_dot, p.db_acc);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3(wblocks + bblocks), dim3(256), 0, stream, p.part, dw, p.splits, T, p.Cout, p.Cin, p.CoP,
+                           p.CiP, p.bpart, dbias, wblocks, out_scale, sn_w, sn_dot, p.db_acc);
+    return lp_check_launch("wgrad_reduce");
+}
+
+template <int PREC>
+static int launch_wgrad1x1(WgradParams& p, float* dw, const float* out_scale, const float* sn_w, float* sn_dot, hipStream_t stream) {
+    constexpr bool SPLIT = (PREC == LP_PREC_BF16X3);
+    W1Params q;
+    q.a_hi = p.a_hi; q.a_lo = p.a_lo; q.d_hi = p.d_hi; q.d_lo = p.d_lo; q.part = p.part;
+    q.P = (long long)p.N * p.H * p.W;
+    q.C8 = p.C8; q.Co8 = p.Co8; q.CoP = p.CoP; q.CiP = p.CiP;
+    q.tiles_co = (p.CoP + 127) / 128; q.tiles_ci = (p.CiP + 127) / 128;
+    q.nstage = (int)((q.P + 63) / 64);
+    int splits = p.splits < q.nstage ? p.splits : q.nstage;
+    const int per = (q.nstage + splits - 1) / splits;
+    splits = (q.nstage + per - 1) / per;                   // no empty split: every slab the reduction sums is written
+    p.splits = q.splits = splits;
+    q.xcd_map = (splits % 8 == 0);
+    const size_t lds = (size_t)2 * 64 * 256 * (SPLIT ? 4 : 2);
+    auto kern = wgrad1x1_kernel<PREC>;
+    static thread_local int attr_dev = -1;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return lp_set_error(LP_ERR_HIP, "hipGetDevice failed");
+    if (attr_dev != dev) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return lp_set_error(LP_ERR_HIP, "hipFuncSetAttribute failed");
+        attr_dev = dev;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(q.tiles_co * q.tiles_ci * splits)), dim3(256), lds, stream, q);
+    int rc = lp_check_launch("wgrad1x1");
+    if (rc) return rc;
+    return launch_wreduce(p, 1, dw, nullptr, out_scale, sn_w, sn_dot, stream);
+}
+
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 extern "C" int lp_conv_wgrad_dot_blocks(int Cin, int Cout, int ksize) { return wred_blocks(Cin, Cout, ksize * ksize); }
@@ -486,6 +676,8 @@ static int dispatch_wgrad(WgradParams& p, float* dw, float* dbias, const float* 
     const bool cob128 = cob_env ? (cob_env == 128) : true;      // measured: -9 % (bf16x3), -6 % (bf16) on the 64..512-channel layers
     if (cob128 && p.Cout >= 128 && ksize == 3)
         return upsample ? launch_wgrad<3, true, PREC, 128>(p, dw, dbias, out_scale, sn_w, sn_dot, s) : launch_wgrad<3, false, PREC, 128>(p, dw, dbias, out_scale, sn_w, sn_dot, s);
+    static const bool w1_old = getenv("LP_WGRAD1X1_OLD") != nullptr;                              // A/B knob: the generic kernel for 1x1 layers
+    if (ksize == 1 && !upsample && !p.bpart && !w1_old) return launch_wgrad1x1<PREC>(p, dw, out_scale, sn_w, sn_dot, s);
     static const int cob1_env = getenv("LP_WGRAD_COB1") ? atoi(getenv("LP_WGRAD_COB1")) : 0;        // 1x1 layers: 64 | 128 forces
     if ((cob1_env ? cob1_env == 128 : true) && p.Cout >= 128 && ksize == 1 && !upsample)
         return launch_wgrad<1, false, PREC, 128>(p, dw, dbias, out_scale, sn_w, sn_dot, s);

@@ -341,11 +341,16 @@ def conv(x: Tensor, pack: WeightPack, *, ksize: int, upsample: bool = False, pro
     return conv16(a, pack, ksize=ksize, upsample=upsample, bias=bias, res=res, res_shift=res_shift, alpha=alpha, prec=prec, relu_mask=m16)
 
 
-def default_splits(n, h, w, cin, cout, ksize=3):
+def default_splits(n, h, w, cin, cout, ksize=3, prec=None, bias=False):
     """pixel-range splits of the weight-gradient launch.  3x3: ~2 workgroups per CU in total (9 taps of MFMA work per staged tile).
-    1x1: a staged 128-pixel tile feeds ONE tap, so the per-tile load -> LDS -> MFMA latency (~4 us) is exposed unless several
-    workgroups share a CU: ~4 per CU, every workgroup still walking >= 4 tiles (the embedder's 1024 x 2048 layers ran 1 workgroup per
-    CU over 32 tiles: 125 us for 17 GFLOP)."""
+    1x1 without a bias gradient (wgrad1x1_kernel: 128 x 128 weight tiles, 64-pixel stages): one resident set of workgroups -- 2 per CU
+    (64 KB of LDS each; 1 per CU for bf16x3's doubled planes) -- each walking >= 8 stages, a multiple of 8 so that the tiles of one
+    pixel range share an XCD.  1x1 with a bias gradient (conv_wgrad_kernel): ~4 workgroups per CU, >= 4 128-pixel tiles each."""
+    if ksize == 1 and not bias and os.environ.get('LP_WGRAD1X1_OLD') is None:
+        stages = (n * h * w + 63) // 64
+        blocks = (_round_up(cout, 64) + 127) // 128 * ((_round_up(cin, 64) + 127) // 128)
+        s = max(1, min((256 if prec == PREC_BF16X3 else 512) // blocks, stages // 8))
+        return s // 8 * 8 if s >= 8 else s
     tiles = (n * h * w + 127) // 128
     if ksize == 1:
         blocks = (_round_up(cout, 128) // 128 if cout >= 128 else 1) * (_round_up(cin, 64) // 64)
@@ -367,7 +372,7 @@ def conv_wgrad16(a: Act16, dy: Act16, *, ksize: int, upsample: bool = False, pre
     assert a.nhw == ((n, h // 2, w // 2) if upsample else (n, h, w)), (a.hi.shape, dy.hi.shape, upsample)
     dev = dy.hi.device
     if splits is None:
-        splits = default_splits(n, h, w, cin, cout, ksize)
+        splits = default_splits(n, h, w, cin, cout, ksize, prec, bias_grad)
     ws = torch.empty(_lib.lib().lp_conv_wgrad_workspace_bytes(cin, cout, ksize, splits) // 4, dtype=torch.float32, device=dev)
     dw = torch.empty((cout, cin, ksize, ksize), dtype=torch.float32, device=dev)
     db = None

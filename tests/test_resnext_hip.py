@@ -279,6 +279,32 @@ def test_bn_relu_pack_and_flat_1x1_contraction(prec):
     report('flat 1x1 wgrad', rel(dw, emu_ops.conv_wgrad16(ra, e16(dy.double()), ksize=1)), TOL[prec])
 
 
+@pytest.mark.parametrize('prec', [0, 1, 2])
+@pytest.mark.parametrize('p_cin_cout_splits', [(148, 24, 144, None), (4096, 64, 256, 8), (4096, 64, 256, 5), (2048, 320, 1280, 16),
+                                              (1024, 2048, 1024, 2), (8192, 128, 128, 64), (60, 16, 8, 1)])
+def test_pointwise_weight_gradient_kernel(prec, p_cin_cout_splits):
+    """wgrad1x1_kernel (LDS-DMA staged 128 x 128 tiles, swizzled rows, XCD-ordered split-K) against the fp64 contraction of the SAME
+    operand planes: only the fp32 accumulation order differs, so the gate is 1e-5 in every precision mode.  Ragged channel counts
+    (MobileNetV2's 24 / 144 / 320 / 1280), pixel counts that are not a multiple of the 64-pixel stage, split counts with and without
+    the XCD mapping (multiples of 8), more splits than stages."""
+    ops = _ops()
+    pix, cin, cout, splits = p_cin_cout_splits
+    g = torch.Generator().manual_seed(pix + cin)
+    fh, fw = ops.flat_hw(pix)
+    x = torch.randn(1, fh, fw, cin, generator=g).cuda()
+    dy = (torch.randn(1, fh, fw, cout, generator=g) * 1e-3).cuda()
+    a = ops.act_pack(x, pro=2, prec=prec)
+    d = ops.act_pack(dy, prec=prec, grad=True)
+    dw = ops.conv_wgrad16(a, d, ksize=1, prec=prec, splits=splits)
+    if prec == 1:       # bf16x3 multiplies hi*hi + hi*lo + lo*hi (the lo*lo term, 2^-16 relative, is dropped by design)
+        pl = lambda t, c: t.view(torch.bfloat16).double().reshape(pix, -1)[:, :c]
+        dh, dl, ah, al = pl(d.hi, cout), pl(d.lo, cout), pl(a.hi, cin), pl(a.lo, cin)
+        ref = dh.t() @ ah + dh.t() @ al + dl.t() @ ah
+    else:
+        ref = decode(d, prec).reshape(pix, cout).t() @ decode(a, prec).reshape(pix, cin)
+    report(f'wgrad1x1 P={pix} {cin}->{cout} splits={splits}', rel(dw.view(cout, cin), ref), 1e-5)
+
+
 def _nets(num_classes, seed, layers=(3, 4, 6, 3)):
     from embedders.backbones import ResNeXt
     torch.manual_seed(seed)
