@@ -301,16 +301,14 @@ void conv_dma_kernel(Conv16Params p) {
     if ((p.Cout & 3) == 0) {
         // Coalesced path: every wave transposes its (MR*16) x (NR*16) accumulator block through LDS (the staging buffers are dead
         // now) and writes whole pixel rows -- NR*64 contiguous bytes per pixel, 16 B per lane; bias, residual, mask likewise.
+        // 1x1 layers transpose 16 rows (one MFMA row block) at a time: their stage buffers are small, and the full-block scratch
+        // (17 KB per wave) was what limited a CU to two workgroups (+10..20 % on the K <= 256 pointwise layers); the 3x3 kernels keep
+        // the whole block in one piece (their stage buffers are larger than the scratch, and one long run of independent LDS reads
+        // and stores measured ~1.5 % faster per step than four short ones) -- profiles/r03_conv_epilogue_lds.txt.
         constexpr int WR = MR * 16, WC = NR * 16, LDW = WC + 4;
+        constexpr int MRP = (KS == 1) ? 1 : MR;                           // MFMA row blocks per transposed piece
         __syncthreads();                                                  // all waves are done with the halo / weight buffers
-        float* tile = (float*)smem + wave_d * (WR * LDW);
-#pragma unroll
-        for (int mr = 0; mr < MR; ++mr)
-#pragma unroll
-            for (int nr = 0; nr < NR; ++nr)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    tile[(mr * 16 + (lane >> 4) * 4 + r) * LDW + nr * 16 + (lane & 15)] = acc[mr][nr][r];
+        float* tile = (float*)smem + wave_d * (MRP * 16 * LDW);
         constexpr int C4 = WC / 4;                 // float4 columns per row
         constexpr int RPP = 64 / C4;               // rows per pass of the wave
         const int c4 = lane % C4, rsub = lane / C4;
@@ -319,15 +317,25 @@ void conv_dma_kernel(Conv16Params p) {
         if (p.bias && co < p.Cout) bv = *(const float4*)(p.bias + co);
         float am = 0.f;
         float st_n = 0.f, st_ref[4] = {0.f, 0.f, 0.f, 0.f}, st_d[4] = {0.f, 0.f, 0.f, 0.f}, st_q[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mp = 0; mp < MR; mp += MRP) {
+#pragma unroll
+            for (int mr = mp; mr < mp + MRP; ++mr)
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        tile[((mr - mp) * 16 + (lane >> 4) * 4 + r) * LDW + nr * 16 + (lane & 15)] = acc[mr][nr][r];
+            // (the wave reads back what its own lanes wrote: LDS operations of one wave execute in order)
 #pragma unroll 4
-        for (int r0 = 0; r0 < WR; r0 += RPP) {
+        for (int r0 = mp * 16; r0 < (mp + MRP) * 16; r0 += RPP) {
             const int row = r0 + rsub;
             const int m = wm * WR + row;
             int nb, py, px;
             tile_row_linear(m, p.lTH, p.lTW, nb, py, px);
             const int n = n0 + nb, oyy = y0 + py, oxx = x0 + px;
             if (nb < NBv && n < p.N && oyy < p.H && oxx < p.W && co < p.Cout) {
-                float4 v = *(const float4*)(tile + row * LDW + c4 * 4);
+                float4 v = *(const float4*)(tile + (row - mp * 16) * LDW + c4 * 4);
                 if (p.ksplit > 1) {        // split-K: the raw partial tile; splitk_reduce_kernel sums the slices and applies the epilogue
                     const size_t pixs = (size_t)(n * p.H + oyy) * p.W + oxx;
                     *(float4*)(p.part + ((size_t)blockIdx.z * p.N * p.H * p.W + pixs) * p.Cout + co) = v;
@@ -368,6 +376,7 @@ void conv_dma_kernel(Conv16Params p) {
                     if (SPLIT) *(ushort4*)(p.o_lo + pix * p.Co8 + co) = ol;
                 }
             }
+        }
         }
         if (p.amax && p.ksplit == 1) lp_amax_commit(am, p.amax, blockIdx.x + blockIdx.y * 7u);
         if (p.stats && p.ksplit == 1) {
@@ -551,7 +560,7 @@ static int launch_conv16(Conv16Params& p, hipStream_t stream) {
     p.a_dbuf = (2 * a_buf + 2 * B_BUF <= LDS_MAX) ? 1 : 0;
     const size_t lds_halo = (p.a_dbuf ? 2 : 1) * a_buf;
     size_t lds = lds_halo + 2 * B_BUF;
-    size_t epi = (size_t)NWAVE * (MR * 16) * (NR * 16 + 4) * sizeof(float);       // LDS transpose of the coalesced epilogue
+    size_t epi = (size_t)NWAVE * ((KS == 1) ? 16 : MR * 16) * (NR * 16 + 4) * sizeof(float);      // LDS transpose of the coalesced epilogue (1x1: 16 rows per wave at a time)
     const int tiles = p.tiles_x * p.tiles_y * ((p.N + NBv - 1) / NBv);
     // ping-pong: two adjacent M tiles per workgroup, when the paired grid still covers the CUs.  LP_CONV_PP = 0 | 1 overrides.
     constexpr bool pp_ok = (KS == 3) && (NWAVE == 4);
