@@ -256,6 +256,11 @@ int lp_gconv16_fwd(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* w
 int lp_gconv16_fwd_stats(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* w_hi, const uint16_t* w_lo, float* y, const float* alpha2,
                          int N, int H, int W, int C, int CP, int prec, float* amax_slots, float* stats, long long stats_capacity_floats,
                          int* stats_rows, void* stream);
+/*   lp_gconv16_fwd_planes: as lp_gconv16_fwd_stats with y (fp32) OPTIONAL and the operand planes of y (o_hi [, o_lo]) as a second, optional
+ *                     output: the fp16 mode keeps the embedder's conv outputs 16-bit resident ("y16": the unscaled fp16 plane, no fp32 y) */
+int lp_gconv16_fwd_planes(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* w_hi, const uint16_t* w_lo, float* y, uint16_t* o_hi,
+                          uint16_t* o_lo, const float* alpha2, int N, int H, int W, int C, int CP, int prec, float* amax_slots, float* stats,
+                          long long stats_capacity_floats, int* stats_rows, void* stream);
 long long lp_gconv_wgrad_workspace_bytes(int C, int splits);
 int lp_gconv16_wgrad(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* dy_hi, const uint16_t* dy_lo, float* dw, float* workspace,
                      int N, int H, int W, int C, int group_size, int splits, int prec, const float* out_scale, void* stream);
@@ -267,6 +272,13 @@ int lp_bn_relu_maxpool_fwd(const float* y, const float* scale, const float* shif
 int lp_maxpool_bwd(const float* dout, const unsigned char* idx, float* dA, int N, int H, int W, int C, void* stream);
 int lp_bn_add_act(const float* y, const float* scale, const float* shift, const float* res, const float* res_scale, const float* res_shift,
                   float* out, uint16_t* hi, uint16_t* lo, long long P, int C, int relu, int prec, void* stream);
+/*   16-bit-resident conv outputs (fp16 mode; y16 = the fp16 plane [P][C] a conv epilogue wrote instead of fp32 y, C % 8 == 0):
+ *   lp_bn_add_act16:  lp_bn_add_act reading y16 (out fp32 + its fp16 operand plane hi|NULL)
+ *   lp_bn_act16:      out_hi = fp16((relu?)(y16*scale[c]+shift[c])): the BatchNorm (+ ReLU) prologue of the next conv (lp_act_pack pro 4 / 5
+ *                     reading 2 B per element) */
+int lp_bn_add_act16(const uint16_t* y16, const float* scale, const float* shift, const float* res, const float* res_scale,
+                    const float* res_shift, float* out, uint16_t* hi, long long P, int C, int relu, void* stream);
+int lp_bn_act16(const uint16_t* y16, const float* scale, const float* shift, uint16_t* out_hi, long long P, int C, int relu, void* stream);
 int lp_subsample2(const void* in, void* out, int N, int H, int W, int row_bytes, void* stream);
 int lp_zero_stuff2(const void* in, void* out, int N, int H, int W, int row_bytes, void* stream);
 int lp_add_strided2(float* d, const float* s, int N, int H, int W, int C, void* stream);
@@ -279,6 +291,12 @@ long long lp_bn_bwd16_workspace_bytes(long long P, int C);
 int lp_bn_bwd16(const float* dA, const float* x, const float* mask_src, const float* gamma, const float* mean, const float* rstd,
                 const float* scale, const float* shift, uint16_t* out_hi, uint16_t* out_lo, float* out_scale, float* dgamma, float* dbeta,
                 float* workspace, long long P, int C, int mask_mode, float act_hi, int frozen_stats, int prec, float* g_out, void* stream);
+/*   lp_bn_bwd16_h:    lp_bn_bwd16 with x given as fp32 (x16 = NULL) or as y16 (x = NULL; fp16 mode) and one more mask mode:
+ *                     3: mask_src = a 16-bit operand plane [P][C] whose elements are > 0 (the block output's planes instead of its fp32 copy) */
+int lp_bn_bwd16_h(const float* dA, const float* x, const uint16_t* x16, const void* mask_src, const float* gamma, const float* mean,
+                  const float* rstd, const float* scale, const float* shift, uint16_t* out_hi, uint16_t* out_lo, float* out_scale,
+                  float* dgamma, float* dbeta, float* workspace, long long P, int C, int mask_mode, float act_hi, int frozen_stats, int prec,
+                  float* g_out, void* stream);
 int lp_spatial_mean_fwd(const float* x, float* out, int N, int HW, int C, void* stream);
 int lp_spatial_mean_bwd(const float* g, float* dx, int N, int HW, int C, void* stream);
 

@@ -36,6 +36,7 @@ SIGNATURES = {
     'lp_conv16_stats_floats': (_ll, [_i] * 4),
     'lp_norm_stats_finalize': (_i, [_vp, _i, _vp, _vp, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     'lp_gconv16_fwd_stats': (_i, [_vp] * 6 + [_i] * 6 + [_vp, _vp, _ll, _vp, _vp]),
+    'lp_gconv16_fwd_planes': (_i, [_vp] * 8 + [_i] * 6 + [_vp, _vp, _ll, _vp, _vp]),
     'lp_conv_wgrad_workspace_bytes': (_ll, [_i, _i, _i, _i]),
     'lp_conv16_wgrad': (_i, [_vp] * 6 + [_i] * 9 + [_vp, _i, _vp, _vp, _vp, _vp]),
     'lp_conv_wgrad_dot_blocks': (_i, [_i] * 3),
@@ -76,11 +77,14 @@ SIGNATURES = {
     'lp_bn_relu_maxpool_fwd': (_i, [_vp] * 7 + [_i] * 5 + [_vp]),
     'lp_maxpool_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'lp_bn_add_act': (_i, [_vp] * 9 + [_ll, _i, _i, _i, _vp]),
+    'lp_bn_add_act16': (_i, [_vp] * 8 + [_ll, _i, _i, _vp]),
+    'lp_bn_act16': (_i, [_vp] * 4 + [_ll, _i, _i, _vp]),
     'lp_subsample2': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'lp_zero_stuff2': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'lp_add_strided2': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'lp_bn_bwd16_workspace_bytes': (_ll, [_ll, _i]),
     'lp_bn_bwd16': (_i, [_vp] * 14 + [_ll, _i, _i, _f, _i, _i, _vp, _vp]),
+    'lp_bn_bwd16_h': (_i, [_vp] * 15 + [_ll, _i, _i, _f, _i, _i, _vp, _vp]),
     'lp_spatial_mean_fwd': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'lp_spatial_mean_bwd': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'lp_dwconv3x3_dgrad': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

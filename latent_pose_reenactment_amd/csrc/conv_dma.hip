@@ -738,15 +738,25 @@ extern "C" int lp_gconv16_fwd(const uint16_t* a_hi, const uint16_t* a_lo, const 
 extern "C" int lp_gconv16_fwd_stats(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* w_hi, const uint16_t* w_lo, float* y,
                                     const float* alpha2, int N, int H, int W, int C, int CP, int prec, float* amax_slots,
                                     float* stats, long long stats_capacity_floats, int* stats_rows, void* stream) {
+    if (!y) return lp_set_error(LP_ERR_ARG, "lp_gconv16_fwd: null pointer");
+    return lp_gconv16_fwd_planes(a_hi, a_lo, w_hi, w_lo, y, nullptr, nullptr, alpha2, N, H, W, C, CP, prec, amax_slots, stats,
+                                 stats_capacity_floats, stats_rows, stream);
+}
+
+// y (fp32, |NULL) and / or the operand planes of y (o_hi [, o_lo], |NULL): the fp16 mode keeps the embedder's conv outputs 16-bit resident
+extern "C" int lp_gconv16_fwd_planes(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* w_hi, const uint16_t* w_lo, float* y,
+                                     uint16_t* o_hi, uint16_t* o_lo, const float* alpha2, int N, int H, int W, int C, int CP, int prec,
+                                     float* amax_slots, float* stats, long long stats_capacity_floats, int* stats_rows, void* stream) {
     if (stats_rows) *stats_rows = 0;
     if (stats && !stats_rows) return lp_set_error(LP_ERR_ARG, "lp_gconv16_fwd: stats needs stats_rows");
-    if (!a_hi || !w_hi || !y) return lp_set_error(LP_ERR_ARG, "lp_gconv16_fwd: null pointer");
+    if (!a_hi || !w_hi || (!y && !o_hi)) return lp_set_error(LP_ERR_ARG, "lp_gconv16_fwd: null pointer");
+    if (o_hi && prec == LP_PREC_BF16X3 && !o_lo) return lp_set_error(LP_ERR_ARG, "lp_gconv16_fwd: bf16x3 output planes need lo");
     if (prec == LP_PREC_BF16X3 && (!w_lo || !a_lo)) return lp_set_error(LP_ERR_ARG, "lp_gconv16_fwd: bf16x3 needs the lo planes");
     if ((C & 63) || CP % 128 || CP < C) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_gconv16_fwd: C must be a multiple of 64, CP of 128");
     if (H < 2 || W < 2) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_gconv16_fwd: H,W must be >= 2");
     Conv16Params p;
     p.a_hi = a_hi; p.a_lo = a_lo; p.w_hi = w_hi; p.w_lo = w_lo; p.y = y; p.bias = nullptr; p.res = nullptr; p.alpha = nullptr; p.alpha2 = alpha2;
-    p.mask16 = nullptr; p.o_relu = 0; p.part = nullptr; p.part_bytes = 0; p.amax = amax_slots; p.o_hi = nullptr; p.o_lo = nullptr;
+    p.mask16 = nullptr; p.o_relu = 0; p.part = nullptr; p.part_bytes = 0; p.amax = amax_slots; p.o_hi = o_hi; p.o_lo = o_lo;
     p.N = N; p.H = H; p.W = W; p.Hin = H; p.Win = W;
     p.Cin = C; p.C8 = C; p.Cout = C; p.Co8 = C; p.CinP = 64; p.CoutP = CP; p.res_shift = 0; p.grouped = 1;
     p.stats = stats; p.stats_cap = stats ? stats_capacity_floats : 0; p.stats_rows = 0;

@@ -31,6 +31,25 @@ __device__ __forceinline__ void store_op8(const float (&v)[8], uint16_t* hi, uin
     if (SPLIT) *(s16x8_t*)(lo + off8) = l;
 }
 
+// 8 consecutive channels of a tensor that lives either as fp32 or -- the fp16 mode's 16-bit-resident conv outputs ("y16": the unscaled
+// fp16 plane the conv epilogue wrote instead of fp32 y) -- as one fp16 operand plane
+template <bool H16> __device__ __forceinline__ void load8(const void* base, size_t off, float (&v)[8]) {
+    if (H16) {
+        const s16x8_t q = *(const s16x8_t*)((const uint16_t*)base + off);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = lp_op16_to_f32<true>((uint16_t)q[j]);
+    } else {
+        const float4 a = *(const float4*)((const float*)base + off), b = *(const float4*)((const float*)base + off + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+}
+// ReLU pattern of 8 channels from a 16-bit plane: > 0  <=>  sign clear and magnitude non-zero
+__device__ __forceinline__ void mask8_16(const uint16_t* plane, size_t off, float (&g)[8]) {
+    const s16x8_t q = *(const s16x8_t*)(plane + off);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = ((unsigned)((uint16_t)q[j]) - 1u) < 0x7fffu ? g[j] : 0.f;
+}
+
 // ---- im2col rows as operand planes -----------------------------------------------------------------------------------------------
 // x [N][C][H][W] fp32 (NCHW, what the dataloader delivers) -> rows [N*Ho*Wo][K8], K = C*KS*KS, k = (c*KS + ky)*KS + kx (the order of
 // nn.Conv2d's weight.view(Cout, -1)), zero padding, pad columns zero.  One thread per (pixel, 8 consecutive k): the row of a pixel is
@@ -195,8 +214,8 @@ extern "C" int lp_maxpool_bwd(const float* dout, const unsigned char* idx, float
 }
 
 // ---- block output: out = act( y*scale[c]+shift[c] + r ),  r = res | res*rscale[c]+rshift[c] | 0;  act = ReLU | identity -------------
-template <int PREC>
-__global__ __launch_bounds__(256) void bn_add_act_kernel(const float* __restrict__ y, const float* __restrict__ sc, const float* __restrict__ sh,
+template <int PREC, bool Y16>
+__global__ __launch_bounds__(256) void bn_add_act_kernel(const void* __restrict__ y, const float* __restrict__ sc, const float* __restrict__ sh,
                                                          const float* __restrict__ res, const float* __restrict__ rsc, const float* __restrict__ rsh,
                                                          float* __restrict__ out, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo,
                                                          long long items, int C, int relu) {
@@ -205,8 +224,8 @@ __global__ __launch_bounds__(256) void bn_add_act_kernel(const float* __restrict
     const float floor_v = relu ? 0.f : -3.0e38f;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < items; i += (long long)gridDim.x * 256) {
         const int c = (int)(i % G) * 8;
-        const float4 p0 = *(const float4*)(y + i * 8), p1 = *(const float4*)(y + i * 8 + 4);
-        float v[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+        float v[8];
+        load8<Y16>(y, (size_t)i * 8, v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], sc[c + j], sh[c + j]);
         if (res) {
@@ -227,23 +246,65 @@ __global__ __launch_bounds__(256) void bn_add_act_kernel(const float* __restrict
     }
 }
 
-extern "C" int lp_bn_add_act(const float* y, const float* scale, const float* shift, const float* res, const float* res_scale,
-                             const float* res_shift, float* out, uint16_t* hi, uint16_t* lo, long long P, int C, int relu, int prec,
-                             void* stream) {
-    if (!y || !scale || !shift || !out) return lp_set_error(LP_ERR_ARG, "lp_bn_add_act: null pointer");
+static int bn_add_act_impl(const float* y, const uint16_t* y16, const float* scale, const float* shift, const float* res, const float* res_scale,
+                           const float* res_shift, float* out, uint16_t* hi, uint16_t* lo, long long P, int C, int relu, int prec, hipStream_t st) {
+    if ((!y && !y16) || !scale || !shift || !out) return lp_set_error(LP_ERR_ARG, "lp_bn_add_act: null pointer");
     if (!res_scale != !res_shift || (res_scale && !res)) return lp_set_error(LP_ERR_ARG, "lp_bn_add_act: res_scale/res_shift go together and need res");
     if (C & 7) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_bn_add_act: C must be a multiple of 8");
     if (hi && prec == LP_PREC_BF16X3 && !lo) return lp_set_error(LP_ERR_ARG, "lp_bn_add_act: bf16x3 planes need lo");
+    if (y16 && prec != LP_PREC_F16) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_bn_add_act16: 16-bit y exists in the fp16 mode only");
     const long long items = P * (C >> 3);
     if (items == 0) return LP_OK;
-    hipStream_t st = (hipStream_t)stream;
-#define LP_BA(Q) hipLaunchKernelGGL(bn_add_act_kernel<Q>, dim3(grid_for(items)), dim3(256), 0, st, y, scale, shift, res, res_scale, res_shift, out, hi, lo, items, C, relu)
-    if (prec == LP_PREC_BF16) LP_BA(LP_PREC_BF16);
-    else if (prec == LP_PREC_BF16X3) LP_BA(LP_PREC_BF16X3);
-    else if (prec == LP_PREC_F16) LP_BA(LP_PREC_F16);
+#define LP_BA(Q, H, SRC) hipLaunchKernelGGL((bn_add_act_kernel<Q, H>), dim3(grid_for(items)), dim3(256), 0, st, (const void*)(SRC), scale, shift, res, res_scale, res_shift, out, hi, lo, items, C, relu)
+    if (y16) LP_BA(LP_PREC_F16, true, y16);
+    else if (prec == LP_PREC_BF16) LP_BA(LP_PREC_BF16, false, y);
+    else if (prec == LP_PREC_BF16X3) LP_BA(LP_PREC_BF16X3, false, y);
+    else if (prec == LP_PREC_F16) LP_BA(LP_PREC_F16, false, y);
     else return lp_set_error(LP_ERR_ARG, "lp_bn_add_act: unknown precision mode");
 #undef LP_BA
     return lp_check_launch("bn_add_act");
+}
+
+extern "C" int lp_bn_add_act(const float* y, const float* scale, const float* shift, const float* res, const float* res_scale,
+                             const float* res_shift, float* out, uint16_t* hi, uint16_t* lo, long long P, int C, int relu, int prec,
+                             void* stream) {
+    if (!y) return lp_set_error(LP_ERR_ARG, "lp_bn_add_act: null pointer");
+    return bn_add_act_impl(y, nullptr, scale, shift, res, res_scale, res_shift, out, hi, lo, P, C, relu, prec, (hipStream_t)stream);
+}
+
+// y as the fp16 plane a conv epilogue wrote instead of fp32 (fp16 mode)
+extern "C" int lp_bn_add_act16(const uint16_t* y16, const float* scale, const float* shift, const float* res, const float* res_scale,
+                               const float* res_shift, float* out, uint16_t* hi, long long P, int C, int relu, void* stream) {
+    if (!y16) return lp_set_error(LP_ERR_ARG, "lp_bn_add_act16: null pointer");
+    return bn_add_act_impl(nullptr, y16, scale, shift, res, res_scale, res_shift, out, hi, nullptr, P, C, relu, LP_PREC_F16, (hipStream_t)stream);
+}
+
+// ---- BatchNorm affine (+ ReLU) of a 16-bit-resident conv output, to the operand planes of the next conv (fp16 mode) ----------------
+// a[p][c] = fp16( relu?( y16[p][c] * scale[c] + shift[c] ) ): lp_act_pack's prologues 4 / 5 reading 2 B instead of 4 B per element
+__global__ __launch_bounds__(256) void bn_act16_kernel(const uint16_t* __restrict__ y, const float* __restrict__ sc, const float* __restrict__ sh,
+                                                       uint16_t* __restrict__ out, long long items, int C, int relu) {
+    const int G = C >> 3;
+    const float floor_v = relu ? 0.f : -3.0e38f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < items; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % G) * 8;
+        float v[8];
+        load8<true>(y, (size_t)i * 8, v);
+        const float4 s0 = *(const float4*)(sc + c), s1 = *(const float4*)(sc + c + 4), h0 = *(const float4*)(sh + c), h1 = *(const float4*)(sh + c + 4);
+        const float a8[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, b8[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaxf(fmaf(v[j], a8[j], b8[j]), floor_v);
+        store_op8<true, false>(v, out, nullptr, (size_t)i * 8);
+    }
+}
+
+extern "C" int lp_bn_act16(const uint16_t* y16, const float* scale, const float* shift, uint16_t* out_hi, long long P, int C, int relu,
+                           void* stream) {
+    if (!y16 || !scale || !shift || !out_hi) return lp_set_error(LP_ERR_ARG, "lp_bn_act16: null pointer");
+    if (C & 7) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_bn_act16: C must be a multiple of 8");
+    const long long items = P * (C >> 3);
+    if (items == 0) return LP_OK;
+    hipLaunchKernelGGL(bn_act16_kernel, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, y16, scale, shift, out_hi, items, C, relu);
+    return lp_check_launch("bn_act16");
 }
 
 // ---- stride-2 plumbing on [N][H][W][row of `units` 16-byte pieces] tensors (fp32 NHWC: units = C/4; operand planes: units = C8/8) ----
@@ -393,8 +454,10 @@ extern "C" int lp_pack_grouped(const float* w, uint16_t* hi, uint16_t* lo, int C
 //                      bound into [2^12, 2^13): the true amax is at most the bound, so the scaled planes cannot overflow)
 //   pass 3 (apply):    recomputes g from dA and the mask, writes dy * s as operand planes (hi [, lo]); block 0 publishes {s, 1/s}
 // 8 B read in pass 1 and 8 B read + 2 B written in pass 3 per element (fp16 mode), against 30 B for partial + apply + lp_act_pack on fp32 dy.
-// mask modes as lp_norm_act_bwd: 0 own activation 0 < x*scale+shift < act_hi, 1 none, 2 mask_src > 0.
-__global__ __launch_bounds__(256) void bn_bwd16_partial_kernel(const float* __restrict__ dA, const float* __restrict__ x, const float* __restrict__ mask_src,
+// mask modes as lp_norm_act_bwd: 0 own activation 0 < x*scale+shift < act_hi, 1 none, 2 mask_src > 0; 3: a 16-bit operand plane > 0.
+// X16: x is the fp16 plane of a 16-bit-resident conv output (6 B read per element and pass instead of 8 B).
+template <bool X16>
+__global__ __launch_bounds__(256) void bn_bwd16_partial_kernel(const float* __restrict__ dA, const void* __restrict__ x, const void* __restrict__ mask_src,
                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                const float* __restrict__ scale, const float* __restrict__ shift,
                                                                float* __restrict__ part, long long P, int C, int mask_mode, float act_hi, int PB) {
@@ -410,13 +473,25 @@ __global__ __launch_bounds__(256) void bn_bwd16_partial_kernel(const float* __re
         const float m4[4] = {mu.x, mu.y, mu.z, mu.w}, r4[4] = {rs.x, rs.y, rs.z, rs.w}, a4[4] = {sc.x, sc.y, sc.z, sc.w}, b4[4] = {sf.x, sf.y, sf.z, sf.w};
 #pragma unroll 4
         for (long long pix = p0 + pl; pix < p1; pix += 16) {
-            const float4 xv = *(const float4*)(x + pix * C + c), gv = *(const float4*)(dA + pix * C + c);
-            float xs[4] = {xv.x, xv.y, xv.z, xv.w}, g[4] = {gv.x, gv.y, gv.z, gv.w};
+            const float4 gv = *(const float4*)(dA + pix * C + c);
+            float xs[4], g[4] = {gv.x, gv.y, gv.z, gv.w};
+            if (X16) {
+                const s16x4_t q = *(const s16x4_t*)((const uint16_t*)x + pix * C + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xs[j] = lp_op16_to_f32<true>((uint16_t)q[j]);
+            } else {
+                const float4 xv = *(const float4*)((const float*)x + pix * C + c);
+                xs[0] = xv.x; xs[1] = xv.y; xs[2] = xv.z; xs[3] = xv.w;
+            }
             if (mask_mode == 2) {
-                const float4 mk = *(const float4*)(mask_src + pix * C + c);
+                const float4 mk = *(const float4*)((const float*)mask_src + pix * C + c);
                 const float k4[4] = {mk.x, mk.y, mk.z, mk.w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) g[j] = k4[j] > 0.f ? g[j] : 0.f;
+            } else if (mask_mode == 3) {
+                const s16x4_t mk = *(const s16x4_t*)((const uint16_t*)mask_src + pix * C + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) g[j] = ((unsigned)((uint16_t)mk[j]) - 1u) < 0x7fffu ? g[j] : 0.f;
             } else if (mask_mode == 0) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { const float a = fmaf(xs[j], a4[j], b4[j]); g[j] = (a > 0.f && a < act_hi) ? g[j] : 0.f; }
@@ -468,8 +543,8 @@ __global__ __launch_bounds__(256) void bn_bwd16_finalize_kernel(const float* __r
     bound[c] = frozen ? fabsf(ca) * gm : fabsf(ca) * (gm + fabsf(S1) * inv_p + xm * fabsf(S2) * inv_p);
 }
 
-template <int PREC>
-__global__ __launch_bounds__(256) void bn_bwd16_apply_kernel(const float* __restrict__ dA, const float* __restrict__ x, const float* __restrict__ mask_src,
+template <int PREC, bool X16>
+__global__ __launch_bounds__(256) void bn_bwd16_apply_kernel(const float* __restrict__ dA, const void* __restrict__ x, const void* __restrict__ mask_src,
                                                              const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ coef,
                                                              const float* __restrict__ bound, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo,
                                                              float* __restrict__ out_scale, long long items, int C, int mask_mode, float act_hi,
@@ -498,13 +573,15 @@ __global__ __launch_bounds__(256) void bn_bwd16_apply_kernel(const float* __rest
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < items; i += (long long)gridDim.x * 256) {
         const int c = (int)(i % G) * 8;
         const float4 g0 = *(const float4*)(dA + i * 8), g1 = *(const float4*)(dA + i * 8 + 4);
-        const float4 x0 = *(const float4*)(x + i * 8), x1 = *(const float4*)(x + i * 8 + 4);
-        float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+        float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, xs[8];
+        load8<X16>(x, (size_t)i * 8, xs);
         if (mask_mode == 2) {
-            const float4 m0 = *(const float4*)(mask_src + i * 8), m1 = *(const float4*)(mask_src + i * 8 + 4);
-            const float k8[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+            float k8[8];
+            load8<false>(mask_src, (size_t)i * 8, k8);
 #pragma unroll
             for (int j = 0; j < 8; ++j) g[j] = k8[j] > 0.f ? g[j] : 0.f;
+        } else if (mask_mode == 3) {
+            mask8_16((const uint16_t*)mask_src, (size_t)i * 8, g);
         } else if (mask_mode == 0) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const float a = fmaf(xs[j], scale[c + j], shift[c + j]); g[j] = (a > 0.f && a < act_hi) ? g[j] : 0.f; }
@@ -526,8 +603,8 @@ __global__ __launch_bounds__(256) void bn_bwd16_apply_kernel(const float* __rest
 // pass 3 for C/8 <= 256 channel groups (every layer of the two encoders): a thread keeps ONE group of 8 channels -- its 40 coefficients
 // (ca, cb, cc, scale, shift) are loaded once as float4s -- and walks the pixels of its block (256 / (C/8) pixels per iteration, the
 // lanes of a pixel contiguous: coalesced 32 B per lane).  The one-item-per-thread form above re-reads 40 scalars per 8 elements.
-template <int PREC>
-__global__ __launch_bounds__(256) void bn_bwd16_apply_rows_kernel(const float* __restrict__ dA, const float* __restrict__ x, const float* __restrict__ mask_src,
+template <int PREC, bool X16>
+__global__ __launch_bounds__(256) void bn_bwd16_apply_rows_kernel(const float* __restrict__ dA, const void* __restrict__ x, const void* __restrict__ mask_src,
                                                                   const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ coef,
                                                                   const float* __restrict__ bound, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo,
                                                                   float* __restrict__ out_scale, long long P, int C, int rows, int PB, int mask_mode, float act_hi,
@@ -572,13 +649,15 @@ __global__ __launch_bounds__(256) void bn_bwd16_apply_rows_kernel(const float* _
     for (long long pix = p0 + r; pix < p1; pix += rows) {
         const size_t off = (size_t)pix * C + c;
         const float4 g0 = *(const float4*)(dA + off), g1 = *(const float4*)(dA + off + 4);
-        const float4 x0 = *(const float4*)(x + off), x1 = *(const float4*)(x + off + 4);
-        float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+        float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, xs[8];
+        load8<X16>(x, off, xs);
         if (mask_mode == 2) {
-            const float4 m0 = *(const float4*)(mask_src + off), m1 = *(const float4*)(mask_src + off + 4);
-            const float k8[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+            float k8[8];
+            load8<false>(mask_src, off, k8);
 #pragma unroll
             for (int j = 0; j < 8; ++j) g[j] = k8[j] > 0.f ? g[j] : 0.f;
+        } else if (mask_mode == 3) {
+            mask8_16((const uint16_t*)mask_src, off, g);
         } else if (mask_mode == 0) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const float a = fmaf(xs[j], a8[j], b8[j]); g[j] = (a > 0.f && a < act_hi) ? g[j] : 0.f; }
@@ -600,15 +679,16 @@ extern "C" long long lp_bn_bwd16_workspace_bytes(long long P, int C) {
     return (S * C * 4 + (long long)C * 4) * (long long)sizeof(float);
 }
 
-extern "C" int lp_bn_bwd16(const float* dA, const float* x, const float* mask_src, const float* gamma, const float* mean, const float* rstd,
-                           const float* scale, const float* shift, uint16_t* out_hi, uint16_t* out_lo, float* out_scale, float* dgamma,
-                           float* dbeta, float* workspace, long long P, int C, int mask_mode, float act_hi, int frozen_stats, int prec,
-                           float* g_out, void* stream) {
-    if (!dA || !x || !gamma || !mean || !rstd || !scale || !shift || !out_hi || !out_scale || !dgamma || !dbeta || !workspace)
+static int bn_bwd16_impl(const float* dA, const float* x, const uint16_t* x16, const void* mask_src, const float* gamma, const float* mean,
+                         const float* rstd, const float* scale, const float* shift, uint16_t* out_hi, uint16_t* out_lo, float* out_scale,
+                         float* dgamma, float* dbeta, float* workspace, long long P, int C, int mask_mode, float act_hi, int frozen_stats,
+                         int prec, float* g_out, hipStream_t st) {
+    if (!dA || (!x && !x16) || !gamma || !mean || !rstd || !scale || !shift || !out_hi || !out_scale || !dgamma || !dbeta || !workspace)
         return lp_set_error(LP_ERR_ARG, "lp_bn_bwd16: null pointer");
     if (C & 7) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_bn_bwd16: C must be a multiple of 8");
-    if (mask_mode < 0 || mask_mode > 2 || (mask_mode == 2 && !mask_src)) return lp_set_error(LP_ERR_ARG, "lp_bn_bwd16: bad mask mode");
+    if (mask_mode < 0 || mask_mode > 3 || (mask_mode >= 2 && !mask_src)) return lp_set_error(LP_ERR_ARG, "lp_bn_bwd16: bad mask mode");
     if (prec == LP_PREC_BF16X3 && !out_lo) return lp_set_error(LP_ERR_ARG, "lp_bn_bwd16: bf16x3 needs the lo plane");
+    if (x16 && prec != LP_PREC_F16) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_bn_bwd16_h: 16-bit x exists in the fp16 mode only");
     if (P < 1) return LP_OK;
     const int PB = lp_stat_split_pix(1, P, C);
     const int S = (int)((P + PB - 1) / PB);
@@ -616,8 +696,9 @@ extern "C" int lp_bn_bwd16(const float* dA, const float* x, const float* mask_sr
     float* coef = workspace + (size_t)S * C * 4;
     float* bound = coef + (size_t)C * 3;
     const float hi_ = act_hi > 0.f ? act_hi : 3.0e38f;
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_bwd16_partial_kernel, dim3(S, (C + 63) / 64), dim3(256), 0, st, dA, x, mask_src, mean, rstd, scale, shift, part, P, C, mask_mode, hi_, PB);
+    const void* xv = x16 ? (const void*)x16 : (const void*)x;
+    if (x16) hipLaunchKernelGGL(bn_bwd16_partial_kernel<true>, dim3(S, (C + 63) / 64), dim3(256), 0, st, dA, xv, mask_src, mean, rstd, scale, shift, part, P, C, mask_mode, hi_, PB);
+    else hipLaunchKernelGGL(bn_bwd16_partial_kernel<false>, dim3(S, (C + 63) / 64), dim3(256), 0, st, dA, xv, mask_src, mean, rstd, scale, shift, part, P, C, mask_mode, hi_, PB);
     int rc = lp_check_launch("bn_bwd16_partial");
     if (rc) return rc;
     hipLaunchKernelGGL(bn_bwd16_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, gamma, mean, rstd, dgamma, dbeta, coef, bound, C, S,
@@ -633,19 +714,42 @@ extern "C" int lp_bn_bwd16(const float* dA, const float* x, const float* mask_sr
         if (ppb < 4ll * rows) ppb = 4ll * rows;
         ppb = (ppb + rows - 1) / rows * rows;
         const unsigned grid = (unsigned)((P + ppb - 1) / ppb);
-#define LP_BR(Q) hipLaunchKernelGGL(bn_bwd16_apply_rows_kernel<Q>, dim3(grid), dim3(256), 0, st, dA, x, mask_src, scale, shift, coef, bound, out_hi, out_lo, out_scale, P, C, rows, (int)ppb, mask_mode, hi_, g_out)
-        if (prec == LP_PREC_BF16) LP_BR(LP_PREC_BF16);
-        else if (prec == LP_PREC_BF16X3) LP_BR(LP_PREC_BF16X3);
-        else if (prec == LP_PREC_F16) LP_BR(LP_PREC_F16);
+#define LP_BR(Q, H) hipLaunchKernelGGL((bn_bwd16_apply_rows_kernel<Q, H>), dim3(grid), dim3(256), 0, st, dA, xv, mask_src, scale, shift, coef, bound, out_hi, out_lo, out_scale, P, C, rows, (int)ppb, mask_mode, hi_, g_out)
+        if (x16) LP_BR(LP_PREC_F16, true);
+        else if (prec == LP_PREC_BF16) LP_BR(LP_PREC_BF16, false);
+        else if (prec == LP_PREC_BF16X3) LP_BR(LP_PREC_BF16X3, false);
+        else if (prec == LP_PREC_F16) LP_BR(LP_PREC_F16, false);
         else return lp_set_error(LP_ERR_ARG, "lp_bn_bwd16: unknown precision mode");
 #undef LP_BR
         return lp_check_launch("bn_bwd16_apply");
     }
-#define LP_BB(Q) hipLaunchKernelGGL(bn_bwd16_apply_kernel<Q>, dim3(grid_for(items, 8192)), dim3(256), 0, st, dA, x, mask_src, scale, shift, coef, bound, out_hi, out_lo, out_scale, items, C, mask_mode, hi_, g_out)
-    if (prec == LP_PREC_BF16) LP_BB(LP_PREC_BF16);
-    else if (prec == LP_PREC_BF16X3) LP_BB(LP_PREC_BF16X3);
-    else if (prec == LP_PREC_F16) LP_BB(LP_PREC_F16);
+#define LP_BB(Q, H) hipLaunchKernelGGL((bn_bwd16_apply_kernel<Q, H>), dim3(grid_for(items, 8192)), dim3(256), 0, st, dA, xv, mask_src, scale, shift, coef, bound, out_hi, out_lo, out_scale, items, C, mask_mode, hi_, g_out)
+    if (x16) LP_BB(LP_PREC_F16, true);
+    else if (prec == LP_PREC_BF16) LP_BB(LP_PREC_BF16, false);
+    else if (prec == LP_PREC_BF16X3) LP_BB(LP_PREC_BF16X3, false);
+    else if (prec == LP_PREC_F16) LP_BB(LP_PREC_F16, false);
     else return lp_set_error(LP_ERR_ARG, "lp_bn_bwd16: unknown precision mode");
 #undef LP_BB
     return lp_check_launch("bn_bwd16_apply");
+}
+
+extern "C" int lp_bn_bwd16(const float* dA, const float* x, const float* mask_src, const float* gamma, const float* mean, const float* rstd,
+                           const float* scale, const float* shift, uint16_t* out_hi, uint16_t* out_lo, float* out_scale, float* dgamma,
+                           float* dbeta, float* workspace, long long P, int C, int mask_mode, float act_hi, int frozen_stats, int prec,
+                           float* g_out, void* stream) {
+    if (!x) return lp_set_error(LP_ERR_ARG, "lp_bn_bwd16: null pointer");
+    if (mask_mode == 3) return lp_set_error(LP_ERR_ARG, "lp_bn_bwd16: mask mode 3 (16-bit plane) is lp_bn_bwd16_h's");
+    return bn_bwd16_impl(dA, x, nullptr, mask_src, gamma, mean, rstd, scale, shift, out_hi, out_lo, out_scale, dgamma, dbeta, workspace, P, C,
+                         mask_mode, act_hi, frozen_stats, prec, g_out, (hipStream_t)stream);
+}
+
+// x as fp32 (x16 = NULL) or as the fp16 plane a conv epilogue wrote instead of fp32 y (x = NULL, fp16 mode); mask modes 0 / 1 / 2 as
+// lp_bn_bwd16 (2: mask_src fp32 > 0) and 3: mask_src = a 16-bit OPERAND PLANE [P][C] whose elements are > 0 (the block output's planes:
+// 2 B instead of 4 B per element for the ReLU pattern behind the residual add)
+extern "C" int lp_bn_bwd16_h(const float* dA, const float* x, const uint16_t* x16, const void* mask_src, const float* gamma, const float* mean,
+                             const float* rstd, const float* scale, const float* shift, uint16_t* out_hi, uint16_t* out_lo, float* out_scale,
+                             float* dgamma, float* dbeta, float* workspace, long long P, int C, int mask_mode, float act_hi, int frozen_stats,
+                             int prec, float* g_out, void* stream) {
+    return bn_bwd16_impl(dA, x, x16, mask_src, gamma, mean, rstd, scale, shift, out_hi, out_lo, out_scale, dgamma, dbeta, workspace, P, C,
+                         mask_mode, act_hi, frozen_stats, prec, g_out, (hipStream_t)stream);
 }

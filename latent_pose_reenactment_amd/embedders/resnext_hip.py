@@ -13,8 +13,14 @@ Data flow (NHWC fp32 activations, 16-bit operand planes for every contraction, a
                         lp_act_pack (pro 4) applies with the ReLU while it writes the next conv's operand planes; the block output's
                         BN + residual + ReLU is lp_bn_add_act.  Backward: lp_norm_act_bwd (the AdaIN backward kernels with one "image").
   head     AdaptiveAvgPool2d(1) (lp_spatial_mean) + the classifier as a 1x1 contraction over the N frames.
-Every raw conv output is kept in fp32 (BatchNorm statistics and backward read it); the saved operand planes are what the weight
-gradients multiply.  Nothing here is a torch op except views and allocation."""
+Raw conv outputs: fp32 in the strict (bf16x3) and bf16 modes.  In the fp16 mode they are 16-BIT RESIDENT ("y16", LP_E_Y16=0 turns it
+off): the conv epilogue leaves the BatchNorm partials (taken from its fp32 accumulators) and the unscaled fp16 plane of y -- no fp32 y --;
+lp_bn_act16 / lp_bn_add_act16 / lp_bn_bwd16_h read 2 B per element where lp_act_pack / lp_bn_add_act / lp_bn_bwd16 read 4, and the ReLU
+pattern behind the residual add is read from the block output's operand planes instead of its fp32 copy.  (The stem, the three stride-2
+grouped convs and the downsample branches keep fp32 y.)  The saved operand planes are what the weight gradients multiply.  Nothing here
+is a torch op except views and allocation."""
+import os
+
 import torch
 
 from latent_pose_reenactment_amd import hipops as ops
@@ -36,14 +42,36 @@ def supported(n: int, h: int, w: int) -> bool:
     return h % 32 == 0 and w % 32 == 0 and h >= 128 and w >= 128 and n % 4 == 0 and n >= 8
 
 
-def _conv1x1(a16, pack, prec, bias=None, res=None, amax=False, stats=False):
+Y16 = os.environ.get('LP_E_Y16', '1') != '0'        # fp16 mode: conv outputs stay 16-bit resident
+
+
+def _v16(a, shape):
+    """operand planes viewed with another (same-size) leading shape"""
+    return ops.Act16(a.hi.view(shape), None if a.lo is None else a.lo.view(shape), a.c, a.inv)
+
+
+def _conv1x1(a16, pack, prec, bias=None, res=None, amax=False, stats=False, y16=False):
     """1x1 contraction on flattened pixels: a16 [..., C8] planes -> y [P, Cout] fp32 (``stats``: -> (y, ConvStats | None): the BatchNorm
-    partials of y over all P pixels, written by the conv epilogue)"""
+    partials of y over all P pixels, written by the conv epilogue).  ``y16``: y is returned as its fp16 plane (``Act16``), no fp32 y."""
     fa = ops.flat16(a16)
     _, h, w, _ = fa.hi.shape
     if res is not None:
         res = res.view(1, h, w, -1)
+    if y16:
+        out = ops.conv16(fa, pack, ksize=1, bias=bias, res=res, prec=prec, stats=stats, want_y=False, out16=0, kind='conv1x1')
+        return out[1:] if stats else out[1]
     return ops.conv16(fa, pack, ksize=1, bias=bias, res=res, prec=prec, amax=amax, stats=stats, kind='conv1x1')
+
+
+def _yview(y, shape):
+    return _v16(y, shape) if isinstance(y, ops.Act16) else y.view(shape)
+
+
+def _bn_relu_planes(y, st, prec):
+    """operand planes of relu(BatchNorm(y)) for the next conv"""
+    if isinstance(y, ops.Act16):
+        return ops.bn_act16(y, st.scale, st.shift)
+    return ops.act_pack(y, pro=4, scale=st.scale, shift=st.shift, prec=prec)
 
 
 def bn_state(y, st, gamma, beta, m, counters):
@@ -52,7 +80,9 @@ def bn_state(y, st, gamma, beta, m, counters):
         counters.append(m.num_batches_tracked)
     rm, rv = (m.running_mean, m.running_var) if m.track_running_stats else (None, None)
     if st is not None:
-        return _BN(*ops.norm_stats_finalize(st, 1, y.shape[-1], gamma, beta, m.eps, running_mean=rm, running_var=rv, momentum=m.momentum))
+        return _BN(*ops.norm_stats_finalize(st, 1, gamma.shape[0], gamma, beta, m.eps, running_mean=rm, running_var=rv, momentum=m.momentum))
+    if isinstance(y, ops.Act16):          # (a geometry the fused statistics do not cover: none of the supported() sizes)
+        y = ops.y16_to_f32(y)
     return _BN(*ops.bn_train_stats(y, gamma, beta, rm, rv, m.momentum, m.eps))
 
 
@@ -92,22 +122,27 @@ class ResNeXtFunction(torch.autograd.Function):
         out, out16, idx = ops.bn_relu_maxpool(y0, st0.scale, st0.shift, prec, want_idx=need_grad)
         saved_blocks = []
         # ---- bottleneck blocks
+        y16 = Y16 and prec == PREC_F16
         for bname, cin, width, cout, stride, down in net._hip_blocks:
             xin, xin16 = out, out16
             _, h, w, _ = xin.shape
-            y1, cs = _conv1x1(xin16, packs[bname + '.conv1.weight'][0], prec, stats=True)
-            y1 = y1.view(n, h, w, width)
+            y1, cs = _conv1x1(xin16, packs[bname + '.conv1.weight'][0], prec, stats=True, y16=y16)
+            y1 = _yview(y1, (n, h, w, width))
             st1 = bn(y1, bname + '.bn1', cs)
-            a1 = ops.act_pack(y1, pro=4, scale=st1.scale, shift=st1.shift, prec=prec)
+            a1 = _bn_relu_planes(y1, st1, prec)
             if stride == 1:
-                y2, cs = ops.gconv16(a1, packs[bname + '.conv2.weight'][0], prec=prec, stats=True)
+                if y16:
+                    _, y2, cs = ops.gconv16(a1, packs[bname + '.conv2.weight'][0], prec=prec, stats=True, want_y=False, out16=True)
+                else:
+                    y2, cs = ops.gconv16(a1, packs[bname + '.conv2.weight'][0], prec=prec, stats=True)
+                ho, wo = h, w
             else:       # (the statistics of the strided output: one pass over the quarter-size tensor)
                 y2, cs = ops.subsample2(ops.gconv16(a1, packs[bname + '.conv2.weight'][0], prec=prec)), None
-            ho, wo = y2.shape[1], y2.shape[2]
+                ho, wo = y2.shape[1], y2.shape[2]
             st2 = bn(y2, bname + '.bn2', cs)
-            a2 = ops.act_pack(y2, pro=4, scale=st2.scale, shift=st2.shift, prec=prec)
-            y3, cs = _conv1x1(a2, packs[bname + '.conv3.weight'][0], prec, stats=True)
-            y3 = y3.view(n, ho, wo, cout)
+            a2 = _bn_relu_planes(y2, st2, prec)
+            y3, cs = _conv1x1(a2, packs[bname + '.conv3.weight'][0], prec, stats=True, y16=y16)
+            y3 = _yview(y3, (n, ho, wo, cout))
             st3 = bn(y3, bname + '.bn3', cs)
             xd16 = yd = std = None
             if down:
@@ -119,7 +154,8 @@ class ResNeXtFunction(torch.autograd.Function):
             else:
                 out, out16 = ops.bn_add_act(y3, st3.scale, st3.shift, xin, relu=True, prec=prec)
             if need_grad:
-                saved_blocks.append((xin16, y1, st1, a1, y2, st2, a2, y3, st3, xd16, yd, std, out, (h, w, ho, wo)))
+                # (the ReLU pattern of the block output: its operand planes in the 16-bit-resident mode, its fp32 copy otherwise)
+                saved_blocks.append((xin16, y1, st1, a1, y2, st2, a2, y3, st3, xd16, yd, std, out16 if y16 else out, (h, w, ho, wo)))
         # ---- head
         _, hl, wl, cl = out.shape
         pooled = ops.spatial_mean(out)                                            # [N, 2048]

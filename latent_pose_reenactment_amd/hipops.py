@@ -804,28 +804,53 @@ def pack_grouped(w: Tensor, mode: int, prec: int) -> WeightPack:
     return WeightPack(hi, lo, c, cg, cp, 64, 9)          # cols = the group size (logical contraction width per output channel)
 
 
-def gconv16(a: Act16, pack: WeightPack, *, prec: int, amax: bool = False, stats: bool = False):
+def gconv16(a: Act16, pack: WeightPack, *, prec: int, amax: bool = False, stats: bool = False, want_y: bool = True, out16: bool = False):
     """grouped 3x3 conv (pad 1, stride 1) on operand planes a [N,H,W,C] -> y [N,H,W,C] fp32; with the mode-1 pack: the data gradient.
-    ``stats``: -> (y, ConvStats | None) as ``conv16``"""
+    ``stats``: -> (y, ConvStats | None) as ``conv16``.  ``out16``: the operand planes of y are a second output (y, Act16[, stats]);
+    ``want_y=False`` (with ``out16``): no fp32 y is written, y is returned as None."""
     n, h, w = a.nhw
     c = a.c
     assert c == pack.rows and a.hi.shape[3] == c, (a.hi.shape, pack.rows)
-    y = torch.empty((n, h, w, c), dtype=torch.float32, device=a.hi.device)
-    slots = _amax_attach(y, amax and prec == PREC_F16)
+    assert want_y or (out16 and not amax)
+    dev = a.hi.device
+    y = torch.empty((n, h, w, c), dtype=torch.float32, device=dev) if want_y else None
+    o_hi = o_lo = None
+    if out16:
+        o_hi, o_lo = _alloc16(n, h, w, c, prec, dev)
+    slots = _amax_attach(y, amax and prec == PREC_F16) if y is not None else None
     st_buf, st_rows, st_cap = None, None, 0
     if stats:
         import ctypes
         st_cap = _lib.lib().lp_conv16_stats_floats(n, h, w, c)
-        st_buf = torch.empty(st_cap, dtype=torch.float32, device=y.device)
+        st_buf = torch.empty(st_cap, dtype=torch.float32, device=dev)
         st_rows = ctypes.c_int(0)
     pl = 4 if prec == PREC_BF16X3 else 2
-    with _Timed('gconv', 2.0 * n * h * w * c * pack.cols * 9, (n, h, w, pack.cols, c, 3, 0, 0), n * h * w * c * (pl + 4) + pack.hi.numel() * pl):
-        check(_lib.lib().lp_gconv16_fwd_stats(a.hi.data_ptr(), _p(a.lo), pack.hi.data_ptr(), _p(pack.lo), y.data_ptr(), _p(a.inv), n, h, w, c,
-                                              pack.rows_p, prec, _p(slots), _p(st_buf), st_cap, None if st_rows is None else ctypes.addressof(st_rows),
-                                              _stream()), 'lp_gconv16_fwd')
+    nbytes = n * h * w * c * (pl + (4 if want_y else 0) + (pl if out16 else 0)) + pack.hi.numel() * pl
+    with _Timed('gconv', 2.0 * n * h * w * c * pack.cols * 9, (n, h, w, pack.cols, c, 3, 0, 0), nbytes):
+        check(_lib.lib().lp_gconv16_fwd_planes(a.hi.data_ptr(), _p(a.lo), pack.hi.data_ptr(), _p(pack.lo), _p(y), _p(o_hi), _p(o_lo), _p(a.inv),
+                                               n, h, w, c, pack.rows_p, prec, _p(slots), _p(st_buf), st_cap,
+                                               None if st_rows is None else ctypes.addressof(st_rows), _stream()), 'lp_gconv16_fwd')
+    out = (y,) if not out16 else (y, Act16(o_hi, o_lo, c, None))
     if stats:
-        return y, (ConvStats(st_buf, st_rows.value, n) if st_rows.value > 0 else None)
-    return y
+        out = out + ((ConvStats(st_buf, st_rows.value, n) if st_rows.value > 0 else None),)
+    return out[0] if len(out) == 1 else out
+
+
+def bn_act16(y16: Act16, scale: Tensor, shift: Tensor, relu: bool = True) -> Act16:
+    """operand planes of (relu?)(y*scale[c]+shift[c]) from a 16-BIT-RESIDENT conv output y16 (fp16 mode: the fp16 plane the conv epilogue
+    wrote instead of fp32 y): ``act_pack`` pro 4 / 5 reading 2 B per element"""
+    c = y16.c
+    assert y16.lo is None and y16.inv is None and y16.hi.shape[-1] == c and c % 8 == 0
+    hi = torch.empty_like(y16.hi)
+    check(_lib.lib().lp_bn_act16(y16.hi.data_ptr(), scale.data_ptr(), shift.data_ptr(), hi.data_ptr(), y16.hi.numel() // c, c, int(relu),
+                                 _stream()), 'lp_bn_act16')
+    return Act16(hi, None, c, None)
+
+
+def y16_to_f32(y16: Act16) -> Tensor:
+    """fp32 copy of a 16-bit-resident conv output (the rare consumers without a 16-bit form: statistics of a geometry the conv epilogue
+    does not cover)"""
+    return y16.hi.view(torch.float16)[..., :y16.c].float()
 
 
 def norm_stats_finalize(st: ConvStats, n: int, c: int, gamma: Optional[Tensor], beta: Optional[Tensor], eps: float, *,
@@ -901,18 +926,30 @@ def maxpool_bwd(dout: Tensor, idx: Tensor, h: int, w: int) -> Tensor:
 def bn_add_act(y: Tensor, scale: Tensor, shift: Tensor, res: Optional[Tensor] = None, res_scale: Optional[Tensor] = None,
                res_shift: Optional[Tensor] = None, relu: bool = True, prec: Optional[int] = None):
     """out = relu?(y*scale[c]+shift[c] + (res | res*res_scale[c]+res_shift[c])) over [..., C]; with ``prec`` -> (out, Act16)"""
-    _chk(y, 'y')
-    c = y.shape[-1]
-    p = y.numel() // c
-    out = torch.empty_like(y)
+    y16 = y if isinstance(y, Act16) else None
+    if y16 is not None:          # 16-bit-resident conv output (fp16 mode)
+        assert prec in (None, PREC_F16) and y16.lo is None and y16.inv is None
+        shape, dev = y16.hi.shape, y16.hi.device
+    else:
+        _chk(y, 'y')
+        shape, dev = y.shape, y.device
+    c = shape[-1]
+    p = 1
+    for d in shape[:-1]:
+        p *= d
+    out = torch.empty(shape, dtype=torch.float32, device=dev)
     hi = lo = None
     if prec is not None:
-        hi = torch.empty(y.shape, dtype=torch.int16, device=y.device)
+        hi = torch.empty(shape, dtype=torch.int16, device=dev)
         lo = torch.empty_like(hi) if prec == PREC_BF16X3 else None
     if res is not None:
-        _chk(res, 'res'); assert res.shape == y.shape, (res.shape, y.shape)
-    check(_lib.lib().lp_bn_add_act(y.data_ptr(), scale.data_ptr(), shift.data_ptr(), _p(res), _p(res_scale), _p(res_shift), out.data_ptr(),
-                                   _p(hi), _p(lo), p, c, int(relu), prec if prec is not None else 0, _stream()), 'lp_bn_add_act')
+        _chk(res, 'res'); assert res.shape == shape, (res.shape, shape)
+    if y16 is not None:
+        check(_lib.lib().lp_bn_add_act16(y16.hi.data_ptr(), scale.data_ptr(), shift.data_ptr(), _p(res), _p(res_scale), _p(res_shift),
+                                         out.data_ptr(), _p(hi), p, c, int(relu), _stream()), 'lp_bn_add_act16')
+    else:
+        check(_lib.lib().lp_bn_add_act(y.data_ptr(), scale.data_ptr(), shift.data_ptr(), _p(res), _p(res_scale), _p(res_shift), out.data_ptr(),
+                                       _p(hi), _p(lo), p, c, int(relu), prec if prec is not None else 0, _stream()), 'lp_bn_add_act')
     return out if prec is None else (out, Act16(hi, lo, c, None))
 
 
@@ -992,20 +1029,35 @@ def bn_bwd16(dA: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, s
              mask_src: Optional[Tensor] = None, want_g: bool = False, act_hi: float = 0.0, frozen: bool = False):
     """backward of act(BatchNorm(x)) over x [..., C] written straight to the OPERAND PLANES of dy (what the weight / data gradient
     contractions consume): -> (Act16 of dy, dgamma [C], dbeta [C], g | None).  No fp32 dy, no masked-gradient temporary; in fp16 mode the
-    planes carry the power-of-two scale of lp_bn_bwd16 (``Act16.inv``).  Arguments as ``norm_act_bwd``."""
-    _chk(dA, 'dA'); _chk(x, 'x')
-    c = x.shape[-1]
-    p = x.numel() // c
-    assert dA.shape == x.shape and c % 8 == 0, (dA.shape, x.shape)
-    hi = torch.empty(x.shape, dtype=torch.int16, device=x.device)
+    planes carry the power-of-two scale of lp_bn_bwd16 (``Act16.inv``).  Arguments as ``norm_act_bwd``; ``x`` may be a 16-bit-resident
+    conv output (``Act16``, fp16 mode) and ``mask_src`` (mask_mode 2) the operand planes of the activated tensor instead of its fp32 copy."""
+    _chk(dA, 'dA')
+    x16 = x if isinstance(x, Act16) else None          # 16-bit-resident conv output (fp16 mode)
+    if x16 is not None:
+        assert prec == PREC_F16 and x16.lo is None and x16.inv is None
+        shape = x16.hi.shape
+    else:
+        _chk(x, 'x')
+        shape = x.shape
+    c = shape[-1]
+    p = dA.numel() // c
+    assert dA.shape == shape and c % 8 == 0, (dA.shape, shape)
+    dev = dA.device
+    hi = torch.empty(shape, dtype=torch.int16, device=dev)
     lo = torch.empty_like(hi) if prec == PREC_BF16X3 else None
-    small = torch.empty(2 + 2 * c, dtype=torch.float32, device=x.device)
+    small = torch.empty(2 + 2 * c, dtype=torch.float32, device=dev)
     sc, dg, db = small[:2], small[2:2 + c], small[2 + c:]
-    g = torch.empty_like(x) if want_g else None
-    ws = torch.empty(_lib.lib().lp_bn_bwd16_workspace_bytes(p, c) // 4, dtype=torch.float32, device=x.device)
-    if mask_src is not None:
-        _chk(mask_src, 'mask_src'); assert mask_src.shape == x.shape
-    check(_lib.lib().lp_bn_bwd16(dA.data_ptr(), x.data_ptr(), _p(mask_src), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(),
-                                 shift.data_ptr(), hi.data_ptr(), _p(lo), sc.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), p, c,
-                                 mask_mode, float(act_hi), int(frozen), prec, _p(g), _stream()), 'lp_bn_bwd16')
+    g = torch.empty(shape, dtype=torch.float32, device=dev) if want_g else None
+    ws = torch.empty(_lib.lib().lp_bn_bwd16_workspace_bytes(p, c) // 4, dtype=torch.float32, device=dev)
+    mptr = None
+    if isinstance(mask_src, Act16):                    # the ReLU pattern from the planes of the activated tensor (2 B per element)
+        assert mask_mode == 2 and mask_src.hi.shape == shape, (mask_mode, mask_src.hi.shape, shape)
+        mask_mode, mptr = 3, mask_src.hi.data_ptr()
+    elif mask_src is not None:
+        _chk(mask_src, 'mask_src'); assert mask_src.shape == shape
+        mptr = mask_src.data_ptr()
+    check(_lib.lib().lp_bn_bwd16_h(dA.data_ptr(), None if x16 is not None else x.data_ptr(), None if x16 is None else x16.hi.data_ptr(), mptr,
+                                   gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), hi.data_ptr(), _p(lo),
+                                   sc.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), p, c, mask_mode, float(act_hi), int(frozen), prec,
+                                   _p(g), _stream()), 'lp_bn_bwd16')
     return Act16(hi, lo, c, sc[1:] if prec == PREC_F16 else None), dg, db, g

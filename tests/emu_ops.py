@@ -82,7 +82,12 @@ def conv16(a, pack, *, ksize, upsample=False, bias=None, res=None, res_shift=0, 
         y = y + bias
     if res is not None:
         y = y + res
-    return (y, ConvStats(y, 1)) if stats else y
+    out = (y if want_y else None,)
+    if out16 is not None:
+        out = out + (Act16(torch.relu(y) if out16 else y, None, y.shape[-1], None),)
+    if stats:
+        out = out + (ConvStats(y, 1),)
+    return out[0] if len(out) == 1 else out
 
 
 def norm_stats_finalize(st, n, c, gamma, beta, eps, *, running_mean=None, running_var=None, momentum=0.0):
@@ -98,13 +103,27 @@ def conv_wgrad16(a, dy, *, ksize, upsample=False, prec=0, splits=None, sn=None, 
     return (dw, d.sum(0)) if bias_grad else dw
 
 
-def gconv16(a, pack, *, prec=0, amax=False, stats=False):
+def gconv16(a, pack, *, prec=0, amax=False, stats=False, want_y=True, out16=False):
     w = pack.w
     groups = a.c // w.shape[1]
     x = a.hi.permute(0, 3, 1, 2)
     y = F.conv2d(x, w, padding=1, groups=groups) if pack.mode == 0 else F.conv_transpose2d(x, w, padding=1, groups=groups)
     y = y.permute(0, 2, 3, 1).contiguous()
-    return (y, ConvStats(y, 1)) if stats else y
+    out = (y if want_y else None,)
+    if out16:
+        out = out + (Act16(y, None, y.shape[-1], None),)
+    if stats:
+        out = out + (ConvStats(y, 1),)
+    return out[0] if len(out) == 1 else out
+
+
+def bn_act16(y16, scale, shift, relu=True):
+    v = y16.hi * scale + shift
+    return Act16(torch.relu(v) if relu else v, None, y16.c, None)
+
+
+def y16_to_f32(y16):
+    return y16.hi
 
 
 def gconv_wgrad16(a, dy, group_size, *, prec=0, splits=None):
@@ -174,6 +193,8 @@ def maxpool_bwd(dout, idx, h, w):
 
 
 def bn_add_act(y, scale, shift, res=None, res_scale=None, res_shift=None, relu=True, prec=None):
+    if isinstance(y, Act16):
+        y = y.hi
     v = y * scale + shift
     if res is not None:
         v = v + (res * res_scale + res_shift if res_scale is not None else res)
@@ -237,6 +258,10 @@ def affine_relu6_mean(y, scale, shift):
 
 
 def bn_bwd16(dA, x, gamma, mean, rstd, scale, shift, *, prec=0, mask_mode=0, mask_src=None, want_g=False, act_hi=0.0, frozen=False):
+    if isinstance(x, Act16):
+        x = x.hi
+    if isinstance(mask_src, Act16):
+        mask_src = mask_src.hi
     dx, dg, db, g = norm_act_bwd(dA, x, gamma, mean, rstd, scale, shift, mask_mode=mask_mode, mask_src=mask_src, want_g=want_g, act_hi=act_hi,
                                  frozen=frozen)
     return Act16(dx, None, x.shape[-1], None), dg, db, g

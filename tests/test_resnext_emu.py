@@ -19,9 +19,11 @@ def rel(a, b):
     return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
 
 
+@pytest.mark.parametrize('mode', ['f16', 'bf16x3'])         # f16: conv outputs 16-bit resident (the y16 wiring); bf16x3: fp32 outputs
 @pytest.mark.parametrize('train', [True, False])
-def test_resnext_function_matches_stock_autograd(monkeypatch, train):
+def test_resnext_function_matches_stock_autograd(monkeypatch, train, mode):
     import emu_ops
+    monkeypatch.setenv('LP_PREC_E', mode)
     from embedders import resnext_hip
     from embedders.backbones import resnext50_32x4d
     from latent_pose_reenactment_amd import hipops
