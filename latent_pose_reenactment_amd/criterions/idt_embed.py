@@ -62,6 +62,8 @@ def compute_bboxes_from_keypoints(keypoints):
 
 
 class Criterion(torch.nn.Module):
+    independent_branch = True          # reads fake / target images only: may run beside the discriminator pass (streams.py)
+
     def __init__(self, idt_embed_weight, vgg_weights_dir, synthetic_seed=None):
         super().__init__()
         self.idt_embed_crit = PerceptualLoss(idt_embed_weight, vgg_weights_dir, 'face', synthetic_seed).eval()

@@ -15,6 +15,8 @@ class Wrapper:
 
 
 class Criterion(nn.Module):
+    independent_branch = True          # reads fake / target images only: may run beside the discriminator pass (streams.py)
+
     def __init__(self, perc_weight, vgg_weights_dir, synthetic_seed=None):
         super().__init__()
         self.perceptual_crit = PerceptualLoss(perc_weight, vgg_weights_dir, 'caffe', synthetic_seed).eval()

@@ -197,22 +197,23 @@ __global__ __launch_bounds__(256) void instnorm_finalize_kernel(const float* __r
     const int idx = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (idx >= N * C) return;
     int n = idx / C, c = idx % C;
-    double na = 0, ma = 0, qa = 0;
+    // {count, mean, M2} partials -> shifted sums about ONE reference (the first partial's mean, the same for all lanes):
+    //   N = sum n_s,  S1 = sum n_s (mean_s - ref),  S2 = sum [M2_s + n_s (mean_s - ref)^2]   (fp64 FMAs, no division per partial)
+    //   mean = ref + S1 / N,  M2 = S2 - S1^2 / N.   |mean_s - ref| is a few standard deviations at most, so the final subtraction is benign
+    //   in fp64; the lanes' sums simply add (6 shuffle steps).  (The pairwise Chan merge this replaces spent two fp64 divisions per partial:
+    //   11 us for the 4096 partials per channel of the embedder's first stage.)
+    const double ref = part[((size_t)n * S * C + c) * 3 + 1];
+    double na = 0, s1 = 0, s2 = 0;
+#pragma unroll 4
     for (int s = lane; s < S; s += 64) {
         const float* q = part + (((size_t)n * S + s) * C + c) * 3;
-        double nb = q[0], mb = q[1], qb = q[2];
-        if (nb == 0) continue;
-        if (na == 0) { na = nb; ma = mb; qa = qb; continue; }
-        double nn = na + nb, d = mb - ma;
-        ma += d * (nb / nn); qa += qb + d * d * (na * nb / nn); na = nn;
+        const double nb = q[0], d = (double)q[1] - ref;
+        na += nb; s1 = fma(nb, d, s1); s2 += (double)q[2] + nb * d * d;
     }
-    for (int o = 32; o > 0; o >>= 1) {
-        const double nb = __shfl_down(na, o, 64), mb = __shfl_down(ma, o, 64), qb = __shfl_down(qa, o, 64);
-        if (nb != 0) {
-            if (na == 0) { na = nb; ma = mb; qa = qb; }
-            else { double nn = na + nb, d = mb - ma; ma += d * (nb / nn); qa += qb + d * d * (na * nb / nn); na = nn; }
-        }
-    }
+    for (int o = 32; o > 0; o >>= 1) { na += __shfl_down(na, o, 64); s1 += __shfl_down(s1, o, 64); s2 += __shfl_down(s2, o, 64); }
+    const double ma = ref + s1 / na;
+    double qa = s2 - s1 * s1 / na;
+    if (qa < 0) qa = 0;
     if (lane != 0) return;
     float var = (float)(qa / na);
     float m = (float)ma, r = 1.0f / sqrtf(var + eps);

@@ -14,18 +14,35 @@ yields the same dicts with their tensors in DEVICE staging buffers:
         of slot s -- completed (recorded when batch k+2 was staged), so the host never runs more than two steps ahead of the device.
 A meta-training batch is 69 MB per step (8 x (8 + 1 + 1 + 1) frames of 3 x 256 x 256 fp32), a fine-tuning batch 25 MB: 1.6 / 0.55 ms at the
 44 GB/s measured, hidden behind a 50 / 22 ms step.  The hipGraph step copies the staging tensors into its static inputs (device-to-device, ~10 us)."""
+import ctypes
+import os
+import time
+
 import torch
 
 SLOTS = 3
+_PIN_COPY = os.environ.get('LP_PIN_COPY', 'memmove')        # memmove | torch
+
+
+def _host_copy(pin, v):
+    """pageable host tensor -> pinned slot.  A plain single-threaded memmove (GIL released): ``Tensor.copy_`` between two host tensors runs
+    on the intra-op thread pool, and on a host with few free cores its workers -- spinning after the copy -- starve the HIP runtime's
+    own threads: measured +14 .. +23 % per captured fine-tuning step for a 25 MB batch, against +0.5 % with the copy below
+    (profiles/r03_input_path.txt).  2.5 ms for 25 MB, hidden behind the step like the H2D itself."""
+    if _PIN_COPY == 'memmove' and v.is_contiguous() and pin.is_contiguous() and v.dtype == pin.dtype:
+        ctypes.memmove(pin.data_ptr(), v.data_ptr(), v.numel() * v.element_size())
+    else:
+        pin.copy_(v)
 
 
 class DevicePrefetcher:
     def __init__(self, loader, device):
         self.loader = loader
         self.device = torch.device(device)
-        self.copy_stream = torch.cuda.Stream(device=self.device)
+        self.copy_stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get('LP_COPY_PRIORITY', '0')))
         self.slots = [None] * SLOTS        # per slot: {'pinned': {...}, 'dev': {...}, 'reader_done': event | None}
         self.markers = []                  # (batch index the marker covers, event): everything enqueued on the compute stream so far
+        self.waits = {'slot_free': 0.0, 'h2d_done': 0.0, 'pin_memcpy': 0.0}      # host seconds spent waiting / copying (diagnostics)
 
     def __len__(self):
         return len(self.loader)
@@ -56,7 +73,7 @@ class DevicePrefetcher:
         while self.markers and self.markers[0][0] < index - SLOTS:
             self.markers.pop(0)
         if self.markers and self.markers[0][0] >= index - SLOTS and index >= SLOTS:
-            self.markers[0][1].synchronize()
+            t0 = time.perf_counter(); self.markers[0][1].synchronize(); self.waits['slot_free'] += time.perf_counter() - t0
         out = []
         with torch.cuda.stream(self.copy_stream):
             for di, d in enumerate(batch):
@@ -65,7 +82,9 @@ class DevicePrefetcher:
                     if torch.is_tensor(v) and not v.is_cuda:
                         pin, dev = self._buffers(slot, (di, k), v, need_pin=not v.is_pinned())
                         if pin is not None:
-                            pin.copy_(v)                                # host memcpy into pinned memory
+                            t0 = time.perf_counter()
+                            _host_copy(pin, v)                          # host memcpy into pinned memory
+                            self.waits['pin_memcpy'] += time.perf_counter() - t0
                             v = pin
                         dev.copy_(v, non_blocking=True)                 # async H2D on the copy stream (pinned source)
                         o[k] = dev
@@ -81,7 +100,7 @@ class DevicePrefetcher:
         for index, batch in enumerate(self.loader):
             staged = self._stage(batch, index)
             if pending is not None:
-                pending[1].synchronize()           # host-side: this H2D was issued a whole step ago
+                t0 = time.perf_counter(); pending[1].synchronize(); self.waits['h2d_done'] += time.perf_counter() - t0      # host-side: this H2D was issued a whole step ago
                 yield pending[0]
             pending = staged
         if pending is not None:

@@ -42,6 +42,15 @@ class Embedder(nn.Module):
         data_dict['pose_embedding'] = self.pose_encoder(data_dict['pose_input_rgbs'][:, 0])
 
     def forward(self, data_dict):
+        from latent_pose_reenactment_amd import streams
+        if not self.finetuning and streams.enabled(data_dict['pose_input_rgbs'], 'encoders'):
+            # the two encoders are independent: the pose encoder's ~600 short launches (forward and, through autograd's per-node streams,
+            # backward) run beside the identity encoder's large ones instead of after them
+            with streams.branch(data_dict['pose_input_rgbs'].device, 0) as b:
+                self.get_pose_embedding(data_dict)
+            self.get_identity_embedding(data_dict)
+            b.join(data_dict['pose_embedding'])
+            return
         if not self.finetuning:          # after fine-tuning the identity lives in the generator (train.py:263-266)
             self.get_identity_embedding(data_dict)
         self.get_pose_embedding(data_dict)

@@ -1,0 +1,66 @@
+"""Concurrent branches of one training step on separate HIP streams.
+
+A meta-training step issues ~2200 kernels, most of them far too small to fill 256 CUs (the MobileNetV2 pose encoder alone: ~600 launches
+of 2 .. 20 us).  Branches that do not depend on each other -- the pose encoder beside the identity encoder, the VGG-19 and VGGFace
+perceptual criterions beside the discriminator -- are therefore ISSUED ON SEPARATE STREAMS: ``fork`` makes a side stream wait for the
+work already queued on the current one, ``join`` makes the current stream wait for the side stream.  Autograd runs every backward node
+on the stream of its forward, so the backward passes of the branches overlap the same way; under hipGraph capture the cross-stream
+waits become graph edges and the branches become parallel paths of the captured graph.  LP_OVERLAP=0 runs everything on one stream."""
+import os
+from contextlib import contextmanager
+
+import torch
+
+_STREAMS = {}
+
+
+# measured on the captured steps (profiles/r03_stream_overlap.txt): meta-training 43.4 ms on one stream, 40.8 with the encoders side by side,
+# 39.0 with the VGG criterions beside the discriminator as well; the fine-tuning step (no identity encoder, pose encoder without autograd)
+# only has the criterion overlap to offer and loses 1.6 % with it.  LP_OVERLAP_ENCODERS / LP_OVERLAP_CRITERIONS = 0 | 1 force.
+def enabled(t, what: str, finetuning: bool = False) -> bool:
+    """``what``: 'encoders' (pose encoder beside the identity encoder) | 'criterions' (VGG stacks beside the discriminator pass)"""
+    if not (torch.is_tensor(t) and t.is_cuda) or os.environ.get('LP_OVERLAP', '1') == '0':
+        return False
+    default = '0' if (what == 'criterions' and finetuning) else '1'
+    return os.environ.get('LP_OVERLAP_' + what.upper(), default) != '0'
+
+
+def side_stream(device, index: int) -> 'torch.cuda.Stream':
+    key = (torch.device(device).index or 0, index)
+    if key not in _STREAMS:
+        _STREAMS[key] = torch.cuda.Stream(device=device)
+    return _STREAMS[key]
+
+
+def _tensors(obj):
+    if torch.is_tensor(obj):
+        yield obj
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            yield from _tensors(v)
+    elif isinstance(obj, (tuple, list)):
+        for v in obj:
+            yield from _tensors(v)
+
+
+@contextmanager
+def branch(device, index: int):
+    """``with branch(dev, i) as b: out = f(...)`` runs f on side stream i, ordered after everything queued on the current stream so far;
+    call ``b.join(out)`` (any time later, on the original stream) before the results are used there."""
+    main = torch.cuda.current_stream(device)
+    side = side_stream(device, index)
+    side.wait_stream(main)
+    b = _Branch(main, side)
+    with torch.cuda.stream(side):
+        yield b
+
+
+class _Branch:
+    def __init__(self, main, side):
+        self.main, self.side = main, side
+
+    def join(self, outputs=None):
+        self.main.wait_stream(self.side)
+        for t in _tensors(outputs):          # allocated on the side stream, consumed on the main one: keep the block until that work is done
+            if t.is_cuda:
+                t.record_stream(self.main)
