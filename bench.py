@@ -45,6 +45,18 @@ def step_algorithmic_tflop(workload, batch, frames=8):
     return per_img * batch / 1e3
 
 
+def stream_config(workload):
+    """which independent branches of the step run on their own HIP streams (latent_pose_reenactment_amd/streams.py)"""
+    from latent_pose_reenactment_amd import streams
+    probe = torch.empty(1, device='cuda') if torch.cuda.is_available() else None
+    ft = workload != 'metatrain_step'
+    on = [k for k in ('encoders', 'criterions', 'optimizer') if probe is not None and streams.enabled(probe, k, finetuning=ft) and not (ft and k == 'encoders')]
+    return {'concurrent_branches': on if workload != 'generator' else [],
+            'note': 'encoders: pose encoder beside the identity encoder; criterions: VGG-19 / VGGFace stacks beside the discriminator pass, their '
+                    'target-image halves beside encoders + generator; autograd runs each backward on its forward stream; captured as parallel '
+                    'paths of the hipGraphs'}
+
+
 def make_args(image_size, batch_size, device, num_gpus, rank, prec_name, finetune=True):
     """finetune=True: configs/finetuning-base.yaml (BASELINE configs[1]); False: configs/default.yaml meta-training (configs[2])"""
     a = argparse.Namespace(
@@ -462,11 +474,21 @@ def main():
     # Live per-kernel timing for the roofline entry: HIP events recorded on the launch stream around every conv launch.
     # Graph replays cannot carry per-kernel events, so the instrumented steps run eagerly right after the timed region
     # (same process, same buffers, same kernels); they are not part of `value`.
+    # They run on ONE stream (LP_OVERLAP=0): beside a concurrent branch (streams.py) a kernel's event span would include the time it shares
+    # the CUs with another stream's kernels, which is not what a per-kernel roofline states.
     hipops.PROFILE = []
     inst = eager_step if a.workload != 'generator' else step
-    for _ in range(2):
-        inst()
-    torch.cuda.synchronize()
+    keep_overlap = os.environ.get('LP_OVERLAP')
+    os.environ['LP_OVERLAP'] = '0'
+    try:
+        for _ in range(2):
+            inst()
+        torch.cuda.synchronize()
+    finally:
+        if keep_overlap is None:
+            os.environ.pop('LP_OVERLAP', None)
+        else:
+            os.environ['LP_OVERLAP'] = keep_overlap
     prof, hipops.PROFILE = hipops.PROFILE, None
     solo = None
     if world > 1:
@@ -594,7 +616,8 @@ def main():
                                     'generator': 'generator forward+backward only (HIP kernels)'}[a.workload],
                        'image_size': a.image_size, 'per_gpu_batch': a.batch, 'global_batch': a.batch * world,
                        'parallelism': f'dp{world}', 'precision_mode': a.prec,
-                       'launch_mode': mode if a.workload != 'generator' else 'eager'},
+                       'launch_mode': mode if a.workload != 'generator' else 'eager',
+                       'streams': stream_config(a.workload)},
             'roofline': roof,
         }
         # whole-step MFMA utilisation: the number the 0.60 target of BASELINE.json is about (useful dense FLOPs of the step / time / peak)

@@ -116,15 +116,25 @@ class PerceptualLoss(nn.Module):
                 pending_relu = False
         return taps
 
-    def forward(self, input, target):
+    def target_features(self, target):
+        """the taps of the REAL image: no autograd, no dependence on the generator -- a training step may compute them early, on a
+        side stream, beside the encoders and the generator (runners/holycow.py TrainingModule.forward, streams.py)"""
+        if not target.is_cuda:
+            raise RuntimeError('PerceptualLoss runs on the MI355X HIP path only (no CPU fallback)')
+        prec = default_prec()
+        with torch.no_grad():
+            ft = self.normalize_inputs((target.detach() + 1) / 2)
+            return self._features(ft, self._packs(prec), prec, [])
+
+    def forward(self, input, target, taps_t=None):
+        """``taps_t``: ``target_features(target)`` computed earlier (else computed here)"""
         if not input.is_cuda:
             raise RuntimeError('PerceptualLoss runs on the MI355X HIP path only (no CPU fallback)')
         prec = default_prec()
         packs = self._packs(prec)
         fi = self.normalize_inputs((input + 1) / 2)
-        with torch.no_grad():
-            ft = self.normalize_inputs((target.detach() + 1) / 2)
-            taps_t = self._features(ft, packs, prec, [])
+        if taps_t is None:
+            taps_t = self.target_features(target)
         terms = self._features(fi, packs, prec, [], targets=taps_t)
         loss = torch.stack(terms).sum() if len(terms) > 1 else terms[0]     # (one cat + one sum instead of a chain of scalar adds)
         return loss * self.weight

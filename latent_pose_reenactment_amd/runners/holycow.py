@@ -122,6 +122,20 @@ class TrainingModule(nn.Module):
         else:
             embedder, generator = self.embedder, self.generator
         data_dict = copy.copy(data_dict)          # inputs only; modules add their outputs
+        # meta-training: the target-image halves of the VGG criterions depend on neither encoder nor generator -- they start now, each on
+        # the side stream its criterion will use later (stream order makes the later call see them; nothing to join here)
+        from latent_pose_reenactment_amd import streams
+        ft = bool(getattr(generator, 'finetuning', False))
+        tgt = target_dict.get('target_rgbs') if isinstance(target_dict, dict) else None
+        crit_stream = {}
+        if self.compute_losses and streams.enabled(tgt, 'criterions', finetuning=ft):
+            both = {**data_dict, **target_dict}
+            for i, criterion in enumerate(self.criterion_list):
+                if getattr(criterion, 'independent_branch', False):
+                    crit_stream[i] = 1 + len(crit_stream)
+                    if hasattr(criterion, 'precompute_targets'):
+                        with streams.branch(tgt.device, crit_stream[i]):
+                            criterion.precompute_targets(both)
         # In fine-tuning the optimizer holds generator parameters only (get_optimizer above, holycow.py:34-41), so the pose
         # encoder's weight gradients are never consumed: run it without autograd (bit-identical parameters afterwards).
         with torch.set_grad_enabled(torch.is_grad_enabled() and not getattr(generator, 'finetuning', False)):
@@ -130,13 +144,12 @@ class TrainingModule(nn.Module):
         data_dict.update(target_dict)
         # criterions that touch neither the discriminator nor each other (the two VGG stacks: ``independent_branch``) are issued on side
         # streams BEFORE the discriminator pass, so that their small-map layers fill the gaps of its launches (streams.py)
-        from latent_pose_reenactment_amd import streams
         early = {}
         fake = data_dict.get('fake_rgbs')
-        if self.compute_losses and streams.enabled(fake, 'criterions', finetuning=bool(getattr(generator, 'finetuning', False))):
+        if self.compute_losses and streams.enabled(fake, 'criterions', finetuning=ft):
             for i, criterion in enumerate(self.criterion_list):
                 if getattr(criterion, 'independent_branch', False):
-                    with streams.branch(fake.device, 1 + len(early)) as b:
+                    with streams.branch(fake.device, crit_stream.get(i, 1 + len(early))) as b:
                         early[i] = (b, criterion(data_dict))
         if self.compute_losses:
             self.discriminator(data_dict)
@@ -282,8 +295,8 @@ class GraphedTrainStep:
     The graphs share one memory pool and are replayed in order; the data-parallel all-reduces run eagerly BETWEEN them
     (collectives are never captured).  One GPU:
         g1: forward (E, G, D x3, criterions) + zero_grad(G) + loss_G.backward
-        g2: optimizer_G.step + zero_grad(D) + loss_D.backward
-        g3: optimizer_D.step + EMA
+        g2: [optimizer_G.step + EMA on a side stream] || zero_grad(D) + loss_D.backward
+        g3: optimizer_D.step
     Data parallel (the step is re-cut so that the generator-side exchange hides behind the discriminator backward):
         g1:  as above
         --   all-reduce of the generator-side gradient arena, ASYNCHRONOUS on RCCL's stream
@@ -324,13 +337,25 @@ class GraphedTrainStep:
             with fused_grad_accumulation():
                 loss_G.backward(retain_graph=True)
         pool = self.g1.pool()
+        from latent_pose_reenactment_amd import streams
+        first = next(iter(self.tm.generator.parameters()))
+        # one GPU: optimizer_G.step and the EMA of embedder + generator touch nothing the discriminator backward reads or writes
+        # (train_step's docstring), so they run on a side stream beside it; g3 is then optimizer_D.step alone
+        self.ema_in_g2 = self.reducer is None and streams.enabled(first, 'optimizer')
         if self.reducer is None:
             self.g2 = G()
             with torch.cuda.graph(self.g2, pool=pool, **kw):
-                self.opt_G.step()
+                if self.ema_in_g2:
+                    with streams.branch(first.device, 3) as b:
+                        self.opt_G.step()
+                        self.tm.update_running_average(self.alpha)
+                else:
+                    self.opt_G.step()
                 self.opt_D.zero_grad()
                 with fused_grad_accumulation():
                     loss_D.backward()
+                if self.ema_in_g2:
+                    b.join()
         else:
             self.reducer.reduce_generator_side()
             self.g2a, self.g2b = G(), G()
@@ -344,7 +369,8 @@ class GraphedTrainStep:
         self.g3 = G()
         with torch.cuda.graph(self.g3, pool=pool, **kw):
             self.opt_D.step()
-            self.tm.update_running_average(self.alpha)
+            if not self.ema_in_g2:
+                self.tm.update_running_average(self.alpha)
         del loss_G, loss_D
         torch.cuda.synchronize()
 
