@@ -31,6 +31,13 @@ timeout 300 python bench.py --workload generator --generator FSTH_plus --image_s
 timeout 300 python bench.py --workload generator --steps 20 --warmup 5 --no-cpu-baseline > $O/${R}_bench_generator_f16.json 2> $O/${R}_bench_generator_f16.err
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 6 --warmup 2 --backend gloo > $O/${R}_bench_dp2_gloo_one_gpu_functional.json 2> $O/${R}_bench_dp2.err
 PREC=2 timeout 120 python scripts/conv_micro.py > $O/${R}_conv_micro_f16.txt 2>&1
+timeout 200 python scripts/bn_micro.py > $O/${R}_bn_micro_f16.txt 2>&1
+LP_OVERLAP=0 timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-also --no-drive > $O/${R}_bench_f16_one_stream.json 2> $O/${R}_bench_f16_one_stream.err
+timeout 900 python -m pytest tests -m gpu -q -x > $O/${R}_pytest_gpu.log 2>&1
+echo "pytest -m gpu rc=$?" >> $O/summary.txt
+tail -3 $O/${R}_pytest_gpu.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/${R}_smoke.log 2>&1
+echo "smoke rc=$?" >> $O/summary.txt
 cut -c1-2500 $O/${R}_bench_f16.json
 tail -3 $O/${R}_bench_f16.err
 cat $O/${R}_pmc_conv_dma_step.json
