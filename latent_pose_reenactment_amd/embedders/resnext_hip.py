@@ -24,6 +24,7 @@ import os
 import torch
 
 from latent_pose_reenactment_amd import hipops as ops
+from latent_pose_reenactment_amd import streams as _streams
 from latent_pose_reenactment_amd._lib import PREC_F16
 
 
@@ -43,6 +44,10 @@ def supported(n: int, h: int, w: int) -> bool:
 
 
 Y16 = os.environ.get('LP_E_Y16', '1') != '0'        # fp16 mode: conv outputs stay 16-bit resident
+
+
+def _side_ok(t):
+    return _streams.enabled(t, 'wgrad')
 
 
 def _v16(a, shape):
@@ -187,6 +192,21 @@ class ResNeXtFunction(torch.autograd.Function):
             grads[name + '.weight'], grads[name + '.bias'] = dg, db
             return d16, g
 
+        # LP_OVERLAP_WGRAD=1 (off by default: measured 38.8 -> 41.7 ms per meta-training step, profiles/r03_stream_overlap.txt): weight gradients
+        # are off the critical path (only the optimizer reads them), so they can be issued on a side stream behind the data-gradient /
+        # BatchNorm-backward chain that produces their operands and joined once, at the end.  Their operand planes are then kept alive until
+        # that join (a tensor the main stream frees may be re-used by its next allocation while the side stream still reads it).
+        wside = _side_ok(d_logits)
+        keep = []
+
+        def wgrad(key, fn, *operands):
+            if wside:
+                keep.extend(operands)
+                with _streams.branch(d_logits.device, 4):
+                    grads[key] = fn(*operands)
+            else:
+                grads[key] = fn(*operands)
+
         # ---- head
         p16, (hl, wl, cl), (fh, fw) = ctx.head
         dl16 = ops.act_pack(d_logits.contiguous().view(1, fh, fw, -1), prec=prec, grad=True)
@@ -199,19 +219,19 @@ class ResNeXtFunction(torch.autograd.Function):
             xin16, y1, st1, a1, y2, st2, a2, y3, st3, xd16, yd, std, out, (h, w, ho, wo) = sv
             # out = relu(bn3(y3) + skip): g = d_out * [out > 0] reaches bn3 and the skip branch alike
             d16, g = bn_bwd(d_out, y3, st3, bname + '.bn3', mask_mode=2, mask_src=out, want_g=not down)
-            grads[bname + '.conv3.weight'] = _wgrad1x1(a2, d16, prec).view(par[bname + '.conv3.weight'].shape)
+            wgrad(bname + '.conv3.weight', lambda a, d, k=bname + '.conv3.weight': _wgrad1x1(a, d, prec).view(par[k].shape), a2, d16)
             dA2 = _conv1x1(d16, packs[bname + '.conv3.weight'][1], prec).view(n, ho, wo, width)
             d16, _ = bn_bwd(dA2, y2, st2, bname + '.bn2')
             if stride == 2:
                 d16 = ops.zero_stuff2_16(d16, h, w)                               # adjoint of the subsample of the full-resolution conv
             cg = par[bname + '.conv2.weight'].shape[1]
-            grads[bname + '.conv2.weight'] = ops.gconv_wgrad16(a1, d16, cg, prec=prec)
+            wgrad(bname + '.conv2.weight', lambda a, d, cg=cg: ops.gconv_wgrad16(a, d, cg, prec=prec), a1, d16)
             dA1 = ops.gconv16(d16, packs[bname + '.conv2.weight'][1], prec=prec)
             d16, _ = bn_bwd(dA1, y1, st1, bname + '.bn1')
-            grads[bname + '.conv1.weight'] = _wgrad1x1(xin16, d16, prec).view(par[bname + '.conv1.weight'].shape)
+            wgrad(bname + '.conv1.weight', lambda a, d, k=bname + '.conv1.weight': _wgrad1x1(a, d, prec).view(par[k].shape), xin16, d16)
             if down:
                 dd16, _ = bn_bwd(d_out, yd, std, bname + '.downsample.1', mask_mode=2, mask_src=out)      # same ReLU pattern as bn3: out > 0
-                grads[bname + '.downsample.0.weight'] = _wgrad1x1(xd16, dd16, prec).view(par[bname + '.downsample.0.weight'].shape)
+                wgrad(bname + '.downsample.0.weight', lambda a, d, k=bname + '.downsample.0.weight': _wgrad1x1(a, d, prec).view(par[k].shape), xd16, dd16)
                 d_xd = _conv1x1(dd16, packs[bname + '.downsample.0.weight'][1], prec)          # [P', cin]
                 if stride == 2:
                     d_xin = _conv1x1(d16, packs[bname + '.conv1.weight'][1], prec).view(n, h, w, cin)
@@ -225,7 +245,10 @@ class ResNeXtFunction(torch.autograd.Function):
         cols, y0, st0, idx, (h0, w0) = ctx.stem
         dA0 = ops.maxpool_bwd(d_out, idx, h0, w0)
         d16, _ = bn_bwd(dA0, y0, st0, 'bn1')
-        grads['conv1.weight'] = _wgrad1x1(cols, d16, prec).view(par['conv1.weight'].shape)
+        wgrad('conv1.weight', lambda a, d: _wgrad1x1(a, d, prec).view(par['conv1.weight'].shape), cols, d16)
+        if wside:
+            torch.cuda.current_stream(d_logits.device).wait_stream(_streams.side_stream(d_logits.device, 4))
+        keep.clear()
         ctx.blocks = ctx.stem = ctx.head = None
         from latent_pose_reenactment_amd.nn import fused_accumulate
         return (None, None) + tuple(fused_accumulate(ctx.params, [grads.get(k) for k in net._hip_param_names]))
