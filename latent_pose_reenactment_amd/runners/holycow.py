@@ -122,13 +122,14 @@ class TrainingModule(nn.Module):
         else:
             embedder, generator = self.embedder, self.generator
         data_dict = copy.copy(data_dict)          # inputs only; modules add their outputs
-        # meta-training: the target-image halves of the VGG criterions depend on neither encoder nor generator -- they start now, each on
-        # the side stream its criterion will use later (stream order makes the later call see them; nothing to join here)
+        # the target-image halves of the VGG criterions depend on neither encoder nor generator -- they start now, each on a side stream
+        # (the stream its criterion uses later where the criterions themselves run on side streams: meta-training; else joined before the call)
         from latent_pose_reenactment_amd import streams
         ft = bool(getattr(generator, 'finetuning', False))
         tgt = target_dict.get('target_rgbs') if isinstance(target_dict, dict) else None
         crit_stream = {}
-        if self.compute_losses and streams.enabled(tgt, 'criterions', finetuning=ft):
+        crit_side = self.compute_losses and streams.enabled(tgt, 'criterions', finetuning=ft)
+        if self.compute_losses and (crit_side or streams.enabled(tgt, 'targets', finetuning=ft)):
             both = {**data_dict, **target_dict}
             for i, criterion in enumerate(self.criterion_list):
                 if getattr(criterion, 'independent_branch', False):
@@ -146,7 +147,7 @@ class TrainingModule(nn.Module):
         # streams BEFORE the discriminator pass, so that their small-map layers fill the gaps of its launches (streams.py)
         early = {}
         fake = data_dict.get('fake_rgbs')
-        if self.compute_losses and streams.enabled(fake, 'criterions', finetuning=ft):
+        if crit_side and streams.enabled(fake, 'criterions', finetuning=ft):
             for i, criterion in enumerate(self.criterion_list):
                 if getattr(criterion, 'independent_branch', False):
                     with streams.branch(fake.device, crit_stream.get(i, 1 + len(early))) as b:
@@ -160,6 +161,8 @@ class TrainingModule(nn.Module):
                     b, out = early[i]
                     b.join(out)
                 else:
+                    if i in crit_stream:          # target features were computed on a side stream, the criterion itself runs here
+                        torch.cuda.current_stream(tgt.device).wait_stream(streams.side_stream(tgt.device, crit_stream[i]))
                     out = criterion(data_dict)
             except Exception:
                 if self.compute_losses:
