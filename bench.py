@@ -52,8 +52,8 @@ def stream_config(workload):
     ft = workload != 'metatrain_step'
     on = [k for k in ('encoders', 'criterions', 'optimizer') if probe is not None and streams.enabled(probe, k, finetuning=ft) and not (ft and k == 'encoders')]
     return {'concurrent_branches': on if workload != 'generator' else [],
-            'note': 'encoders: pose encoder beside the identity encoder; criterions: VGG-19 / VGGFace stacks beside the discriminator pass, their '
-                    'target-image halves beside encoders + generator; autograd runs each backward on its forward stream; captured as parallel '
+            'note': 'encoders: pose encoder beside the identity encoder; criterions: VGG-19 / VGGFace stacks beside the discriminator pass; '
+                    'autograd runs each backward on its forward stream; captured as parallel '
                     'paths of the hipGraphs'}
 
 

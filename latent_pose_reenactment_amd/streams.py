@@ -19,8 +19,9 @@ _STREAMS = {}
 # only has the criterion overlap to offer and loses 1.6 % with it.  optimizer_G.step + EMA beside the discriminator backward: 38.98 -> 38.87 ms
 # (meta-training, within noise) and 22.47 -> 23.17 ms (fine-tuning): off by default.  The identity encoder's weight gradients beside its
 # data-gradient chain: 38.8 -> 41.7 ms (two bandwidth-bound kernel sequences sharing HBM and the L2s run slower than one after the other): off.
-# Only the target-image halves of the VGG criterions ahead of pose encoder + generator in the fine-tuning step: 22.40 vs 22.40 ms: off there
-# (the fine-tuning step stays a single-stream graph).  LP_OVERLAP_ENCODERS / _CRITERIONS / _OPTIMIZER = 0 | 1 force.
+# The target-image halves of the VGG criterions at the top of the step (beside encoders + generator): 38.9 -> 42.3 ms (meta-training),
+# 22.4 -> 24.1 ms (fine-tuning) -- large kernels beside large kernels again: off.  What pays is a branch of SMALL kernels beside a
+# branch of large ones.  LP_OVERLAP_{ENCODERS,CRITERIONS,OPTIMIZER,WGRAD,TARGETS} = 0 | 1 force; LP_OVERLAP=0 turns everything off.
 def enabled(t, what: str, finetuning: bool = False) -> bool:
     """``what``: 'encoders' (pose encoder beside the identity encoder) | 'criterions' (VGG stacks beside the discriminator pass, their
     target-image halves beside encoders + generator) | 'optimizer' (optimizer_G.step + EMA beside the discriminator backward) |
@@ -28,7 +29,7 @@ def enabled(t, what: str, finetuning: bool = False) -> bool:
     VGG criterions ahead of encoders + generator)"""
     if not (torch.is_tensor(t) and t.is_cuda) or os.environ.get('LP_OVERLAP', '1') == '0':
         return False
-    default = '0' if (what in ('optimizer', 'wgrad') or (what in ('criterions', 'targets') and finetuning)) else '1'
+    default = '0' if (what in ('optimizer', 'wgrad', 'targets') or (what == 'criterions' and finetuning)) else '1'
     return os.environ.get('LP_OVERLAP_' + what.upper(), default) != '0'
 
 
