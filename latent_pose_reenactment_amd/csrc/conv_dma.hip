@@ -642,11 +642,21 @@ static int dispatch_conv16(Conv16Params& p, int ks, int ups, hipStream_t s) {
         // drops) -- profiles/r03_conv1x1_cc64.txt.  LP_CONV_CC1 = 32 | 64 forces.
         static const int cc_env = getenv("LP_CONV_CC1") ? atoi(getenv("LP_CONV_CC1")) : 0;
         const bool cc64 = (cc_env ? cc_env == 64 : (p.Cin >= 512 && PREC != LP_PREC_BF16X3)) && (p.CinP % 64 == 0);
+        // LP_CONV1X1_TILE=256: 256 x 128 output tiles (8 waves, 64 x 64 each) for the big pointwise layers -- 25 % fewer operand bytes staged
+        // L2 -> LDS per flop than the 128 x 128 tile.  Measured NULL (profiles/r03_conv1x1_tile256.txt: every layer within +-5 %, the step
+        // 39.4 vs 39.3 ms), so the K >= 512 layers' ~470-600 TF/s is not an L2-bandwidth limit but the one-stage-ahead DMA + barrier per stage
+        // of this loop; the default stays 128.
+        static const int tile_env = getenv("LP_CONV1X1_TILE") ? atoi(getenv("LP_CONV1X1_TILE")) : 0;
+        const long long pix = (long long)p.N * p.H * p.W;
+        const bool tall = (tile_env ? tile_env == 256 : false) && p.Cout >= 128 && p.H * p.W >= 256 &&
+                          (pix / 256) * ((p.Cout + 127) / 128) >= 512;
         if (cc64) {
             if (p.Cout <= 64 && big_img) return launch_conv16<1, false, 4, 1, 4, 4, PREC, 64>(p, s);
+            if (tall) return launch_conv16<1, false, 4, 2, 4, 4, PREC, 64>(p, s);
             return launch_conv16<1, false, 2, 2, 4, 4, PREC, 64>(p, s);
         }
         if (p.Cout <= 64 && big_img) return launch_conv16<1, false, 4, 1, 4, 4, PREC>(p, s);
+        if (tall) return launch_conv16<1, false, 4, 2, 4, 4, PREC>(p, s);
         return launch_conv16<1, false, 2, 2, 4, 4, PREC>(p, s);
     }
     return lp_set_error(LP_ERR_UNSUPPORTED, "unsupported conv configuration");
