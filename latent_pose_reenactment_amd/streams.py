@@ -36,6 +36,12 @@ def enabled(t, what: str, finetuning: bool = False) -> bool:
 def side_stream(device, index: int) -> 'torch.cuda.Stream':
     key = (torch.device(device).index or 0, index)
     if key not in _STREAMS:
+        if not _STREAMS:
+            # a parameter whose backward node runs on a side stream is accumulated there while its AccumulateGrad node was created on
+            # the main stream: intended here (the engine orders the two streams), so the per-step warning about it is switched off
+            quiet = getattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch', None)
+            if quiet is not None:
+                quiet(False)
         _STREAMS[key] = torch.cuda.Stream(device=device)
     return _STREAMS[key]
 
