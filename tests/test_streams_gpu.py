@@ -1,0 +1,75 @@
+"""Concurrent branches (latent_pose_reenactment_amd/streams.py) must not change the result: one eager meta-training iteration (default.yaml
+workload at 128 px: both encoders trained, 6 criterions) from the same initial state, once on ONE stream (LP_OVERLAP=0) and once with the
+pose encoder beside the identity encoder and the VGG criterions beside the discriminator pass, must produce the same losses and the same
+gradients of every parameter -- to the run-to-run spread of the one-stream step itself (the crop-and-resize backward scatters with float
+atomics, like the reference's grid_sample, so two runs differ in the last bits; a missing cross-stream dependency or a tensor re-used
+while another stream still reads it shows up as an O(1) error).  Also with every optional branch switched on."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'latent_pose_reenactment_amd'))
+pytestmark = pytest.mark.gpu
+KNOBS = ('LP_OVERLAP', 'LP_OVERLAP_ENCODERS', 'LP_OVERLAP_CRITERIONS', 'LP_OVERLAP_OPTIMIZER', 'LP_OVERLAP_WGRAD', 'LP_OVERLAP_TARGETS')
+
+
+def _iteration(monkeypatch, env):
+    import bench
+    from latent_pose_reenactment_amd.nn import fused_grad_accumulation
+    for k in KNOBS:
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    args = bench.make_args(128, 8, 'cuda:0', 1, 0, 'f16', finetune=False)
+    args.num_labels = 100
+    tm, opt_G, opt_D, holycow = bench.build(args)
+    data, target = bench.synthetic_batch(args, 8, seed=500)
+    all_data, losses_G, losses_D = tm(data, target)
+    loss_G = sum(v for v in losses_G.values() if torch.is_tensor(v))
+    loss_D = sum(v for v in losses_D.values() if torch.is_tensor(v))
+    opt_G.zero_grad()
+    with fused_grad_accumulation():
+        loss_G.backward(retain_graph=True)
+    out = {'loss.' + k: v.detach().clone() for k, v in {**losses_G, **losses_D}.items() if torch.is_tensor(v)}
+    out.update({'fwd.' + k: all_data[k].detach().clone() for k in ('fake_rgbs', 'embeds', 'pose_embedding') if k in all_data})
+    for name, mod in (('E', tm.embedder), ('G', tm.generator)):
+        out.update({f'{name}.{k}': p.grad.detach().clone() for k, p in mod.named_parameters() if p.grad is not None})
+    opt_D.zero_grad()
+    with fused_grad_accumulation():
+        loss_D.backward()
+    out.update({f'D.{k}': p.grad.detach().clone() for k, p in tm.discriminator.named_parameters() if p.grad is not None})
+    out.update({f'buf.{k}': b.detach().clone() for k, b in tm.embedder.named_buffers() if b.dtype.is_floating_point})
+    torch.cuda.synchronize()
+    return out
+
+
+def _spread(a, b):
+    """relative L2 difference of two runs per group (E / G / D gradient vectors, losses, forward outputs, BatchNorm buffers), each group taken
+    as ONE vector: several BatchNorm biases of the encoders have a true gradient of exactly 0 (they feed a conv followed by a train-mode
+    BatchNorm), so a per-tensor relative figure would compare rounding noise with rounding noise"""
+    num, den = {}, {}
+    for k in a:
+        g = k.split('.')[0]
+        num[g] = num.get(g, 0.0) + float((a[k].double() - b[k].double()).pow(2).sum())
+        den[g] = den.get(g, 0.0) + float(b[k].double().pow(2).sum())
+    return {g: (num[g] / max(den[g], 1e-60)) ** 0.5 for g in num}
+
+
+def test_concurrent_branches_reproduce_the_one_stream_iteration(monkeypatch):
+    one = _iteration(monkeypatch, {'LP_OVERLAP': '0'})
+    again = _iteration(monkeypatch, {'LP_OVERLAP': '0'})
+    floor = _spread(again, one)
+    default = _iteration(monkeypatch, {})
+    everything = _iteration(monkeypatch, {'LP_OVERLAP_WGRAD': '1', 'LP_OVERLAP_TARGETS': '1'})
+    assert one.keys() == default.keys() == everything.keys()
+    fmt = lambda sp: ', '.join(f'{g} {v:.1e}' for g, v in sorted(sp.items()))
+    print(f'[streams] one stream, run to run: {fmt(floor)}')
+    for name, run in (('default branches', default), ('all branches', everything)):
+        sp = _spread(run, one)
+        print(f'[streams] {name} vs one stream: {fmt(sp)}')
+        for g, d in sp.items():
+            assert d <= max(20 * floor[g], 1e-5), (name, g, d, floor[g])
