@@ -132,19 +132,43 @@ class Discriminator(nn.Module):
         packs = pb.update()
         return {(w.data_ptr(), mode): p for (w, mode, _), p in zip(specs, packs)}
 
+    def _conv_sn_layers(self):
+        layers = self.__dict__.get('_sn_layer_cache')
+        if layers is None:
+            d0, d2, sk = self.down_block._modules['0'], self.down_block._modules['2'], self.skip._modules['0']
+            layers = [d0, d2, sk] + [l for blk in self.blocks for l in blk.sn_layers()] + [self.linear]
+            self.__dict__['_sn_layer_cache'] = layers
+            self.__dict__['_sn_batch'] = SNBatch(layers)
+        return layers
+
+    def _embed_batch(self):
+        esn = self.__dict__.get('_embed_sn')
+        if esn is None or esn.layers[0] is not self.embed:
+            esn = SNBatch([self.embed])
+            self.__dict__['_embed_sn'] = esn
+        return esn
+
+    def prepare_step(self):
+        """The parts of a TRAINING forward that depend on the weights only -- the 16-bit weight packs, the power iteration of the label
+        embedding and the power iterations of the three passes -- may be issued ahead of ``forward`` (on a side stream, beside the
+        encoders: runners/holycow.py, streams.py).  ``forward`` / ``pass_inputs`` pick the results up in order.  Same arithmetic either way."""
+        if not (self.training and torch.is_grad_enabled() and next(self.parameters()).is_cuda):
+            return
+        self._conv_sn_layers()
+        self.__dict__['_prepared'] = (self._fresh_packs(), self._embed_batch().update(True)[0])
+        self.__dict__['_prepared_passes'] = [self._sn_batch.update(True) for _ in range(3)]
+
     def pass_inputs(self, x, embed=None, track_weights=True):
         """``track_weights=False``: the discriminator's own parameters are constants for autograd in this pass (gradients
         still flow to ``x`` and ``embed``)."""
         if not x.is_cuda:
             raise RuntimeError('the discriminator runs on the MI355X HIP path only (no CPU fallback)')
         d0, d2, sk = self.down_block._modules['0'], self.down_block._modules['2'], self.skip._modules['0']
-        # one launch power-iterates all spectrally normalised layers of this pass (every pass does its own iteration)
-        layers = self.__dict__.get('_sn_layer_cache')
-        if layers is None:
-            layers = [d0, d2, sk] + [l for blk in self.blocks for l in blk.sn_layers()] + [self.linear]
-            self.__dict__['_sn_layer_cache'] = layers
-            self.__dict__['_sn_batch'] = SNBatch(layers)
-        st = self._sn_batch.update(self.training)
+        # one launch power-iterates all spectrally normalised layers of this pass (every pass does its own iteration; prepare_step() may
+        # have run the three iterations of this step ahead)
+        layers = self._conv_sn_layers()
+        ahead = self.__dict__.get('_prepared_passes')
+        st = ahead.pop(0) if ahead else self._sn_batch.update(self.training)
         states = {id(l): s for l, s in zip(layers, st)}
         states['packs'] = self.__dict__.setdefault('_step_packs', {})
         xn = to_nhwc(x)
@@ -186,16 +210,16 @@ class Discriminator(nn.Module):
             fake = fake[:, 0]
         if real.dim() > 4:
             real = real[:, 0]
-        self.__dict__['_step_packs'] = self._fresh_packs()   # new step: the optimizer has changed W_orig since the last forward
+        prepared = self.__dict__.pop('_prepared', None)
+        if prepared is None or not (self.training and torch.is_grad_enabled()):
+            prepared = None
+            self.__dict__.pop('_prepared_passes', None)
+        self.__dict__['_step_packs'] = prepared[0] if prepared is not None else self._fresh_packs()   # new step: the optimizer has changed W_orig
         # label embedding: power iteration on the (98000 x 512 | 1 x 512) matrix by the batched SN kernels, then a row gather scaled
         # by 1/sigma -- W/sigma is never materialised and the backward is row-sparse + rank-1 (SNEmbeddingFn)
         if not label.is_cuda:
             raise RuntimeError('the discriminator runs on the MI355X HIP path only (no CPU fallback)')
-        esn = self.__dict__.get('_embed_sn')
-        if esn is None or esn.layers[0] is not self.embed:
-            esn = SNBatch([self.embed])
-            self.__dict__['_embed_sn'] = esn
-        eu, ev, esig = esn.update(self.training)[0]
+        eu, ev, esig = prepared[1] if prepared is not None else self._embed_batch().update(self.training)[0]
         embed = SNEmbeddingFn.apply(label, self.embed.weight_orig, eu, ev, esig, self.__dict__.setdefault('_embed_parts', {}))
         # Pass 1 feeds only generator-side losses; the gradients it would deposit on the discriminator's parameters are erased
         # by optimizer_D.zero_grad() before loss_D.backward (runners/holycow.py:246-248) and no optimizer reads them, so they

@@ -599,13 +599,63 @@ class Generator(nn.Module):
         joint = torch.cat((identity, pose), dim=1)
         if not joint.is_cuda:
             raise RuntimeError('the generator runs on the MI355X HIP path only (no CPU fallback); move the model and inputs to cuda')
+        states = self.__dict__.pop('_prepared_sn', None)         # prepare_step() ran ahead (beside the encoders): use its result
+        if states is None or not (self.training and torch.is_grad_enabled()):
+            states = self._sn_update()
+        self.__dict__['_sn_states'] = states
+        return self._project(joint, states)
+
+    def _sn_update(self):
         # ONE launch power-iterates every spectrally normalised layer of the generator (23 convs + 2 projector linears)
         layers, slots = self._sn_layers()
         if self.__dict__.get('_sn_batch') is None or self._sn_batch.layers != layers:
             self.__dict__['_sn_batch'] = SNBatch(layers)
-        states = self._sn_batch.update(self.training)
-        self.__dict__['_sn_states'] = states
-        return self._project(joint, states)
+        return self._sn_batch.update(self.training)
+
+    def _conv_weights(self, states):
+        """(weights, sn): the decoder's conv weights / biases in _DecoderFunction's argument order, with each conv's SN state"""
+        weights, sn = [], []
+        nb = len(self.blocks_cfg)
+        k = 0
+        for i in range(nb):
+            c1, c2, sk = self.decoder_blocks._modules[str(i)].convs()
+            weights += [c1.weight_orig, c2.weight_orig]
+            sn += [states[k], states[k + 1]]
+            k += 2
+            if sk is not None:
+                weights += [sk.weight_orig, sk.bias]
+                sn += [states[k], None]
+                k += 1
+        head = self.decoder_blocks._modules[str(nb + 2)]
+        weights += [head.weight_orig, head.bias]
+        sn += [states[k], None]
+        return weights, sn
+
+    def _train_packs_update(self, weights, sn):
+        """training: every conv weight changed in the last optimizer step -> ONE launch re-packs all of them, both orientations"""
+        conv_idx = [i for i, s_ in enumerate(sn) if s_ is not None]
+        specs = [(weights[i], 0, False) for i in conv_idx] + [(weights[i], 1, i == len(weights) - 2) for i in conv_idx]
+        pb = self.__dict__.get('_train_packs')
+        if pb is None or pb.prec != self.prec or pb.key != tuple((w.data_ptr(), m, bool(k_)) for w, m, k_ in specs):
+            pb = ops.PackBatch(specs, self.prec)
+            self.__dict__['_train_packs'] = pb
+        allp = pb.update()
+        packs, packsT = [None] * len(weights), [None] * len(weights)
+        for j, i in enumerate(conv_idx):
+            packs[i], packsT[i] = allp[j], allp[len(conv_idx) + j]
+        return packs, packsT
+
+    def prepare_step(self):
+        """The parts of a TRAINING forward that depend on the weights only -- the spectral-norm power iteration and the 16-bit weight packs
+        -- may be issued ahead of ``forward`` (on a side stream, beside the encoders: runners/holycow.py, streams.py).  ``forward`` picks
+        the results up; without this call it computes them itself.  Same arithmetic either way."""
+        if not (self.training and torch.is_grad_enabled() and next(self.parameters()).is_cuda):
+            return
+        states = self._sn_update()
+        self.__dict__['_prepared_sn'] = states
+        weights, sn = self._conv_weights(states)
+        if any(w.requires_grad for w in weights):
+            self.__dict__['_prepared_packs'] = self._train_packs_update(weights, sn)
 
     def _sn_layers(self):
         """batched SNWeight layers in a fixed order: decoder convs (block order, w1, w2[, skip]), head conv, projector.0, projector.2"""
@@ -625,35 +675,14 @@ class Generator(nn.Module):
     def forward(self, data_dict):
         affine = self._affine_params(data_dict)
         states = self._sn_states
-        weights, sn = [], []
-        nb = len(self.blocks_cfg)
-        k = 0
-        for i in range(nb):
-            c1, c2, sk = self.decoder_blocks._modules[str(i)].convs()
-            weights += [c1.weight_orig, c2.weight_orig]
-            sn += [states[k], states[k + 1]]
-            k += 2
-            if sk is not None:
-                weights += [sk.weight_orig, sk.bias]
-                sn += [states[k], None]
-                k += 1
-        head = self.decoder_blocks._modules[str(nb + 2)]
-        weights += [head.weight_orig, head.bias]
-        sn += [states[k], None]
+        weights, sn = self._conv_weights(states)
         need_grad = torch.is_grad_enabled() and (affine.requires_grad or any(w.requires_grad for w in weights))
         packs = packsT = None
+        prepared = self.__dict__.pop('_prepared_packs', None)
+        if not torch.is_grad_enabled():
+            prepared = None
         if need_grad and self.training:
-            # training: every conv weight changed in the last optimizer step -> ONE launch re-packs all of them, both orientations
-            conv_idx = [i for i, s_ in enumerate(sn) if s_ is not None]
-            specs = [(weights[i], 0, False) for i in conv_idx] + [(weights[i], 1, i == len(weights) - 2) for i in conv_idx]
-            pb = self.__dict__.get('_train_packs')
-            if pb is None or pb.prec != self.prec or pb.key != tuple((w.data_ptr(), m, bool(k_)) for w, m, k_ in specs):
-                pb = ops.PackBatch(specs, self.prec)
-                self.__dict__['_train_packs'] = pb
-            allp = pb.update()
-            packs, packsT = [None] * len(weights), [None] * len(weights)
-            for j, i in enumerate(conv_idx):
-                packs[i], packsT[i] = allp[j], allp[len(conv_idx) + j]
+            packs, packsT = prepared if prepared is not None else self._train_packs_update(weights, sn)
         if not need_grad and not self.training:
             # inference (drive.py): the weights do not change between frames -> pack them to 16 bit once.  The key also carries the
             # generation counter of the fused optimizer / EMA kernels: those update weights through raw pointers without bumping

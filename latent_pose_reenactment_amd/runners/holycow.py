@@ -140,10 +140,20 @@ class TrainingModule(nn.Module):
                     if ahead and hasattr(criterion, 'precompute_targets'):
                         with streams.branch(tgt.device, crit_stream[i]):
                             criterion.precompute_targets(both)
+        # meta-training: what a training forward of G and D derives from the weights alone (spectral-norm power iterations, 16-bit weight
+        # packs: ~40 short launches) is issued on a side stream beside the encoders' large kernels and joined before the generator runs
+        prep = None
+        if self.compute_losses and self.training and torch.is_grad_enabled() and streams.enabled(tgt, 'prepare', finetuning=ft) \
+                and hasattr(generator, 'prepare_step') and hasattr(self.discriminator, 'prepare_step'):
+            with streams.branch(tgt.device, 5) as prep:
+                generator.prepare_step()
+                self.discriminator.prepare_step()
         # In fine-tuning the optimizer holds generator parameters only (get_optimizer above, holycow.py:34-41), so the pose
         # encoder's weight gradients are never consumed: run it without autograd (bit-identical parameters afterwards).
         with torch.set_grad_enabled(torch.is_grad_enabled() and not getattr(generator, 'finetuning', False)):
             embedder(data_dict)
+        if prep is not None:
+            prep.join()
         generator(data_dict)
         data_dict.update(target_dict)
         # criterions that touch neither the discriminator nor each other (the two VGG stacks: ``independent_branch``) are issued on side

@@ -21,15 +21,17 @@ _STREAMS = {}
 # data-gradient chain: 38.8 -> 41.7 ms (two bandwidth-bound kernel sequences sharing HBM and the L2s run slower than one after the other): off.
 # The target-image halves of the VGG criterions at the top of the step (beside encoders + generator): 38.9 -> 42.3 ms (meta-training),
 # 22.4 -> 24.1 ms (fine-tuning) -- large kernels beside large kernels again: off.  What pays is a branch of SMALL kernels beside a
-# branch of large ones.  LP_OVERLAP_{ENCODERS,CRITERIONS,OPTIMIZER,WGRAD,TARGETS} = 0 | 1 force; LP_OVERLAP=0 turns everything off.
+# branch of large ones -- e.g. the spectral-norm power iterations + weight packs of G and D (~40 short launches) beside the encoders:
+# 38.95 -> 38.62 ms, on (meta-training).  LP_OVERLAP_{ENCODERS,CRITERIONS,PREPARE,OPTIMIZER,WGRAD,TARGETS} = 0 | 1 force; LP_OVERLAP=0 turns
+# everything off.
 def enabled(t, what: str, finetuning: bool = False) -> bool:
     """``what``: 'encoders' (pose encoder beside the identity encoder) | 'criterions' (VGG stacks beside the discriminator pass, their
     target-image halves beside encoders + generator) | 'optimizer' (optimizer_G.step + EMA beside the discriminator backward) |
     'wgrad' (the identity encoder's weight gradients beside its data-gradient chain) | 'targets' (only the target-image halves of the
-    VGG criterions ahead of encoders + generator)"""
+    VGG criterions ahead of encoders + generator) | 'prepare' (spectral-norm power iterations + weight packs of G and D beside the encoders)"""
     if not (torch.is_tensor(t) and t.is_cuda) or os.environ.get('LP_OVERLAP', '1') == '0':
         return False
-    default = '0' if (what in ('optimizer', 'wgrad', 'targets') or (what == 'criterions' and finetuning)) else '1'
+    default = '0' if (what in ('optimizer', 'wgrad', 'targets') or (what in ('criterions', 'prepare') and finetuning)) else '1'
     return os.environ.get('LP_OVERLAP_' + what.upper(), default) != '0'
 
 
