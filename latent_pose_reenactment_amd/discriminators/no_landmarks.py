@@ -158,7 +158,7 @@ class Discriminator(nn.Module):
         self.__dict__['_prepared'] = (self._fresh_packs(), self._embed_batch().update(True)[0])
         self.__dict__['_prepared_passes'] = [self._sn_batch.update(True) for _ in range(3)]
 
-    def pass_inputs(self, x, embed=None, track_weights=True):
+    def pass_inputs(self, x, embed=None, track_weights=True, sn_states=None):
         """``track_weights=False``: the discriminator's own parameters are constants for autograd in this pass (gradients
         still flow to ``x`` and ``embed``)."""
         if not x.is_cuda:
@@ -168,7 +168,7 @@ class Discriminator(nn.Module):
         # have run the three iterations of this step ahead)
         layers = self._conv_sn_layers()
         ahead = self.__dict__.get('_prepared_passes')
-        st = ahead.pop(0) if ahead else self._sn_batch.update(self.training)
+        st = sn_states if sn_states is not None else (ahead.pop(0) if ahead else self._sn_batch.update(self.training))
         states = {id(l): s for l, s in zip(layers, st)}
         states['packs'] = self.__dict__.setdefault('_step_packs', {})
         xn = to_nhwc(x)
@@ -225,8 +225,24 @@ class Discriminator(nn.Module):
         # by optimizer_D.zero_grad() before loss_D.backward (runners/holycow.py:246-248) and no optimizer reads them, so they
         # are not computed unless ``keep_reference_waste`` asks for the reference's exact .grad side effects (parity tests).
         track1 = bool(getattr(self, 'keep_reference_waste', False))
-        fake_score_G, fake_features = self.pass_inputs(fake, embed if track1 else embed.detach(), track_weights=track1)
-        fake_score_D, _ = self.pass_inputs(fake.detach(), embed.detach())
-        real_score, real_features = self.pass_inputs(real, embed)
+        from latent_pose_reenactment_amd import streams
+        if self.training and torch.is_grad_enabled() and streams.enabled(fake, 'dpasses', finetuning=self.finetuning):
+            # the three passes are independent given the images and the label embedding: the two discriminator-side passes run on side
+            # streams beside the generator-side one, and -- autograd keeps a node on its forward stream -- their backward passes, the whole
+            # of loss_D.backward, run beside each other.  The power iterations keep their order: pass k gets the k-th iteration.
+            self._conv_sn_layers()
+            ahead = self.__dict__.pop('_prepared_passes', None)
+            sts = ahead if ahead else [self._sn_batch.update(True) for _ in range(3)]
+            with streams.branch(fake.device, 6) as b2:
+                fake_score_D, _ = self.pass_inputs(fake.detach(), embed.detach(), sn_states=sts[1])
+            with streams.branch(fake.device, 7) as b3:
+                real_score, real_features = self.pass_inputs(real, embed, sn_states=sts[2])
+            fake_score_G, fake_features = self.pass_inputs(fake, embed if track1 else embed.detach(), track_weights=track1, sn_states=sts[0])
+            b2.join(fake_score_D)
+            b3.join((real_score, real_features))
+        else:
+            fake_score_G, fake_features = self.pass_inputs(fake, embed if track1 else embed.detach(), track_weights=track1)
+            fake_score_D, _ = self.pass_inputs(fake.detach(), embed.detach())
+            real_score, real_features = self.pass_inputs(real, embed)
         data_dict.update(fake_features=fake_features, real_features=real_features, real_embedding=embed,
                          fake_score_G=fake_score_G, fake_score_D=fake_score_D, real_score=real_score)

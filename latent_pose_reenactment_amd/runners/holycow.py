@@ -13,6 +13,7 @@ import time
 import torch
 from torch import nn
 
+from latent_pose_reenactment_amd import streams as _streams
 from latent_pose_reenactment_amd.nn import fused_grad_accumulation
 from latent_pose_reenactment_amd.utils import radam as _radam
 from latent_pose_reenactment_amd.utils.utils import Meter, dict_to_device
@@ -216,6 +217,7 @@ def train_step(training_module, data_dict, target_dict, optimizer_G, optimizer_D
     optimizer_G.zero_grad()
     with fused_grad_accumulation():
         loss_G.backward(retain_graph=True)
+    _streams.join_all()
     if multi:
         reducer.reduce_generator_side(async_op=True)
     else:
@@ -224,6 +226,7 @@ def train_step(training_module, data_dict, target_dict, optimizer_G, optimizer_D
         optimizer_D.zero_grad()
         with fused_grad_accumulation():
             loss_D.backward()
+        _streams.join_all()
     if multi:
         reducer.wait_generator_side()
         optimizer_G.step()
@@ -352,6 +355,7 @@ class GraphedTrainStep:
             self.opt_G.zero_grad()
             with fused_grad_accumulation():
                 loss_G.backward(retain_graph=True)
+            _streams.join_all()
         pool = self.g1.pool()
         from latent_pose_reenactment_amd import streams
         first = next(iter(self.tm.generator.parameters()))
@@ -370,6 +374,7 @@ class GraphedTrainStep:
                 self.opt_D.zero_grad()
                 with fused_grad_accumulation():
                     loss_D.backward()
+                _streams.join_all()
                 if self.ema_in_g2:
                     b.join()
         else:
@@ -379,6 +384,7 @@ class GraphedTrainStep:
                 self.opt_D.zero_grad()
                 with fused_grad_accumulation():
                     loss_D.backward()
+                _streams.join_all()
             with torch.cuda.graph(self.g2b, pool=pool, **kw):
                 self.opt_G.step()
             self.reducer.reduce_discriminator_side()

@@ -22,16 +22,18 @@ _STREAMS = {}
 # The target-image halves of the VGG criterions at the top of the step (beside encoders + generator): 38.9 -> 42.3 ms (meta-training),
 # 22.4 -> 24.1 ms (fine-tuning) -- large kernels beside large kernels again: off.  What pays is a branch of SMALL kernels beside a
 # branch of large ones -- e.g. the spectral-norm power iterations + weight packs of G and D (~40 short launches) beside the encoders:
-# 38.95 -> 38.62 ms, on (meta-training).  LP_OVERLAP_{ENCODERS,CRITERIONS,PREPARE,OPTIMIZER,WGRAD,TARGETS} = 0 | 1 force; LP_OVERLAP=0 turns
+# 38.95 -> 38.62 ms, on (meta-training); the discriminator's three passes beside each other (forward and, through autograd, the whole of
+# loss_D.backward): 38.9 -> 37.4 ms, on (meta-training; fine-tuning 22.34 -> 22.09 ms, left off: that step stays a single-stream graph).  LP_OVERLAP_{ENCODERS,CRITERIONS,PREPARE,DPASSES,OPTIMIZER,WGRAD,TARGETS} = 0 | 1 force; LP_OVERLAP=0 turns
 # everything off.
 def enabled(t, what: str, finetuning: bool = False) -> bool:
     """``what``: 'encoders' (pose encoder beside the identity encoder) | 'criterions' (VGG stacks beside the discriminator pass, their
     target-image halves beside encoders + generator) | 'optimizer' (optimizer_G.step + EMA beside the discriminator backward) |
     'wgrad' (the identity encoder's weight gradients beside its data-gradient chain) | 'targets' (only the target-image halves of the
-    VGG criterions ahead of encoders + generator) | 'prepare' (spectral-norm power iterations + weight packs of G and D beside the encoders)"""
+    VGG criterions ahead of encoders + generator) | 'prepare' (spectral-norm power iterations + weight packs of G and D beside the encoders) | 'dpasses' (the discriminator's three
+    passes beside each other)"""
     if not (torch.is_tensor(t) and t.is_cuda) or os.environ.get('LP_OVERLAP', '1') == '0':
         return False
-    default = '0' if (what in ('optimizer', 'wgrad', 'targets') or (what in ('criterions', 'prepare') and finetuning)) else '1'
+    default = '0' if (what in ('optimizer', 'wgrad', 'targets') or (what in ('criterions', 'prepare', 'dpasses') and finetuning)) else '1'
     return os.environ.get('LP_OVERLAP_' + what.upper(), default) != '0'
 
 
@@ -57,6 +59,27 @@ def _tensors(obj):
     elif isinstance(obj, (tuple, list)):
         for v in obj:
             yield from _tensors(v)
+
+
+def join_all(device=None):
+    """make the current stream wait for every side stream (of ``device``) that has taken part so far.  Called after a backward pass: a
+    branch whose backward feeds nothing downstream (the discriminator's detached-input pass: its gradients are accumulated inside its own
+    kernels) is otherwise never waited for by autograd -- harmless in eager mode only until the next consumer of those gradients runs on
+    another stream, and an 'unjoined work' error at the end of a hipGraph capture.  Under capture only side streams that are themselves
+    part of the capture are waited for (waiting for an uncaptured stream would be an illegal dependency)."""
+    if not _STREAMS:
+        return
+    main = torch.cuda.current_stream(device)
+    dev = main.device.index or 0
+    capturing = torch.cuda.is_current_stream_capturing()
+    for (d, _), side in _STREAMS.items():
+        if d != dev:
+            continue
+        if capturing:
+            with torch.cuda.stream(side):
+                if not torch.cuda.is_current_stream_capturing():
+                    continue
+        main.wait_stream(side)
 
 
 @contextmanager

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'latent_pose_reenactment_amd'))
 pytestmark = pytest.mark.gpu
-KNOBS = ('LP_OVERLAP', 'LP_OVERLAP_ENCODERS', 'LP_OVERLAP_CRITERIONS', 'LP_OVERLAP_OPTIMIZER', 'LP_OVERLAP_WGRAD', 'LP_OVERLAP_TARGETS', 'LP_OVERLAP_PREPARE')
+KNOBS = ('LP_OVERLAP', 'LP_OVERLAP_ENCODERS', 'LP_OVERLAP_CRITERIONS', 'LP_OVERLAP_OPTIMIZER', 'LP_OVERLAP_WGRAD', 'LP_OVERLAP_TARGETS', 'LP_OVERLAP_PREPARE', 'LP_OVERLAP_DPASSES')
 
 
 def _iteration(monkeypatch, env):
