@@ -233,11 +233,13 @@ class Discriminator(nn.Module):
             self._conv_sn_layers()
             ahead = self.__dict__.pop('_prepared_passes', None)
             sts = ahead if ahead else [self._sn_batch.update(True) for _ in range(3)]
-            with streams.branch(fake.device, 6) as b2:
-                fake_score_D, _ = self.pass_inputs(fake.detach(), embed.detach(), sn_states=sts[1])
-            with streams.branch(fake.device, 7) as b3:
-                real_score, real_features = self.pass_inputs(real, embed, sn_states=sts[2])
+            # (issued in the reference's order -- the debug tape of the parity tests records ReLU sites in issue order -- from one fork point)
+            here = streams.fork_point(fake.device)
             fake_score_G, fake_features = self.pass_inputs(fake, embed if track1 else embed.detach(), track_weights=track1, sn_states=sts[0])
+            with streams.branch(fake.device, 6, after=here) as b2:
+                fake_score_D, _ = self.pass_inputs(fake.detach(), embed.detach(), sn_states=sts[1])
+            with streams.branch(fake.device, 7, after=here) as b3:
+                real_score, real_features = self.pass_inputs(real, embed, sn_states=sts[2])
             b2.join(fake_score_D)
             b3.join((real_score, real_features))
         else:

@@ -82,13 +82,23 @@ def join_all(device=None):
         main.wait_stream(side)
 
 
+def fork_point(device):
+    """an event at the current position of the current stream: ``branch(..., after=event)`` lets a side stream start from HERE even though
+    more work has been queued on the current stream in the meantime (the host issues the branches one after the other)"""
+    return torch.cuda.current_stream(device).record_event()
+
+
 @contextmanager
-def branch(device, index: int):
-    """``with branch(dev, i) as b: out = f(...)`` runs f on side stream i, ordered after everything queued on the current stream so far;
-    call ``b.join(out)`` (any time later, on the original stream) before the results are used there."""
+def branch(device, index: int, after=None):
+    """``with branch(dev, i) as b: out = f(...)`` runs f on side stream i, ordered after everything queued on the current stream so far
+    (or after the ``fork_point`` event ``after``); call ``b.join(out)`` (any time later, on the original stream) before the results are
+    used there."""
     main = torch.cuda.current_stream(device)
     side = side_stream(device, index)
-    side.wait_stream(main)
+    if after is not None:
+        side.wait_event(after)
+    else:
+        side.wait_stream(main)
     b = _Branch(main, side)
     with torch.cuda.stream(side):
         yield b
