@@ -381,6 +381,20 @@ def drive_fps(args, frames=60):
                                           '16-bit weight packs cached), frames resident in HBM'}
 
 
+def self_launch(n):
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    rc = subprocess.run(cmd, env=env).returncode
+    if rc:
+        raise SystemExit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -408,6 +422,10 @@ def main():
     if a.cpu_worker:
         return cpu_worker(a.cpu_worker)
 
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU under torch.distributed.run, rendezvous on
+        # 127.0.0.1, a free port) with the same command line; rank 0 of the job prints the JSON line on the inherited stdout
+        return self_launch(a.gpus)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -432,7 +450,7 @@ def main():
     tm, opt_G, opt_D, holycow = build(args)
     if world > 1:
         from latent_pose_reenactment_amd.parallel import GradReducer
-        tm.reducer = GradReducer(tm, finetune=finetune, optimizer_G=opt_G, optimizer_D=opt_D)
+        tm.reducer = GradReducer(tm, finetune=finetune, optimizer_G=opt_G, optimizer_D=opt_D, max_batch=a.batch)
     data, target = synthetic_batch(args, a.batch, seed=123 + rank)
 
     from latent_pose_reenactment_amd import hipops

@@ -37,6 +37,14 @@ def flat_broadcast(tensors, src: int = 0):
             torch._foreach_copy_(ts, views)
 
 
+def _mean_op():
+    """(reduce op, needs a divide afterwards): RCCL averages inside the collective (ReduceOp.AVG: no extra pass over a 256 MB arena);
+    gloo (functional tests only) has no AVG -- SUM, then one ``div_``"""
+    if dist.get_backend() == 'nccl':
+        return dist.ReduceOp.AVG, False
+    return dist.ReduceOp.SUM, True
+
+
 class _Bucket:
     def __init__(self, params: Iterable[torch.nn.Parameter], optimizer=None):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
@@ -46,6 +54,7 @@ class _Bucket:
         self.live: List[torch.nn.Parameter] = []
         self.optimizer = optimizer if hasattr(optimizer, 'ensure_flat') else None
         self.arena = None
+        self.divide = False
 
     def arena_slice_of(self, param):
         """(offset, numel) of ``param``'s gradient inside the optimizer's flat arena, or None"""
@@ -62,16 +71,17 @@ class _Bucket:
 
     def start(self, world_size: int, async_op: bool, skip=None):
         """``skip`` = (offset, numel): leave that slice of the arena out of the all-reduce (the caller rebuilds it)"""
+        op, self.divide = _mean_op()
         if self.optimizer is not None and len(self.optimizer.param_groups) == 1:
             # fused optimizers keep every gradient in one flat arena: reduce it in place, no gather/scatter
             self.arena = self.optimizer.ensure_flat(0)
             if skip is None:
-                self.handle = [dist.all_reduce(self.arena, op=dist.ReduceOp.SUM, async_op=async_op)]
+                self.handle = [dist.all_reduce(self.arena, op=op, async_op=async_op)]
                 self.parts = [self.arena]
             else:
                 off, n = skip
                 self.parts = [t for t in (self.arena[:off], self.arena[off + n:]) if t.numel()]
-                self.handle = [dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=async_op) for t in self.parts]
+                self.handle = [dist.all_reduce(t, op=op, async_op=async_op) for t in self.parts]
             if not async_op:
                 self.finish(world_size)
             return
@@ -82,7 +92,7 @@ class _Bucket:
         if self.flat is None or self.flat.numel() != n or self.flat.device != self.live[0].grad.device:
             self.flat = torch.empty(n, dtype=torch.float32, device=self.live[0].grad.device)
         torch.cat([p.grad.reshape(-1) for p in self.live], out=self.flat)      # one gather kernel instead of one copy per tensor
-        self.handle = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
+        self.handle = dist.all_reduce(self.flat, op=op, async_op=async_op)
         if not async_op:
             self.finish(world_size)
 
@@ -92,8 +102,9 @@ class _Bucket:
                 if h is not None and hasattr(h, 'wait'):
                     h.wait()          # (RCCL: the current stream waits for the collective's stream; the host does not block)
             self.handle = None
-            for t in self.parts:
-                t.div_(world_size)
+            if self.divide:
+                for t in self.parts:
+                    t.div_(world_size)
             self.arena = None
             return
         if not self.live:
@@ -101,7 +112,8 @@ class _Bucket:
         if self.handle is not None:
             self.handle.wait()
             self.handle = None
-        self.flat.div_(world_size)
+        if self.divide:
+            self.flat.div_(world_size)
         views, off = [], 0
         for p in self.live:
             k = p.grad.numel()
@@ -112,8 +124,10 @@ class _Bucket:
 
 
 class GradReducer:
-    def __init__(self, training_module, finetune: bool = False, broadcast: bool = True, optimizer_G=None, optimizer_D=None):
-        """``optimizer_G/_D`` (optional): the fused optimizers; their flat gradient arenas are then all-reduced in place."""
+    def __init__(self, training_module, finetune: bool = False, broadcast: bool = True, optimizer_G=None, optimizer_D=None,
+                 max_batch: Optional[int] = None):
+        """``optimizer_G/_D`` (optional): the fused optimizers; their flat gradient arenas are then all-reduced in place.
+        ``max_batch``: the largest per-rank batch (rows of the label-embedding exchange); None = agreed on at the first exchange."""
         self.world_size = dist.get_world_size()
         g_side = list(training_module.generator.parameters())
         if not finetune:
@@ -121,7 +135,7 @@ class GradReducer:
         self.g_bucket = _Bucket(g_side, optimizer_G)
         self.d_bucket = _Bucket(training_module.discriminator.parameters(), optimizer_D)
         self.discriminator = training_module.discriminator
-        self._checked_b = None
+        self.max_batch = max_batch
         if broadcast:        # apex Reducer broadcasts rank 0's parameters at construction
             # ONE flat collective per dtype instead of one per tensor (hundreds of tiny broadcasts).  Parameters only, like apex
             # (buffers / EMA stay rank-local) -- plus the (u, v) power-iteration buffers of the label embedding: the row-sparse
@@ -140,39 +154,46 @@ class GradReducer:
         self.g_bucket.finish(self.world_size)
 
     def reduce_discriminator_side(self, async_op: bool = False):
+        """All-reduce (mean) of the discriminator arena; the label-embedding slice is rebuilt from a row-sparse exchange.
+
+        The SEQUENCE AND SIZES of the collectives issued here depend only on state every rank shares: the exchange buffers
+        have a fixed capacity ``max_batch`` rows per rank -- the constructor argument, or the maximum over ranks of the first batch
+        (one int64 MAX all-reduce on every rank's FIRST call, unconditionally) -- and each rank publishes its own row count next to its
+        labels, so a ragged last batch on some ranks (b < capacity) needs no other collective: its unused rows are zero and add nothing.
+        Issue order: the two small exchanges first, then the arena all-reduce ASYNCHRONOUSLY on RCCL's stream, then the rebuild of the
+        embedding gradient on the compute stream while the arena is in flight; ``finish`` waits."""
         sparse = self._sparse_embedding()
         if sparse is None:
             self.d_bucket.start(self.world_size, async_op)
             return
         (off, n), (label, rows, coef, u, v) = sparse
         b, e = rows.shape
-        if self._checked_b != b:
-            # the exchange buffers are [world, B * E + 1]: every rank must bring the same B (a ragged last batch would mis-size the
-            # collective and hang).  Checked once per batch size; unequal sizes fall back to the dense all-reduce.
-            mm = torch.tensor([b, -b], dtype=torch.int64, device=rows.device)
+        if self.max_batch is None:
+            mm = torch.tensor([b], dtype=torch.int64, device=rows.device)
             dist.all_reduce(mm, op=dist.ReduceOp.MAX)
-            self._equal_b = bool(mm[0].item() == b and -mm[1].item() == b)
-            self._checked_b = b
-        if not self._equal_b:
-            self.d_bucket.start(self.world_size, async_op)
-            return
-        self.d_bucket.start(self.world_size, True, skip=(off, n))
-        # row-sparse exchange of the label-embedding gradient: one small all-reduce of a zero-padded fp32 [world, B*E + 1] buffer
-        # (gradient rows + rank-1 coefficient) and one of an int64 [world, B] buffer (the labels: exact for any label value)
+            self.max_batch = int(mm.item())
+        cap = self.max_batch
+        if b > cap:
+            raise RuntimeError(f'GradReducer: this rank brought {b} samples but the row-sparse exchange was sized for {cap} per rank at its '
+                               'first call; construct GradReducer(max_batch=<largest per-GPU batch>)')
         rank = dist.get_rank()
-        buf = torch.zeros(self.world_size, b * e + 1, dtype=rows.dtype, device=rows.device)
+        # fp32 [world, cap * E + 1]: gradient rows + rank-1 coefficient; int64 [world, cap]: the labels (exact for any label value; the
+        # padding rows carry label 0 and zero gradient rows).  Zero-padded all-reduces: gloo has no all_gather for device tensors.
+        buf = torch.zeros(self.world_size, cap * e + 1, dtype=rows.dtype, device=rows.device)
         buf[rank, :b * e] = rows.reshape(-1)
-        buf[rank, b * e] = coef.reshape(())
-        lab = torch.zeros(self.world_size, b, dtype=torch.int64, device=rows.device)
-        lab[rank] = label.to(torch.int64)
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
-        dist.all_reduce(lab, op=dist.ReduceOp.SUM)
+        buf[rank, cap * e] = coef.reshape(())
+        lab = torch.zeros(self.world_size, cap, dtype=torch.int64, device=rows.device)
+        lab[rank, :b] = label.to(torch.int64)
+        h1 = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
+        h2 = dist.all_reduce(lab, op=dist.ReduceOp.SUM, async_op=True)
+        self.d_bucket.start(self.world_size, True, skip=(off, n))
+        h1.wait(); h2.wait()          # (RCCL: stream dependencies, the host does not block; the arena all-reduce stays in flight)
         grad = self.d_bucket.arena[off:off + n].view(-1, e)
         inv = 1.0 / self.world_size
         grad.zero_()
         grad.addmm_((u * (-(buf[:, -1].sum() * inv)))[:, None], v[None, :])
         for r in range(self.world_size):                              # fixed order: every rank rebuilds the same bits
-            grad.index_add_(0, lab[r], buf[r, :b * e].view(b, e) * inv)
+            grad.index_add_(0, lab[r], buf[r, :cap * e].view(cap, e) * inv)
         if not async_op:
             self.d_bucket.finish(self.world_size)
 

@@ -138,7 +138,8 @@ def main():
         if 1 < args.num_gpus <= 8:
             from latent_pose_reenactment_amd.parallel import GradReducer
             training_module.reducer = GradReducer(training_module, finetune=args.finetune, broadcast=broadcast,
-                                                  optimizer_G=optimizer_G, optimizer_D=optimizer_D)
+                                                  optimizer_G=optimizer_G, optimizer_D=optimizer_D,
+                                                  max_batch=max(1, args.batch_size // args.num_gpus))
             training_module.__dict__['module'] = training_module
     attach_reducer(broadcast=True)
 

@@ -61,3 +61,21 @@ def test_recut_graph_step_equals_eager_data_parallel_step(tmp_path):
     assert [o for o in order if not isinstance(o, str) and o[1] == 'G'][0][2] is True, order          # async_op=True: RCCL's own stream
     d_side = [j for j, n_ in enumerate(names) if n_ == 'all_reduce:D-side']
     assert d_side and all(i['g2b'] < j < i['g3'] for j in d_side), order
+
+
+def test_bench_starts_its_own_ranks_from_plain_python():
+    """`python bench.py --gpus 2` with NO launcher and NO WORLD_SIZE in the environment (how the driver starts the N = 1 point) must start
+    its two ranks itself (bench.self_launch -> torch.distributed.run on 127.0.0.1) and print exactly ONE JSON line -- rank 0's -- on stdout.
+    gloo backend: the two ranks share the box's single GPU (RCCL refuses that); the collectives' sequence is the same."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--steps', '2', '--warmup', '1',
+                        '--image_size', '128', '--no-cpu-baseline', '--no-also', '--no-drive'], env=env, cwd=ROOT, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 2 and j['config']['global_batch'] == 16 and j['config']['parallelism'] == 'dp2' and j['value'] > 0, j
+    assert j['single_gpu_same_workload'].get('value', 0) > 0, j['single_gpu_same_workload']

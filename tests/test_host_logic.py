@@ -157,6 +157,18 @@ alld = [None] * W; dist.all_gather_object(alld, dense.tolist())
 want = sum(torch.tensor(d_) for d_ in alld) / W
 ok &= bool(torch.allclose(emb_grad, want, atol=1e-5))
 ok &= all(torch.allclose(p.grad, torch.full_like(p, mean)) for p in tm2.discriminator.lin.parameters())
+# ragged last batch (ADVICE r03): rank 0 brings 3 rows, every other rank 2 -- the collective sequence and sizes must not depend on the
+# rank-local row count (a rank-local guard collective would mismatch and hang); the capacity (3) was agreed on at the first exchange
+Br = B if rank == 0 else B - 1
+label2 = torch.randint(0, 5000, (Br,), generator=g); rows2 = torch.randn(Br, E, generator=g); coef2 = torch.randn((), generator=g)
+dense2 = torch.zeros(5000, E); dense2.index_add_(0, label2, rows2); dense2.addmm_((u * (-coef2))[:, None], v[None, :])
+oD2.flat.fill_(float(rank + 1)); emb_grad.fill_(float('nan'))
+tm2.discriminator._embed_parts = {'parts': (label2, rows2, coef2, u, v)}
+red3.reduce_discriminator_side()
+alld = [None] * W; dist.all_gather_object(alld, dense2.tolist())
+want = sum(torch.tensor(d_) for d_ in alld) / W
+ok &= bool(torch.allclose(emb_grad, want, atol=1e-5)) and red3.max_batch == B
+ok &= all(torch.allclose(p.grad, torch.full_like(p, mean)) for p in tm2.discriminator.lin.parameters())
 print('REDUCER_OK' if ok else 'REDUCER_FAIL', flush=True)
 dist.destroy_process_group()
 '''
