@@ -390,7 +390,16 @@ def self_launch(n):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    rc = subprocess.run(cmd, env=env).returncode
+    # stdout of the job is filtered to the JSON line(s): libraries of the ranks (gloo's "[Gloo] Rank 0 is connected ..." banner, launcher
+    # notices) also write there, and the driver reads stdout as ONE JSON line
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:
+        if line.lstrip().startswith('{'):
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
     if rc:
         raise SystemExit(rc)
 

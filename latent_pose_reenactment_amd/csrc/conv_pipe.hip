@@ -1,0 +1,276 @@
+// 3x3 implicit-GEMM convolution for gfx950, second main loop: a TAP-granular LDS-DMA pipeline with counted `s_waitcnt vmcnt(N)` (round 4).
+//
+// Same contraction, operand formats, zero-page padding, fused x2 upsampling and epilogue as conv_dma.hip (conv_common.h); what differs is how
+// the K loop is fed.  conv_dma_kernel stages one kernel ROW of weights per barrier, waits `vmcnt(0)` before every barrier (the DMA round trip
+// of a stage is exposed in the phase that issued it) and gives every wave 64 x 64 outputs.  Here:
+//   * the unit of the loop is one TAP of one 32-channel chunk: BN x 64 B of weights (8 KiB at BN = 128) in a ring of three slots; the weights
+//     of tap g+3 are issued right after the barrier of tap g and are only waited for at the barrier of tap g+2 -- two full taps of MFMA work
+//     (>= 1000 cycles) later -- with `s_waitcnt vmcnt(N)`, N = the DMA instructions that were issued AFTER the ones needed (a compile-time
+//     count: every wave issues the same number of pieces per tap and per halo), so DMA is never drained inside the loop;
+//   * the halo of the next chunk is issued at tap 0 of the current one into the other halo buffer (8 taps to land);
+//   * every wave multiplies AND issues DMA (no producer / consumer roles), one raw `s_barrier` per tap;
+//   * a wave owns 128 x 64 (MR = 8) or 64 x 64 (MR = 4) outputs; its A fragments are read in two halves per tap, each half one step ahead of the
+//     MFMAs that consume it, the B fragments of the next tap behind the barrier that publishes them;
+//   * 4-wave workgroups at <= 256 VGPRs and 72 KB of LDS: two of them share a CU, so one's epilogue (the fp32 / plane stores that nothing
+//     overlapped in the one-workgroup-per-CU ping-pong kernel) runs beside the other's K loop.
+// XOR swizzle of the lane-linear LDS images (applied to the DMA SOURCE address, undone by the fragment reads): weights: key (row >> 1) & 3 as
+// in conv_dma.hip; halo: key (hx >> 1) & 3 with hx the halo COLUMN -- 16 consecutive pixels of a patch row see the same key sequence as with
+// the pixel-index key (halo rows start at even pixel indices), and the address of a fragment read splits into a per-lane term per kernel
+// column (3 VGPRs), a wave-uniform row term and an immediate: one VALU add per ds_read_b128.
+// Covered: 3x3 (stride 1, optional fused x2 nearest upsampling), Cout >= 128, maps >= 32 x 32 whose tiling fills the chip, all three
+// precision modes; everything else stays on conv_dma_kernel (lp_conv_pipe_launch returns 0).
+#include "lp_common.h"
+#include "conv_common.h"
+#include "lp_hip.h"
+#include "lp_internal.h"
+#include <stdlib.h>
+
+static __device__ __attribute__((aligned(64))) unsigned int lp_zero_page_pipe[16];      // what out-of-image DMA lanes read
+
+__device__ __forceinline__ void lp_barrier_raw() { asm volatile("s_barrier" ::: "memory"); }
+
+template <bool UPS, int WM, int WN, int MR, int NR, int PREC, int AIT>
+__global__ __launch_bounds__(WM * WN * 64, (PREC == LP_PREC_BF16X3) ? 1 : 2)
+void conv_pipe_kernel(Conv16Params p) {
+    constexpr int ROWB = 64;                             // bytes per halo pixel / weight row of a 32-channel chunk
+    constexpr bool SPLIT = (PREC == LP_PREC_BF16X3), F16 = (PREC == LP_PREC_F16);
+    constexpr int NWAVE = WM * WN, BN = WN * NR * 16;
+    constexpr int B_TAP = BN * ROWB;                     // one tap's weights (hi)
+    constexpr int B_SLOT = B_TAP * (SPLIT ? 2 : 1);
+    constexpr int NQW = B_TAP / 1024 / NWAVE;            // 1 KiB weight pieces per wave and tap (hi)
+    constexpr int NBW = NQW * (SPLIT ? 2 : 1);           // weight DMA instructions per wave and tap
+    constexpr int NAW = AIT * (SPLIT ? 2 : 1);           // halo DMA instructions per wave and chunk (always AIT pieces: a static count)
+    constexpr int A_BYTES = AIT * NWAVE * 1024;          // one halo image (hi)
+    constexpr int A_BUF = A_BYTES * (SPLIT ? 2 : 1);
+    constexpr int MH = MR / 2;
+    constexpr int HW = UPS ? 10 : 18;                    // halo width of a 16-pixel-wide patch
+    static_assert(B_TAP % (1024 * NWAVE) == 0, "a tap's weights must be a whole number of DMA pieces per wave");
+    static_assert(MR % 2 == 0, "the A fragments are read in two halves");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int TH = 1 << p.lTH;                           // (host: lTW == 4, lNB == 0)
+
+    int t = (int)blockIdx.x;
+    const int tx = t % p.tiles_x; t /= p.tiles_x;
+    const int ty = t % p.tiles_y; const int n0 = t / p.tiles_y;
+    const int y0 = ty << p.lTH, x0 = tx << 4;
+    const int co0 = blockIdx.y * BN;
+    const int HH = UPS ? (TH >> 1) + 2 : TH + 2;
+    const int oy = UPS ? (y0 >> 1) - 1 : y0 - 1, ox = UPS ? (x0 >> 1) - 1 : x0 - 1;
+    const int halo_px = HH * HW;
+
+    unsigned char* const H_base = smem;                  // [halo 0][halo 1][slot 0][slot 1][slot 2]
+    unsigned char* const B_base = smem + 2 * A_BUF;
+
+    // ---- fragment addressing.  Tile rows are pixels of the TH x 16 patch in linear order: row m -> (py = m >> 4, px = m & 15); the 16 rows of
+    // an MFMA row block are one patch row, so py is wave-uniform per block and px = lane & 15.
+    const int kb = lane >> 4, l15 = lane & 15;
+    int acol[3];                                         // per-lane byte offset of the fragment slice inside its halo row, per kernel column
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+        const int hx = UPS ? ((l15 + dx - 1) >> 1) + 1 : l15 + dx;
+        acol[dx] = hx * ROWB + ((kb ^ ((hx >> 1) & 3)) << 4);
+    }
+    const int py0 = (wm * MR) & (TH - 1);                // patch row of the wave's first row block (uniform)
+    int b_addr[NR];
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) b_addr[nr] = (wn * (NR * 16) + nr * 16 + l15) * ROWB + ((kb ^ ((l15 >> 1) & 3)) << 4);
+
+    f32x4_t acc[MR][NR];
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr) acc[mr][nr] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // ---- DMA descriptors.  Halo piece q = k*NWAVE + wave covers halo pixels 16q .. 16q+15: lane -> pixel 16q + lane/4, LDS slot lane%4,
+    // which holds the 8-channel group slot ^ key(hx).  Weight piece q = j*NWAVE + wave covers rows 16q .. 16q+15 of the tap's [BN][32] tile.
+    int a_off[AIT];
+#pragma unroll
+    for (int k = 0; k < AIT; ++k) {
+        const int hp = (k * NWAVE + wave) * 16 + (lane >> 2);
+        const int hx = hp % HW, hy = hp / HW;
+        const int iy = oy + hy, ix = ox + hx;
+        const bool inb = (hp < halo_px) && (iy >= 0) && (iy < p.Hin) && (ix >= 0) && (ix < p.Win);
+        a_off[k] = inb ? (((n0 * p.Hin + iy) * p.Win + ix) * p.C8 + (((lane & 3) ^ ((hx >> 1) & 3)) << 3)) : -1;
+    }
+    int w_off[NQW];
+#pragma unroll
+    for (int j = 0; j < NQW; ++j) {
+        const int r = (j * NWAVE + wave) * 16 + (lane >> 2);
+        w_off[j] = (co0 + r) * p.CinP + (((lane & 3) ^ ((r >> 1) & 3)) << 3);
+    }
+    const uint16_t* zero16 = (const uint16_t*)lp_zero_page_pipe;
+    const size_t tap_stride = (size_t)p.CoutP * p.CinP;
+
+    auto issue_a = [&](int chunk, int buf) {
+        const int c0 = chunk * 32;
+        const unsigned dst = (unsigned)(uintptr_t)(H_base + buf * A_BUF);
+#pragma unroll
+        for (int k = 0; k < AIT; ++k) {
+            const bool ok = a_off[k] >= 0;
+            const size_t off = (size_t)(ok ? a_off[k] + c0 : 0);
+            const unsigned d = dst + (unsigned)((k * NWAVE + wave) * 1024);
+            lp_glds16(ok ? (p.a_hi + off) : zero16, d);
+            if (SPLIT) lp_glds16(ok ? (p.a_lo + off) : zero16, d + A_BYTES);
+        }
+    };
+    auto issue_w = [&](int chunk, int tap) {             // tap: compile-time after unrolling
+        const size_t base = (size_t)tap * tap_stride + (size_t)chunk * 32;
+        const unsigned dst = (unsigned)(uintptr_t)(B_base + (tap % 3) * B_SLOT);
+#pragma unroll
+        for (int j = 0; j < NQW; ++j) {
+            const unsigned d = dst + (unsigned)((j * NWAVE + wave) * 1024);
+            lp_glds16(p.w_hi + base + w_off[j], d);
+            if (SPLIT) lp_glds16(p.w_lo + base + w_off[j], d + B_TAP);
+        }
+    };
+
+    s16x8_t fbc[NR], fbn[NR], fa0[MH], fa1[MH];
+    s16x8_t fbcl[NR], fbnl[NR], fa0l[MH], fa1l[MH];
+    auto load_b = [&](s16x8_t (&fb)[NR], s16x8_t (&fbl)[NR], int tap) {
+        const unsigned char* Bk = B_base + (tap % 3) * B_SLOT;
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr) {
+            fb[nr] = *(const s16x8_t*)(Bk + b_addr[nr]);
+            if (SPLIT) fbl[nr] = *(const s16x8_t*)(Bk + B_TAP + b_addr[nr]);
+        }
+    };
+    auto load_a = [&](s16x8_t (&fa)[MH], s16x8_t (&fal)[MH], int half, int tap, const unsigned char* Hb) {
+        const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+        for (int i = 0; i < MH; ++i) {
+            const int py = py0 + half * MH + i;                          // uniform
+            const int row = UPS ? (((py + dy - 1) >> 1) + 1) * HW : (py + dy) * HW;
+            const int off = row * ROWB + acol[dx];
+            fa[i] = *(const s16x8_t*)(Hb + off);
+            if (SPLIT) fal[i] = *(const s16x8_t*)(Hb + A_BYTES + off);
+        }
+    };
+    auto mm = [&](int half, const s16x8_t (&fa)[MH], const s16x8_t (&fal)[MH], const s16x8_t (&fb)[NR], const s16x8_t (&fbl)[NR]) {
+#pragma unroll
+        for (int i = 0; i < MH; ++i)
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) {
+                f32x4_t& c = acc[half * MH + i][nr];
+                if (SPLIT) {
+                    c = mfma16(fal[i], fb[nr], c);
+                    c = mfma16(fa[i], fbl[nr], c);
+                }
+                c = mfma16t<F16>(fa[i], fb[nr], c);
+            }
+    };
+
+    const int nch = p.CinP / 32;
+    // ---- prologue: three taps of weights and the first halo; everything lands before the first fragment read
+    issue_w(0, 0); issue_w(0, 1); issue_w(0, 2);
+    issue_a(0, 0);
+    lp_wait_vm0();
+    lp_barrier_raw();
+    load_b(fbc, fbcl, 0);
+    load_a(fa0, fa0l, 0, 0, H_base);
+
+    for (int chunk = 0; chunk < nch; ++chunk) {
+        const unsigned char* Hc = H_base + (chunk & 1) * A_BUF;
+        const unsigned char* Hn = H_base + ((chunk + 1) & 1) * A_BUF;
+        const bool has_next = chunk + 1 < nch;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            // first half of the tap's MFMAs; the second half's A fragments are read beside them
+            load_a(fa1, fa1l, 1, tap, Hc);
+            mm(0, fa0, fa0l, fbc, fbcl);
+            // ---- sync point of step g = (chunk, tap): the weights of tap g+1 (every wave's pieces) have landed, and every wave is done with
+            // the slot of tap g (its fragments were read one step ago and consumed by the MFMAs above) and, at tap 0, with the other halo buffer.
+            // Allowed outstanding = DMA instructions issued after those of tap g+1: the weights of tap g+2 (issued one step ago) and, at taps
+            // 1 and 2, the next chunk's halo (issued at tap 0).
+            if (tap == 1 || tap == 2) { if (has_next) lp_wait_vm<NBW + NAW>(); else lp_wait_vm<NBW>(); }
+            else if (tap == 7) { if (has_next) lp_wait_vm<NBW>(); else lp_wait_vm0(); }
+            else if (tap == 8) { if (has_next) lp_wait_vm<NBW>(); }
+            else lp_wait_vm<NBW>();
+            lp_barrier_raw();
+            if (tap + 3 < 9) issue_w(chunk, tap + 3);
+            else if (has_next) issue_w(chunk + 1, tap + 3 - 9);
+            if (tap == 0 && has_next) issue_a(chunk + 1, (chunk + 1) & 1);
+            // (fa0 was consumed by the MFMAs above the barrier: the next tap's first half goes straight into it)
+            if (tap < 8) { load_b(fbn, fbnl, tap + 1); load_a(fa0, fa0l, 0, tap + 1, Hc); }
+            else if (has_next) { load_b(fbn, fbnl, 0); load_a(fa0, fa0l, 0, 0, Hn); }
+            mm(1, fa1, fa1l, fbc, fbcl);
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) { fbc[nr] = fbn[nr]; if (SPLIT) fbcl[nr] = fbnl[nr]; }
+        }
+    }
+    // ---- epilogue (conv_common.h; 16 rows through LDS at a time: 4.3 KB of scratch per wave)
+    conv16_epilogue<WM, WN, MR, NR, PREC, 1>(p, acc, smem, wave, wm, wn, lane, n0, y0, x0, co0, 1, (int)blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------------
+template <bool UPS, int WM, int WN, int MR, int NR, int PREC, int AIT>
+static int launch_pipe(Conv16Params& p, hipStream_t stream) {
+    constexpr int NWAVE = WM * WN, BM = WM * MR * 16, BN = WN * NR * 16;
+    constexpr bool SPLIT = (PREC == LP_PREC_BF16X3);
+    constexpr size_t A_BUF = (size_t)AIT * NWAVE * 1024 * (SPLIT ? 2 : 1), B_SLOT = (size_t)BN * 64 * (SPLIT ? 2 : 1);
+    p.lTW = 4; p.lNB = 0;
+    p.lTH = 0; while ((16 << (p.lTH + 1)) <= BM) ++p.lTH;               // TH = BM / 16
+    const int TH = 1 << p.lTH;
+    const int HH = UPS ? TH / 2 + 2 : TH + 2, HWc = UPS ? 10 : 18;
+    const int pieces = (HH * HWc + 15) / 16;
+    if ((pieces + NWAVE - 1) / NWAVE > AIT) return 0;
+    p.tiles_x = (p.W + 15) / 16; p.tiles_y = (p.H + TH - 1) / TH;
+    p.hit = AIT; p.a_dbuf = 1; p.ksplit = 1;
+    const int tiles = p.tiles_x * p.tiles_y * p.N;
+    size_t lds = 2 * A_BUF + 3 * B_SLOT;
+    const size_t epi = (size_t)NWAVE * 16 * (NR * 16 + 4) * sizeof(float);
+    if (lds < epi) lds = epi;
+    if (lds > 160 * 1024) return 0;
+    p.stats_rows = 0;
+    if (p.stats) {      // as conv_dma.hip: full tiles, every wave's MR*16 rows inside one image, coalesced epilogue, room in the buffer
+        constexpr int WR = MR * 16;
+        const long long rows = (long long)tiles * WM;
+        const bool ok = (p.H % TH == 0) && (p.W % 16 == 0) && ((p.Cout & 3) == 0) && rows * p.Cout * 3 <= p.stats_cap;
+        if (ok) p.stats_rows = (p.H * p.W) / WR; else p.stats = nullptr;
+    }
+    auto kern = conv_pipe_kernel<UPS, WM, WN, MR, NR, PREC, AIT>;
+    static thread_local int attr_dev = -1;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return lp_set_error(LP_ERR_HIP, "hipGetDevice failed");
+    if (attr_dev != dev) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return lp_set_error(LP_ERR_HIP, "hipFuncSetAttribute failed");
+        attr_dev = dev;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles, (p.Cout + BN - 1) / BN), dim3(NWAVE * 64), lds, stream, p);
+    const int rc = lp_check_launch("conv_pipe");
+    return rc ? rc : 1;
+}
+
+template <int PREC>
+static int pipe_dispatch(Conv16Params& p, int ups, int mr, hipStream_t s) {
+    if (ups) return mr == 8 ? launch_pipe<true, 2, 2, 8, 4, PREC, 2>(p, s) : launch_pipe<true, 2, 2, 4, 4, PREC, 1>(p, s);
+    return mr == 8 ? launch_pipe<false, 2, 2, 8, 4, PREC, 6>(p, s) : launch_pipe<false, 2, 2, 4, 4, PREC, 3>(p, s);
+}
+
+// -> 1: launched; 0: this layer is not covered (the caller runs conv_dma_kernel); < 0: error.  p: as filled by lp_conv16_fwd_stats.
+int lp_conv_pipe_launch(Conv16Params& p, int ups, int prec, hipStream_t s) {
+    static const int on = getenv("LP_CONV_PIPE") ? atoi(getenv("LP_CONV_PIPE")) : 1;
+    static const int mr_env = getenv("LP_CONV_PIPE_MR") ? atoi(getenv("LP_CONV_PIPE_MR")) : 0;      // 4 | 8 forces the rows per wave
+    if (!on || p.grouped) return 0;
+    if (p.Cout < 128 || (p.C8 & 31) || p.CinP % 32 || p.W < 16 || p.H < 16) return 0;
+    const long long coblk = (p.Cout + 127) / 128;
+    const long long t256 = (long long)((p.W + 15) / 16) * ((p.H + 15) / 16) * p.N * coblk;
+    const long long t128 = (long long)((p.W + 15) / 16) * ((p.H + 7) / 8) * p.N * coblk;
+    // 256 x 128 tiles (128 x 64 outputs per wave: fewest LDS fragment bytes per MFMA) when they still give every CU two workgroups;
+    // 128 x 128 tiles while those cover the chip; smaller layers keep the split-K path of conv_dma_kernel
+    int mr = 0;
+    if (t256 >= 480 && p.H >= 16) mr = 8;
+    else if (t128 >= 200) mr = 4;
+    if (mr_env == 8 || mr_env == 4) mr = mr_env;          // (test knob: any grid size)
+    if (!mr) return 0;
+    if (prec == LP_PREC_BF16) return pipe_dispatch<LP_PREC_BF16>(p, ups, mr, s);
+    if (prec == LP_PREC_BF16X3) return pipe_dispatch<LP_PREC_BF16X3>(p, ups, mr, s);
+    if (prec == LP_PREC_F16) return pipe_dispatch<LP_PREC_F16>(p, ups, mr, s);
+    return 0;
+}
