@@ -381,6 +381,35 @@ def drive_fps(args, frames=60):
                                           '16-bit weight packs cached), frames resident in HBM'}
 
 
+def encoder_modes(tm):
+    try:
+        m = tm.embedder.identity_encoder.block_precs()
+        n16 = sum(1 for v in m if v == 2)
+        head = {0: 'bf16', 1: 'bf16x3 (3 MFMAs per MAC)', 2: 'f16'}[m[0]]
+        return f'; identity encoder: {head} operands in its first {len(m) - n16} bottlenecks + stem, fp16 in the last {n16} (train-mode BatchNorm conditioning); pose encoder: bf16x3'
+    except Exception:
+        return ''
+
+
+def measured_parity(mode, workload):
+    """the parity statement of a precision assignment: MEASURED figures, written by tests/test_metatrain_full_gpu.py (the full configs[2]
+    forward at 256 x 256, 8 x 8 encoder frames, 98000 labels against fp64 stock encoders + the CPU oracle) into profiles/ -- never a literal"""
+    path = os.path.join(ROOT, 'profiles', f'r04_parity_configs2_{mode}.json')
+    try:
+        res = json.load(open(path))
+    except Exception:
+        return {'status': 'unmeasured', 'note': f'{os.path.relpath(path, ROOT)} not present: run tests/test_metatrain_full_gpu.py with LP_PARITY_OUT=profiles'}
+    worst = max(res['errors'].items(), key=lambda kv: kv[1])
+    out = {'status': 'measured', 'source': f'tests/test_metatrain_full_gpu.py -> {os.path.relpath(path, ROOT)}', 'geometry': res.get('geometry'),
+           'identity_encoder_fp16_tail_blocks': res['identity_encoder_blocks'].count('f16') if res['identity_encoder_blocks'][0] != 'f16' else 'all',
+           'rel_l2_vs_reference_chain': {k: float(f'{v:.3g}') for k, v in res['errors'].items()},
+           'worst': [worst[0], float(f'{worst[1]:.3g}')], 'within_1e-3': bool(worst[1] < 1e-3),
+           'stock_fp32_encoders_vs_fp64': res.get('stock_fp32_encoders_vs_fp64')}
+    if workload != 'metatrain_step':
+        out['note'] = 'figures of the meta-training configuration (this workload shares its generator, discriminator and criterions; its pose encoder runs without autograd)'
+    return out
+
+
 def self_launch(n):
     import socket
     import subprocess
@@ -634,7 +663,8 @@ def main():
             'value': round(imgs / dt, 3), 'unit': 'images/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': {'bf16x3': 'bf16x3 (hi+lo split bf16 MFMA operands, 3 MFMAs per MAC, fp32 accumulate)', 'bf16': 'bf16 (MFMA operands, fp32 accumulate)',
-                      'f16': 'f16 (IEEE fp16 MFMA operands incl. power-of-two scaled gradient operands, fp32 accumulate, fp32 activations/weights/optimizer)'}[a.prec],
+                      'f16': 'f16 (IEEE fp16 MFMA operands incl. power-of-two scaled gradient operands, fp32 accumulate, fp32 activations/weights/optimizer)'
+                             + (encoder_modes(tm) if a.workload == 'metatrain_step' else '')}[a.prec],
             'data': 'synthetic VoxCeleb2-shaped batch, random-init weights (VGG weights seeded He-normal)',
             'config': {'workload': {'finetune_step': 'finetuning-base.yaml step (configs[1]): G, D, VGG19/VGGFace criterions, RAdam, EMA, spectral '
                                                      'norm and the MobileNetV2 pose encoder on hand-written gfx950 kernels',
@@ -654,6 +684,8 @@ def main():
                                         'frac_of_bf16_peak': round(tf / (dt / a.steps) / (MFMA_BF16_PEAK_TFLOPS * world), 4),
                                         'note': 'useful dense 2*MAC of one step as executed (step_algorithmic_tflop) / ms_per_step / (2.5 PF x n_gpus)'}
         out.update(extra)
+        if a.workload != 'generator':
+            out['parity'] = measured_parity('default' if a.prec == 'f16' and not os.environ.get('LP_PREC_E') else a.prec, a.workload)
         if solo is not None:
             out['single_gpu_same_workload'] = solo
         if world == 1 and not a.no_drive:
@@ -674,9 +706,7 @@ def main():
                 j = child(['--prec', 'bf16x3', '--workload', a.workload])
                 out['strict_mode_bf16x3'] = {'value': j['value'], 'unit': j['unit'], 'ms_per_step': j['ms_per_step'],
                                              'roofline_frac': (j.get('roofline') or {}).get('frac'),
-                                             'parity': 'meets the full SURVEY 8(d) gate: outputs 2.5e-6, tie-masked gradients <= 2.4e-4 from the fp32 '
-                                                       'CPU path (tests/test_full_size_parity.py); the f16 headline meets the 1e-3 output gate '
-                                                       '(1.7e-4) but its gradients are 4e-4 .. 9e-3'}
+                                             'parity': measured_parity('bf16x3', a.workload)}
             except Exception as ex:
                 out['strict_mode_bf16x3'] = {'error': repr(ex)}
         if world == 1 and default_run and not a.no_also:

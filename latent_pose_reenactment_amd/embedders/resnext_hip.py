@@ -124,11 +124,17 @@ class ResNeXtFunction(torch.autograd.Function):
         y0, cs = _conv1x1(cols, packs['conv1.weight'][0], prec, stats=True)
         y0 = y0.view(n, h0, w0, 64)
         st0 = bn(y0, 'bn1', cs)
-        out, out16, idx = ops.bn_relu_maxpool(y0, st0.scale, st0.shift, prec, want_idx=need_grad)
+        bprecs = net.block_precs()          # operand mode per bottleneck (a bf16x3 head of the network, an fp16 tail: backbones.ResNeXt.block_precs)
+        out, out16, idx = ops.bn_relu_maxpool(y0, st0.scale, st0.shift, bprecs[0], want_idx=need_grad)
         saved_blocks = []
-        # ---- bottleneck blocks
-        y16 = Y16 and prec == PREC_F16
-        for bname, cin, width, cout, stride, down in net._hip_blocks:
+        # ---- bottleneck blocks.  Inside the loop ``prec`` is the block's own mode; the block output's operand planes are written in the
+        # mode of the block that consumes them.
+        base_prec = prec
+        for bi, (bname, cin, width, cout, stride, down) in enumerate(net._hip_blocks):
+            prec = bprecs[bi]
+            nprec = bprecs[bi + 1] if bi + 1 < len(bprecs) else prec
+            y16 = Y16 and prec == PREC_F16
+            assert not (y16 and nprec != PREC_F16), 'an fp16 block must be followed by fp16 blocks (lp_bn_add_act16 writes fp16 planes)'
             xin, xin16 = out, out16
             _, h, w, _ = xin.shape
             y1, cs = _conv1x1(xin16, packs[bname + '.conv1.weight'][0], prec, stats=True, y16=y16)
@@ -155,13 +161,14 @@ class ResNeXtFunction(torch.autograd.Function):
                 yd, cs = _conv1x1(xd16, packs[bname + '.downsample.0.weight'][0], prec, stats=True)
                 yd = yd.view(n, ho, wo, cout)
                 std = bn(yd, bname + '.downsample.1', cs)
-                out, out16 = ops.bn_add_act(y3, st3.scale, st3.shift, yd, std.scale, std.shift, relu=True, prec=prec)
+                out, out16 = ops.bn_add_act(y3, st3.scale, st3.shift, yd, std.scale, std.shift, relu=True, prec=nprec)
             else:
-                out, out16 = ops.bn_add_act(y3, st3.scale, st3.shift, xin, relu=True, prec=prec)
+                out, out16 = ops.bn_add_act(y3, st3.scale, st3.shift, xin, relu=True, prec=nprec)
             if need_grad:
                 # (the ReLU pattern of the block output: its operand planes in the 16-bit-resident mode, its fp32 copy otherwise)
-                saved_blocks.append((xin16, y1, st1, a1, y2, st2, a2, y3, st3, xd16, yd, std, out16 if y16 else out, (h, w, ho, wo)))
+                saved_blocks.append((xin16, y1, st1, a1, y2, st2, a2, y3, st3, xd16, yd, std, out16 if y16 else out, (h, w, ho, wo), prec))
         # ---- head
+        prec = base_prec
         _, hl, wl, cl = out.shape
         pooled = ops.spatial_mean(out)                                            # [N, 2048]
         fh, fw = ops.flat_hw(n)
@@ -186,7 +193,8 @@ class ResNeXtFunction(torch.autograd.Function):
         n = ctx.n
         grads = {}
 
-        def bn_bwd(dA, y, st, name, **kw):
+        def bn_bwd(dA, y, st, name, prec=None, **kw):
+            prec = net.prec if prec is None else prec
             # BatchNorm (+ ReLU) backward straight to the operand planes of dy: the only consumers are the two gradient contractions
             d16, dg, db, g = ops.bn_bwd16(dA, y, par[name + '.weight'].detach(), st.mean, st.rstd, st.scale, st.shift, prec=prec, frozen=frozen, **kw)
             grads[name + '.weight'], grads[name + '.bias'] = dg, db
@@ -216,21 +224,21 @@ class ResNeXtFunction(torch.autograd.Function):
         d_out = ops.spatial_mean_bwd(d_pooled, hl, wl)                            # [N, hl, wl, 2048]
         # ---- blocks, last to first
         for (bname, cin, width, cout, stride, down), sv in zip(reversed(net._hip_blocks), reversed(ctx.blocks)):
-            xin16, y1, st1, a1, y2, st2, a2, y3, st3, xd16, yd, std, out, (h, w, ho, wo) = sv
+            xin16, y1, st1, a1, y2, st2, a2, y3, st3, xd16, yd, std, out, (h, w, ho, wo), prec = sv       # prec: the block's own operand mode
             # out = relu(bn3(y3) + skip): g = d_out * [out > 0] reaches bn3 and the skip branch alike
-            d16, g = bn_bwd(d_out, y3, st3, bname + '.bn3', mask_mode=2, mask_src=out, want_g=not down)
+            d16, g = bn_bwd(d_out, y3, st3, bname + '.bn3', prec, mask_mode=2, mask_src=out, want_g=not down)
             wgrad(bname + '.conv3.weight', lambda a, d, k=bname + '.conv3.weight': _wgrad1x1(a, d, prec).view(par[k].shape), a2, d16)
             dA2 = _conv1x1(d16, packs[bname + '.conv3.weight'][1], prec).view(n, ho, wo, width)
-            d16, _ = bn_bwd(dA2, y2, st2, bname + '.bn2')
+            d16, _ = bn_bwd(dA2, y2, st2, bname + '.bn2', prec)
             if stride == 2:
                 d16 = ops.zero_stuff2_16(d16, h, w)                               # adjoint of the subsample of the full-resolution conv
             cg = par[bname + '.conv2.weight'].shape[1]
             wgrad(bname + '.conv2.weight', lambda a, d, cg=cg: ops.gconv_wgrad16(a, d, cg, prec=prec), a1, d16)
             dA1 = ops.gconv16(d16, packs[bname + '.conv2.weight'][1], prec=prec)
-            d16, _ = bn_bwd(dA1, y1, st1, bname + '.bn1')
+            d16, _ = bn_bwd(dA1, y1, st1, bname + '.bn1', prec)
             wgrad(bname + '.conv1.weight', lambda a, d, k=bname + '.conv1.weight': _wgrad1x1(a, d, prec).view(par[k].shape), xin16, d16)
             if down:
-                dd16, _ = bn_bwd(d_out, yd, std, bname + '.downsample.1', mask_mode=2, mask_src=out)      # same ReLU pattern as bn3: out > 0
+                dd16, _ = bn_bwd(d_out, yd, std, bname + '.downsample.1', prec, mask_mode=2, mask_src=out)      # same ReLU pattern as bn3: out > 0
                 wgrad(bname + '.downsample.0.weight', lambda a, d, k=bname + '.downsample.0.weight': _wgrad1x1(a, d, prec).view(par[k].shape), xd16, dd16)
                 d_xd = _conv1x1(dd16, packs[bname + '.downsample.0.weight'][1], prec)          # [P', cin]
                 if stride == 2:
@@ -242,6 +250,7 @@ class ResNeXtFunction(torch.autograd.Function):
                 d_xin = _conv1x1(d16, packs[bname + '.conv1.weight'][1], prec, res=g).view(n, h, w, cin)
             d_out = d_xin
         # ---- stem
+        prec = net.prec
         cols, y0, st0, idx, (h0, w0) = ctx.stem
         dA0 = ops.maxpool_bwd(d_out, idx, h0, w0)
         d16, _ = bn_bwd(dA0, y0, st0, 'bn1')

@@ -1,0 +1,117 @@
+"""BASELINE configs[2] at FULL size -- the step bench.py times: 256 x 256, 8 samples x 8 encoder frames through the ResNeXt-50 identity
+encoder and MobileNetV2 pose encoder in TRAIN-mode BatchNorm (as the reference holds them, runners/holycow.py:34-41), the generator, the
+discriminator with the 98000 x 512 label embedding, all six criterions of configs/default.yaml -- forward quantities of the HIP path
+against the reference chain restated on the same inputs and weights:
+    encoders : the stock layers of embedders/backbones.py in fp64 on the device (torchvision-compatible restatement; fp64 so that the
+               comparison is not limited by the reference arithmetic's own conditioning -- the stock fp32 layers are printed beside it),
+    G, D, losses : oracle/lp_oracle.py on the CPU (fp32, pinned by the reference goldens), fed with the REFERENCE embeddings.
+Gate (north_star): `embeds`, `pose_embedding`, `fake_rgbs`, `fake_segm` and every loss scalar within 1e-3 rel-L2 in the DEFAULT precision
+assignment (fp16 operands; identity encoder: bf16x3 with an fp16 tail, pose encoder bf16x3 -- what `python bench.py` runs), 1e-4-class in
+the strict mode.  bench.py reads the measured figures of this test from profiles/ for its parity statement."""
+import copy
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a = torch.as_tensor(a).detach().double().cpu(); b = torch.as_tensor(b).detach().double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def run(out_path):
+    """(child process: the precision environment is read at import)"""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'latent_pose_reenactment_amd'))
+    import bench
+    from embedders import backbones
+    from oracle import lp_oracle as O
+    prec = os.environ.get('LP_PREC', 'f16')
+    args = bench.make_args(256, 8, 'cuda', 1, 0, prec, finetune=False)
+    tm, _, _, _ = bench.build(args)
+    tm.embedder.pose_encoder.classifier[0].p = 0.0          # Dropout draws from the RNG stream: off on both sides
+    data, target = bench.synthetic_batch(args, 8, seed=123)
+    # reference-side copies BEFORE the forward (it advances the power iterations and the BatchNorm running statistics)
+    idt64 = copy.deepcopy(tm.embedder.identity_encoder).double()
+    pose64 = copy.deepcopy(tm.embedder.pose_encoder).double()
+    idt32, pose32 = copy.deepcopy(tm.embedder.identity_encoder), copy.deepcopy(tm.embedder.pose_encoder)
+    sdG = {k: v.detach().cpu().clone() for k, v in tm.generator.state_dict().items()}
+    sdD = {k: v.detach().cpu().clone() for k, v in tm.discriminator.state_dict().items()}
+    vgg = {}
+    for c in tm.criterion_list:
+        if hasattr(c, 'perceptual_crit'):
+            vgg['VGG'] = ({k: v.detach().cpu() for k, v in c.perceptual_crit.model.state_dict().items()}, c.perceptual_crit.weight)
+        if hasattr(c, 'idt_embed_crit'):
+            vgg['VGGFace'] = ({k: v.detach().cpu() for k, v in c.idt_embed_crit.model.state_dict().items()}, c.idt_embed_crit.weight)
+    all_data, lG, lD = tm(data, target)
+    torch.cuda.synchronize()
+    assert tm.embedder.identity_encoder.__dict__.get('_hip_param_names') is not None, 'the HIP identity encoder did not run'
+    # ---- reference encoders (stock layers, fp64 / fp32, train-mode BatchNorm)
+    enc = data['enc_rgbs']
+    b, k = enc.shape[:2]
+    frames, pose_in = enc.reshape(b * k, *enc.shape[2:]), data['pose_input_rgbs'][:, 0]
+    backbones.set_hip_forward(False)
+    try:
+        with torch.no_grad():
+            pf64 = idt64.train()(frames.double()).view(b, k, -1)
+            p64 = pose64.train()(pose_in.double())
+            pf32 = idt32.train()(frames).view(b, k, -1)
+            p32 = pose32.train()(pose_in)
+    finally:
+        backbones.set_hip_forward(True)
+    errs = {'embeds': rel(all_data['embeds'], pf64.mean(1)), 'embeds_elemwise': rel(all_data['embeds_elemwise'], pf64),
+            'pose_embedding': rel(all_data['pose_embedding'], p64)}
+    calib = {'embeds': rel(pf32.mean(1), pf64.mean(1)), 'pose_embedding': rel(p32, p64)}
+    # ---- reference generator, discriminator and criterions (CPU oracle, fp32) on the reference embeddings
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    with torch.no_grad():
+        per_frame = pf64.float().cpu()
+        embeds, pose = per_frame.mean(1), p64.float().cpu()
+        tgt = data['target_rgbs'][:, 0].cpu()
+        rgb, segm = O.generator_forward(sdG, embeds, pose, num_channels=64, max_num_channels=512, image_size=256, train=True)
+        out = O.discriminator_forward(sdD, rgb, tgt, target['label'].cpu(), image_size=256, dis_num_blocks=7, train=True, embed_eps=O.SN_EPS_CONV)
+        lg, ld = O.adversarial_gan(out['fake_score_G'], out['fake_score_D'], out['real_score'])
+        ref_losses = {'adversarial_G': lg, 'adversarial_D': ld,
+                      'feature_matching': O.feature_matching(out['fake_features'], out['real_features']),
+                      'VGGFace': O.perceptual_loss(vgg['VGGFace'][0], O.crop_and_resize_fixed(rgb), O.crop_and_resize_fixed(tgt), vgg['VGGFace'][1], O.VGG16_CFG),
+                      'VGG': O.perceptual_loss(vgg['VGG'][0], rgb, tgt, vgg['VGG'][1], O.VGG19_CFG),
+                      'segmentation_dice': O.dice(segm, target['real_segm'].cpu()),
+                      'embedding_matching': O.dis_embed(per_frame, out['real_embedding'], args.dis_embed_weight)}
+    errs['fake_rgbs'], errs['fake_segm'] = rel(all_data['fake_rgbs'], rgb), rel(all_data['fake_segm'], segm)
+    mine = {**lG, **lD}
+    assert set(mine) == set(ref_losses), (sorted(mine), sorted(ref_losses))
+    for name, v in ref_losses.items():
+        errs['loss.' + name] = rel(mine[name], v)
+    modes = [{0: 'bf16', 1: 'bf16x3', 2: 'f16'}[m] for m in tm.embedder.identity_encoder.block_precs()]
+    res = {'LP_PREC': prec, 'identity_encoder_blocks': modes, 'errors': errs, 'stock_fp32_encoders_vs_fp64': calib,
+           'geometry': '256x256, 8 samples x 8 encoder frames, 98000 labels, train-mode BatchNorm, default.yaml criterions'}
+    json.dump(res, open(out_path, 'w'))
+
+
+@pytest.mark.parametrize('mode,gate', [('default', 1e-3), ('bf16x3', 2e-4)])
+def test_full_size_metatrain_forward_vs_reference_chain(tmp_path, mode, gate):
+    env = {k: v for k, v in os.environ.items() if k not in ('LP_PREC', 'LP_PREC_E', 'LP_E_F16_TAIL')}
+    if mode != 'default':
+        env['LP_PREC'] = mode
+    out = str(tmp_path / 'res.json')
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), out], env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    res = json.load(open(out))
+    worst = sorted(res['errors'].items(), key=lambda kv: -kv[1])
+    print(f"[parity-configs2] mode {mode} (identity encoder blocks: {res['identity_encoder_blocks'].count('f16')} fp16 of {len(res['identity_encoder_blocks'])}): "
+          f"{[(k, f'{v:.2e}') for k, v in worst]} | stock fp32 encoders vs fp64: {res['stock_fp32_encoders_vs_fp64']}")
+    keep = os.environ.get('LP_PARITY_OUT')        # (scripts: copy the measured figures to profiles/)
+    if keep:
+        json.dump(res, open(os.path.join(keep, f'r04_parity_configs2_{mode}.json'), 'w'), indent=1)
+    bad = {k: v for k, v in res['errors'].items() if not v < gate}
+    assert not bad, bad
+
+
+if __name__ == '__main__':
+    run(sys.argv[1])
