@@ -501,7 +501,9 @@ extern "C" long long lp_conv16_fwd_workspace_bytes(int N, int H, int W, int Cout
     if (ksize != 3 || (Cout & 3)) return 0;
     const long long P = (long long)N * H * W;
     const long long wgs_lb = ((P + 255) / 256) * ((Cout + 127) / 128);
-    long long ks = 256 / wgs_lb; if (ks > 8) ks = 8;
+    static const int max_split = getenv("LP_CONV_KSPLIT") ? atoi(getenv("LP_CONV_KSPLIT")) : 8;         // (the knobs of launch_conv16)
+    static const int split_wgs = getenv("LP_CONV_SPLIT_WGS") ? atoi(getenv("LP_CONV_SPLIT_WGS")) : 256;
+    long long ks = split_wgs / wgs_lb; if (ks > max_split) ks = max_split;
     if (ks < 2) return 0;
     return ks * P * Cout * (long long)sizeof(float);
 }

@@ -17,8 +17,8 @@
 // in conv_dma.hip; halo: key (hx >> 1) & 3 with hx the halo COLUMN -- 16 consecutive pixels of a patch row see the same key sequence as with
 // the pixel-index key (halo rows start at even pixel indices), and the address of a fragment read splits into a per-lane term per kernel
 // column (3 VGPRs), a wave-uniform row term and an immediate: one VALU add per ds_read_b128.
-// Covered: 3x3 (stride 1, optional fused x2 nearest upsampling), Cout >= 128, maps >= 32 x 32 whose tiling fills the chip, all three
-// precision modes; everything else stays on conv_dma_kernel (lp_conv_pipe_launch returns 0).
+// Covered: 3x3 (stride 1, optional fused x2 nearest upsampling), Cout >= 128 (128-channel tiles) or 32 < Cout <= 64 (64-channel tiles), maps
+// whose tiling fills the chip, all three precision modes; everything else stays on conv_dma_kernel (lp_conv_pipe_launch returns 0).
 #include "lp_common.h"
 #include "conv_common.h"
 #include "lp_hip.h"
@@ -248,7 +248,10 @@ static int launch_pipe(Conv16Params& p, hipStream_t stream) {
 }
 
 template <int PREC>
-static int pipe_dispatch(Conv16Params& p, int ups, int mr, hipStream_t s) {
+static int pipe_dispatch(Conv16Params& p, int ups, int mr, int bn, hipStream_t s) {
+    if (bn == 64) {      // <= 64 output channels: 256 x 64 tiles, four waves of 64 x 64 (the layers bound by their output store: two workgroups per CU)
+        return ups ? launch_pipe<true, 4, 1, 4, 4, PREC, 2>(p, s) : launch_pipe<false, 4, 1, 4, 4, PREC, 6>(p, s);
+    }
     if (ups) return mr == 8 ? launch_pipe<true, 2, 2, 8, 4, PREC, 2>(p, s) : launch_pipe<true, 2, 2, 4, 4, PREC, 1>(p, s);
     return mr == 8 ? launch_pipe<false, 2, 2, 8, 4, PREC, 6>(p, s) : launch_pipe<false, 2, 2, 4, 4, PREC, 3>(p, s);
 }
@@ -256,21 +259,30 @@ static int pipe_dispatch(Conv16Params& p, int ups, int mr, hipStream_t s) {
 // -> 1: launched; 0: this layer is not covered (the caller runs conv_dma_kernel); < 0: error.  p: as filled by lp_conv16_fwd_stats.
 int lp_conv_pipe_launch(Conv16Params& p, int ups, int prec, hipStream_t s) {
     static const int on = getenv("LP_CONV_PIPE") ? atoi(getenv("LP_CONV_PIPE")) : 1;
-    static const int mr_env = getenv("LP_CONV_PIPE_MR") ? atoi(getenv("LP_CONV_PIPE_MR")) : 0;      // 4 | 8 forces the rows per wave
+    static const int mr_env = getenv("LP_CONV_PIPE_MR") ? atoi(getenv("LP_CONV_PIPE_MR")) : 0;      // 4 | 8 forces the rows per wave (test knob)
+    static const int n64 = getenv("LP_CONV_PIPE_N64") ? atoi(getenv("LP_CONV_PIPE_N64")) : 1;       // 0: <= 64-channel outputs stay on conv_dma_kernel
     if (!on || p.grouped) return 0;
-    if (p.Cout < 128 || (p.C8 & 31) || p.CinP % 32 || p.W < 16 || p.H < 16) return 0;
-    const long long coblk = (p.Cout + 127) / 128;
-    const long long t256 = (long long)((p.W + 15) / 16) * ((p.H + 15) / 16) * p.N * coblk;
-    const long long t128 = (long long)((p.W + 15) / 16) * ((p.H + 7) / 8) * p.N * coblk;
-    // 256 x 128 tiles (128 x 64 outputs per wave: fewest LDS fragment bytes per MFMA) when they still give every CU two workgroups;
-    // 128 x 128 tiles while those cover the chip; smaller layers keep the split-K path of conv_dma_kernel
-    int mr = 0;
-    if (t256 >= 480 && p.H >= 16) mr = 8;
-    else if (t128 >= 200) mr = 4;
-    if (mr_env == 8 || mr_env == 4) mr = mr_env;          // (test knob: any grid size)
-    if (!mr) return 0;
-    if (prec == LP_PREC_BF16) return pipe_dispatch<LP_PREC_BF16>(p, ups, mr, s);
-    if (prec == LP_PREC_BF16X3) return pipe_dispatch<LP_PREC_BF16X3>(p, ups, mr, s);
-    if (prec == LP_PREC_F16) return pipe_dispatch<LP_PREC_F16>(p, ups, mr, s);
+    if ((p.C8 & 31) || p.CinP % 32 || p.W < 16 || p.H < 16) return 0;
+    int mr = 0, bn = 128;
+    const long long px_tiles = (long long)((p.W + 15) / 16) * p.N;
+    if (p.Cout <= 64) {
+        if (!n64 || p.Cout < 32) return 0;                 // (the 4- / 3-channel head and RGB layers have their own kernels)
+        const long long t = px_tiles * ((p.H + 15) / 16);
+        if (t < 400 && !mr_env) return 0;
+        bn = 64; mr = 4;
+    } else {
+        if (p.Cout < 128) return 0;
+        const long long coblk = (p.Cout + 127) / 128;
+        const long long t256 = px_tiles * ((p.H + 15) / 16) * coblk, t128 = px_tiles * ((p.H + 7) / 8) * coblk;
+        // 256 x 128 tiles (128 x 64 outputs per wave: fewest LDS fragment bytes per MFMA) when they still give every CU two workgroups;
+        // 128 x 128 tiles while those cover the chip; smaller layers keep the split-K path of conv_dma_kernel
+        if (t256 >= 480) mr = 8;
+        else if (t128 >= 200) mr = 4;
+        if (mr_env == 8 || mr_env == 4) mr = mr_env;          // (test knob: any grid size)
+        if (!mr) return 0;
+    }
+    if (prec == LP_PREC_BF16) return pipe_dispatch<LP_PREC_BF16>(p, ups, mr, bn, s);
+    if (prec == LP_PREC_BF16X3) return pipe_dispatch<LP_PREC_BF16X3>(p, ups, mr, bn, s);
+    if (prec == LP_PREC_F16) return pipe_dispatch<LP_PREC_F16>(p, ups, mr, bn, s);
     return 0;
 }

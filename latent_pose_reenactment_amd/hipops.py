@@ -302,7 +302,7 @@ def thin_conv_supported(cin: int, cout: int, ksize: int, w: int) -> bool:
 
 
 def thin_conv(x: Tensor, pack: WeightPack, *, ksize: int, bias: Optional[Tensor] = None, alpha: Optional[Tensor] = None,
-              prec: int = PREC_BF16, out16: Optional[int] = None):
+              prec: int = PREC_BF16, out16: Optional[int] = None, out16_prec: Optional[int] = None):
     """conv with <= 4 input channels (RGB -> 64, dz -> 64) on the plain NHWC tensor (no input operand planes): fp32 VALU kernel, or --
     RGB 3x3 in the fp16 / bf16 modes -- one MFMA k-step per output block.  ``out16`` = 0 | 1: also return the operand planes of y
     (1: of relu(y)) -> (y, Act16); written by the same launch where the MFMA kernel runs, by a pack pass otherwise."""
@@ -310,7 +310,9 @@ def thin_conv(x: Tensor, pack: WeightPack, *, ksize: int, bias: Optional[Tensor]
     n, h, w, cin = x.shape
     cout = pack.rows
     y = torch.empty((n, h, w, cout), dtype=torch.float32, device=x.device)
-    fused = out16 is not None and bool(_lib.lib().lp_thin_conv_emits_planes(cin, cout, ksize, w, prec)) and _THIN_MFMA
+    # ``out16_prec``: operand mode of the emitted planes when it differs from this conv's own (a strict first layer feeding fp16 layers)
+    oprec = prec if out16_prec is None else out16_prec
+    fused = out16 is not None and oprec == prec and bool(_lib.lib().lp_thin_conv_emits_planes(cin, cout, ksize, w, prec)) and _THIN_MFMA
     o_hi = torch.empty((n, h, w, cout), dtype=torch.int16, device=x.device) if fused else None
     with _Timed('conv_thin', 2.0 * n * h * w * cout * cin * ksize * ksize, (n, h, w, cin, cout, ksize, 0, 0)):
         check(_lib.lib().lp_thin_conv_fwd(x.data_ptr(), pack.hi.data_ptr(), _p(pack.lo), y.data_ptr(), _p(bias), _p(alpha), n, h, w, cin,
@@ -320,7 +322,7 @@ def thin_conv(x: Tensor, pack: WeightPack, *, ksize: int, bias: Optional[Tensor]
         return y
     if fused:
         return y, Act16(o_hi, None, cout, None)
-    return y, act_pack(y, pro=2 if out16 else 0, prec=prec)
+    return y, act_pack(y, pro=2 if out16 else 0, prec=oprec)
 
 
 def conv(x: Tensor, pack: WeightPack, *, ksize: int, upsample: bool = False, pro: int = 0, scale: Optional[Tensor] = None,

@@ -766,7 +766,8 @@ class ConvFn(torch.autograd.Function):
         thin_w = need_w and ops.thin_wgrad_supported(cin, cout, ksize, pro, width)       # the weight gradient will want fp32 x
         a16 = x16
         if a16 is None and pro == 0 and res is None and ops.thin_conv_supported(cin, cout, ksize, width):
-            y = ops.thin_conv(x, pack, ksize=ksize, bias=bd, alpha=alpha, prec=prec, out16=None if emit is None else emit[0])
+            y = ops.thin_conv(x, pack, ksize=ksize, bias=bd, alpha=alpha, prec=prec, out16=None if emit is None else emit[0],
+                              out16_prec=None if emit is None or len(emit) < 3 else emit[2])
             if emit is not None:
                 y, o16 = y
                 emit[1].append(o16)
@@ -839,15 +840,16 @@ class ConvFn(torch.autograd.Function):
         return dx, dw, db, dres, None, None, None, None, None, None, None
 
 
-def hip_conv(x, w, bias=None, res=None, ksize=3, pro=0, prec=None, packs=None, sn=None, x16=None, emit16=None):
+def hip_conv(x, w, bias=None, res=None, ksize=3, pro=0, prec=None, packs=None, sn=None, x16=None, emit16=None, emit_prec=None):
     """``x16``: existing operand planes of act(x); ``emit16`` = 0 | 1: also return the operand planes of y (1: of relu(y)), written
-    by the conv's epilogue -> ``(y, Act16)``."""
+    by the conv's epilogue -> ``(y, Act16)``; ``emit_prec``: their operand mode when the consumer's differs from this conv's ``prec``
+    (thin-channel first layers only)."""
     prec = default_prec() if prec is None else prec
     _TAPE_GRAD[0] = torch.is_grad_enabled()
     if emit16 is None:
         return ConvFn.apply(x, w, bias, res, ksize, pro, prec, packs, sn, x16, None)
     holder = []
-    y = ConvFn.apply(x, w, bias, res, ksize, pro, prec, packs, sn, x16, (int(emit16), holder))
+    y = ConvFn.apply(x, w, bias, res, ksize, pro, prec, packs, sn, x16, (int(emit16), holder) + (() if emit_prec is None else (emit_prec,)))
     return y, holder[0]
 
 

@@ -45,6 +45,9 @@ CASES = [  # N, H, W, Cin, Cout, ups, bias, res, mask, out16 (None | 0 | 1), sta
     (1, 32, 32, 32, 128, 1, 1, 0, 0, None, 0, 1),          # ONE chunk (the loop's tail logic from the first step on)
     (1, 32, 64, 256, 128, 0, 0, 0, 0, 1, 1, 0),            # eight chunks, planes-only output
     (2, 48, 32, 160, 256, 1, 1, 1, 0, 0, 0, 1),            # upsampled, ragged rows, five chunks
+    (2, 32, 48, 64, 64, 0, 1, 1, 1, 1, 1, 1),              # 64-channel tiles (256 x 64, four waves of 64 x 64): every epilogue option
+    (1, 64, 64, 128, 64, 1, 0, 1, 0, 0, 1, 1),             # 64-channel tiles, fused upsampling
+    (3, 40, 16, 96, 48, 0, 1, 0, 0, None, 0, 1),           # 48 output channels (masked channel tail), ragged rows
 ]
 
 

@@ -475,7 +475,11 @@ def _install_backbones():
 META_SEED = 21
 
 
-def make_metatrain_step(train_bn=False):
+sys.path.insert(0, os.path.dirname(OUT))
+from golden_inputs import metatrain_big_batch          # noqa: E402  (seeded inputs shared with tests/test_metatrain_step.py)
+
+
+def make_metatrain_step(train_bn=False, big=False):
     """runners/holycow.run_epoch for ONE batch of the META-TRAINING configuration (configs/default.yaml: criterions idt_embed,
     perceptual, adversarial, featmat, dis_embed, dice; Adam; embedder parameters in optimizer_G; many labels), reduced size, with
     the reference's own TrainingModule / get_optimizer / Embedder.  torchvision is absent, so the reference's embedder receives this
@@ -487,6 +491,12 @@ def make_metatrain_step(train_bn=False):
     from embedders import unsupervised_pose_separate_embResNeXt_segmentation as ref_emb
     out = {}
     args = small_args()
+    if big:
+        # third fixture (round 4): a geometry the HIP ENCODER kernels accept (resnext_hip.supported / mobilenet_hip.supported: >= 128 px,
+        # >= 8 frames) -- 128 x 128, 16 samples x 4 encoder frames (BatchNorm statistics over 64 / 16 frames: as well conditioned as the real workload), both encoders in train mode -- so that the reference's run_epoch pins
+        # the hand-written identity / pose encoders, not their stock-layer fallback.  Inputs are seeded on both sides (checksums stored).
+        assert train_bn
+        args.image_size = 128
     args.average_function = 'sum'; args.optimizer = 'Adam'; args.lr_gen = 5e-5; args.lr_dis = 2e-4; args.beta1 = 0.0
     args.finetune = False; args.num_gpus = 1; args.detailed_metrics = True; args.gan_type = 'gan'
     torch.manual_seed(META_SEED)
@@ -511,17 +521,23 @@ def make_metatrain_step(train_bn=False):
     for nm, mod in (('G', tm.generator), ('D', tm.discriminator)):
         out.update(sd_np(mod, f'init.{nm}.'))
     g = torch.Generator().manual_seed(5)
-    data = {'enc_rgbs': torch.rand(2, 2, 3, 32, 32, generator=g), 'pose_input_rgbs': torch.rand(2, 1, 3, 32, 32, generator=g),
-            'target_rgbs': torch.rand(2, 1, 3, 32, 32, generator=g)}
-    target = {'real_segm': torch.rand(2, 1, 1, 32, 32, generator=g).expand(2, 1, 3, 32, 32).contiguous(), 'label': torch.tensor([3, 1])}
-    for k, v in {**data, **target}.items():
-        out['init.in.' + k] = npy(v)
+    if big:
+        data, target = metatrain_big_batch()
+        out['init.in.checksum'] = np.array([float(v.double().sum()) for v in list(data.values()) + [target['real_segm']]])
+        out['init.in.label'] = npy(target['label'])
+    else:
+        data = {'enc_rgbs': torch.rand(2, 2, 3, 32, 32, generator=g), 'pose_input_rgbs': torch.rand(2, 1, 3, 32, 32, generator=g),
+                'target_rgbs': torch.rand(2, 1, 3, 32, 32, generator=g)}
+        target = {'real_segm': torch.rand(2, 1, 1, 32, 32, generator=g).expand(2, 1, 3, 32, 32).contiguous(), 'label': torch.tensor([3, 1])}
+        for k, v in {**data, **target}.items():
+            out['init.in.' + k] = npy(v)
     captured = {}
     orig_fwd = tm.embedder.forward
 
     def rec_fwd(d):
         orig_fwd(d)
         captured['embeds'] = d['embeds'].detach().clone(); captured['pose'] = d['pose_embedding'].detach().clone()
+        captured['elemwise'] = d['embeds_elemwise'].detach().clone()
     tm.embedder.forward = rec_fwd
     args.device = 'cpu'
     meters = []
@@ -557,7 +573,9 @@ def make_metatrain_step(train_bn=False):
         out['E.buffer_norms'] = np.array([float(b.double().norm()) for k, b in tm.embedder.named_buffers() if 'running' in k])
         # keep the fixture small: the generator / discriminator states are pinned by the eval-mode fixture already
         out = {k: v for k, v in out.items() if not (k.startswith('after.') and ('.weight_orig' in k or 'weight_u' in k or 'weight_v' in k) and v.size > 4096)}
-    name = 'metatrain_step_trainbn_small.npz' if train_bn else 'metatrain_step_small.npz'
+    if big:
+        out['embeds_elemwise'] = npy(captured['elemwise'])
+    name = 'metatrain_step_128.npz' if big else 'metatrain_step_trainbn_small.npz' if train_bn else 'metatrain_step_small.npz'
     np.savez_compressed(os.path.join(OUT, name), **out)
     print(name, len(out), 'arrays; losses', {k: float(v) for k, v in out.items() if k.startswith('loss.')})
 
@@ -657,9 +675,13 @@ def make_fsth_plus():
 
 if __name__ == '__main__':
     torch.set_num_threads(1)
-    which = sys.argv[1:] or ['ops', 'generator', 'discriminator', 'perceptual', 'train_step', 'metatrain_step', 'metatrain_step_trainbn', 'checkpoint', 'fsth_plus']
+    which = sys.argv[1:] or ['ops', 'generator', 'discriminator', 'perceptual', 'train_step', 'metatrain_step', 'metatrain_step_trainbn', 'metatrain_step_128', 'checkpoint', 'fsth_plus']
     for w in which:
         if w == 'metatrain_step_trainbn':
             make_metatrain_step(train_bn=True)
+        elif w == 'metatrain_step_128':
+            torch.set_num_threads(8)
+            make_metatrain_step(train_bn=True, big=True)
+            torch.set_num_threads(1)
         else:
             globals()['make_' + w]()

@@ -171,3 +171,103 @@ def test_metatrain_step_hip_embedder_vs_stock_layers(monkeypatch):
     print('[parity] meta-train step, train-mode encoders, HIP vs stock layers:', {k: f'{v:.2e}' for k, v in errs.items()}, f'encoder-gradient cosine {cos:.4f}')
     assert all(v < 2e-3 for v in errs.values()), errs
     assert cos > 0.9, cos
+
+
+@pytest.mark.parametrize('mode', ['default', 'bf16x3'])
+def test_metatrain_128_reference_golden_runs_the_hip_encoders(monkeypatch, mode):
+    """The reference's own run_epoch at a geometry the HAND-WRITTEN encoders accept (tests/golden/metatrain_step_128.npz, written by
+    make_golden.py::make_metatrain_step(big=True) from /root/reference: 128 x 128, 16 samples x 4 encoder frames, BOTH encoders in train
+    mode): `embeds`, the pose vector, all seven losses, the updated generator / discriminator / EMA states and the encoders' BatchNorm
+    running statistics after the step -- in the DEFAULT precision assignment (fp16 operands; identity encoder bf16x3 head + fp16 tail;
+    what bench.py times) and in the strict mode.  The HIP encoders must actually run (asserted)."""
+    for k in ('LP_PREC', 'LP_PREC_E', 'LP_E_F16_TAIL'):
+        monkeypatch.delenv(k, raising=False)
+    if mode != 'default':
+        monkeypatch.setenv('LP_PREC', mode)
+    z = dict(np.load(os.path.join(ROOT, 'tests', 'golden', 'metatrain_step_128.npz')))
+    zv = dict(np.load(os.path.join(ROOT, 'tests', 'golden', 'perceptual_small.npz')))
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from golden_inputs import metatrain_big_batch
+    from generators.vector_pose_unsupervised_segmentation_noBottleneck import Wrapper as GW
+    from embedders.unsupervised_pose_separate_embResNeXt_segmentation import Wrapper as EW
+    from discriminators.no_landmarks import Wrapper as DW
+    from criterions import adversarial, featmat, dice, dis_embed, idt_embed, perceptual
+    from criterions.common.perceptual_loss import PerceptualLoss
+    from runners import holycow
+    a = argparse.Namespace(image_size=128, num_channels=4, max_num_channels=16, embed_channels=8, pose_embedding_size=4, in_channels=3,
+                           out_channels=3, num_labels=5, dis_num_blocks=5, gen_padding='zero', norm_layer='in', gen_constant_input_size=4,
+                           gen_num_residual_blocks=2, dis_padding='zero', device='cuda', optimizer='Adam', lr_gen=5e-5, lr_dis=2e-4,
+                           beta1=0.0, finetune=False, num_gpus=1, average_function='sum')
+    a_cpu = argparse.Namespace(**{**vars(a), 'device': 'cpu'})
+    torch.manual_seed(META_SEED)
+    E = EW.get_net(a_cpu)
+    chk = np.array([float(sum(p.detach().double().sum() for p in E.parameters())), float(sum((p.detach().double() ** 2).sum() for p in E.parameters()))])
+    assert np.allclose(chk, z['E.checksum'], rtol=1e-9), (chk, z['E.checksum'])
+    E = E.cuda()
+    G, D = GW.get_net(a), DW.get_net(a)
+    G.load_state_dict({k[len('init.G.'):]: torch.from_numpy(v) for k, v in z.items() if k.startswith('init.G.')})
+    D.load_state_dict({k[len('init.D.'):]: torch.from_numpy(v) for k, v in z.items() if k.startswith('init.D.')})
+    div = int(zv['width_div'])
+    p19 = perceptual.Criterion.__new__(perceptual.Criterion); torch.nn.Module.__init__(p19)
+    p19.perceptual_crit = PerceptualLoss(3e-2, '/nonexistent', 'caffe', synthetic_seed=0, width_div=div)
+    p19.perceptual_crit.model.load_state_dict({k[len('vgg19.'):]: torch.from_numpy(v) for k, v in zv.items()
+                                               if k.startswith('vgg19.') and int(k.split('.')[1]) < 30})
+    pf = idt_embed.Criterion.__new__(idt_embed.Criterion); torch.nn.Module.__init__(pf)
+    pf.idt_embed_crit = PerceptualLoss(6e-3, '/nonexistent', 'face', synthetic_seed=0, width_div=div).eval()
+    pf.idt_embed_crit.model.load_state_dict({k[len('vggface.'):]: torch.from_numpy(v) for k, v in zv.items()
+                                             if k.startswith('vggface.') and int(k.split('.')[1]) < 30})
+    crits = [pf.cuda(), p19.cuda(), adversarial.Criterion('gan'), featmat.Criterion(10.0), dis_embed.Criterion(1e-2), dice.Criterion(1.0)]
+    tm = holycow.TrainingModule(E, G, D, crits, [], {})
+    opt_G = holycow.get_optimizer(tm.embedder, tm.generator, a)
+    opt_D = DW.get_optimizer(tm.discriminator, a)
+    tm.train()
+    tm.embedder.pose_encoder.classifier[0].p = 0.0
+    data, target = metatrain_big_batch()
+    chk_in = np.array([float(v.double().sum()) for v in list(data.values()) + [target['real_segm']]])
+    assert np.allclose(chk_in, z['init.in.checksum'], rtol=1e-9) and np.array_equal(target['label'].numpy(), z['init.in.label'])
+    data = {k: v.cuda() for k, v in data.items()}
+    target = {k: v.cuda() for k, v in target.items()}
+    all_data, lG, lD = holycow.train_step(tm, data, target, opt_G, opt_D, a)
+    torch.cuda.synchronize()
+    assert E.identity_encoder.__dict__.get('_hip_param_names') is not None, 'the HIP identity encoder did not run'
+    assert E.pose_encoder.__dict__.get('_hip_feature_param_names') is not None, 'the HIP pose encoder did not run'
+    errs = {'embeds': rel(all_data['embeds'], z['embeds']), 'embeds_elemwise': rel(all_data['embeds_elemwise'], z['embeds_elemwise']),
+            'pose_embedding': rel(all_data['pose_embedding'], z['pose_embedding'])}
+    for name, v in {**lG, **lD}.items():
+        errs['loss.' + name] = rel(v, z['loss.' + name])
+    # states after ONE Adam step (beta1 = 0: every element moves by at most lr, so two correct runs differ by at most 2 lr on an element whose
+    # ~0 gradient flips sign; EMA copies by 2 lr * (1 - 0.999)), plus fp32 rounding of the stored value itself
+    state_abs = {}
+    for nm, mod, lr in (('G', tm.generator, a.lr_gen), ('D', tm.discriminator, a.lr_dis), ('G_ema', tm.running_averages['generator'], a.lr_gen * 1e-3)):
+        for k, v in mod.state_dict().items():
+            key = f'after.{nm}.{k}'
+            if key in z and v.dtype.is_floating_point:
+                ref = torch.from_numpy(z[key]).double()
+                state_abs[f'{nm}.{k}'] = float(((v.detach().cpu().double() - ref).abs() / (2 * lr + 1e-6 * (1 + ref.abs()))).max())
+    norms = np.array([float(b.double().norm()) for k, b in tm.embedder.named_buffers() if 'running' in k])
+    errs['E.running_statistics'] = float(np.abs(norms - z['E.buffer_norms']).max() / np.abs(z['E.buffer_norms']).max())
+    gp = torch.Generator().manual_seed(9)
+    summ = []
+    for p_ in tm.embedder.parameters():
+        r = torch.randn(p_.shape, generator=gp)
+        gr = p_.grad.detach().cpu() if p_.grad is not None else torch.zeros(p_.shape)
+        summ.append([float(gr.double().norm()), float((gr.double() * r.double()).sum())])
+    summ = np.array(summ)
+    e_gn = float(np.linalg.norm(summ[:, 0] - z['E.grad_summary'][:, 0]) / np.linalg.norm(z['E.grad_summary'][:, 0]))
+    worst_state = max(state_abs.items(), key=lambda kv: kv[1])
+    print(f'[parity] 128-px meta-train golden, HIP encoders, mode {mode}:', {k: f'{v:.2e}' for k, v in sorted(errs.items(), key=lambda kv: -kv[1])},
+          f'| encoder gradient norms {e_gn:.2e} (reported) | worst state |delta| / (2 lr + fp32 eps): {worst_state[0]} {worst_state[1]:.2f}')
+    # forward quantities: north_star's 1e-3 in the default assignment (the reference run is fp32 on the CPU).  The VGG terms are gated in the
+    # strict mode only: the fixture's narrow VGG shim (make_golden.py: width / 16, N(0, 0.35) weights) produces activations of 1e5 .. 1e6 at
+    # 128 px -- beyond the fp16 range (operand conversion saturates at 65504), which real VGG weights on [0, 255] images do not reach; the
+    # full-width stacks are gated in fp16 by tests/test_full_size_parity.py and tests/test_metatrain_full_gpu.py.
+    # Measured (MI355X): default  embeds 5e-4, per-frame logits (embeds_elemwise, before the mean over a sample's frames) 1.4e-3, pose vector
+    # 6e-4, losses <= 4e-4;  strict  embeds 3e-4, per-frame 8e-4, pose 6e-4, losses <= 3e-5.  The per-frame logits of the fp16-tail
+    # assignment get 3e-3 here (64 frames of 128 px are worse conditioned than the workload's 64 frames of 256 px, where they are 6e-4:
+    # tests/test_metatrain_full_gpu.py carries the 1e-3 gate at the real geometry).
+    skip = ('loss.VGG', 'loss.VGGFace') if mode == 'default' else ()
+    gates = {'embeds_elemwise': 3e-3} if mode == 'default' else {}
+    assert all(np.isfinite(v) for v in errs.values()), errs
+    bad = {k: v for k, v in errs.items() if k not in skip and not v < gates.get(k, 1e-3)}
+    assert not bad, bad
+    assert worst_state[1] <= 1.03, worst_state
