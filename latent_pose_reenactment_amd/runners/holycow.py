@@ -153,6 +153,20 @@ class TrainingModule(nn.Module):
         # encoder's weight gradients are never consumed: run it without autograd (bit-identical parameters afterwards).
         with torch.set_grad_enabled(torch.is_grad_enabled() and not getattr(generator, 'finetuning', False)):
             embedder(data_dict)
+        # ``_ebwd_cut`` (set by train_step / GraphedTrainStep, one GPU, meta-training): the autograd graph is CUT behind the embedder -- the
+        # generator, discriminator and criterions see leaf copies of its outputs, loss_G.backward stops there, and ``embedder_backward()``
+        # later continues into the encoders with the gradients those leaves collected.  Same arithmetic; it lets the encoders' backward
+        # (bandwidth-bound kernels) run BESIDE loss_D.backward (the discriminator's convolutions) instead of in front of it.
+        cut = None
+        if self.__dict__.get('_ebwd_cut') and torch.is_grad_enabled() and self.compute_losses and not ft:
+            cut = {}
+            for k in ('embeds', 'embeds_elemwise', 'pose_embedding'):
+                v = data_dict.get(k)
+                if torch.is_tensor(v) and v.requires_grad:
+                    leaf = v.detach().requires_grad_(True)
+                    cut[k] = (v, leaf)
+                    data_dict[k] = leaf
+        self.__dict__['_ebwd_pending'] = cut
         if prep is not None:
             prep.join()
         generator(data_dict)
@@ -193,6 +207,17 @@ class TrainingModule(nn.Module):
                 raise TypeError(f'Unexpected type of {type(criterion)} output: expected dict or tuple of two dicts, got {type(out)}')
         return data_dict, losses_G, losses_D
 
+    def embedder_backward(self):
+        """second half of a cut backward pass (see ``forward``): from the gradients loss_G.backward left on the embedder-output leaves into
+        the encoders; a no-op when the last forward was not cut"""
+        cut = self.__dict__.pop('_ebwd_pending', None)
+        if not cut:
+            return
+        outs = [v for v, leaf in cut.values() if leaf.grad is not None]
+        grads = [leaf.grad for v, leaf in cut.values() if leaf.grad is not None]
+        if outs:
+            torch.autograd.backward(outs, grads)
+
     def compute_metrics(self, data_dict):
         meter = Meter()
         for metric in self.metric_list:
@@ -209,15 +234,40 @@ def train_step(training_module, data_dict, target_dict, optimizer_G, optimizer_D
     overlaps zero_grad(D) + loss_D.backward; optimizer_G.step waits for it.  Moving optimizer_G.step behind loss_D.backward is
     result-identical: loss_D depends on fake.detach() and on tensors the discriminator saved in the forward pass, never on the
     generator's parameters or gradients (the reference reduces, steps G, then runs the D backward, holycow.py:239-250)."""
-    all_data, losses_G, losses_D = training_module(data_dict, target_dict)
-    loss_G = sum(v for v in losses_G.values() if isinstance(v, torch.Tensor))
-    loss_D = sum(v for v in losses_D.values() if isinstance(v, torch.Tensor))
     reducer = getattr(training_module, 'reducer', None)
     multi = 1 < args.num_gpus <= 8 and reducer is not None
+    ebwd = _ebwd_enabled(training_module, args, multi)
+    training_module.__dict__['_ebwd_cut'] = ebwd
+    try:
+        all_data, losses_G, losses_D = training_module(data_dict, target_dict)
+    finally:
+        training_module.__dict__['_ebwd_cut'] = False          # (only this step's forward is cut: other callers get the plain graph)
+    loss_G = sum(v for v in losses_G.values() if isinstance(v, torch.Tensor))
+    loss_D = sum(v for v in losses_D.values() if isinstance(v, torch.Tensor))
     optimizer_G.zero_grad()
     with fused_grad_accumulation():
         loss_G.backward(retain_graph=True)
     _streams.join_all()
+    if ebwd and losses_D:
+        # one GPU, meta-training: the encoders' half of the generator-side backward runs beside the discriminator-side backward
+        # (``TrainingModule.forward`` cut the graph behind the embedder).  loss_D.backward is CALLED from a side stream: autograd orders
+        # every node behind the stream the root gradient lives on, which must not be the stream the encoders' backward is queued on.
+        dev = next(training_module.generator.parameters()).device
+        with _streams.branch(dev, 8) as b:
+            optimizer_D.zero_grad()
+            with fused_grad_accumulation():
+                loss_D.backward()
+            _streams.join_all()
+        with fused_grad_accumulation():
+            training_module.embedder_backward()
+        _streams.join_all()
+        b.join()
+        optimizer_G.step()
+        optimizer_D.step()
+        training_module.update_running_average(0.972 if args.finetune else 0.999)
+        return all_data, losses_G, losses_D
+    with fused_grad_accumulation():
+        training_module.embedder_backward()          # (cut without a discriminator-side loss: finish the backward pass here)
     if multi:
         reducer.reduce_generator_side(async_op=True)
     else:
@@ -236,6 +286,15 @@ def train_step(training_module, data_dict, target_dict, optimizer_G, optimizer_D
         optimizer_D.step()
     training_module.update_running_average(0.972 if args.finetune else 0.999)
     return all_data, losses_G, losses_D
+
+
+def _ebwd_enabled(training_module, args, multi):
+    """encoders' backward beside loss_D.backward: one GPU (the data-parallel step keeps the generator-side gradients in ONE backward pass so
+    that their all-reduce can start early), meta-training (fine-tuning trains no encoder), training mode, LP_OVERLAP_EBWD != 0"""
+    if multi or getattr(args, 'finetune', False) or not training_module.training:
+        return False
+    p = next(training_module.generator.parameters(), None)
+    return p is not None and _streams.enabled(p, 'ebwd', finetuning=False)
 
 
 GRAPH_WARMUP_ITERATIONS = 3      # eager iterations before the step is captured (lazy state: optimizer moments, packs, MIOpen plans)
@@ -347,9 +406,14 @@ class GraphedTrainStep:
         kw = dict(stream=side, capture_error_mode='thread_local')
         # capture on the stream the warm-up ran on: the AccumulateGrad nodes autograd keeps per parameter stay on one stream
         # thread_local error mode: CUDA calls of OTHER threads (the RCCL watchdog polling its events) must not invalidate the capture
+        self.ebwd = _ebwd_enabled(self.tm, args, self.reducer is not None)
+        self.tm.__dict__['_ebwd_cut'] = self.ebwd
         self.g1 = G()
         with torch.cuda.graph(self.g1, **kw):
-            self.all_data, self.losses_G, self.losses_D = self.tm(self.data, self.target)
+            try:
+                self.all_data, self.losses_G, self.losses_D = self.tm(self.data, self.target)
+            finally:
+                self.tm.__dict__['_ebwd_cut'] = False
             loss_G = sum(v for v in self.losses_G.values() if isinstance(v, torch.Tensor))
             loss_D = sum(v for v in self.losses_D.values() if isinstance(v, torch.Tensor))
             self.opt_G.zero_grad()
@@ -362,9 +426,27 @@ class GraphedTrainStep:
         # one GPU: optimizer_G.step and the EMA of embedder + generator touch nothing the discriminator backward reads or writes
         # (train_step's docstring), so they run on a side stream beside it; g3 is then optimizer_D.step alone
         self.ema_in_g2 = self.reducer is None and streams.enabled(first, 'optimizer')
-        if self.reducer is None:
+        if self.reducer is None and self.ebwd and self.losses_D:
+            # g2: the encoders' backward (main path) beside zero_grad(D) + loss_D.backward (side path, called from its own stream: see
+            # train_step), then optimizer_G.step
+            self.ema_in_g2 = False
             self.g2 = G()
             with torch.cuda.graph(self.g2, pool=pool, **kw):
+                with streams.branch(first.device, 8) as b:
+                    self.opt_D.zero_grad()
+                    with fused_grad_accumulation():
+                        loss_D.backward()
+                    _streams.join_all()
+                with fused_grad_accumulation():
+                    self.tm.embedder_backward()
+                _streams.join_all()
+                b.join()
+                self.opt_G.step()
+        elif self.reducer is None:
+            self.g2 = G()
+            with torch.cuda.graph(self.g2, pool=pool, **kw):
+                with fused_grad_accumulation():
+                    self.tm.embedder_backward()          # (a cut forward without a discriminator-side loss: finish the backward pass; else a no-op)
                 if self.ema_in_g2:
                     with streams.branch(first.device, 3) as b:
                         self.opt_G.step()

@@ -30,10 +30,13 @@ def enabled(t, what: str, finetuning: bool = False) -> bool:
     target-image halves beside encoders + generator) | 'optimizer' (optimizer_G.step + EMA beside the discriminator backward) |
     'wgrad' (the identity encoder's weight gradients beside its data-gradient chain) | 'targets' (only the target-image halves of the
     VGG criterions ahead of encoders + generator) | 'prepare' (spectral-norm power iterations + weight packs of G and D beside the encoders) | 'dpasses' (the discriminator's three
-    passes beside each other)"""
+    passes beside each other) | 'ebwd' (one GPU, meta-training: the encoders' backward beside loss_D.backward -- runners/holycow.py cuts the
+    autograd graph behind the embedder)"""
     if not (torch.is_tensor(t) and t.is_cuda) or os.environ.get('LP_OVERLAP', '1') == '0':
         return False
-    default = '0' if (what in ('optimizer', 'wgrad', 'targets') or (what in ('criterions', 'prepare', 'dpasses') and finetuning)) else '1'
+    # 'ebwd': measured null on the captured full-size step (42.9 / 43.5 ms on vs 43.4 / 43.5 ms off, profiles/r04_stream_overlap.txt): the
+    # encoders' backward and the discriminator's backward are both bound by HBM traffic -- off
+    default = '0' if (what in ('optimizer', 'wgrad', 'targets', 'ebwd') or (what in ('criterions', 'prepare', 'dpasses') and finetuning)) else '1'
     return os.environ.get('LP_OVERLAP_' + what.upper(), default) != '0'
 
 
@@ -73,7 +76,7 @@ def join_all(device=None):
     dev = main.device.index or 0
     capturing = torch.cuda.is_current_stream_capturing()
     for (d, _), side in _STREAMS.items():
-        if d != dev:
+        if d != dev or side == main:          # (called from inside a branch: a stream does not wait for itself)
             continue
         if capturing:
             with torch.cuda.stream(side):
