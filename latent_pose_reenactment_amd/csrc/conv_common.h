@@ -27,8 +27,23 @@ struct Conv16Params {
                                   // the weight image then has 64 columns (CinP = 64) and the activation channel offset is co0
 };
 
+static inline int ilog2_floor(int v) { int l = 0; while ((1 << (l + 1)) <= v) ++l; return l; }
+
+// choose NB x TH x TW = BM with TH<=H, TW<=W (powers of two), preferring wide patches (TW up to 16)
+static inline void choose_tile(int BM, int N, int H, int W, int* lTH, int* lTW, int* lNB) {
+    int lbm = ilog2_floor(BM);
+    int ltw = ilog2_floor(W); if (ltw > 4) ltw = 4;
+    int lth = ilog2_floor(H); if (lth > lbm - ltw) lth = lbm - ltw;
+    if (lth < 1) lth = 1;
+    if (ltw < 1) ltw = 1;
+    int lnb = lbm - ltw - lth; if (lnb < 0) lnb = 0;
+    while (lnb > 0 && (1 << (lnb - 1)) >= N) --lnb;      // no more images per tile than exist (keeps the LDS halo small)
+    *lTH = lth; *lTW = ltw; *lNB = lnb;
+}
+
 // conv_pipe.hip: the tap-pipelined 3x3 kernel.  -> 1: launched; 0: layer not covered (run conv_dma_kernel); < 0: error
 int lp_conv_pipe_launch(Conv16Params& p, int ups, int prec, hipStream_t s);
+int lp_conv1x1_pipe_launch(Conv16Params& p, int prec, hipStream_t s);      // the chunk-pipelined 1x1 kernel
 
 // Epilogue of a conv workgroup.  acc[MR][NR]: the wave's (MR*16) x (NR*16) block in the MFMA 16x16 C layout (col = lane&15 = channel,
 // row = (lane>>4)*4 + reg = tile row); wave (wm, wn) of a WM x WN group whose tile starts at image n0, pixel (y0, x0), channel co0; `wave_d`

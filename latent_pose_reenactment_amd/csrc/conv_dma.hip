@@ -334,20 +334,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(Conv16Params p) {
 // ------------------------------------------------------------------------------------------------------------------
 // host side: tile selection + dispatch
 // ------------------------------------------------------------------------------------------------------------------
-static int ilog2_floor(int v) { int l = 0; while ((1 << (l + 1)) <= v) ++l; return l; }
-
-// choose NB x TH x TW = BM with TH<=H, TW<=W (powers of two), preferring wide patches (TW up to 16)
-static void choose_tile(int BM, int N, int H, int W, int* lTH, int* lTW, int* lNB) {
-    int lbm = ilog2_floor(BM);
-    int ltw = ilog2_floor(W); if (ltw > 4) ltw = 4;
-    int lth = ilog2_floor(H); if (lth > lbm - ltw) lth = lbm - ltw;
-    if (lth < 1) lth = 1;
-    if (ltw < 1) ltw = 1;
-    int lnb = lbm - ltw - lth; if (lnb < 0) lnb = 0;
-    while (lnb > 0 && (1 << (lnb - 1)) >= N) --lnb;      // no more images per tile than exist (keeps the LDS halo small)
-    *lTH = lth; *lTW = ltw; *lNB = lnb;
-}
-
 template <int KS, bool UPS, int WM, int WN, int MR, int NR, int PREC, bool PP, int NBUF = 2, int CC = 32>
 static int launch_v(Conv16Params& p, size_t lds, dim3 grid, hipStream_t stream) {
     auto kern = conv_dma_kernel<KS, UPS, WM, WN, MR, NR, PREC, PP, NBUF, CC>;
@@ -446,8 +432,12 @@ static int launch_conv16(Conv16Params& p, hipStream_t stream) {
 
 template <int PREC>
 static int dispatch_conv16(Conv16Params& p, int ks, int ups, hipStream_t s) {
-    if (ks == 3) {      // the tap-pipelined kernel (conv_pipe.hip) takes the layers it covers: Cout >= 128, maps whose tiling fills the chip
+    if (ks == 3) {      // the tap-pipelined kernel (conv_pipe.hip) takes the layers it covers: maps whose tiling fills the chip
         const int r = lp_conv_pipe_launch(p, ups, PREC, s);
+        if (r) return r < 0 ? r : LP_OK;
+    }
+    if (ks == 1 && !ups) {      // the chunk-pipelined 1x1 kernel: layers with >= 256 workgroups
+        const int r = lp_conv1x1_pipe_launch(p, PREC, s);
         if (r) return r < 0 ? r : LP_OK;
     }
     const bool big_img = p.H * p.W >= 256;     // a 256-pixel patch fits inside one image

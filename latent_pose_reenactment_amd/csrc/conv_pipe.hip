@@ -206,6 +206,189 @@ void conv_pipe_kernel(Conv16Params p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// 1x1 convs (the encoders' pointwise layers on flattened pixels, the generator's / critic's skip convs): the same idea without taps.
+// conv_dma_kernel<1> stages a 32-channel chunk ONE stage ahead and drains vmcnt(0) per chunk, so a workgroup's life is (Cin / 32) DMA
+// round trips in sequence -- 2 .. 8 of them for the layers that carry the bytes (Cin 64 .. 256 at 65 k .. 262 k pixels), each 1 - 2 us under
+// load against 0.1 - 0.35 us of MFMA work: the layers ran at 2 TB/s of algorithmic traffic.  Here a chunk = {BM x 64 B of activations, BN x 64 B
+// of weights} goes into a ring of R slots, the first R chunks are issued back to back in the prologue (everything a small layer needs is in
+// flight at once), chunk c+R-1 is issued behind the barrier of chunk c, and the only waits are counted `vmcnt`.  One barrier per chunk.
+template <int WM, int WN, int PREC, int R>
+__global__ __launch_bounds__(256, (PREC == LP_PREC_BF16X3) ? 1 : 2)
+void conv1x1_pipe_kernel(Conv16Params p) {
+    constexpr int ROWB = 64, MR = 4, NR = 4, NWAVE = 4;
+    static_assert(WM * WN == NWAVE, "four waves");
+    constexpr bool SPLIT = (PREC == LP_PREC_BF16X3), F16 = (PREC == LP_PREC_F16);
+    constexpr int BM = WM * 64, BN = WN * 64;
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;          // one chunk (hi)
+    constexpr int NPA = A_BYTES / 1024 / NWAVE, NPB = B_BYTES / 1024 / NWAVE;
+    constexpr int NPC = (NPA + NPB) * (SPLIT ? 2 : 1);              // DMA instructions per wave and chunk
+    constexpr int SLOT = (A_BYTES + B_BYTES) * (SPLIT ? 2 : 1);    // [A hi][A lo][B hi][B lo]
+    constexpr int B_OFF = A_BYTES * (SPLIT ? 2 : 1);
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int NBv = 1 << p.lNB;
+    int t = (int)blockIdx.x;
+    const int tx = t % p.tiles_x; t /= p.tiles_x;
+    const int ty = t % p.tiles_y; const int ng = t / p.tiles_y;
+    const int n0 = ng << p.lNB, y0 = ty << p.lTH, x0 = tx << p.lTW;
+    const int co0 = blockIdx.y * BN;
+
+    const int kb = lane >> 4, l15 = lane & 15;
+    const int fkey = (kb ^ ((l15 >> 1) & 3)) << 4;                   // swizzled slot of this lane's fragment slice (row & 15 == lane & 15)
+    int a_addr[MR], b_addr[NR];
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr) a_addr[mr] = (wm * 64 + mr * 16 + l15) * ROWB + fkey;
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) b_addr[nr] = B_OFF + (wn * 64 + nr * 16 + l15) * ROWB + fkey;
+
+    f32x4_t acc[MR][NR];
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr) acc[mr][nr] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // DMA descriptors: piece q = k*4 + wave covers tile rows 16q .. 16q+15 (lane -> row 16q + lane/4, slot lane%4 holding channel group
+    // slot ^ key(row)); the key only depends on the lane (16q is a multiple of 8)
+    const int g8 = ((lane & 3) ^ ((lane >> 3) & 3)) << 3;
+    int a_off[NPA], w_off[NPB];
+#pragma unroll
+    for (int k = 0; k < NPA; ++k) {
+        const int m = (k * NWAVE + wave) * 16 + (lane >> 2);
+        int nb, py, px;
+        tile_row_linear(m, p.lTH, p.lTW, nb, py, px);
+        const int n = n0 + nb, iy = y0 + py, ix = x0 + px;
+        const bool inb = (nb < NBv) && (n < p.N) && (iy < p.H) && (ix < p.W);
+        a_off[k] = inb ? (((n * p.H + iy) * p.W + ix) * p.C8 + g8) : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < NPB; ++j) w_off[j] = (co0 + (j * NWAVE + wave) * 16 + (lane >> 2)) * p.CinP + g8;
+    const uint16_t* zero16 = (const uint16_t*)lp_zero_page_pipe;
+
+    auto issue = [&](int chunk, int slot) {
+        const int c0 = chunk * 32;
+        const bool cok = (c0 + g8) < p.C8;
+        const unsigned dst = (unsigned)(uintptr_t)(smem + slot * SLOT);
+#pragma unroll
+        for (int k = 0; k < NPA; ++k) {
+            const bool ok = cok && a_off[k] >= 0;
+            const size_t off = (size_t)(ok ? a_off[k] + c0 : 0);
+            const unsigned d = dst + (unsigned)((k * NWAVE + wave) * 1024);
+            lp_glds16(ok ? (p.a_hi + off) : zero16, d);
+            if (SPLIT) lp_glds16(ok ? (p.a_lo + off) : zero16, d + A_BYTES);
+        }
+#pragma unroll
+        for (int j = 0; j < NPB; ++j) {
+            const unsigned d = dst + B_OFF + (unsigned)((j * NWAVE + wave) * 1024);
+            lp_glds16(p.w_hi + w_off[j] + c0, d);
+            if (SPLIT) lp_glds16(p.w_lo + w_off[j] + c0, d + B_BYTES);
+        }
+    };
+
+    const int nch = p.CinP / 32;
+    const int npro = nch < R - 1 ? nch : R - 1;                      // chunks 0 .. R-2 in the prologue; chunk c+R-1 behind the barrier of chunk c
+    for (int c = 0; c < npro; ++c) issue(c, c);
+    int slot = 0;
+    for (int c = 0; c < nch; ++c) {
+        // chunk c must have landed; issued after it so far: chunks c+1 .. min(c+R-2, nch-1)
+        const int newer = min(R - 2, nch - 1 - c);
+        if (newer >= R - 2) lp_wait_vm<(R - 2) * NPC>();
+        else if (R > 3 && newer == 1) lp_wait_vm<NPC>();
+        else if (R > 4 && newer == 2) lp_wait_vm<2 * NPC>();
+        else lp_wait_vm0();
+        lp_barrier_raw();                                            // every wave's pieces of chunk c are in; everyone is done with chunk c-1
+        if (c + R - 1 < nch) issue(c + R - 1, (slot + R - 1) % R);   // into the slot chunk c-1 used
+        const unsigned char* S = smem + slot * SLOT;
+        s16x8_t fa[MR], fb[NR], fal[MR], fbl[NR];
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) {
+            fa[mr] = *(const s16x8_t*)(S + a_addr[mr]);
+            if (SPLIT) fal[mr] = *(const s16x8_t*)(S + A_BYTES + a_addr[mr]);
+        }
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr) {
+            fb[nr] = *(const s16x8_t*)(S + b_addr[nr]);
+            if (SPLIT) fbl[nr] = *(const s16x8_t*)(S + B_BYTES + b_addr[nr]);
+        }
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) {
+                if (SPLIT) {
+                    acc[mr][nr] = mfma16(fal[mr], fb[nr], acc[mr][nr]);
+                    acc[mr][nr] = mfma16(fa[mr], fbl[nr], acc[mr][nr]);
+                }
+                acc[mr][nr] = mfma16t<F16>(fa[mr], fb[nr], acc[mr][nr]);
+            }
+        slot = (slot + 1 == R) ? 0 : slot + 1;
+    }
+    conv16_epilogue<WM, WN, MR, NR, PREC, 1>(p, acc, smem, wave, wm, wn, lane, n0, y0, x0, co0, NBv, (int)blockIdx.x);
+}
+
+template <int WM, int WN, int PREC, int R>
+static int launch_pipe1x1(Conv16Params& p, hipStream_t stream) {
+    constexpr int BM = WM * 64, BN = WN * 64;
+    constexpr bool SPLIT = (PREC == LP_PREC_BF16X3);
+    constexpr size_t SLOT = (size_t)(BM + BN) * 64 * (SPLIT ? 2 : 1);
+    choose_tile(BM, p.N, p.H, p.W, &p.lTH, &p.lTW, &p.lNB);
+    const int TH = 1 << p.lTH, TW = 1 << p.lTW, NBv = 1 << p.lNB;
+    p.tiles_x = (p.W + TW - 1) / TW; p.tiles_y = (p.H + TH - 1) / TH;
+    const int tiles = p.tiles_x * p.tiles_y * ((p.N + NBv - 1) / NBv);
+    p.hit = 0; p.a_dbuf = 1; p.ksplit = 1;
+    size_t lds = R * SLOT;
+    const size_t epi = (size_t)4 * 16 * (64 + 4) * sizeof(float);
+    if (lds < epi) lds = epi;
+    if (lds > 160 * 1024) return 0;
+    p.stats_rows = 0;
+    if (p.stats) {
+        const long long rows = (long long)tiles * WM;
+        const bool ok = (NBv * TH * TW == BM) && (TH * TW >= 64) && (p.H % TH == 0) && (p.W % TW == 0) && ((p.Cout & 3) == 0) &&
+                        rows * p.Cout * 3 <= p.stats_cap;
+        if (ok) p.stats_rows = (p.H * p.W) / 64; else p.stats = nullptr;
+    }
+    auto kern = conv1x1_pipe_kernel<WM, WN, PREC, R>;
+    static thread_local int attr_dev = -1;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return lp_set_error(LP_ERR_HIP, "hipGetDevice failed");
+    if (attr_dev != dev) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return lp_set_error(LP_ERR_HIP, "hipFuncSetAttribute failed");
+        attr_dev = dev;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles, (p.Cout + BN - 1) / BN), dim3(256), lds, stream, p);
+    const int rc = lp_check_launch("conv1x1_pipe");
+    return rc ? rc : 1;
+}
+
+template <int PREC>
+static int pipe1x1_dispatch(Conv16Params& p, int bn, hipStream_t s) {
+    constexpr int R = (PREC == LP_PREC_BF16X3) ? 3 : 4;      // 96 KB (one workgroup per CU at hi+lo planes) / 64 KB (two)
+    return bn == 64 ? launch_pipe1x1<4, 1, PREC, R>(p, s) : launch_pipe1x1<2, 2, PREC, R>(p, s);
+}
+
+// -> 1: launched; 0: not covered; < 0: error
+int lp_conv1x1_pipe_launch(Conv16Params& p, int prec, hipStream_t s) {
+    // OFF by default (round 4, profiles/r04_conv1x1_pipe.txt): the pointwise layers turned out to be bound by HBM traffic and by how many
+    // workgroups a CU holds, not by the chunk-by-chunk DMA round trips -- the ring costs LDS (64 / 96 KB per workgroup against 32 / 64 KB),
+    // i.e. a resident workgroup per CU, and the kernel measured 5 - 25 % SLOWER than conv_dma_kernel<1> on the layers that carry the bytes
+    // (fp16: 79 -> 87 us at 262 k pixels x 128 -> 256; bf16x3: 137 -> 167 us), equal on the long contractions.  1: on; 2: every shape (tests).
+    static const int on = getenv("LP_CONV1X1_PIPE") ? atoi(getenv("LP_CONV1X1_PIPE")) : 0;
+    if (!on || p.grouped || p.CinP % 32 || p.H < 2 || p.W < 2) return 0;
+    const long long pix = (long long)p.N * p.H * p.W;
+    const int bn = p.Cout <= 64 ? 64 : 128;
+    const long long wgs = ((pix + (bn == 64 ? 255 : 127)) / (bn == 64 ? 256 : 128)) * ((p.Cout + bn - 1) / bn);
+    static const int maxk = getenv("LP_CONV1X1_PIPE_MAXK") ? atoi(getenv("LP_CONV1X1_PIPE_MAXK")) : 256;
+    // small layers: the 8-wave paths of conv_dma_kernel; long contractions (> maxk input channels): its 64-channel stages
+    if (on != 2 && (wgs < 256 || p.CinP > maxk)) return 0;
+    if (prec == LP_PREC_BF16) return pipe1x1_dispatch<LP_PREC_BF16>(p, bn, s);
+    if (prec == LP_PREC_BF16X3) return pipe1x1_dispatch<LP_PREC_BF16X3>(p, bn, s);
+    if (prec == LP_PREC_F16) return pipe1x1_dispatch<LP_PREC_F16>(p, bn, s);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------------
 template <bool UPS, int WM, int WN, int MR, int NR, int PREC, int AIT>

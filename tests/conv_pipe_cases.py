@@ -25,9 +25,9 @@ def planes64(hi, lo, prec, c):
     return out
 
 
-def weights64(pack, prec, cout, cin):
+def weights64(pack, prec, cout, cin, ks=3):
     dt = torch.float16 if prec == 2 else torch.bfloat16
-    dec = lambda t: t.view(dt).double()[:, :cout, :cin].reshape(3, 3, cout, cin).permute(2, 3, 0, 1).contiguous()
+    dec = lambda t: t.view(dt).double()[:, :cout, :cin].reshape(ks, ks, cout, cin).permute(2, 3, 0, 1).contiguous()
     return [dec(pack.hi)] + ([dec(pack.lo)] if prec == 1 else [])
 
 
@@ -51,12 +51,21 @@ CASES = [  # N, H, W, Cin, Cout, ups, bias, res, mask, out16 (None | 0 | 1), sta
 ]
 
 
-def run_case(case, prec):
+CASES_1X1 = [  # (LP_CONV1X1_PIPE=2: the chunk-pipelined 1x1 kernel on every shape) same fields, ups = 0
+    (1, 64, 16, 64, 128, 0, 0, 0, 0, None, 1, 1),          # flattened pixels (W = 16), two chunks: everything issued in the prologue
+    (1, 100, 16, 152, 256, 0, 1, 1, 0, 0, 1, 1),           # 152 channels (the stem's im2col width): masked channel tail in the last chunk; ragged rows
+    (2, 24, 24, 256, 64, 0, 1, 0, 1, 1, 0, 1),             # an image-shaped 1x1 (skip conv), 64-channel tiles, eight chunks (ring wrap-around)
+    (1, 512, 16, 320, 192, 0, 0, 1, 0, 1, 1, 0),           # ten chunks, planes-only output, Cout not a multiple of 128
+    (3, 8, 8, 96, 136, 0, 1, 0, 0, None, 0, 1),            # tiny maps: several images per tile, masked rows
+]
+
+
+def run_case(case, prec, ks=3):
     n, h, w, cin, cout, ups, has_bias, has_res, has_mask, out16, stats, want_y = case
     g = torch.Generator().manual_seed(sum(case[:6]) + prec)
     hin, win = (h // 2, w // 2) if ups else (h, w)
     x = torch.randn(n, hin, win, cin, generator=g).cuda()
-    wt = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).cuda()
+    wt = (torch.randn(cout, cin, ks, ks, generator=g) / (cin * ks * ks) ** 0.5).cuda()
     bias = torch.randn(cout, generator=g).cuda() if has_bias else None
     rs = 1 if (ups and has_res) else 0
     res = torch.randn(n, h >> rs, w >> rs, cout, generator=g).cuda() if has_res else None
@@ -65,7 +74,7 @@ def run_case(case, prec):
     a = ops.act_pack(x, pro=2, prec=prec)
     pack = ops.pack_weights(wt, 0, prec)
     m16 = ops.act_pack(mask_src, pro=0, prec=0) if has_mask else None
-    out = ops.conv16(a, pack, ksize=3, upsample=bool(ups), bias=bias, res=res, res_shift=rs, alpha=alpha, prec=prec, relu_mask=m16,
+    out = ops.conv16(a, pack, ksize=ks, upsample=bool(ups), bias=bias, res=res, res_shift=rs, alpha=alpha, prec=prec, relu_mask=m16,
                      out16=out16, stats=bool(stats), want_y=bool(want_y))
     out = out if isinstance(out, tuple) else (out,)
     y = out[0]
@@ -73,11 +82,12 @@ def run_case(case, prec):
     cs = out[-1] if stats else None
     torch.cuda.synchronize()
     # fp64 reference on the same operands
-    A, Wt = planes64(a.hi, a.lo, prec, cin), weights64(pack, prec, cout, cin)
+    A, Wt = planes64(a.hi, a.lo, prec, cin), weights64(pack, prec, cout, cin, ks)
     up = (lambda t: t.repeat_interleave(2, 2).repeat_interleave(2, 3)) if ups else (lambda t: t)
-    ref = F.conv2d(up(A[0]), Wt[0], None, 1, 1)
+    pad = ks // 2
+    ref = F.conv2d(up(A[0]), Wt[0], None, 1, pad)
     if prec == 1:
-        ref = ref + F.conv2d(up(A[0]), Wt[1], None, 1, 1) + F.conv2d(up(A[1]), Wt[0], None, 1, 1)
+        ref = ref + F.conv2d(up(A[0]), Wt[1], None, 1, pad) + F.conv2d(up(A[1]), Wt[0], None, 1, pad)
     ref = ref * 1.37
     if bias is not None:
         ref = ref + bias.double()[None, :, None, None]
@@ -96,7 +106,7 @@ def run_case(case, prec):
         got = sum(planes64(o16.hi, o16.lo, prec, cout))
         errs['planes'] = rel(got, want)
     if stats:
-        ragged = (h % 16) or (w % 16)
+        ragged = ((h % 16) or (w % 16)) if ks == 3 else False
         if ragged:
             assert cs is None, 'ragged tiles must not claim fused statistics'
         elif cs is not None:
@@ -105,7 +115,7 @@ def run_case(case, prec):
             r64 = ref.reshape(n, cout, -1)
             errs['mean'] = rel(mean, r64.mean(2))
             errs['rstd'] = rel(rstd, (r64.var(2, unbiased=False) + 1e-4).rsqrt())
-        elif os.environ.get('LP_CONV_PIPE_MR'):            # (default heuristics: small test shapes stay on conv_dma_kernel, whose split-K
+        elif os.environ.get('LP_CONV_PIPE_MR') and ks == 3:            # (default heuristics: small test shapes stay on conv_dma_kernel, whose split-K
             errs['stats_missing'] = 1.0                    #  launches legitimately return no fused statistics)
     return errs
 
@@ -114,11 +124,11 @@ def main():
     torch.manual_seed(0)
     bad = []
     for prec in (2, 1, 0):
-        for case in CASES:
-            errs = run_case(case, prec)
+        for case, ks in [(c, 3) for c in CASES] + [(c, 1) for c in CASES_1X1]:
+            errs = run_case(case, prec, ks)
             tol = {'y': 2e-5, 'planes': {0: 6e-3, 1: 3e-5, 2: 8e-4}[prec], 'mean': 2e-5, 'rstd': 2e-5, 'stats_missing': 0.5}
             line = ' '.join(f'{k}={v:.2e}' for k, v in errs.items())
-            print(f'[conv_pipe MR={os.environ.get("LP_CONV_PIPE_MR")}] prec={prec} {case}: {line}', flush=True)
+            print(f'[conv_pipe MR={os.environ.get("LP_CONV_PIPE_MR")} 1x1={os.environ.get("LP_CONV1X1_PIPE")}] prec={prec} k={ks} {case}: {line}', flush=True)
             for k, v in errs.items():
                 if not v < tol[k]:
                     bad.append((prec, case, k, v))

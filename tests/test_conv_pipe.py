@@ -16,8 +16,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_conv_pipe_kernel_vs_fp64_of_the_same_operands(mr):
     env = dict(os.environ)
     env.pop('LP_CONV_PIPE_MR', None)
+    env.pop('LP_CONV1X1_PIPE', None)
     if mr != 'default':
         env['LP_CONV_PIPE_MR'] = mr
+        env['LP_CONV1X1_PIPE'] = '2'           # the chunk-pipelined 1x1 kernel on every 1x1 shape
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'conv_pipe_cases.py')], cwd=ROOT, env=env, capture_output=True, text=True,
                        timeout=900)
     print(r.stdout[-6000:])
