@@ -367,6 +367,11 @@ int lp_sn_row_block(void);
 int lp_sn_power_iter(const void* table, int num_layers, int do_iter, int max_rows, int max_cols, void* stream);
 int lp_sn_grad_apply(float* g, const float* w_orig, const float* u, const float* v, const float* sig, float* dot, int ndot,
                      float* accum, int rows, int cols, void* stream);
+/* Label embedding of the projection critic (discriminators/no_landmarks.py:84-86,152), gradient w.r.t. W_orig [N][E] ADDED to grad:
+ * grad[label[b]] += rows[b] (b = 0 .. B-1, in order: duplicate labels accumulate deterministically) and grad -= coef * u v^T with
+ * coef a device scalar (<G, W_orig> / sigma^2), u [N], v [E] the power-iteration vectors.  label: int64.  E % 4 == 0. */
+int lp_sn_embed_grad(float* grad, const float* u, const float* v, const float* coef, const long long* label, const float* rows,
+                     int N, int E, int B, void* stream);
 
 #ifdef __cplusplus
 }

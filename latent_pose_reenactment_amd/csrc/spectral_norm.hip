@@ -238,3 +238,41 @@ extern "C" int lp_sn_grad_apply(float* g, const float* w_orig, const float* u, c
                        db, accum, rows, cols);
     return lp_check_launch("sn_grad_apply");
 }
+
+// Gradient of the spectrally normalised label embedding (discriminators/no_landmarks.py:84-86,152; nn.SNEmbeddingFn): the dense part of
+//   dW_orig = scatter(rows at label) - coef * u v^T        (coef = <G, W_orig> / sigma^2, device scalar)
+// ADDED to grad [N][E]: one read-modify-write pass over the 98000 x 512 matrix for the rank-1 term (what torch.addmm_ did through
+// rocBLAS), then the B gradient rows in ONE workgroup that walks the batch in order (duplicate labels accumulate deterministically).
+__global__ __launch_bounds__(256) void sn_embed_rank1_kernel(float* __restrict__ grad, const float* __restrict__ u, const float* __restrict__ v,
+                                                             const float* __restrict__ coef, long long total4, int E4) {
+    const float c = -coef[0];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+        const long long row = i / E4;
+        const int c4 = (int)(i - row * E4);
+        const float s = c * u[row];
+        const float4 vv = ((const float4*)v)[c4];
+        float4 g = ((float4*)grad)[i];
+        g.x = fmaf(s, vv.x, g.x); g.y = fmaf(s, vv.y, g.y); g.z = fmaf(s, vv.z, g.z); g.w = fmaf(s, vv.w, g.w);
+        ((float4*)grad)[i] = g;
+    }
+}
+
+__global__ __launch_bounds__(256) void sn_embed_rows_kernel(float* __restrict__ grad, const long long* __restrict__ label, const float* __restrict__ rows,
+                                                            int N, int E, int B) {
+    for (int b = 0; b < B; ++b) {
+        const long long r = label[b];
+        if (r < 0 || r >= N) continue;
+        for (int j = threadIdx.x; j < E; j += 256) grad[r * E + j] += rows[(long long)b * E + j];      // (a column stays with its thread)
+    }
+}
+
+extern "C" int lp_sn_embed_grad(float* grad, const float* u, const float* v, const float* coef, const long long* label, const float* rows,
+                                int N, int E, int B, void* stream) {
+    if (!grad || !u || !v || !coef || !label || !rows) return lp_set_error(LP_ERR_ARG, "lp_sn_embed_grad: null pointer");
+    if (E & 3) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_sn_embed_grad: embedding width must be a multiple of 4");
+    const long long total4 = (long long)N * (E / 4);
+    long long blocks = (total4 + 1023) / 1024; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(sn_embed_rank1_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, grad, u, v, coef, total4, E / 4);
+    hipLaunchKernelGGL(sn_embed_rows_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, grad, label, rows, N, E, B);
+    return lp_check_launch("sn_embed_grad");
+}

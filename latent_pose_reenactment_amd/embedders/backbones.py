@@ -21,6 +21,19 @@ E_F16_TAIL_DEFAULT = 6      # trailing ResNeXt bottlenecks that run with fp16 op
 _HIP_FORWARD = [os.environ.get('LP_EMBEDDER_HIP', '1') != '0']       # set_hip_forward() / LP_EMBEDDER_HIP=0
 
 
+def _stock_fallback(module, name, rule, x):
+    """a geometry the hand-written encoder does not cover: the stock PyTorch-ROCm layers (MIOpen / rocBLAS) run instead -- with a warning
+    (once per module), or NOT AT ALL under LP_STRICT_HIP=1 (benchmarks: a run must never quietly time the library path)"""
+    if os.environ.get('LP_STRICT_HIP', '0') != '0':
+        raise RuntimeError(f'{name}: input {tuple(x.shape)} is outside the HIP path\'s geometry ({rule}) and LP_STRICT_HIP=1 forbids the '
+                           'stock-layer fallback')
+    if not module.__dict__.get('_warned_stock'):
+        module.__dict__['_warned_stock'] = True
+        import logging
+        logging.getLogger('embedder').warning('%s: input %s is outside the HIP path\'s geometry (see %s); running the stock PyTorch-ROCm layers',
+                                              name, tuple(x.shape), rule)
+
+
 def set_hip_forward(on: bool):
     """route MobileNetV2's no-grad forward through the HIP kernels (default on; LP_EMBEDDER_HIP=0 in the environment turns it off)"""
     _HIP_FORWARD[0] = bool(on)
@@ -100,11 +113,8 @@ class ResNeXt(nn.Module):
             from . import resnext_hip
             if resnext_hip.supported(x.shape[0], x.shape[2], x.shape[3]):
                 return self._forward_hip(x)
-        if _HIP_FORWARD[0] and x.is_cuda and not self.__dict__.get('_warned_stock'):
-            self.__dict__['_warned_stock'] = True
-            import logging
-            logging.getLogger('embedder').warning('ResNeXt: input %s is outside the HIP path\'s geometry (see resnext_hip.supported); '
-                                                  'running the stock PyTorch-ROCm layers', tuple(x.shape))
+        if _HIP_FORWARD[0] and x.is_cuda:
+            _stock_fallback(self, 'ResNeXt', 'resnext_hip.supported', x)
         x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         _flush_bn_counters()
@@ -269,11 +279,7 @@ class MobileNetV2(nn.Module):
             from . import mobilenet_hip
             if mobilenet_hip.supported(x.shape[0], x.shape[2], x.shape[3]):
                 return self._forward_hip_train(x)            # autograd on (meta-training): forward + backward on the HIP kernels
-            if not self.__dict__.get('_warned_stock'):
-                self.__dict__['_warned_stock'] = True
-                import logging
-                logging.getLogger('embedder').warning('MobileNetV2: input %s is outside the HIP training path\'s geometry (see '
-                                                      'mobilenet_hip.supported); running the stock PyTorch-ROCm layers', tuple(x.shape))
+            _stock_fallback(self, 'MobileNetV2', 'mobilenet_hip.supported', x)
         x = self.features(x)
         _flush_bn_counters()
         return self.classifier(x.mean([2, 3]))

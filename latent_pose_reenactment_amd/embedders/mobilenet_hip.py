@@ -23,8 +23,11 @@ PREC = PREC_BF16X3
 
 
 def supported(n: int, h: int, w: int) -> bool:
-    """N >= 8 frames, a multiple of 4 (the classifier / 1x1 contractions flatten N x H x W pixels to rows of >= 4); 32 | H, W"""
-    return n >= 8 and n % 4 == 0 and h % 32 == 0 and w % 32 == 0 and h >= 32 and w >= 32
+    """32 | H, W and the last stage's N x H/32 x W/32 pixels a multiple of 4, at least 8 (the 1x1 contractions flatten all pixels of a
+    tensor to rows of >= 4).  N = 4 frames of >= 64 x 64 qualify -- the reference's own configs/default.yaml:19-20 gives each GPU 4
+    samples -- since round 4 (the classifier pads its N rows, ``LinearRowsFunction``)."""
+    last = n * (h // 32) * (w // 32)
+    return n >= 1 and h % 32 == 0 and w % 32 == 0 and h >= 32 and w >= 32 and last >= 8 and last % 4 == 0
 
 
 class MobileNetFeaturesFunction(torch.autograd.Function):
@@ -158,26 +161,35 @@ class MobileNetFeaturesFunction(torch.autograd.Function):
 
 
 class LinearRowsFunction(torch.autograd.Function):
-    """y = x W^T + b for N >= 8 rows (N % 4 == 0) as a 1x1 contraction on the operand-plane kernels (forward, data and weight gradient)"""
+    """y = x W^T + b over N rows as a 1x1 contraction on the operand-plane kernels (forward, data and weight gradient).  The kernels see
+    rows of >= 4 pixels and >= 2 rows: N is padded with zero rows to a multiple of 4, at least 8 (zero rows add nothing to the weight
+    gradient; their outputs / gradients are dropped; the bias gradient is taken over the real rows' dy, whose padding is zero too)."""
 
     @staticmethod
     def forward(ctx, x, w, b):
         n, k = x.shape
-        fh, fw = ops.flat_hw(n)
-        x16 = ops.act_pack(x.detach().contiguous().view(1, fh, fw, k), pro=0, prec=PREC)
+        npad = max(8, (n + 3) // 4 * 4)
+        xd = x.detach().contiguous()
+        if npad != n:
+            xd = torch.cat([xd, xd.new_zeros(npad - n, k)])
+        fh, fw = ops.flat_hw(npad)
+        x16 = ops.act_pack(xd.view(1, fh, fw, k), pro=0, prec=PREC)
         wd = w.detach().contiguous()
         y = ops.conv16(x16, ops.pack_weights(wd, 0, PREC), ksize=1, bias=None if b is None else b.detach().contiguous(), prec=PREC)
-        ctx.x16, ctx.wd, ctx.dims = x16, wd, (n, k, fh, fw)
-        return y.view(n, -1)
+        ctx.x16, ctx.wd, ctx.dims = x16, wd, (n, npad, k, fh, fw)
+        return y.view(npad, -1)[:n]
 
     @staticmethod
     def backward(ctx, dy):
-        n, k, fh, fw = ctx.dims
-        d16 = ops.act_pack(dy.contiguous().view(1, fh, fw, -1), prec=PREC, grad=True)
+        n, npad, k, fh, fw = ctx.dims
+        dy = dy.contiguous()
+        if npad != n:
+            dy = torch.cat([dy, dy.new_zeros(npad - n, dy.shape[1])])
+        d16 = ops.act_pack(dy.view(1, fh, fw, -1), prec=PREC, grad=True)
         dx = dw = db = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             dw, db = ops.conv_wgrad16(ctx.x16, d16, ksize=1, prec=PREC, bias_grad=True)
             dw = dw.view(ctx.wd.shape)
         if ctx.needs_input_grad[0]:
-            dx = ops.conv16(d16, ops.pack_weights(ctx.wd, 1, PREC), ksize=1, prec=PREC).view(n, k)
+            dx = ops.conv16(d16, ops.pack_weights(ctx.wd, 1, PREC), ksize=1, prec=PREC).view(npad, k)[:n]
         return dx, dw, (db if ctx.needs_input_grad[2] else None)

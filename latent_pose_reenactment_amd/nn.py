@@ -294,8 +294,15 @@ class SNEmbeddingFn(torch.autograd.Function):
             ctx.holder['parts'] = (label, g_rows, coef, u, v)
         target = None if ctx.w_param is None else _accum_target(ctx.w_param)
         out = target if target is not None else torch.zeros_like(w)
-        out.addmm_((u * (-coef))[:, None], v[None, :])        # dense rank-1 term: one read + one write of the gradient
-        out.index_add_(0, label, g_rows)
+        if out.is_cuda and out.shape[1] % 4 == 0:
+            # lp_sn_embed_grad: the rank-1 term (one read + one write of the gradient) and the B rows, in order -- no library GEMM
+            from . import _lib
+            _lib.check(_lib.lib().lp_sn_embed_grad(out.data_ptr(), u.contiguous().data_ptr(), v.contiguous().data_ptr(), coef.reshape(1).contiguous().data_ptr(),
+                                                   label.to(torch.int64).contiguous().data_ptr(), g_rows.contiguous().data_ptr(), out.shape[0], out.shape[1],
+                                                   label.numel(), torch.cuda.current_stream().cuda_stream), 'lp_sn_embed_grad')
+        else:
+            out.addmm_((u * (-coef))[:, None], v[None, :])
+            out.index_add_(0, label, g_rows)
         return None, (None if target is not None else out), None, None, None, None
 
 

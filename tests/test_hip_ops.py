@@ -378,3 +378,26 @@ def test_l1_backward_from_the_saved_sign_pattern(relu_in):
     got = ops.l1_bwd(None, None, go, 1.0 / a.numel(), False, add=add, sign=sgn, shape=a.shape)
     assert torch.equal(got, ref)
     assert torch.equal(ops.l1_bwd(None, None, go, 2.0, False, sign=sgn, shape=a.shape), ops.l1_bwd(a, b, go, 2.0, relu_in))
+
+
+@pytest.mark.parametrize('n,e,labels', [(98000, 512, [5, 97999, 5, 0, 40000, 5, 123, 0]), (7, 8, [3, 1])])
+def test_label_embedding_gradient_kernel(n, e, labels):
+    """lp_sn_embed_grad (the dense part of the spectrally normalised label embedding's gradient, nn.SNEmbeddingFn): rank-1 term + the B
+    gradient rows added to an existing gradient, duplicate labels included, against the torch formulation it replaces"""
+    from latent_pose_reenactment_amd import _lib
+    g = torch.Generator().manual_seed(n + e)
+    grad0 = torch.randn(n, e, generator=g).cuda()
+    u, v = torch.randn(n, generator=g).cuda(), torch.randn(e, generator=g).cuda()
+    coef = torch.tensor([0.37]).cuda()
+    label = torch.tensor(labels).cuda()
+    rows = torch.randn(len(labels), e, generator=g).cuda()
+    want = grad0.double().clone()
+    want.addmm_((u.double() * (-0.37))[:, None], v.double()[None, :])
+    want.index_add_(0, label, rows.double())
+    got = grad0.clone()
+    _lib.check(_lib.lib().lp_sn_embed_grad(got.data_ptr(), u.data_ptr(), v.data_ptr(), coef.data_ptr(), label.data_ptr(), rows.data_ptr(), n, e,
+                                           len(labels), torch.cuda.current_stream().cuda_stream), 'lp_sn_embed_grad')
+    torch.cuda.synchronize()
+    report(f'sn_embed_grad {n}x{e}', rel(got, want), 1e-6)
+    for r in set(labels):
+        assert rel(got[r], want[r]) < 1e-6, r

@@ -47,13 +47,15 @@ def test_depthwise_backward(case):
     report(f'dwconv wgrad {case}', rel(dw, emu_ops.dwconv3x3_wgrad(x.double(), dy.double(), stride, d64(sc), d64(sh))), 3e-6)
 
 
-def test_linear_rows_function():
+@pytest.mark.parametrize('rows', [8, 4, 5, 1])
+def test_linear_rows_function(rows):
+    """rows = 4: the reference's shipped configs/default.yaml:19-20 gives each GPU 4 samples (the classifier pads its rows to the kernels' >= 8)"""
     from embedders.mobilenet_hip import LinearRowsFunction
     g = torch.Generator().manual_seed(3)
-    x = torch.randn(8, 1280, generator=g).cuda().requires_grad_(True)
+    x = torch.randn(rows, 1280, generator=g).cuda().requires_grad_(True)
     w = (torch.randn(256, 1280, generator=g) * 0.02).cuda().requires_grad_(True)
     b = torch.randn(256, generator=g).cuda().requires_grad_(True)
-    r = torch.randn(8, 256, generator=g).cuda()
+    r = torch.randn(rows, 256, generator=g).cuda()
     y = LinearRowsFunction.apply(x, w, b)
     (y * r).sum().backward()
     xr, wr, br = (t.detach().double().requires_grad_(True) for t in (x, w, b))
@@ -126,3 +128,39 @@ def test_mobilenet_v2_forward_backward_vs_fp64(train, size, shallow):
     for (k, b), (_, q) in zip(m.named_buffers(), ref.named_buffers()):
         if not b.dtype.is_floating_point:
             assert int(b) == int(q), k
+
+
+def test_mobilenet_v2_four_frames_take_the_hip_path():
+    """N = 4 frames (configs/default.yaml: batch 8 over 2 GPUs) must run on the HIP training path -- not silently on the stock layers --
+    and agree with them (eval-mode BatchNorm: a well-conditioned comparison of the whole network, forward + all gradients)"""
+    from embedders import backbones, mobilenet_hip
+    from test_resnext_hip import _grad_err, structured_frames
+    assert mobilenet_hip.supported(4, 256, 256) and mobilenet_hip.supported(4, 128, 128) and not mobilenet_hip.supported(4, 32, 32)
+    m, ref = _nets(13, False)
+    m.eval(); ref.eval()
+    x = structured_frames(4, 128, 6).cuda()
+    r = torch.randn(4, 256, device='cuda')
+    y = m(x)
+    assert m.__dict__.get('_hip_feature_param_names') is not None, 'the HIP training path did not run for 4 frames'
+    (y * r).sum().backward()
+    backbones.set_hip_forward(False)
+    try:
+        yr = ref(x.double())
+        (yr * r.double()).sum().backward()
+    finally:
+        backbones.set_hip_forward(True)
+    e_out, tot = rel(y, yr), _grad_err(list(m.parameters()), list(ref.parameters()))
+    print(f'[parity] mobilenet_v2, 4 frames, eval-mode BatchNorm: pose vector {e_out:.2e}, all-gradients {tot:.2e}')
+    assert e_out < 3e-5 and tot < 2e-3, (e_out, tot)
+
+
+def test_strict_hip_switch_refuses_the_stock_layer_fallback(monkeypatch):
+    """LP_STRICT_HIP=1 (bench.py sets it): a geometry outside the hand-written encoders raises instead of quietly running MIOpen"""
+    from embedders import backbones
+    monkeypatch.setenv('LP_STRICT_HIP', '1')
+    m = backbones.mobilenet_v2(8).cuda().train()
+    with pytest.raises(RuntimeError, match='LP_STRICT_HIP'):
+        m(torch.rand(2, 3, 32, 32, device='cuda'))
+    e = backbones.resnext50_32x4d(8).cuda().train()
+    with pytest.raises(RuntimeError, match='LP_STRICT_HIP'):
+        e(torch.rand(8, 3, 64, 64, device='cuda'))
