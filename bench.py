@@ -288,10 +288,50 @@ def _median_time(fn, warm, reps, budget_s):
     return ts[len(ts) // 2], len(ts)
 
 
+def _numa_nodes():
+    """[(node, [ONE logical cpu per physical core of that node])] from sysfs -- the placement `numactl --cpunodebind / --membind` would give
+    (numactl itself is not in the image; first-touch allocation by the pinned threads keeps the memory node-local)"""
+    import glob
+    import re
+
+    def cpus(txt):
+        out = []
+        for part in txt.strip().split(','):
+            if '-' in part:
+                a, b = part.split('-'); out += list(range(int(a), int(b) + 1))
+            elif part:
+                out.append(int(part))
+        return out
+    nodes = []
+    allowed = set(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else None
+    for d in sorted(glob.glob('/sys/devices/system/node/node[0-9]*'), key=lambda x: int(re.findall(r'(\d+)$', x)[0])):
+        try:
+            lst = cpus(open(os.path.join(d, 'cpulist')).read())
+        except OSError:
+            continue
+        seen, pick = set(), []
+        for c in lst:
+            if allowed is not None and c not in allowed:
+                continue
+            try:
+                sib = tuple(cpus(open(f'/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list').read()))
+            except OSError:
+                sib = (c,)
+            if sib not in seen:
+                seen.add(sib); pick.append(c)
+        if pick:
+            nodes.append((int(re.findall(r'(\d+)$', d)[0]), pick))
+    return nodes
+
+
 def cpu_worker(spec):
-    """child process of cpu_baseline: `threads,batch,warm,reps,budget,image_size` -> one JSON line {"t": median seconds per step, "n": timed steps}
-    (its own process so that OMP_NUM_THREADS / torch.set_num_threads take effect before any CPU kernel has run)"""
+    """child process of cpu_baseline: `threads,batch,warm,reps,budget,image_size,meta` -> one JSON line {"t": median seconds per step, "n": timed steps}
+    (its own process so that OMP_NUM_THREADS / torch.set_num_threads / the CPU affinity take effect before any CPU kernel has run).
+    LP_CPU_AFFINITY = comma-separated logical cpus: pin this worker (one worker per NUMA node)."""
     threads, batch, warm, reps, budget, image_size, meta = [int(float(v)) for v in spec.split(',')]
+    aff = os.environ.get('LP_CPU_AFFINITY')
+    if aff and hasattr(os, 'sched_setaffinity'):
+        os.sched_setaffinity(0, {int(c) for c in aff.split(',')})
     torch.set_num_threads(threads)
     args = make_args(image_size, 8, 'cpu', 1, 0, 'bf16x3', finetune=not meta)
     t, n = _median_time((_cpu_step_metatrain if meta else _cpu_step)(args, batch), warm, reps, budget)
@@ -301,37 +341,49 @@ def cpu_worker(spec):
 def cpu_baseline(args, full=False, workload='metatrain_step'):
     """The CPU path timed on this box's host cores: the parity-pinned fp32 torch-CPU restatement of the reference
     (oracle/lp_oracle.py; for the encoders the torchvision-compatible stock layers) running the SAME training step on the SAME kind of
-    synthetic batch, each row in its own process.
-      all-core row : every physical core (torch.set_num_threads(physical cores)); meta-training: a bounded sample of 2 samples per step
-                     (16 encoder frames; a full bs = 8 step is ~8 TFLOP of fp32 CPU work); fine-tuning: the full bs = 8 batch;
+    synthetic batch, each row in its own process(es).
+      all-core row : EVERY physical core, the bs = 8 batch of the GPU step: one worker process per NUMA node, pinned to that node's physical
+                     cores (sched_setaffinity: what numactl --cpunodebind / --membind does), each stepping its share of the 8 samples
+                     concurrently; value = 8 samples / the slowest worker's median step time.  (Round 3 ran ONE process over 64 of 128
+                     cores on 2 samples: torch-CPU scales badly across sockets from a single process.)
       1-thread row : how the reference configures itself (OMP_NUM_THREADS=1, torch.set_num_threads(1): train.py:2, utils/utils.py:19), 1 sample.
     Default = a bounded sample (1 warm-up + up to 3 timed all-core steps, 1 + up to 2 one-thread steps: 1-2 minutes);
     --cpu-baseline-full runs the >= 3 warm-up + >= 10 timed protocol."""
     import subprocess
     model, cores, logical = _cpu_info()
-    # torch-CPU on this 2-socket box is SLOWER on all 128 physical cores than on the 64 of one socket (measured: meta-training sample
-    # 21.1 s/step on 128 threads; the fine-tuning step 19.2 s on 64): the all-core row uses min(physical cores, 64) threads and says so
-    use = min(cores, 64)
     warm, reps = (3, 10) if full else (1, 3)
     meta = int(workload == 'metatrain_step')
     name = 'meta-training' if meta else 'fine-tuning'
-    ab = 2 if meta else 8
+    nodes = _numa_nodes() or [(0, list(range(cores)))]
+    while len(nodes) > 8 or (8 % len(nodes)):          # the 8 samples must split evenly: merge neighbouring nodes
+        nodes = [(nodes[i][0], nodes[i][1] + (nodes[i + 1][1] if i + 1 < len(nodes) else [])) for i in range(0, len(nodes), 2)]
+    per = 8 // len(nodes)
 
-    def run(threads, batch, w, r, budget):
+    def spawn(threads, batch, w, r, budget, cpus=None):
         env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
-        out = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-worker', f'{threads},{batch},{w},{r},{budget},{args.image_size},{meta}'],
-                             env=env, capture_output=True, text=True, timeout=budget * 4 + 900)
-        return json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
-    a = run(use, ab, warm, reps, 600 if full else 45)
-    o = run(1, 1, warm if full else 1, reps if full else 2, 900 if full else 40)
-    return {'value': round(ab / a['t'], 4), 'unit': 'images/s', 'cores': use, 'kind': 'port', 'cpu_model': model, 'physical_cores': cores,
-            'logical_cpus': logical, 'workload': workload,
+        if cpus:
+            env['LP_CPU_AFFINITY'] = ','.join(str(c) for c in cpus)
+        return subprocess.Popen([sys.executable, os.path.abspath(__file__), '--cpu-worker', f'{threads},{batch},{w},{r},{budget},{args.image_size},{meta}'],
+                                env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+
+    def result(proc, budget):
+        out, _ = proc.communicate(timeout=budget * 4 + 900)
+        return json.loads([l for l in out.splitlines() if l.startswith('{')][-1])
+    budget = 600 if full else 60
+    procs = [spawn(len(cpus), per, warm, reps, budget, cpus) for _, cpus in nodes]
+    rs = [result(p_, budget) for p_ in procs]
+    t_all = max(r['t'] for r in rs)
+    used = sum(len(cpus) for _, cpus in nodes)
+    o = result(spawn(1, 1, warm if full else 1, reps if full else 2, 900 if full else 40), 900 if full else 40)
+    return {'value': round(8 / t_all, 4), 'unit': 'images/s', 'cores': used, 'kind': 'port', 'cpu_model': model, 'physical_cores': cores,
+            'logical_cpus': logical, 'workload': workload, 'numa_workers': [{'node': n_, 'cores': len(c_), 'samples': per, 's_per_step': round(r['t'], 3)}
+                                                                            for (n_, c_), r in zip(nodes, rs)],
             'one_thread': {'value': round(1 / o['t'], 4), 'unit': 'images/s', 'cores': 1,
                            'sample': f"median of {o['n']} {name} step(s) of 1 sample at {args.image_size}x{args.image_size}, OMP_NUM_THREADS=1 / "
                                      f"torch.set_num_threads(1): {o['t']:.2f} s per step"},
-            'sample': f"median of {a['n']} {name} step(s) of {ab} samples at {args.image_size}x{args.image_size} through oracle/lp_oracle.py "
-                      f"(+ the stock torch-CPU encoder layers; torch CPU fp32, {use} threads on a host with {cores} physical cores ({model}): more threads "
-                      f"run slower, NUMA); {a['t']:.2f} s per step"
+            'sample': f"the bs = 8 {name} step at {args.image_size}x{args.image_size} through oracle/lp_oracle.py (+ the stock torch-CPU encoder layers), torch CPU fp32, "
+                      f"on all {used} physical cores of the host ({model}): {len(nodes)} worker process(es), one per NUMA node, pinned to the node's physical cores, "
+                      f"{per} samples each, concurrently; median of {min(r['n'] for r in rs)} step(s) per worker, slowest worker {t_all:.2f} s per step"
                       + ('' if full else '; bounded sample -- the >= 3 + >= 10 protocol is `bench.py --cpu-baseline-full` (profiles/)')}
 
 
@@ -615,38 +667,33 @@ def main():
             for k_ in ('mfma_per_algorithmic_flop', 'mfma_work_tflops', 'algorithmic_gflop_per_launch'):
                 entry.pop(k_, None)
         if kind == 'conv_igemm':
-            # HBM bytes per launch of this kernel family from the committed PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs of
-            # `bench.py --workload generator` under rocprofv3, scripts/r02_artifacts.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md)
+            # HBM bytes per launch of this kernel family from the committed PMC passes: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs
+            # of THIS workload (the meta-training step), counter collection restricted to the 3x3 kernels (scripts/r04_artifacts.sh; FETCH_SIZE
+            # doubled per MI355X_MICROARCH.md).  Round-3 file (generator-only population) as the fallback.
             try:
-                pm_path = os.path.join(ROOT, 'profiles', 'r03_pmc_conv_dma_step.json')
-                step_pop = os.path.exists(pm_path)
-                if not step_pop:
-                    pm_path = os.path.join(ROOT, 'profiles', 'r02_pmc_conv_dma.json')
+                pm_path = os.path.join(ROOT, 'profiles', 'r04_pmc_conv3x3_metatrain.json')
+                pop = 'the launch population of the meta-training step (warm-up, capture and replays of `bench.py --steps 2 --warmup 1`)'
+                if not os.path.exists(pm_path):
+                    pm_path = os.path.join(ROOT, 'profiles', 'r03_pmc_conv_dma_step.json')
+                    pop = 'the launch population of one generator fwd+bwd step (round 3)'
                 pm = json.load(open(pm_path))
                 entry['traffic'] = pm.get('hbm_bytes_per_launch')
-                # algorithmic bytes of the SAME population (the 12 layer classes of scripts/conv_micro.py, N tiles of 128 channels):
-                micro = [(8, 4, 4, 512, 512, 3, 0), (8, 16, 16, 512, 512, 3, 0), (8, 32, 32, 512, 512, 3, 0), (8, 64, 64, 256, 256, 3, 0),
-                         (8, 128, 128, 128, 128, 3, 0), (8, 256, 256, 64, 64, 3, 0), (8, 256, 256, 128, 64, 3, 1), (8, 256, 256, 64, 128, 3, 0),
-                         (8, 64, 64, 512, 256, 3, 1), (8, 64, 64, 256, 128, 1, 0), (16, 128, 128, 128, 128, 3, 0), (16, 64, 64, 256, 256, 3, 0)]
-                alg = sum(2 * n_ * (h_ >> u_) * (w_ >> u_) * ci_ * ((co_ + 127) // 128) + 2 * k_ * k_ * ci_ * co_ + 4 * n_ * h_ * w_ * co_
-                          for n_, h_, w_, ci_, co_, k_, u_ in micro) / len(micro)
-                if step_pop:
-                    entry['traffic_note'] = ('mean HBM bytes per conv_dma_kernel launch over the launch population of one generator fwd+bwd step '
-                                             '(profiles/r03_pmc_conv_dma_step.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of '
-                                             '`bench.py --workload generator`, kernel filter conv_dma; (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per '
-                                             f"MI355X_MICROARCH.md); MFMA busy fraction from SQ_VALU_MFMA_BUSY_CYCLES: {pm.get('mfma_busy_fraction')}")
-                else:
-                  entry['traffic_note'] = ('mean HBM bytes per conv_dma_kernel launch over the per-layer micro-benchmark (scripts/conv_micro.py, 12 layer '
-                                         'classes; profiles/r02_pmc_conv_dma.json: (2 x FETCH_SIZE + WRITE_SIZE) x 1024, separate rocprofv3 --pmc '
-                                         f'passes); algorithmic bytes of the same 12 launches: {alg / 1e6:.1f} MB mean; per-shape values: '
-                                         'profiles/r02_pmc_conv_micro_f16.csv; MFMA busy fraction from SQ_VALU_MFMA_BUSY_CYCLES: '
-                                         f"{pm.get('mfma_busy_fraction')}")
+                entry['traffic_note'] = (f'mean HBM bytes per 3x3 conv launch (conv_pipe_kernel + conv_dma_kernel<3>) over {pop}: '
+                                         f'{os.path.relpath(pm_path, ROOT)}, separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, '
+                                         '(2 x FETCH_SIZE + WRITE_SIZE) x 1024 per MI355X_MICROARCH.md; MFMA busy fraction from '
+                                         f"SQ_VALU_MFMA_BUSY_CYCLES: {pm.get('mfma_busy_fraction')}")
+                entry['mfma_busy_fraction_pmc'] = pm.get('mfma_busy_fraction')
             except Exception:
-                entry['traffic_note'] = 'profiles/r02_pmc_conv_dma.json not present'
+                entry['traffic_note'] = 'no PMC summary under profiles/'
             entry['algorithmic_bytes_note'] = ('f16 operands: 2 B per input activation (once per N tile), 2 B per weight, 4 B per fp32 output '
                                                '(+ 2 B when the epilogue also emits the consumer planes)')
+            try:      # the same family INSIDE the graph replay (rocprofv3 kernel trace of the captured step: no eager launch gaps)
+                ig = json.load(open(os.path.join(ROOT, 'profiles', 'r04_conv3x3_in_graph.json')))
+                entry['in_graph'] = ig
+            except Exception:
+                pass
         if kind == 'conv_igemm':
-            entry['kernel'] = 'conv_dma_kernel (lp_conv16_fwd: forward and data-gradient convs)'
+            entry['kernel'] = 'conv_pipe_kernel / conv_dma_kernel<3> (lp_conv16_fwd: forward and data-gradient 3x3 convs)'
             roof = entry
         else:
             extra['roofline_' + kind] = entry

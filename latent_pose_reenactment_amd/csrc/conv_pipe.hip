@@ -29,6 +29,27 @@ static __device__ __attribute__((aligned(64))) unsigned int lp_zero_page_pipe[16
 
 __device__ __forceinline__ void lp_barrier_raw() { asm volatile("s_barrier" ::: "memory"); }
 
+// MFMA with the accumulator TIED (D = C, the same four registers): hipcc's allocator otherwise rotates accumulators through fresh
+// registers across the unrolled taps (40 accumulator quads for 16 in the 64 x 64-per-wave kernel; spills at 128 x 64 per wave).  An asm
+// statement is opaque to the hazard recogniser (cdna_hip_programming.md 5.7): here the producers of a / b are ds_reads hipcc waits for
+// itself, the next writer of c is an MFMA taking it whole as C (0 wait states), and the first non-MFMA reader sits behind a workgroup barrier.
+template <bool F16> __device__ __forceinline__ void mfma16_tied(const s16x8_t& a, const s16x8_t& b, f32x4_t& c) {
+    if (F16) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+
+#ifndef LP_PIPE_SCHED
+#define LP_PIPE_SCHED 1          // 0: no order pinning (A/B builds)
+#endif
+#ifndef LP_PIPE_SETPRIO
+#define LP_PIPE_SETPRIO 1        // s_setprio 1 around the first-half MFMA group (r04: 128^2 x 128 layer 49.8 -> 44 .. 47 us, others +-1 %); 0: A/B builds
+#endif
+#if LP_PIPE_SCHED
+#define LP_PIPE_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#else
+#define LP_PIPE_SCHED_BARRIER() do {} while (0)
+#endif
+
 template <bool UPS, int WM, int WN, int MR, int NR, int PREC, int AIT>
 __global__ __launch_bounds__(WM * WN * 64, (PREC == LP_PREC_BF16X3) ? 1 : 2)
 void conv_pipe_kernel(Conv16Params p) {
@@ -74,7 +95,13 @@ void conv_pipe_kernel(Conv16Params p) {
         const int hx = UPS ? ((l15 + dx - 1) >> 1) + 1 : l15 + dx;
         acol[dx] = hx * ROWB + ((kb ^ ((hx >> 1) & 3)) << 4);
     }
+    // The address of an A fragment read = a per-lane base per kernel column (acol[dx] + the wave's first patch row) + a COMPILE-TIME offset
+    // (row block, kernel row, halo width 18 | 10): three base registers, the rest rides in the ds_read offset field.  (wm * MR is even, so
+    // the upsampled row ((py + dy - 1) >> 1) + 1 splits into wm*MR/2 and a constant, too.)
     const int py0 = (wm * MR) & (TH - 1);                // patch row of the wave's first row block (uniform)
+    int abase[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) abase[dx] = acol[dx] + (UPS ? (py0 >> 1) : py0) * HW * ROWB;
     int b_addr[NR];
 #pragma unroll
     for (int nr = 0; nr < NR; ++nr) b_addr[nr] = (wn * (NR * 16) + nr * 16 + l15) * ROWB + ((kb ^ ((l15 >> 1) & 3)) << 4);
@@ -128,39 +155,42 @@ void conv_pipe_kernel(Conv16Params p) {
         }
     };
 
-    s16x8_t fbc[NR], fbn[NR], fa0[MH], fa1[MH];
-    s16x8_t fbcl[NR], fbnl[NR], fa0l[MH], fa1l[MH];
-    auto load_b = [&](s16x8_t (&fb)[NR], s16x8_t (&fbl)[NR], int tap) {
+    // Register plan (MR = 8, one-plane modes): 128 accumulators + the A fragments of the two half taps (fa0, fa1: 16 + 16) + ONE set of B
+    // fragments (fbc: 16) = 176 of the 256 VGPRs two co-resident workgroups allow.  The B fragments of the next tap replace the current
+    // ones IN PLACE while the second half multiplies (both halves run output-column-major: fbc[nr] is dead after its four MFMAs of the
+    // second half and is needed again only nr groups into the next tap's first half).  A first version kept two B sets: 256 VGPRs + scratch
+    // spills, whose reloads made hipcc put `vmcnt(0)` into the loop -- draining the DMA pipeline this kernel exists for.
+    s16x8_t fbc[NR], fa0[MH], fa1[MH];
+    s16x8_t fbcl[NR], fa0l[MH], fa1l[MH];
+    auto load_b1 = [&](int nr, int tap) {
         const unsigned char* Bk = B_base + (tap % 3) * B_SLOT;
-#pragma unroll
-        for (int nr = 0; nr < NR; ++nr) {
-            fb[nr] = *(const s16x8_t*)(Bk + b_addr[nr]);
-            if (SPLIT) fbl[nr] = *(const s16x8_t*)(Bk + B_TAP + b_addr[nr]);
-        }
+        fbc[nr] = *(const s16x8_t*)(Bk + b_addr[nr]);
+        if (SPLIT) fbcl[nr] = *(const s16x8_t*)(Bk + B_TAP + b_addr[nr]);
     };
-    auto load_a = [&](s16x8_t (&fa)[MH], s16x8_t (&fal)[MH], int half, int tap, const unsigned char* Hb) {
+    auto load_a = [&](s16x8_t (&fa)[MH], s16x8_t (&fal)[MH], int half, int tap, const unsigned char* const (&Hb)[3]) {
         const int dy = tap / 3, dx = tap % 3;
 #pragma unroll
         for (int i = 0; i < MH; ++i) {
-            const int py = py0 + half * MH + i;                          // uniform
-            const int row = UPS ? (((py + dy - 1) >> 1) + 1) * HW : (py + dy) * HW;
-            const int off = row * ROWB + acol[dx];
-            fa[i] = *(const s16x8_t*)(Hb + off);
-            if (SPLIT) fal[i] = *(const s16x8_t*)(Hb + A_BYTES + off);
+            const int k = half * MH + i;                                  // row block of the wave: compile-time
+            const int off = (UPS ? (((k + dy - 1) >> 1) + 1) : (k + dy)) * HW * ROWB;
+            fa[i] = *(const s16x8_t*)(Hb[dx] + off);
+            if (SPLIT) fal[i] = *(const s16x8_t*)(Hb[dx] + A_BYTES + off);
         }
     };
-    auto mm = [&](int half, const s16x8_t (&fa)[MH], const s16x8_t (&fal)[MH], const s16x8_t (&fb)[NR], const s16x8_t (&fbl)[NR]) {
+    auto mm_col = [&](int half, int nr, const s16x8_t (&fa)[MH], const s16x8_t (&fal)[MH]) {
 #pragma unroll
-        for (int i = 0; i < MH; ++i)
-#pragma unroll
-            for (int nr = 0; nr < NR; ++nr) {
-                f32x4_t& c = acc[half * MH + i][nr];
-                if (SPLIT) {
-                    c = mfma16(fal[i], fb[nr], c);
-                    c = mfma16(fa[i], fbl[nr], c);
-                }
-                c = mfma16t<F16>(fa[i], fb[nr], c);
+        for (int i = 0; i < MH; ++i) {
+            f32x4_t& c = acc[half * MH + i][nr];
+            if (SPLIT) {
+                // (bf16x3: 512-register budget, part of the fragments live in AGPRs -- the copies hipcc puts in front of an asm statement
+                //  are VALU writes whose MFMA-operand wait states nobody would pad: the compiler-scheduled builtin here)
+                c = mfma16(fal[i], fbc[nr], c);
+                c = mfma16(fa[i], fbcl[nr], c);
+                c = mfma16(fa[i], fbc[nr], c);
+            } else {
+                mfma16_tied<F16>(fa[i], fbc[nr], c);
             }
+        }
     };
 
     const int nch = p.CinP / 32;
@@ -169,18 +199,30 @@ void conv_pipe_kernel(Conv16Params p) {
     issue_a(0, 0);
     lp_wait_vm0();
     lp_barrier_raw();
-    load_b(fbc, fbcl, 0);
-    load_a(fa0, fa0l, 0, 0, H_base);
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) load_b1(nr, 0);
+    {
+        const unsigned char* const H0[3] = {H_base + abase[0], H_base + abase[1], H_base + abase[2]};
+        load_a(fa0, fa0l, 0, 0, H0);
+    }
 
     for (int chunk = 0; chunk < nch; ++chunk) {
-        const unsigned char* Hc = H_base + (chunk & 1) * A_BUF;
-        const unsigned char* Hn = H_base + ((chunk + 1) & 1) * A_BUF;
+        const int hc = (chunk & 1) * A_BUF, hn = A_BUF - hc;
+        const unsigned char* const Hc[3] = {H_base + hc + abase[0], H_base + hc + abase[1], H_base + hc + abase[2]};
+        const unsigned char* const Hn[3] = {H_base + hn + abase[0], H_base + hn + abase[1], H_base + hn + abase[2]};
         const bool has_next = chunk + 1 < nch;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            // first half of the tap's MFMAs; the second half's A fragments are read beside them
+            // first half of the tap's MFMAs; the second half's A fragments are read ahead of them.  The sched_barriers pin the ORDER of the
+            // read groups and the MFMA groups (inside a group the compiler schedules freely): left alone, hipcc re-used one register quad
+            // for successive A fragments and emitted read -> lgkmcnt(0) -> 4 MFMAs -> read ..., an exposed LDS round trip per 4 MFMAs.
             load_a(fa1, fa1l, 1, tap, Hc);
-            mm(0, fa0, fa0l, fbc, fbcl);
+            LP_PIPE_SCHED_BARRIER();
+            if (LP_PIPE_SETPRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) mm_col(0, nr, fa0, fa0l);
+            if (LP_PIPE_SETPRIO) __builtin_amdgcn_s_setprio(0);
+            LP_PIPE_SCHED_BARRIER();
             // ---- sync point of step g = (chunk, tap): the weights of tap g+1 (every wave's pieces) have landed, and every wave is done with
             // the slot of tap g (its fragments were read one step ago and consumed by the MFMAs above) and, at tap 0, with the other halo buffer.
             // Allowed outstanding = DMA instructions issued after those of tap g+1: the weights of tap g+2 (issued one step ago) and, at taps
@@ -193,12 +235,17 @@ void conv_pipe_kernel(Conv16Params p) {
             if (tap + 3 < 9) issue_w(chunk, tap + 3);
             else if (has_next) issue_w(chunk + 1, tap + 3 - 9);
             if (tap == 0 && has_next) issue_a(chunk + 1, (chunk + 1) & 1);
+            const bool more = (tap < 8) || has_next;
             // (fa0 was consumed by the MFMAs above the barrier: the next tap's first half goes straight into it)
-            if (tap < 8) { load_b(fbn, fbnl, tap + 1); load_a(fa0, fa0l, 0, tap + 1, Hc); }
-            else if (has_next) { load_b(fbn, fbnl, 0); load_a(fa0, fa0l, 0, 0, Hn); }
-            mm(1, fa1, fa1l, fbc, fbcl);
+            if (tap < 8) load_a(fa0, fa0l, 0, tap + 1, Hc);
+            else if (has_next) load_a(fa0, fa0l, 0, 0, Hn);
+            LP_PIPE_SCHED_BARRIER();
 #pragma unroll
-            for (int nr = 0; nr < NR; ++nr) { fbc[nr] = fbn[nr]; if (SPLIT) fbcl[nr] = fbnl[nr]; }
+            for (int nr = 0; nr < NR; ++nr) {
+                mm_col(1, nr, fa1, fa1l);
+                if (more) load_b1(nr, tap < 8 ? tap + 1 : 0);            // the next tap's B fragment into the registers that just became free
+                LP_PIPE_SCHED_BARRIER();
+            }
         }
     }
     // ---- epilogue (conv_common.h; 16 rows through LDS at a time: 4.3 KB of scratch per wave)

@@ -1,0 +1,37 @@
+"""3x3 dense conv family INSIDE a captured step: kernel durations from a one-step rocprofv3 breakdown (scripts/step_breakdown.py) against the
+algorithmic FLOPs of the same launches (bench.py --shapes table, kind conv_igemm, two instrumented steps) -> the in-graph roofline figure
+that bench.py prints beside its live eager-event one.
+usage: python scripts/in_graph_conv.py <step_breakdown.csv> <conv_shapes.csv> > profiles/r04_conv3x3_in_graph.json
+Family = conv_pipe_kernel (all variants) + conv_dma_kernel<3, ...> except the <3, false, 4, 1, 4, 4, ...> instantiation, which since round 4
+only runs the identity encoder's GROUPED 3x3 convs (the dense <= 64-channel layers moved to conv_pipe_kernel<.., 4, 1, 4, 4, ..>), + the
+split-K finishes (splitk_reduce_kernel)."""
+import csv
+import json
+import sys
+
+bd, shapes = sys.argv[1], sys.argv[2]
+t_ms, launches, parts = 0.0, 0, {}
+for line in open(bd):
+    if line.startswith('#') or line.startswith('kernel,'):
+        continue
+    r = next(csv.reader([line]))
+    name, n, ms = r[0], int(r[1]), float(r[2])
+    fam = None
+    if name.startswith('conv_pipe_kernel'):
+        fam = 'conv_pipe_kernel'
+    elif name.startswith('conv_dma_kernel<3,') and not name.startswith('conv_dma_kernel<3, false, 4, 1, 4, 4,'):
+        fam = 'conv_dma_kernel<3> (small maps, <= 16-channel outputs, leftovers)'
+    elif name.startswith('splitk_reduce_kernel'):
+        fam = 'splitk_reduce_kernel'
+    if fam:
+        t_ms += ms; launches += n
+        p = parts.setdefault(fam, [0, 0.0]); p[0] += n; p[1] += ms
+fl = 0.0
+for r in csv.DictReader(open(shapes)):
+    if r['kind'] == 'conv_igemm':
+        fl += float(r['TFLOPs']) * float(r['total_us']) * 1e-6      # TF/s x s = TFLOP (two instrumented steps)
+tflop_step = fl / 2
+ach = tflop_step / (t_ms * 1e-3)
+print(json.dumps({'source': 'rocprofv3 kernel trace of one hipGraph replay (scripts/step_breakdown.py) + bench.py --shapes', 'ms_per_step': round(t_ms, 3),
+                  'launches_per_step': launches, 'algorithmic_tflop_per_step': round(tflop_step, 3), 'achieved_tflops': round(ach, 1),
+                  'frac_of_2500': round(ach / 2500.0, 4), 'by_kernel': {k: {'launches': v[0], 'ms': round(v[1], 3)} for k, v in parts.items()}}))

@@ -4,7 +4,7 @@ usage: python scripts/pmc_summary.py <counter_collection.csv> [...]  > summary.c
        python scripts/pmc_summary.py --json <kernel name prefix> <counter_collection.csv> [...]  > traffic.json
 FETCH_SIZE / WRITE_SIZE are reported in KiB by rocprofv3; FETCH_SIZE is doubled as MI355X_MICROARCH.md (HBM section) prescribes for
 wide coalesced reads on gfx950.  The --json form sums over every launch of the kernels whose name starts with the prefix (all tile
-variants of one kernel family) -> average HBM bytes per launch, which bench.py reports as roofline.traffic."""
+variants of one kernel family; several prefixes may be joined with '|') -> average HBM bytes per launch, which bench.py reports as roofline.traffic."""
 import collections
 import csv
 import json
@@ -23,7 +23,7 @@ for path in args:
             k = (name[:100] + ' grid=' + str(r.get('Grid_Size', '')), r['Counter_Name'])
             acc[k][0] += 1
             acc[k][1] += float(r['Counter_Value'])
-            if prefix and prefix in name.split('(')[0]:
+            if prefix and any(pf in name.split('(')[0] for pf in prefix.split('|')):
                 fam[r['Counter_Name']][0] += 1
                 fam[r['Counter_Name']][1] += float(r['Counter_Value'])
 if prefix:
