@@ -491,7 +491,12 @@ int lp_conv_pipe_launch(Conv16Params& p, int ups, int prec, hipStream_t s) {
     static const int on = getenv("LP_CONV_PIPE") ? atoi(getenv("LP_CONV_PIPE")) : 1;
     static const int mr_env = getenv("LP_CONV_PIPE_MR") ? atoi(getenv("LP_CONV_PIPE_MR")) : 0;      // 4 | 8 forces the rows per wave (test knob)
     static const int n64 = getenv("LP_CONV_PIPE_N64") ? atoi(getenv("LP_CONV_PIPE_N64")) : 1;       // 0: <= 64-channel outputs stay on conv_dma_kernel
+    static const int x3 = getenv("LP_CONV_PIPE_X3") ? atoi(getenv("LP_CONV_PIPE_X3")) : 0;
     if (!on || p.grouped) return 0;
+    // bf16x3 (hi + lo planes: 144 KB of LDS, one workgroup per CU, compiler-scheduled MFMAs): measured SLOWER than conv_dma_kernel on the
+    // 64^2 .. 128^2 layers (115 vs 86 .. 93 us, profiles/r04_conv_pipe_micro.txt) -- the strict mode stays on conv_dma_kernel unless forced
+    // (LP_CONV_PIPE_X3=1, or the test knob LP_CONV_PIPE_MR)
+    if (prec == LP_PREC_BF16X3 && !x3 && !mr_env) return 0;
     if ((p.C8 & 31) || p.CinP % 32 || p.W < 16 || p.H < 16) return 0;
     int mr = 0, bn = 128;
     const long long px_tiles = (long long)((p.W + 15) / 16) * p.N;
