@@ -70,7 +70,6 @@ def make_args(image_size, batch_size, device, num_gpus, rank, prec_name, finetun
         optimizer='RAdam' if finetune else 'Adam', lr_gen=5e-4 if finetune else 5e-5, lr_dis=8e-4 if finetune else 2e-4, beta1=0.0,
         finetune=finetune, random_seed=123)
     os.environ['LP_PREC'] = prec_name
-    os.environ.setdefault('LP_STRICT_HIP', '1')      # a geometry outside the hand-written encoders raises instead of quietly timing MIOpen
     return a
 
 
@@ -512,6 +511,7 @@ def main():
     a = ap.parse_args()
     if a.cpu_worker:
         return cpu_worker(a.cpu_worker)
+    os.environ.setdefault('LP_STRICT_HIP', '1')      # a geometry outside the hand-written encoders raises instead of quietly timing MIOpen
 
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU under torch.distributed.run, rendezvous on

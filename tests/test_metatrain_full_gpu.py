@@ -114,6 +114,7 @@ def test_full_size_metatrain_forward_vs_reference_chain(tmp_path, mode, gate):
     env = {k: v for k, v in os.environ.items() if k not in ('LP_PREC', 'LP_PREC_E', 'LP_E_F16_TAIL')}
     if mode != 'default':
         env['LP_PREC'] = mode
+    env['LP_STRICT_HIP'] = '1'          # the hand-written encoders or an error: never the stock layers
     out = str(tmp_path / 'res.json')
     r = subprocess.run([sys.executable, os.path.abspath(__file__), out], env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
