@@ -279,7 +279,7 @@ def _median_time(fn, warm, reps, budget_s):
     for _ in range(warm):
         t0 = time.time(); fn(); last = time.time() - t0
     ts = []
-    while len(ts) < reps and (time.time() - t_all < budget_s or (not ts and last is None)):
+    while len(ts) < reps and (time.time() - t_all < budget_s or not ts):      # always at least ONE timed (warm) step
         t0 = time.time(); fn(); ts.append(time.time() - t0)
     if not ts:
         return last, 1
@@ -308,10 +308,11 @@ def _numa_nodes():
             lst = cpus(open(os.path.join(d, 'cpulist')).read())
         except OSError:
             continue
-        seen, pick = set(), []
+        seen, pick, every = set(), [], []
         for c in lst:
             if allowed is not None and c not in allowed:
                 continue
+            every.append(c)
             try:
                 sib = tuple(cpus(open(f'/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list').read()))
             except OSError:
@@ -319,7 +320,7 @@ def _numa_nodes():
             if sib not in seen:
                 seen.add(sib); pick.append(c)
         if pick:
-            nodes.append((int(re.findall(r'(\d+)$', d)[0]), pick))
+            nodes.append((int(re.findall(r'(\d+)$', d)[0]), pick, every))
     return nodes
 
 
@@ -353,13 +354,16 @@ def cpu_baseline(args, full=False, workload='metatrain_step'):
     warm, reps = (3, 10) if full else (1, 3)
     meta = int(workload == 'metatrain_step')
     name = 'meta-training' if meta else 'fine-tuning'
-    nodes = _numa_nodes() or [(0, list(range(cores)))]
+    nodes = _numa_nodes() or [(0, list(range(cores)), list(range(logical)))]
     while len(nodes) > 8 or (8 % len(nodes)):          # the 8 samples must split evenly: merge neighbouring nodes
-        nodes = [(nodes[i][0], nodes[i][1] + (nodes[i + 1][1] if i + 1 < len(nodes) else [])) for i in range(0, len(nodes), 2)]
+        nodes = [(nodes[i][0], nodes[i][1] + (nodes[i + 1][1] if i + 1 < len(nodes) else []), nodes[i][2] + (nodes[i + 1][2] if i + 1 < len(nodes) else []))
+                 for i in range(0, len(nodes), 2)]
     per = 8 // len(nodes)
 
     def spawn(threads, batch, w, r, budget, cpus=None):
-        env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
+        # OMP_WAIT_POLICY=passive: the autograd engine's thread runs its own OpenMP team beside the forward thread's; with active waiting
+        # the two teams of a pinned worker spin against each other on the same cores (measured: 145 - 207 s per step instead of ~20 s)
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), OMP_WAIT_POLICY='passive', GOMP_SPINCOUNT='0')
         if cpus:
             env['LP_CPU_AFFINITY'] = ','.join(str(c) for c in cpus)
         return subprocess.Popen([sys.executable, os.path.abspath(__file__), '--cpu-worker', f'{threads},{batch},{w},{r},{budget},{args.image_size},{meta}'],
@@ -369,14 +373,14 @@ def cpu_baseline(args, full=False, workload='metatrain_step'):
         out, _ = proc.communicate(timeout=budget * 4 + 900)
         return json.loads([l for l in out.splitlines() if l.startswith('{')][-1])
     budget = 600 if full else 60
-    procs = [spawn(len(cpus), per, warm, reps, budget, cpus) for _, cpus in nodes]
+    procs = [spawn(len(phys), per, warm, reps, budget, every) for _, phys, every in nodes]      # threads = physical cores; mask = their SMT siblings too
     rs = [result(p_, budget) for p_ in procs]
     t_all = max(r['t'] for r in rs)
-    used = sum(len(cpus) for _, cpus in nodes)
+    used = sum(len(phys) for _, phys, _e in nodes)
     o = result(spawn(1, 1, warm if full else 1, reps if full else 2, 900 if full else 40), 900 if full else 40)
     return {'value': round(8 / t_all, 4), 'unit': 'images/s', 'cores': used, 'kind': 'port', 'cpu_model': model, 'physical_cores': cores,
-            'logical_cpus': logical, 'workload': workload, 'numa_workers': [{'node': n_, 'cores': len(c_), 'samples': per, 's_per_step': round(r['t'], 3)}
-                                                                            for (n_, c_), r in zip(nodes, rs)],
+            'logical_cpus': logical, 'workload': workload, 'numa_workers': [{'node': n_, 'cores': len(c_), 'samples': per, 's_per_step': round(r['t'], 3), 'timed_steps': r['n']}
+                                                                            for (n_, c_, _e), r in zip(nodes, rs)],
             'one_thread': {'value': round(1 / o['t'], 4), 'unit': 'images/s', 'cores': 1,
                            'sample': f"median of {o['n']} {name} step(s) of 1 sample at {args.image_size}x{args.image_size}, OMP_NUM_THREADS=1 / "
                                      f"torch.set_num_threads(1): {o['t']:.2f} s per step"},
@@ -502,6 +506,7 @@ def main():
                          'workload so that the 1/2/4/8-GPU values form a scaling curve).  finetune_step = BASELINE configs[1] (single GPU in the '
                          'reference); the default N = 1 run also reports it under "finetune_step"')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-baseline-only', action='store_true', help='only the CPU baseline leg (no GPU work): prints its JSON object')
     ap.add_argument('--no-also', action='store_true', help='skip the side measurements (strict bf16x3 mode, fine-tuning step)')
     ap.add_argument('--no-drive', action='store_true', help='skip the drive.py frame-loop measurement (PMC passes: keeps the launch population to the step)')
     ap.add_argument('--eager', action='store_true', help='do not capture the step into hipGraphs')
@@ -512,6 +517,10 @@ def main():
     if a.cpu_worker:
         return cpu_worker(a.cpu_worker)
     os.environ.setdefault('LP_STRICT_HIP', '1')      # a geometry outside the hand-written encoders raises instead of quietly timing MIOpen
+    if a.cpu_baseline_only:
+        wl = a.workload or 'metatrain_step'
+        print(json.dumps(cpu_baseline(make_args(a.image_size, a.batch, 'cpu', 1, 0, a.prec, finetune=wl != 'metatrain_step'), full=a.cpu_baseline_full, workload=wl)))
+        return
 
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU under torch.distributed.run, rendezvous on
