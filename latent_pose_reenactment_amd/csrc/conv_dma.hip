@@ -38,7 +38,13 @@ template <int KS, bool UPS, int WM, int WN, int MR, int NR, int PREC, bool PP, i
 #ifndef LP_PP_MINW
 #define LP_PP_MINW 2          // min waves per SIMD of the ping-pong kernels in the 16-bit modes: 2 = one workgroup per CU, 4 = two (<= 128 VGPRs)
 #endif
-__global__ __launch_bounds__(WM * WN * 64 * (PP ? 2 : 1), (PP && PREC != LP_PREC_BF16X3) ? LP_PP_MINW : (!PP && NBUF == 2 && WM * WN == 4 && PREC != LP_PREC_BF16X3) ? 2 : 1)
+#ifndef LP_X3_1X1_MINW
+#define LP_X3_1X1_MINW 3      // min waves per SIMD of the bf16x3 1x1 kernels: hipcc then fits them in 127 VGPRs (170 without the bound: two
+                              // workgroups per CU); with ONE activation buffer (48 KB of LDS) three share a CU -- r04: 133 -> 120 us at 262 k pixels x
+                              // 128 -> 256, 47.9 -> 40.6 us at 64 -> 128 (profiles/r04_conv1x1_x3_occupancy.txt); 1: the round-3 build
+#endif
+__global__ __launch_bounds__(WM * WN * 64 * (PP ? 2 : 1), (PP && PREC != LP_PREC_BF16X3) ? LP_PP_MINW : (!PP && NBUF == 2 && WM * WN == 4 && PREC != LP_PREC_BF16X3) ? 2 :
+                             (KS == 1 && !PP && WM * WN == 4 && PREC == LP_PREC_BF16X3) ? LP_X3_1X1_MINW : 1)
 void conv_dma_kernel(Conv16Params p) {
     constexpr int ROWB = CC * 2;                         // CC channels per chunk; bytes per halo pixel / weight row of a chunk
     constexpr int SL = CC / 8, RPI = 64 / SL;            // 16-byte slots per row; rows covered by one 1 KiB DMA piece
@@ -373,7 +379,12 @@ static int launch_conv16(Conv16Params& p, hipStream_t stream) {
     p.hit = (NH + NWAVE - 1) / NWAVE;
     if (p.hit > AIT) return lp_set_error(LP_ERR_UNSUPPORTED, "conv16: halo exceeds the DMA descriptor budget");
     const size_t a_buf = (size_t)p.hit * NWAVE * 1024 * (SPLIT ? 2 : 1);
+    static const int adbuf_env = getenv("LP_CONV_ADBUF") ? atoi(getenv("LP_CONV_ADBUF")) : -1;      // 0: one A buffer also where two fit (A/B knob)
     p.a_dbuf = (2 * a_buf + 2 * B_BUF <= LDS_MAX) ? 1 : 0;
+    if (adbuf_env == 0 && KS == 1) p.a_dbuf = 0;
+    // bf16x3 pointwise layers with short contractions (<= 8 chunks: the layers bound by their traffic): one activation buffer, i.e. a
+    // third resident workgroup per CU, beats the double buffer (longer contractions lose 5 - 10 % with it and keep two)
+    if (adbuf_env < 0 && KS == 1 && SPLIT && CC == 32 && p.CinP <= 256) p.a_dbuf = 0;
     const size_t lds_halo = (p.a_dbuf ? 2 : 1) * a_buf;
     size_t lds = lds_halo + 2 * B_BUF;
     size_t epi = (size_t)NWAVE * ((KS == 1) ? 16 : MR * 16) * (NR * 16 + 4) * sizeof(float);      // LDS transpose of the coalesced epilogue (1x1: 16 rows per wave at a time)
