@@ -493,11 +493,13 @@ struct W1Params {
 };
 static __device__ __attribute__((aligned(64))) unsigned int w1_zero_page[16];      // what out-of-range DMA lanes read
 
-template <int PREC>
-__global__ __launch_bounds__(256) void wgrad1x1_kernel(W1Params p) {
+// KP = pixels per stage: 64; 32 in the bf16x3 mode, whose doubled planes would otherwise need 128 KB of LDS -- ONE workgroup per CU for a kernel
+// bound by its operand stream (round 4: two 64 KB workgroups per CU, profiles/r04_wgrad1x1_x3.txt; LP_W1_KP = 64 restores the old stage)
+template <int PREC, int KP>
+__global__ __launch_bounds__(256, 2) void wgrad1x1_kernel(W1Params p) {
     constexpr bool SPLIT = (PREC == LP_PREC_BF16X3), F16 = (PREC == LP_PREC_F16);
-    constexpr int KP = 64;                                  // pixels per stage
-    constexpr int TILE_B = KP * 256;                        // one [64][128] 16-bit tile
+    constexpr int NPW = KP / 16;                            // 1 KiB DMA pieces (4 rows) per wave, operand plane and stage
+    constexpr int TILE_B = KP * 256;                        // one [KP][128] 16-bit tile
     constexpr int STAGE_B = TILE_B * (SPLIT ? 4 : 2);       // D_hi | A_hi [| D_lo | A_lo]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -511,9 +513,9 @@ __global__ __launch_bounds__(256) void wgrad1x1_kernel(W1Params p) {
     const int s_beg = split * per, s_end = min(p.nstage, s_beg + per);
 
     // DMA descriptors: piece q = i*4 + wave covers rows 4q .. 4q+3 of a tile; lane -> row 4q + lane/16, slot lane%16
-    int d_rel[4], a_rel[4], row_[4];
+    int d_rel[NPW], a_rel[NPW], row_[NPW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NPW; ++i) {
         const int row = (i * 4 + wave) * 4 + (lane >> 4);
         const int chunk = (lane & 15) ^ ((row & 7) << 1);
         const int dch = co0 + chunk * 8, ach = ci0 + chunk * 8;
@@ -527,7 +529,7 @@ __global__ __launch_bounds__(256) void wgrad1x1_kernel(W1Params p) {
         const unsigned dst = (unsigned)(uintptr_t)(smem + buf * STAGE_B);
         const size_t dbase = (size_t)pix0 * p.Co8, abase = (size_t)pix0 * p.C8;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NPW; ++i) {
             const bool pok = pix0 + row_[i] < p.P;
             const bool dok = pok && d_rel[i] >= 0, aok = pok && a_rel[i] >= 0;
             const unsigned o = dst + (unsigned)((i * 4 + wave) * 1024);
@@ -629,7 +631,7 @@ static int launch_wreduce(const WgradParams& p, int T, float* dw, float* dbias, 
     return lp_check_launch("wgrad_reduce");
 }
 
-template <int PREC>
+template <int PREC, int KP>
 static int launch_wgrad1x1(WgradParams& p, float* dw, const float* out_scale, const float* sn_w, float* sn_dot, hipStream_t stream) {
     constexpr bool SPLIT = (PREC == LP_PREC_BF16X3);
     W1Params q;
@@ -637,14 +639,14 @@ static int launch_wgrad1x1(WgradParams& p, float* dw, const float* out_scale, co
     q.P = (long long)p.N * p.H * p.W;
     q.C8 = p.C8; q.Co8 = p.Co8; q.CoP = p.CoP; q.CiP = p.CiP;
     q.tiles_co = (p.CoP + 127) / 128; q.tiles_ci = (p.CiP + 127) / 128;
-    q.nstage = (int)((q.P + 63) / 64);
+    q.nstage = (int)((q.P + KP - 1) / KP);
     int splits = p.splits < q.nstage ? p.splits : q.nstage;
     const int per = (q.nstage + splits - 1) / splits;
     splits = (q.nstage + per - 1) / per;                   // no empty split: every slab the reduction sums is written
     p.splits = q.splits = splits;
     q.xcd_map = (splits % 8 == 0);
-    const size_t lds = (size_t)2 * 64 * 256 * (SPLIT ? 4 : 2);
-    auto kern = wgrad1x1_kernel<PREC>;
+    const size_t lds = (size_t)2 * KP * 256 * (SPLIT ? 4 : 2);
+    auto kern = wgrad1x1_kernel<PREC, KP>;
     static thread_local int attr_dev = -1;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return lp_set_error(LP_ERR_HIP, "hipGetDevice failed");
@@ -677,7 +679,12 @@ static int dispatch_wgrad(WgradParams& p, float* dw, float* dbias, const float* 
     if (cob128 && p.Cout >= 128 && ksize == 3)
         return upsample ? launch_wgrad<3, true, PREC, 128>(p, dw, dbias, out_scale, sn_w, sn_dot, s) : launch_wgrad<3, false, PREC, 128>(p, dw, dbias, out_scale, sn_w, sn_dot, s);
     static const bool w1_old = getenv("LP_WGRAD1X1_OLD") != nullptr;                              // A/B knob: the generic kernel for 1x1 layers
-    if (ksize == 1 && !upsample && !p.bpart && !w1_old) return launch_wgrad1x1<PREC>(p, dw, out_scale, sn_w, sn_dot, s);
+    static const int w1_kp = getenv("LP_W1_KP") ? atoi(getenv("LP_W1_KP")) : 0;                   // bf16x3 stage: 32 (default) | 64 pixels
+    if (ksize == 1 && !upsample && !p.bpart && !w1_old) {
+        const int kp = w1_kp ? w1_kp : (PREC == LP_PREC_BF16X3 ? 32 : 64);
+        if (kp == 32) return launch_wgrad1x1<PREC, 32>(p, dw, out_scale, sn_w, sn_dot, s);
+        return launch_wgrad1x1<PREC, 64>(p, dw, out_scale, sn_w, sn_dot, s);
+    }
     static const int cob1_env = getenv("LP_WGRAD_COB1") ? atoi(getenv("LP_WGRAD_COB1")) : 0;        // 1x1 layers: 64 | 128 forces
     if ((cob1_env ? cob1_env == 128 : true) && p.Cout >= 128 && ksize == 1 && !upsample)
         return launch_wgrad<1, false, PREC, 128>(p, dw, dbias, out_scale, sn_w, sn_dot, s);

@@ -351,7 +351,7 @@ def default_splits(n, h, w, cin, cout, ksize=3, prec=None, bias=False):
     if ksize == 1 and not bias and os.environ.get('LP_WGRAD1X1_OLD') is None:
         stages = (n * h * w + 63) // 64
         blocks = (_round_up(cout, 64) + 127) // 128 * ((_round_up(cin, 64) + 127) // 128)
-        s = max(1, min((256 if prec == PREC_BF16X3 else 512) // blocks, stages // 8))
+        s = max(1, min(512 // blocks, stages // 8))          # (bf16x3 too since round 4: 32-pixel stages, two workgroups per CU)
         return s // 8 * 8 if s >= 8 else s
     tiles = (n * h * w + 127) // 128
     if ksize == 1:
