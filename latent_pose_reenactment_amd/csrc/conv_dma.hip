@@ -263,7 +263,9 @@ void conv_dma_kernel(Conv16Params p) {
 #pragma unroll
             for (int ky = 0; ky < KS; ++ky) {
                 const int s = chunk * KS + ky;
-                if (NBUF == 3 && s + 1 < S) lp_wait_vm<NBW>(); else lp_wait_vm0();
+                // (one halo buffer: the next chunk's halo is issued AFTER this stage's weights -- it is the newest DMA, so only a full drain
+                //  covers it; the counted wait is for the double-buffered halo, which is issued first)
+                if (NBUF == 3 && s + 1 < S && p.a_dbuf) lp_wait_vm<NBW>(); else lp_wait_vm0();
                 __syncthreads();
                 // (halo first: it is older than the weights issued below, so the counted wait of the next stage covers it)
                 if (p.a_dbuf && ky == 0 && has_next) issue_a(cbeg + chunk + 1, H_base + (abuf ^ 1) * a_buf);
