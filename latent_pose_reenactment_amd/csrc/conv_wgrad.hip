@@ -377,36 +377,51 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
-// Small layers (few weights, many pixel splits: 64 x 64 x 9 weights summed over up to 512 slabs): one thread per (tap, co, ci) so that
-// the grid is as wide as the layer allows; the strided 4-byte stores do not matter at these sizes.
+// Small layers (few weights, many pixel splits: 64 x 64 x 9 weights summed over up to 512 slabs): 32 outputs (tap, co, ci; ci fastest: one
+// 128-byte run per slab) x 8 groups of slabs per block, so that the grid is as wide as the layer allows AND the slab loop is short (round 4:
+// one thread per output over 512 slabs left the 64 x 64 layer at 145 blocks, 25 us for 75 MB); the 8 group sums meet in LDS in a fixed
+// order.  The strided 4-byte stores do not matter at these sizes.
+template <int WREDF_OUT>                                  // outputs per block: 32 (x 8 slab groups) | 256 (x 1: layers that fill the chip anyway)
 __global__ __launch_bounds__(256) void wgrad_reduce_flat_kernel(const float* __restrict__ part, float* __restrict__ dw, int S, int T, int Cout,
                                                                 int Cin, int CoP, int CiP, const float* __restrict__ bpart,
                                                                 float* __restrict__ dbias, int wblocks, const float* __restrict__ out_scale,
                                                                 const float* __restrict__ sn_w, float* __restrict__ sn_dot, int db_acc) {
     const float osc = out_scale ? out_scale[0] : 1.f;
     if ((int)blockIdx.x >= wblocks) { wred_bias_block(bpart, dbias, S, Cout, CoP, blockIdx.x - wblocks, osc, db_acc); return; }
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    float dsum = 0.f;
-    if (idx < T * Cout * Cin) {
+    constexpr int SG = 256 / WREDF_OUT;
+    __shared__ float gsum[SG][WREDF_OUT];
+    const int lo = threadIdx.x % WREDF_OUT, sg = threadIdx.x / WREDF_OUT;
+    const int idx = blockIdx.x * WREDF_OUT + lo;
+    const bool live = idx < T * Cout * Cin;
+    size_t o = 0;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
         const int ci = idx % Cin, r = idx / Cin;
         const int co = r % Cout, t = r / Cout;
         const size_t slab = (size_t)T * CoP * CiP;
         const float* p = part + ((size_t)t * CoP + co) * CiP + ci;
-        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        int k = 0;
-        for (; k + 8 <= S; k += 8) {
+        o = ((size_t)co * Cin + ci) * T + t;
+        int k = sg;
+        for (; k + 3 * SG < S; k += 4 * SG) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) a[q] += p[(size_t)(k + q) * slab];
+            for (int q = 0; q < 4; ++q) a[q] += p[(size_t)(k + SG * q) * slab];
         }
-        for (; k < S; ++k) a[0] += p[(size_t)k * slab];
-        const float val = (((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) * osc;
-        const size_t o = ((size_t)co * Cin + ci) * T + t;
+        for (; k < S; k += SG) a[0] += p[(size_t)k * slab];
+    }
+    gsum[sg][lo] = (a[0] + a[1]) + (a[2] + a[3]);
+    __syncthreads();
+    float dsum = 0.f;
+    if (sg == 0 && live) {
+        float val = gsum[0][lo];
+#pragma unroll
+        for (int q = 1; q < SG; ++q) val += gsum[q][lo];                   // fixed order
+        val *= osc;
         dw[o] = val;
         if (sn_w) dsum = val * sn_w[o];
     }
-    if (sn_w) {
+    if (sn_w) {                                          // (slab groups > 0 contribute zeros)
         __shared__ float dred[4];
-        for (int o = 32; o > 0; o >>= 1) dsum += __shfl_down(dsum, o, 64);
+        for (int off = 32; off > 0; off >>= 1) dsum += __shfl_down(dsum, off, 64);
         if ((threadIdx.x & 63) == 0) dred[threadIdx.x >> 6] = dsum;
         __syncthreads();
         if (threadIdx.x == 0) sn_dot[blockIdx.x] = (dred[0] + dred[1]) + (dred[2] + dred[3]);
@@ -415,11 +430,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_flat_kernel(const float* __r
 
 // which reduction a layer gets, and with it the number of <dw, W_orig> partials
 static bool wred_tiled(int Cin, int Cout) { return Cout * ((Cin + WRED_CI - 1) / WRED_CI) >= 512; }
+// flat reduction: 32 outputs x 8 slab groups per block where 256 outputs per block would leave the grid under ~1.5 blocks per CU
+static int wred_flat_out(int Cin, int Cout, int T) { return (T * Cout * Cin + 255) / 256 < 400 ? 32 : 256; }
 static int wred_blocks(int Cin, int Cout, int T) {
-    return wred_tiled(Cin, Cout) ? Cout * ((Cin + WRED_CI - 1) / WRED_CI) : (T * Cout * Cin + 255) / 256;
+    const int fo = wred_flat_out(Cin, Cout, T);
+    return wred_tiled(Cin, Cout) ? Cout * ((Cin + WRED_CI - 1) / WRED_CI) : (T * Cout * Cin + fo - 1) / fo;
 }
 
 static int ilog2_floor_w(int v) { int l = 0; while ((1 << (l + 1)) <= v) ++l; return l; }
+
+struct WgradParams;
+static int launch_wreduce(const WgradParams& p, int T, float* dw, float* dbias, const float* out_scale, const float* sn_w, float* sn_dot,
+                          hipStream_t stream);
 
 template <int KS, bool UPS, int PREC, int COB = 64>
 static int launch_wgrad(WgradParams& p, float* dw, float* dbias, const float* out_scale, const float* sn_w, float* sn_dot, hipStream_t stream) {
@@ -454,19 +476,7 @@ static int launch_wgrad(WgradParams& p, float* dw, float* dbias, const float* ou
     int rc = lp_check_launch("conv_wgrad");
     if (rc) return rc;
     if (p.diag) return LP_OK;                              // the grouped reduction is launched by lp_gconv16_wgrad
-    int total = KS * KS * p.Cout * p.Cin;
-    (void)total;
-    const int bblocks = p.bpart ? (p.Cout + 63) / 64 : 0;
-    if (wred_tiled(p.Cin, p.Cout)) {
-        const int wblocks = wred_blocks(p.Cin, p.Cout, KS * KS);
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wblocks + bblocks), dim3(256), 0, stream, p.part, dw, p.splits, KS * KS,
-                           p.Cout, p.Cin, p.CoP, p.CiP, p.bpart, dbias, wblocks, out_scale, sn_w, sn_dot, p.db_acc);
-    } else {
-        const int wblocks = wred_blocks(p.Cin, p.Cout, KS * KS);
-        hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3(wblocks + bblocks), dim3(256), 0, stream, p.part, dw, p.splits, KS * KS, p.Cout, p.Cin,
-                           p.CoP, p.CiP, p.bpart, dbias, wblocks, out_scale, sn_w, sn_dot, p.db_acc);
-    }
-    return lp_check_launch("wgrad_reduce");
+    return launch_wreduce(p, KS * KS, dw, dbias, out_scale, sn_w, sn_dot, stream);
 }
 
 
@@ -625,8 +635,11 @@ static int launch_wreduce(const WgradParams& p, int T, float* dw, float* dbias, 
     if (wred_tiled(p.Cin, p.Cout))
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wblocks + bblocks), dim3(256), 0, stream, p.part, dw, p.splits, T, p.Cout, p.Cin, p.CoP, p.CiP,
                            p.bpart, dbias, wblocks, out_scale, sn_w, sn_dot, p.db_acc);
+    else if (wred_flat_out(p.Cin, p.Cout, T) == 32)
+        hipLaunchKernelGGL(wgrad_reduce_flat_kernel<32>, dim3(wblocks + bblocks), dim3(256), 0, stream, p.part, dw, p.splits, T, p.Cout, p.Cin, p.CoP,
+                           p.CiP, p.bpart, dbias, wblocks, out_scale, sn_w, sn_dot, p.db_acc);
     else
-        hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3(wblocks + bblocks), dim3(256), 0, stream, p.part, dw, p.splits, T, p.Cout, p.Cin, p.CoP,
+        hipLaunchKernelGGL(wgrad_reduce_flat_kernel<256>, dim3(wblocks + bblocks), dim3(256), 0, stream, p.part, dw, p.splits, T, p.Cout, p.Cin, p.CoP,
                            p.CiP, p.bpart, dbias, wblocks, out_scale, sn_w, sn_dot, p.db_acc);
     return lp_check_launch("wgrad_reduce");
 }
@@ -661,6 +674,219 @@ static int launch_wgrad1x1(WgradParams& p, float* dw, const float* out_scale, co
     return launch_wreduce(p, 1, dw, nullptr, out_scale, sn_w, sn_dot, stream);
 }
 
+
+// ---- 3x3 weight gradient, DMA-staged (round 4) ------------------------------------------------------------------------------------------
+// conv_wgrad_kernel stages both operands load -> register -> LDS -> barrier with nothing in flight while it multiplies, and a wave's
+// 32(co) x 32(ci) x 9-tap block costs 40 transposing LDS reads per 36 MFMAs: 0.117 of the MFMA peak over the step's 3x3 layers for three
+// rounds.  This kernel is the same contraction on the wgrad1x1_kernel template:
+//   * a workgroup owns 64(co) x 64(ci) x 9 taps and a contiguous range of 8 x 16-pixel tiles (split-K over pixels); a wave owns ALL 64 output
+//     channels x 16 input channels x 9 taps (36 accumulator tiles): the 4 dy fragments of a k-step are read once and used by all 9 taps,
+//     each tap needs ONE input fragment -> 26 transposing reads per 36 MFMAs;
+//   * the dy tile [128 pixels][64 co] and the input halo [10 x 18 (6 x 10 low-resolution with the fused x2 upsampling) pixels][64 ci] go
+//     global -> LDS by DMA (1 KiB pieces of 8 pixel rows x 128 B), double buffered: the DMA of tile t+1 is in flight while tile t multiplies,
+//     one barrier per tile; two workgroups per CU (78 KB of LDS, <= 256 registers each) overlap each other's waits;
+//   * 128-byte rows: the 32-byte units of row r are XOR-swizzled with (r >> 1) & 3 -- with the row's parity that spreads any 8 CONSECUTIVE
+//     rows over the 8 units of the 256-byte bank period, and the 8 pixels a half-wave's transposing read touches are consecutive halo rows for
+//     every tap shift (halo rows are 18 | 10 = 2 mod 8 pixels apart: the key of pixel (row, col) is (row + (col >> 1)) & 3);
+//   * the bias gradient (column sums of dy) comes from the matrix core as well: dy x ones, one extra MFMA per k-step and wave;
+//   * XCD-aware block order as wgrad1x1_kernel: the (co, ci) tiles of one pixel range run on one XCD.
+// Output: the [split][tap][CoP][CiP] slabs of the common reduction.  f16 / bf16 operands (the bf16x3 mode keeps conv_wgrad_kernel).
+struct W3Params {
+    const uint16_t* a_hi; const uint16_t* d_hi; float* part; float* bpart;
+    int N, H, W, Hin, Win, C8, Co8, CoP, CiP;
+    int splits, per, num_tiles, tiles_x, tiles_y, tiles_co, tiles_ci, xcd_map, diag;
+};
+
+template <bool UPS, bool F16>
+__global__ __launch_bounds__(256, 2) void wgrad3_pipe_kernel(W3Params p) {
+    constexpr int HH = UPS ? 6 : 10, HW = UPS ? 10 : 18;
+    constexpr int HALO_PX = HH * HW;
+    constexpr int NAH = (HALO_PX + 7) / 8;                  // 1 KiB DMA pieces of the halo: 23 | 8
+    constexpr int NAW = (NAH + 3) / 4;                      // per wave
+    constexpr int HALO_B = NAH * 1024, DY_B = 128 * 128, STAGE_B = HALO_B + DY_B;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntile = p.tiles_co * p.tiles_ci;
+    int tile, split;
+    if (p.xcd_map) { const int x = blockIdx.x & 7, j = blockIdx.x >> 3; tile = j % ntile; split = (j / ntile) * 8 + x; }
+    else { tile = blockIdx.x % ntile; split = blockIdx.x / ntile; }
+    const int tco = tile / p.tiles_ci, tci = tile - tco * p.tiles_ci;
+    const int co0 = tco * 64, ci0 = p.diag ? co0 : tci * 64;
+    const int t_beg = split * p.per, t_end = min(p.num_tiles, t_beg + p.per);
+    const uint16_t* zero16 = (const uint16_t*)w1_zero_page;
+
+    // DMA piece q = i*4 + wave covers LDS rows 8q .. 8q+7 (a row = one pixel x 64 channels); lane -> row 8q + lane/8, 16-byte slot lane%8,
+    // which holds the channel chunk slot ^ (((row >> 1) & 3) << 1)
+    auto issue = [&](int t, int buf) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));                        // re-derive the lane's piece coordinates per tile: hoisted out of the loop they cost
+        const int lrow = ln >> 3, lslot = ln & 7;           // ~20 registers that the 144 + 48 accumulator / fragment registers do not leave
+        int r = t;
+        const int tx = r % p.tiles_x; r /= p.tiles_x;
+        const int ty = r % p.tiles_y; const int n0 = r / p.tiles_y;
+        const int y0 = ty * 8, x0 = tx * 16;
+        const int oy = UPS ? (y0 >> 1) - 1 : y0 - 1, ox = UPS ? (x0 >> 1) - 1 : x0 - 1;
+        const unsigned dst = (unsigned)(uintptr_t)(smem + buf * STAGE_B);
+#pragma unroll
+        for (int i = 0; i < NAW; ++i) {
+            const int q = i * 4 + wave;
+            if (q < NAH) {                                  // (wave-uniform)
+                const int hp = q * 8 + lrow;
+                const int hy = hp / HW, hx = hp - hy * HW;
+                const int ch = ci0 + ((lslot ^ (((hp >> 1) & 3) << 1)) << 3);
+                const int iy = oy + hy, ix = ox + hx;
+                const bool ok = (hp < HALO_PX) && (ch < p.C8) && (iy >= 0) && (iy < p.Hin) && (ix >= 0) && (ix < p.Win);
+                lp_glds16(ok ? p.a_hi + ((size_t)((n0 * p.Hin + iy) * p.Win + ix) * p.C8 + ch) : zero16, dst + (unsigned)(q * 1024));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = i * 4 + wave;
+            const int kp = q * 8 + lrow;
+            const int ch = co0 + ((lslot ^ (((kp >> 1) & 3) << 1)) << 3);
+            const int yy = y0 + (kp >> 4), xx = x0 + (kp & 15);
+            const bool ok = (ch < p.Co8) && (yy < p.H) && (xx < p.W);
+            lp_glds16(ok ? p.d_hi + ((size_t)((n0 * p.H + yy) * p.W + xx) * p.Co8 + ch) : zero16, dst + (unsigned)(HALO_B + q * 1024));
+        }
+    };
+
+    f32x4_t acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[t][i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    f32x4_t accb = (f32x4_t){0.f, 0.f, 0.f, 0.f};           // wave w: column sums of dy for co0 + 16 w .. + 15 (every column of the tile is the sum)
+    const bool do_bias = (p.bpart != nullptr) && (tci == 0);
+    const short one16 = F16 ? (short)0x3C00 : (short)0x3F80;
+    const s16x8_t ones = (s16x8_t){one16, one16, one16, one16, one16, one16, one16, one16};
+
+    // source-lane role of the transposing reads (header of this file): pixel column pxl of the 16-pixel patch row, channels 4 sq .. 4 sq + 3
+    const int G = lane >> 4, sj = (lane & 15) >> 2, sq = lane & 3;
+    const int pxl = G * 4 + sj;
+    const int swA = (pxl >> 1) & 3;                         // key of dy row 16 m + pxl
+    int aoff[4];
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf) aoff[mf] = pxl * 128 + ((mf ^ swA) << 5) + sq * 8;
+    int bl[3], bs[3];                                      // per tap column dx: byte offset of the lane's halo column, key part of that column
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+        const int col = UPS ? ((pxl + dx - 1) >> 1) + 1 : pxl + dx;
+        bl[dx] = col * 128 + sq * 8; bs[dx] = col >> 1;
+    }
+
+    auto compute = [&](int buf) {
+        const unsigned char* Hb = smem + buf * STAGE_B;
+        const unsigned char* Db = Hb + HALO_B;
+        s16x8_t fa[2][4], fb[3];
+        auto fetch_a = [&](int ks, int set) {
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf) {
+                const s16x4_t v0 = tr_read(Db + (ks * 32) * 128 + aoff[mf]), v1 = tr_read(Db + (ks * 32 + 16) * 128 + aoff[mf]);
+                fa[set][mf] = (s16x8_t){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            }
+        };
+        auto fetch_b = [&](int g, int set) {
+            const int ks = g / 9, tap = g - ks * 9;
+            const int dy = tap / 3, dx = tap - dy * 3;
+            const int r0 = UPS ? ((2 * ks + dy - 1) >> 1) + 1 : 2 * ks + dy;
+            const int r1 = UPS ? ((2 * ks + dy) >> 1) + 1 : 2 * ks + dy + 1;
+            const s16x4_t v0 = tr_read(Hb + r0 * HW * 128 + bl[dx] + ((wave ^ ((bs[dx] + r0) & 3)) << 5));
+            const s16x4_t v1 = tr_read(Hb + r1 * HW * 128 + bl[dx] + ((wave ^ ((bs[dx] + r1) & 3)) << 5));
+            fb[set] = (s16x8_t){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        };
+        fetch_a(0, 0); fetch_b(0, 0); fetch_b(1, 1);
+#pragma unroll
+        for (int g = 0; g < 36; ++g) {
+            const int ks = g / 9, tap = g - ks * 9;
+            if (g + 2 < 36) fetch_b(g + 2, (g + 2) % 3);
+            if (tap == 4 && ks + 1 < 4) fetch_a(ks + 1, (ks + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf) acc[tap][mf] = mfma16t<F16>(fa[ks & 1][mf], fb[g % 3], acc[tap][mf]);
+            if (tap == 0 && do_bias) {                      // (scalar selects: no dynamic register indexing)
+                const s16x8_t fw = wave == 0 ? fa[ks & 1][0] : wave == 1 ? fa[ks & 1][1] : wave == 2 ? fa[ks & 1][2] : fa[ks & 1][3];
+                accb = mfma16t<F16>(fw, ones, accb);
+            }
+        }
+    };
+
+    if (t_beg < t_end) issue(t_beg, 0);
+    for (int t = t_beg; t < t_end; ++t) {
+        const int buf = (t - t_beg) & 1;
+        lp_wait_vm0();
+        __syncthreads();                    // tile t has landed for every wave; everyone is done with the other buffer
+        if (t + 1 < t_end) issue(t + 1, buf ^ 1);
+        compute(buf);
+    }
+
+    // C layout of the 16x16 MFMA: row (co) = (lane >> 4) * 4 + r, column (ci) = lane & 15
+    const int cib = (p.diag ? 0 : ci0) + wave * 16 + (lane & 15);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + mf * 16 + (lane >> 4) * 4 + r;
+                p.part[(((size_t)split * 9 + tap) * p.CoP + co) * p.CiP + cib] = acc[tap][mf][r];
+            }
+    if (do_bias && (lane & 15) == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p.bpart[(size_t)split * p.CoP + co0 + wave * 16 + (lane >> 4) * 4 + r] = accb[r];
+    }
+}
+
+template <bool UPS, int PREC>
+static int launch_wgrad3_pipe(WgradParams& p, float* dw, float* dbias, const float* out_scale, const float* sn_w, float* sn_dot, hipStream_t stream) {
+    static_assert(PREC != LP_PREC_BF16X3, "one-plane operand modes only");
+    static const int target_env = getenv("LP_WGRAD3_WGS") ? atoi(getenv("LP_WGRAD3_WGS")) : 0;
+    W3Params q;
+    q.a_hi = p.a_hi; q.d_hi = p.d_hi; q.part = p.part; q.bpart = p.bpart;
+    q.N = p.N; q.H = p.H; q.W = p.W; q.Hin = p.Hin; q.Win = p.Win; q.C8 = p.C8; q.Co8 = p.Co8; q.CoP = p.CoP; q.CiP = p.CiP;
+    q.diag = p.diag;
+    q.tiles_x = (p.W + 15) / 16; q.tiles_y = (p.H + 7) / 8;
+    q.num_tiles = q.tiles_x * q.tiles_y * p.N;
+    q.tiles_co = p.CoP / 64; q.tiles_ci = p.diag ? 1 : p.CiP / 64;
+    const int ntile = q.tiles_co * q.tiles_ci;
+    const int target = target_env > 0 ? target_env : 1024;                 // ~2 resident sets of two workgroups per CU
+    int splits = target / ntile; if (splits < 1) splits = 1;
+    if (splits > p.splits) splits = p.splits;
+    if (splits > q.num_tiles) splits = q.num_tiles;
+    if (splits >= 8) splits = splits / 8 * 8;
+    q.per = (q.num_tiles + splits - 1) / splits;
+    splits = (q.num_tiles + q.per - 1) / q.per;                            // no empty split: every slab the reduction sums is written
+    p.splits = q.splits = splits;
+    q.xcd_map = (splits % 8 == 0);
+    constexpr int HALO_PX = UPS ? 60 : 180;
+    const size_t lds = (size_t)2 * (((HALO_PX + 7) / 8) * 1024 + 128 * 128);
+    auto kern = wgrad3_pipe_kernel<UPS, PREC == LP_PREC_F16>;
+    static thread_local int attr_dev = -1;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return lp_set_error(LP_ERR_HIP, "hipGetDevice failed");
+    if (attr_dev != dev) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return lp_set_error(LP_ERR_HIP, "hipFuncSetAttribute failed");
+        attr_dev = dev;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(ntile * splits)), dim3(256), lds, stream, q);
+    int rc = lp_check_launch("wgrad3_pipe");
+    if (rc) return rc;
+    if (p.diag) return LP_OK;                              // the grouped reduction is launched by lp_gconv16_wgrad
+    return launch_wreduce(p, 9, dw, dbias, out_scale, sn_w, sn_dot, stream);
+}
+
+// LP_WGRAD3_PIPE = 0: conv_wgrad_kernel everywhere | 1 (default): the DMA-staged kernel for layers with >= LP_WGRAD3_MIN_TILES (32) pixel
+// tiles and W >= 16 | 2: for every 3x3 layer of a one-plane mode (tests)
+template <int PREC>
+static bool wgrad3_pipe_wanted(const WgradParams& p) {
+    if (PREC == LP_PREC_BF16X3) return false;
+    static const int mode = getenv("LP_WGRAD3_PIPE") ? atoi(getenv("LP_WGRAD3_PIPE")) : 1;
+    static const int min_tiles = getenv("LP_WGRAD3_MIN_TILES") ? atoi(getenv("LP_WGRAD3_MIN_TILES")) : 32;
+    if (mode == 0) return false;
+    if (mode == 2) return true;
+    return p.W >= 16 && p.H >= 8 && ((p.W + 15) / 16) * ((p.H + 7) / 8) * p.N >= min_tiles;
+}
+
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 extern "C" int lp_conv_wgrad_dot_blocks(int Cin, int Cout, int ksize) { return wred_blocks(Cin, Cout, ksize * ksize); }
@@ -676,6 +902,10 @@ static int dispatch_wgrad(WgradParams& p, float* dw, float* dbias, const float* 
     // 128 output channels per workgroup (8 waves) where the layer is wide enough; LP_WGRAD_COB = 64 | 128 overrides
     static const int cob_env = getenv("LP_WGRAD_COB") ? atoi(getenv("LP_WGRAD_COB")) : 0;
     const bool cob128 = cob_env ? (cob_env == 128) : true;      // measured: -9 % (bf16x3), -6 % (bf16) on the 64..512-channel layers
+    if constexpr (PREC != LP_PREC_BF16X3) {
+        if (ksize == 3 && wgrad3_pipe_wanted<PREC>(p))
+            return upsample ? launch_wgrad3_pipe<true, PREC>(p, dw, dbias, out_scale, sn_w, sn_dot, s) : launch_wgrad3_pipe<false, PREC>(p, dw, dbias, out_scale, sn_w, sn_dot, s);
+    }
     if (cob128 && p.Cout >= 128 && ksize == 3)
         return upsample ? launch_wgrad<3, true, PREC, 128>(p, dw, dbias, out_scale, sn_w, sn_dot, s) : launch_wgrad<3, false, PREC, 128>(p, dw, dbias, out_scale, sn_w, sn_dot, s);
     static const bool w1_old = getenv("LP_WGRAD1X1_OLD") != nullptr;                              // A/B knob: the generic kernel for 1x1 layers
@@ -752,7 +982,9 @@ extern "C" int lp_gconv16_wgrad(const uint16_t* a_hi, const uint16_t* a_lo, cons
     p.splits = splits; p.db_acc = 0; p.diag = 1; p.bpart = nullptr;
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    if (prec == LP_PREC_BF16) rc = launch_wgrad<3, false, LP_PREC_BF16>(p, dw, nullptr, out_scale, nullptr, nullptr, s);
+    if (prec == LP_PREC_BF16 && wgrad3_pipe_wanted<LP_PREC_BF16>(p)) rc = launch_wgrad3_pipe<false, LP_PREC_BF16>(p, dw, nullptr, out_scale, nullptr, nullptr, s);
+    else if (prec == LP_PREC_F16 && wgrad3_pipe_wanted<LP_PREC_F16>(p)) rc = launch_wgrad3_pipe<false, LP_PREC_F16>(p, dw, nullptr, out_scale, nullptr, nullptr, s);
+    else if (prec == LP_PREC_BF16) rc = launch_wgrad<3, false, LP_PREC_BF16>(p, dw, nullptr, out_scale, nullptr, nullptr, s);
     else if (prec == LP_PREC_BF16X3) rc = launch_wgrad<3, false, LP_PREC_BF16X3>(p, dw, nullptr, out_scale, nullptr, nullptr, s);
     else if (prec == LP_PREC_F16) rc = launch_wgrad<3, false, LP_PREC_F16>(p, dw, nullptr, out_scale, nullptr, nullptr, s);
     else return lp_set_error(LP_ERR_ARG, "lp_gconv16_wgrad: unknown precision");

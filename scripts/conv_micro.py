@@ -16,6 +16,11 @@ if os.environ.get('SHAPES') == '1x1':        # the embedder's pointwise layers o
     SHAPES = [(1, p // 16, 16, ci, co, 1, 0) for p, ci, co in
               [(262144, 64, 128), (262144, 128, 256), (262144, 256, 128), (65536, 256, 512), (65536, 512, 256), (16384, 512, 1024),
                (16384, 1024, 512), (4096, 1024, 2048), (4096, 2048, 1024)]]
+if os.environ.get('SHAPES') == 'wgrad':      # the 3x3 weight-gradient classes of the meta-training step (generator, critic)
+    SHAPES = [(8, 256, 256, 64, 64, 3, 0), (8, 128, 128, 64, 128, 3, 0), (8, 128, 128, 128, 128, 3, 0), (8, 64, 64, 128, 256, 3, 0),
+              (8, 64, 64, 256, 256, 3, 0), (8, 32, 32, 256, 512, 3, 0), (8, 32, 32, 512, 512, 3, 0), (8, 16, 16, 512, 512, 3, 0),
+              (8, 256, 256, 128, 64, 3, 1), (8, 128, 128, 256, 128, 3, 1), (8, 64, 64, 512, 256, 3, 1), (8, 32, 32, 512, 512, 3, 1)]
+BIAS = os.environ.get('BIAS', '0') != '0'     # the weight-gradient launch also produces the bias gradient (as the step's layers do)
 prec = int(os.environ.get('PREC', '0'))
 REPS = int(os.environ.get('REPS', '20'))
 WHAT = os.environ.get('WHAT', 'conv,pack,wgrad').split(',')
@@ -52,6 +57,6 @@ for (n, h, w, cin, cout, ks, ups) in SHAPES:
         gb = x.numel() * (4 + (4 if prec == 1 else 2)) / 1e3
         out.append(f'pack {us:6.1f} us {gb / us:6.0f} GB/s')
     if 'wgrad' in WHAT:
-        us = timeit(lambda: ops.conv_wgrad16(a, d, ksize=ks, upsample=bool(ups), prec=prec))
+        us = timeit(lambda: ops.conv_wgrad16(a, d, ksize=ks, upsample=bool(ups), prec=prec, bias_grad=BIAS))
         out.append(f'wgrad {us:7.1f} us {fl / us / 1e6:7.1f} TF/s')
     print(' | '.join(out), flush=True)
