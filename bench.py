@@ -50,11 +50,11 @@ def stream_config(workload):
     from latent_pose_reenactment_amd import streams
     probe = torch.empty(1, device='cuda') if torch.cuda.is_available() else None
     ft = workload != 'metatrain_step'
-    on = [k for k in ('encoders', 'criterions', 'prepare', 'dpasses', 'optimizer') if probe is not None and streams.enabled(probe, k, finetuning=ft) and not (ft and k == 'encoders')]
+    on = [k for k in ('encoders', 'criterions', 'prepare', 'dpasses', 'real', 'optimizer') if probe is not None and streams.enabled(probe, k, finetuning=ft) and not (ft and k == 'encoders')]
     return {'concurrent_branches': on if workload != 'generator' else [],
             'note': 'encoders: pose encoder beside the identity encoder; criterions: VGG-19 / VGGFace stacks beside the discriminator pass; '
                     'prepare: spectral-norm power iterations + weight packs of G and D beside the encoders; dpasses: the discriminator\'s three '
-                    'passes beside each other; autograd runs each backward on its forward stream; captured as parallel '
+                    'passes beside each other; real: its real-image pass already beside the generator forward; autograd runs each backward on its forward stream; captured as parallel '
                     'paths of the hipGraphs'}
 
 

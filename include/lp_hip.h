@@ -121,7 +121,8 @@ int lp_conv_wgrad_dot_blocks(int Cin, int Cout, int ksize);
  * gradient): bandwidth-bound kernels on plain NHWC fp32 activations (no input operand planes); weights from the same packs.
  *   lp_thin_conv_fwd:  y = alpha * conv(x, w) + bias for Cin <= 4, Cout % 64 == 0 (lp_thin_conv_supported).  fp32 VALU kernel; the
  *                      RGB 3x3 case in the fp16 / bf16 modes (lp_thin_conv_emits_planes: Cin 3, W % 16 == 0) runs as one MFMA k-step
- *                      per output block and can also write out_hi [N][H][W][Cout] = the operand planes of (out_relu ? relu(y) : y).
+ *                      per output block and can also write out_hi [N][H][W][Cout] = the operand planes of (out_relu ? relu(y) : y);
+ *                      y may then be NULL (planes-only output, ABI 7).
  *   lp_thin_wgrad:     dw (and dbias when lp_thin_wgrad_has_dbias) for Cin <= 4 (pro 0) or Cout <= 4 (3x3; the AdaIN/ReLU prologue
  *                      pro/scale/shift of the wide input is applied on the fly); workspace as lp_conv_wgrad_workspace_bytes(). */
 int lp_thin_conv_supported(int Cin, int Cout, int ksize, int W);
@@ -314,6 +315,9 @@ int lp_relu_bwd(const float* dA, const float* x, float* dx, long long numel, voi
 /* y = AvgPool2d(2)(relu?(x)); x [N][2H][2W][C], y [N][H][W][C]   (nn.AvgPool2d, blocks.py:89-90; perceptual_loss.py:77);
  * out_hi [N][H][W][C]|NULL (C % 8 == 0, prec bf16 | fp16): also the operand planes of y for the conv that follows */
 int lp_avgpool2_fwd(const float* x, float* y, int N, int H, int W, int C, int relu_in, uint16_t* out_hi, int prec, void* stream);
+/* the same on operand planes (ABI 7): x_hi [N][2H][2W][C] -> out_hi [N][H][W][C] (C % 8 == 0, prec bf16 | fp16; fp32 sum, one rounding) --
+ * for no-grad chains that keep no fp32 activations: the VGG stacks over the TARGET image (perceptual_loss.py:86-93: `with torch.no_grad()`) */
+int lp_avgpool2_fwd16(const uint16_t* x_hi, uint16_t* out_hi, int N, int H, int W, int C, int prec, void* stream);
 /* dx [N][H][W][C] = 0.25 * dy[.., y>>1, x>>1, ..] * (relu_in ? [x>0] : 1); H, W = full-resolution dims */
 int lp_avgpool2_bwd(const float* dy, const float* x, float* dx, int N, int H, int W, int C, int relu_in, float* amax_slots, void* stream);
 /* L1 taps: partial[lp_l1_partial_blocks()] block sums of |relu?(a) - relu?(b)| (F.l1_loss numerator; featmat.py:17, perceptual_loss.py:107);
@@ -325,6 +329,9 @@ int lp_l1_partial_blocks(void);
  * reads one byte per element instead of a and b again (a, b may be NULL). */
 int lp_l1_fwd(const float* a, const float* b, float* partial, long long numel, int relu_in, float coef, float* out, int8_t* sign_out,
               void* stream);
+/* lp_l1_fwd with b given as 16-bit operand planes b_hi [numel] (prec bf16 | fp16; same element order as a) -- ABI 7 */
+int lp_l1_fwd_b16(const float* a, const uint16_t* b_hi, int prec, float* partial, long long numel, int relu_in, float coef, float* out,
+                  int8_t* sign_out, void* stream);
 int lp_l1_bwd(const float* a, const float* b, const float* grad_out, float coef, const float* add, float* da, long long numel, int relu_in,
               const int8_t* sign, float* amax_slots, void* stream);
 

@@ -95,9 +95,11 @@ SIGNATURES = {
     'lp_head_bwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     'lp_relu_bwd': (_i, [_vp, _vp, _vp, _ll, _vp]),
     'lp_avgpool2_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    'lp_avgpool2_fwd16': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'lp_avgpool2_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     'lp_l1_partial_blocks': (_i, []),
     'lp_l1_fwd': (_i, [_vp, _vp, _vp, _ll, _i, _f, _vp, _vp, _vp]),
+    'lp_l1_fwd_b16': (_i, [_vp, _vp, _i, _vp, _ll, _i, _f, _vp, _vp, _vp]),
     'lp_l1_bwd': (_i, [_vp, _vp, _vp, _f, _vp, _vp, _ll, _i, _vp, _vp, _vp]),
     'lp_dice_partial_blocks': (_i, []),
     'lp_reduce_dice': (_i, [_vp] * 5 + [_i] * 4 + [_f, _vp]),

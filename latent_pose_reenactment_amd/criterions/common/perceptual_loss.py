@@ -22,6 +22,7 @@ CFG = {
     'vgg19': [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512, 512, 'M', 512, 512, 512, 512, 'M'],
     'vgg16': [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512, 'M'],
 }
+TAPS16 = os.environ.get('LP_VGG_TAPS16', '1') != '0'       # target-image taps as 16-bit planes in the fp16 mode (0: fp32 taps, the round-3 path)
 WEIGHT_FILES = {'caffe': ('vgg19', 'vgg19-d01eb7cb.pth'), 'face': ('vgg16', 'vgg_face_weights.pth')}
 
 
@@ -116,6 +117,32 @@ class PerceptualLoss(nn.Module):
                 pending_relu = False
         return taps
 
+    def _features16(self, x, packs, prec):
+        """The taps of an image that needs NO gradient (the target image), without any fp32 activation: every conv writes only the 16-bit
+        operand planes of relu(y) -- what the next conv consumes anyway -- the pools run plane to plane, and a tap IS those planes
+        (``ops.Tap16``; the L1 kernel of the other image's pass decodes them).  One-plane fp16 mode only: the taps are then rounded to 11
+        significant bits ONCE, on top of features that carry the operand rounding of up to 13 fp16 convs already (measured on the full step:
+        tests/test_metatrain_full_gpu.py loss.VGG / loss.VGGFace).  Per 256 x 256 x 64 layer and image batch this avoids a 134 MB fp32
+        store, 134 MB of L1 reads and 67 MB of pool reads."""
+        cur16, taps = None, []
+        x = to_nhwc(x)
+        for i, layer in enumerate(self.model):
+            if isinstance(layer, nn.Conv2d):
+                bias = None if layer.bias is None else layer.bias.detach().contiguous()
+                if cur16 is None:
+                    n, h, w, cin = x.shape
+                    if ops.thin_conv_supported(cin, layer.weight.shape[0], 3, w):
+                        _, cur16 = ops.thin_conv(x, packs[i][0], ksize=3, bias=bias, prec=prec, out16=1, want_y=False)
+                    else:
+                        _, cur16 = ops.conv16(ops.act_pack(x, pro=0, prec=prec), packs[i][0], ksize=3, bias=bias, prec=prec, out16=1, want_y=False)
+                else:
+                    _, cur16 = ops.conv16(cur16, packs[i][0], ksize=3, bias=bias, prec=prec, out16=1, want_y=False)
+            elif isinstance(layer, nn.ReLU):
+                taps.append(ops.Tap16(cur16, prec))
+            else:
+                cur16 = ops.avgpool2_fwd16(cur16, prec)
+        return taps
+
     def target_features(self, target):
         """the taps of the REAL image: no autograd, no dependence on the generator -- a training step may compute them early, on a
         side stream, beside the encoders and the generator (runners/holycow.py TrainingModule.forward, streams.py)"""
@@ -124,6 +151,8 @@ class PerceptualLoss(nn.Module):
         prec = default_prec()
         with torch.no_grad():
             ft = self.normalize_inputs((target.detach() + 1) / 2)
+            if prec == lpnn.PREC_F16 and TAPS16 and lpnn.RELU_TAPE is None and all(m.weight.shape[0] % 8 == 0 for m in self.model if isinstance(m, nn.Conv2d)):
+                return self._features16(ft, self._packs(prec), prec)
             return self._features(ft, self._packs(prec), prec, [])
 
     def forward(self, input, target, taps_t=None):

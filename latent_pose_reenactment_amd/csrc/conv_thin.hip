@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256) void conv_rgb_mfma_kernel(RgbMfmaParams p) {
                 const float4 v = *(const float4*)(T + pq * 68 + cq + j4 * 4);
                 o[j4 * 4 + 0] = fmaf(v.x, alpha, bias16[j4 * 4 + 0]); o[j4 * 4 + 1] = fmaf(v.y, alpha, bias16[j4 * 4 + 1]);
                 o[j4 * 4 + 2] = fmaf(v.z, alpha, bias16[j4 * 4 + 2]); o[j4 * 4 + 3] = fmaf(v.w, alpha, bias16[j4 * 4 + 3]);
-                *(float4*)(dst + j4 * 4) = make_float4(o[j4 * 4], o[j4 * 4 + 1], o[j4 * 4 + 2], o[j4 * 4 + 3]);
+                if (p.y) *(float4*)(dst + j4 * 4) = make_float4(o[j4 * 4], o[j4 * 4 + 1], o[j4 * 4 + 2], o[j4 * 4 + 3]);
             }
             if (p.o_hi) {
                 s16x8_t h0, h1;
@@ -404,8 +404,10 @@ extern "C" int lp_thin_conv_emits_planes(int Cin, int Cout, int ksize, int W, in
 extern "C" int lp_thin_conv_fwd(const float* x, const uint16_t* w_hi, const uint16_t* w_lo, float* y, const float* bias, const float* alpha,
                                 int N, int H, int W, int Cin, int Cout, int CinP, int CoutP, int ksize, int prec, uint16_t* out_hi,
                                 int out_relu, void* stream) {
-    if (!x || !w_hi || !y) return lp_set_error(LP_ERR_ARG, "lp_thin_conv_fwd: null pointer");
+    if (!x || !w_hi) return lp_set_error(LP_ERR_ARG, "lp_thin_conv_fwd: null pointer");
     if (!lp_conv_thin_fwd_supported(Cin, Cout, ksize, 0, 0, false, W)) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_thin_conv_fwd: unsupported shape");
+    // y == NULL: planes-only output, where the MFMA kernel emits them (lp_thin_conv_emits_planes)
+    if (!y && !(out_hi && rgb_mfma_ok(Cin, Cout, ksize, W, prec))) return lp_set_error(LP_ERR_ARG, "lp_thin_conv_fwd: y may only be NULL where the operand planes are emitted");
     if (rgb_mfma_ok(Cin, Cout, ksize, W, prec)) {
         RgbMfmaParams q;
         q.x = x; q.w_hi = w_hi; q.y = y; q.bias = bias; q.alpha = alpha; q.o_hi = out_hi; q.o_relu = out_relu;

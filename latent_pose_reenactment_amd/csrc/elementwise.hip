@@ -576,6 +576,42 @@ __global__ void avgpool2_fwd_kernel(const float* __restrict__ x, float* __restri
     }
 }
 
+// the same on operand planes (no-grad chains that never need the fp32 tensors: the VGG stacks over the TARGET image): x16 [N][2H][2W][C] ->
+// o16 [N][H][W][C], 8 channels per thread; the sum is taken in fp32 and rounded once
+template <bool F16>
+__global__ void avgpool2_fwd16_kernel(const uint16_t* __restrict__ x16, uint16_t* __restrict__ o16, long long total8, int H, int W, int C) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const int C8 = C >> 3;
+    for (; i < total8; i += stride) {
+        const int c = (int)(i % C8) * 8;
+        long long pix = i / C8;
+        const int xx = (int)(pix % W); long long t = pix / W;
+        const int yy = (int)(t % H); const int n = (int)(t / H);
+        const uint16_t* b = x16 + (((size_t)n * 2 * H + 2 * yy) * 2 * W + 2 * xx) * C + c;
+        const s16x8_t a0 = *(const s16x8_t*)b, a1 = *(const s16x8_t*)(b + C), a2 = *(const s16x8_t*)(b + (size_t)2 * W * C),
+                      a3 = *(const s16x8_t*)(b + (size_t)2 * W * C + C);
+        s16x8_t o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = 0.25f * ((lp_op16_to_f32<F16>((uint16_t)a0[j]) + lp_op16_to_f32<F16>((uint16_t)a1[j])) +
+                                     (lp_op16_to_f32<F16>((uint16_t)a2[j]) + lp_op16_to_f32<F16>((uint16_t)a3[j])));
+            o[j] = (short)lp_f32_to_op16<F16>(v);
+        }
+        *(s16x8_t*)(o16 + (size_t)i * 8) = o;
+    }
+}
+
+extern "C" int lp_avgpool2_fwd16(const uint16_t* x_hi, uint16_t* out_hi, int N, int H, int W, int C, int prec, void* stream) {
+    if (!x_hi || !out_hi) return lp_set_error(LP_ERR_ARG, "lp_avgpool2_fwd16: null pointer");
+    if ((C & 7) || prec == LP_PREC_BF16X3) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_avgpool2_fwd16: C % 8 == 0 and a one-plane precision mode");
+    const long long total8 = (long long)N * H * W * C / 8;
+    int blocks = (int)((total8 + 255) / 256); if (blocks > 8192) blocks = 8192; if (blocks < 1) blocks = 1;
+    if (prec == LP_PREC_F16) hipLaunchKernelGGL(avgpool2_fwd16_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x_hi, out_hi, total8, H, W, C);
+    else hipLaunchKernelGGL(avgpool2_fwd16_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x_hi, out_hi, total8, H, W, C);
+    return lp_check_launch("avgpool2_fwd16");
+}
+
 // dx[n,y,x,c] = 0.25 * dy[n,y>>1,x>>1,c] * (relu_in ? [x>0] : 1).  H, W = INPUT (full-res) dims; one thread per 2x2 block.
 __global__ void avgpool2_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx, long long total4,
                                     int H, int W, int C, int relu_in, float* __restrict__ amax) {
@@ -630,14 +666,21 @@ extern "C" int lp_avgpool2_bwd(const float* dy, const float* x, float* dx, int N
 // partial[b] = sum over this block's elements of |relu?(a) - relu?(b)|   (criterions/common/perceptual_loss.py:104-108 L1 taps)
 // sgn != NULL: also the backward's sign pattern, one int8 per element: sign(relu?(a) - relu?(b)) * (relu_in ? [a > 0] : 1) -- the backward
 // then reads 1 byte per element instead of a and b again (8 bytes).
-__global__ __launch_bounds__(256) void l1_partial_kernel(const float4* __restrict__ a, const float4* __restrict__ b,
+// BMODE 0: b fp32 | 1: b = fp16 operand planes | 2: bf16 operand planes (the taps of the target image kept 16-bit, round 4)
+template <int BMODE>
+__global__ __launch_bounds__(256) void l1_partial_kernel(const float4* __restrict__ a, const void* __restrict__ bv,
                                                          float* __restrict__ part, long long total4, int relu_in, char4* __restrict__ sgn) {
     __shared__ float sh[4];
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long stride = (long long)gridDim.x * blockDim.x;
     float s = 0.f;
     for (; i < total4; i += stride) {
-        float4 u = a[i], v = b[i];
+        float4 u = a[i], v;
+        if (BMODE == 0) v = ((const float4*)bv)[i];
+        else {
+            const ushort4 q = ((const ushort4*)bv)[i];
+            v = make_float4(lp_op16_to_f32<BMODE == 1>(q.x), lp_op16_to_f32<BMODE == 1>(q.y), lp_op16_to_f32<BMODE == 1>(q.z), lp_op16_to_f32<BMODE == 1>(q.w));
+        }
         if (relu_in) {
             u.x = fmaxf(u.x, 0.f); u.y = fmaxf(u.y, 0.f); u.z = fmaxf(u.z, 0.f); u.w = fmaxf(u.w, 0.f);
             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
@@ -718,10 +761,26 @@ extern "C" int lp_l1_fwd(const float* a, const float* b, float* partial, long lo
                          int8_t* sign_out, void* stream) {
     if (!a || !b || !partial) return lp_set_error(LP_ERR_ARG, "lp_l1_fwd: null pointer");
     if (numel & 3) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_l1_fwd: numel must be a multiple of 4");
-    hipLaunchKernelGGL(l1_partial_kernel, dim3(L1_BLOCKS), dim3(256), 0, (hipStream_t)stream, (const float4*)a, (const float4*)b, partial,
+    hipLaunchKernelGGL(l1_partial_kernel<0>, dim3(L1_BLOCKS), dim3(256), 0, (hipStream_t)stream, (const float4*)a, (const void*)b, partial,
                        numel / 4, relu_in, (char4*)sign_out);
     if (out) hipLaunchKernelGGL(l1_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, L1_BLOCKS, coef, out);
     return lp_check_launch("l1_fwd");
+}
+
+// the same with b given as 16-bit operand planes (same element order as a: channel counts that are multiples of 8)
+extern "C" int lp_l1_fwd_b16(const float* a, const uint16_t* b_hi, int prec, float* partial, long long numel, int relu_in, float coef, float* out,
+                             int8_t* sign_out, void* stream) {
+    if (!a || !b_hi || !partial) return lp_set_error(LP_ERR_ARG, "lp_l1_fwd_b16: null pointer");
+    if (numel & 3) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_l1_fwd_b16: numel must be a multiple of 4");
+    if (prec == LP_PREC_BF16X3) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_l1_fwd_b16: one-plane precision modes only");
+    if (prec == LP_PREC_F16)
+        hipLaunchKernelGGL(l1_partial_kernel<1>, dim3(L1_BLOCKS), dim3(256), 0, (hipStream_t)stream, (const float4*)a, (const void*)b_hi, partial,
+                           numel / 4, relu_in, (char4*)sign_out);
+    else
+        hipLaunchKernelGGL(l1_partial_kernel<2>, dim3(L1_BLOCKS), dim3(256), 0, (hipStream_t)stream, (const float4*)a, (const void*)b_hi, partial,
+                           numel / 4, relu_in, (char4*)sign_out);
+    if (out) hipLaunchKernelGGL(l1_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, L1_BLOCKS, coef, out);
+    return lp_check_launch("l1_fwd_b16");
 }
 
 extern "C" int lp_l1_bwd(const float* a, const float* b, const float* grad_out, float coef, const float* add, float* da, long long numel,

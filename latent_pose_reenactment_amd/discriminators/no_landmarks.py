@@ -216,6 +216,26 @@ class Discriminator(nn.Module):
                 self.embed = fresh
                 self.finetuning = True
 
+    def start_real_pass(self, data_dict):
+        """streams 'real' (LP_OVERLAP_REAL, on in meta-training; runners/holycow.py calls this between the encoders and the generator): the pass over the REAL image depends on
+        neither encoder nor generator -- with the weights prepared ahead (``prepare_step``) it can be issued on its side stream beside the
+        generator's forward instead of beside the other two passes.  Same arithmetic: it still uses the third power iteration of the step."""
+        from latent_pose_reenactment_amd import streams
+        real, label = data_dict.get('target_rgbs'), data_dict.get('label')
+        prepared, ahead = self.__dict__.get('_prepared'), self.__dict__.get('_prepared_passes')
+        if (real is None or label is None or prepared is None or not ahead or len(ahead) != 3 or lpnn.RELU_TAPE is not None
+                or not (self.training and torch.is_grad_enabled()) or not streams.enabled(real, 'dpasses', finetuning=self.finetuning)):
+            return
+        if real.dim() > 4:
+            real = real[:, 0]
+        self._conv_sn_layers()
+        self.__dict__['_step_packs'] = prepared[0]
+        eu, ev, esig = prepared[1]
+        embed = SNEmbeddingFn.apply(label, self.embed.weight_orig, eu, ev, esig, self.__dict__.setdefault('_embed_parts', {}))
+        with streams.branch(real.device, 7) as b3:
+            real_score, real_features = self.pass_inputs(real, embed, sn_states=ahead[2])
+        self.__dict__['_early_real'] = (embed, b3, real_score, real_features)
+
     def forward(self, data_dict):
         fake, real, label = data_dict['fake_rgbs'], data_dict['target_rgbs'], data_dict['label']
         if fake.dim() > 4:
@@ -231,8 +251,12 @@ class Discriminator(nn.Module):
         # by 1/sigma -- W/sigma is never materialised and the backward is row-sparse + rank-1 (SNEmbeddingFn)
         if not label.is_cuda:
             raise RuntimeError('the discriminator runs on the MI355X HIP path only (no CPU fallback)')
-        eu, ev, esig = prepared[1] if prepared is not None else self._embed_batch().update(self.training)[0]
-        embed = SNEmbeddingFn.apply(label, self.embed.weight_orig, eu, ev, esig, self.__dict__.setdefault('_embed_parts', {}))
+        early_real = self.__dict__.pop('_early_real', None)
+        if early_real is not None:
+            embed = early_real[0]
+        else:
+            eu, ev, esig = prepared[1] if prepared is not None else self._embed_batch().update(self.training)[0]
+            embed = SNEmbeddingFn.apply(label, self.embed.weight_orig, eu, ev, esig, self.__dict__.setdefault('_embed_parts', {}))
         # Pass 1 feeds only generator-side losses; the gradients it would deposit on the discriminator's parameters are erased
         # by optimizer_D.zero_grad() before loss_D.backward (runners/holycow.py:246-248) and no optimizer reads them, so they
         # are not computed unless ``keep_reference_waste`` asks for the reference's exact .grad side effects (parity tests).
@@ -250,8 +274,11 @@ class Discriminator(nn.Module):
             fake_score_G, fake_features = self.pass_inputs(fake, embed if track1 else embed.detach(), track_weights=track1, sn_states=sts[0])
             with streams.branch(fake.device, 6, after=here) as b2:
                 fake_score_D, _ = self.pass_inputs(fake.detach(), embed.detach(), sn_states=sts[1])
-            with streams.branch(fake.device, 7, after=here) as b3:
-                real_score, real_features = self.pass_inputs(real, embed, sn_states=sts[2])
+            if early_real is not None:
+                _, b3, real_score, real_features = early_real
+            else:
+                with streams.branch(fake.device, 7, after=here) as b3:
+                    real_score, real_features = self.pass_inputs(real, embed, sn_states=sts[2])
             b2.join(fake_score_D)
             b3.join((real_score, real_features))
         else:

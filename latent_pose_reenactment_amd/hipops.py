@@ -302,20 +302,21 @@ def thin_conv_supported(cin: int, cout: int, ksize: int, w: int) -> bool:
 
 
 def thin_conv(x: Tensor, pack: WeightPack, *, ksize: int, bias: Optional[Tensor] = None, alpha: Optional[Tensor] = None,
-              prec: int = PREC_BF16, out16: Optional[int] = None, out16_prec: Optional[int] = None):
+              prec: int = PREC_BF16, out16: Optional[int] = None, out16_prec: Optional[int] = None, want_y: bool = True):
     """conv with <= 4 input channels (RGB -> 64, dz -> 64) on the plain NHWC tensor (no input operand planes): fp32 VALU kernel, or --
     RGB 3x3 in the fp16 / bf16 modes -- one MFMA k-step per output block.  ``out16`` = 0 | 1: also return the operand planes of y
     (1: of relu(y)) -> (y, Act16); written by the same launch where the MFMA kernel runs, by a pack pass otherwise."""
     _chk(x, 'x')
     n, h, w, cin = x.shape
     cout = pack.rows
-    y = torch.empty((n, h, w, cout), dtype=torch.float32, device=x.device)
     # ``out16_prec``: operand mode of the emitted planes when it differs from this conv's own (a strict first layer feeding fp16 layers)
     oprec = prec if out16_prec is None else out16_prec
     fused = out16 is not None and oprec == prec and bool(_lib.lib().lp_thin_conv_emits_planes(cin, cout, ksize, w, prec)) and _THIN_MFMA
+    # ``want_y=False``: planes-only output where the MFMA kernel emits them (else y is produced and dropped by the caller)
+    y = torch.empty((n, h, w, cout), dtype=torch.float32, device=x.device) if (want_y or not fused) else None
     o_hi = torch.empty((n, h, w, cout), dtype=torch.int16, device=x.device) if fused else None
     with _Timed('conv_thin', 2.0 * n * h * w * cout * cin * ksize * ksize, (n, h, w, cin, cout, ksize, 0, 0)):
-        check(_lib.lib().lp_thin_conv_fwd(x.data_ptr(), pack.hi.data_ptr(), _p(pack.lo), y.data_ptr(), _p(bias), _p(alpha), n, h, w, cin,
+        check(_lib.lib().lp_thin_conv_fwd(x.data_ptr(), pack.hi.data_ptr(), _p(pack.lo), _p(y), _p(bias), _p(alpha), n, h, w, cin,
                                           cout, pack.cols_p, pack.rows_p, ksize, prec, _p(o_hi), int(bool(out16)), _stream()),
               'lp_thin_conv_fwd')
     if out16 is None:
@@ -702,6 +703,16 @@ def avgpool2_fwd(x: Tensor, relu_in: bool, out16_prec: Optional[int] = None):
     return y, (Act16(o_hi, None, c, None) if fused else act_pack(y, pro=0, prec=out16_prec))
 
 
+def avgpool2_fwd16(x: Act16, prec: int) -> Act16:
+    """AvgPool2d(2) on operand planes (one-plane modes): planes in, planes out -- for no-grad chains that keep no fp32 activations"""
+    n, h2, w2 = x.nhw
+    c = x.c
+    assert x.lo is None and c % 8 == 0 and x.hi.shape[3] == c and prec != PREC_BF16X3
+    o_hi = torch.empty((n, h2 // 2, w2 // 2, c), dtype=torch.int16, device=x.hi.device)
+    check(_lib.lib().lp_avgpool2_fwd16(x.hi.data_ptr(), o_hi.data_ptr(), n, h2 // 2, w2 // 2, c, prec, _stream()), 'lp_avgpool2_fwd16')
+    return Act16(o_hi, None, c, None)
+
+
 def avgpool2_bwd(dy: Tensor, x: Tensor, relu_in: bool, amax: bool = False) -> Tensor:
     _chk(dy, 'dy'); _chk(x, 'x')
     n, h, w, c = x.shape
@@ -711,14 +722,33 @@ def avgpool2_bwd(dy: Tensor, x: Tensor, relu_in: bool, amax: bool = False) -> Te
     return dx
 
 
-def l1_sum(a: Tensor, b: Tensor, relu_in: bool, coef: float = 1.0, want_sign: bool = False):
+class Tap16(NamedTuple):
+    """a feature tap kept as 16-bit operand planes (of relu(y): what the next conv consumes anyway) instead of an fp32 tensor"""
+    act: Act16
+    prec: int
+
+    def float(self):
+        """decoded fp32 NHWC tensor (debug tapes / tests)"""
+        return self.act.hi.view(torch.float16 if self.prec == PREC_F16 else torch.bfloat16).float()
+
+    def detach(self):
+        return self
+
+
+def l1_sum(a: Tensor, b, relu_in: bool, coef: float = 1.0, want_sign: bool = False):
     """coef * sum |relu?(a) - relu?(b)| as a 0-d tensor (block partials + a one-block finalize launch).  ``want_sign``: -> (term, sgn)
     with sgn int8 [numel] = the sign pattern the backward needs (``l1_bwd(sign=...)`` then does not read a and b again)"""
-    _chk(a, 'a'); _chk(b, 'b')
-    assert a.shape == b.shape
+    _chk(a, 'a')
     buf = torch.empty(_lib.lib().lp_l1_partial_blocks() + 1, dtype=torch.float32, device=a.device)
     out = buf[-1:]
     sgn = torch.empty(a.numel(), dtype=torch.int8, device=a.device) if want_sign else None
+    if isinstance(b, Tap16):           # b = 16-bit operand planes of the other image's tap (same NHWC element order, no channel padding)
+        assert tuple(b.act.hi.shape) == tuple(a.shape) and b.act.lo is None, (b.act.hi.shape, a.shape)
+        check(_lib.lib().lp_l1_fwd_b16(a.data_ptr(), b.act.hi.data_ptr(), b.prec, buf.data_ptr(), a.numel(), int(relu_in), float(coef),
+                                       out.data_ptr(), _p(sgn), _stream()), 'lp_l1_fwd_b16')
+        return (out.reshape(()), sgn) if want_sign else out.reshape(())
+    _chk(b, 'b')
+    assert a.shape == b.shape
     check(_lib.lib().lp_l1_fwd(a.data_ptr(), b.data_ptr(), buf.data_ptr(), a.numel(), int(relu_in), float(coef), out.data_ptr(), _p(sgn),
                                _stream()), 'lp_l1_fwd')
     return (out.reshape(()), sgn) if want_sign else out.reshape(())

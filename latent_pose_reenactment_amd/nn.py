@@ -928,7 +928,9 @@ class L1TapFn(torch.autograd.Function):
 
 
 def hip_l1_tap(a, b, relu_in=False):
-    """-> (a passed through, l1 term); use the returned tensor as the input of the following layer"""
+    """-> (a passed through, l1 term); use the returned tensor as the input of the following layer.  ``b``: fp32 tensor, or ``ops.Tap16``
+    (the other image's tap kept as the 16-bit operand planes of relu(y))"""
     if RELU_TAPE is not None:       # sign pattern of this L1 site (tie-masked parity tests)
-        tape_relu(lambda: torch.sign((torch.relu(a) if relu_in else a) - (torch.relu(b) if relu_in else b)).to(torch.int8))
+        bb = b.float() if isinstance(b, ops.Tap16) else b
+        tape_relu(lambda: torch.sign((torch.relu(a) if relu_in else a) - (torch.relu(bb) if relu_in else bb)).to(torch.int8))
     return L1TapFn.apply(a, b.detach(), relu_in)

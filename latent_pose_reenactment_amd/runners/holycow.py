@@ -6,6 +6,7 @@ The reference's apex ``Reducer`` is replaced by ``parallel.GradReducer`` (RCCL a
 gradients each optimizer is about to consume).  TensorBoard / image-grid logging branches (holycow.py:266-400) are
 observability and out of scope; scalar losses go to ``Meter`` as in the reference."""
 import copy
+import os
 import itertools
 import logging
 import time
@@ -133,14 +134,22 @@ class TrainingModule(nn.Module):
         crit_stream = {}
         crit_side = self.compute_losses and streams.enabled(tgt, 'criterions', finetuning=ft)
         ahead = self.compute_losses and streams.enabled(tgt, 'targets', finetuning=ft)
-        if crit_side or ahead:
+        # LP_OVERLAP_TARGETS=2: start them only when the encoders are done, i.e. beside the GENERATOR's forward alone (its 4x4 .. 32x32 layers
+        # are short launches that leave most of the chip idle)
+        ahead_late = ahead and os.environ.get('LP_OVERLAP_TARGETS') == '2'
+
+        def start_targets():
             both = {**data_dict, **target_dict}
+            for i, criterion in enumerate(self.criterion_list):
+                if i in crit_stream and hasattr(criterion, 'precompute_targets'):
+                    with streams.branch(tgt.device, crit_stream[i]):
+                        criterion.precompute_targets(both)
+        if crit_side or ahead:
             for i, criterion in enumerate(self.criterion_list):
                 if getattr(criterion, 'independent_branch', False):
                     crit_stream[i] = 1 + len(crit_stream)
-                    if ahead and hasattr(criterion, 'precompute_targets'):
-                        with streams.branch(tgt.device, crit_stream[i]):
-                            criterion.precompute_targets(both)
+            if ahead and not ahead_late:
+                start_targets()
         # meta-training: what a training forward of G and D derives from the weights alone (spectral-norm power iterations, 16-bit weight
         # packs: ~40 short launches) is issued on a side stream beside the encoders' large kernels and joined before the generator runs
         prep = None
@@ -169,6 +178,10 @@ class TrainingModule(nn.Module):
         self.__dict__['_ebwd_pending'] = cut
         if prep is not None:
             prep.join()
+        if ahead_late:
+            start_targets()
+        if prep is not None and streams.enabled(tgt, 'real', finetuning=ft) and hasattr(self.discriminator, 'start_real_pass'):
+            self.discriminator.start_real_pass({**data_dict, **target_dict})
         generator(data_dict)
         data_dict.update(target_dict)
         # criterions that touch neither the discriminator nor each other (the two VGG stacks: ``independent_branch``) are issued on side

@@ -23,20 +23,23 @@ _STREAMS = {}
 # 22.4 -> 24.1 ms (fine-tuning) -- large kernels beside large kernels again: off.  What pays is a branch of SMALL kernels beside a
 # branch of large ones -- e.g. the spectral-norm power iterations + weight packs of G and D (~40 short launches) beside the encoders:
 # 38.95 -> 38.62 ms, on (meta-training); the discriminator's three passes beside each other (forward and, through autograd, the whole of
-# loss_D.backward): 38.9 -> 37.4 ms, on (meta-training; fine-tuning 22.34 -> 22.09 ms, left off: that step stays a single-stream graph).  LP_OVERLAP_{ENCODERS,CRITERIONS,PREPARE,DPASSES,OPTIMIZER,WGRAD,TARGETS} = 0 | 1 force; LP_OVERLAP=0 turns
+# loss_D.backward): 38.9 -> 37.4 ms, on (meta-training; fine-tuning 22.34 -> 22.09 ms, left off: that step stays a single-stream graph).  LP_OVERLAP_{ENCODERS,CRITERIONS,PREPARE,DPASSES,REAL,OPTIMIZER,WGRAD,TARGETS,EBWD} = 0 | 1 force; LP_OVERLAP=0 turns
 # everything off.
 def enabled(t, what: str, finetuning: bool = False) -> bool:
     """``what``: 'encoders' (pose encoder beside the identity encoder) | 'criterions' (VGG stacks beside the discriminator pass, their
     target-image halves beside encoders + generator) | 'optimizer' (optimizer_G.step + EMA beside the discriminator backward) |
     'wgrad' (the identity encoder's weight gradients beside its data-gradient chain) | 'targets' (only the target-image halves of the
     VGG criterions ahead of encoders + generator) | 'prepare' (spectral-norm power iterations + weight packs of G and D beside the encoders) | 'dpasses' (the discriminator's three
-    passes beside each other) | 'ebwd' (one GPU, meta-training: the encoders' backward beside loss_D.backward -- runners/holycow.py cuts the
+    passes beside each other) | 'real' (with 'dpasses' + 'prepare': its real-image pass already beside the generator's forward) | 'ebwd' (one GPU, meta-training: the encoders' backward beside loss_D.backward -- runners/holycow.py cuts the
     autograd graph behind the embedder)"""
     if not (torch.is_tensor(t) and t.is_cuda) or os.environ.get('LP_OVERLAP', '1') == '0':
         return False
     # 'ebwd': measured null on the captured full-size step (42.9 / 43.5 ms on vs 43.4 / 43.5 ms off, profiles/r04_stream_overlap.txt): the
     # encoders' backward and the discriminator's backward are both bound by HBM traffic -- off
-    default = '0' if (what in ('optimizer', 'wgrad', 'targets', 'ebwd') or (what in ('criterions', 'prepare', 'dpasses') and finetuning)) else '1'
+    # 'real' (round 4): the critic's pass over the REAL image issued beside the generator's forward (whose 4x4 .. 32x32 layers leave most of the
+    # chip idle) instead of beside the other two passes: 42.2 -> 41.75 ms; the VGG target halves at the same place ('targets' = 2): 42.2 -> 42.0,
+    # not additive (profiles/r04_stream_overlap.txt)
+    default = '0' if (what in ('optimizer', 'wgrad', 'targets', 'ebwd') or (what in ('criterions', 'prepare', 'dpasses', 'real') and finetuning)) else '1'
     return os.environ.get('LP_OVERLAP_' + what.upper(), default) != '0'
 
 

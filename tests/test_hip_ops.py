@@ -401,3 +401,29 @@ def test_label_embedding_gradient_kernel(n, e, labels):
     report(f'sn_embed_grad {n}x{e}', rel(got, want), 1e-6)
     for r in set(labels):
         assert rel(got[r], want[r]) < 1e-6, r
+
+
+@pytest.mark.parametrize('prec', [2, 0])
+@pytest.mark.parametrize('shape', [(2, 16, 16, 64), (1, 12, 20, 128), (3, 4, 4, 512)])
+def test_plane_to_plane_pool_and_l1_against_planes(shape, prec):
+    """lp_avgpool2_fwd16 (planes in, planes out) and lp_l1_fwd_b16 (second operand = 16-bit planes) -- the target-image half of the VGG
+    criterions keeps no fp32 activation (criterions/common/perceptual_loss.py::_features16)"""
+    ops = _ops()
+    n, h, w, c = shape
+    g = torch.Generator().manual_seed(5)
+    dt = torch.float16 if prec == 2 else torch.bfloat16
+    x = torch.randn(n, h, w, c, generator=g).cuda()
+    a16 = ops.act_pack(x, pro=2, prec=prec)                       # planes of relu(x)
+    dec = lambda t: t.view(dt).double()
+    p16 = ops.avgpool2_fwd16(a16, prec)
+    torch.cuda.synchronize()
+    want = F.avg_pool2d(dec(a16.hi).permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+    report(f'avgpool2_fwd16{shape} prec={prec}', rel(dec(p16.hi), want), 2e-3 if prec == 2 else 1.6e-2)      # one rounding of the fp32 mean
+    assert torch.equal(p16.hi.view(dt), want.to(dt)) or rel(dec(p16.hi), want.to(dt).double()) < 1e-3         # (RNE of the exact mean up to fp32 summation)
+    other = torch.randn(n, h, w, c, generator=g).cuda()
+    term, sgn = ops.l1_sum(other, ops.Tap16(a16, prec), True, 1.0 / other.numel(), want_sign=True)
+    torch.cuda.synchronize()
+    u, v = torch.relu(other.double()), dec(a16.hi)
+    report(f'l1_fwd_b16{shape} prec={prec}', rel(term, (u - v).abs().mean()), 1e-5)
+    ref_sgn = (torch.sign(u - v) * ((other > 0) | (u > v))).to(torch.int8).flatten()
+    assert torch.equal(sgn, ref_sgn)

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'latent_pose_reenactment_amd'))
 pytestmark = pytest.mark.gpu
-KNOBS = ('LP_OVERLAP', 'LP_OVERLAP_ENCODERS', 'LP_OVERLAP_CRITERIONS', 'LP_OVERLAP_OPTIMIZER', 'LP_OVERLAP_WGRAD', 'LP_OVERLAP_TARGETS', 'LP_OVERLAP_PREPARE', 'LP_OVERLAP_DPASSES')
+KNOBS = ('LP_OVERLAP', 'LP_OVERLAP_ENCODERS', 'LP_OVERLAP_CRITERIONS', 'LP_OVERLAP_OPTIMIZER', 'LP_OVERLAP_WGRAD', 'LP_OVERLAP_TARGETS', 'LP_OVERLAP_PREPARE', 'LP_OVERLAP_DPASSES', 'LP_OVERLAP_REAL', 'LP_OVERLAP_EBWD')
 
 
 def _iteration(monkeypatch, env):
@@ -65,12 +65,44 @@ def test_concurrent_branches_reproduce_the_one_stream_iteration(monkeypatch):
     floor = _spread(again, one)
     default = _iteration(monkeypatch, {})
     everything = _iteration(monkeypatch, {'LP_OVERLAP_WGRAD': '1', 'LP_OVERLAP_TARGETS': '1'})
-    assert one.keys() == default.keys() == everything.keys()
+    late = _iteration(monkeypatch, {'LP_OVERLAP_TARGETS': '2', 'LP_OVERLAP_REAL': '0'})      # target halves beside the generator; real pass beside the other two
+    assert one.keys() == default.keys() == everything.keys() == late.keys()
     fmt = lambda sp: ', '.join(f'{g} {v:.1e}' for g, v in sorted(sp.items()))
     print(f'[streams] one stream, run to run: {fmt(floor)}')
-    for name, run in (('default branches', default), ('all branches', everything)):
+    for name, run in (('default branches', default), ('all branches', everything), ('late targets, real pass with the others', late)):
         sp = _spread(run, one)
         print(f'[streams] {name} vs one stream: {fmt(sp)}')
         for g, d in sp.items():
             # (E, G: the run-to-run spread is itself random -- 1.7e-3 / 2.6e-4 typically; a missing dependency shows up as 0.1 .. 1)
             assert d <= max(20 * floor[g], 1e-2 if g in ('E', 'G') else 1e-5), (name, g, d, floor[g])
+
+
+def _train_step_grads(monkeypatch, env):
+    import bench
+    for k in KNOBS:
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    args = bench.make_args(128, 8, 'cuda:0', 1, 0, 'f16', finetune=False)
+    args.num_labels = 100
+    tm, opt_G, opt_D, holycow = bench.build(args)
+    data, target = bench.synthetic_batch(args, 8, seed=500)
+    _, losses_G, losses_D = holycow.train_step(tm, data, target, opt_G, opt_D, args)
+    torch.cuda.synchronize()
+    out = {'loss.' + k: v.detach().clone() for k, v in {**losses_G, **losses_D}.items() if torch.is_tensor(v)}
+    for name, mod in (('E', tm.embedder), ('G', tm.generator), ('D', tm.discriminator)):
+        out.update({f'{name}.{k}': p.grad.detach().clone() for k, p in mod.named_parameters() if p.grad is not None})
+    return out
+
+
+def test_embedder_backward_beside_the_discriminator_backward_reproduces_the_step(monkeypatch):
+    """LP_OVERLAP_EBWD=1 (off by default: measured null): train_step cuts the autograd graph behind the embedder and runs the encoders' backward
+    on a side stream beside loss_D.backward -- same gradients as the uncut step"""
+    plain = _train_step_grads(monkeypatch, {'LP_OVERLAP_EBWD': '0'})
+    again = _train_step_grads(monkeypatch, {'LP_OVERLAP_EBWD': '0'})
+    cut = _train_step_grads(monkeypatch, {'LP_OVERLAP_EBWD': '1'})
+    assert plain.keys() == cut.keys()
+    floor, sp = _spread(again, plain), _spread(cut, plain)
+    print('[streams] EBWD: run to run', {g: f'{v:.1e}' for g, v in floor.items()}, '| cut vs plain', {g: f'{v:.1e}' for g, v in sp.items()})
+    for g, d in sp.items():
+        assert d <= max(20 * floor[g], 1e-2 if g in ('E', 'G') else 1e-5), (g, d, floor[g])
