@@ -17,6 +17,7 @@ import torch.nn.functional as F
 from torch import nn
 
 _PENDING_COUNTERS = []
+E_HEAD_F16_DEFAULT = ''     # layer kinds of the bf16x3 head that run with fp16 operands (ResNeXt.layer_precs)
 E_F16_TAIL_DEFAULT = 6      # trailing ResNeXt bottlenecks that run with fp16 operands under the default modes (ResNeXt.block_precs)
 _HIP_FORWARD = [os.environ.get('LP_EMBEDDER_HIP', '1') != '0']       # set_hip_forward() / LP_EMBEDDER_HIP=0
 
@@ -146,6 +147,21 @@ class ResNeXt(nn.Module):
             tail = max(0, min(nb, int(os.environ.get('LP_E_F16_TAIL', str(E_F16_TAIL_DEFAULT)))))
         return [base] * (nb - tail) + [PREC_NAMES['f16']] * tail
 
+    def layer_precs(self):
+        """operand mode per contraction: {(block name, 'conv1' | 'conv2' | 'conv3'): mode}; the downsample conv shares conv1's input planes
+        and mode.  ``LP_E_HEAD_F16`` = comma list of layer kinds that run with fp16 operands ALSO in the bf16x3 blocks of the default
+        assignment (an experiment knob, empty by default: profiles/r04_e1_parity.txt has the sweep)."""
+        from latent_pose_reenactment_amd.nn import PREC_NAMES, default_prec
+        self._hip_structure()
+        kinds = set(k for k in os.environ.get('LP_E_HEAD_F16', E_HEAD_F16_DEFAULT).split(',') if k)
+        assert kinds <= {'conv1', 'conv2', 'conv3'}, kinds
+        mixed = bool(kinds) and default_prec() == PREC_NAMES['f16'] and not os.environ.get('LP_PREC_E')
+        out = {}
+        for (bname, *_), p in zip(self._hip_blocks, self.block_precs()):
+            for kind in ('conv1', 'conv2', 'conv3'):
+                out[(bname, kind)] = PREC_NAMES['f16'] if (mixed and p == PREC_NAMES['bf16x3'] and kind in kinds) else p
+        return out
+
     def _hip_structure(self):
         if self.__dict__.get('_hip_param_names') is None:
             self.__dict__['_hip_param_names'] = [k for k, _ in self.named_parameters()]
@@ -164,10 +180,11 @@ class ResNeXt(nn.Module):
         from latent_pose_reenactment_amd import hipops as ops
         from latent_pose_reenactment_amd.optim import WEIGHTS_GENERATION
         base = self.prec
-        bprec = dict(zip((b[0] for b in self._hip_blocks), self.block_precs()))
+        bprec = self.layer_precs()
 
-        def prec_of(k):          # 'layer3.4.conv1.weight' -> the mode of block 'layer3.4'; stem and classifier: the base mode
-            return bprec.get('.'.join(k.split('.')[:2]), base)
+        def prec_of(k):          # 'layer3.4.conv1.weight' -> the mode of that contraction ('...downsample.0.weight': conv1's); stem and classifier: the base mode
+            part = k.split('.')
+            return bprec.get(('.'.join(part[:2]), 'conv1' if part[2] == 'downsample' else part[2]), base) if len(part) > 3 else base
         dense = [k for k in self._hip_param_names
                  if k == 'conv1.weight' or k == 'fc.weight' or (par[k].dim() == 4 and par[k].shape[2] == 1)]      # stem, classifier, 1x1 convs
         grouped = [k for k in self._hip_param_names if par[k].dim() == 4 and par[k].shape[2] == 3]                 # the 16 grouped 3x3 convs

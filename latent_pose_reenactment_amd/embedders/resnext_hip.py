@@ -125,40 +125,42 @@ class ResNeXtFunction(torch.autograd.Function):
         y0 = y0.view(n, h0, w0, 64)
         st0 = bn(y0, 'bn1', cs)
         bprecs = net.block_precs()          # operand mode per bottleneck (a bf16x3 head of the network, an fp16 tail: backbones.ResNeXt.block_precs)
-        out, out16, idx = ops.bn_relu_maxpool(y0, st0.scale, st0.shift, bprecs[0], want_idx=need_grad)
+        lprecs = net.layer_precs()          # mode per contraction (the block's mode unless LP_E_HEAD_F16 moves a layer kind of the head to fp16)
+        out, out16, idx = ops.bn_relu_maxpool(y0, st0.scale, st0.shift, lprecs[(net._hip_blocks[0][0], 'conv1')], want_idx=need_grad)
         saved_blocks = []
         # ---- bottleneck blocks.  Inside the loop ``prec`` is the block's own mode; the block output's operand planes are written in the
         # mode of the block that consumes them.
         base_prec = prec
         for bi, (bname, cin, width, cout, stride, down) in enumerate(net._hip_blocks):
             prec = bprecs[bi]
-            nprec = bprecs[bi + 1] if bi + 1 < len(bprecs) else prec
-            y16 = Y16 and prec == PREC_F16
+            p1, p2, p3 = lprecs[(bname, 'conv1')], lprecs[(bname, 'conv2')], lprecs[(bname, 'conv3')]
+            nprec = lprecs[(net._hip_blocks[bi + 1][0], 'conv1')] if bi + 1 < len(bprecs) else prec
+            y16 = Y16 and p1 == p2 == p3 == PREC_F16
             assert not (y16 and nprec != PREC_F16), 'an fp16 block must be followed by fp16 blocks (lp_bn_add_act16 writes fp16 planes)'
             xin, xin16 = out, out16
             _, h, w, _ = xin.shape
-            y1, cs = _conv1x1(xin16, packs[bname + '.conv1.weight'][0], prec, stats=True, y16=y16)
+            y1, cs = _conv1x1(xin16, packs[bname + '.conv1.weight'][0], p1, stats=True, y16=y16)
             y1 = _yview(y1, (n, h, w, width))
             st1 = bn(y1, bname + '.bn1', cs)
-            a1 = _bn_relu_planes(y1, st1, prec)
+            a1 = _bn_relu_planes(y1, st1, p2)
             if stride == 1:
                 if y16:
-                    _, y2, cs = ops.gconv16(a1, packs[bname + '.conv2.weight'][0], prec=prec, stats=True, want_y=False, out16=True)
+                    _, y2, cs = ops.gconv16(a1, packs[bname + '.conv2.weight'][0], prec=p2, stats=True, want_y=False, out16=True)
                 else:
-                    y2, cs = ops.gconv16(a1, packs[bname + '.conv2.weight'][0], prec=prec, stats=True)
+                    y2, cs = ops.gconv16(a1, packs[bname + '.conv2.weight'][0], prec=p2, stats=True)
                 ho, wo = h, w
             else:       # (the statistics of the strided output: one pass over the quarter-size tensor)
-                y2, cs = ops.subsample2(ops.gconv16(a1, packs[bname + '.conv2.weight'][0], prec=prec)), None
+                y2, cs = ops.subsample2(ops.gconv16(a1, packs[bname + '.conv2.weight'][0], prec=p2)), None
                 ho, wo = y2.shape[1], y2.shape[2]
             st2 = bn(y2, bname + '.bn2', cs)
-            a2 = _bn_relu_planes(y2, st2, prec)
-            y3, cs = _conv1x1(a2, packs[bname + '.conv3.weight'][0], prec, stats=True, y16=y16)
+            a2 = _bn_relu_planes(y2, st2, p3)
+            y3, cs = _conv1x1(a2, packs[bname + '.conv3.weight'][0], p3, stats=True, y16=y16)
             y3 = _yview(y3, (n, ho, wo, cout))
             st3 = bn(y3, bname + '.bn3', cs)
             xd16 = yd = std = None
             if down:
                 xd16 = ops.subsample2_16(xin16) if stride == 2 else xin16
-                yd, cs = _conv1x1(xd16, packs[bname + '.downsample.0.weight'][0], prec, stats=True)
+                yd, cs = _conv1x1(xd16, packs[bname + '.downsample.0.weight'][0], p1, stats=True)
                 yd = yd.view(n, ho, wo, cout)
                 std = bn(yd, bname + '.downsample.1', cs)
                 out, out16 = ops.bn_add_act(y3, st3.scale, st3.shift, yd, std.scale, std.shift, relu=True, prec=nprec)
@@ -166,7 +168,7 @@ class ResNeXtFunction(torch.autograd.Function):
                 out, out16 = ops.bn_add_act(y3, st3.scale, st3.shift, xin, relu=True, prec=nprec)
             if need_grad:
                 # (the ReLU pattern of the block output: its operand planes in the 16-bit-resident mode, its fp32 copy otherwise)
-                saved_blocks.append((xin16, y1, st1, a1, y2, st2, a2, y3, st3, xd16, yd, std, out16 if y16 else out, (h, w, ho, wo), prec))
+                saved_blocks.append((xin16, y1, st1, a1, y2, st2, a2, y3, st3, xd16, yd, std, out16 if y16 else out, (h, w, ho, wo), (p1, p2, p3)))
         # ---- head
         prec = base_prec
         _, hl, wl, cl = out.shape
@@ -224,30 +226,30 @@ class ResNeXtFunction(torch.autograd.Function):
         d_out = ops.spatial_mean_bwd(d_pooled, hl, wl)                            # [N, hl, wl, 2048]
         # ---- blocks, last to first
         for (bname, cin, width, cout, stride, down), sv in zip(reversed(net._hip_blocks), reversed(ctx.blocks)):
-            xin16, y1, st1, a1, y2, st2, a2, y3, st3, xd16, yd, std, out, (h, w, ho, wo), prec = sv       # prec: the block's own operand mode
+            xin16, y1, st1, a1, y2, st2, a2, y3, st3, xd16, yd, std, out, (h, w, ho, wo), (p1, p2, p3) = sv       # operand modes of conv1 (+ downsample), conv2, conv3
             # out = relu(bn3(y3) + skip): g = d_out * [out > 0] reaches bn3 and the skip branch alike
-            d16, g = bn_bwd(d_out, y3, st3, bname + '.bn3', prec, mask_mode=2, mask_src=out, want_g=not down)
-            wgrad(bname + '.conv3.weight', lambda a, d, k=bname + '.conv3.weight': _wgrad1x1(a, d, prec).view(par[k].shape), a2, d16)
-            dA2 = _conv1x1(d16, packs[bname + '.conv3.weight'][1], prec).view(n, ho, wo, width)
-            d16, _ = bn_bwd(dA2, y2, st2, bname + '.bn2', prec)
+            d16, g = bn_bwd(d_out, y3, st3, bname + '.bn3', p3, mask_mode=2, mask_src=out, want_g=not down)
+            wgrad(bname + '.conv3.weight', lambda a, d, k=bname + '.conv3.weight', p=p3: _wgrad1x1(a, d, p).view(par[k].shape), a2, d16)
+            dA2 = _conv1x1(d16, packs[bname + '.conv3.weight'][1], p3).view(n, ho, wo, width)
+            d16, _ = bn_bwd(dA2, y2, st2, bname + '.bn2', p2)
             if stride == 2:
                 d16 = ops.zero_stuff2_16(d16, h, w)                               # adjoint of the subsample of the full-resolution conv
             cg = par[bname + '.conv2.weight'].shape[1]
-            wgrad(bname + '.conv2.weight', lambda a, d, cg=cg: ops.gconv_wgrad16(a, d, cg, prec=prec), a1, d16)
-            dA1 = ops.gconv16(d16, packs[bname + '.conv2.weight'][1], prec=prec)
-            d16, _ = bn_bwd(dA1, y1, st1, bname + '.bn1', prec)
-            wgrad(bname + '.conv1.weight', lambda a, d, k=bname + '.conv1.weight': _wgrad1x1(a, d, prec).view(par[k].shape), xin16, d16)
+            wgrad(bname + '.conv2.weight', lambda a, d, cg=cg, p=p2: ops.gconv_wgrad16(a, d, cg, prec=p), a1, d16)
+            dA1 = ops.gconv16(d16, packs[bname + '.conv2.weight'][1], prec=p2)
+            d16, _ = bn_bwd(dA1, y1, st1, bname + '.bn1', p1)
+            wgrad(bname + '.conv1.weight', lambda a, d, k=bname + '.conv1.weight', p=p1: _wgrad1x1(a, d, p).view(par[k].shape), xin16, d16)
             if down:
-                dd16, _ = bn_bwd(d_out, yd, std, bname + '.downsample.1', prec, mask_mode=2, mask_src=out)      # same ReLU pattern as bn3: out > 0
-                wgrad(bname + '.downsample.0.weight', lambda a, d, k=bname + '.downsample.0.weight': _wgrad1x1(a, d, prec).view(par[k].shape), xd16, dd16)
-                d_xd = _conv1x1(dd16, packs[bname + '.downsample.0.weight'][1], prec)          # [P', cin]
+                dd16, _ = bn_bwd(d_out, yd, std, bname + '.downsample.1', p1, mask_mode=2, mask_src=out)      # same ReLU pattern as bn3: out > 0
+                wgrad(bname + '.downsample.0.weight', lambda a, d, k=bname + '.downsample.0.weight', p=p1: _wgrad1x1(a, d, p).view(par[k].shape), xd16, dd16)
+                d_xd = _conv1x1(dd16, packs[bname + '.downsample.0.weight'][1], p1)          # [P', cin]
                 if stride == 2:
-                    d_xin = _conv1x1(d16, packs[bname + '.conv1.weight'][1], prec).view(n, h, w, cin)
+                    d_xin = _conv1x1(d16, packs[bname + '.conv1.weight'][1], p1).view(n, h, w, cin)
                     ops.add_strided2(d_xin, d_xd.view(n, ho, wo, cin))
                 else:
-                    d_xin = _conv1x1(d16, packs[bname + '.conv1.weight'][1], prec, res=d_xd).view(n, h, w, cin)
+                    d_xin = _conv1x1(d16, packs[bname + '.conv1.weight'][1], p1, res=d_xd).view(n, h, w, cin)
             else:
-                d_xin = _conv1x1(d16, packs[bname + '.conv1.weight'][1], prec, res=g).view(n, h, w, cin)
+                d_xin = _conv1x1(d16, packs[bname + '.conv1.weight'][1], p1, res=g).view(n, h, w, cin)
             d_out = d_xin
         # ---- stem
         prec = net.prec

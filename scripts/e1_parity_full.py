@@ -80,6 +80,6 @@ for _ in range(5):
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 5
 modes = [{0: 'bf16', 1: 'bf16x3', 2: 'f16'}[m] for m in net.block_precs()]
-print(f'[e1-parity] encoder base mode {modes[0]}, fp16 tail {sum(m == "f16" for m in modes) if modes[0] != "f16" else 16} blocks, Y16={os.environ.get("LP_E_Y16", "1")}, eager fwd+bwd {ms:.2f} ms: '
+print(f'[e1-parity] encoder base mode {modes[0]}, fp16 tail {sum(m == "f16" for m in modes) if modes[0] != "f16" else 16} blocks, head fp16 kinds [{os.environ.get("LP_E_HEAD_F16", "")}], Y16={os.environ.get("LP_E_Y16", "1")}, eager fwd+bwd {ms:.2f} ms: '
       f'{frames} frames {size}px train-mode BN: per-frame logits {rel(y, yr):.3e}  embeds {rel(emb, embr):.3e}  '
       f'all-gradients {float((num / den).sqrt()):.3e} (cosine {float((ga * gb).sum() / (ga.norm() * gb.norm())):.4f})  | stock fp32 layers vs fp64: logits {rel(y32, yr):.3e} embeds {rel(e32, embr):.3e} all-gradients {float((n32 / den).sqrt()):.3e}  [{content}; {time.time() - t0:.0f} s]', flush=True)
