@@ -259,9 +259,10 @@ int lp_gconv16_fwd_stats(const uint16_t* a_hi, const uint16_t* a_lo, const uint1
                          int* stats_rows, void* stream);
 /*   lp_gconv16_fwd_planes: as lp_gconv16_fwd_stats with y (fp32) OPTIONAL and the operand planes of y (o_hi [, o_lo]) as a second, optional
  *                     output: the fp16 mode keeps the embedder's conv outputs 16-bit resident ("y16": the unscaled fp16 plane, no fp32 y) */
+/*                     group_size (ABI 7; 0 = not given): groups of <= 32 channels let the kernel skip the zero half of the block-diagonal product */
 int lp_gconv16_fwd_planes(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* w_hi, const uint16_t* w_lo, float* y, uint16_t* o_hi,
-                          uint16_t* o_lo, const float* alpha2, int N, int H, int W, int C, int CP, int prec, float* amax_slots, float* stats,
-                          long long stats_capacity_floats, int* stats_rows, void* stream);
+                          uint16_t* o_lo, const float* alpha2, int N, int H, int W, int C, int CP, int group_size, int prec, float* amax_slots,
+                          float* stats, long long stats_capacity_floats, int* stats_rows, void* stream);
 long long lp_gconv_wgrad_workspace_bytes(int C, int splits);
 int lp_gconv16_wgrad(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* dy_hi, const uint16_t* dy_lo, float* dw, float* workspace,
                      int N, int H, int W, int C, int group_size, int splits, int prec, const float* out_scale, void* stream);

@@ -36,7 +36,7 @@ SIGNATURES = {
     'lp_conv16_stats_floats': (_ll, [_i] * 4),
     'lp_norm_stats_finalize': (_i, [_vp, _i, _vp, _vp, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     'lp_gconv16_fwd_stats': (_i, [_vp] * 6 + [_i] * 6 + [_vp, _vp, _ll, _vp, _vp]),
-    'lp_gconv16_fwd_planes': (_i, [_vp] * 8 + [_i] * 6 + [_vp, _vp, _ll, _vp, _vp]),
+    'lp_gconv16_fwd_planes': (_i, [_vp] * 8 + [_i] * 7 + [_vp, _vp, _ll, _vp, _vp]),
     'lp_conv_wgrad_workspace_bytes': (_ll, [_i, _i, _i, _i]),
     'lp_conv16_wgrad': (_i, [_vp] * 6 + [_i] * 9 + [_vp, _i, _vp, _vp, _vp, _vp]),
     'lp_conv_wgrad_dot_blocks': (_i, [_i] * 3),

@@ -30,11 +30,15 @@
 #include "lp_hip.h"
 #include "lp_internal.h"
 #include <stdlib.h>
+#include <type_traits>
 
 __device__ __attribute__((aligned(64))) unsigned int lp_zero_page[16];      // what out-of-image / out-of-channel DMA lanes read
 
 
-template <int KS, bool UPS, int WM, int WN, int MR, int NR, int PREC, bool PP, int NBUF = 2, int CC = 32>
+// GH (grouped convs with groups of <= 32 channels): output channels [co0, co0 + 32) only contract with the chunk co0 .. co0 + 31 and
+// [co0 + 32, co0 + 64) only with the second chunk -- the other half of every stage's MFMAs multiplies the zeros of the block-diagonal weight
+// image and is skipped (half the matrix work: in the bf16x3 mode the layer-1 / layer-2 grouped convs were bound by it, not by their traffic)
+template <int KS, bool UPS, int WM, int WN, int MR, int NR, int PREC, bool PP, int NBUF = 2, int CC = 32, bool GH = false>
 #ifndef LP_PP_MINW
 #define LP_PP_MINW 2          // min waves per SIMD of the ping-pong kernels in the 16-bit modes: 2 = one workgroup per CU, 4 = two (<= 128 VGPRs)
 #endif
@@ -162,7 +166,10 @@ void conv_dma_kernel(Conv16Params p) {
         }
     };
     // MFMAs of one stage: kernel row ky, halo image Hbuf, weights in stage buffer bbuf
-    auto compute = [&](int ky, const unsigned char* Hbuf, int bbuf) {
+    // HC (GH only): integral constant = which half of the N fragments this chunk feeds (compile time: a run-time predicate inside the unrolled
+    // MFMA loops cost more than the skipped work saved -- 79 -> 106 us per grouped launch, scripts/r04_call25.sh)
+    auto compute_h = [&](int ky, const unsigned char* Hbuf, int bbuf, auto HC) {
+        constexpr int half = decltype(HC)::value;
         const unsigned char* A_hi = Hbuf;
         const unsigned char* A_lo = Hbuf + a_bytes;
         const unsigned char* Bc = B_base + bbuf * B_BUF;
@@ -187,6 +194,7 @@ void conv_dma_kernel(Conv16Params p) {
             const int bsl = (grp8 ^ bkey) << 4;
 #pragma unroll
             for (int nr = 0; nr < NR; ++nr) {
+                if (GH && nr / (NR / 2) != half) continue;
                 fb[set][nr] = *(const s16x8_t*)(Bk + b_off[nr] + bsl);
                 if (SPLIT) fbl[set][nr] = *(const s16x8_t*)(Bk + B_STAGE + b_off[nr] + bsl);
             }
@@ -203,6 +211,7 @@ void conv_dma_kernel(Conv16Params p) {
             for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
                 for (int nr = 0; nr < NR; ++nr) {
+                    if (GH && nr / (NR / 2) != half) continue;
                     if (SPLIT) {
                         acc[mr][nr] = mfma16(fal[cur][mr], fb[cur][nr], acc[mr][nr]);
                         acc[mr][nr] = mfma16(fa[cur][mr], fbl[cur][nr], acc[mr][nr]);
@@ -210,6 +219,11 @@ void conv_dma_kernel(Conv16Params p) {
                     acc[mr][nr] = mfma16t<F16>(fa[cur][mr], fb[cur][nr], acc[mr][nr]);
                 }
         }
+    };
+    auto compute = [&](int ky, const unsigned char* Hbuf, int bbuf, int chunk_abs) {
+        if constexpr (!GH) compute_h(ky, Hbuf, bbuf, std::integral_constant<int, -1>{});
+        else if (chunk_abs & 1) compute_h(ky, Hbuf, bbuf, std::integral_constant<int, 1>{});
+        else compute_h(ky, Hbuf, bbuf, std::integral_constant<int, 0>{});
     };
 
     const int nch_total = p.CinP / CC;
@@ -236,7 +250,7 @@ void conv_dma_kernel(Conv16Params p) {
                 lp_wait_vm0();
                 __syncthreads();                                   // ---- phase A(k)
                 if (grp == 0) {
-                    compute(ky, H_base, bbuf);
+                    compute(ky, H_base, bbuf, cbeg + chunk);
                 } else {
                     if (ky == 0 && chunk > 0) issue_a(cbeg + chunk, H_base);
                     if (k + 1 < S) issue_b(cbeg + (k + 1) / KS, (k + 1) % KS, bbuf ^ 1);
@@ -244,7 +258,7 @@ void conv_dma_kernel(Conv16Params p) {
                 lp_wait_vm0();
                 __syncthreads();                                   // ---- phase B(k)
                 if (grp == 1) {
-                    compute(ky, H_base, bbuf);
+                    compute(ky, H_base, bbuf, cbeg + chunk);
                 } else {
                     if (ky == KS - 1 && has_next) issue_a(cbeg + chunk + 1, H_base);
                     if (k + 1 < S) issue_b(cbeg + (k + 1) / KS, (k + 1) % KS, bbuf ^ 1);
@@ -271,7 +285,7 @@ void conv_dma_kernel(Conv16Params p) {
                 if (p.a_dbuf && ky == 0 && has_next) issue_a(cbeg + chunk + 1, H_base + (abuf ^ 1) * a_buf);
                 const int sp = s + NBUF - 1;
                 if (sp < S) issue_b(cbeg + sp / KS, sp % KS, sp % NBUF);
-                compute(ky, H_base + abuf * a_buf, s % NBUF);
+                compute(ky, H_base + abuf * a_buf, s % NBUF, cbeg + chunk);
                 if (!p.a_dbuf && ky == KS - 1 && has_next) {      // (LDS-tight tiles) one halo buffer: restage it once everyone has read it
                     __syncthreads();
                     issue_a(cbeg + chunk + 1, H_base);
@@ -342,9 +356,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(Conv16Params p) {
 // ------------------------------------------------------------------------------------------------------------------
 // host side: tile selection + dispatch
 // ------------------------------------------------------------------------------------------------------------------
-template <int KS, bool UPS, int WM, int WN, int MR, int NR, int PREC, bool PP, int NBUF = 2, int CC = 32>
+template <int KS, bool UPS, int WM, int WN, int MR, int NR, int PREC, bool PP, int NBUF = 2, int CC = 32, bool GH = false>
 static int launch_v(Conv16Params& p, size_t lds, dim3 grid, hipStream_t stream) {
-    auto kern = conv_dma_kernel<KS, UPS, WM, WN, MR, NR, PREC, PP, NBUF, CC>;
+    auto kern = conv_dma_kernel<KS, UPS, WM, WN, MR, NR, PREC, PP, NBUF, CC, GH>;
     static thread_local int attr_dev = -1;                 // per host thread and device (main and autograd threads both launch)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return lp_set_error(LP_ERR_HIP, "hipGetDevice failed");
@@ -357,7 +371,7 @@ static int launch_v(Conv16Params& p, size_t lds, dim3 grid, hipStream_t stream) 
     return lp_check_launch("conv_dma");
 }
 
-template <int KS, bool UPS, int WM, int WN, int MR, int NR, int PREC, int CC = 32>
+template <int KS, bool UPS, int WM, int WN, int MR, int NR, int PREC, int CC = 32, bool GH = false>
 static int launch_conv16(Conv16Params& p, hipStream_t stream) {
     constexpr int BM = WM * MR * 16, BN = WN * NR * 16, NWAVE = WM * WN;
     constexpr bool SPLIT = (PREC == LP_PREC_BF16X3);
@@ -429,7 +443,7 @@ static int launch_conv16(Conv16Params& p, hipStream_t stream) {
     }
     // (64-channel chunks -- CC = 64, twice the MFMAs between two barriers -- were measured 7-15 % SLOWER on the 64^2..256^2 layers: their
     //  146 KB of LDS leave one workgroup per CU, while the 72 KB of the 32-channel kernel let two ping-pong workgroups share a CU)
-    if constexpr (pp_ok) { if (pp) return launch_v<KS, UPS, WM, WN, MR, NR, PREC, true, 2, CC>(p, lds, grid, stream); }
+    if constexpr (pp_ok) { if (pp) return launch_v<KS, UPS, WM, WN, MR, NR, PREC, true, 2, CC, GH>(p, lds, grid, stream); }
     // 3-deep weight ring when the grid gives each CU at most ~one workgroup (its LDS would exclude a second one anyway) and it fits
     constexpr int NQ = KS * BN * ROWB / 1024;
     constexpr bool ring_ok = (NQ % NWAVE == 0);
@@ -438,9 +452,9 @@ static int launch_conv16(Conv16Params& p, hipStream_t stream) {
         const size_t lds3 = lds_halo + 3 * B_BUF;
         const long long total_wgs = (long long)grid.x * grid.y * grid.z;
         const bool ring = (nbuf_env ? nbuf_env == 3 : total_wgs <= 320) && lds3 <= LDS_MAX;
-        if (ring) return launch_v<KS, UPS, WM, WN, MR, NR, PREC, false, 3, CC>(p, lds3 > epi ? lds3 : epi, grid, stream);
+        if (ring) return launch_v<KS, UPS, WM, WN, MR, NR, PREC, false, 3, CC, GH>(p, lds3 > epi ? lds3 : epi, grid, stream);
     }
-    return launch_v<KS, UPS, WM, WN, MR, NR, PREC, false, 2, CC>(p, lds, grid, stream);
+    return launch_v<KS, UPS, WM, WN, MR, NR, PREC, false, 2, CC, GH>(p, lds, grid, stream);
 }
 
 template <int PREC>
@@ -588,14 +602,15 @@ extern "C" int lp_gconv16_fwd_stats(const uint16_t* a_hi, const uint16_t* a_lo, 
                                     const float* alpha2, int N, int H, int W, int C, int CP, int prec, float* amax_slots,
                                     float* stats, long long stats_capacity_floats, int* stats_rows, void* stream) {
     if (!y) return lp_set_error(LP_ERR_ARG, "lp_gconv16_fwd: null pointer");
-    return lp_gconv16_fwd_planes(a_hi, a_lo, w_hi, w_lo, y, nullptr, nullptr, alpha2, N, H, W, C, CP, prec, amax_slots, stats,
+    return lp_gconv16_fwd_planes(a_hi, a_lo, w_hi, w_lo, y, nullptr, nullptr, alpha2, N, H, W, C, CP, 0, prec, amax_slots, stats,
                                  stats_capacity_floats, stats_rows, stream);
 }
 
 // y (fp32, |NULL) and / or the operand planes of y (o_hi [, o_lo], |NULL): the fp16 mode keeps the embedder's conv outputs 16-bit resident
 extern "C" int lp_gconv16_fwd_planes(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* w_hi, const uint16_t* w_lo, float* y,
-                                     uint16_t* o_hi, uint16_t* o_lo, const float* alpha2, int N, int H, int W, int C, int CP, int prec,
-                                     float* amax_slots, float* stats, long long stats_capacity_floats, int* stats_rows, void* stream) {
+                                     uint16_t* o_hi, uint16_t* o_lo, const float* alpha2, int N, int H, int W, int C, int CP, int group_size,
+                                     int prec, float* amax_slots, float* stats, long long stats_capacity_floats, int* stats_rows,
+                                     void* stream) {
     if (stats_rows) *stats_rows = 0;
     if (stats && !stats_rows) return lp_set_error(LP_ERR_ARG, "lp_gconv16_fwd: stats needs stats_rows");
     if (!a_hi || !w_hi || (!y && !o_hi)) return lp_set_error(LP_ERR_ARG, "lp_gconv16_fwd: null pointer");
@@ -611,9 +626,13 @@ extern "C" int lp_gconv16_fwd_planes(const uint16_t* a_hi, const uint16_t* a_lo,
     p.stats = stats; p.stats_cap = stats ? stats_capacity_floats : 0; p.stats_rows = 0;
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    if (prec == LP_PREC_BF16) rc = launch_conv16<3, false, 4, 1, 4, 4, LP_PREC_BF16>(p, s);
-    else if (prec == LP_PREC_BF16X3) rc = launch_conv16<3, false, 4, 1, 4, 4, LP_PREC_BF16X3>(p, s);
-    else if (prec == LP_PREC_F16) rc = launch_conv16<3, false, 4, 1, 4, 4, LP_PREC_F16>(p, s);
+    // group_size (0: unknown) in 1 .. 32: the two 32-channel halves of a 64-channel block do not interact -- the kernel variant that skips
+    // the zero half of every stage (LP_GCONV_HALF=0: the full block-diagonal product, the A/B baseline)
+    static const bool half_env = !(getenv("LP_GCONV_HALF") && atoi(getenv("LP_GCONV_HALF")) == 0);
+    const bool gh = half_env && group_size >= 1 && group_size <= 32 && (32 % group_size) == 0;
+    if (prec == LP_PREC_BF16) rc = gh ? launch_conv16<3, false, 4, 1, 4, 4, LP_PREC_BF16, 32, true>(p, s) : launch_conv16<3, false, 4, 1, 4, 4, LP_PREC_BF16>(p, s);
+    else if (prec == LP_PREC_BF16X3) rc = gh ? launch_conv16<3, false, 4, 1, 4, 4, LP_PREC_BF16X3, 32, true>(p, s) : launch_conv16<3, false, 4, 1, 4, 4, LP_PREC_BF16X3>(p, s);
+    else if (prec == LP_PREC_F16) rc = gh ? launch_conv16<3, false, 4, 1, 4, 4, LP_PREC_F16, 32, true>(p, s) : launch_conv16<3, false, 4, 1, 4, 4, LP_PREC_F16>(p, s);
     else return lp_set_error(LP_ERR_ARG, "lp_gconv16_fwd: unknown precision mode");
     if (stats_rows) *stats_rows = p.stats_rows;
     return rc;

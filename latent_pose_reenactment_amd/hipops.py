@@ -860,7 +860,7 @@ def gconv16(a: Act16, pack: WeightPack, *, prec: int, amax: bool = False, stats:
     nbytes = n * h * w * c * (pl + (4 if want_y else 0) + (pl if out16 else 0)) + pack.hi.numel() * pl
     with _Timed('gconv', 2.0 * n * h * w * c * pack.cols * 9, (n, h, w, pack.cols, c, 3, 0, 0), nbytes):
         check(_lib.lib().lp_gconv16_fwd_planes(a.hi.data_ptr(), _p(a.lo), pack.hi.data_ptr(), _p(pack.lo), _p(y), _p(o_hi), _p(o_lo), _p(a.inv),
-                                               n, h, w, c, pack.rows_p, prec, _p(slots), _p(st_buf), st_cap,
+                                               n, h, w, c, pack.rows_p, pack.cols, prec, _p(slots), _p(st_buf), st_cap,
                                                None if st_rows is None else ctypes.addressof(st_rows), _stream()), 'lp_gconv16_fwd')
     out = (y,) if not out16 else (y, Act16(o_hi, o_lo, c, None))
     if stats:
