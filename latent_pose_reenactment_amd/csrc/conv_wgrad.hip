@@ -692,18 +692,29 @@ static int launch_wgrad1x1(WgradParams& p, float* dw, const float* out_scale, co
 //   * XCD-aware block order as wgrad1x1_kernel: the (co, ci) tiles of one pixel range run on one XCD.
 // Output: the [split][tap][CoP][CiP] slabs of the common reduction.  f16 / bf16 operands (the bf16x3 mode keeps conv_wgrad_kernel).
 struct W3Params {
-    const uint16_t* a_hi; const uint16_t* d_hi; float* part; float* bpart;
+    const uint16_t* a_hi; const uint16_t* a_lo; const uint16_t* d_hi; const uint16_t* d_lo; float* part; float* bpart;
     int N, H, W, Hin, Win, C8, Co8, CoP, CiP;
     int splits, per, num_tiles, tiles_x, tiles_y, tiles_co, tiles_ci, xcd_map, diag;
 };
 
-template <bool UPS, bool F16>
+// DIAGB (grouped convs, block-diagonal form: the workgroup of output channels [co0, co0 + 64) only meets input channels [co0, co0 + 64)):
+//   0: dense 64 x 64 block (every wave all four 16-row fragments) | 16: groups of <= 16 channels -- only the 16 x 16 diagonal tiles are
+//   non-zero, a wave keeps ONE row fragment (its own: 9 accumulator tiles, 1/4 of the matrix work and of the slab bytes) | 32: groups of 32
+//   -- the two row fragments of the wave's 32-channel half.  The bf16x3 mode (hi + lo planes, 3 MFMAs) is built for the diagonal forms only:
+//   their 9 / 18 accumulator tiles leave the registers for the second fragment set, and ONE workgroup per CU holds the doubled planes.
+template <bool UPS, int PREC, int DIAGB>
 __global__ __launch_bounds__(256, 2) void wgrad3_pipe_kernel(W3Params p) {
+    constexpr bool SPLIT = (PREC == LP_PREC_BF16X3), F16 = (PREC == LP_PREC_F16);
+    static_assert(!SPLIT || DIAGB != 0, "bf16x3: diagonal forms only");
+    static_assert(!UPS || DIAGB == 0, "grouped convs are not upsampled");
+    constexpr int NT = DIAGB == 16 ? 1 : DIAGB == 32 ? 2 : 4;     // row (co) fragments per wave
     constexpr int HH = UPS ? 6 : 10, HW = UPS ? 10 : 18;
     constexpr int HALO_PX = HH * HW;
     constexpr int NAH = (HALO_PX + 7) / 8;                  // 1 KiB DMA pieces of the halo: 23 | 8
     constexpr int NAW = (NAH + 3) / 4;                      // per wave
-    constexpr int HALO_B = NAH * 1024, DY_B = 128 * 128, STAGE_B = HALO_B + DY_B;
+    constexpr int HALO_B = NAH * 1024, DY_B = 128 * 128;
+    constexpr int NP = SPLIT ? 2 : 1;                       // planes: stage = [halo hi][halo lo][dy hi][dy lo]
+    constexpr int DY_O = HALO_B * NP, STAGE_B = (HALO_B + DY_B) * NP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ntile = p.tiles_co * p.tiles_ci;
@@ -736,7 +747,9 @@ __global__ __launch_bounds__(256, 2) void wgrad3_pipe_kernel(W3Params p) {
                 const int ch = ci0 + ((lslot ^ (((hp >> 1) & 3) << 1)) << 3);
                 const int iy = oy + hy, ix = ox + hx;
                 const bool ok = (hp < HALO_PX) && (ch < p.C8) && (iy >= 0) && (iy < p.Hin) && (ix >= 0) && (ix < p.Win);
-                lp_glds16(ok ? p.a_hi + ((size_t)((n0 * p.Hin + iy) * p.Win + ix) * p.C8 + ch) : zero16, dst + (unsigned)(q * 1024));
+                const size_t off = ok ? ((size_t)((n0 * p.Hin + iy) * p.Win + ix) * p.C8 + ch) : 0;
+                lp_glds16(ok ? p.a_hi + off : zero16, dst + (unsigned)(q * 1024));
+                if (SPLIT) lp_glds16(ok ? p.a_lo + off : zero16, dst + (unsigned)(HALO_B + q * 1024));
             }
         }
 #pragma unroll
@@ -746,17 +759,19 @@ __global__ __launch_bounds__(256, 2) void wgrad3_pipe_kernel(W3Params p) {
             const int ch = co0 + ((lslot ^ (((kp >> 1) & 3) << 1)) << 3);
             const int yy = y0 + (kp >> 4), xx = x0 + (kp & 15);
             const bool ok = (ch < p.Co8) && (yy < p.H) && (xx < p.W);
-            lp_glds16(ok ? p.d_hi + ((size_t)((n0 * p.H + yy) * p.W + xx) * p.Co8 + ch) : zero16, dst + (unsigned)(HALO_B + q * 1024));
+            const size_t off = ok ? ((size_t)((n0 * p.H + yy) * p.W + xx) * p.Co8 + ch) : 0;
+            lp_glds16(ok ? p.d_hi + off : zero16, dst + (unsigned)(DY_O + q * 1024));
+            if (SPLIT) lp_glds16(ok ? p.d_lo + off : zero16, dst + (unsigned)(DY_O + DY_B + q * 1024));
         }
     };
 
-    f32x4_t acc[9][4];
+    f32x4_t acc[9][NT];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[t][i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < NT; ++i) acc[t][i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     f32x4_t accb = (f32x4_t){0.f, 0.f, 0.f, 0.f};           // wave w: column sums of dy for co0 + 16 w .. + 15 (every column of the tile is the sum)
-    const bool do_bias = (p.bpart != nullptr) && (tci == 0);
+    const bool do_bias = (DIAGB == 0) && (p.bpart != nullptr) && (tci == 0);
     const short one16 = F16 ? (short)0x3C00 : (short)0x3F80;
     const s16x8_t ones = (s16x8_t){one16, one16, one16, one16, one16, one16, one16, one16};
 
@@ -764,9 +779,10 @@ __global__ __launch_bounds__(256, 2) void wgrad3_pipe_kernel(W3Params p) {
     const int G = lane >> 4, sj = (lane & 15) >> 2, sq = lane & 3;
     const int pxl = G * 4 + sj;
     const int swA = (pxl >> 1) & 3;                         // key of dy row 16 m + pxl
-    int aoff[4];
+    const int mf0 = DIAGB == 16 ? wave : DIAGB == 32 ? (wave >> 1) * 2 : 0;      // first row fragment of this wave
+    int aoff[NT];
 #pragma unroll
-    for (int mf = 0; mf < 4; ++mf) aoff[mf] = pxl * 128 + ((mf ^ swA) << 5) + sq * 8;
+    for (int j = 0; j < NT; ++j) aoff[j] = pxl * 128 + (((mf0 + j) ^ swA) << 5) + sq * 8;
     int bl[3], bs[3];                                      // per tap column dx: byte offset of the lane's halo column, key part of that column
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) {
@@ -776,13 +792,17 @@ __global__ __launch_bounds__(256, 2) void wgrad3_pipe_kernel(W3Params p) {
 
     auto compute = [&](int buf) {
         const unsigned char* Hb = smem + buf * STAGE_B;
-        const unsigned char* Db = Hb + HALO_B;
-        s16x8_t fa[2][4], fb[3];
+        const unsigned char* Db = Hb + DY_O;
+        s16x8_t fa[2][NT], fb[3], fal[2][NT], fbl[3];
         auto fetch_a = [&](int ks, int set) {
 #pragma unroll
-            for (int mf = 0; mf < 4; ++mf) {
-                const s16x4_t v0 = tr_read(Db + (ks * 32) * 128 + aoff[mf]), v1 = tr_read(Db + (ks * 32 + 16) * 128 + aoff[mf]);
-                fa[set][mf] = (s16x8_t){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            for (int j = 0; j < NT; ++j) {
+                const s16x4_t v0 = tr_read(Db + (ks * 32) * 128 + aoff[j]), v1 = tr_read(Db + (ks * 32 + 16) * 128 + aoff[j]);
+                fa[set][j] = (s16x8_t){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                if (SPLIT) {
+                    const s16x4_t w0 = tr_read(Db + DY_B + (ks * 32) * 128 + aoff[j]), w1 = tr_read(Db + DY_B + (ks * 32 + 16) * 128 + aoff[j]);
+                    fal[set][j] = (s16x8_t){w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
+                }
             }
         };
         auto fetch_b = [&](int g, int set) {
@@ -790,9 +810,14 @@ __global__ __launch_bounds__(256, 2) void wgrad3_pipe_kernel(W3Params p) {
             const int dy = tap / 3, dx = tap - dy * 3;
             const int r0 = UPS ? ((2 * ks + dy - 1) >> 1) + 1 : 2 * ks + dy;
             const int r1 = UPS ? ((2 * ks + dy) >> 1) + 1 : 2 * ks + dy + 1;
-            const s16x4_t v0 = tr_read(Hb + r0 * HW * 128 + bl[dx] + ((wave ^ ((bs[dx] + r0) & 3)) << 5));
-            const s16x4_t v1 = tr_read(Hb + r1 * HW * 128 + bl[dx] + ((wave ^ ((bs[dx] + r1) & 3)) << 5));
+            const int o0 = r0 * HW * 128 + bl[dx] + ((wave ^ ((bs[dx] + r0) & 3)) << 5);
+            const int o1 = r1 * HW * 128 + bl[dx] + ((wave ^ ((bs[dx] + r1) & 3)) << 5);
+            const s16x4_t v0 = tr_read(Hb + o0), v1 = tr_read(Hb + o1);
             fb[set] = (s16x8_t){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            if (SPLIT) {
+                const s16x4_t w0 = tr_read(Hb + HALO_B + o0), w1 = tr_read(Hb + HALO_B + o1);
+                fbl[set] = (s16x8_t){w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
+            }
         };
         fetch_a(0, 0); fetch_b(0, 0); fetch_b(1, 1);
 #pragma unroll
@@ -802,10 +827,18 @@ __global__ __launch_bounds__(256, 2) void wgrad3_pipe_kernel(W3Params p) {
             if (tap == 4 && ks + 1 < 4) fetch_a(ks + 1, (ks + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int mf = 0; mf < 4; ++mf) acc[tap][mf] = mfma16t<F16>(fa[ks & 1][mf], fb[g % 3], acc[tap][mf]);
-            if (tap == 0 && do_bias) {                      // (scalar selects: no dynamic register indexing)
-                const s16x8_t fw = wave == 0 ? fa[ks & 1][0] : wave == 1 ? fa[ks & 1][1] : wave == 2 ? fa[ks & 1][2] : fa[ks & 1][3];
-                accb = mfma16t<F16>(fw, ones, accb);
+            for (int j = 0; j < NT; ++j) {
+                if (SPLIT) {
+                    acc[tap][j] = mfma16(fal[ks & 1][j], fb[g % 3], acc[tap][j]);
+                    acc[tap][j] = mfma16(fa[ks & 1][j], fbl[g % 3], acc[tap][j]);
+                }
+                acc[tap][j] = mfma16t<F16>(fa[ks & 1][j], fb[g % 3], acc[tap][j]);
+            }
+            if constexpr (DIAGB == 0) {
+                if (tap == 0 && do_bias) {                  // (scalar selects: no dynamic register indexing)
+                    const s16x8_t fw = wave == 0 ? fa[ks & 1][0] : wave == 1 ? fa[ks & 1][1] : wave == 2 ? fa[ks & 1][2] : fa[ks & 1][3];
+                    accb = mfma16t<F16>(fw, ones, accb);
+                }
             }
         }
     };
@@ -824,11 +857,11 @@ __global__ __launch_bounds__(256, 2) void wgrad3_pipe_kernel(W3Params p) {
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-        for (int mf = 0; mf < 4; ++mf)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int co = co0 + mf * 16 + (lane >> 4) * 4 + r;
-                p.part[(((size_t)split * 9 + tap) * p.CoP + co) * p.CiP + cib] = acc[tap][mf][r];
+                const int co = co0 + (mf0 + j) * 16 + (lane >> 4) * 4 + r;
+                p.part[(((size_t)split * 9 + tap) * p.CoP + co) * p.CiP + cib] = acc[tap][j][r];
             }
     if (do_bias && (lane & 15) == 0) {
 #pragma unroll
@@ -836,19 +869,19 @@ __global__ __launch_bounds__(256, 2) void wgrad3_pipe_kernel(W3Params p) {
     }
 }
 
-template <bool UPS, int PREC>
+template <bool UPS, int PREC, int DIAGB = 0>
 static int launch_wgrad3_pipe(WgradParams& p, float* dw, float* dbias, const float* out_scale, const float* sn_w, float* sn_dot, hipStream_t stream) {
-    static_assert(PREC != LP_PREC_BF16X3, "one-plane operand modes only");
+    constexpr bool SPLIT = (PREC == LP_PREC_BF16X3);
     static const int target_env = getenv("LP_WGRAD3_WGS") ? atoi(getenv("LP_WGRAD3_WGS")) : 0;
     W3Params q;
-    q.a_hi = p.a_hi; q.d_hi = p.d_hi; q.part = p.part; q.bpart = p.bpart;
+    q.a_hi = p.a_hi; q.a_lo = p.a_lo; q.d_hi = p.d_hi; q.d_lo = p.d_lo; q.part = p.part; q.bpart = p.bpart;
     q.N = p.N; q.H = p.H; q.W = p.W; q.Hin = p.Hin; q.Win = p.Win; q.C8 = p.C8; q.Co8 = p.Co8; q.CoP = p.CoP; q.CiP = p.CiP;
     q.diag = p.diag;
     q.tiles_x = (p.W + 15) / 16; q.tiles_y = (p.H + 7) / 8;
     q.num_tiles = q.tiles_x * q.tiles_y * p.N;
     q.tiles_co = p.CoP / 64; q.tiles_ci = p.diag ? 1 : p.CiP / 64;
     const int ntile = q.tiles_co * q.tiles_ci;
-    const int target = target_env > 0 ? target_env : 1024;                 // ~2 resident sets of two workgroups per CU
+    const int target = target_env > 0 ? target_env : (SPLIT ? 512 : 1024);    // ~2 resident sets of two (bf16x3: one) workgroups per CU
     int splits = target / ntile; if (splits < 1) splits = 1;
     if (splits > p.splits) splits = p.splits;
     if (splits > q.num_tiles) splits = q.num_tiles;
@@ -858,8 +891,8 @@ static int launch_wgrad3_pipe(WgradParams& p, float* dw, float* dbias, const flo
     p.splits = q.splits = splits;
     q.xcd_map = (splits % 8 == 0);
     constexpr int HALO_PX = UPS ? 60 : 180;
-    const size_t lds = (size_t)2 * (((HALO_PX + 7) / 8) * 1024 + 128 * 128);
-    auto kern = wgrad3_pipe_kernel<UPS, PREC == LP_PREC_F16>;
+    const size_t lds = (size_t)2 * (((HALO_PX + 7) / 8) * 1024 + 128 * 128) * (SPLIT ? 2 : 1);
+    auto kern = wgrad3_pipe_kernel<UPS, PREC, DIAGB>;
     static thread_local int attr_dev = -1;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return lp_set_error(LP_ERR_HIP, "hipGetDevice failed");
@@ -878,8 +911,8 @@ static int launch_wgrad3_pipe(WgradParams& p, float* dw, float* dbias, const flo
 // LP_WGRAD3_PIPE = 0: conv_wgrad_kernel everywhere | 1 (default): the DMA-staged kernel for layers with >= LP_WGRAD3_MIN_TILES (32) pixel
 // tiles and W >= 16 | 2: for every 3x3 layer of a one-plane mode (tests)
 template <int PREC>
-static bool wgrad3_pipe_wanted(const WgradParams& p) {
-    if (PREC == LP_PREC_BF16X3) return false;
+static bool wgrad3_pipe_wanted(const WgradParams& p, bool diag_form = false) {
+    if (PREC == LP_PREC_BF16X3 && !diag_form) return false;          // (bf16x3: the diagonal forms of the grouped convs only)
     static const int mode = getenv("LP_WGRAD3_PIPE") ? atoi(getenv("LP_WGRAD3_PIPE")) : 1;
     static const int min_tiles = getenv("LP_WGRAD3_MIN_TILES") ? atoi(getenv("LP_WGRAD3_MIN_TILES")) : 32;
     if (mode == 0) return false;
@@ -982,7 +1015,16 @@ extern "C" int lp_gconv16_wgrad(const uint16_t* a_hi, const uint16_t* a_lo, cons
     p.splits = splits; p.db_acc = 0; p.diag = 1; p.bpart = nullptr;
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    if (prec == LP_PREC_BF16 && wgrad3_pipe_wanted<LP_PREC_BF16>(p)) rc = launch_wgrad3_pipe<false, LP_PREC_BF16>(p, dw, nullptr, out_scale, nullptr, nullptr, s);
+    // groups of <= 16 / 32 channels: the DMA-staged kernel on the non-zero diagonal tiles only (LP_GWGRAD_DIAG=0: the dense 64 x 64 block)
+    static const bool diag_env = !(getenv("LP_GWGRAD_DIAG") && atoi(getenv("LP_GWGRAD_DIAG")) == 0);
+    const int db = !diag_env ? 0 : (group_size <= 16 && 16 % group_size == 0) ? 16 : (group_size == 32 ? 32 : 0);
+#define LP_GW3(PR) (db == 16 ? launch_wgrad3_pipe<false, PR, 16>(p, dw, nullptr, out_scale, nullptr, nullptr, s) \
+                             : launch_wgrad3_pipe<false, PR, 32>(p, dw, nullptr, out_scale, nullptr, nullptr, s))
+    if (db && prec == LP_PREC_BF16 && wgrad3_pipe_wanted<LP_PREC_BF16>(p, true)) rc = LP_GW3(LP_PREC_BF16);
+    else if (db && prec == LP_PREC_F16 && wgrad3_pipe_wanted<LP_PREC_F16>(p, true)) rc = LP_GW3(LP_PREC_F16);
+    else if (db && prec == LP_PREC_BF16X3 && wgrad3_pipe_wanted<LP_PREC_BF16X3>(p, true)) rc = LP_GW3(LP_PREC_BF16X3);
+#undef LP_GW3
+    else if (prec == LP_PREC_BF16 && wgrad3_pipe_wanted<LP_PREC_BF16>(p)) rc = launch_wgrad3_pipe<false, LP_PREC_BF16>(p, dw, nullptr, out_scale, nullptr, nullptr, s);
     else if (prec == LP_PREC_F16 && wgrad3_pipe_wanted<LP_PREC_F16>(p)) rc = launch_wgrad3_pipe<false, LP_PREC_F16>(p, dw, nullptr, out_scale, nullptr, nullptr, s);
     else if (prec == LP_PREC_BF16) rc = launch_wgrad<3, false, LP_PREC_BF16>(p, dw, nullptr, out_scale, nullptr, nullptr, s);
     else if (prec == LP_PREC_BF16X3) rc = launch_wgrad<3, false, LP_PREC_BF16X3>(p, dw, nullptr, out_scale, nullptr, nullptr, s);

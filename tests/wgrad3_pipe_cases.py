@@ -42,6 +42,8 @@ GROUPED = [  # N, H, W, C, group size
     (2, 16, 16, 128, 4),
     (1, 32, 16, 256, 8),
     (3, 8, 24, 64, 16),
+    (2, 16, 32, 128, 32),                   # groups of 32: two row fragments per wave
+    (1, 40, 24, 192, 4),                    # ragged tiles, three 64-channel blocks
 ]
 
 
@@ -73,6 +75,8 @@ def run_grouped(case, prec):
     dw = ops.gconv_wgrad16(a, d, cg, prec=prec)
     torch.cuda.synchronize()
     A, D = dec(a.hi, prec, c), dec(d.hi, prec, c)
+    if prec == 1:          # bf16x3: operands = hi + lo (the kernel drops the lo x lo term: 2^-16 relative)
+        A, D = A + dec(a.lo, prec, c), D + dec(d.lo, prec, c)
     wgt = torch.zeros(c, cg, 3, 3, dtype=torch.float64, device=A.device, requires_grad=True)
     F.conv2d(A, wgt, None, 1, 1, 1, c // cg).backward(D)
     return {'dw': rel(dw, wgt.grad)}
@@ -91,6 +95,10 @@ def main():
             errs = run_grouped(case, prec)
             print(f'[wgrad3_pipe grouped] prec={prec} {case}: ' + ' '.join(f'{k}={v:.2e}' for k, v in errs.items()), flush=True)
             bad += [(prec, case, k, v) for k, v in errs.items() if not v < 2e-5]
+    for case in GROUPED:                     # bf16x3: the grouped (block-diagonal) forms are the only ones the DMA-staged kernel takes
+        errs = run_grouped(case, 1)
+        print(f'[wgrad3_pipe grouped] prec=1 {case}: ' + ' '.join(f'{k}={v:.2e}' for k, v in errs.items()), flush=True)
+        bad += [(1, case, k, v) for k, v in errs.items() if not v < 3e-5]
     if bad:
         print('FAILED', bad)
         sys.exit(1)
