@@ -272,7 +272,9 @@ class Discriminator(nn.Module):
             # (issued in the reference's order -- the debug tape of the parity tests records ReLU sites in issue order -- from one fork point)
             here = streams.fork_point(fake.device)
             fake_score_G, fake_features = self.pass_inputs(fake, embed if track1 else embed.detach(), track_weights=track1, sn_states=sts[0])
-            with streams.branch(fake.device, 6, after=here) as b2:
+            # (this pass and the real-image pass deposit gradients on the same parameters from two streams: this one accumulates into the
+            #  parameters' SECOND buffers -- nn.alt_accumulation)
+            with streams.branch(fake.device, 6, after=here) as b2, lpnn.alt_accumulation():
                 fake_score_D, _ = self.pass_inputs(fake.detach(), embed.detach(), sn_states=sts[1])
             if early_real is not None:
                 _, b3, real_score, real_features = early_real

@@ -106,13 +106,61 @@ class fused_grad_accumulation:
 
     def __exit__(self, *exc):
         _FUSED_ACCUM[0] = self.prev
+        if exc[0] is None:
+            #  every branch that accumulated on a side stream is joined HERE, so no caller can read .grad early; then the
+            # second accumulation buffers (``alt_accumulation``) are folded into .grad
+            from latent_pose_reenactment_amd import streams
+            streams.join_all()
+            flush_alt_accumulation()
 
 
-def _accum_target(w):
-    if not _FUSED_ACCUM[0] or not (w.is_leaf and w.requires_grad):
+# Two backward passes that run CONCURRENTLY on different streams and deposit gradients on the SAME parameters (the critic's fake-image and
+# real-image passes of loss_D.backward: streams.py 'dpasses') must not both ``.grad += g`` from their own kernels -- that is a read-modify-write
+# race as soon as the two streams really overlap (hipGraph replays; found by tests/test_train_entry_gpu.py when the real pass moved beside the
+# generator, round 4).  Functions whose FORWARD ran inside ``alt_accumulation()`` accumulate into a second, persistent buffer per parameter
+# instead; ``flush_alt_accumulation`` (called by ``fused_grad_accumulation.__exit__`` after the streams are joined) adds those buffers to
+# .grad with one multi-tensor add and clears them with one multi-tensor zero.
+_ALT = {'on': False, 'bufs': {}, 'dirty': {}}
+
+
+class alt_accumulation:
+    def __enter__(self):
+        self.prev = _ALT['on']
+        _ALT['on'] = True
+
+    def __exit__(self, *exc):
+        _ALT['on'] = self.prev
+
+
+def flush_alt_accumulation():
+    dirty = _ALT['dirty']
+    if not dirty:
+        return
+    tgt, src = [g for g, _ in dirty.values()], [b for _, b in dirty.values()]
+    torch._foreach_add_(tgt, src)
+    torch._foreach_zero_(src)
+    dirty.clear()
+
+
+_FUSED_ACCUM_ENV = os.environ.get('LP_FUSED_ACCUM', '1') != '0'      # 0: plain autograd accumulation everywhere (diagnosis knob)
+
+
+def _accum_target(w, alt=False):
+    """the tensor a gradient-producing kernel may add into: ``w.grad``, or (``alt``: the pass runs beside another one that feeds the same
+    parameters) the parameter's second accumulation buffer (zero between steps)"""
+    if not _FUSED_ACCUM[0] or not _FUSED_ACCUM_ENV or not (w.is_leaf and w.requires_grad):
         return None
     g = w.grad
-    return g if (g is not None and g.is_contiguous() and g.dtype == torch.float32 and g.shape == w.shape) else None
+    if not (g is not None and g.is_contiguous() and g.dtype == torch.float32 and g.shape == w.shape):
+        return None
+    if not alt:
+        return g
+    ent = _ALT['bufs'].get(id(w))
+    if ent is None or ent[0] is not w or ent[1].shape != g.shape or ent[1].device != g.device:
+        ent = (w, torch.zeros_like(g))
+        _ALT['bufs'][id(w)] = ent
+    _ALT['dirty'][id(w)] = (g, ent[1])
+    return ent[1]
 
 
 def fused_accumulate(params, grads):
@@ -231,6 +279,7 @@ class SNLinearFn(torch.autograd.Function):
     def forward(ctx, x, w, b, u, v, sig):
         ctx.save_for_backward(x, w, u, v, sig)
         ctx.w_param = w if (w.requires_grad and w.is_leaf) else None
+        ctx.accum_alt = _ALT['on']
         x2 = x.reshape(-1, x.shape[-1])
         ctx.hip = x.is_cuda and ops.linear_supported(x2.shape[0], x2.shape[1])
         if ctx.hip:
@@ -251,14 +300,14 @@ class SNLinearFn(torch.autograd.Function):
             if dx is not None:
                 dx = dx.reshape(x.shape)
             if graw is not None:
-                dw = ops.sn_grad_apply(graw, w.detach(), u, v, sig, accum=None if ctx.w_param is None else _accum_target(ctx.w_param))
+                dw = ops.sn_grad_apply(graw, w.detach(), u, v, sig, accum=None if ctx.w_param is None else _accum_target(ctx.w_param, ctx.accum_alt))
             return dx, dw, db, None, None, None
         if ctx.needs_input_grad[0]:
             dx = (g @ w) * alpha
         if ctx.needs_input_grad[1]:
             graw = (g2.t() @ x2).contiguous()
             if graw.is_cuda:
-                dw = ops.sn_grad_apply(graw, w.detach(), u, v, sig, accum=None if ctx.w_param is None else _accum_target(ctx.w_param))
+                dw = ops.sn_grad_apply(graw, w.detach(), u, v, sig, accum=None if ctx.w_param is None else _accum_target(ctx.w_param, ctx.accum_alt))
             else:
                 dot = (graw * w).sum()
                 dw = graw * alpha - (dot * alpha * alpha) * torch.outer(u, v)
@@ -282,6 +331,7 @@ class SNEmbeddingFn(torch.autograd.Function):
         ctx.save_for_backward(label, w, u, v, sig)
         ctx.holder = holder
         ctx.w_param = w if (w.requires_grad and w.is_leaf) else None
+        assert not _ALT['on'], 'the label embedding is differentiated by ONE pass (its 200 MB gradient has no second buffer)'
         return w.detach().index_select(0, label) * sig[1]
 
     @staticmethod
@@ -798,6 +848,7 @@ class ConvFn(torch.autograd.Function):
         ctx.wd = wd
         ctx.w_param = w if (sn is not None and w.requires_grad and w.is_leaf) else None
         ctx.b_param = bias if (bias is not None and bias.requires_grad and bias.is_leaf) else None
+        ctx.accum_alt = _ALT['on']
         ctx.cfg = (ksize, pro, prec, packs, bias is not None, res is not None, sn)
         return y
 
@@ -832,11 +883,11 @@ class ConvFn(torch.autograd.Function):
         want_db = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             kw = dict(ksize=ksize, sn=None if sn is None else (wd,) + tuple(sn),
-                      accum=None if ctx.w_param is None else _accum_target(ctx.w_param), bias_grad=want_db)
+                      accum=None if ctx.w_param is None else _accum_target(ctx.w_param, ctx.accum_alt), bias_grad=want_db)
             if x is not None:
                 dw = ops.thin_wgrad(x, dy, pro=pro, **kw)
             else:      # (fused accumulation: the reduce launch adds the bias gradient straight into the bias parameter's .grad)
-                dw = ops.conv_wgrad16(a16, dy16(), prec=prec, bias_accum=_accum_target(ctx.b_param) if (want_db and ctx.b_param is not None) else None,
+                dw = ops.conv_wgrad16(a16, dy16(), prec=prec, bias_accum=_accum_target(ctx.b_param, ctx.accum_alt) if (want_db and ctx.b_param is not None) else None,
                                       **kw)
             if want_db:
                 dw, db = dw
