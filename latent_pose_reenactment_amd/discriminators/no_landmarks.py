@@ -23,6 +23,8 @@ from latent_pose_reenactment_amd.utils import radam as _radam
 torch.optim.RAdam = _radam.RAdam      # the reference swaps in its own RAdam the same way (no_landmarks.py:5-6)
 import os as _os
 RGB_STRICT = _os.environ.get('LP_D_RGB_STRICT', '0') != '0'
+# conv -> ReLU -> conv chains: the first conv writes only the operand planes of relu(h) (round 4; 0: also the fp32 h nobody reads)
+PLANES_ONLY = _os.environ.get('LP_D_PLANES_ONLY', '1') != '0'
 
 
 class Wrapper:
@@ -77,7 +79,7 @@ class _DisBlock(nn.Module):
         c1, c2 = self.block._modules['2'], self.block._modules['5']
         # relu(x) is packed to operand planes ONCE for its two consumers; conv1's epilogue emits the planes of relu(h) for conv2
         xr16 = ops.act_pack(x_relu, pro=0, prec=default_prec())
-        h, h16 = _conv(x_relu, c1, track, states, ksize=3, x16=xr16, emit16=1)
+        h, h16 = _conv(x_relu, c1, track, states, ksize=3, x16=xr16, emit16=1, want_y=not PLANES_ONLY)      # (h itself is never read: conv2 takes the planes)
         shortcut = _conv(x_relu, self.skip._modules['0'], track, states, ksize=1, x16=xr16) if self.has_skip else x_relu
         out = _conv(h, c2, track, states, res=shortcut, ksize=3, pro=2, x16=h16)
         return AvgPool2Fn.apply(out, False) if self.downsample else out
@@ -184,7 +186,7 @@ class Discriminator(nn.Module):
             ws_, bs_, ss_ = _wb(sk, track_weights, states)
             shortcut = hip_conv(xn, ws_, bs_, sn=ss_, ksize=1, prec=first)
         else:
-            h, h16 = _conv(xn, d0, track_weights, states, ksize=3, emit16=1)
+            h, h16 = _conv(xn, d0, track_weights, states, ksize=3, emit16=1, want_y=not PLANES_ONLY)
             shortcut = _conv(xn, sk, track_weights, states, ksize=1)
         out = AvgPool2Fn.apply(_conv(h, d2, track_weights, states, res=shortcut, ksize=3, pro=2, x16=h16), False)
         feats = []

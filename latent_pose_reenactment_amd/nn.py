@@ -809,6 +809,9 @@ class ConvFn(torch.autograd.Function):
         operand planes of (relu?)(y) for the consumer conv; they are appended to ``holder``."""
         small_k = ksize == 3 and w.shape[1] <= 32
         wd = w.detach().contiguous()
+        # planes-only output (emit = (relu, holder, emit_prec | None, False)): nothing reads the fp32 y of a conv whose only consumer takes the
+        # emitted planes (conv -> ReLU -> conv chains of the critic) -- the autograd edge is carried by a zero-stride phantom of y's shape
+        want_y = not (emit is not None and len(emit) > 3 and emit[3] is False)
         if isinstance(packs, dict):          # per-step cache shared by several calls on the same W_orig (discriminator passes)
             key = (wd.data_ptr(), 0)
             if key not in packs:
@@ -824,7 +827,7 @@ class ConvFn(torch.autograd.Function):
         a16 = x16
         if a16 is None and pro == 0 and res is None and ops.thin_conv_supported(cin, cout, ksize, width):
             y = ops.thin_conv(x, pack, ksize=ksize, bias=bd, alpha=alpha, prec=prec, out16=None if emit is None else emit[0],
-                              out16_prec=None if emit is None or len(emit) < 3 else emit[2])
+                              out16_prec=None if emit is None or len(emit) < 3 else emit[2], want_y=want_y)
             if emit is not None:
                 y, o16 = y
                 emit[1].append(o16)
@@ -835,12 +838,15 @@ class ConvFn(torch.autograd.Function):
                 a16 = ops.act_pack(x, pro=pro, prec=prec)
                 if pro == 2:
                     tape_relu(lambda: a16.hi[..., :cin] > 0, True)
-            y = ops.conv16(a16, pack, ksize=ksize, bias=bd, res=res, alpha=alpha, prec=prec, out16=None if emit is None else emit[0])
+            y = ops.conv16(a16, pack, ksize=ksize, bias=bd, res=res, alpha=alpha, prec=prec, out16=None if emit is None else emit[0],
+                           want_y=want_y or cout % 8 != 0)
             if emit is not None:
                 y, o16 = y
                 emit[1].append(o16)
                 if emit[0]:
                     tape_relu(lambda: o16.hi[..., :cout] > 0, True)
+        if y is None:
+            y = torch.zeros(1, dtype=torch.float32, device=x.device).expand(x.shape[0], x.shape[1], x.shape[2], cout)
         if need_w and not thin_w and a16 is None:
             a16 = ops.act_pack(x, pro=pro, prec=prec)
         ctx.x = x if thin_w else None                               # fp32 input only where a thin-channel weight gradient needs it
@@ -898,16 +904,17 @@ class ConvFn(torch.autograd.Function):
         return dx, dw, db, dres, None, None, None, None, None, None, None
 
 
-def hip_conv(x, w, bias=None, res=None, ksize=3, pro=0, prec=None, packs=None, sn=None, x16=None, emit16=None, emit_prec=None):
+def hip_conv(x, w, bias=None, res=None, ksize=3, pro=0, prec=None, packs=None, sn=None, x16=None, emit16=None, emit_prec=None, want_y=True):
     """``x16``: existing operand planes of act(x); ``emit16`` = 0 | 1: also return the operand planes of y (1: of relu(y)), written
     by the conv's epilogue -> ``(y, Act16)``; ``emit_prec``: their operand mode when the consumer's differs from this conv's ``prec``
-    (thin-channel first layers only)."""
+    (thin-channel first layers only).  ``want_y=False`` (with ``emit16``): the returned y is a PHANTOM (shape and autograd edge only, no
+    storage) -- for convs whose fp32 output nobody reads."""
     prec = default_prec() if prec is None else prec
     _TAPE_GRAD[0] = torch.is_grad_enabled()
     if emit16 is None:
         return ConvFn.apply(x, w, bias, res, ksize, pro, prec, packs, sn, x16, None)
     holder = []
-    y = ConvFn.apply(x, w, bias, res, ksize, pro, prec, packs, sn, x16, (int(emit16), holder) + (() if emit_prec is None else (emit_prec,)))
+    y = ConvFn.apply(x, w, bias, res, ksize, pro, prec, packs, sn, x16, (int(emit16), holder) + ((() if emit_prec is None else (emit_prec,)) if want_y else (emit_prec, False)))
     return y, holder[0]
 
 
