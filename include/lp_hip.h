@@ -321,6 +321,8 @@ int lp_avgpool2_fwd(const float* x, float* y, int N, int H, int W, int C, int re
 int lp_avgpool2_fwd16(const uint16_t* x_hi, uint16_t* out_hi, int N, int H, int W, int C, int prec, void* stream);
 /* dx [N][H][W][C] = 0.25 * dy[.., y>>1, x>>1, ..] * (relu_in ? [x>0] : 1); H, W = full-resolution dims */
 int lp_avgpool2_bwd(const float* dy, const float* x, float* dx, int N, int H, int W, int C, int relu_in, float* amax_slots, void* stream);
+/* the same with the ReLU mask read from the operand planes mask_hi [N][H][W][C] of relu(x) (ABI 7: planes-only chains keep no fp32 x) */
+int lp_avgpool2_bwd_m16(const float* dy, const uint16_t* mask_hi, float* dx, int N, int H, int W, int C, float* amax_slots, void* stream);
 /* L1 taps: partial[lp_l1_partial_blocks()] block sums of |relu?(a) - relu?(b)| (F.l1_loss numerator; featmat.py:17, perceptual_loss.py:107);
  * backward: da = coef * grad_out[0] * sign(relu?(a) - relu?(b)) * (relu_in ? [a>0] : 1)  (+ add [numel]|NULL: the gradient that
  * reaches `a` from its other consumer -- the next conv / pool of the VGG stack -- summed here instead of by an autograd add) */
@@ -333,6 +335,9 @@ int lp_l1_fwd(const float* a, const float* b, float* partial, long long numel, i
 /* lp_l1_fwd with b given as 16-bit operand planes b_hi [numel] (prec bf16 | fp16; same element order as a) -- ABI 7 */
 int lp_l1_fwd_b16(const float* a, const uint16_t* b_hi, int prec, float* partial, long long numel, int relu_in, float coef, float* out,
                   int8_t* sign_out, void* stream);
+/* both operands as the 16-bit operand planes of relu(.) (ABI 7; relu_in semantics: the sign pattern carries the [a > 0] mask) */
+int lp_l1_fwd_ab16(const uint16_t* a_hi, const uint16_t* b_hi, int prec, float* partial, long long numel, float coef, float* out,
+                   int8_t* sign_out, void* stream);
 int lp_l1_bwd(const float* a, const float* b, const float* grad_out, float coef, const float* add, float* da, long long numel, int relu_in,
               const int8_t* sign, float* amax_slots, void* stream);
 

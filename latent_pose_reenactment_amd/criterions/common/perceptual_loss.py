@@ -22,6 +22,7 @@ CFG = {
     'vgg19': [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512, 512, 'M', 512, 512, 512, 512, 'M'],
     'vgg16': [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512, 'M'],
 }
+FAKE16 = os.environ.get('LP_VGG_FAKE16', '1') != '0'        # ... and the generated image's pass planes-only as well (autograd through phantoms)
 TAPS16 = os.environ.get('LP_VGG_TAPS16', '1') != '0'       # target-image taps as 16-bit planes in the fp16 mode (0: fp32 taps, the round-3 path)
 WEIGHT_FILES = {'caffe': ('vgg19', 'vgg19-d01eb7cb.pth'), 'face': ('vgg16', 'vgg_face_weights.pth')}
 
@@ -91,6 +92,9 @@ class PerceptualLoss(nn.Module):
         """``targets`` None: collect the taps (pre-ReLU conv outputs; the ReLU is fused into their consumers) into ``taps``.
         ``targets`` = taps of the other image: append the L1 term of every tap instead (the tap tensor flows on through
         L1TapFn so that its two gradients are summed inside the L1 backward kernel)."""
+        if (targets is not None and targets and isinstance(targets[0], ops.Tap16) and prec == lpnn.PREC_F16 and FAKE16 and lpnn.RELU_TAPE is None
+                and all(m.weight.shape[0] % 8 == 0 for m in self.model if isinstance(m, nn.Conv2d))):
+            return self._features_planes(x, packs, prec, taps, targets)
         cur, pending_relu, cur16 = to_nhwc(x), False, None
         n_layers = len(self.model)
         for i, layer in enumerate(self.model):
@@ -115,6 +119,28 @@ class PerceptualLoss(nn.Module):
                 cur = AvgPool2Fn.apply(cur, pending_relu, None if holder is None else (prec, holder))
                 cur16 = holder[0] if holder else None
                 pending_relu = False
+        return taps
+
+    def _features_planes(self, x, packs, prec, taps, targets):
+        """the generated image's pass WITH autograd and without fp32 activations (fp16 mode, 16-bit target taps): every conv writes only
+        the operand planes of relu(y), the L1 taps and the pools read planes, and phantom tensors (nn.phantom: shape + autograd edge, no
+        storage) connect the Functions; the gradients (fp32) are unchanged: sign pattern x scale from the L1 sites, the ReLU masks from
+        the planes."""
+        from latent_pose_reenactment_amd.nn import AvgPool2Fn16, hip_l1_tap16
+        cur, cur16, first = to_nhwc(x), None, True
+        for i, layer in enumerate(self.model):
+            if isinstance(layer, nn.Conv2d):
+                # (after a pool the planes hold the pooled tensor itself: no ReLU between pool and conv)
+                cur, cur16 = hip_conv(cur, layer.weight, layer.bias, ksize=3, pro=2 if (not first and relu_pending) else 0, prec=prec, packs=packs[i],
+                                      x16=cur16, emit16=1, want_y=False)
+                first, relu_pending = False, True
+            elif isinstance(layer, nn.ReLU):
+                cur, term = hip_l1_tap16(cur, ops.Tap16(cur16, prec), targets[len(taps)])
+                taps.append(term)
+            else:
+                holder = []
+                cur = AvgPool2Fn16.apply(cur, cur16, prec, holder)
+                cur16, relu_pending = holder[0], False
         return taps
 
     def _features16(self, x, packs, prec):

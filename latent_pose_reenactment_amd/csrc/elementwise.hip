@@ -642,6 +642,44 @@ __global__ void avgpool2_bwd_kernel(const float* __restrict__ dy, const float* _
     if (amax) lp_amax_commit(am, amax, blockIdx.x);
 }
 
+// dx = 0.25 * dy[.., y>>1, x>>1, ..] * [m16 > 0]: the ReLU mask read from the operand planes of relu(x) (no fp32 x exists in the planes-only chains)
+__global__ void avgpool2_bwd_m16_kernel(const float* __restrict__ dy, const uint16_t* __restrict__ m16, float* __restrict__ dx, long long total4,
+                                        int H, int W, int C, float* __restrict__ amax) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const int C4 = C >> 2, Ho = H >> 1, Wo = W >> 1;
+    float am = 0.f;
+    for (; i < total4; i += stride) {
+        int c = (int)(i % C4) * 4;
+        long long pix = i / C4;
+        int xx = (int)(pix % Wo); long long t = pix / Wo;
+        int yy = (int)(t % Ho); int n = (int)(t / Ho);
+        float4 g = ((const float4*)dy)[i];
+        g.x *= 0.25f; g.y *= 0.25f; g.z *= 0.25f; g.w *= 0.25f;
+        size_t base = (((size_t)n * H + 2 * yy) * W + 2 * xx) * C + c;
+        const size_t offs[4] = {0, (size_t)C, (size_t)W * C, (size_t)W * C + C};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const ushort4 mv = *(const ushort4*)(m16 + base + offs[k]);          // (v - 1) < 0x7fff: a positive, non-zero 16-bit float
+            float4 o;
+            o.x = (mv.x - 1u) < 0x7fffu ? g.x : 0.f; o.y = (mv.y - 1u) < 0x7fffu ? g.y : 0.f;
+            o.z = (mv.z - 1u) < 0x7fffu ? g.z : 0.f; o.w = (mv.w - 1u) < 0x7fffu ? g.w : 0.f;
+            *(float4*)(dx + base + offs[k]) = o;
+            am = lp_amax4(am, o);
+        }
+    }
+    if (amax) lp_amax_commit(am, amax, blockIdx.x);
+}
+
+extern "C" int lp_avgpool2_bwd_m16(const float* dy, const uint16_t* mask_hi, float* dx, int N, int H, int W, int C, float* amax_slots, void* stream) {
+    if (!dy || !dx || !mask_hi) return lp_set_error(LP_ERR_ARG, "lp_avgpool2_bwd_m16: null pointer");
+    if ((C & 3) || (H & 1) || (W & 1)) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_avgpool2_bwd_m16: C%4, H%2, W%2 must be 0");
+    long long total4 = (long long)N * (H / 2) * (W / 2) * C / 4;
+    int blocks = (int)((total4 + 255) / 256); if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(avgpool2_bwd_m16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, mask_hi, dx, total4, H, W, C, amax_slots);
+    return lp_check_launch("avgpool2_bwd_m16");
+}
+
 extern "C" int lp_avgpool2_fwd(const float* x, float* y, int N, int H, int W, int C, int relu_in, uint16_t* out_hi, int prec, void* stream) {
     if (out_hi && ((C & 7) || prec == LP_PREC_BF16X3)) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_avgpool2_fwd: planes need C % 8 == 0 and a one-plane precision mode");
     if (!x || !y) return lp_set_error(LP_ERR_ARG, "lp_avgpool2_fwd: null pointer");
@@ -667,15 +705,21 @@ extern "C" int lp_avgpool2_bwd(const float* dy, const float* x, float* dx, int N
 // sgn != NULL: also the backward's sign pattern, one int8 per element: sign(relu?(a) - relu?(b)) * (relu_in ? [a > 0] : 1) -- the backward
 // then reads 1 byte per element instead of a and b again (8 bytes).
 // BMODE 0: b fp32 | 1: b = fp16 operand planes | 2: bf16 operand planes (the taps of the target image kept 16-bit, round 4)
-template <int BMODE>
-__global__ __launch_bounds__(256) void l1_partial_kernel(const float4* __restrict__ a, const void* __restrict__ bv,
+// AMODE: the same for a (1 | 2: a = the operand planes of relu(a_true): the ReLU is already applied, [a_true > 0] == [plane > 0])
+template <int BMODE, int AMODE = 0>
+__global__ __launch_bounds__(256) void l1_partial_kernel(const void* __restrict__ av, const void* __restrict__ bv,
                                                          float* __restrict__ part, long long total4, int relu_in, char4* __restrict__ sgn) {
     __shared__ float sh[4];
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long stride = (long long)gridDim.x * blockDim.x;
     float s = 0.f;
     for (; i < total4; i += stride) {
-        float4 u = a[i], v;
+        float4 u, v;
+        if (AMODE == 0) u = ((const float4*)av)[i];
+        else {
+            const ushort4 q = ((const ushort4*)av)[i];
+            u = make_float4(lp_op16_to_f32<AMODE == 1>(q.x), lp_op16_to_f32<AMODE == 1>(q.y), lp_op16_to_f32<AMODE == 1>(q.z), lp_op16_to_f32<AMODE == 1>(q.w));
+        }
         if (BMODE == 0) v = ((const float4*)bv)[i];
         else {
             const ushort4 q = ((const ushort4*)bv)[i];
@@ -761,7 +805,7 @@ extern "C" int lp_l1_fwd(const float* a, const float* b, float* partial, long lo
                          int8_t* sign_out, void* stream) {
     if (!a || !b || !partial) return lp_set_error(LP_ERR_ARG, "lp_l1_fwd: null pointer");
     if (numel & 3) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_l1_fwd: numel must be a multiple of 4");
-    hipLaunchKernelGGL(l1_partial_kernel<0>, dim3(L1_BLOCKS), dim3(256), 0, (hipStream_t)stream, (const float4*)a, (const void*)b, partial,
+    hipLaunchKernelGGL(l1_partial_kernel<0>, dim3(L1_BLOCKS), dim3(256), 0, (hipStream_t)stream, (const void*)a, (const void*)b, partial,
                        numel / 4, relu_in, (char4*)sign_out);
     if (out) hipLaunchKernelGGL(l1_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, L1_BLOCKS, coef, out);
     return lp_check_launch("l1_fwd");
@@ -774,13 +818,29 @@ extern "C" int lp_l1_fwd_b16(const float* a, const uint16_t* b_hi, int prec, flo
     if (numel & 3) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_l1_fwd_b16: numel must be a multiple of 4");
     if (prec == LP_PREC_BF16X3) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_l1_fwd_b16: one-plane precision modes only");
     if (prec == LP_PREC_F16)
-        hipLaunchKernelGGL(l1_partial_kernel<1>, dim3(L1_BLOCKS), dim3(256), 0, (hipStream_t)stream, (const float4*)a, (const void*)b_hi, partial,
+        hipLaunchKernelGGL(l1_partial_kernel<1>, dim3(L1_BLOCKS), dim3(256), 0, (hipStream_t)stream, (const void*)a, (const void*)b_hi, partial,
                            numel / 4, relu_in, (char4*)sign_out);
     else
-        hipLaunchKernelGGL(l1_partial_kernel<2>, dim3(L1_BLOCKS), dim3(256), 0, (hipStream_t)stream, (const float4*)a, (const void*)b_hi, partial,
+        hipLaunchKernelGGL(l1_partial_kernel<2>, dim3(L1_BLOCKS), dim3(256), 0, (hipStream_t)stream, (const void*)a, (const void*)b_hi, partial,
                            numel / 4, relu_in, (char4*)sign_out);
     if (out) hipLaunchKernelGGL(l1_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, L1_BLOCKS, coef, out);
     return lp_check_launch("l1_fwd_b16");
+}
+
+// both operands as 16-bit operand planes of relu(.) (relu_in semantics: the sign pattern carries the [a > 0] mask)
+extern "C" int lp_l1_fwd_ab16(const uint16_t* a_hi, const uint16_t* b_hi, int prec, float* partial, long long numel, float coef, float* out,
+                              int8_t* sign_out, void* stream) {
+    if (!a_hi || !b_hi || !partial) return lp_set_error(LP_ERR_ARG, "lp_l1_fwd_ab16: null pointer");
+    if (numel & 3) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_l1_fwd_ab16: numel must be a multiple of 4");
+    if (prec == LP_PREC_BF16X3) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_l1_fwd_ab16: one-plane precision modes only");
+    if (prec == LP_PREC_F16)
+        hipLaunchKernelGGL((l1_partial_kernel<1, 1>), dim3(L1_BLOCKS), dim3(256), 0, (hipStream_t)stream, (const void*)a_hi, (const void*)b_hi, partial,
+                           numel / 4, 1, (char4*)sign_out);
+    else
+        hipLaunchKernelGGL((l1_partial_kernel<2, 2>), dim3(L1_BLOCKS), dim3(256), 0, (hipStream_t)stream, (const void*)a_hi, (const void*)b_hi, partial,
+                           numel / 4, 1, (char4*)sign_out);
+    if (out) hipLaunchKernelGGL(l1_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, L1_BLOCKS, coef, out);
+    return lp_check_launch("l1_fwd_ab16");
 }
 
 extern "C" int lp_l1_bwd(const float* a, const float* b, const float* grad_out, float coef, const float* add, float* da, long long numel,

@@ -754,6 +754,31 @@ def l1_sum(a: Tensor, b, relu_in: bool, coef: float = 1.0, want_sign: bool = Fal
     return (out.reshape(()), sgn) if want_sign else out.reshape(())
 
 
+def l1_sum16(a: 'Tap16', b: 'Tap16', coef: float = 1.0, want_sign: bool = False):
+    """coef * sum |a - b| for two taps held as the operand planes of relu(.) (same precision mode); ``want_sign`` as ``l1_sum`` with relu_in"""
+    assert a.prec == b.prec and tuple(a.act.hi.shape) == tuple(b.act.hi.shape) and a.act.lo is None and b.act.lo is None
+    dev = a.act.hi.device
+    buf = torch.empty(_lib.lib().lp_l1_partial_blocks() + 1, dtype=torch.float32, device=dev)
+    out = buf[-1:]
+    numel = a.act.hi.numel()
+    sgn = torch.empty(numel, dtype=torch.int8, device=dev) if want_sign else None
+    check(_lib.lib().lp_l1_fwd_ab16(a.act.hi.data_ptr(), b.act.hi.data_ptr(), a.prec, buf.data_ptr(), numel, float(coef), out.data_ptr(), _p(sgn),
+                                    _stream()), 'lp_l1_fwd_ab16')
+    return (out.reshape(()), sgn) if want_sign else out.reshape(())
+
+
+def avgpool2_bwd_m16(dy: Tensor, mask: Act16, amax: bool = False) -> Tensor:
+    """backward of AvgPool2d(2)(relu(x)) with the ReLU mask read from the operand planes of relu(x)"""
+    _chk(dy, 'dy')
+    n, h, w = mask.nhw
+    c = mask.c
+    assert mask.hi.shape[3] == c and tuple(dy.shape) == (n, h // 2, w // 2, c)
+    dx = torch.empty((n, h, w, c), dtype=torch.float32, device=dy.device)
+    check(_lib.lib().lp_avgpool2_bwd_m16(dy.data_ptr(), mask.hi.data_ptr(), dx.data_ptr(), n, h, w, c, _p(_amax_attach(dx, amax)), _stream()),
+          'lp_avgpool2_bwd_m16')
+    return dx
+
+
 def l1_bwd(a: Optional[Tensor], b: Optional[Tensor], grad_out: Tensor, coef: float, relu_in: bool, add: Optional[Tensor] = None,
            amax: bool = False, sign: Optional[Tensor] = None, shape=None) -> Tensor:
     """gradient of coef * sum|relu?(a) - relu?(b)| w.r.t. a, times grad_out; ``add`` (same shape) is summed in.  ``sign`` (from

@@ -846,7 +846,7 @@ class ConvFn(torch.autograd.Function):
                 if emit[0]:
                     tape_relu(lambda: o16.hi[..., :cout] > 0, True)
         if y is None:
-            y = torch.zeros(1, dtype=torch.float32, device=x.device).expand(x.shape[0], x.shape[1], x.shape[2], cout)
+            y = phantom((x.shape[0], x.shape[1], x.shape[2], cout), x.device)
         if need_w and not thin_w and a16 is None:
             a16 = ops.act_pack(x, pro=pro, prec=prec)
         ctx.x = x if thin_w else None                               # fp32 input only where a thin-channel weight gradient needs it
@@ -983,6 +983,54 @@ class L1TapFn(torch.autograd.Function):
         add = None if g_next is None else g_next.contiguous()
         return ops.l1_bwd(None, None, g_loss, 1.0 / ctx.sgn.numel(), False, add=add, sign=ctx.sgn, shape=ctx.shape,
                           amax=ctx.f16), None, None
+
+
+def phantom(shape, device):
+    """a tensor that carries a shape and an autograd edge but no storage (stride 0): planes-only chains hand it from Function to Function"""
+    return torch.zeros(1, dtype=torch.float32, device=device).expand(*shape)
+
+
+class L1Tap16Fn(torch.autograd.Function):
+    """``L1TapFn`` for a planes-only chain: the tap is the 16-bit operand planes of relu(y) (``a16``), ``a`` is the phantom that carries the
+    autograd edge of y.  Backward as L1TapFn (the sign pattern of the forward carries the ReLU mask)."""
+
+    @staticmethod
+    def forward(ctx, a, a16, b16):
+        if not ctx.needs_input_grad[0]:
+            return a.view_as(a), ops.l1_sum16(a16, b16, 1.0 / a16.act.hi.numel())
+        term, ctx.sgn = ops.l1_sum16(a16, b16, 1.0 / a16.act.hi.numel(), want_sign=True)
+        ctx.shape = tuple(a16.act.hi.shape)
+        ctx.f16 = a16.prec == PREC_F16
+        return a.view_as(a), term
+
+    @staticmethod
+    def backward(ctx, g_next, g_loss):
+        if g_loss is None:
+            return g_next, None, None
+        add = None if g_next is None else g_next.contiguous()
+        return ops.l1_bwd(None, None, g_loss, 1.0 / ctx.sgn.numel(), False, add=add, sign=ctx.sgn, shape=ctx.shape, amax=ctx.f16), None, None
+
+
+class AvgPool2Fn16(torch.autograd.Function):
+    """AvgPool2d(2) of relu(x) in a planes-only chain: x16 = operand planes of relu(x) -> the planes of the pooled tensor (appended to
+    ``holder``); x and the result are phantoms.  Backward: 0.25 * dy * [x16 > 0]."""
+
+    @staticmethod
+    def forward(ctx, x, x16, prec, holder):
+        o16 = ops.avgpool2_fwd16(x16, prec)
+        holder.append(o16)
+        ctx.x16 = x16
+        ctx.f16 = prec == PREC_F16
+        return phantom(o16.hi.shape, o16.hi.device)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.avgpool2_bwd_m16(dy.contiguous(), ctx.x16, amax=ctx.f16), None, None, None
+
+
+def hip_l1_tap16(a, a16, b16):
+    """planes-only form of ``hip_l1_tap``: -> (phantom passed through, l1 term)"""
+    return L1Tap16Fn.apply(a, a16, b16)
 
 
 def hip_l1_tap(a, b, relu_in=False):
