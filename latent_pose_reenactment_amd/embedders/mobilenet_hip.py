@@ -38,6 +38,8 @@ class MobileNetFeaturesFunction(torch.autograd.Function):
     def forward(ctx, net, x, *params):
         names = net._hip_feature_param_names
         par = dict(zip(names, params))
+        if ctx.needs_input_grad[1]:          #  the image gradient is not produced: say so instead of returning None silently
+            raise RuntimeError('the HIP encoder does not differentiate with respect to its input frames (detach them, or use the stock layers: LP_EMBEDDER_HIP=0)')
         need_grad = any(ctx.needs_input_grad[2:])
         feats = list(net.features)
         train = feats[0][1].training
@@ -112,6 +114,8 @@ class MobileNetFeaturesFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_pooled):
+        if getattr(ctx, 'stem', None) is None:
+            raise RuntimeError('backward through the HIP encoder a second time: its saved activations were released by the first pass (retain_graph is not supported)')
         net, par, packs, n = ctx.net, ctx.par, ctx.packs, ctx.n
         frozen = not ctx.train
         grads = {}

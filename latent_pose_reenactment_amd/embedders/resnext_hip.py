@@ -104,6 +104,8 @@ class ResNeXtFunction(torch.autograd.Function):
         prec = net.prec
         train = net.training
         need_grad = any(ctx.needs_input_grad[2:])
+        if ctx.needs_input_grad[1]:          #  the image gradient is not produced: say so instead of returning None silently
+            raise RuntimeError('the HIP encoder does not differentiate with respect to its input frames (detach them, or use the stock layers: LP_EMBEDDER_HIP=0)')
         par = dict(zip(net._hip_param_names, params))
         packs = net._hip_packs(par, need_grad)
         bn_eval = None if train else net._hip_eval_affines(par)
@@ -189,6 +191,8 @@ class ResNeXtFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_logits):
+        if ctx.blocks is None:
+            raise RuntimeError('backward through the HIP encoder a second time: its saved activations were released by the first pass (retain_graph is not supported)')
         net, par, packs, train = ctx.net, ctx.par, ctx.packs, ctx.train
         prec = net.prec
         frozen = not train
