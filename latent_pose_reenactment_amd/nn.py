@@ -987,7 +987,7 @@ class L1TapFn(torch.autograd.Function):
 
 def phantom(shape, device):
     """a tensor that carries a shape and an autograd edge but no storage (stride 0): planes-only chains hand it from Function to Function"""
-    return torch.zeros(1, dtype=torch.float32, device=device).expand(*shape)
+    return torch.empty(1, dtype=torch.float32, device=device).expand(*shape)          # (never read: no fill launch)
 
 
 class L1Tap16Fn(torch.autograd.Function):
