@@ -347,7 +347,10 @@ def run_epoch(dataloader, training_module, optimizer_G, optimizer_D, epoch, args
             optimizer_D.zero_grad()
     use_graph = phase == 'train' and getattr(args, 'hip_graph', False) and str(args.device).startswith('cuda')
     if phase == 'train' and str(args.device).startswith('cuda') and getattr(args, 'prefetch_to_device', True):
-        # pinned, double-buffered H2D on a side stream, one batch ahead of the computing step (dataloaders/prefetch.py)
+        # pinned, double-buffered H2D on a side stream, one batch ahead of the computing step (dataloaders/prefetch.py).  LIFETIME:
+        # the batches handed out are views of THREE rotating device slots -- a tensor of data_dict / target_dict (or of all_data, which
+        # aliases the inputs) that is kept for more than two further iterations (visualisation, saver hooks, debugging) is overwritten by a
+        # later copy: clone what must outlive the iteration, or pass --prefetch_to_device False.
         from latent_pose_reenactment_amd.dataloaders.prefetch import DevicePrefetcher
         dataloader = DevicePrefetcher(dataloader, args.device)
     log_every = max(1, int(getattr(args, 'log_frequency_loss', 1)))

@@ -202,3 +202,56 @@ def test_radam_state_loads_into_a_reference_style_radam():
     opt = RAdam([torch.nn.Parameter(torch.zeros(3))])
     opt.load_state_dict(sd)
     assert 'buffer' in opt.param_groups[0]
+
+
+def test_second_accumulation_buffers_fold_into_grad_once():
+    """nn.alt_accumulation (round 4): a backward pass that runs beside another one feeding the same parameters adds into per-parameter SECOND
+    buffers; leaving ``fused_grad_accumulation`` folds them into .grad exactly once and leaves them zero for the next step"""
+    import torch
+    from latent_pose_reenactment_amd import nn as lpnn
+    w = torch.nn.Parameter(torch.zeros(3, 4))
+    w.grad = torch.full((3, 4), 1.0)
+    assert lpnn._accum_target(w) is None                      # outside the context: plain autograd accumulation
+    with lpnn.fused_grad_accumulation():
+        direct = lpnn._accum_target(w)
+        assert direct is w.grad
+        alt = lpnn._accum_target(w, alt=True)
+        assert alt is not w.grad and float(alt.abs().sum()) == 0.0
+        direct += 2.0                                        # "real-image pass": straight into .grad
+        alt += 5.0                                           # "fake-image pass" on the other stream: second buffer
+        assert torch.equal(w.grad, torch.full((3, 4), 3.0))
+    assert torch.equal(w.grad, torch.full((3, 4), 8.0))     # folded in on exit
+    assert float(alt.abs().sum()) == 0.0 and not lpnn._ALT['dirty']
+    with lpnn.fused_grad_accumulation():
+        assert lpnn._accum_target(w, alt=True) is alt          # persistent buffer (static address: hipGraph friendly)
+    assert torch.equal(w.grad, torch.full((3, 4), 8.0))     # nothing added twice
+    # forward-time marker
+    assert lpnn._ALT['on'] is False
+    with lpnn.alt_accumulation():
+        assert lpnn._ALT['on'] is True
+    assert lpnn._ALT['on'] is False
+
+
+def test_resnext_operand_modes_per_block_and_per_contraction(monkeypatch):
+    """backbones.ResNeXt.block_precs / layer_precs: default assignment under the global fp16 mode = bf16x3 head + fp16 tail of 6 blocks; the
+    LP_E_HEAD_F16 experiment knob moves single KINDS of contractions of the head to fp16 (empty by default)"""
+    from embedders import backbones
+    from latent_pose_reenactment_amd.nn import PREC_NAMES
+    for k in ('LP_PREC', 'LP_PREC_E', 'LP_E_F16_TAIL', 'LP_E_HEAD_F16'):
+        monkeypatch.delenv(k, raising=False)
+    net = backbones.resnext50_32x4d(num_classes=8)
+    x3, f16 = PREC_NAMES['bf16x3'], PREC_NAMES['f16']
+    if net.prec != x3:
+        import pytest
+        pytest.skip('the process was started with another encoder mode')
+    bp = net.block_precs()
+    assert len(bp) == 16 and bp == [x3] * 10 + [f16] * 6
+    lp = net.layer_precs()
+    assert all(lp[(b[0], k)] == p for b, p in zip(net._hip_blocks, bp) for k in ('conv1', 'conv2', 'conv3'))
+    monkeypatch.setenv('LP_E_HEAD_F16', 'conv2')
+    lp = net.layer_precs()
+    first, last = net._hip_blocks[0][0], net._hip_blocks[-1][0]
+    assert lp[(first, 'conv1')] == x3 and lp[(first, 'conv2')] == f16 and lp[(first, 'conv3')] == x3
+    assert lp[(last, 'conv1')] == lp[(last, 'conv2')] == f16
+    monkeypatch.setenv('LP_E_F16_TAIL', '0')
+    assert net.block_precs() == [x3] * 16
