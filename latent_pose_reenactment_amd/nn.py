@@ -156,8 +156,11 @@ def _accum_target(w, alt=False):
     if not alt:
         return g
     ent = _ALT['bufs'].get(id(w))
-    if ent is None or ent[0] is not w or ent[1].shape != g.shape or ent[1].device != g.device:
-        ent = (w, torch.zeros_like(g))
+    if ent is None or ent[0]() is not w or ent[1].shape != g.shape or ent[1].device != g.device:
+        import weakref
+        for k in [k for k, e in _ALT['bufs'].items() if e[0]() is None]:       # (parameters that are gone: release their buffers)
+            del _ALT['bufs'][k]
+        ent = (weakref.ref(w), torch.zeros_like(g))
         _ALT['bufs'][id(w)] = ent
     _ALT['dirty'][id(w)] = (g, ent[1])
     return ent[1]
