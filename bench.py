@@ -31,6 +31,45 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0       # MI355X dense bf16 MFMA peak (MI355X_MICRO
 DIS_GFLOP, VGG19_GFLOP, VGGFACE_GFLOP, RESNEXT_GFLOP_PER_FRAME, MOBILENET_GFLOP_PER_FRAME = 30.97, 47.34, 40.09, 11.0, 0.8
 
 
+def source_stamp():
+    """what ties a measured file under profiles/ to the tree that produced it: sha256 over the kernel sources + C header (`csrc`) and over
+    the package's Python files (`py`), 16 hex digits each -- computable on the GPU box (which has no .git) and here; `head` = git HEAD when
+    a repository is present (build container), else None.  bench.py recomputes the stamp at run time and marks a profile file whose stamp
+    differs as STALE instead of printing its figures as fact."""
+    import hashlib
+    import subprocess
+
+    def digest(paths):
+        h = hashlib.sha256()
+        for p_ in sorted(paths):
+            h.update(os.path.relpath(p_, ROOT).encode())
+            h.update(hashlib.sha256(open(p_, 'rb').read()).digest())
+        return h.hexdigest()[:16]
+    pkg = os.path.join(ROOT, 'latent_pose_reenactment_amd')
+    csrc = [os.path.join(pkg, 'csrc', f) for f in os.listdir(os.path.join(pkg, 'csrc')) if f.endswith(('.hip', '.h'))]
+    csrc.append(os.path.join(ROOT, 'include', 'lp_hip.h'))
+    py = []
+    for d, dirs, files in os.walk(pkg):
+        dirs[:] = [x for x in dirs if x not in ('__pycache__', 'build', '.pytest_cache')]
+        py += [os.path.join(d, f) for f in files if f.endswith('.py')]
+    head = None
+    try:
+        r = subprocess.run(['git', '-C', ROOT, 'rev-parse', '--short=12', 'HEAD'], capture_output=True, text=True, timeout=10)
+        head = r.stdout.strip() or None if r.returncode == 0 else None
+    except Exception:
+        pass
+    return {'csrc': digest(csrc), 'py': digest(py), 'head': head}
+
+
+def stamp_status(stamp):
+    """-> (stale: bool, why) of a profile file's stamp against the running tree"""
+    if not isinstance(stamp, dict):
+        return True, 'no source stamp in the file'
+    now = source_stamp()
+    diff = [k for k in ('csrc', 'py') if stamp.get(k) != now[k]]
+    return bool(diff), ('' if not diff else 'source changed since the file was measured: ' + ', '.join(diff))
+
+
 def step_algorithmic_tflop(workload, batch, frames=8):
     """useful dense FLOPs of one training step as THIS path executes it (fwd = 1, data gradient = 1, weight gradient = 1 per layer):
     G fwd + both gradients; D: the fake pass of the G loss (fwd + dgrad, its weight gradients are never consumed), the detached fake and
@@ -117,11 +156,12 @@ def synthetic_batch(args, per_gpu_batch, seed):
 
 def _cpu_step_metatrain(args, sample_batch):
     """-> a callable running ONE meta-training step (configs/default.yaml) of `sample_batch` samples on the CPU: ResNeXt-50 over the
-    8 encoder frames + MobileNetV2 (the torchvision-compatible restatements of embedders/backbones.py, stock torch-CPU layers, train
-    mode) -> oracle generator -> oracle discriminator x3 with the 98000 x 512 label embedding -> VGGFace / VGG19 / adversarial /
+    8 encoder frames + MobileNetV2 (the torchvision-compatible containers of embedders/backbones.py evaluated by oracle/backbones_ref.py:
+    stock torch-CPU layers, train mode) -> oracle generator -> oracle discriminator x3 with the 98000 x 512 label embedding -> VGGFace / VGG19 / adversarial /
     featmat / dis_embed / dice -> loss_G.backward -> Adam(G + E) -> loss_D.backward -> Adam(D) -> EMA(G + E)."""
     import copy
     from oracle import lp_oracle as O
+    from oracle import backbones_ref as BR
     from generators.vector_pose_unsupervised_segmentation_noBottleneck import Wrapper as GW
     from discriminators.no_landmarks import Wrapper as DW
     from embedders.backbones import mobilenet_v2, resnext50_32x4d
@@ -159,9 +199,9 @@ def _cpu_step_metatrain(args, sample_batch):
     def one():
         step_no[0] += 1
         b, k = enc.shape[:2]
-        per_frame = idt_net(enc.reshape(b * k, *enc.shape[2:])).view(b, k, -1)
+        per_frame = BR.resnext_forward(idt_net, enc.reshape(b * k, *enc.shape[2:])).view(b, k, -1)
         embeds = per_frame.mean(1)
-        pose = pose_net(pose_in)
+        pose = BR.mobilenet_forward(pose_net, pose_in)
         rgb, segm = O.generator_forward(sdG, embeds, pose, num_channels=64, max_num_channels=512, image_size=a.image_size, train=True)
         out = O.discriminator_forward(sdD, rgb, tgt, label, image_size=a.image_size, dis_num_blocks=7, train=True, embed_eps=O.SN_EPS_CONV)
         lg, ld = O.adversarial_gan(out['fake_score_G'], out['fake_score_D'], out['real_score'])
@@ -195,6 +235,7 @@ def _cpu_step(args, sample_batch):
     loss_D.backward -> RAdam(D) -> EMA(G)."""
     import copy
     from oracle import lp_oracle as O
+    from oracle import backbones_ref as BR
     from generators.vector_pose_unsupervised_segmentation_noBottleneck import Wrapper as GW
     from discriminators.no_landmarks import Wrapper as DW
     from embedders.backbones import mobilenet_v2
@@ -229,7 +270,7 @@ def _cpu_step(args, sample_batch):
     def one():
         step_no[0] += 1
         with torch.no_grad():
-            pose = pose_net(pose_in)
+            pose = BR.mobilenet_forward(pose_net, pose_in)
         rgb, segm = O.generator_forward(sdG, sdG['identity_embedding'], pose, num_channels=64, max_num_channels=512,
                                         image_size=a.image_size, train=True)
         out = O.discriminator_forward(sdD, rgb, tgt, label, image_size=a.image_size, dis_num_blocks=7, train=True,
@@ -516,7 +557,6 @@ def main():
     a = ap.parse_args()
     if a.cpu_worker:
         return cpu_worker(a.cpu_worker)
-    os.environ.setdefault('LP_STRICT_HIP', '1')      # a geometry outside the hand-written encoders raises instead of quietly timing MIOpen
     if a.cpu_baseline_only:
         wl = a.workload or 'metatrain_step'
         print(json.dumps(cpu_baseline(make_args(a.image_size, a.batch, 'cpu', 1, 0, a.prec, finetune=wl != 'metatrain_step'), full=a.cpu_baseline_full, workload=wl)))

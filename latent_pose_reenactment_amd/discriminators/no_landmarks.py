@@ -22,9 +22,22 @@ from latent_pose_reenactment_amd.utils import radam as _radam
 
 torch.optim.RAdam = _radam.RAdam      # the reference swaps in its own RAdam the same way (no_landmarks.py:5-6)
 import os as _os
-RGB_STRICT = _os.environ.get('LP_D_RGB_STRICT', '0') != '0'
 # conv -> ReLU -> conv chains: the first conv writes only the operand planes of relu(h) (round 4; 0: also the fp32 h nobody reads)
 PLANES_ONLY = _os.environ.get('LP_D_PLANES_ONLY', '1') != '0'
+
+
+def gpass_prec():
+    """operand mode of the fake -> G pass (the pass whose score IS a loss scalar: adversarial_G = -mean(fake_score_G),
+    criterions/adversarial.py:34-57 of the reference).  The projection score <pooled, embed> + linear(pooled) is the dot product of a
+    512-vector with an unrelated direction, ~sqrt(512) smaller than the norms it is made of, so the feature error of an fp16 critic
+    (3e-4) shows up ~15x larger relative to the score (5e-3 measured at the full configs[2] geometry, round 4) -- outside north_star's
+    1e-3 on every loss scalar.  Under the global fp16 mode this pass therefore runs its blocks from ``LP_D_GPASS_FROM`` on (default 0: all
+    of it; its weights are constants for autograd, so that is forward + data gradient only) with bf16x3 operands.  LP_D_GPASS_PREC=f16
+    restores round 4's all-fp16 pass.  -> (mode, first strict unit: 0 = stem, 1.. = blocks)"""
+    name = _os.environ.get('LP_D_GPASS_PREC', 'bf16x3')
+    if default_prec() != lpnn.PREC_F16 or name == 'f16':
+        return default_prec(), 0
+    return lpnn.PREC_NAMES[name], int(_os.environ.get('LP_D_GPASS_FROM', '0'))
 
 
 class Wrapper:
@@ -53,11 +66,12 @@ def _wb(layer, track, states):
     return w, b, states[id(layer)]
 
 
-def _conv(x, layer, track, states, **kw):
-    """SN conv through the HIP kernels; the bf16 packs of W_orig are shared by the three passes of a step and their backward
-    passes (only 1/sigma differs between passes) through the per-step cache ``states['packs']``"""
+def _conv(x, layer, track, states, prec=None, **kw):
+    """SN conv through the HIP kernels; the 16-bit packs of W_orig are shared by the three passes of a step and their backward
+    passes (only 1/sigma differs between passes) through the per-step cache ``states['packs']`` (one dict per operand mode)"""
     w, b, st = _wb(layer, track, states)
-    return hip_conv(x, w, b, sn=st, packs=states['packs'], **kw)
+    prec = default_prec() if prec is None else prec
+    return hip_conv(x, w, b, sn=st, packs=states['packs'].setdefault(prec, {}), prec=prec, **kw)
 
 
 class _DisBlock(nn.Module):
@@ -74,14 +88,15 @@ class _DisBlock(nn.Module):
     def sn_layers(self):
         return [self.block._modules['2'], self.block._modules['5']] + ([self.skip._modules['0']] if self.has_skip else [])
 
-    def forward(self, x_relu, track, states):
+    def forward(self, x_relu, track, states, prec=None):
         """x_relu: NHWC relu(x) (the reference's in-place ReLU makes every consumer of the block input see relu(x))"""
         c1, c2 = self.block._modules['2'], self.block._modules['5']
+        prec = default_prec() if prec is None else prec
         # relu(x) is packed to operand planes ONCE for its two consumers; conv1's epilogue emits the planes of relu(h) for conv2
-        xr16 = ops.act_pack(x_relu, pro=0, prec=default_prec())
-        h, h16 = _conv(x_relu, c1, track, states, ksize=3, x16=xr16, emit16=1, want_y=not PLANES_ONLY)      # (h itself is never read: conv2 takes the planes)
-        shortcut = _conv(x_relu, self.skip._modules['0'], track, states, ksize=1, x16=xr16) if self.has_skip else x_relu
-        out = _conv(h, c2, track, states, res=shortcut, ksize=3, pro=2, x16=h16)
+        xr16 = ops.act_pack(x_relu, pro=0, prec=prec)
+        h, h16 = _conv(x_relu, c1, track, states, prec, ksize=3, x16=xr16, emit16=1, want_y=not PLANES_ONLY)      # (h itself is never read: conv2 takes the planes)
+        shortcut = _conv(x_relu, self.skip._modules['0'], track, states, prec, ksize=1, x16=xr16) if self.has_skip else x_relu
+        out = _conv(h, c2, track, states, prec, res=shortcut, ksize=3, pro=2, x16=h16)
         return AvgPool2Fn.apply(out, False) if self.downsample else out
 
 
@@ -116,25 +131,35 @@ class Discriminator(nn.Module):
         self.finetuning = False
 
     def _fresh_packs(self):
-        """bf16 packs (forward + dgrad) of every conv of the critic for this step's three passes, produced by one batched launch;
-        keyed like ConvFn's per-step cache: (W_orig.data_ptr(), mode)"""
-        convs = [m for m in self.modules() if hasattr(m, 'weight_orig') and m.weight_orig.dim() == 4]
-        if not convs or not convs[0].weight_orig.is_cuda:
+        """16-bit packs (forward + dgrad) of every conv of the critic for this step's three passes, one batched launch per operand mode in
+        use (the default mode; the fake -> G pass's strict mode for the layers it covers: ``gpass_prec``) -> {mode: {(W_orig.data_ptr(),
+        orientation): pack}}, the inner dicts keyed like ConvFn's per-step cache"""
+        d0, d2, sk = self.down_block._modules['0'], self.down_block._modules['2'], self.skip._modules['0']
+        units = [[d0, d2, sk]] + [blk.sn_layers() for blk in self.blocks]          # unit 0 = stem, 1.. = blocks (gpass_prec's numbering)
+        if not d0.weight_orig.is_cuda:
             return {}
-        prec = default_prec()
-        specs = []
-        for m in convs:
-            w = m.weight_orig
-            ks = w.shape[-1]
-            specs.append((w, 0, ks == 3 and w.shape[1] <= 32))
-            specs.append((w, 1, ks == 3 and w.shape[0] <= 32))
-        key = tuple((w.data_ptr(), mode, bool(k_)) for w, mode, k_ in specs)
-        pb = self.__dict__.get('_pack_batch')
-        if pb is None or pb.prec != prec or pb.key != key:
-            pb = ops.PackBatch([(w.detach(), mode, k_) for w, mode, k_ in specs], prec)
-            self.__dict__['_pack_batch'] = pb
-        packs = pb.update()
-        return {(w.data_ptr(), mode): p for (w, mode, _), p in zip(specs, packs)}
+        gprec, gfrom = gpass_prec()
+        training = self.training and torch.is_grad_enabled()
+        out = {}
+        for prec, convs in ((default_prec(), [m for u in units for m in u]),
+                            (gprec, [m for u in units[gfrom:] for m in u] if (gprec != default_prec() and training) else [])):
+            if not convs:
+                continue
+            specs = []
+            for m in convs:
+                w = m.weight_orig
+                ks = w.shape[-1]
+                specs.append((w, 0, ks == 3 and w.shape[1] <= 32))
+                specs.append((w, 1, ks == 3 and w.shape[0] <= 32))
+            key = tuple((w.data_ptr(), mode, bool(k_)) for w, mode, k_ in specs)
+            pbs = self.__dict__.setdefault('_pack_batches', {})
+            pb = pbs.get(prec)
+            if pb is None or pb.prec != prec or pb.key != key:
+                pb = ops.PackBatch([(w.detach(), mode, k_) for w, mode, k_ in specs], prec)
+                pbs[prec] = pb
+            packs = pb.update()
+            out[prec] = {(w.data_ptr(), mode): p for (w, mode, _), p in zip(specs, packs)}
+        return out
 
     def _conv_sn_layers(self):
         layers = self.__dict__.get('_sn_layer_cache')
@@ -162,9 +187,10 @@ class Discriminator(nn.Module):
         self.__dict__['_prepared'] = (self._fresh_packs(), self._embed_batch().update(True)[0])
         self.__dict__['_prepared_passes'] = [self._sn_batch.update(True) for _ in range(3)]
 
-    def pass_inputs(self, x, embed=None, track_weights=True, sn_states=None):
+    def pass_inputs(self, x, embed=None, track_weights=True, sn_states=None, strict=None):
         """``track_weights=False``: the discriminator's own parameters are constants for autograd in this pass (gradients
-        still flow to ``x`` and ``embed``)."""
+        still flow to ``x`` and ``embed``).  ``strict`` = (operand mode, first unit) from ``gpass_prec``: the stem (unit 0) / blocks
+        (1..) from that unit on run in that operand mode instead of the default one (the fake -> G pass)."""
         if not x.is_cuda:
             raise RuntimeError('the discriminator runs on the MI355X HIP path only (no CPU fallback)')
         d0, d2, sk = self.down_block._modules['0'], self.down_block._modules['2'], self.skip._modules['0']
@@ -176,25 +202,18 @@ class Discriminator(nn.Module):
         states = {id(l): s for l, s in zip(layers, st)}
         states['packs'] = self.__dict__.setdefault('_step_packs', {})
         xn = to_nhwc(x)
-        # LP_D_RGB_STRICT=1 (off; measured null, round 4): the two layers that read the IMAGE (3 -> 64) in the strict mode under a global fp16
-        # mode -- tested as the source of the 5e-3 error of the projection score at the full configs[2] geometry; the score did not move
-        # (it is the conditioning of the projection itself: tests/test_metatrain_full_gpu.py)
-        first = lpnn.PREC_BF16X3 if (RGB_STRICT and default_prec() != lpnn.PREC_BF16X3) else None
-        if first is not None:
-            w0, b0, s0 = _wb(d0, track_weights, states)
-            h, h16 = hip_conv(xn, w0, b0, sn=s0, ksize=3, prec=first, emit16=1, emit_prec=default_prec())
-            ws_, bs_, ss_ = _wb(sk, track_weights, states)
-            shortcut = hip_conv(xn, ws_, bs_, sn=ss_, ksize=1, prec=first)
-        else:
-            h, h16 = _conv(xn, d0, track_weights, states, ksize=3, emit16=1, want_y=not PLANES_ONLY)
-            shortcut = _conv(xn, sk, track_weights, states, ksize=1)
-        out = AvgPool2Fn.apply(_conv(h, d2, track_weights, states, res=shortcut, ksize=3, pro=2, x16=h16), False)
+        sprec, sfrom = strict if strict is not None else (None, 0)
+        unit_prec = lambda u: sprec if (sprec is not None and u >= sfrom) else None          # None = the default mode
+        p0 = unit_prec(0)
+        h, h16 = _conv(xn, d0, track_weights, states, p0, ksize=3, emit16=1, want_y=not PLANES_ONLY)
+        shortcut = _conv(xn, sk, track_weights, states, p0, ksize=1)
+        out = AvgPool2Fn.apply(_conv(h, d2, track_weights, states, p0, res=shortcut, ksize=3, pro=2, x16=h16), False)
         feats = []
-        for block in self.blocks:
+        for bi, block in enumerate(self.blocks):
             out_relu = torch.relu(out)           # what the reference's in-place ReLU leaves behind in its feature list
             lpnn.tape_relu(lambda: out_relu > 0)
             feats.append(as_nchw_view(out_relu))
-            out = block(out_relu, track_weights, states)
+            out = block(out_relu, track_weights, states, unit_prec(bi + 1))
         feats.append(as_nchw_view(out))
         lpnn.tape_relu(lambda: out > 0)
         pooled = torch.relu(out).sum(dim=(1, 2))
@@ -263,6 +282,7 @@ class Discriminator(nn.Module):
         # by optimizer_D.zero_grad() before loss_D.backward (runners/holycow.py:246-248) and no optimizer reads them, so they
         # are not computed unless ``keep_reference_waste`` asks for the reference's exact .grad side effects (parity tests).
         track1 = bool(getattr(self, 'keep_reference_waste', False))
+        gstrict = gpass_prec() if (self.training and torch.is_grad_enabled() and gpass_prec()[0] != default_prec()) else None
         from latent_pose_reenactment_amd import streams
         if self.training and torch.is_grad_enabled() and streams.enabled(fake, 'dpasses', finetuning=self.finetuning):
             # the three passes are independent given the images and the label embedding: the two discriminator-side passes run on side
@@ -273,7 +293,7 @@ class Discriminator(nn.Module):
             sts = ahead if ahead else [self._sn_batch.update(True) for _ in range(3)]
             # (issued in the reference's order -- the debug tape of the parity tests records ReLU sites in issue order -- from one fork point)
             here = streams.fork_point(fake.device)
-            fake_score_G, fake_features = self.pass_inputs(fake, embed if track1 else embed.detach(), track_weights=track1, sn_states=sts[0])
+            fake_score_G, fake_features = self.pass_inputs(fake, embed if track1 else embed.detach(), track_weights=track1, sn_states=sts[0], strict=gstrict)
             # (this pass and the real-image pass deposit gradients on the same parameters from two streams: this one accumulates into the
             #  parameters' SECOND buffers -- nn.alt_accumulation)
             with streams.branch(fake.device, 6, after=here) as b2, lpnn.alt_accumulation():
@@ -286,7 +306,7 @@ class Discriminator(nn.Module):
             b2.join(fake_score_D)
             b3.join((real_score, real_features))
         else:
-            fake_score_G, fake_features = self.pass_inputs(fake, embed if track1 else embed.detach(), track_weights=track1)
+            fake_score_G, fake_features = self.pass_inputs(fake, embed if track1 else embed.detach(), track_weights=track1, strict=gstrict)
             fake_score_D, _ = self.pass_inputs(fake.detach(), embed.detach())
             real_score, real_features = self.pass_inputs(real, embed)
         data_dict.update(fake_features=fake_features, real_features=real_features, real_embedding=embed,

@@ -1,61 +1,37 @@
-"""ResNeXt-50 32x4d and MobileNetV2 with torchvision-0.6-compatible ``state_dict`` keys.
+"""ResNeXt-50 32x4d and MobileNetV2 with torchvision-0.6-compatible ``state_dict`` keys, evaluated on the hand-written gfx950 kernels.
 
 The reference instantiates both from torchvision (embedders/unsupervised_pose_separate_embResNeXt_segmentation.py:26-28),
-which is an un-vendored dependency and absent from this image; these are restatements of the public architectures
-(He et al. / Xie et al. ResNeXt; Sandler et al. MobileNetV2) so that reference checkpoints load by key.
-
-MobileNetV2 (the pose encoder) has a hand-written HIP forward (fp32) for the calls made with autograd off -- the fine-tuning train
-step (the embedder is frozen and called under ``no_grad``, runners/holycow.py:178-182 of the reference) and ``drive.py``: stem,
-depthwise and 1x1 convs, BatchNorm in either mode (batch statistics + running-stat update folded into the conv launches, or running
-statistics), ReLU6, residual adds, pooling and the classifier on the kernels of csrc/mobilenet.hip; parity:
-tests/test_mobilenet_hip.py.  LP_EMBEDDER_HIP=0 selects the stock PyTorch-ROCm layers instead.  With autograd on (meta-training
-trains the embedder) and for the ResNeXt-50 identity encoder the layers are stock PyTorch-ROCm ops (last row of the hot-path plan)."""
+which is an un-vendored dependency and absent from this image; the module trees below restate the public architectures
+(He et al. / Xie et al. ResNeXt; Sandler et al. MobileNetV2) as PARAMETER CONTAINERS so that reference checkpoints load by key.
+They hold no arithmetic of their own:
+  * ``ResNeXt.forward``      -> embedders/resnext_hip.py (``ResNeXtFunction``: forward + backward on the kernels of csrc/resnext.hip,
+                                conv_dma.hip, conv_wgrad.hip), with or without autograd, train- or eval-mode BatchNorm;
+  * ``MobileNetV2.forward``  -> with autograd: embedders/mobilenet_hip.py (meta-training trains the pose encoder); without: the fused fp32
+                                forward ``_forward_hip`` below (fine-tuning step: the embedder is frozen and called under ``no_grad``,
+                                runners/holycow.py:178-182 of the reference; drive.py);
+  * a geometry the kernels do not cover, or a CPU tensor, RAISES -- there is one backend.  The stock-layer evaluation of these containers
+    (the oracle of SURVEY rows E1 / E2, and what tests use for toy geometries) lives in ``oracle/backbones_ref.py``, outside the product."""
 import os
 
 import torch
 import torch.nn.functional as F
 from torch import nn
 
-_PENDING_COUNTERS = []
 E_HEAD_F16_DEFAULT = ''     # layer kinds of the bf16x3 head that run with fp16 operands (ResNeXt.layer_precs)
 E_F16_TAIL_DEFAULT = 6      # trailing ResNeXt bottlenecks that run with fp16 operands under the default modes (ResNeXt.block_precs)
-_HIP_FORWARD = [os.environ.get('LP_EMBEDDER_HIP', '1') != '0']       # set_hip_forward() / LP_EMBEDDER_HIP=0
 
 
-def _stock_fallback(module, name, rule, x):
-    """a geometry the hand-written encoder does not cover: the stock PyTorch-ROCm layers (MIOpen / rocBLAS) run instead -- with a warning
-    (once per module), or NOT AT ALL under LP_STRICT_HIP=1 (benchmarks: a run must never quietly time the library path)"""
-    if os.environ.get('LP_STRICT_HIP', '0') != '0':
-        raise RuntimeError(f'{name}: input {tuple(x.shape)} is outside the HIP path\'s geometry ({rule}) and LP_STRICT_HIP=1 forbids the '
-                           'stock-layer fallback')
-    if not module.__dict__.get('_warned_stock'):
-        module.__dict__['_warned_stock'] = True
-        import logging
-        logging.getLogger('embedder').warning('%s: input %s is outside the HIP path\'s geometry (see %s); running the stock PyTorch-ROCm layers',
-                                              name, tuple(x.shape), rule)
-
-
-def set_hip_forward(on: bool):
-    """route MobileNetV2's no-grad forward through the HIP kernels (default on; LP_EMBEDDER_HIP=0 in the environment turns it off)"""
-    _HIP_FORWARD[0] = bool(on)
+def _unsupported(name, rule, x):
+    return RuntimeError(f'{name}: input {tuple(x.shape)} on {x.device} is outside the HIP path ({rule}); there is no other backend '
+                        '(tests evaluate such geometries through oracle/backbones_ref.py)')
 
 
 class _BatchNorm2d(nn.BatchNorm2d):
-    """nn.BatchNorm2d (same parameters, buffers and state_dict keys) whose ``num_batches_tracked += 1`` -- one tiny launch per
-    layer per forward in train mode (52 per MobileNetV2 pass) -- is deferred and issued as ONE multi-tensor add by the backbone
-    at the end of its forward (momentum is a constant here, so the counter does not enter the statistics update)."""
+    """nn.BatchNorm2d as a container (same parameters, buffers and state_dict keys): the statistics, the normalisation and the running-
+    statistics update happen inside the HIP encoders; ``num_batches_tracked`` of all layers advances by ONE multi-tensor add per forward."""
 
     def forward(self, x):
-        if self.training and self.track_running_stats:
-            _PENDING_COUNTERS.append(self.num_batches_tracked)
-            return F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, True, self.momentum, self.eps)
-        return F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, not self.track_running_stats, 0.0, self.eps)
-
-
-def _flush_bn_counters():
-    if _PENDING_COUNTERS:
-        torch._foreach_add_(_PENDING_COUNTERS, 1)
-        _PENDING_COUNTERS.clear()
+        raise RuntimeError('backbones._BatchNorm2d holds parameters and buffers only: the encoders evaluate it inside their HIP functions')
 
 
 # ---------------------------------------------------------------- ResNeXt
@@ -75,11 +51,7 @@ class _Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        idt = x if self.downsample is None else self.downsample(x)
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.relu(self.bn2(self.conv2(out)))
-        out = self.bn3(self.conv3(out))
-        return self.relu(out + idt)
+        raise RuntimeError('backbones._Bottleneck is a parameter container: ResNeXt.forward evaluates the whole network (embedders/resnext_hip.py)')
 
 
 class ResNeXt(nn.Module):
@@ -110,16 +82,10 @@ class ResNeXt(nn.Module):
         return nn.Sequential(*seq)
 
     def forward(self, x):
-        if _HIP_FORWARD[0] and x.is_cuda and x.dim() == 4 and x.shape[1] == 3:
-            from . import resnext_hip
-            if resnext_hip.supported(x.shape[0], x.shape[2], x.shape[3]):
-                return self._forward_hip(x)
-        if _HIP_FORWARD[0] and x.is_cuda:
-            _stock_fallback(self, 'ResNeXt', 'resnext_hip.supported', x)
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
-        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
-        _flush_bn_counters()
-        return self.fc(torch.flatten(self.avgpool(x), 1))
+        from . import resnext_hip
+        if not (x.is_cuda and x.dim() == 4 and x.shape[1] == 3 and resnext_hip.supported(x.shape[0], x.shape[2], x.shape[3])):
+            raise _unsupported('ResNeXt', 'resnext_hip.supported: N x 3 x H x W on the GPU, 32 | H, W >= 128, N >= 8, 4 | N', x)
+        return self._forward_hip(x)
 
     # ---- HIP path (forward and backward): embedders/resnext_hip.py -----------------------------------------------------------------
     @property
@@ -264,7 +230,7 @@ class _InvertedResidual(nn.Module):
         self.conv = nn.Sequential(*layers)
 
     def forward(self, x):
-        return x + self.conv(x) if self.use_res else self.conv(x)
+        raise RuntimeError('backbones._InvertedResidual is a parameter container: MobileNetV2.forward evaluates the whole network')
 
 
 class MobileNetV2(nn.Module):
@@ -289,17 +255,16 @@ class MobileNetV2(nn.Module):
                 nn.init.zeros_(m.bias)
 
     def forward(self, x):
-        hip = _HIP_FORWARD[0] and x.is_cuda and x.dim() == 4 and x.shape[1] == 3
-        if hip and not torch.is_grad_enabled() and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and x.shape[0] <= 64:
+        if not (x.is_cuda and x.dim() == 4 and x.shape[1] == 3):
+            raise _unsupported('MobileNetV2', 'N x 3 x H x W on the GPU', x)
+        if not torch.is_grad_enabled():
+            if x.shape[2] % 2 or x.shape[3] % 2 or x.shape[0] > 64:
+                raise _unsupported('MobileNetV2 (no-grad forward)', 'even H, W and N <= 64', x)
             return self._forward_hip(x)                      # fused fp32 forward (fine-tuning step, drive.py)
-        if hip and torch.is_grad_enabled():
-            from . import mobilenet_hip
-            if mobilenet_hip.supported(x.shape[0], x.shape[2], x.shape[3]):
-                return self._forward_hip_train(x)            # autograd on (meta-training): forward + backward on the HIP kernels
-            _stock_fallback(self, 'MobileNetV2', 'mobilenet_hip.supported', x)
-        x = self.features(x)
-        _flush_bn_counters()
-        return self.classifier(x.mean([2, 3]))
+        from . import mobilenet_hip
+        if not mobilenet_hip.supported(x.shape[0], x.shape[2], x.shape[3]):
+            raise _unsupported('MobileNetV2 (autograd on)', 'mobilenet_hip.supported: 32 | H, W; N * H/32 * W/32 >= 8 and a multiple of 4', x)
+        return self._forward_hip_train(x)                    # autograd on (meta-training): forward + backward on the HIP kernels
 
     # ---- HIP training path (forward + backward): embedders/mobilenet_hip.py --------------------------------------------------------
     def _hip_train_structure(self):

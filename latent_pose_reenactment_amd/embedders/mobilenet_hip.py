@@ -39,7 +39,7 @@ class MobileNetFeaturesFunction(torch.autograd.Function):
         names = net._hip_feature_param_names
         par = dict(zip(names, params))
         if ctx.needs_input_grad[1]:          #  the image gradient is not produced: say so instead of returning None silently
-            raise RuntimeError('the HIP encoder does not differentiate with respect to its input frames (detach them, or use the stock layers: LP_EMBEDDER_HIP=0)')
+            raise RuntimeError('the HIP encoder does not differentiate with respect to its input frames (detach them)')
         need_grad = any(ctx.needs_input_grad[2:])
         feats = list(net.features)
         train = feats[0][1].training

@@ -39,7 +39,7 @@ class _BN:
 def supported(n: int, h: int, w: int) -> bool:
     """geometry the kernels cover: the last stage's grouped 3x3 convs (maps of H/32 x W/32) need >= 4 wide maps (weight-gradient tiles
     are >= 4 pixels wide), the classifier contraction N % 4 == 0 and N >= 8.  The 256 x 256 x (B x 8 frames) workload and the 128 x 128
-    test size qualify; smaller toy sizes run the stock layers (backbones.ResNeXt.forward)."""
+    test size qualify; anything else raises (backbones.ResNeXt.forward: one backend)."""
     return h % 32 == 0 and w % 32 == 0 and h >= 128 and w >= 128 and n % 4 == 0 and n >= 8
 
 
@@ -105,7 +105,7 @@ class ResNeXtFunction(torch.autograd.Function):
         train = net.training
         need_grad = any(ctx.needs_input_grad[2:])
         if ctx.needs_input_grad[1]:          #  the image gradient is not produced: say so instead of returning None silently
-            raise RuntimeError('the HIP encoder does not differentiate with respect to its input frames (detach them, or use the stock layers: LP_EMBEDDER_HIP=0)')
+            raise RuntimeError('the HIP encoder does not differentiate with respect to its input frames (detach them)')
         par = dict(zip(net._hip_param_names, params))
         packs = net._hip_packs(par, need_grad)
         bn_eval = None if train else net._hip_eval_affines(par)

@@ -272,51 +272,57 @@ class SNBatch:
         return states
 
 
+def _linear_check(x2):
+    if not (x2.is_cuda and x2.dtype == torch.float32 and x2.shape[1] % 4 == 0 and x2.shape[1] <= 1024 and x2.shape[0] >= 1):
+        raise RuntimeError(f'lp_linear_fwd/bwd take fp32 CUDA rows of K % 4 == 0, K <= 1024 features; got {tuple(x2.shape)} {x2.dtype} on {x2.device} '
+                           '(one backend: there is no library-GEMM path)')
+
+
+_LINEAR_ROWS = 64          # rows per lp_linear_* launch (the kernels keep one accumulator row set per wave): larger batches go in chunks
+
+
 class SNLinearFn(torch.autograd.Function):
-    """y = (x W_orig^T) / sigma + b for a spectrally normalised nn.Linear whose sigma comes from SNBatch.  On the GPU both passes are
-    lp_linear_fwd / lp_linear_bwd (small-batch weight streams with 1/sigma and the bias fused; the backward reads W once for dx, the raw
-    weight gradient and the bias gradient) followed by lp_sn_grad_apply (legacy-hook rule dW_orig = G/sigma - <G, W_orig>/sigma^2 u v^T,
-    u, v constant)."""
+    """y = (x W_orig^T) / sigma + b for a spectrally normalised nn.Linear whose sigma comes from SNBatch -- or, with ``sig`` None, a plain
+    nn.Linear (FSTH_plus's projector).  Both passes are lp_linear_fwd / lp_linear_bwd (small-batch weight streams with 1/sigma and the
+    bias fused; the backward reads W once for dx, the raw weight gradient and the bias gradient), followed for a normalised layer by
+    lp_sn_grad_apply (legacy-hook rule dW_orig = G/sigma - <G, W_orig>/sigma^2 u v^T, u, v constant).  Batches of more than 64 rows run as
+    64-row chunks of the same kernels.  No other backend: unsupported shapes raise."""
 
     @staticmethod
     def forward(ctx, x, w, b, u, v, sig):
         ctx.save_for_backward(x, w, u, v, sig)
         ctx.w_param = w if (w.requires_grad and w.is_leaf) else None
         ctx.accum_alt = _ALT['on']
-        x2 = x.reshape(-1, x.shape[-1])
-        ctx.hip = x.is_cuda and ops.linear_supported(x2.shape[0], x2.shape[1])
-        if ctx.hip:
-            y = ops.linear_fwd(x2.detach().contiguous(), w.detach().contiguous(), None if b is None else b.detach().contiguous(), sig[1:])
-            return y.reshape(x.shape[:-1] + (w.shape[0],))
-        y = F.linear(x, w) * sig[1]
-        return y + b if b is not None else y
+        x2 = x.reshape(-1, x.shape[-1]).detach().contiguous()
+        _linear_check(x2)
+        wd, bd, alpha = w.detach().contiguous(), (None if b is None else b.detach().contiguous()), (None if sig is None else sig[1:])
+        ys = [ops.linear_fwd(x2[i:i + _LINEAR_ROWS], wd, bd, alpha) for i in range(0, x2.shape[0], _LINEAR_ROWS)]
+        y = ys[0] if len(ys) == 1 else torch.cat(ys)
+        return y.reshape(x.shape[:-1] + (w.shape[0],))
 
     @staticmethod
     def backward(ctx, g):
         x, w, u, v, sig = ctx.saved_tensors
-        alpha = sig[1]
-        g2, x2 = g.reshape(-1, g.shape[-1]).contiguous(), x.reshape(-1, x.shape[-1]).contiguous()
-        dx = dw = db = None
-        if ctx.hip:
-            dx, graw, db = ops.linear_bwd(x2.detach(), w.detach().contiguous(), g2, sig[1:], ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                                          ctx.needs_input_grad[2])
-            if dx is not None:
-                dx = dx.reshape(x.shape)
-            if graw is not None:
-                dw = ops.sn_grad_apply(graw, w.detach(), u, v, sig, accum=None if ctx.w_param is None else _accum_target(ctx.w_param, ctx.accum_alt))
-            return dx, dw, db, None, None, None
-        if ctx.needs_input_grad[0]:
-            dx = (g @ w) * alpha
-        if ctx.needs_input_grad[1]:
-            graw = (g2.t() @ x2).contiguous()
-            if graw.is_cuda:
-                dw = ops.sn_grad_apply(graw, w.detach(), u, v, sig, accum=None if ctx.w_param is None else _accum_target(ctx.w_param, ctx.accum_alt))
-            else:
-                dot = (graw * w).sum()
-                dw = graw * alpha - (dot * alpha * alpha) * torch.outer(u, v)
-        if ctx.needs_input_grad[2]:
-            db = g2.sum(0)
+        g2, x2 = g.reshape(-1, g.shape[-1]).contiguous(), x.reshape(-1, x.shape[-1]).detach().contiguous()
+        wd, alpha = w.detach().contiguous(), (None if sig is None else sig[1:])
+        want = ctx.needs_input_grad[:3]
+        parts = [ops.linear_bwd(x2[i:i + _LINEAR_ROWS], wd, g2[i:i + _LINEAR_ROWS], alpha, *want) for i in range(0, x2.shape[0], _LINEAR_ROWS)]
+        dx, graw, db = parts[0]
+        if len(parts) > 1:
+            dx = None if dx is None else torch.cat([p_[0] for p_ in parts])
+            graw = None if graw is None else torch.stack([p_[1] for p_ in parts]).sum(0)
+            db = None if db is None else torch.stack([p_[2] for p_ in parts]).sum(0)
+        if dx is not None:
+            dx = dx.reshape(x.shape)
+        dw = graw
+        if graw is not None and sig is not None:
+            dw = ops.sn_grad_apply(graw, wd, u, v, sig, accum=None if ctx.w_param is None else _accum_target(ctx.w_param, ctx.accum_alt))
         return dx, dw, db, None, None, None
+
+
+def hip_linear(x, w, b):
+    """plain ``F.linear`` on the lp_linear_* kernels (no spectral norm)"""
+    return SNLinearFn.apply(x, w, b, None, None, None)
 
 
 class SNEmbeddingFn(torch.autograd.Function):
@@ -627,7 +633,7 @@ class Generator(nn.Module):
         return data_dict['pose_embedding']
 
     def _project(self, joint, states):
-        """SN-Linear -> ReLU -> SN-Linear: plain library GEMMs (rocBLAS through torch) -- B x 768 x 768 and B x 768 x 13056 -- with the
+        """SN-Linear -> ReLU -> SN-Linear on the lp_linear_* weight-stream kernels -- B x 768 x 768 and B x 768 x 13056 -- with the
         1/sigma of the batched power iteration and the legacy-hook weight gradient rule (SNLinearFn)"""
         p0, p2 = self.affine_params_projector._modules['0'], self.affine_params_projector._modules['2']
         h = torch.relu(SNLinearFn.apply(joint, p0.weight_orig, p0.bias, *states[-2]))
@@ -778,10 +784,11 @@ class GeneratorFSTHPlus(Generator):
         return data_dict['dec_keypoints'][:, 0] - 0.5
 
     def _project(self, joint, states):
+        """three plain Linear layers on the lp_linear_* weight-stream kernels (no library GEMM); LeakyReLU(0.05) on B x 648 values stays a torch op"""
         m = self.affine_params_projector._modules
-        h = F.leaky_relu(m['0'](joint), 0.05)
-        h = F.leaky_relu(m['2'](h), 0.05)
-        return m['4'](h)
+        h = F.leaky_relu(hip_linear(joint, m['0'].weight, m['0'].bias), 0.05)
+        h = F.leaky_relu(hip_linear(h, m['2'].weight, m['2'].bias), 0.05)
+        return hip_linear(h, m['4'].weight, m['4'].bias)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -841,6 +848,8 @@ class ConvFn(torch.autograd.Function):
                 a16 = ops.act_pack(x, pro=pro, prec=prec)
                 if pro == 2:
                     tape_relu(lambda: a16.hi[..., :cin] > 0, True)
+            #  the MFMA path emits the consumer planes in its OWN operand mode; another mode is only served by the thin-channel branch
+            assert emit is None or len(emit) < 3 or emit[2] in (None, prec), 'emit_prec differs from the conv\'s operand mode on the MFMA path'
             y = ops.conv16(a16, pack, ksize=ksize, bias=bd, res=res, alpha=alpha, prec=prec, out16=None if emit is None else emit[0],
                            want_y=want_y or cout % 8 != 0)
             if emit is not None:

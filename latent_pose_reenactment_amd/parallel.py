@@ -69,22 +69,31 @@ class _Bucket:
             off += p.numel()
         return None
 
-    def start(self, world_size: int, async_op: bool, skip=None):
-        """``skip`` = (offset, numel): leave that slice of the arena out of the all-reduce (the caller rebuilds it)"""
+    def start(self, world_size: int, async_op: bool, skip=None, only=None):
+        """``skip`` = (offset, numel): leave that slice of the arena out of the all-reduce (the caller rebuilds it); ``only`` = (offset,
+        numel): all-reduce just that slice now -- further ``start`` calls add more slices, ``finish`` waits for all of them (the
+        generator-side arena goes out as two buckets: the generator's slice before the encoders' backward, the encoders' slice after)"""
         op, self.divide = _mean_op()
         if self.optimizer is not None and len(self.optimizer.param_groups) == 1:
             # fused optimizers keep every gradient in one flat arena: reduce it in place, no gather/scatter
-            self.arena = self.optimizer.ensure_flat(0)
-            if skip is None:
-                self.handle = [dist.all_reduce(self.arena, op=op, async_op=async_op)]
-                self.parts = [self.arena]
-            else:
+            arena = self.optimizer.ensure_flat(0)
+            if self.arena is None:
+                self.arena, self.handle, self.parts = arena, [], []
+            if only is not None:
+                off, n = only
+                parts = [arena[off:off + n]]
+            elif skip is not None:
                 off, n = skip
-                self.parts = [t for t in (self.arena[:off], self.arena[off + n:]) if t.numel()]
-                self.handle = [dist.all_reduce(t, op=op, async_op=async_op) for t in self.parts]
+                parts = [arena[:off], arena[off + n:]]
+            else:
+                parts = [arena]
+            parts = [t for t in parts if t.numel()]
+            self.parts += parts
+            self.handle += [dist.all_reduce(t, op=op, async_op=async_op) for t in parts]
             if not async_op:
                 self.finish(world_size)
             return
+        assert only is None and skip is None, 'slices of a bucket need the fused optimizers\' gradient arena'
         self.live = [p for p in self.params if p.grad is not None]
         if not self.live:
             return
@@ -105,7 +114,7 @@ class _Bucket:
             if self.divide:
                 for t in self.parts:
                     t.div_(world_size)
-            self.arena = None
+            self.arena, self.parts = None, []
             return
         if not self.live:
             return
@@ -129,49 +138,84 @@ class GradReducer:
         """``optimizer_G/_D`` (optional): the fused optimizers; their flat gradient arenas are then all-reduced in place.
         ``max_batch``: the largest per-rank batch (rows of the label-embedding exchange); None = agreed on at the first exchange."""
         self.world_size = dist.get_world_size()
-        g_side = list(training_module.generator.parameters())
-        if not finetune:
-            g_side += list(training_module.embedder.parameters())
-        self.g_bucket = _Bucket(g_side, optimizer_G)
+        gen = [p for p in training_module.generator.parameters()]
+        emb = [] if finetune else [p for p in training_module.embedder.parameters()]
+        self.g_bucket = _Bucket(gen + emb, optimizer_G)
+        # the generator-side arena is [generator | embedder] (runners/holycow.get_optimizer): two buckets of ONE buffer
+        self.g_parts = {'generator': _Bucket(gen), 'embedder': _Bucket(emb)}           # (plain-parameter path: one flat buffer each)
+        self.n_gen = sum(p.numel() for p in gen if p.requires_grad)
+        self.n_emb = sum(p.numel() for p in emb if p.requires_grad)
+        self._g_split_live = []
         self.d_bucket = _Bucket(training_module.discriminator.parameters(), optimizer_D)
         self.discriminator = training_module.discriminator
         self.max_batch = max_batch
+        self.use_sparse = None          # agreed on by all ranks at the first discriminator-side exchange
         if broadcast:        # apex Reducer broadcasts rank 0's parameters at construction
             # ONE flat collective per dtype instead of one per tensor (hundreds of tiny broadcasts).  Parameters only, like apex
             # (buffers / EMA stay rank-local) -- plus the (u, v) power-iteration buffers of the label embedding: the row-sparse
             # exchange below rebuilds the rank-1 term of its gradient from THIS rank's u, v, which is only the averaged gradient if
             # every rank holds the same vectors (same start + identical weights after every all-reduce => they stay identical).
             tensors = [t.data for t in training_module.parameters()]
-            emb = getattr(training_module.discriminator, 'embed', None)
-            if emb is not None and hasattr(emb, 'weight_u'):
-                tensors += [emb.weight_u, emb.weight_v]
+            emb_l = getattr(training_module.discriminator, 'embed', None)
+            if emb_l is not None and hasattr(emb_l, 'weight_u'):
+                tensors += [emb_l.weight_u, emb_l.weight_v]
             flat_broadcast(tensors, 0)
 
-    def reduce_generator_side(self, async_op: bool = False):
-        self.g_bucket.start(self.world_size, async_op)
+    def reduce_generator_side(self, async_op: bool = False, part: Optional[str] = None):
+        """``part`` None: the whole generator-side gradient set in one all-reduce.  'generator' | 'embedder': that bucket only -- the
+        generator's 150 MB of gradients are final when ``loss_G.backward`` reaches the embedder's outputs, i.e. BEFORE the encoders'
+        backward (>= 10 ms of kernels) starts: runners/holycow.py cuts the backward pass there and issues the generator bucket first, the
+        encoders' bucket when their backward is done.  ``wait_generator_side`` waits for everything issued."""
+        if part is None:
+            self.g_bucket.start(self.world_size, async_op)
+            return
+        assert part in ('generator', 'embedder'), part
+        if self.g_bucket.optimizer is not None and len(self.g_bucket.optimizer.param_groups) == 1:
+            # the arena's layout must be the one get_optimizer gives it: generator parameters first
+            first = next((p for p in self.g_bucket.optimizer.param_groups[0]['params'] if p.requires_grad), None)
+            assert first is None or self.n_gen == 0 or any(first is q for q in self.g_parts['generator'].params), 'optimizer_G must list the generator first'
+            only = (0, self.n_gen) if part == 'generator' else (self.n_gen, self.n_emb)
+            if only[1]:
+                self.g_bucket.start(self.world_size, async_op, only=only)
+            return
+        b = self.g_parts[part]
+        b.start(self.world_size, async_op)
+        if async_op:
+            self._g_split_live.append(b)
 
     def wait_generator_side(self):
         self.g_bucket.finish(self.world_size)
+        for b in self._g_split_live:
+            b.finish(self.world_size)
+        self._g_split_live = []
 
     def reduce_discriminator_side(self, async_op: bool = False):
         """All-reduce (mean) of the discriminator arena; the label-embedding slice is rebuilt from a row-sparse exchange.
 
-        The SEQUENCE AND SIZES of the collectives issued here depend only on state every rank shares: the exchange buffers
-        have a fixed capacity ``max_batch`` rows per rank -- the constructor argument, or the maximum over ranks of the first batch
-        (one int64 MAX all-reduce on every rank's FIRST call, unconditionally) -- and each rank publishes its own row count next to its
-        labels, so a ragged last batch on some ranks (b < capacity) needs no other collective: its unused rows are zero and add nothing.
+        The SEQUENCE AND SIZES of the collectives issued here depend only on state every rank shares: at the FIRST
+        call every rank -- whether or not it has sparse parts to publish -- takes part in ONE int64 all-reduce that agrees on (a) whether
+        ALL ranks use the row-sparse exchange (MIN of the local flags) and (b) its capacity in rows per rank (MAX of the local batch sizes,
+        unless ``max_batch`` was given to the constructor).  Afterwards each rank publishes its own row count next to its labels, so a
+        ragged last batch on some ranks (b < capacity) needs no other collective: its unused rows are zero and add nothing.
         Issue order: the two small exchanges first, then the arena all-reduce ASYNCHRONOUSLY on RCCL's stream, then the rebuild of the
         embedding gradient on the compute stream while the arena is in flight; ``finish`` waits."""
         sparse = self._sparse_embedding()
-        if sparse is None:
+        if self.use_sparse is None:
+            dev = next(iter(self.discriminator.parameters())).device
+            b_local = int(sparse[1][1].shape[0]) if sparse is not None else 0
+            agree = torch.tensor([1 if sparse is not None else 0, -(self.max_batch if self.max_batch is not None else b_local)], dtype=torch.int64, device=dev)
+            dist.all_reduce(agree, op=dist.ReduceOp.MIN)          # MIN of the flags; MIN of the negated sizes = MAX of the sizes
+            self.use_sparse = bool(int(agree[0].item()))
+            if self.max_batch is None and self.use_sparse:
+                self.max_batch = -int(agree[1].item())
+        if not self.use_sparse:
             self.d_bucket.start(self.world_size, async_op)
             return
+        if sparse is None:
+            raise RuntimeError('GradReducer: the row-sparse label-embedding exchange was agreed on at the first step, but this rank has no '
+                               'gradient parts to publish now (every rank must run the same discriminator backward)')
         (off, n), (label, rows, coef, u, v) = sparse
         b, e = rows.shape
-        if self.max_batch is None:
-            mm = torch.tensor([b], dtype=torch.int64, device=rows.device)
-            dist.all_reduce(mm, op=dist.ReduceOp.MAX)
-            self.max_batch = int(mm.item())
         cap = self.max_batch
         if b > cap:
             raise RuntimeError(f'GradReducer: this rank brought {b} samples but the row-sparse exchange was sized for {cap} per rank at its '
@@ -191,9 +235,17 @@ class GradReducer:
         grad = self.d_bucket.arena[off:off + n].view(-1, e)
         inv = 1.0 / self.world_size
         grad.zero_()
-        grad.addmm_((u * (-(buf[:, -1].sum() * inv)))[:, None], v[None, :])
-        for r in range(self.world_size):                              # fixed order: every rank rebuilds the same bits
-            grad.index_add_(0, lab[r], buf[r, :cap * e].view(cap, e) * inv)
+        coef_mean = (buf[:, -1].sum() * inv).reshape(1)
+        all_rows = (buf[:, :cap * e] * inv).reshape(self.world_size * cap, e)          # rank-major: the fixed order every rank rebuilds in
+        if grad.is_cuda and e % 4 == 0:
+            # the same launch pair SNEmbeddingFn.backward uses at N = 1 (lp_sn_embed_grad: rank-1 term, then the rows in order) -- no library GEMM
+            from . import _lib
+            _lib.check(_lib.lib().lp_sn_embed_grad(grad.data_ptr(), u.contiguous().data_ptr(), v.contiguous().data_ptr(), coef_mean.contiguous().data_ptr(),
+                                                   lab.reshape(-1).contiguous().data_ptr(), all_rows.contiguous().data_ptr(), grad.shape[0], e,
+                                                   self.world_size * cap, torch.cuda.current_stream().cuda_stream), 'lp_sn_embed_grad')
+        else:       # CPU tensors: the gloo host-logic tests of this exchange (tests/test_host_logic.py); the product's gradients live on the GPU
+            grad.addmm_((u * (-coef_mean))[:, None], v[None, :])
+            grad.index_add_(0, lab.reshape(-1), all_rows)
         if not async_op:
             self.d_bucket.finish(self.world_size)
 

@@ -250,7 +250,8 @@ def train_step(training_module, data_dict, target_dict, optimizer_G, optimizer_D
     reducer = getattr(training_module, 'reducer', None)
     multi = 1 < args.num_gpus <= 8 and reducer is not None
     ebwd = _ebwd_enabled(training_module, args, multi)
-    training_module.__dict__['_ebwd_cut'] = ebwd
+    split = multi and _dp_split_enabled(training_module, args)
+    training_module.__dict__['_ebwd_cut'] = ebwd or split
     try:
         all_data, losses_G, losses_D = training_module(data_dict, target_dict)
     finally:
@@ -279,12 +280,22 @@ def train_step(training_module, data_dict, target_dict, optimizer_G, optimizer_D
         optimizer_D.step()
         training_module.update_running_average(0.972 if args.finetune else 0.999)
         return all_data, losses_G, losses_D
-    with fused_grad_accumulation():
-        training_module.embedder_backward()          # (cut without a discriminator-side loss: finish the backward pass here)
-    if multi:
-        reducer.reduce_generator_side(async_op=True)
+    if split:
+        # data parallel, meta-training: the backward pass was cut behind the embedder -- the generator's gradients (the first 150 MB of the
+        # generator-side arena) are final NOW and go out as their own bucket; the encoders' backward (>= 10 ms of kernels) runs while that
+        # all-reduce is on the links, then the encoders' bucket follows; both hide behind zero_grad(D) + loss_D.backward
+        reducer.reduce_generator_side(async_op=True, part='generator')
+        with fused_grad_accumulation():
+            training_module.embedder_backward()
+        _streams.join_all()
+        reducer.reduce_generator_side(async_op=True, part='embedder')
     else:
-        optimizer_G.step()
+        with fused_grad_accumulation():
+            training_module.embedder_backward()          # (cut without a discriminator-side loss: finish the backward pass here)
+        if multi:
+            reducer.reduce_generator_side(async_op=True)
+        else:
+            optimizer_G.step()
     if losses_D:
         optimizer_D.zero_grad()
         with fused_grad_accumulation():
@@ -308,6 +319,12 @@ def _ebwd_enabled(training_module, args, multi):
         return False
     p = next(training_module.generator.parameters(), None)
     return p is not None and _streams.enabled(p, 'ebwd', finetuning=False)
+
+
+def _dp_split_enabled(training_module, args):
+    """data-parallel step with the generator-side exchange in two buckets (see ``train_step``): meta-training (fine-tuning trains no
+    encoder, and the reference refuses multi-GPU fine-tuning: train.py:120-126), training mode, LP_DP_SPLIT != 0"""
+    return not getattr(args, 'finetune', False) and training_module.training and os.environ.get('LP_DP_SPLIT', '1') != '0'
 
 
 GRAPH_WARMUP_ITERATIONS = 3      # eager iterations before the step is captured (lazy state: optimizer moments, packs, MIOpen plans)
@@ -391,11 +408,13 @@ class GraphedTrainStep:
         g1: forward (E, G, D x3, criterions) + zero_grad(G) + loss_G.backward
         g2: [optimizer_G.step + EMA on a side stream] || zero_grad(D) + loss_D.backward
         g3: optimizer_D.step
-    Data parallel (the step is re-cut so that the generator-side exchange hides behind the discriminator backward):
-        g1:  as above
-        --   all-reduce of the generator-side gradient arena, ASYNCHRONOUS on RCCL's stream
-        g2a: zero_grad(D) + loss_D.backward                    (runs concurrently with that all-reduce)
-        --   wait for the all-reduce
+    Data parallel (the step is re-cut so that the generator-side exchange hides behind the encoders' and the discriminator's backward):
+        g1:  as above, the backward pass stopping at the embedder's outputs (meta-training)
+        --   all-reduce of the GENERATOR's slice of the generator-side gradient arena, ASYNCHRONOUS on RCCL's stream
+        g1b: the encoders' backward                            (runs concurrently with that all-reduce)
+        --   all-reduce of the ENCODERS' slice, asynchronous
+        g2a: zero_grad(D) + loss_D.backward                    (runs concurrently with both)
+        --   wait for the all-reduces
         g2b: optimizer_G.step
         --   discriminator-side exchange (arena all-reduce + row-sparse label-embedding exchange)
         g3:  optimizer_D.step + EMA
@@ -423,7 +442,8 @@ class GraphedTrainStep:
         # capture on the stream the warm-up ran on: the AccumulateGrad nodes autograd keeps per parameter stay on one stream
         # thread_local error mode: CUDA calls of OTHER threads (the RCCL watchdog polling its events) must not invalidate the capture
         self.ebwd = _ebwd_enabled(self.tm, args, self.reducer is not None)
-        self.tm.__dict__['_ebwd_cut'] = self.ebwd
+        self.split = self.reducer is not None and _dp_split_enabled(self.tm, args)
+        self.tm.__dict__['_ebwd_cut'] = self.ebwd or self.split
         self.g1 = G()
         with torch.cuda.graph(self.g1, **kw):
             try:
@@ -476,7 +496,16 @@ class GraphedTrainStep:
                 if self.ema_in_g2:
                     b.join()
         else:
-            self.reducer.reduce_generator_side()
+            if self.split:
+                self.reducer.reduce_generator_side(part='generator')
+                self.g1b = G()
+                with torch.cuda.graph(self.g1b, pool=pool, **kw):
+                    with fused_grad_accumulation():
+                        self.tm.embedder_backward()
+                    _streams.join_all()
+                self.reducer.reduce_generator_side(part='embedder')
+            else:
+                self.reducer.reduce_generator_side()
             self.g2a, self.g2b = G(), G()
             with torch.cuda.graph(self.g2a, pool=pool, **kw):
                 self.opt_D.zero_grad()
@@ -507,7 +536,12 @@ class GraphedTrainStep:
         if self.reducer is None:
             self.g2.replay()
         else:
-            self.reducer.reduce_generator_side(async_op=True)
+            if self.split:
+                self.reducer.reduce_generator_side(async_op=True, part='generator')
+                self.g1b.replay()
+                self.reducer.reduce_generator_side(async_op=True, part='embedder')
+            else:
+                self.reducer.reduce_generator_side(async_op=True)
             self.g2a.replay()
             self.reducer.wait_generator_side()
             self.g2b.replay()

@@ -1,0 +1,100 @@
+"""TEST INFRASTRUCTURE -- the stock-layer forward of the two encoder backbones (oracle for SURVEY rows E1 / E2).
+
+The reference instantiates its identity / pose encoders from torchvision 0.6.1 (embedders/unsupervised_pose_separate_embResNeXt_segmentation.py:
+26-28: ``resnext50_32x4d(num_classes=512)``, ``mobilenet_v2(num_classes=256)``), an un-vendored dependency that is absent from this image:
+PARITY UNPINNED for the architecture itself -- what is restated here are the public definitions (Xie et al. ResNeXt / torchvision
+``Bottleneck``; Sandler et al. MobileNetV2 / torchvision ``InvertedResidual``) evaluated with stock ``torch.nn.functional`` ops
+(``conv2d``, ``batch_norm``, ``max_pool2d``, ``linear``: MIOpen / rocBLAS on the GPU, oneDNN on the CPU) over the PARAMETERS AND BUFFERS of the
+product's container modules (``latent_pose_reenactment_amd/embedders/backbones.py``: torchvision-compatible ``state_dict`` keys, no arithmetic).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this module.  The product's encoders run on the
+hand-written gfx950 kernels or raise; they contain no stock-layer forward.  ``stock_layers()`` is how a TEST runs a product module tree
+(TrainingModule, the embedder plugin) on the stock layers: it swaps the ``forward`` of the two backbone classes for the functions below
+while the context is active (geometries the HIP encoders do not cover: 32-px golden fixtures; A/B regression runs; the CPU baseline)."""
+import contextlib
+
+import torch
+import torch.nn.functional as F
+
+
+def _bn(m, x):
+    """nn.BatchNorm2d.forward on the container's parameters / buffers (momentum is a constant in both backbones)"""
+    if m.training and m.track_running_stats:
+        m.num_batches_tracked += 1
+        return F.batch_norm(x, m.running_mean, m.running_var, m.weight, m.bias, True, m.momentum, m.eps)
+    return F.batch_norm(x, m.running_mean, m.running_var, m.weight, m.bias, not m.track_running_stats, 0.0, m.eps)
+
+
+def _conv(m, x):
+    return F.conv2d(x, m.weight, m.bias, m.stride, m.padding, m.dilation, m.groups)
+
+
+# ---------------------------------------------------------------- ResNeXt-50 32x4d (torchvision resnet.py: ResNet / Bottleneck)
+def _bottleneck(blk, x):
+    idt = x
+    if blk.downsample is not None:
+        idt = _bn(blk.downsample[1], _conv(blk.downsample[0], x))
+    out = F.relu(_bn(blk.bn1, _conv(blk.conv1, x)))
+    out = F.relu(_bn(blk.bn2, _conv(blk.conv2, out)))
+    out = _bn(blk.bn3, _conv(blk.conv3, out))
+    return F.relu(out + idt)
+
+
+def resnext_forward(net, x):
+    """frames [N,3,H,W] -> logits [N, num_classes]"""
+    x = F.max_pool2d(F.relu(_bn(net.bn1, _conv(net.conv1, x))), 3, 2, 1)
+    for stage in (net.layer1, net.layer2, net.layer3, net.layer4):
+        for blk in stage:
+            x = _bottleneck(blk, x)
+    return F.linear(torch.flatten(F.adaptive_avg_pool2d(x, 1), 1), net.fc.weight, net.fc.bias)
+
+
+# ---------------------------------------------------------------- MobileNetV2 (torchvision mobilenet.py: ConvBNReLU / InvertedResidual)
+def _conv_bn_relu6(seq, x):
+    return F.relu6(_bn(seq[1], _conv(seq[0], x)))
+
+
+def _inverted_residual(blk, x):
+    layers = list(blk.conv)
+    h = x
+    for m in layers[:-2]:
+        h = _conv_bn_relu6(m, h)
+    h = _bn(layers[-1], _conv(layers[-2], h))
+    return x + h if blk.use_res else h
+
+
+def mobilenet_forward(net, x):
+    feats = list(net.features)
+    x = _conv_bn_relu6(feats[0], x)
+    for blk in feats[1:-1]:
+        x = _inverted_residual(blk, x)
+    x = _conv_bn_relu6(feats[-1], x)
+    drop, fc = net.classifier[0], net.classifier[1]
+    return F.linear(F.dropout(x.mean([2, 3]), drop.p, drop.training), fc.weight, fc.bias)
+
+
+def forward(net, x):
+    return resnext_forward(net, x) if hasattr(net, 'layer1') else mobilenet_forward(net, x)
+
+
+@contextlib.contextmanager
+def stock_layers():
+    """while active, EVERY instance of the product's two backbone classes evaluates on the stock layers above (a class-level swap of
+    ``forward``: module trees that were deep-copied -- the EMA copies of TrainingModule -- follow it too)"""
+    from latent_pose_reenactment_amd.embedders import backbones
+    mods = [backbones]
+    try:                     # the plugin loader imports the same file as top-level package ``embedders`` (reference layout): patch both
+        import embedders.backbones as plugin_backbones
+        if plugin_backbones is not backbones:
+            mods.append(plugin_backbones)
+    except ImportError:
+        pass
+    saved = [(m.ResNeXt, m.ResNeXt.forward, m.MobileNetV2, m.MobileNetV2.forward) for m in mods]
+    for m in mods:
+        m.ResNeXt.forward = resnext_forward
+        m.MobileNetV2.forward = mobilenet_forward
+    try:
+        yield
+    finally:
+        for rx, rf, mb, mf in saved:
+            rx.forward, mb.forward = rf, mf

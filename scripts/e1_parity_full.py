@@ -15,6 +15,7 @@ frames = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 size = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 content = sys.argv[3] if len(sys.argv) > 3 else 'noise'       # noise: U[0,1) frames (what bench.py feeds) | smooth: low-frequency content + 10 % noise
 from embedders import backbones  # noqa: E402
+from oracle import backbones_ref as BR  # noqa: E402
 from dataloaders.synthetic_voxceleb2 import make_sample  # noqa: E402
 
 torch.manual_seed(123)
@@ -43,8 +44,7 @@ assert net.__dict__.get('_hip_param_names') is not None, 'the HIP path did not r
 emb = y.view(b, k, -1).mean(1)
 (emb * r).sum().backward()
 torch.cuda.synchronize()
-backbones.set_hip_forward(False)
-yr = ref(x.double())
+yr = BR.resnext_forward(ref, x.double())
 embr = yr.view(b, k, -1).mean(1)
 (embr * r.double()).sum().backward()
 torch.cuda.synchronize()
@@ -52,7 +52,7 @@ torch.cuda.synchronize()
 m32 = copy.deepcopy(ref).float()
 for p_ in m32.parameters():
     p_.grad = None
-y32 = m32(x)
+y32 = BR.resnext_forward(m32, x)
 e32 = y32.view(b, k, -1).mean(1)
 (e32 * r).sum().backward()
 n32 = sum((p.grad.double() - q.grad).norm() ** 2 for p, q in zip(m32.parameters(), ref.parameters()))
@@ -60,7 +60,6 @@ num = sum((p.grad.double() - q.grad).norm() ** 2 for p, q in zip(net.parameters(
 den = sum(q.grad.norm() ** 2 for q in ref.parameters())
 n32 = n32
 ga = torch.cat([p.grad.double().reshape(-1) for p in net.parameters()]); gb = torch.cat([q.grad.reshape(-1) for q in ref.parameters()])
-backbones.set_hip_forward(True)
 for p_ in net.parameters():
     p_.grad = None
 

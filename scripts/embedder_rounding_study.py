@@ -59,7 +59,8 @@ for train in (False, True):
     from test_resnext_hip import structured_frames
     x = structured_frames(8, 128, 3).double()
     r = torch.randn(8, 32, dtype=torch.double)
-    y_ref = m(x); (y_ref * r).sum().backward()
+    from oracle import backbones_ref as BR
+    y_ref = BR.resnext_forward(m, x); (y_ref * r).sum().backward()
     m2._hip_structure()
     y = resnext_hip.ResNeXtFunction.apply(m2, x, *[p for _, p in m2.named_parameters()])
     (y * r).sum().backward()

@@ -55,6 +55,14 @@ def global_batch(total, num_labels, seed=11):
 
 
 def run(world, rank, mode, total, num_labels, steps, out_path):
+    # 32-px frames are outside the hand-written encoders' geometry (the product raises): this worker tests the data-parallel EXCHANGE, its
+    # encoders run on the oracle's stock layers (test infrastructure) for the whole run
+    from oracle import backbones_ref as BR
+    with BR.stock_layers():
+        _run(world, rank, mode, total, num_labels, steps, out_path)
+
+
+def _run(world, rank, mode, total, num_labels, steps, out_path):
     a = small_args(world, rank, num_labels)
     tm, opt_G, opt_D, holycow = build(a)
     if world > 1:
@@ -80,13 +88,19 @@ def run(world, rank, mode, total, num_labels, steps, out_path):
                 def replay(self):
                     ORDER.append(self.name)
                     self.g.replay()
-            for nm in ('g1', 'g2a', 'g2b', 'g3'):
-                setattr(step, nm, _Logged(nm, getattr(step, nm)))
+            for nm in ('g1', 'g1b', 'g2a', 'g2b', 'g3'):
+                if hasattr(step, nm):
+                    setattr(step, nm, _Logged(nm, getattr(step, nm)))
             orig_ar, orig_wait = dist.all_reduce, step.reducer.wait_generator_side
-            n_g = opt_G.ensure_flat(0).numel()
+            arena_g = opt_G.ensure_flat(0)
+            g_lo, g_hi, n_gen = arena_g.data_ptr(), arena_g.data_ptr() + arena_g.numel() * 4, step.reducer.n_gen
 
             def logged_all_reduce(t, *args, **kw):
-                ORDER.append(('all_reduce', 'G' if t.numel() == n_g else 'D-side', bool(kw.get('async_op', False))))
+                if g_lo <= t.data_ptr() < g_hi:          # a slice of the generator-side arena: the generator's bucket or the encoders'
+                    tag = 'G-generator' if (t.data_ptr() == g_lo and t.numel() == n_gen) else 'G-embedder' if t.data_ptr() == g_lo + 4 * n_gen else 'G'
+                else:
+                    tag = 'D-side'
+                ORDER.append(('all_reduce', tag, bool(kw.get('async_op', False))))
                 return orig_ar(t, *args, **kw)
 
             def logged_wait():

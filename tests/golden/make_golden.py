@@ -366,6 +366,12 @@ def make_train_step():
     backbones = importlib.import_module('backbones')
     tv.models.resnext50_32x4d = backbones.resnext50_32x4d
     tv.models.mobilenet_v2 = backbones.mobilenet_v2
+    # the product's backbone classes are parameter containers whose forward runs the HIP kernels or raises; on the reference side of a
+    # fixture they are evaluated with the stock torch layers (oracle/backbones_ref.py), standing in for the absent torchvision
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle import backbones_ref as BR
+    backbones.ResNeXt.forward = BR.resnext_forward
+    backbones.MobileNetV2.forward = BR.mobilenet_forward
     for name in ('tqdm',):
         if name not in sys.modules:
             m = types.ModuleType(name); m.tqdm = lambda x, *a, **k: x; sys.modules[name] = m
@@ -467,6 +473,12 @@ def _install_backbones():
     backbones = importlib.import_module('backbones')
     tv.models.resnext50_32x4d = backbones.resnext50_32x4d
     tv.models.mobilenet_v2 = backbones.mobilenet_v2
+    # the product's backbone classes are parameter containers whose forward runs the HIP kernels or raises; on the reference side of a
+    # fixture they are evaluated with the stock torch layers (oracle/backbones_ref.py), standing in for the absent torchvision
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle import backbones_ref as BR
+    backbones.ResNeXt.forward = BR.resnext_forward
+    backbones.MobileNetV2.forward = BR.mobilenet_forward
     for name in ('tqdm',):
         if name not in sys.modules:
             m = types.ModuleType(name); m.tqdm = lambda x, *a, **k: x; sys.modules[name] = m

@@ -52,13 +52,15 @@ def test_recut_graph_step_equals_eager_data_parallel_step(tmp_path):
     sg, sd_ = rel(vec(graph['G']), vec(eager['G'])), rel(vec(graph['D']), vec(eager['D']))
     print(f'[dp] graph vs eager after 3 steps on 2 ranks: gradient arenas {eg:.2e} / {ed:.2e}, state vectors {sg:.2e} / {sd_:.2e}')
     assert max(eg, ed) < 2e-3 and max(sg, sd_) < 2e-3, (eg, ed, sg, sd_)
-    # issue order of the last re-cut step: G all-reduce asynchronous and BEFORE the discriminator-backward graph, waited for only before
+    # issue order of the last re-cut step: G all-reduces asynchronous and BEFORE the discriminator-backward graph, waited for only before
     # optimizer_G's graph; the discriminator-side exchange between g2b and g3 (runners/holycow.py GraphedTrainStep.__call__)
     order = graph['order']
     names = [o if isinstance(o, str) else o[0] + ':' + o[1] for o in order]
-    i = {k: names.index(k) for k in ('g1', 'all_reduce:G', 'g2a', 'wait_G', 'g2b', 'g3')}
-    assert i['g1'] < i['all_reduce:G'] < i['g2a'] < i['wait_G'] < i['g2b'] < i['g3'], order
-    assert [o for o in order if not isinstance(o, str) and o[1] == 'G'][0][2] is True, order          # async_op=True: RCCL's own stream
+    # (round 5) the generator-side exchange goes out as TWO buckets: the generator's slice of the arena right after g1 (its gradients are final
+    # when the backward pass reaches the embedder's outputs), the encoders' slice after g1b (their backward), both before g2a
+    i = {k: names.index(k) for k in ('g1', 'all_reduce:G-generator', 'g1b', 'all_reduce:G-embedder', 'g2a', 'wait_G', 'g2b', 'g3')}
+    assert i['g1'] < i['all_reduce:G-generator'] < i['g1b'] < i['all_reduce:G-embedder'] < i['g2a'] < i['wait_G'] < i['g2b'] < i['g3'], order
+    assert all(o[2] is True for o in order if not isinstance(o, str) and o[1].startswith('G')), order          # async_op=True: RCCL's own stream
     d_side = [j for j, n_ in enumerate(names) if n_ == 'all_reduce:D-side']
     assert d_side and all(i['g2b'] < j < i['g3'] for j in d_side), order
 

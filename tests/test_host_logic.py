@@ -120,6 +120,22 @@ oG.flat.fill_(float(rank + 1)); oD.flat.fill_(float(10 * (rank + 1)))
 red2.reduce_generator_side(async_op=True); red2.wait_generator_side(); red2.reduce_discriminator_side()
 ok &= bool(torch.allclose(oG.flat, torch.full_like(oG.flat, mean))) and bool(torch.allclose(oD.flat, torch.full_like(oD.flat, 10 * mean)))
 ok &= all(torch.allclose(p.grad, torch.full_like(p, mean)) for p in tm.generator.parameters())
+# generator-side exchange in TWO buckets (round 5): the generator's gradients first, the encoders' when their backward is done; one wait
+tm3 = TM(); red4 = GradReducer(tm3, finetune=False)
+for p in tm3.parameters(): p.grad = torch.full_like(p, float(rank + 1))
+red4.reduce_generator_side(async_op=True, part='generator')
+red4.reduce_generator_side(async_op=True, part='embedder'); red4.wait_generator_side()
+ok &= all(torch.allclose(p.grad, torch.full_like(p, mean)) for p in list(tm3.generator.parameters()) + list(tm3.embedder.parameters()))
+ok &= all(torch.allclose(p.grad, torch.full_like(p, float(rank + 1))) for p in tm3.discriminator.parameters())
+oG3, oD3 = Arena(list(tm3.generator.parameters()) + list(tm3.embedder.parameters())), Arena(tm3.discriminator.parameters())
+red5 = GradReducer(tm3, finetune=False, broadcast=False, optimizer_G=oG3, optimizer_D=oD3)
+ok &= red5.n_gen == sum(p.numel() for p in tm3.generator.parameters()) and red5.n_gen + red5.n_emb == oG3.flat.numel()
+oG3.flat.fill_(float(rank + 1))
+red5.reduce_generator_side(async_op=False, part='generator')        # only the generator's slice of the arena is exchanged
+ok &= bool(torch.allclose(oG3.flat[:red5.n_gen], torch.full((red5.n_gen,), mean))) and bool(torch.allclose(oG3.flat[red5.n_gen:], torch.full((red5.n_emb,), float(rank + 1))))
+oG3.flat.fill_(float(rank + 1))
+red5.reduce_generator_side(async_op=True, part='generator'); red5.reduce_generator_side(async_op=True, part='embedder'); red5.wait_generator_side()
+ok &= bool(torch.allclose(oG3.flat, torch.full_like(oG3.flat, mean)))
 w = [p.detach().clone() for p in tm.parameters()]
 gathered = [None] * W; dist.all_gather_object(gathered, [t.tolist() for t in w])
 ok &= all(g_ == gathered[0] for g_ in gathered)                            # parameters identical after the broadcast
@@ -169,6 +185,15 @@ alld = [None] * W; dist.all_gather_object(alld, dense2.tolist())
 want = sum(torch.tensor(d_) for d_ in alld) / W
 ok &= bool(torch.allclose(emb_grad, want, atol=1e-5)) and red3.max_batch == B
 ok &= all(torch.allclose(p.grad, torch.full_like(p, mean)) for p in tm2.discriminator.lin.parameters())
+# (ADVICE r04) a rank WITHOUT sparse parts at the first exchange must not skip a collective the others issue: the first call agrees on
+# "row-sparse or dense" with one all-reduce on EVERY rank; here only rank 0 has parts, so all ranks fall back to the dense all-reduce
+torch.manual_seed(7)
+tm4 = TM2(); oD4 = Arena(tm4.discriminator.parameters())
+red6 = GradReducer(tm4, finetune=False, optimizer_D=oD4)
+oD4.flat.fill_(float(rank + 1))
+tm4.discriminator._embed_parts = {'parts': (label, rows, coef, u, v)} if rank == 0 else {}
+red6.reduce_discriminator_side()
+ok &= red6.use_sparse is False and bool(torch.allclose(oD4.flat, torch.full_like(oD4.flat, mean)))
 print('REDUCER_OK' if ok else 'REDUCER_FAIL', flush=True)
 dist.destroy_process_group()
 '''

@@ -2,12 +2,15 @@
 encoder and MobileNetV2 pose encoder in TRAIN-mode BatchNorm (as the reference holds them, runners/holycow.py:34-41), the generator, the
 discriminator with the 98000 x 512 label embedding, all six criterions of configs/default.yaml -- forward quantities of the HIP path
 against the reference chain restated on the same inputs and weights:
-    encoders : the stock layers of embedders/backbones.py in fp64 on the device (torchvision-compatible restatement; fp64 so that the
+    encoders : the stock layers of oracle/backbones_ref.py in fp64 on the device (torchvision-compatible restatement; fp64 so that the
                comparison is not limited by the reference arithmetic's own conditioning -- the stock fp32 layers are printed beside it),
     G, D, losses : oracle/lp_oracle.py on the CPU (fp32, pinned by the reference goldens), fed with the REFERENCE embeddings.
-Gate (north_star): `embeds`, `pose_embedding`, `fake_rgbs`, `fake_segm` and every loss scalar within 1e-3 rel-L2 in the DEFAULT precision
-assignment (fp16 operands; identity encoder: bf16x3 with an fp16 tail, pose encoder bf16x3 -- what `python bench.py` runs), 1e-4-class in
-the strict mode.  bench.py reads the measured figures of this test from profiles/ for its parity statement."""
+Gate (north_star): `embeds`, `pose_embedding`, `fake_rgbs`, `fake_segm`, the critic's score of the generated image and every loss scalar
+within 1e-3 PLAIN rel-L2 in the DEFAULT precision assignment (fp16 operands; identity encoder: bf16x3 with an fp16 tail, pose encoder
+bf16x3, the critic's fake -> G pass bf16x3 -- what `python bench.py` runs), 5e-4 in the strict mode.  Every gated and exported figure is
+the plain relative error |a - b| / |b| (round 4 replaced two of them by a conditioned figure: VERDICT r04 weak 1); the conditioned
+figure of the projection score is kept as an EXTRA column (`conditioned`).  bench.py reads the measured figures of this test from
+profiles/ for its parity statement, with the source stamp of the tree that produced them."""
 import copy
 import json
 import os
@@ -30,7 +33,7 @@ def run(out_path):
     """(child process: the precision environment is read at import)"""
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'latent_pose_reenactment_amd'))
     import bench
-    from embedders import backbones
+    from oracle import backbones_ref as BR
     from oracle import lp_oracle as O
     prec = os.environ.get('LP_PREC', 'f16')
     args = bench.make_args(256, 8, 'cuda', 1, 0, prec, finetune=False)
@@ -56,15 +59,11 @@ def run(out_path):
     enc = data['enc_rgbs']
     b, k = enc.shape[:2]
     frames, pose_in = enc.reshape(b * k, *enc.shape[2:]), data['pose_input_rgbs'][:, 0]
-    backbones.set_hip_forward(False)
-    try:
-        with torch.no_grad():
-            pf64 = idt64.train()(frames.double()).view(b, k, -1)
-            p64 = pose64.train()(pose_in.double())
-            pf32 = idt32.train()(frames).view(b, k, -1)
-            p32 = pose32.train()(pose_in)
-    finally:
-        backbones.set_hip_forward(True)
+    with torch.no_grad():
+        pf64 = BR.resnext_forward(idt64.train(), frames.double()).view(b, k, -1)
+        p64 = BR.mobilenet_forward(pose64.train(), pose_in.double())
+        pf32 = BR.resnext_forward(idt32.train(), frames).view(b, k, -1)
+        p32 = BR.mobilenet_forward(pose32.train(), pose_in)
     errs = {'embeds': rel(all_data['embeds'], pf64.mean(1)), 'embeds_elemwise': rel(all_data['embeds_elemwise'], pf64),
             'pose_embedding': rel(all_data['pose_embedding'], p64)}
     calib = {'embeds': rel(pf32.mean(1), pf64.mean(1)), 'pose_embedding': rel(p32, p64)}
@@ -88,46 +87,45 @@ def run(out_path):
     assert set(mine) == set(ref_losses), (sorted(mine), sorted(ref_losses))
     for name, v in ref_losses.items():
         errs['loss.' + name] = rel(mine[name], v)
-    # The critic's projection score <pooled features, label embedding + w> is the dot product of a 512-vector with an (at initialisation)
-    # unrelated direction: it is ~sqrt(512) smaller than |pooled| |embedding|, so ANY arithmetic's feature error (3e-4 in fp16, the gate of
-    # tests/test_full_size_parity.py) appears ~20x larger relative to the score itself.  The score and adversarial_G = -mean(score) are
-    # therefore measured against the scale of what is summed, |pooled_i| |embedding_i|; the plain relative figures are kept beside them
-    # (`ill_conditioned_plain_relative`) and gated at 1e-2.
+    errs['fake_score_G'] = rel(all_data['fake_score_G'], out['fake_score_G'])
+    # EXTRA column, not a gate: the critic's projection score <pooled features, label embedding> + linear(pooled) is the dot product of a
+    # 512-vector with an (at initialisation) unrelated direction, ~sqrt(512) smaller than |pooled| |embedding|, so a feature error appears
+    # ~15x larger relative to the score itself.  `conditioned` measures the same two errors against the scale of what is summed.
     pooled = torch.relu(out['fake_features'][-1]).sum(dim=(2, 3)).double()
     scale = pooled.norm(dim=1) * out['real_embedding'].double().norm(dim=1)
     d_score = (all_data['fake_score_G'].detach().double().cpu() - out['fake_score_G'].double())
-    plain = {'fake_score_G': rel(all_data['fake_score_G'], out['fake_score_G']), 'loss.adversarial_G': errs['loss.adversarial_G']}
-    errs['fake_score_G'] = float(d_score.norm() / scale.norm())
-    errs['loss.adversarial_G'] = float(d_score.mean().abs() / scale.mean())
+    conditioned = {'fake_score_G': float(d_score.norm() / scale.norm()), 'loss.adversarial_G': float(d_score.mean().abs() / scale.mean())}
     modes = [{0: 'bf16', 1: 'bf16x3', 2: 'f16'}[m] for m in tm.embedder.identity_encoder.block_precs()]
-    res = {'LP_PREC': prec, 'identity_encoder_blocks': modes, 'errors': errs, 'stock_fp32_encoders_vs_fp64': calib,
-           'ill_conditioned_plain_relative': plain, 'loss_values': {k: float(v) for k, v in ref_losses.items()},
-           'note': 'fake_score_G / loss.adversarial_G: error relative to |pooled features| |label embedding| (the projection score is a dot '
-                   'product with an unrelated direction at initialisation); their plain relative errors: ill_conditioned_plain_relative; '
-                   'everything else plain rel-L2',
-           'geometry': '256x256, 8 samples x 8 encoder frames, 98000 labels, train-mode BatchNorm, default.yaml criterions'}
+    from discriminators.no_landmarks import gpass_prec
+    gp, gfrom = gpass_prec()
+    res = {'LP_PREC': prec, 'identity_encoder_blocks': modes,
+           'critic_fake_to_G_pass': {'operands': {0: 'bf16', 1: 'bf16x3', 2: 'f16'}[gp], 'from_unit': gfrom},
+           'errors': errs, 'conditioned': conditioned, 'stock_fp32_encoders_vs_fp64': calib,
+           'loss_values': {k: float(v) for k, v in ref_losses.items()},
+           'note': 'errors: PLAIN rel-L2 |a - b| / |b| of every quantity (all gated); conditioned: fake_score_G / loss.adversarial_G relative to '
+                   '|pooled features| |label embedding| (extra column: the conditioning of the projection score)',
+           'geometry': '256x256, 8 samples x 8 encoder frames, 98000 labels, train-mode BatchNorm, default.yaml criterions',
+           'stamp': bench.source_stamp()}
     json.dump(res, open(out_path, 'w'))
 
 
 @pytest.mark.parametrize('mode,gate', [('default', 1e-3), ('bf16x3', 5e-4)])
 def test_full_size_metatrain_forward_vs_reference_chain(tmp_path, mode, gate):
-    env = {k: v for k, v in os.environ.items() if k not in ('LP_PREC', 'LP_PREC_E', 'LP_E_F16_TAIL')}
+    env = {k: v for k, v in os.environ.items() if k not in ('LP_PREC', 'LP_PREC_E', 'LP_E_F16_TAIL', 'LP_D_GPASS_PREC', 'LP_D_GPASS_FROM')}
     if mode != 'default':
         env['LP_PREC'] = mode
-    env['LP_STRICT_HIP'] = '1'          # the hand-written encoders or an error: never the stock layers
     out = str(tmp_path / 'res.json')
     r = subprocess.run([sys.executable, os.path.abspath(__file__), out], env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     res = json.load(open(out))
     worst = sorted(res['errors'].items(), key=lambda kv: -kv[1])
-    print(f"[parity-configs2] mode {mode} (identity encoder blocks: {res['identity_encoder_blocks'].count('f16')} fp16 of {len(res['identity_encoder_blocks'])}): "
-          f"{[(k, f'{v:.2e}') for k, v in worst]} | stock fp32 encoders vs fp64: {res['stock_fp32_encoders_vs_fp64']}")
+    print(f"[parity-configs2] mode {mode} (identity encoder blocks: {res['identity_encoder_blocks'].count('f16')} fp16 of {len(res['identity_encoder_blocks'])}; "
+          f"critic fake->G pass: {res['critic_fake_to_G_pass']}): PLAIN rel-L2 {[(k, f'{v:.2e}') for k, v in worst]} | conditioned {res['conditioned']} "
+          f"| stock fp32 encoders vs fp64: {res['stock_fp32_encoders_vs_fp64']}")
     keep = os.environ.get('LP_PARITY_OUT')        # (scripts: copy the measured figures to profiles/)
     if keep:
-        json.dump(res, open(os.path.join(keep, f'r04_parity_configs2_{mode}.json'), 'w'), indent=1)
+        json.dump(res, open(os.path.join(keep, f'r05_parity_configs2_{mode}.json'), 'w'), indent=1)
     bad = {k: v for k, v in res['errors'].items() if not v < gate}
-    assert not bad, bad
-    bad = {k: v for k, v in res['ill_conditioned_plain_relative'].items() if not v < 10 * gate}
     assert not bad, bad
 
 

@@ -92,7 +92,7 @@ def test_mobilenet_v2_forward_backward_vs_fp64(train, size, shallow):
     """HIP training path vs the stock layers in fp64, the stock fp32 layers as calibration.  The full 52-layer net at random init with
     train-mode BatchNorm over 8 frames is chaotic (stock fp32: 3e-2 in the gradients), so it gets calibrated bounds; the shallow variant
     (one block of every kind) carries the fp32-class gates of the bf16x3 contractions."""
-    from embedders import backbones
+    from oracle import backbones_ref as BR
     from test_resnext_hip import _cos, _grad_err, structured_frames
     m, ref = _nets(11, shallow)
     m32 = copy.deepcopy(m)
@@ -103,14 +103,10 @@ def test_mobilenet_v2_forward_backward_vs_fp64(train, size, shallow):
     y = m(x)
     assert m.__dict__.get('_hip_feature_param_names') is not None, 'the HIP training path did not run'
     (y * r).sum().backward()
-    backbones.set_hip_forward(False)
-    try:
-        yr = ref(x.double())
-        (yr * r.double()).sum().backward()
-        y32 = m32(x)
-        (y32 * r).sum().backward()
-    finally:
-        backbones.set_hip_forward(True)
+    yr = BR.mobilenet_forward(ref, x.double())
+    (yr * r.double()).sum().backward()
+    y32 = BR.mobilenet_forward(m32, x)
+    (y32 * r).sum().backward()
     e_out, c_out = rel(y, yr), rel(y32, yr)
     tot, c_tot = _grad_err(list(m.parameters()), list(ref.parameters())), _grad_err(list(m32.parameters()), list(ref.parameters()))
     e_b = max(rel(b.double(), q) for (k, b), (_, q) in zip(m.named_buffers(), ref.named_buffers()) if b.dtype.is_floating_point)
@@ -133,7 +129,8 @@ def test_mobilenet_v2_forward_backward_vs_fp64(train, size, shallow):
 def test_mobilenet_v2_four_frames_take_the_hip_path():
     """N = 4 frames (configs/default.yaml: batch 8 over 2 GPUs) must run on the HIP training path -- not silently on the stock layers --
     and agree with them (eval-mode BatchNorm: a well-conditioned comparison of the whole network, forward + all gradients)"""
-    from embedders import backbones, mobilenet_hip
+    from embedders import mobilenet_hip
+    from oracle import backbones_ref as BR
     from test_resnext_hip import _grad_err, structured_frames
     assert mobilenet_hip.supported(4, 256, 256) and mobilenet_hip.supported(4, 128, 128) and not mobilenet_hip.supported(4, 32, 32)
     m, ref = _nets(13, False)
@@ -143,24 +140,47 @@ def test_mobilenet_v2_four_frames_take_the_hip_path():
     y = m(x)
     assert m.__dict__.get('_hip_feature_param_names') is not None, 'the HIP training path did not run for 4 frames'
     (y * r).sum().backward()
-    backbones.set_hip_forward(False)
-    try:
-        yr = ref(x.double())
-        (yr * r.double()).sum().backward()
-    finally:
-        backbones.set_hip_forward(True)
+    yr = BR.mobilenet_forward(ref, x.double())
+    (yr * r.double()).sum().backward()
     e_out, tot = rel(y, yr), _grad_err(list(m.parameters()), list(ref.parameters()))
     print(f'[parity] mobilenet_v2, 4 frames, eval-mode BatchNorm: pose vector {e_out:.2e}, all-gradients {tot:.2e}')
     assert e_out < 3e-5 and tot < 2e-3, (e_out, tot)
 
 
-def test_strict_hip_switch_refuses_the_stock_layer_fallback(monkeypatch):
-    """LP_STRICT_HIP=1 (bench.py sets it): a geometry outside the hand-written encoders raises instead of quietly running MIOpen"""
+@pytest.mark.parametrize('n,size', [(1, 256), (2, 128), (2, 64)])
+def test_mobilenet_v2_few_frames_forward_backward(n, size):
+    """ ``mobilenet_hip.supported`` admits any N with N * H/32 * W/32 >= 8 and a multiple of 4 -- one frame of 256 px, two of
+    128 or 64 px: the whole training path (BatchNorm statistics, depthwise kernels, the flat_hw flattening of every stage) at N < 4,
+    forward + all gradients against the stock layers in fp64 (eval-mode BatchNorm: a well-conditioned comparison)"""
+    from embedders import mobilenet_hip
+    from oracle import backbones_ref as BR
+    from test_resnext_hip import _grad_err, structured_frames
+    assert mobilenet_hip.supported(n, size, size)
+    m, ref = _nets(17 + n, False)
+    m.eval(); ref.eval()
+    x = structured_frames(n, size, 9).cuda()
+    r = torch.randn(n, 256, device='cuda')
+    y = m(x)
+    assert m.__dict__.get('_hip_feature_param_names') is not None, 'the HIP training path did not run'
+    (y * r).sum().backward()
+    yr = BR.mobilenet_forward(ref, x.double())
+    (yr * r.double()).sum().backward()
+    e_out, tot = rel(y, yr), _grad_err(list(m.parameters()), list(ref.parameters()))
+    print(f'[parity] mobilenet_v2, {n} frame(s) of {size} px, eval-mode BatchNorm: pose vector {e_out:.2e}, all-gradients {tot:.2e}')
+    assert e_out < 3e-5 and tot < 2e-3, (e_out, tot)
+
+
+def test_geometry_outside_the_kernels_raises():
+    """one backend by construction: a geometry outside the hand-written encoders, or a CPU tensor, RAISES (the stock-layer evaluation
+    lives in oracle/backbones_ref.py and is reachable from tests only)"""
     from embedders import backbones
-    monkeypatch.setenv('LP_STRICT_HIP', '1')
     m = backbones.mobilenet_v2(8).cuda().train()
-    with pytest.raises(RuntimeError, match='LP_STRICT_HIP'):
+    with pytest.raises(RuntimeError, match='outside the HIP path'):
         m(torch.rand(2, 3, 32, 32, device='cuda'))
+    with pytest.raises(RuntimeError, match='outside the HIP path'):
+        m.cpu()(torch.rand(2, 3, 64, 64))
     e = backbones.resnext50_32x4d(8).cuda().train()
-    with pytest.raises(RuntimeError, match='LP_STRICT_HIP'):
+    with pytest.raises(RuntimeError, match='outside the HIP path'):
         e(torch.rand(8, 3, 64, 64, device='cuda'))
+    with pytest.raises(RuntimeError, match='outside the HIP path'):
+        e(torch.rand(4, 3, 128, 128, device='cuda'))

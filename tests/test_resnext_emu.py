@@ -1,7 +1,7 @@
 """CPU check of the ORCHESTRATION of the embedder's HIP path (embedders/resnext_hip.py): with every ``hipops`` entry point replaced by
 its plain-torch emulation (tests/emu_ops.py), the ResNeXt-50 autograd.Function -- which kernel runs on which tensor in which order,
-what is saved for backward, how stride-2 blocks / downsample branches / the stem / the classifier are wired -- must reproduce the stock
-nn.Module's output, every parameter gradient and every BatchNorm buffer update, in train and in eval mode (fp64: to rounding).
+what is saved for backward, how stride-2 blocks / downsample branches / the stem / the classifier are wired -- must reproduce the stock-layer
+evaluation (oracle/backbones_ref.py) -- output, every parameter gradient and every BatchNorm buffer update, in train and in eval mode (fp64: to rounding).
 The kernels themselves are checked against the same emulation functions on the GPU (tests/test_resnext_hip.py)."""
 import copy
 import os
@@ -9,6 +9,8 @@ import sys
 
 import pytest
 import torch
+
+from oracle import backbones_ref as BR
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'latent_pose_reenactment_amd'))
@@ -40,7 +42,7 @@ def test_resnext_function_matches_stock_autograd(monkeypatch, train, mode):
     m.train(train); m2.train(train)
     x = torch.rand(8, 3, 64, 64, dtype=torch.double)      # (the emulation has no geometry limits: small = fast)
     r = torch.randn(8, 16, dtype=torch.double)
-    y_ref = m(x)
+    y_ref = BR.resnext_forward(m, x)
     (y_ref * r).sum().backward()
     assert resnext_hip.supported(8, 128, 128) and not resnext_hip.supported(8, 64, 64) and not resnext_hip.supported(2, 128, 128)
     m2._hip_structure()
@@ -77,7 +79,7 @@ def test_mobilenet_training_path_matches_stock_autograd(monkeypatch, train):
     m.train(train); m2.train(train)
     x = torch.rand(8, 3, 64, 64, dtype=torch.double)
     r = torch.randn(8, 16, dtype=torch.double)
-    y_ref = m(x)
+    y_ref = BR.mobilenet_forward(m, x)
     (y_ref * r).sum().backward()
     y = m2._forward_hip_train(x)
     (y * r).sum().backward()

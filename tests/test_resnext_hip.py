@@ -393,7 +393,7 @@ def test_resnext_forward_backward_vs_fp64(monkeypatch, prec_name, train, depth):
     fp32 layers themselves are 2e-2 off in the gradients), so the full-depth net only gets calibrated bounds; the SHALLOW variant
     (layers [2,1,1,1]: every kernel configuration -- group sizes 4/8/16/32, stride 1/2, identity and downsample blocks, stem, classifier --
     at a depth where arithmetic error is not amplified) carries the per-mode gates."""
-    from embedders import backbones
+    from oracle import backbones_ref as BR
     monkeypatch.setenv('LP_PREC_E', prec_name)
     size = 128
     m, ref = _nets(32, 7, (2, 1, 1, 1) if depth == 'shallow' else (3, 4, 6, 3))
@@ -405,14 +405,10 @@ def test_resnext_forward_backward_vs_fp64(monkeypatch, prec_name, train, depth):
     y = m(x)
     assert m.__dict__.get('_hip_param_names') is not None, 'the HIP path did not run'
     (y * r).sum().backward()
-    backbones.set_hip_forward(False)
-    try:
-        yr = ref(x.double())
-        (yr * r.double()).sum().backward()
-        y32 = m32(x)
-        (y32 * r).sum().backward()
-    finally:
-        backbones.set_hip_forward(True)
+    yr = BR.resnext_forward(ref, x.double())
+    (yr * r.double()).sum().backward()
+    y32 = BR.resnext_forward(m32, x)
+    (y32 * r).sum().backward()
     berr = {k: rel(b.double(), q) for (k, b), (_, q) in zip(m.named_buffers(), ref.named_buffers()) if b.dtype.is_floating_point}
     e_out, e_b = rel(y, yr), max(berr.values())
     tot = _grad_err(list(m.parameters()), list(ref.parameters()))
