@@ -365,17 +365,64 @@ def _numa_nodes():
     return nodes
 
 
+def _cpu_generator_only(args, sample_batch):
+    """-> a callable: generator forward + backward of `sample_batch` images through the oracle (BASELINE.md section 3: the generator-only row;
+    the same white-noise loss as `bench.py --workload generator`)"""
+    import copy
+    from oracle import lp_oracle as O
+    from generators.vector_pose_unsupervised_segmentation_noBottleneck import Wrapper as GW
+    a = copy.copy(args)
+    a.device = 'cpu'
+    torch.manual_seed(0)
+    G = GW.get_net(a)
+    sd = {k: v.detach().clone() for k, v in G.state_dict().items()}
+    params = [k for k, _ in G.named_parameters()]
+    for k in params:
+        sd[k].requires_grad_(True)
+    e, p = torch.randn(sample_batch, a.embed_channels), torch.randn(sample_batch, a.pose_embedding_size)
+
+    def one():
+        rgb, segm = O.generator_forward(sd, e, p, num_channels=64, max_num_channels=512, image_size=a.image_size, train=True)
+        torch.autograd.grad(rgb.mean() + segm.mean(), [sd[k] for k in params], allow_unused=True)
+    return one
+
+
+def _cpu_drive_frame(args):
+    """-> a callable: ONE frame of the drive.py loop (drive.py:84-88): MobileNetV2 pose encoder + generator, B = 1, eval mode, no autograd"""
+    import copy
+    from oracle import lp_oracle as O
+    from oracle import backbones_ref as BR
+    from generators.vector_pose_unsupervised_segmentation_noBottleneck import Wrapper as GW
+    from embedders.backbones import mobilenet_v2
+    a = copy.copy(args)
+    a.device = 'cpu'
+    torch.manual_seed(0)
+    G, pose_net = GW.get_net(a), mobilenet_v2(a.pose_embedding_size).eval()
+    G.enable_finetuning({'embeds': torch.randn(1, a.embed_channels) * 0.1})
+    sd = {k: v.detach().clone() for k, v in G.state_dict().items()}
+    frame = torch.rand(1, 3, a.image_size, a.image_size)
+
+    def one():
+        with torch.no_grad():
+            pose = BR.mobilenet_forward(pose_net, frame)
+            O.generator_forward(sd, sd['identity_embedding'], pose, num_channels=64, max_num_channels=512, image_size=a.image_size, train=False)
+    return one
+
+
 def cpu_worker(spec):
-    """child process of cpu_baseline: `threads,batch,warm,reps,budget,image_size,meta` -> one JSON line {"t": median seconds per step, "n": timed steps}
+    """child process of cpu_baseline: `threads,batch,warm,reps,budget,image_size,kind` -> one JSON line {"t": median seconds per step, "n": timed steps}
     (its own process so that OMP_NUM_THREADS / torch.set_num_threads / the CPU affinity take effect before any CPU kernel has run).
+    kind 0: fine-tuning step, 1: meta-training step, 2: generator forward + backward only, 3: one drive.py frame.
     LP_CPU_AFFINITY = comma-separated logical cpus: pin this worker (one worker per NUMA node)."""
-    threads, batch, warm, reps, budget, image_size, meta = [int(float(v)) for v in spec.split(',')]
+    threads, batch, warm, reps, budget, image_size, kind = [int(float(v)) for v in spec.split(',')]
     aff = os.environ.get('LP_CPU_AFFINITY')
     if aff and hasattr(os, 'sched_setaffinity'):
         os.sched_setaffinity(0, {int(c) for c in aff.split(',')})
     torch.set_num_threads(threads)
-    args = make_args(image_size, 8, 'cpu', 1, 0, 'bf16x3', finetune=not meta)
-    t, n = _median_time((_cpu_step_metatrain if meta else _cpu_step)(args, batch), warm, reps, budget)
+    args = make_args(image_size, 8, 'cpu', 1, 0, 'bf16x3', finetune=kind != 1)
+    fn = {0: lambda: _cpu_step(args, batch), 1: lambda: _cpu_step_metatrain(args, batch), 2: lambda: _cpu_generator_only(args, batch),
+          3: lambda: _cpu_drive_frame(args)}[kind]()
+    t, n = _median_time(fn, warm, reps, budget)
     print(json.dumps({'t': t, 'n': n, 'threads': torch.get_num_threads()}))
 
 
@@ -401,14 +448,16 @@ def cpu_baseline(args, full=False, workload='metatrain_step'):
                  for i in range(0, len(nodes), 2)]
     per = 8 // len(nodes)
 
-    def spawn(threads, batch, w, r, budget, cpus=None):
+    def spawn(threads, batch, w, r, budget, cpus=None, kind=None):
         # OMP_WAIT_POLICY=passive: the autograd engine's thread runs its own OpenMP team beside the forward thread's; with active waiting
         # the two teams of a pinned worker spin against each other on the same cores (measured: 145 - 207 s per step instead of ~20 s)
         env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), OMP_WAIT_POLICY='passive', GOMP_SPINCOUNT='0')
         if cpus:
             env['LP_CPU_AFFINITY'] = ','.join(str(c) for c in cpus)
-        return subprocess.Popen([sys.executable, os.path.abspath(__file__), '--cpu-worker', f'{threads},{batch},{w},{r},{budget},{args.image_size},{meta}'],
-                                env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        #  stderr goes to /dev/null: the workers are waited for one at a time, and a later one that filled a 64 KB stderr pipe
+        # with warnings would block -- and be timed -- until its turn
+        return subprocess.Popen([sys.executable, os.path.abspath(__file__), '--cpu-worker', f'{threads},{batch},{w},{r},{budget},{args.image_size},{kind if kind is not None else meta}'],
+                                env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
 
     def result(proc, budget):
         out, _ = proc.communicate(timeout=budget * 4 + 900)
@@ -419,7 +468,28 @@ def cpu_baseline(args, full=False, workload='metatrain_step'):
     t_all = max(r['t'] for r in rs)
     used = sum(len(phys) for _, phys, _e in nodes)
     o = result(spawn(1, 1, warm if full else 1, reps if full else 2, 900 if full else 40), 900 if full else 40)
+    # BASELINE.md section 3 also asks for the generator-only fwd+bwd and the drive.py single frame on the host cores: one process on the cores of
+    # ONE NUMA node (a B = 8 generator batch does not split over processes without changing nothing but the bookkeeping; a frame is B = 1),
+    # and the frame also with 1 thread, the reference's own setting
+    extra = {}
+    try:
+        node0 = nodes[0]
+        g_ = result(spawn(len(node0[1]), 8, 1, 3 if full else 2, 120 if full else 30, node0[2], kind=2), 120 if full else 30)
+        d_ = result(spawn(len(node0[1]), 1, 1, 5 if full else 3, 60 if full else 20, node0[2], kind=3), 60 if full else 20)
+        d1 = result(spawn(1, 1, 1, 5 if full else 2, 60 if full else 20, kind=3), 60 if full else 20)
+        extra = {'generator_only': {'value': round(8 / g_['t'], 3), 'unit': 'images/s', 'cores': len(node0[1]), 's_per_step': round(g_['t'], 3),
+                                    'sample': f"generator forward + backward, bs 8 at {args.image_size}x{args.image_size}, oracle/lp_oracle.py on the {len(node0[1])} physical cores "
+                                              f"of NUMA node {node0[0]}; median of {g_['n']} step(s)"},
+                 'drive_frame': {'value': round(1 / d_['t'], 3), 'unit': 'frames/s', 'cores': len(node0[1]), 'ms_per_frame': round(d_['t'] * 1e3, 1),
+                                 'one_thread': {'value': round(1 / d1['t'], 3), 'unit': 'frames/s', 'cores': 1, 'ms_per_frame': round(d1['t'] * 1e3, 1)},
+                                 'sample': f"drive.py:84-88 loop body (MobileNetV2 stock layers + oracle generator, eval, B = 1, {args.image_size}x{args.image_size}); "
+                                           f"median of {d_['n']} / {d1['n']} frame(s)"}}
+    except Exception as ex:
+        extra = {'generator_only': {'error': repr(ex)}}
     return {'value': round(8 / t_all, 4), 'unit': 'images/s', 'cores': used, 'kind': 'port', 'cpu_model': model, 'physical_cores': cores,
+            'value_is': 'aggregate throughput of the concurrent per-NUMA-node workers (each steps its share of the 8 samples: per-worker BatchNorm / dice '
+                        'statistics, no gradient exchange between them) -- the most favourable reading of "all cores" for the CPU',
+            **extra,
             'logical_cpus': logical, 'workload': workload, 'numa_workers': [{'node': n_, 'cores': len(c_), 'samples': per, 's_per_step': round(r['t'], 3), 'timed_steps': r['n']}
                                                                             for (n_, c_, _e), r in zip(nodes, rs)],
             'one_thread': {'value': round(1 / o['t'], 4), 'unit': 'images/s', 'cores': 1,
@@ -431,8 +501,9 @@ def cpu_baseline(args, full=False, workload='metatrain_step'):
                       + ('' if full else '; bounded sample -- the >= 3 + >= 10 protocol is `bench.py --cpu-baseline-full` (profiles/)')}
 
 
-def drive_fps(args, frames=60):
-    """drive.py hot loop (drive.py:84-88): per frame pose encoder + generator, B = 1, eval mode, replayed as one hipGraph."""
+def drive_fps(args, frames=60, batch=1):
+    """drive.py hot loop (drive.py:84-88): per frame pose encoder + generator, eval mode, replayed as one hipGraph; ``batch`` driving frames
+    per iteration (1: the reference's loop; 8: drive.py --batch_size 8 of this package, ``drive_frames``)."""
     from generators.vector_pose_unsupervised_segmentation_noBottleneck import Wrapper as GW
     from embedders.unsupervised_pose_separate_embResNeXt_segmentation import Wrapper as EW
     torch.manual_seed(5)
@@ -440,7 +511,7 @@ def drive_fps(args, frames=60):
     G.enable_finetuning({'embeds': torch.randn(1, args.embed_channels, device=args.device) * 0.1})
     E.enable_finetuning()
     G.eval(); E.eval()
-    frame = torch.rand(1, 1, 3, args.image_size, args.image_size, device=args.device)
+    frame = torch.rand(batch, 1, 3, args.image_size, args.image_size, device=args.device)
     out = {}
 
     def one():
@@ -473,7 +544,7 @@ def drive_fps(args, frames=60):
             step()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-    return {'value': round(frames / dt, 2), 'unit': 'frames/s', 'ms_per_frame': round(dt / frames * 1e3, 3), 'batch': 1,
+    return {'value': round(frames * batch / dt, 2), 'unit': 'frames/s', 'ms_per_frame': round(dt / (frames * batch) * 1e3, 3), 'ms_per_iteration': round(dt / frames * 1e3, 3), 'batch': batch,
             'launch_mode': mode, 'note': 'drive.py:84-88 loop (MobileNetV2 pose encoder + generator on the HIP kernels, eval mode, '
                                           '16-bit weight packs cached), frames resident in HBM'}
 
@@ -488,20 +559,68 @@ def encoder_modes(tm):
         return ''
 
 
-def measured_parity(mode, workload):
-    """the parity statement of a precision assignment: MEASURED figures, written by tests/test_metatrain_full_gpu.py (the full configs[2]
-    forward at 256 x 256, 8 x 8 encoder frames, 98000 labels against fp64 stock encoders + the CPU oracle) into profiles/ -- never a literal"""
-    path = os.path.join(ROOT, 'profiles', f'r04_parity_configs2_{mode}.json')
+def _load_profile(name):
+    """-> (dict | None, stale flag, reason) of a measured file under profiles/ (``source_stamp`` of the tree that produced it inside)"""
+    path = os.path.join(ROOT, 'profiles', name)
     try:
         res = json.load(open(path))
     except Exception:
-        return {'status': 'unmeasured', 'note': f'{os.path.relpath(path, ROOT)} not present: run tests/test_metatrain_full_gpu.py with LP_PARITY_OUT=profiles'}
+        return None, True, f'profiles/{name} not present'
+    stale, why = stamp_status(res.get('stamp'))
+    return res, stale, why
+
+
+def measured_parity(mode, workload):
+    """the parity statement of a precision assignment: MEASURED figures, never a literal.
+      forward  : tests/test_metatrain_full_gpu.py -- the full configs[2] forward (256 x 256, 8 x 8 encoder frames, 98000 labels) against fp64
+                 stock encoders + the CPU oracle; every figure is the PLAIN rel-L2 |a - b| / |b| (the conditioned figure of the projection
+                 score is an extra column);
+      gradients: tests/test_full_size_parity.py (G, D, VGG19, VGGFace at 256 x 256: tie-masked against the oracle) and
+                 tests/test_e1_full_gpu.py (identity encoder, 64 frames: all-gradient rel-L2 / cosine vs fp64 with the stock-fp32 calibration).
+    The files carry the source stamp of the tree that produced them; a file whose stamp differs from the running tree is reported STALE."""
+    res, stale, why = _load_profile(f'r05_parity_configs2_{mode}.json')
+    if res is None:
+        return {'status': 'unmeasured', 'note': why + ': run tests/test_metatrain_full_gpu.py with LP_PARITY_OUT=profiles'}
     worst = max(res['errors'].items(), key=lambda kv: kv[1])
-    out = {'status': 'measured', 'source': f'tests/test_metatrain_full_gpu.py -> {os.path.relpath(path, ROOT)}', 'geometry': res.get('geometry'),
+    out = {'status': 'stale' if stale else 'measured', 'stale': stale, 'source': f'tests/test_metatrain_full_gpu.py -> profiles/r05_parity_configs2_{mode}.json',
+           'geometry': res.get('geometry'),
            'identity_encoder_fp16_tail_blocks': res['identity_encoder_blocks'].count('f16') if res['identity_encoder_blocks'][0] != 'f16' else 'all',
-           'rel_l2_vs_reference_chain': {k: float(f'{v:.3g}') for k, v in res['errors'].items()},
+           'critic_fake_to_G_pass': res.get('critic_fake_to_G_pass'),
+           'plain_rel_l2_vs_reference_chain': {k: float(f'{v:.3g}') for k, v in res['errors'].items()},
            'worst': [worst[0], float(f'{worst[1]:.3g}')], 'within_1e-3': bool(worst[1] < 1e-3),
+           'conditioned_extra_column': {k: float(f'{v:.3g}') for k, v in (res.get('conditioned') or {}).items()},
            'stock_fp32_encoders_vs_fp64': res.get('stock_fp32_encoders_vs_fp64')}
+    if stale:
+        out['stale_reason'] = why
+    g, gstale, gwhy = _load_profile(f"r05_parity_gradients_{'f16' if mode == 'default' else mode}.json")
+    if g is None:
+        out['gradients'] = {'status': 'unmeasured', 'note': gwhy}
+    else:
+        r3 = lambda v: float(f'{v:.3g}')
+        grads = {'status': 'stale' if gstale else 'measured', 'stale': gstale,
+                 'source': 'tests/test_full_size_parity.py + tests/test_e1_full_gpu.py -> profiles/' + f"r05_parity_gradients_{'f16' if mode == 'default' else mode}.json"}
+        tie = {}
+        if 'generator' in g:
+            tie['generator'] = r3(g['generator']['tie_masked_worst'][1])
+        if 'discriminator' in g:
+            tie['discriminator_G_loss'] = r3(g['discriminator']['tie_masked_worst_G_loss'][1])
+            tie['discriminator_D_loss'] = r3(g['discriminator']['tie_masked_worst_D_loss'][1])
+        for k in ('vgg19', 'vggface'):
+            if k in g:
+                tie[k + '_d_image'] = r3(g[k]['tie_masked_d_fake'])
+        grads['tie_masked_worst_rel_l2'] = tie
+        grads['within_1e-3'] = bool(tie) and all(v < 1e-3 for v in tie.values())
+        if 'identity_encoder' in g:
+            e = g['identity_encoder']
+            grads['identity_encoder'] = {'all_gradients_rel_l2': r3(e['all_gradients_rel']), 'all_gradients_cosine': r3(e['all_gradients_cosine']),
+                                         'stock_fp32_layers_all_gradients_rel_l2': r3(e['stock_fp32_layers_vs_fp64']['all_gradients_rel']),
+                                         'note': 'train-mode BatchNorm at random initialisation is chaotic: the stock fp32 layers (the reference\'s own '
+                                                 'arithmetic class) are this far from fp64 themselves; no 1e-3 claim is made for these gradients in any mode'}
+        if gstale:
+            grads['stale_reason'] = gwhy
+        out['gradients'] = grads
+    out['gates_met'] = {'forward_quantities_and_losses_1e-3': out['within_1e-3'] and not stale,
+                        'tie_masked_parameter_gradients_1e-3 (G, D, VGG)': bool(out['gradients'].get('within_1e-3')) and not out['gradients'].get('stale', True)}
     if workload != 'metatrain_step':
         out['note'] = 'figures of the meta-training configuration (this workload shares its generator, discriminator and criterions; its pose encoder runs without autograd)'
     return out
@@ -649,6 +768,23 @@ def main():
         else:
             os.environ['LP_OVERLAP'] = keep_overlap
     prof, hipops.PROFILE = hipops.PROFILE, None
+    replicas = None
+    if world > 1 and a.workload != 'generator':
+        # data-parallel invariant (apex Reducer semantics, train.py:196-200): after any number of steps every rank holds bit-identical parameters
+        # (same start by broadcast, same averaged gradients, same optimizer arithmetic).  Checked on the parameters' BIT patterns: two int64
+        # checksums per rank, MIN and MAX over ranks must agree.
+        with torch.no_grad():
+            flat = torch.cat([p_.detach().reshape(-1) for m_ in (tm.generator, tm.embedder, tm.discriminator) for p_ in m_.parameters()])
+            bits = flat.view(torch.int32).to(torch.int64)
+            cs = torch.stack([bits.sum(), (bits * (torch.arange(bits.numel(), device=device, dtype=torch.int64) % 65521 + 1)).sum()])
+            lo, hi = cs.clone(), cs.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            replicas = {'bit_identical_parameters': bool((lo == hi).all().item()), 'parameters': int(flat.numel()),
+                        'after_steps': a.warmup + a.steps + 2,
+                        'note': 'checked after the warm-up, timed and instrumented steps, BEFORE the exchange-free single-GPU leg (which lets the ranks drift apart on purpose)'}
+            del flat, bits
+
     solo = None
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -717,30 +853,28 @@ def main():
                 entry.pop(k_, None)
         if kind == 'conv_igemm':
             # HBM bytes per launch of this kernel family from the committed PMC passes: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs
-            # of THIS workload (the meta-training step), counter collection restricted to the 3x3 kernels (scripts/r04_artifacts.sh; FETCH_SIZE
-            # doubled per MI355X_MICROARCH.md).  Round-3 file (generator-only population) as the fallback.
-            try:
-                pm_path = os.path.join(ROOT, 'profiles', 'r04_pmc_conv3x3_metatrain.json')
-                pop = 'the launch population of the meta-training step (warm-up, capture and replays of `bench.py --steps 2 --warmup 1`)'
-                if not os.path.exists(pm_path):
-                    pm_path = os.path.join(ROOT, 'profiles', 'r03_pmc_conv_dma_step.json')
-                    pop = 'the launch population of one generator fwd+bwd step (round 3)'
-                pm = json.load(open(pm_path))
+            # of THIS workload (the meta-training step), counter collection restricted to the 3x3 kernels (scripts/r05_artifacts.sh; FETCH_SIZE
+            # doubled per MI355X_MICROARCH.md).  The file carries the source stamp of the tree it was measured on: a stale file is SAID to be stale.
+            pm, pstale, pwhy = _load_profile('r05_pmc_conv3x3_metatrain.json')
+            if pm is not None:
                 entry['traffic'] = pm.get('hbm_bytes_per_launch')
-                entry['traffic_note'] = (f'mean HBM bytes per 3x3 conv launch (conv_pipe_kernel + conv_dma_kernel<3>) over {pop}: '
-                                         f'{os.path.relpath(pm_path, ROOT)}, separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, '
-                                         '(2 x FETCH_SIZE + WRITE_SIZE) x 1024 per MI355X_MICROARCH.md; MFMA busy fraction from '
-                                         f"SQ_VALU_MFMA_BUSY_CYCLES: {pm.get('mfma_busy_fraction')}")
+                entry['traffic_stale'] = pstale
+                entry['traffic_note'] = ('mean HBM bytes per 3x3 conv launch (conv_pipe_kernel + conv_dma_kernel<3>) over the launch population of the '
+                                         'meta-training step (warm-up, capture and replays of `bench.py --steps 2 --warmup 1`): profiles/r05_pmc_conv3x3_metatrain.json, '
+                                         'separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per MI355X_MICROARCH.md; '
+                                         f"MFMA busy fraction from SQ_VALU_MFMA_BUSY_CYCLES: {pm.get('mfma_busy_fraction')}" + (f' -- STALE: {pwhy}' if pstale else ''))
                 entry['mfma_busy_fraction_pmc'] = pm.get('mfma_busy_fraction')
-            except Exception:
-                entry['traffic_note'] = 'no PMC summary under profiles/'
+            else:
+                entry['traffic_note'] = 'no PMC summary of this round under profiles/ (' + pwhy + ')'
             entry['algorithmic_bytes_note'] = ('f16 operands: 2 B per input activation (once per N tile), 2 B per weight, 4 B per fp32 output '
-                                               '(+ 2 B when the epilogue also emits the consumer planes)')
-            try:      # the same family INSIDE the graph replay (rocprofv3 kernel trace of the captured step: no eager launch gaps)
-                ig = json.load(open(os.path.join(ROOT, 'profiles', 'r04_conv3x3_in_graph.json')))
-                entry['in_graph'] = ig
-            except Exception:
-                pass
+                                               '(+ 2 B when the epilogue also emits the consumer planes; planes-only outputs: 2 B)')
+            entry['frac_note'] = ('frac / achieved: LIVE -- HIP events on the launch stream around every launch of the family in two eager one-stream steps of this '
+                                  'process (each event pair adds a few microseconds to a ~35 us launch); in_graph: the same family inside the captured step '
+                                  '(rocprofv3 kernel trace of a graph replay x the shape list, scripts/in_graph_conv.py) -- the figure without eager launch gaps')
+            ig, istale, iwhy = _load_profile('r05_conv3x3_in_graph.json')
+            if ig is not None:      # the same family INSIDE the graph replay (rocprofv3 kernel trace of the captured step: no eager launch gaps)
+                entry['in_graph'] = dict(ig, stale=istale, **({'stale_reason': iwhy} if istale else {}))
+                entry['frac_in_graph'] = ig.get('frac')
         if kind == 'conv_igemm':
             entry['kernel'] = 'conv_pipe_kernel / conv_dma_kernel<3> (lp_conv16_fwd: forward and data-gradient 3x3 convs)'
             roof = entry
@@ -785,9 +919,12 @@ def main():
             out['parity'] = measured_parity('default' if a.prec == 'f16' and not os.environ.get('LP_PREC_E') else a.prec, a.workload)
         if solo is not None:
             out['single_gpu_same_workload'] = solo
+        if replicas is not None:
+            out['replicas'] = replicas
         if world == 1 and not a.no_drive:
             try:
                 out['drive'] = drive_fps(args)
+                out['drive']['batch_8'] = {k: v for k, v in drive_fps(args, frames=30, batch=8).items() if k != 'note'}
             except Exception as ex:
                 out['drive'] = {'error': repr(ex)}
         def child(extra_args, timeout=600):

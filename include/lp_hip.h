@@ -281,6 +281,19 @@ int lp_bn_add_act(const float* y, const float* scale, const float* shift, const 
 int lp_bn_add_act16(const uint16_t* y16, const float* scale, const float* shift, const float* res, const float* res_scale,
                     const float* res_shift, float* out, uint16_t* hi, long long P, int C, int relu, void* stream);
 int lp_bn_act16(const uint16_t* y16, const float* scale, const float* shift, uint16_t* out_hi, long long P, int C, int relu, void* stream);
+/*   The generator's 16-bit-resident conv outputs (round 5; fp16 mode: no fp32 copy of a conv output between the AdaIN blocks):
+ *   lp_adain_act16:      out_hi = fp16((relu?)(y16[n]*scale[n][c]+shift[n][c])), per-IMAGE affines [N][C] -- AdaptiveNorm2d + ReLU
+ *                        (generators/common/blocks.py:18-26,70-73) as the prologue of the next conv, 2 B read + 2 B written per element
+ *   lp_adain_relu_bwd16: lp_adain_relu_bwd with x given as that fp16 plane (x-hat and the ReLU pattern from the values the forward normalised)
+ *   lp_thin_wgrad16:     lp_thin_wgrad of a conv with <= 4 output channels (the head, noBottleneck.py:80-88) on the fp16 plane of its input */
+int lp_adain_act16(const uint16_t* y16, const float* scale, const float* shift, uint16_t* out_hi, int N, long long HW, int C, int relu,
+                   void* stream);
+int lp_adain_relu_bwd16(const float* dA, const uint16_t* x16, const float* add, const float* gamma, int ab_stride,
+                        const float* mean, const float* rstd, const float* scale, const float* shift,
+                        float* dx, float* dgamma, float* dbeta, float* workspace,
+                        int N, int H, int W, int C, int upsample, float* amax_slots, void* stream);
+int lp_thin_wgrad16(const uint16_t* x16, const float* dy, float* dw, float* workspace, const float* scale, const float* shift,
+                    int N, int H, int W, int Cin, int Cout, int ksize, int pro, int splits, void* stream);
 int lp_subsample2(const void* in, void* out, int N, int H, int W, int row_bytes, void* stream);
 int lp_zero_stuff2(const void* in, void* out, int N, int H, int W, int row_bytes, void* stream);
 int lp_add_strided2(float* d, const float* s, int N, int H, int W, int C, void* stream);

@@ -79,6 +79,9 @@ SIGNATURES = {
     'lp_bn_add_act': (_i, [_vp] * 9 + [_ll, _i, _i, _i, _vp]),
     'lp_bn_add_act16': (_i, [_vp] * 8 + [_ll, _i, _i, _vp]),
     'lp_bn_act16': (_i, [_vp] * 4 + [_ll, _i, _i, _vp]),
+    'lp_adain_act16': (_i, [_vp] * 4 + [_i, _ll, _i, _i, _vp]),
+    'lp_adain_relu_bwd16': (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    'lp_thin_wgrad16': (_i, [_vp] * 6 + [_i] * 8 + [_vp]),
     'lp_subsample2': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'lp_zero_stuff2': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'lp_add_strided2': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

@@ -18,6 +18,7 @@
 
 struct ThinParams {
     const float* x; const float* dy; float* part; float* dw;
+    const uint16_t* x16;             // !THIN_X only: the wide operand as a 16-bit-resident fp16 plane [N][H][W][Cin] instead of fp32 x (NULL: fp32)
     float* bpart; float* dbias;      // NULL | [G][Cout] partial column sums of dy (THIN_X only) and the bias gradient they reduce to
     const float* scale; const float* shift;
     int N, H, W, Cin, Cout, pro, G;
@@ -67,12 +68,14 @@ __global__ __launch_bounds__(256) void wgrad_thin_kernel(ThinParams p) {
         const int nrow = min(RB, p.H - y0);
         const int npx = nrow * p.W;                                      // pixels of the group, row-major; this wave: ph, ph+4, ...
         const float* wbase = wide + (size_t)(n * p.H + y0) * p.W * wideC + wc;
+        const uint16_t* wbase16 = (!THIN_X && p.x16) ? p.x16 + (size_t)(n * p.H + y0) * p.W * wideC + wc : nullptr;
         for (int j0 = ph; j0 < npx; j0 += 4 * UB) {
             float av[UB];
 #pragma unroll
             for (int u = 0; u < UB; ++u) {
                 const int j = j0 + 4 * u;
-                av[u] = wbase[(size_t)(j < npx ? j : 0) * wideC];          // unconditional load, masked below
+                if (!THIN_X && wbase16) av[u] = lp_op16_to_f32<true>(wbase16[(size_t)(j < npx ? j : 0) * wideC]);
+                else av[u] = wbase[(size_t)(j < npx ? j : 0) * wideC];          // unconditional load, masked below
             }
 #pragma unroll
             for (int u = 0; u < UB; ++u) {
@@ -161,10 +164,19 @@ bool lp_wgrad_thin_supported(int Cin, int Cout, int ksize, int upsample, int pro
 }
 
 // workspace: the caller's lp_conv_wgrad workspace (splits * T * 64 * 64k floats) holds G <= 16 * splits slabs of T * 4 * wide
+static int wgrad_thin_impl(const float* x, const uint16_t* x16, const float* dy, float* dw, float* workspace, const float* scale, const float* shift,
+                           int N, int H, int W, int Cin, int Cout, int ksize, int pro, int splits, float* dbias, hipStream_t stream);
+
 int lp_wgrad_thin(const float* x, const float* dy, float* dw, float* workspace, const float* scale, const float* shift, int N, int H,
                   int W, int Cin, int Cout, int ksize, int pro, int splits, float* dbias, hipStream_t stream) {
+    return wgrad_thin_impl(x, nullptr, dy, dw, workspace, scale, shift, N, H, W, Cin, Cout, ksize, pro, splits, dbias, stream);
+}
+
+static int wgrad_thin_impl(const float* x, const uint16_t* x16, const float* dy, float* dw, float* workspace, const float* scale, const float* shift,
+                           int N, int H, int W, int Cin, int Cout, int ksize, int pro, int splits, float* dbias, hipStream_t stream) {
     const bool thin_x = (Cin <= 4 && Cout % 64 == 0 && pro == 0);
     ThinParams p;
+    p.x16 = thin_x ? nullptr : x16;
     p.x = x; p.dy = dy; p.part = workspace; p.dw = dw; p.scale = scale; p.shift = shift;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.pro = pro;
     int G = N * ((H + 3) / 4);                  // row groups (RB = 4 rows each)
@@ -429,6 +441,17 @@ extern "C" int lp_thin_wgrad_supported(int Cin, int Cout, int ksize, int pro, in
 }
 
 extern "C" int lp_thin_wgrad_has_dbias(int Cin, int Cout) { (void)Cin; return Cout > 4; }
+
+// lp_thin_wgrad for a conv with <= 4 OUTPUT channels (the generator head, 64 -> 4) whose wide input is a 16-bit-resident conv output:
+// x16 = the unscaled fp16 plane [N][H][W][Cin] (Cin % 64 == 0), AdaIN + ReLU prologue (pro 1) applied on the fly as in the fp32 form
+extern "C" int lp_thin_wgrad16(const uint16_t* x16, const float* dy, float* dw, float* workspace, const float* scale, const float* shift,
+                               int N, int H, int W, int Cin, int Cout, int ksize, int pro, int splits, void* stream) {
+    if (!x16 || !dy || !dw || !workspace) return lp_set_error(LP_ERR_ARG, "lp_thin_wgrad16: null pointer");
+    if (pro == 1 && (!scale || !shift)) return lp_set_error(LP_ERR_ARG, "lp_thin_wgrad16: pro=1 needs scale/shift");
+    if (!(Cout <= 4 && Cin % 64 == 0 && ksize == 3) || !lp_wgrad_thin_supported(Cin, Cout, ksize, 0, pro, W))
+        return lp_set_error(LP_ERR_UNSUPPORTED, "lp_thin_wgrad16: needs Cout <= 4, Cin % 64 == 0, 3x3, rows that fit LDS");
+    return wgrad_thin_impl(nullptr, x16, dy, dw, workspace, scale, shift, N, H, W, Cin, Cout, ksize, pro, splits, nullptr, (hipStream_t)stream);
+}
 
 extern "C" int lp_thin_wgrad(const float* x, const float* dy, float* dw, float* workspace, const float* scale, const float* shift,
                              int N, int H, int W, int Cin, int Cout, int ksize, int pro, int splits, float* dbias, void* stream) {

@@ -293,7 +293,17 @@ extern "C" int lp_bn_train_stats(const float* y, const float* gamma, const float
 // mask_mode 0: the activation's own pattern 0 < x*scale+shift < act_hi (ReLU: act_hi = inf; ReLU6: 6);  1: no mask (a plain norm);
 // 2: mask_src > 0 (the ReLU sits behind a residual add: mask_src = the block output).  g_copy (|NULL): the masked gradient g is also
 // written there (the identity branch of the residual block receives exactly that).
-__global__ __launch_bounds__(256) void adain_bwd_partial_kernel(const float* __restrict__ dA, const float* __restrict__ x,
+// X16: x is a 16-BIT-RESIDENT conv output (the unscaled fp16 plane [N][HW][C] the conv epilogue left instead of fp32 y; C % 8 == 0)
+template <bool X16> __device__ __forceinline__ float4 lp_ldx4(const void* x, size_t e) {
+    if (X16) {
+        const ushort4 h = *(const ushort4*)((const uint16_t*)x + e);
+        return make_float4(lp_op16_to_f32<true>(h.x), lp_op16_to_f32<true>(h.y), lp_op16_to_f32<true>(h.z), lp_op16_to_f32<true>(h.w));
+    }
+    return *(const float4*)((const float*)x + e);
+}
+
+template <bool X16 = false>
+__global__ __launch_bounds__(256) void adain_bwd_partial_kernel(const float* __restrict__ dA, const void* __restrict__ x,
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
                                                                 float* __restrict__ g_out, float* __restrict__ part, int H, int W, int C,
@@ -311,7 +321,7 @@ __global__ __launch_bounds__(256) void adain_bwd_partial_kernel(const float* __r
         float4 sc = *(const float4*)(scale + (size_t)n * C + c), sf = *(const float4*)(shift + (size_t)n * C + c);
 #pragma unroll 2
         for (int pix = p0 + pl; pix < p1; pix += 16) {
-            float4 xv = *(const float4*)(x + ((size_t)n * HW + pix) * C + c);
+            float4 xv = lp_ldx4<X16>(x, ((size_t)n * HW + pix) * C + c);
             float4 g;
             if (ups) {
                 int yy = pix / W, xx = pix % W;
@@ -369,7 +379,8 @@ __global__ __launch_bounds__(256) void adain_bwd_finalize_kernel(const float* __
     coef[(size_t)idx * 3 + 0] = ca; coef[(size_t)idx * 3 + 1] = cb; coef[(size_t)idx * 3 + 2] = cc;
 }
 
-__global__ void adain_bwd_apply_kernel(float* __restrict__ dx /* holds g */, const float* __restrict__ x, const float* __restrict__ add,
+template <bool X16 = false>
+__global__ void adain_bwd_apply_kernel(float* __restrict__ dx /* holds g */, const void* __restrict__ x, const float* __restrict__ add,
                                        const float* __restrict__ coef, long long total4, int HW, int C, float* __restrict__ amax) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -379,7 +390,7 @@ __global__ void adain_bwd_apply_kernel(float* __restrict__ dx /* holds g */, con
         int c = (int)(i % C4) * 4;
         int n = (int)(i / ((long long)C4 * HW));
         const float* cf = coef + ((size_t)n * C + c) * 3;
-        float4 g = ((const float4*)dx)[i], xv = ((const float4*)x)[i], o;
+        float4 g = ((const float4*)dx)[i], xv = lp_ldx4<X16>(x, (size_t)i * 4), o;
         o.x = fmaf(cf[0], g.x, fmaf(cf[1], xv.x, cf[2]));
         o.y = fmaf(cf[3], g.y, fmaf(cf[4], xv.y, cf[5]));
         o.z = fmaf(cf[6], g.z, fmaf(cf[7], xv.z, cf[8]));
@@ -404,10 +415,33 @@ extern "C" int lp_adain_relu_bwd(const float* dA, const float* x, const float* a
                            nullptr, nullptr, 0.f, 0, amax_slots, stream);
 }
 
+static int norm_act_bwd_impl(const float* dA, const void* x, int x16, const float* add, const float* gamma, int ab_stride, const float* mean,
+                             const float* rstd, const float* scale, const float* shift, float* dx, float* dgamma, float* dbeta,
+                             float* workspace, int N, int H, int W, int C, int upsample, int mask_mode, const float* mask_src,
+                             float* g_copy, float act_hi, int frozen_stats, float* amax_slots, void* stream);
+
+// lp_adain_relu_bwd with x held as a 16-bit-resident conv output (fp16 plane [N][H][W][C], C % 8 == 0): the generator's fp16 mode keeps
+// no fp32 copy of its conv outputs (round 5); x-hat and the ReLU pattern are recomputed from the SAME fp16 values the forward normalised
+extern "C" int lp_adain_relu_bwd16(const float* dA, const uint16_t* x16, const float* add, const float* gamma, int ab_stride, const float* mean,
+                                   const float* rstd, const float* scale, const float* shift, float* dx, float* dgamma, float* dbeta,
+                                   float* workspace, int N, int H, int W, int C, int upsample, float* amax_slots, void* stream) {
+    if (C & 7) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_adain_relu_bwd16: C must be a multiple of 8");
+    return norm_act_bwd_impl(dA, x16, 1, add, gamma, ab_stride, mean, rstd, scale, shift, dx, dgamma, dbeta, workspace, N, H, W, C, upsample, 0,
+                             nullptr, nullptr, 0.f, 0, amax_slots, stream);
+}
+
 extern "C" int lp_norm_act_bwd(const float* dA, const float* x, const float* add, const float* gamma, int ab_stride, const float* mean,
                                const float* rstd, const float* scale, const float* shift, float* dx, float* dgamma, float* dbeta,
                                float* workspace, int N, int H, int W, int C, int upsample, int mask_mode, const float* mask_src,
                                float* g_copy, float act_hi, int frozen_stats, float* amax_slots, void* stream) {
+    return norm_act_bwd_impl(dA, x, 0, add, gamma, ab_stride, mean, rstd, scale, shift, dx, dgamma, dbeta, workspace, N, H, W, C, upsample, mask_mode,
+                             mask_src, g_copy, act_hi, frozen_stats, amax_slots, stream);
+}
+
+static int norm_act_bwd_impl(const float* dA, const void* x, int x16, const float* add, const float* gamma, int ab_stride, const float* mean,
+                             const float* rstd, const float* scale, const float* shift, float* dx, float* dgamma, float* dbeta,
+                             float* workspace, int N, int H, int W, int C, int upsample, int mask_mode, const float* mask_src,
+                             float* g_copy, float act_hi, int frozen_stats, float* amax_slots, void* stream) {
     if (!dA || !x || !mean || !rstd || !scale || !shift || !dx || !workspace) return lp_set_error(LP_ERR_ARG, "lp_norm_act_bwd: null pointer");
     if (C & 3) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_norm_act_bwd: C must be a multiple of 4");
     if (mask_mode < 0 || mask_mode > 2 || (mask_mode == 2 && !mask_src)) return lp_set_error(LP_ERR_ARG, "lp_norm_act_bwd: bad mask mode");
@@ -418,8 +452,10 @@ extern "C" int lp_norm_act_bwd(const float* dA, const float* x, const float* add
     float* part = workspace;
     float* coef = workspace + (size_t)N * S * C * 2;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(adain_bwd_partial_kernel, dim3(S, (C + 63) / 64, N), dim3(256), 0, st, dA, x, mean, rstd, scale, shift, dx, part,
-                       H, W, C, upsample, S, PB, mask_mode, mask_src, g_copy, act_hi > 0.f ? act_hi : 3.0e38f);
+    if (x16) hipLaunchKernelGGL(adain_bwd_partial_kernel<true>, dim3(S, (C + 63) / 64, N), dim3(256), 0, st, dA, x, mean, rstd, scale, shift, dx, part,
+                                H, W, C, upsample, S, PB, mask_mode, mask_src, g_copy, act_hi > 0.f ? act_hi : 3.0e38f);
+    else hipLaunchKernelGGL(adain_bwd_partial_kernel<false>, dim3(S, (C + 63) / 64, N), dim3(256), 0, st, dA, x, mean, rstd, scale, shift, dx, part,
+                            H, W, C, upsample, S, PB, mask_mode, mask_src, g_copy, act_hi > 0.f ? act_hi : 3.0e38f);
     int rc = lp_check_launch("adain_bwd_partial");
     if (rc) return rc;
     hipLaunchKernelGGL(adain_bwd_finalize_kernel, dim3(cdiv((long long)N * C, 4)), dim3(256), 0, st, part, gamma, ab_stride, mean, rstd,
@@ -428,7 +464,8 @@ extern "C" int lp_norm_act_bwd(const float* dA, const float* x, const float* add
     if (rc) return rc;
     long long total4 = (long long)N * HW * C / 4;
     int blocks = (int)((total4 + 255) / 256); if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(adain_bwd_apply_kernel, dim3(blocks), dim3(256), 0, st, dx, x, add, coef, total4, HW, C, amax_slots);
+    if (x16) hipLaunchKernelGGL(adain_bwd_apply_kernel<true>, dim3(blocks), dim3(256), 0, st, dx, x, add, coef, total4, HW, C, amax_slots);
+    else hipLaunchKernelGGL(adain_bwd_apply_kernel<false>, dim3(blocks), dim3(256), 0, st, dx, x, add, coef, total4, HW, C, amax_slots);
     return lp_check_launch("adain_bwd_apply");
 }
 

@@ -307,6 +307,35 @@ extern "C" int lp_bn_act16(const uint16_t* y16, const float* scale, const float*
     return lp_check_launch("bn_act16");
 }
 
+// ---- AdaIN (+ ReLU) of a 16-bit-resident conv output with PER-IMAGE (n, c) affines (the generator's instance norms: blocks.py:18-26,70-73) --
+// a[n][p][c] = fp16( relu?( y16[n][p][c] * scale[n][c] + shift[n][c] ) ): lp_act_pack's prologue 1 reading 2 B instead of 4 B per element
+__global__ __launch_bounds__(256) void adain_act16_kernel(const uint16_t* __restrict__ y, const float* __restrict__ sc, const float* __restrict__ sh,
+                                                          uint16_t* __restrict__ out, long long items, long long items_per_image, int C, int relu) {
+    const int G = C >> 3;
+    const float floor_v = relu ? 0.f : -3.0e38f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < items; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % G) * 8;
+        const size_t a = (size_t)(i / items_per_image) * C + c;
+        float v[8];
+        load8<true>(y, (size_t)i * 8, v);
+        const float4 s0 = *(const float4*)(sc + a), s1 = *(const float4*)(sc + a + 4), h0 = *(const float4*)(sh + a), h1 = *(const float4*)(sh + a + 4);
+        const float a8[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, b8[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaxf(fmaf(v[j], a8[j], b8[j]), floor_v);
+        store_op8<true, false>(v, out, nullptr, (size_t)i * 8);
+    }
+}
+
+extern "C" int lp_adain_act16(const uint16_t* y16, const float* scale, const float* shift, uint16_t* out_hi, int N, long long HW, int C, int relu,
+                              void* stream) {
+    if (!y16 || !scale || !shift || !out_hi) return lp_set_error(LP_ERR_ARG, "lp_adain_act16: null pointer");
+    if (C & 7) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_adain_act16: C must be a multiple of 8");
+    const long long per = HW * (C >> 3), items = per * N;
+    if (items == 0) return LP_OK;
+    hipLaunchKernelGGL(adain_act16_kernel, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, y16, scale, shift, out_hi, items, per, C, relu);
+    return lp_check_launch("adain_act16");
+}
+
 // ---- stride-2 plumbing on [N][H][W][row of `units` 16-byte pieces] tensors (fp32 NHWC: units = C/4; operand planes: units = C8/8) ----
 // subsample: out[n,i,j] = in[n,2i,2j]  (what a stride-2 1x1 conv reads; the stride-2 3x3 conv output picked from the stride-1 result)
 __global__ __launch_bounds__(256) void subsample2_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, long long items, int Ho, int Wo,

@@ -637,17 +637,23 @@ def adain_relu_bwd(dA: Tensor, x: Tensor, add: Optional[Tensor], gamma: Tensor, 
                    shift: Tensor, dgamma: Tensor, dbeta: Tensor, upsample: bool, amax: bool = False) -> Tensor:
     """Backward of relu(AdaIN(x)) (+x2 upsample).  dgamma/dbeta: [N,C] views into the projector-output gradient (written).
     ``amax`` (here and below): the result will be packed as an fp16 gradient operand -- fold its max|.| into the kernel."""
-    _chk(dA, 'dA'); _chk(x, 'x')
-    n, h, w, c = x.shape
-    assert dA.shape == (n, h << int(upsample), w << int(upsample), c), (dA.shape, x.shape)
+    _chk(dA, 'dA')
+    x16 = x if isinstance(x, Act16) else None          # 16-bit-resident conv output (the generator's fp16 mode: no fp32 copy of x exists)
+    if x16 is not None:
+        assert x16.lo is None and x16.inv is None and x16.hi.shape[3] == x16.c, 'a 16-bit-resident x is ONE unscaled fp16 plane with C % 8 == 0'
+        n, h, w, c = x16.hi.shape
+    else:
+        _chk(x, 'x')
+        n, h, w, c = x.shape
+    assert dA.shape == (n, h << int(upsample), w << int(upsample), c), (dA.shape, (n, h, w, c))
     assert gamma.stride(1) == 1 and dgamma.stride(1) == 1 and dbeta.stride(1) == 1
     assert gamma.stride(0) == dgamma.stride(0) == dbeta.stride(0)
-    dx = torch.empty_like(x)
-    ws = torch.empty(_lib.lib().lp_adain_bwd_workspace_bytes(n, h * w, c) // 4, dtype=torch.float32, device=x.device)
-    check(_lib.lib().lp_adain_relu_bwd(dA.data_ptr(), x.data_ptr(), _p(add), gamma.data_ptr(), gamma.stride(0), mean.data_ptr(),
-                                       rstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), dx.data_ptr(), dgamma.data_ptr(),
-                                       dbeta.data_ptr(), ws.data_ptr(), n, h, w, c, int(upsample), _p(_amax_attach(dx, amax)), _stream()),
-          'lp_adain_relu_bwd')
+    dx = torch.empty((n, h, w, c), dtype=torch.float32, device=dA.device)
+    ws = torch.empty(_lib.lib().lp_adain_bwd_workspace_bytes(n, h * w, c) // 4, dtype=torch.float32, device=dA.device)
+    fn, xp, nm = (_lib.lib().lp_adain_relu_bwd, x.data_ptr(), 'lp_adain_relu_bwd') if x16 is None else \
+        (_lib.lib().lp_adain_relu_bwd16, x16.hi.data_ptr(), 'lp_adain_relu_bwd16')
+    check(fn(dA.data_ptr(), xp, _p(add), gamma.data_ptr(), gamma.stride(0), mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+             dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), n, h, w, c, int(upsample), _p(_amax_attach(dx, amax)), _stream()), nm)
     return dx
 
 
@@ -902,6 +908,38 @@ def bn_act16(y16: Act16, scale: Tensor, shift: Tensor, relu: bool = True) -> Act
     check(_lib.lib().lp_bn_act16(y16.hi.data_ptr(), scale.data_ptr(), shift.data_ptr(), hi.data_ptr(), y16.hi.numel() // c, c, int(relu),
                                  _stream()), 'lp_bn_act16')
     return Act16(hi, None, c, None)
+
+
+def adain_act16(y16: Act16, scale: Tensor, shift: Tensor, relu: bool = True) -> Act16:
+    """operand planes of (relu?)(y*scale[n,c]+shift[n,c]) from a 16-BIT-RESIDENT conv output y16 [N,H,W,C] (fp16 mode) with per-IMAGE affines
+    [N, C] -- AdaIN + ReLU as the next conv's prologue (``act_pack`` pro 1 reading 2 B per element instead of 4)"""
+    c = y16.c
+    n = y16.hi.shape[0]
+    assert y16.lo is None and y16.inv is None and y16.hi.shape[-1] == c and c % 8 == 0
+    _chk(scale, 'scale'); _chk(shift, 'shift')
+    assert tuple(scale.shape) == (n, c) and tuple(shift.shape) == (n, c), (scale.shape, shift.shape, (n, c))
+    hi = torch.empty_like(y16.hi)
+    check(_lib.lib().lp_adain_act16(y16.hi.data_ptr(), scale.data_ptr(), shift.data_ptr(), hi.data_ptr(), n, y16.hi.numel() // (n * c), c, int(relu),
+                                    _stream()), 'lp_adain_act16')
+    return Act16(hi, None, c, None)
+
+
+def thin_wgrad16(x16: Act16, dy: Tensor, *, ksize: int, pro: int = 0, scale: Optional[Tensor] = None, shift: Optional[Tensor] = None,
+                 splits: Optional[int] = None, sn=None, accum: Optional[Tensor] = None, bias_grad: bool = False):
+    """``thin_wgrad`` of a conv with <= 4 OUTPUT channels whose wide input is a 16-bit-resident conv output (the generator head in the fp16 mode)"""
+    _chk(dy, 'dy')
+    n, h, w, cout = dy.shape
+    cin = x16.c
+    assert x16.lo is None and x16.inv is None and tuple(x16.hi.shape) == (n, h, w, cin)
+    if splits is None:
+        splits = default_splits(n, h, w, cin, cout)
+    ws = torch.empty(_lib.lib().lp_conv_wgrad_workspace_bytes(cin, cout, ksize, splits) // 4, dtype=torch.float32, device=dy.device)
+    dw = torch.empty((cout, cin, ksize, ksize), dtype=torch.float32, device=dy.device)
+    with _Timed('wgrad_thin', 2.0 * n * h * w * cout * cin * ksize * ksize, (n, h, w, cin, cout, ksize, 0, pro)):
+        check(_lib.lib().lp_thin_wgrad16(x16.hi.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), _p(scale), _p(shift), n, h, w, cin, cout,
+                                         ksize, pro, splits, _stream()), 'lp_thin_wgrad16')
+    dw = _sn_finish(dw, sn, accum)
+    return (dw, dy.sum(dim=(0, 1, 2))) if bias_grad else dw
 
 
 def y16_to_f32(y16: Act16) -> Tensor:

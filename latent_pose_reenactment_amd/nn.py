@@ -106,12 +106,19 @@ class fused_grad_accumulation:
 
     def __exit__(self, *exc):
         _FUSED_ACCUM[0] = self.prev
+        from latent_pose_reenactment_amd import streams
         if exc[0] is None:
             #  every branch that accumulated on a side stream is joined HERE, so no caller can read .grad early; then the
             # second accumulation buffers (``alt_accumulation``) are folded into .grad
-            from latent_pose_reenactment_amd import streams
             streams.join_all()
             flush_alt_accumulation()
+        else:
+            #  a backward pass that raised half-way (out of memory, a caught-and-skipped step) leaves partial gradients in the second
+            # buffers; zero_grad never touches those, so they are DISCARDED here instead of being added into the next successful step's .grad
+            try:
+                streams.join_all()
+            finally:
+                discard_alt_accumulation()
 
 
 # Two backward passes that run CONCURRENTLY on different streams and deposit gradients on the SAME parameters (the critic's fake-image and
@@ -140,6 +147,13 @@ def flush_alt_accumulation():
     torch._foreach_add_(tgt, src)
     torch._foreach_zero_(src)
     dirty.clear()
+
+
+def discard_alt_accumulation():
+    dirty = _ALT['dirty']
+    if dirty:
+        torch._foreach_zero_([b for _, b in dirty.values()])
+        dirty.clear()
 
 
 _FUSED_ACCUM_ENV = os.environ.get('LP_FUSED_ACCUM', '1') != '0'      # 0: plain autograd accumulation everywhere (diagnosis knob)
@@ -273,9 +287,15 @@ class SNBatch:
 
 
 def _linear_check(x2):
-    if not (x2.is_cuda and x2.dtype == torch.float32 and x2.shape[1] % 4 == 0 and x2.shape[1] <= 1024 and x2.shape[0] >= 1):
-        raise RuntimeError(f'lp_linear_fwd/bwd take fp32 CUDA rows of K % 4 == 0, K <= 1024 features; got {tuple(x2.shape)} {x2.dtype} on {x2.device} '
+    if not (x2.is_cuda and x2.dtype == torch.float32 and x2.shape[1] <= 1024 and x2.shape[0] >= 1):
+        raise RuntimeError(f'lp_linear_fwd/bwd take fp32 CUDA rows of K <= 1024 features; got {tuple(x2.shape)} {x2.dtype} on {x2.device} '
                            '(one backend: there is no library-GEMM path)')
+
+
+def _pad4(t):
+    """rows of K features -> rows of ceil4(K) (zero columns): the lp_linear_* kernels read 16-byte pieces.  Only toy configurations have K % 4 != 0."""
+    k = t.shape[-1]
+    return t if k % 4 == 0 else F.pad(t, (0, 4 - k % 4))
 
 
 _LINEAR_ROWS = 64          # rows per lp_linear_* launch (the kernels keep one accumulator row set per wave): larger batches go in chunks
@@ -293,9 +313,9 @@ class SNLinearFn(torch.autograd.Function):
         ctx.save_for_backward(x, w, u, v, sig)
         ctx.w_param = w if (w.requires_grad and w.is_leaf) else None
         ctx.accum_alt = _ALT['on']
-        x2 = x.reshape(-1, x.shape[-1]).detach().contiguous()
+        x2 = _pad4(x.reshape(-1, x.shape[-1]).detach()).contiguous()
         _linear_check(x2)
-        wd, bd, alpha = w.detach().contiguous(), (None if b is None else b.detach().contiguous()), (None if sig is None else sig[1:])
+        wd, bd, alpha = _pad4(w.detach()).contiguous(), (None if b is None else b.detach().contiguous()), (None if sig is None else sig[1:])
         ys = [ops.linear_fwd(x2[i:i + _LINEAR_ROWS], wd, bd, alpha) for i in range(0, x2.shape[0], _LINEAR_ROWS)]
         y = ys[0] if len(ys) == 1 else torch.cat(ys)
         return y.reshape(x.shape[:-1] + (w.shape[0],))
@@ -303,8 +323,9 @@ class SNLinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, w, u, v, sig = ctx.saved_tensors
-        g2, x2 = g.reshape(-1, g.shape[-1]).contiguous(), x.reshape(-1, x.shape[-1]).detach().contiguous()
-        wd, alpha = w.detach().contiguous(), (None if sig is None else sig[1:])
+        k = x.shape[-1]
+        g2, x2 = g.reshape(-1, g.shape[-1]).contiguous(), _pad4(x.reshape(-1, k).detach()).contiguous()
+        wd, alpha = _pad4(w.detach()).contiguous(), (None if sig is None else sig[1:])
         want = ctx.needs_input_grad[:3]
         parts = [ops.linear_bwd(x2[i:i + _LINEAR_ROWS], wd, g2[i:i + _LINEAR_ROWS], alpha, *want) for i in range(0, x2.shape[0], _LINEAR_ROWS)]
         dx, graw, db = parts[0]
@@ -312,6 +333,10 @@ class SNLinearFn(torch.autograd.Function):
             dx = None if dx is None else torch.cat([p_[0] for p_ in parts])
             graw = None if graw is None else torch.stack([p_[1] for p_ in parts]).sum(0)
             db = None if db is None else torch.stack([p_[2] for p_ in parts]).sum(0)
+        if k % 4:          # (toy configurations: drop the zero columns again)
+            dx = None if dx is None else dx[:, :k].contiguous()
+            graw = None if graw is None else graw[:, :k].contiguous()
+            wd = w.detach().contiguous()
         if dx is not None:
             dx = dx.reshape(x.shape)
         dw = graw
@@ -422,6 +447,9 @@ def generator_channels(num_channels: int, max_num_channels: int, image_size: int
 # ----------------------------------------------------------------------------------------------------------------------
 # the decoder as ONE autograd Function over HIP kernels
 # ----------------------------------------------------------------------------------------------------------------------
+G_Y16 = os.environ.get('LP_G_Y16', '1') != '0'      # fp16 mode: the decoder's conv outputs on >= 32 x 32 maps stay 16-bit resident (round 5)
+
+
 class _DecoderFunction(torch.autograd.Function):
     """inputs: affine [B, n_aff] (projector output; per AdaIN: C biases then C weights, noBottleneck.py:108-125),
     constant [1,C,s,s], then per block (w1, w2[, w_skip, b_skip]) and (w_head, b_head) -- effective (W/sigma) weights.
@@ -451,12 +479,34 @@ class _DecoderFunction(torch.autograd.Function):
             off += 2 * c
             return gamma, beta, o
 
+        # 16-BIT-RESIDENT conv outputs (round 5, fp16 mode, maps of >= 32 x 32 -- where the conv epilogue also leaves the norm statistics): a
+        # conv between two AdaIN blocks writes the UNSCALED fp16 plane of y (+ the {count, mean, M2} partials from its fp32 accumulators) and no
+        # fp32 y.  The plane IS the raw operand of the next block's 1x1 skip conv (exactly what lp_act_pack pro 0 produced from fp32 y), the
+        # AdaIN + ReLU prologue reads 2 B per element (lp_adain_act16), and the backward recomputes x-hat / the ReLU pattern from the same plane
+        # (lp_adain_relu_bwd16).  Per element over forward + backward: a conv1 output 16 B -> 8 B, a block output 22 B -> 8 B.  LP_G_Y16=0: fp32.
+        y16 = bool(cfg.get('y16')) and prec == PREC_F16
+
+        def dims(t):
+            return tuple(t.hi.shape) if isinstance(t, ops.Act16) else tuple(t.shape)
+
         def in_stats(t, cs, gamma, beta):
             # instance-norm statistics of a conv output: from the {count, mean, M2} partials its epilogue left (no pass over the tensor),
             # else -- maps under 64 pixels, split-K launches, the constant input -- by the two-launch statistics kernel
             if cs is not None:
-                return ops.norm_stats_finalize(cs, t.shape[0], t.shape[3], gamma, beta, ADAIN_EPS)
-            return ops.instnorm_stats(t, gamma, beta, ADAIN_EPS)
+                return ops.norm_stats_finalize(cs, dims(t)[0], dims(t)[3], gamma, beta, ADAIN_EPS)
+            return ops.instnorm_stats(ops.y16_to_f32(t) if isinstance(t, ops.Act16) else t, gamma, beta, ADAIN_EPS)
+
+        def norm_planes(t, st):          # operand planes of relu(AdaIN(t))
+            if isinstance(t, ops.Act16):
+                return ops.adain_act16(t, st[2], st[3])
+            return ops.act_pack(t, pro=1, scale=st[2], shift=st[3], prec=prec)
+
+        def conv_out(a, pk, hout, **kw):
+            """-> (y fp32 | the fp16 plane of y, statistics partials | None)"""
+            if y16 and hout >= 32 and pk.rows % 8 == 0:
+                _, o16, cs = ops.conv16(a, pk, prec=prec, stats=True, want_y=False, out16=0, **kw)
+                return o16, cs
+            return ops.conv16(a, pk, prec=prec, stats=True, **kw)
         x_cs = None
         for (cin, cout, up) in blocks:
             w1, w2 = wl[wi], wl[wi + 1]
@@ -464,27 +514,29 @@ class _DecoderFunction(torch.autograd.Function):
             has_skip = (cin != cout) or up
             g0, b0, o0 = aff(cin)
             g1, b1, o1 = aff(cout)
+            hout = dims(x)[1] * (2 if up else 1)
             # AdaIN + ReLU are applied ONCE per tensor while it is packed to the conv's 16-bit operand planes (the same planes feed
             # the weight gradient in backward); the convs themselves stage their operands by LDS-DMA only
             st0 = in_stats(x, x_cs, g0, b0)
-            a0 = ops.act_pack(x, pro=1, scale=st0[2], shift=st0[3], prec=prec)
+            a0 = norm_planes(x, st0)
             p1 = fpack(wi - 2, w1)
-            h1, cs1 = ops.conv16(a0, p1, ksize=3, upsample=up, alpha=sn[wi - 2][2][1:], prec=prec, stats=True)
+            h1, cs1 = conv_out(a0, p1, hout, ksize=3, upsample=up, alpha=sn[wi - 2][2][1:])
             st1 = in_stats(h1, cs1, g1, b1)
-            a1 = ops.act_pack(h1, pro=1, scale=st1[2], shift=st1[3], prec=prec)
+            a1 = norm_planes(h1, st1)
             xs = None
             if has_skip:
                 ws, bs = wl[wi], wl[wi + 1]
                 wi += 2
                 ps = fpack(wi - 2, ws)
-                xs = ops.act_pack(x, pro=0, prec=prec)
+                xs = x if isinstance(x, ops.Act16) else ops.act_pack(x, pro=0, prec=prec)
                 s = ops.conv16(xs, ps, ksize=1, bias=bs.detach().contiguous(), alpha=sn[wi - 2][2][1:], prec=prec)   # 1x1 commutes with nearest upsampling
                 rs = 1 if up else 0
             else:
+                assert not isinstance(x, ops.Act16), 'an identity skip adds the fp32 block input (blocks without a skip conv sit on the < 32 x 32 maps)'
                 s, rs = x, 0
             i2 = wi - (3 if has_skip else 1)
             p2 = fpack(i2, w2)
-            out, x_cs = ops.conv16(a1, p2, ksize=3, res=s, res_shift=rs, alpha=sn[i2][2][1:], prec=prec, stats=True)
+            out, x_cs = conv_out(a1, p2, hout, ksize=3, res=s, res_shift=rs, alpha=sn[i2][2][1:])
             if need_grad:
                 saved.append((x, h1, st0, st1, o0, o1, a0, a1, xs))
             if cfg.get('debug') is not None:      # activation patterns of the AdaIN+ReLU sites (tie-masked parity checks)
@@ -495,7 +547,7 @@ class _DecoderFunction(torch.autograd.Function):
         sth = in_stats(x, x_cs, gh, bh)
         wh, bhd = wl[wi], wl[wi + 1]
         ph = fpack(wi, wh)
-        ah = ops.act_pack(x, pro=1, scale=sth[2], shift=sth[3], prec=prec)
+        ah = norm_planes(x, sth)
         z = ops.conv16(ah, ph, ksize=3, bias=bhd.detach().contiguous(), alpha=sn[wi][2][1:], prec=prec)
         if cfg.get('debug') is not None:
             cfg['debug'].setdefault('relu_planes', []).append(ah.hi)
@@ -532,8 +584,9 @@ class _DecoderFunction(torch.autograd.Function):
         dz = ops.head_bwd(t, d_rgbs.contiguous(), None if d_segm is None else d_segm.contiguous(), amax=f16)
         wi = len(wl) - 2
         if ops.thin_wgrad_supported(ch, dz.shape[3], 3, 1, dz.shape[2]):
-            grads[wi], grads[wi + 1] = ops.thin_wgrad(x, dz, ksize=3, pro=1, scale=sth[2], shift=sth[3], sn=snw(wi),
-                                                      accum=_accum_target(params[wi]), bias_grad=True)
+            thin = ops.thin_wgrad16 if isinstance(x, ops.Act16) else ops.thin_wgrad
+            grads[wi], grads[wi + 1] = thin(x, dz, ksize=3, pro=1, scale=sth[2], shift=sth[3], sn=snw(wi),
+                                            accum=_accum_target(params[wi]), bias_grad=True)
         else:
             grads[wi], grads[wi + 1] = ops.conv_wgrad16(ah, ops.act_pack(dz, prec=prec, grad=True), ksize=3, prec=prec, sn=snw(wi),
                                                         accum=_accum_target(params[wi]), bias_grad=True)
@@ -762,7 +815,7 @@ class Generator(nn.Module):
                 self.__dict__['_pack_cache'] = cache
             packs = cache[1]
         cfg = dict(blocks=self.blocks_cfg, prec=self.prec, need_grad=need_grad, sn=sn, packs=packs, packsT=packsT,
-                   debug=getattr(self, '_debug', None))
+                   debug=getattr(self, '_debug', None), y16=G_Y16 and self.training and need_grad)
         rgbs, segm = _DecoderFunction.apply(cfg, affine, self.constant.constant, *weights)
         data_dict['fake_rgbs'] = rgbs
         data_dict['fake_segm'] = segm

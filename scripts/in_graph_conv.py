@@ -1,13 +1,17 @@
 """3x3 dense conv family INSIDE a captured step: kernel durations from a one-step rocprofv3 breakdown (scripts/step_breakdown.py) against the
 algorithmic FLOPs of the same launches (bench.py --shapes table, kind conv_igemm, two instrumented steps) -> the in-graph roofline figure
 that bench.py prints beside its live eager-event one.
-usage: python scripts/in_graph_conv.py <step_breakdown.csv> <conv_shapes.csv> > profiles/r04_conv3x3_in_graph.json
+usage: python scripts/in_graph_conv.py <step_breakdown.csv> <conv_shapes.csv> > profiles/r05_conv3x3_in_graph.json
 Family = conv_pipe_kernel (all variants) + conv_dma_kernel<3, ...> except the <3, false, 4, 1, 4, 4, ...> instantiation, which since round 4
 only runs the identity encoder's GROUPED 3x3 convs (the dense <= 64-channel layers moved to conv_pipe_kernel<.., 4, 1, 4, 4, ..>), + the
 split-K finishes (splitk_reduce_kernel)."""
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402  (source_stamp: ties the figure to the tree it was measured on)
 
 bd, shapes = sys.argv[1], sys.argv[2]
 t_ms, launches, parts = 0.0, 0, {}
@@ -34,4 +38,4 @@ tflop_step = fl / 2
 ach = tflop_step / (t_ms * 1e-3)
 print(json.dumps({'source': 'rocprofv3 kernel trace of one hipGraph replay (scripts/step_breakdown.py) + bench.py --shapes', 'ms_per_step': round(t_ms, 3),
                   'launches_per_step': launches, 'algorithmic_tflop_per_step': round(tflop_step, 3), 'achieved_tflops': round(ach, 1),
-                  'frac_of_2500': round(ach / 2500.0, 4), 'by_kernel': {k: {'launches': v[0], 'ms': round(v[1], 3)} for k, v in parts.items()}}))
+                  'frac': round(ach / 2500.0, 4), 'peak_tflops': 2500.0, 'stamp': bench.source_stamp(), 'by_kernel': {k: {'launches': v[0], 'ms': round(v[1], 3)} for k, v in parts.items()}}))

@@ -8,6 +8,7 @@ variants of one kernel family; several prefixes may be joined with '|') -> avera
 import collections
 import csv
 import json
+import os
 import sys
 
 args = sys.argv[1:]
@@ -39,6 +40,9 @@ if prefix:
         out['mfma_busy_fraction'] = round(b[1] / (g[1] / 8 * 256 * 4), 4)
     if b and m and m[1] > 0:
         out['mfma_busy_clocks_per_instruction'] = round(b[1] / (m[1] / 32), 2)   # MOPS counts 512-FLOP units; one 16x16x32 MFMA = 32 of them
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench          # source_stamp: ties the counters to the tree they were measured on
+    out['stamp'] = bench.source_stamp()
     print(json.dumps(out))
     sys.exit(0)
 print('kernel,counter,launches,mean_per_launch_raw,mean_bytes_per_launch_corrected')

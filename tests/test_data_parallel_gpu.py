@@ -81,3 +81,23 @@ def test_bench_starts_its_own_ranks_from_plain_python():
     j = json.loads(lines[0])
     assert j['n_gpus'] == 2 and j['config']['global_batch'] == 16 and j['config']['parallelism'] == 'dp2' and j['value'] > 0, j
     assert j['single_gpu_same_workload'].get('value', 0) > 0, j['single_gpu_same_workload']
+    assert j['replicas']['bit_identical_parameters'] is True, j['replicas']          # the data-parallel invariant, checked on the parameters' bits
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs: RCCL refuses two ranks on one device (the builder\'s box has one; the driver\'s node has eight)')
+def test_bench_two_gpus_over_rccl_keeps_replicas_bit_identical():
+    """ the FIRST execution of this code on the nccl (= RCCL) backend must not fail for a trivial reason: two ranks on
+    two GPUs, the real meta-training step with the re-cut hipGraphs (generator bucket | encoders' bucket | discriminator-side exchange incl. the
+    row-sparse label-embedding rows, ReduceOp.AVG), 1 warm-up + 2 timed + 2 instrumented steps -- the replicas' parameters must be bit-identical
+    afterwards and the JSON line well-formed.  Skipped on a one-GPU box; no scaling figure is derived from it."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'nccl', '--steps', '2', '--warmup', '1',
+                        '--no-cpu-baseline', '--no-also', '--no-drive'], env=env, cwd=ROOT, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 2 and j['config']['parallelism'] == 'dp2' and j['value'] > 0, j
+    assert j['replicas']['bit_identical_parameters'] is True, j['replicas']

@@ -21,6 +21,30 @@ def rel(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
 
 
+def export(mode, net, figures):
+    """LP_PARITY_OUT=<dir> (the artifact scripts): merge this test's measured figures into <dir>/r05_parity_gradients_<mode>.json -- bench.py's
+    ``parity.gradients`` reads them from profiles/ (with the source stamp of the tree that produced them)"""
+    keep = os.environ.get('LP_PARITY_OUT')
+    if not keep:
+        return
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    path = os.path.join(keep, f'r05_parity_gradients_{mode}.json')
+    try:
+        cur = json.load(open(path))
+    except Exception:
+        cur = {}
+    cur[net] = figures
+    cur['stamp'] = bench.source_stamp()
+    cur['note'] = ('tie-masked rel-L2 of parameter / input gradients against the CPU oracle evaluated on the HIP path\'s own ReLU / L1-sign pattern '
+                   '(tests/test_full_size_parity.py: 256 x 256, full channel counts); `untied` = against the true-ReLU oracle; the critic\'s and the '
+                   'VGG stacks\' figures are of the modules in isolation (f16: the critic\'s fake -> G pass runs its strict assignment, discriminators/no_landmarks.gpass_prec)')
+    json.dump(cur, open(path, 'w'), indent=1)
+
+
 # (mode, gate on outputs, gate on tie-masked gradients): bf16 operands miss the 1e-3 output gate (~1.3e-3) and are only bounded
 @pytest.mark.parametrize('prec,tol_out,tol_grad', [(1, 1e-4, 1e-4), (2, 1e-3, 2e-3), (0, 3e-3, 2e-2)])
 def test_generator_256_vs_oracle(prec, tol_out, tol_grad):
@@ -88,6 +112,9 @@ def test_generator_256_vs_oracle(prec, tol_out, tol_grad):
     worst = sorted(gerr.items(), key=lambda kv: -kv[1])[:4]
     print(f'[parity-256] prec={prec}: outputs {errs}; tie-masked grads worst {[(k, round(v, 6)) for k, v in worst]}; '
           f'untied worst {max(gerr_untied.values()):.3e} | calibration vs the fp64 oracle: HIP untied {untied64:.3e}, fp32 CPU oracle untied (the tie floor) {floor32:.3e}')
+    export({0: 'bf16', 1: 'bf16x3', 2: 'f16'}[prec], 'generator',
+           {'outputs': errs, 'tie_masked_worst': [worst[0][0], worst[0][1]], 'tie_masked_all': gerr, 'untied_worst': max(gerr_untied.values()),
+            'fp32_oracle_tie_floor_vs_fp64': floor32, 'hip_untied_vs_fp64': untied64, 'gate': tol_grad})
     assert all(v < tol_out for v in errs.values()), errs
     assert all(v < tol_grad for v in gerr.values()), worst
     if prec == 1:
@@ -183,6 +210,10 @@ def test_discriminator_256_three_passes_vs_oracle(prec_name, tol_out, tol_grad, 
     worst = sorted(gerr.items(), key=lambda kv: -kv[1])[:4]
     print(f'[parity-256] critic {prec_name}: forward worst {max(errs.values()):.2e} ({max(errs, key=errs.get)}); tie-masked grads worst '
           f'{[(k, round(v, 6)) for k, v in worst]} over {len(gerr)} tensors')
+    export(prec_name, 'discriminator', {'forward_worst': [max(errs, key=errs.get), max(errs.values())],
+                                        'tie_masked_worst_G_loss': max(((k, v) for k, v in gerr.items() if k.startswith('G.')), key=lambda kv: kv[1]),
+                                        'tie_masked_worst_D_loss': max(((k, v) for k, v in gerr.items() if k.startswith('D.')), key=lambda kv: kv[1]),
+                                        'gate_G_loss': tol_grad, 'gate_D_loss': 3 * tol_grad})
     assert all(v < tol_out for v in errs.values()), errs
     # D-loss weight gradients of the last blocks are DIFFERENCES of nearly equal fake / real terms (hinge: -1/2 on the real, +1/2 on the
     # fake sample, both images uniform noise here): the cancellation amplifies any operand rounding ~20x, so they get 3x the gate
@@ -225,6 +256,7 @@ def test_vgg_stacks_256_vs_oracle(net, prec_name, tol_out, tol_grad, monkeypatch
     _, g_tied = oracle(masks)
     e_l, e_g, e_gu = rel(loss, l_true), rel(fake.grad, g_tied), rel(fake.grad, g_true)
     print(f'[parity-256] {net} stack {prec_name}: loss {e_l:.2e}, tie-masked d_fake {e_g:.2e} (untied {e_gu:.2e})')
+    export(prec_name, 'vgg19' if net == 'caffe' else 'vggface', {'loss': e_l, 'tie_masked_d_fake': e_g, 'untied_d_fake': e_gu, 'gate': tol_grad})
     assert e_l < tol_out and e_g < tol_grad, (e_l, e_g)
 
 

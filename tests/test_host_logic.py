@@ -250,6 +250,15 @@ def test_second_accumulation_buffers_fold_into_grad_once():
     with lpnn.fused_grad_accumulation():
         assert lpnn._accum_target(w, alt=True) is alt          # persistent buffer (static address: hipGraph friendly)
     assert torch.equal(w.grad, torch.full((3, 4), 8.0))     # nothing added twice
+    #  a backward pass that raises inside the context must not leak its partial second-buffer gradients into the next step
+    with pytest.raises(ZeroDivisionError):
+        with lpnn.fused_grad_accumulation():
+            lpnn._accum_target(w, alt=True).add_(7.0)
+            1 / 0
+    assert float(alt.abs().sum()) == 0.0 and not lpnn._ALT['dirty'] and torch.equal(w.grad, torch.full((3, 4), 8.0))
+    with lpnn.fused_grad_accumulation():
+        pass
+    assert torch.equal(w.grad, torch.full((3, 4), 8.0))
     # forward-time marker
     assert lpnn._ALT['on'] is False
     with lpnn.alt_accumulation():
