@@ -774,16 +774,24 @@ def main():
         # (same start by broadcast, same averaged gradients, same optimizer arithmetic).  Checked on the parameters' BIT patterns: two int64
         # checksums per rank, MIN and MAX over ranks must agree.
         with torch.no_grad():
-            flat = torch.cat([p_.detach().reshape(-1) for m_ in (tm.generator, tm.embedder, tm.discriminator) for p_ in m_.parameters()])
-            bits = flat.view(torch.int32).to(torch.int64)
-            cs = torch.stack([bits.sum(), (bits * (torch.arange(bits.numel(), device=device, dtype=torch.int64) % 65521 + 1)).sum()])
+            groups = {'generator': list(tm.generator.parameters()), 'embedder': list(tm.embedder.parameters()),
+                      'discriminator.embed': [p_ for k_, p_ in tm.discriminator.named_parameters() if k_.startswith('embed.')],
+                      'discriminator.rest': [p_ for k_, p_ in tm.discriminator.named_parameters() if not k_.startswith('embed.')]}
+            sums, total = [], 0
+            for ps in groups.values():
+                flat = torch.cat([p_.detach().reshape(-1) for p_ in ps])
+                bits = flat.view(torch.int32).to(torch.int64)
+                sums += [bits.sum(), (bits * (torch.arange(bits.numel(), device=device, dtype=torch.int64) % 65521 + 1)).sum()]
+                total += flat.numel()
+            cs = torch.stack(sums)
             lo, hi = cs.clone(), cs.clone()
             dist.all_reduce(lo, op=dist.ReduceOp.MIN)
             dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-            replicas = {'bit_identical_parameters': bool((lo == hi).all().item()), 'parameters': int(flat.numel()),
+            same = (lo == hi).view(-1, 2).all(dim=1).tolist()
+            replicas = {'bit_identical_parameters': bool(all(same)), 'parameters': int(total),
+                        'by_group': {k_: bool(v_) for k_, v_ in zip(groups, same)},
                         'after_steps': a.warmup + a.steps + 2,
                         'note': 'checked after the warm-up, timed and instrumented steps, BEFORE the exchange-free single-GPU leg (which lets the ranks drift apart on purpose)'}
-            del flat, bits
 
     solo = None
     if world > 1:

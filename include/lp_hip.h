@@ -327,7 +327,10 @@ int lp_head_bwd(const float* t, const float* d_rgbs, const float* d_segm, float*
 /* dx = dA * [x > 0]                       (autograd of nn.ReLU, blocks.py:71-73,84) */
 int lp_relu_bwd(const float* dA, const float* x, float* dx, long long numel, void* stream);
 /* y = AvgPool2d(2)(relu?(x)); x [N][2H][2W][C], y [N][H][W][C]   (nn.AvgPool2d, blocks.py:89-90; perceptual_loss.py:77);
- * out_hi [N][H][W][C]|NULL (C % 8 == 0, prec bf16 | fp16): also the operand planes of y for the conv that follows */
+ * out_hi [N][H][W][C]|NULL (C % 8 == 0, prec bf16 | fp16): also the operand planes of y for the conv that follows.
+ * relu_in is a flag word (ABI 8): bit 0 = ReLU on the input; bit 1 = ReLU on the OUTPUT, y = relu(pool(x)) -- the in-place ReLU the critic's next
+ * ResBlock applies to its input (blocks.py:71-73), fused so that the pooled tensor, its feature-list entry and the next conv's planes come from one
+ * pass.  lp_avgpool2_bwd with bit 1: `x` points at that output y [N][H/2][W/2][C] and dy is masked by [y > 0] (bits 0 and 1 are exclusive there). */
 int lp_avgpool2_fwd(const float* x, float* y, int N, int H, int W, int C, int relu_in, uint16_t* out_hi, int prec, void* stream);
 /* the same on operand planes (ABI 7): x_hi [N][2H][2W][C] -> out_hi [N][H][W][C] (C % 8 == 0, prec bf16 | fp16; fp32 sum, one rounding) --
  * for no-grad chains that keep no fp32 activations: the VGG stacks over the TARGET image (perceptual_loss.py:86-93: `with torch.no_grad()`) */
@@ -393,6 +396,12 @@ int lp_sn_row_block(void);
 int lp_sn_power_iter(const void* table, int num_layers, int do_iter, int max_rows, int max_cols, void* stream);
 int lp_sn_grad_apply(float* g, const float* w_orig, const float* u, const float* v, const float* sig, float* dot, int ndot,
                      float* accum, int rows, int cols, void* stream);
+/* (ABI 8) `count` lp_sn_grad_apply jobs in ceil(count / 40) launches.  host_descs: HOST array of lp_sn_apply_desc_bytes()-sized records
+ * {float* g; const float* u, *v, *sig, *dot; float* accum; int ndot, rows, cols, reserved} (device pointers inside; read at call time and passed
+ * to the kernel by value, so the launch is hipGraph-capturable without a device table).  Every job accumulates into its OWN accum target and
+ * brings its <g, w_orig> partials (ndot >= 1: what lp_conv16_wgrad's reduction left). */
+int lp_sn_apply_desc_bytes(void);
+int lp_sn_grad_apply_batch(const void* host_descs, int count, void* stream);
 /* Label embedding of the projection critic (discriminators/no_landmarks.py:84-86,152), gradient w.r.t. W_orig [N][E] ADDED to grad:
  * grad[label[b]] += rows[b] (b = 0 .. B-1, in order: duplicate labels accumulate deterministically) and grad -= coef * u v^T with
  * coef a device scalar (<G, W_orig> / sigma^2), u [N], v [E] the power-iteration vectors.  label: int64.  E % 4 == 0. */

@@ -118,6 +118,8 @@ SIGNATURES = {
     'lp_sn_power_iter': (_i, [_vp, _i, _i, _i, _i, _vp]),
     'lp_sn_row_block': (_i, []),
     'lp_sn_grad_apply': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp]),
+    'lp_sn_apply_desc_bytes': (_i, []),
+    'lp_sn_grad_apply_batch': (_i, [_vp, _i, _vp]),
     'lp_sn_embed_grad': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
 }
 

@@ -1,6 +1,7 @@
 """Embedder-vs-discriminator identity embedding matching (reference API: criterions/dis_embed.py:5-34)."""
-import torch.nn.functional as F
 from torch import nn
+
+from latent_pose_reenactment_amd.nn import hip_l1_mean
 
 
 class Wrapper:
@@ -24,4 +25,4 @@ class Criterion(nn.Module):
             fake = fake[:, 0]
         if real.dim() > 2:
             real = real[:, 0]
-        return {'embedding_matching': F.l1_loss(fake, real.detach()) * self.weight}
+        return {'embedding_matching': hip_l1_mean(fake, real) * self.weight}          # lp_l1_fwd / lp_l1_bwd (round 5: no ATen l1_loss left)

@@ -1,9 +1,8 @@
 """Feature matching over the discriminator's feature maps (reference API: criterions/featmat.py:4-29)."""
 import torch
-import torch.nn.functional as F
 from torch import nn
 
-from latent_pose_reenactment_amd.nn import hip_l1
+from latent_pose_reenactment_amd.nn import hip_l1_mean
 
 
 class Wrapper:
@@ -24,10 +23,8 @@ class Criterion(nn.Module):
     def forward(self, data_dict):
         fake, real = data_dict['fake_features'], data_dict['real_features']
         def l1(f, r):
-            # discriminator features arrive as channels_last views: feed their NHWC storage to the fused kernel
-            if f.is_cuda and f.dim() == 4 and f.numel() % 4 == 0:
-                return hip_l1(f.permute(0, 2, 3, 1).contiguous(), r.detach().permute(0, 2, 3, 1).contiguous())
-            return F.l1_loss(f, r.detach())
+            # discriminator features arrive as channels_last views: their NHWC storage goes to the fused kernel as it is
+            return hip_l1_mean(f, r)
         terms = [l1(f, r) for f, r in zip(fake, real)]
         total = torch.stack(terms).sum() if len(terms) > 1 else terms[0]
         return {'feature_matching': total / len(fake) * self.fm_weight}

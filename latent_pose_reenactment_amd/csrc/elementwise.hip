@@ -582,8 +582,10 @@ extern "C" int lp_relu_bwd(const float* dA, const float* x, float* dx, long long
 
 // y[n,Y,X,c] = 0.25 * sum_{2x2} act(x[n,2Y+i,2X+j,c]),  act = relu if relu_in else identity.  H, W = OUTPUT dims.
 // o16 != NULL (C % 8 == 0): also the 16-bit operand planes [N][H][W][C] of y for the conv that follows (fp16 when f16, else bf16)
+// relu_out: y = relu(pool(.)) -- the ReLU the reference's NEXT block applies in place to its input (generators/common/blocks.py:71-73), so that
+// every consumer of the pooled tensor (skip branch, feature list, next conv) sees relu(y): pool + ReLU + operand planes in ONE pass
 __global__ void avgpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long total4, int H, int W, int C, int relu_in,
-                                    uint16_t* __restrict__ o16, int f16) {
+                                    uint16_t* __restrict__ o16, int f16, int relu_out) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long stride = (long long)gridDim.x * blockDim.x;
     const int C4 = C >> 2;
@@ -603,6 +605,7 @@ __global__ void avgpool2_fwd_kernel(const float* __restrict__ x, float* __restri
         }
         o.x = 0.25f * ((a0.x + a1.x) + (a2.x + a3.x)); o.y = 0.25f * ((a0.y + a1.y) + (a2.y + a3.y));
         o.z = 0.25f * ((a0.z + a1.z) + (a2.z + a3.z)); o.w = 0.25f * ((a0.w + a1.w) + (a2.w + a3.w));
+        if (relu_out) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
         ((float4*)y)[i] = o;
         if (o16) {
             ushort4 h;
@@ -650,8 +653,10 @@ extern "C" int lp_avgpool2_fwd16(const uint16_t* x_hi, uint16_t* out_hi, int N, 
 }
 
 // dx[n,y,x,c] = 0.25 * dy[n,y>>1,x>>1,c] * (relu_in ? [x>0] : 1).  H, W = INPUT (full-res) dims; one thread per 2x2 block.
+// relu_out (flag bit 1 of the C entry point): the forward returned relu(pool(x)); `x` then points at that OUTPUT y [N][H/2][W/2][C] and dy is
+// masked by [y > 0] first
 __global__ void avgpool2_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx, long long total4,
-                                    int H, int W, int C, int relu_in, float* __restrict__ amax) {
+                                    int H, int W, int C, int relu_in, float* __restrict__ amax, int relu_out) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long stride = (long long)gridDim.x * blockDim.x;
     const int C4 = C >> 2, Ho = H >> 1, Wo = W >> 1;
@@ -663,6 +668,10 @@ __global__ void avgpool2_bwd_kernel(const float* __restrict__ dy, const float* _
         int yy = (int)(t % Ho); int n = (int)(t / Ho);
         float4 g = ((const float4*)dy)[i];
         g.x *= 0.25f; g.y *= 0.25f; g.z *= 0.25f; g.w *= 0.25f;
+        if (relu_out) {
+            const float4 yv = ((const float4*)x)[i];
+            g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f; g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+        }
         size_t base = (((size_t)n * H + 2 * yy) * W + 2 * xx) * C + c;
         const size_t offs[4] = {0, (size_t)C, (size_t)W * C, (size_t)W * C + C};
 #pragma unroll
@@ -723,18 +732,20 @@ extern "C" int lp_avgpool2_fwd(const float* x, float* y, int N, int H, int W, in
     if (C & 3) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_avgpool2_fwd: C must be a multiple of 4");
     long long total4 = (long long)N * H * W * C / 4;
     int blocks = (int)((total4 + 255) / 256); if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(avgpool2_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, total4, H, W, C, relu_in, out_hi,
-                       prec == LP_PREC_F16 ? 1 : 0);
+    hipLaunchKernelGGL(avgpool2_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, total4, H, W, C, relu_in & 1, out_hi,
+                       prec == LP_PREC_F16 ? 1 : 0, (relu_in >> 1) & 1);
     return lp_check_launch("avgpool2_fwd");
 }
 
 extern "C" int lp_avgpool2_bwd(const float* dy, const float* x, float* dx, int N, int H, int W, int C, int relu_in, float* amax_slots,
                                void* stream) {
     if (!dy || !dx || (relu_in && !x)) return lp_set_error(LP_ERR_ARG, "lp_avgpool2_bwd: null pointer");
+    if (relu_in == 3) return lp_set_error(LP_ERR_ARG, "lp_avgpool2_bwd: relu_in and relu_out masks are exclusive (one mask pointer)");
     if ((C & 3) || (H & 1) || (W & 1)) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_avgpool2_bwd: C%4, H%2, W%2 must be 0");
     long long total4 = (long long)N * (H / 2) * (W / 2) * C / 4;
     int blocks = (int)((total4 + 255) / 256); if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, dx, total4, H, W, C, relu_in, amax_slots);
+    hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, dx, total4, H, W, C, relu_in & 1, amax_slots,
+                       (relu_in >> 1) & 1);
     return lp_check_launch("avgpool2_bwd");
 }
 

@@ -239,6 +239,58 @@ extern "C" int lp_sn_grad_apply(float* g, const float* w_orig, const float* u, c
     return lp_check_launch("sn_grad_apply");
 }
 
+// MANY lp_sn_grad_apply jobs in one launch (round 5 launch diet: 67 per-layer launches of a meta-training step -> 3).  Every job's <G, W_orig>
+// partials must already exist (ndot > 0: written by the weight-gradient reduction that produced G) and every job ACCUMULATES into its own
+// `accum` (distinct per job: two jobs on one target would race).  The descriptors travel BY VALUE in the kernel arguments (captured by value in
+// a hipGraph: no device table, no host-to-device copy), SN_BATCH_MAX per launch; `host_descs` is read on the host at call time only.
+struct SnApplyDesc { float* g; const float* u; const float* v; const float* sig; const float* dot; float* accum; int ndot, rows, cols, block0; };
+#define SN_BATCH_MAX 40
+struct SnApplyBatch { int n; int pad; SnApplyDesc d[SN_BATCH_MAX]; };
+
+__global__ __launch_bounds__(256) void sn_grad_apply_batch_kernel(SnApplyBatch b) {
+    __shared__ float red[4];
+    int j = 0;
+    while (j + 1 < b.n && (int)blockIdx.x >= b.d[j + 1].block0) ++j;          // (block0 ascending; <= 40 entries, scalar loads from the kernarg segment)
+    const SnApplyDesc q = b.d[j];
+    float d = 0.f;
+    for (int t = threadIdx.x; t < q.ndot; t += 256) d += q.dot[t];
+    d = block_sum_256(d, red);
+    const float alpha = q.sig[1];
+    const float k = d * alpha * alpha;
+    const long long total = (long long)q.rows * q.cols;
+    const long long base = (long long)((int)blockIdx.x - q.block0) * 1024;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const long long i = base + e * 256 + threadIdx.x;
+        if (i < total) {
+            const int r = (int)(i / q.cols), c = (int)(i % q.cols);
+            q.accum[i] += fmaf(alpha, q.g[i], -k * q.u[r] * q.v[c]);
+        }
+    }
+}
+
+extern "C" int lp_sn_apply_desc_bytes(void) { return (int)sizeof(SnApplyDesc); }
+
+extern "C" int lp_sn_grad_apply_batch(const void* host_descs, int count, void* stream) {
+    if (count < 0 || (count > 0 && !host_descs)) return lp_set_error(LP_ERR_ARG, "lp_sn_grad_apply_batch: bad arguments");
+    const SnApplyDesc* src = (const SnApplyDesc*)host_descs;
+    for (int i0 = 0; i0 < count; i0 += SN_BATCH_MAX) {
+        SnApplyBatch b;
+        b.n = count - i0 < SN_BATCH_MAX ? count - i0 : SN_BATCH_MAX; b.pad = 0;
+        long long blocks = 0;
+        for (int i = 0; i < b.n; ++i) {
+            b.d[i] = src[i0 + i];
+            if (!b.d[i].g || !b.d[i].u || !b.d[i].v || !b.d[i].sig || !b.d[i].dot || !b.d[i].accum || b.d[i].ndot < 1)
+                return lp_set_error(LP_ERR_ARG, "lp_sn_grad_apply_batch: every job needs g, u, v, sig, dot partials (ndot >= 1) and an accumulation target");
+            b.d[i].block0 = (int)blocks;
+            blocks += ((long long)b.d[i].rows * b.d[i].cols + 1023) / 1024;
+        }
+        if (blocks > 0x7fffffffll) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_sn_grad_apply_batch: too many elements in one batch");
+        if (blocks > 0) hipLaunchKernelGGL(sn_grad_apply_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, b);
+    }
+    return lp_check_launch("sn_grad_apply_batch");
+}
+
 // Gradient of the spectrally normalised label embedding (discriminators/no_landmarks.py:84-86,152; nn.SNEmbeddingFn): the dense part of
 //   dW_orig = scatter(rows at label) - coef * u v^T        (coef = <G, W_orig> / sigma^2, device scalar)
 // ADDED to grad [N][E]: one read-modify-write pass over the 98000 x 512 matrix for the rank-1 term (what torch.addmm_ did through

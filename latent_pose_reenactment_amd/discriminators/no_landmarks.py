@@ -24,6 +24,8 @@ torch.optim.RAdam = _radam.RAdam      # the reference swaps in its own RAdam the
 import os as _os
 # conv -> ReLU -> conv chains: the first conv writes only the operand planes of relu(h) (round 4; 0: also the fp32 h nobody reads)
 PLANES_ONLY = _os.environ.get('LP_D_PLANES_ONLY', '1') != '0'
+# pool -> (next block's in-place) ReLU -> operand planes in ONE launch (round 5; 0: three launches)
+FUSE_POOL_RELU = _os.environ.get('LP_D_POOL_RELU', '1') != '0'
 
 
 def gpass_prec():
@@ -88,16 +90,34 @@ class _DisBlock(nn.Module):
     def sn_layers(self):
         return [self.block._modules['2'], self.block._modules['5']] + ([self.skip._modules['0']] if self.has_skip else [])
 
-    def forward(self, x_relu, track, states, prec=None):
-        """x_relu: NHWC relu(x) (the reference's in-place ReLU makes every consumer of the block input see relu(x))"""
+    def forward(self, x_relu, track, states, prec=None, xr16=None, next_prec=None, last=False):
+        """x_relu: NHWC relu(x) (the reference's in-place ReLU makes every consumer of the block input see relu(x)); ``xr16``: its operand
+        planes when the producer already wrote them.  A down-sampling block returns ``(relu(pool(out)), planes | None)``: the in-place ReLU
+        the NEXT block applies (blocks.py:71-73) and the next conv's operand planes (mode ``next_prec``) come from the pool launch itself
+        (FUSE_POOL_RELU); the last block returns its pre-activation output."""
         c1, c2 = self.block._modules['2'], self.block._modules['5']
         prec = default_prec() if prec is None else prec
         # relu(x) is packed to operand planes ONCE for its two consumers; conv1's epilogue emits the planes of relu(h) for conv2
-        xr16 = ops.act_pack(x_relu, pro=0, prec=prec)
+        if xr16 is None:
+            xr16 = ops.act_pack(x_relu, pro=0, prec=prec)
         h, h16 = _conv(x_relu, c1, track, states, prec, ksize=3, x16=xr16, emit16=1, want_y=not PLANES_ONLY)      # (h itself is never read: conv2 takes the planes)
         shortcut = _conv(x_relu, self.skip._modules['0'], track, states, prec, ksize=1, x16=xr16) if self.has_skip else x_relu
         out = _conv(h, c2, track, states, prec, res=shortcut, ksize=3, pro=2, x16=h16)
-        return AvgPool2Fn.apply(out, False) if self.downsample else out
+        if self.downsample and last:          # the final feature map is handed out BEFORE any ReLU (the reference appends it un-mutated)
+            return AvgPool2Fn.apply(out, False)
+        return pool_relu(out, next_prec) if self.downsample else out
+
+
+def pool_relu(out, next_prec):
+    """-> (relu(AvgPool2d(2)(out)), its operand planes in mode ``next_prec`` | None) in one launch; LP_D_POOL_RELU=0: pool, then torch.relu"""
+    next_prec = default_prec() if next_prec is None else next_prec
+    if not FUSE_POOL_RELU:
+        return torch.relu(AvgPool2Fn.apply(out, False)), None
+    holder = []
+    y = AvgPool2Fn.apply(out, False, (next_prec, holder), True)
+    o16 = holder[0] if holder else None
+    # (the pool launch writes one-plane operand modes; for a bf16x3 consumer hipops.avgpool2_fwd falls back to an act_pack of y)
+    return y, o16
 
 
 class Discriminator(nn.Module):
@@ -207,13 +227,23 @@ class Discriminator(nn.Module):
         p0 = unit_prec(0)
         h, h16 = _conv(xn, d0, track_weights, states, p0, ksize=3, emit16=1, want_y=not PLANES_ONLY)
         shortcut = _conv(xn, sk, track_weights, states, p0, ksize=1)
-        out = AvgPool2Fn.apply(_conv(h, d2, track_weights, states, p0, res=shortcut, ksize=3, pro=2, x16=h16), False)
+        nb = len(self.blocks)
+        out_relu, xr16 = pool_relu(_conv(h, d2, track_weights, states, p0, res=shortcut, ksize=3, pro=2, x16=h16), unit_prec(1) if nb else None)
         feats = []
+        out = out_relu
         for bi, block in enumerate(self.blocks):
-            out_relu = torch.relu(out)           # what the reference's in-place ReLU leaves behind in its feature list
+            # out_relu = relu(previous unit's output): what the reference's in-place ReLU leaves behind in its feature list
             lpnn.tape_relu(lambda: out_relu > 0)
             feats.append(as_nchw_view(out_relu))
-            out = block(out_relu, track_weights, states, unit_prec(bi + 1))
+            last = bi + 1 == nb
+            res = block(out_relu, track_weights, states, unit_prec(bi + 1), xr16=xr16, next_prec=None if last else unit_prec(bi + 2), last=last)
+            if block.downsample and not last:
+                out_relu, xr16 = res
+                out = out_relu
+            else:
+                out = res
+                if bi + 1 < nb:          # (a non-pooling block in the middle of the stack: its successor's in-place ReLU)
+                    out_relu, xr16 = torch.relu(out), None
         feats.append(as_nchw_view(out))
         lpnn.tape_relu(lambda: out > 0)
         pooled = torch.relu(out).sum(dim=(1, 2))

@@ -400,11 +400,49 @@ def conv_wgrad16(a: Act16, dy: Act16, *, ksize: int, upsample: bool = False, pre
     return (dw, None if bias_accum is not None else db) if bias_grad else dw
 
 
+# Launch diet (round 5): inside ``nn.fused_grad_accumulation`` the spectral-norm gradient rule of a conv weight whose result is ACCUMULATED into
+# the parameter's .grad (nothing is returned to autograd) is not launched per layer; the jobs are collected and run by lp_sn_grad_apply_batch
+# when the context is left (after every side stream is joined, before anything reads .grad).  LP_SN_DEFER=0: per-layer launches.
+SN_DEFER = os.environ.get('LP_SN_DEFER', '1') != '0'
+_SN_DEFER = {'depth': 0, 'jobs': []}
+
+
+def sn_defer_begin():
+    _SN_DEFER['depth'] += 1
+
+
+def sn_defer_end(discard: bool = False):
+    """leave one level of deferral; the outermost level runs (or, after a failed backward, drops) the collected jobs"""
+    _SN_DEFER['depth'] -= 1
+    if _SN_DEFER['depth'] > 0:
+        return
+    jobs, _SN_DEFER['jobs'] = _SN_DEFER['jobs'], []
+    if not jobs or discard:
+        return
+    import struct
+    assert _lib.lib().lp_sn_apply_desc_bytes() == 64
+    blob = bytearray()
+    targets = set()
+    for dw, u, v, sig, dot, ndot, accum in jobs:
+        assert accum.data_ptr() not in targets, 'two deferred spectral-norm jobs accumulate into the same tensor'
+        targets.add(accum.data_ptr())
+        blob += struct.pack('<QQQQQQiiii', dw.data_ptr(), u.data_ptr(), v.data_ptr(), sig.data_ptr(), dot.data_ptr(), accum.data_ptr(), ndot,
+                            dw.shape[0], dw.numel() // dw.shape[0], 0)
+    import ctypes
+    buf = (ctypes.c_char * len(blob)).from_buffer(blob)
+    check(_lib.lib().lp_sn_grad_apply_batch(ctypes.addressof(buf), len(jobs), _stream()), 'lp_sn_grad_apply_batch')
+    # (the temporaries in `jobs` are released here, AFTER the launch was enqueued on the stream that allocated them or was joined with it)
+
+
 def _sn_finish(dw, sn, accum, dot=None, ndot=0):
     if sn is None:
         return dw
     w_orig, u, v, sig = sn
     cout = dw.shape[0]
+    if accum is not None and ndot > 0 and dot is not None and SN_DEFER and _SN_DEFER['depth'] > 0:
+        assert accum.is_contiguous() and accum.dtype == torch.float32 and accum.numel() == dw.numel()
+        _SN_DEFER['jobs'].append((dw, u, v, sig, dot, ndot, accum))
+        return None
     if dot is None:
         dot = torch.empty(512, dtype=torch.float32, device=dw.device)      # per-block partials of <g, W>, taken by lp_sn_grad_apply
     if accum is not None:
@@ -695,14 +733,15 @@ def relu_bwd(dA: Tensor, x: Tensor) -> Tensor:
     return dx
 
 
-def avgpool2_fwd(x: Tensor, relu_in: bool, out16_prec: Optional[int] = None):
-    """AvgPool2d(2) of relu?(x).  ``out16_prec`` (PREC_F16 | PREC_BF16, C % 8 == 0): also the operand planes of y -> (y, Act16)"""
+def avgpool2_fwd(x: Tensor, relu_in: bool, out16_prec: Optional[int] = None, relu_out: bool = False):
+    """AvgPool2d(2) of relu?(x); ``relu_out``: y = relu(pool(x)).  ``out16_prec`` (PREC_F16 | PREC_BF16, C % 8 == 0): also the operand planes of y
+    -> (y, Act16)"""
     _chk(x, 'x')
     n, h2, w2, c = x.shape
     y = torch.empty((n, h2 // 2, w2 // 2, c), dtype=torch.float32, device=x.device)
     fused = out16_prec is not None and out16_prec != PREC_BF16X3 and c % 8 == 0
     o_hi = torch.empty((n, h2 // 2, w2 // 2, c), dtype=torch.int16, device=x.device) if fused else None
-    check(_lib.lib().lp_avgpool2_fwd(x.data_ptr(), y.data_ptr(), n, h2 // 2, w2 // 2, c, int(relu_in), _p(o_hi),
+    check(_lib.lib().lp_avgpool2_fwd(x.data_ptr(), y.data_ptr(), n, h2 // 2, w2 // 2, c, int(relu_in) | (2 if relu_out else 0), _p(o_hi),
                                      out16_prec if fused else 0, _stream()), 'lp_avgpool2_fwd')
     if out16_prec is None:
         return y
@@ -719,12 +758,23 @@ def avgpool2_fwd16(x: Act16, prec: int) -> Act16:
     return Act16(o_hi, None, c, None)
 
 
-def avgpool2_bwd(dy: Tensor, x: Tensor, relu_in: bool, amax: bool = False) -> Tensor:
-    _chk(dy, 'dy'); _chk(x, 'x')
-    n, h, w, c = x.shape
-    dx = torch.empty_like(x)
-    check(_lib.lib().lp_avgpool2_bwd(dy.data_ptr(), x.data_ptr(), dx.data_ptr(), n, h, w, c, int(relu_in), _p(_amax_attach(dx, amax)),
-                                     _stream()), 'lp_avgpool2_bwd')
+def avgpool2_bwd(dy: Tensor, x: Optional[Tensor], relu_in: bool, amax: bool = False, y_relu: Optional[Tensor] = None) -> Tensor:
+    """backward of ``avgpool2_fwd``: ``x`` = the forward's input (read only with ``relu_in``); ``y_relu`` = the forward's OUTPUT when it applied
+    ``relu_out`` (dy is masked by [y > 0]); with neither mask nothing of the forward needs to be kept"""
+    _chk(dy, 'dy')
+    assert not (relu_in and y_relu is not None)
+    n, ho, wo, c = dy.shape
+    h, w = 2 * ho, 2 * wo
+    mask = None
+    if relu_in:
+        _chk(x, 'x'); assert tuple(x.shape) == (n, h, w, c)
+        mask = x
+    elif y_relu is not None:
+        _chk(y_relu, 'y_relu'); assert tuple(y_relu.shape) == tuple(dy.shape)
+        mask = y_relu
+    dx = torch.empty((n, h, w, c), dtype=torch.float32, device=dy.device)
+    check(_lib.lib().lp_avgpool2_bwd(dy.data_ptr(), _p(mask), dx.data_ptr(), n, h, w, c, int(relu_in) | (2 if y_relu is not None else 0),
+                                     _p(_amax_attach(dx, amax)), _stream()), 'lp_avgpool2_bwd')
     return dx
 
 

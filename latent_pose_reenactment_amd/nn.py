@@ -103,16 +103,20 @@ class fused_grad_accumulation:
     def __enter__(self):
         self.prev = _FUSED_ACCUM[0]
         _FUSED_ACCUM[0] = True
+        ops.sn_defer_begin()          # spectral-norm gradient rules of accumulated conv weights: one batched launch at the exit (hipops.sn_defer_end)
 
     def __exit__(self, *exc):
         _FUSED_ACCUM[0] = self.prev
         from latent_pose_reenactment_amd import streams
         if exc[0] is None:
-            #  every branch that accumulated on a side stream is joined HERE, so no caller can read .grad early; then the
-            # second accumulation buffers (``alt_accumulation``) are folded into .grad
+            #  every branch that accumulated on a side stream is joined HERE, so no caller can read .grad early; then the deferred
+            # spectral-norm jobs run (their operands were produced on the joined streams) and the second accumulation buffers
+            # (``alt_accumulation``) are folded into .grad
             streams.join_all()
+            ops.sn_defer_end()
             flush_alt_accumulation()
         else:
+            ops.sn_defer_end(discard=True)
             #  a backward pass that raised half-way (out of memory, a caught-and-skipped step) leaves partial gradients in the second
             # buffers; zero_grad never touches those, so they are DISCARDED here instead of being added into the next successful step's .grad
             try:
@@ -984,24 +988,28 @@ def hip_conv(x, w, bias=None, res=None, ksize=3, pro=0, prec=None, packs=None, s
 
 
 class AvgPool2Fn(torch.autograd.Function):
-    """AvgPool2d(2) of relu?(x), NHWC (blocks.py:89-90 / perceptual_loss.py:77 with the preceding ReLU fused)."""
+    """AvgPool2d(2) of relu?(x), NHWC (blocks.py:89-90 / perceptual_loss.py:77 with the preceding ReLU fused); ``relu_out``: relu(pool(x)) -- the
+    in-place ReLU of the critic's NEXT block (blocks.py:71-73) fused into the pool launch (round 5: one launch instead of pool + relu + pack)."""
 
     @staticmethod
-    def forward(ctx, x, relu_in, emit=None):
+    def forward(ctx, x, relu_in, emit=None, relu_out=False):
         """``emit`` = (prec, holder list): the pool launch also writes the operand planes of y for the conv that follows"""
-        ctx.save_for_backward(x)
         ctx.relu_in = relu_in
         ctx.f16 = (default_prec() if emit is None else emit[0]) == PREC_F16      # the mode of the module that owns this pool
         if emit is None:
-            return ops.avgpool2_fwd(x, relu_in)
-        y, o16 = ops.avgpool2_fwd(x, relu_in, out16_prec=emit[0])
-        emit[1].append(o16)
+            y = ops.avgpool2_fwd(x, relu_in, relu_out=relu_out)
+        else:
+            y, o16 = ops.avgpool2_fwd(x, relu_in, out16_prec=emit[0], relu_out=relu_out)
+            emit[1].append(o16)
+        # only what the backward reads is kept: the input for a ReLU on the way in, the OUTPUT for a ReLU on the way out, else nothing
+        ctx.kept = 'x' if relu_in else 'y' if relu_out else None
+        ctx.save_for_backward(x if relu_in else y if relu_out else None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        (x,) = ctx.saved_tensors
-        return ops.avgpool2_bwd(dy.contiguous(), x, ctx.relu_in, amax=ctx.f16), None, None
+        (t,) = ctx.saved_tensors
+        return ops.avgpool2_bwd(dy.contiguous(), t if ctx.kept == 'x' else None, ctx.relu_in, amax=ctx.f16, y_relu=t if ctx.kept == 'y' else None), None, None, None
 
 
 class L1Fn(torch.autograd.Function):
@@ -1024,6 +1032,22 @@ class L1Fn(torch.autograd.Function):
 
 def hip_l1(a, b, relu_in=False):
     return L1Fn.apply(a, b.detach(), relu_in)
+
+
+def hip_l1_mean(a, b):
+    """``F.l1_loss(a, b.detach())`` (mean reduction) of two equally shaped fp32 CUDA tensors of ANY shape on the lp_l1_* kernels: the tensors are
+    taken in their storage order (an element-wise loss does not care), flattened, and -- toy shapes only -- zero-padded to a multiple of 4"""
+    if not (a.is_cuda and b.is_cuda):
+        raise RuntimeError('the L1 criterions run on the MI355X HIP path only (no CPU fallback)')
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if a.dim() == 4 and a.stride() == b.stride() and a.permute(0, 2, 3, 1).is_contiguous():      # channels_last views (the critic's feature lists): no copy
+        a, b = a.permute(0, 2, 3, 1), b.permute(0, 2, 3, 1)
+    a, b = a.contiguous().reshape(-1), b.detach().contiguous().reshape(-1)
+    n = a.numel()
+    if n % 4:
+        a, b = F.pad(a, (0, 4 - n % 4)), F.pad(b, (0, 4 - n % 4))
+        return L1Fn.apply(a, b, False) * (a.numel() / n)
+    return L1Fn.apply(a, b, False)
 
 
 class L1TapFn(torch.autograd.Function):

@@ -58,5 +58,17 @@ for i in range(steps):
     step()
     torch.cuda.synchronize()
     compare(f'after {mode} step {i + 1}')
+if mode == 'graph' and os.environ.get('DIAG_EAGER_AFTER', '1') != '0':
+    # what bench.py does after its timed replays: two EAGER one-stream steps (the instrumented steps of its live roofline)
+    keep = os.environ.get('LP_OVERLAP')
+    os.environ['LP_OVERLAP'] = '0'
+    for i in range(2):
+        holycow.train_step(tm, data, target, opt_G, opt_D, args)
+        torch.cuda.synchronize()
+        compare(f'after eager one-stream step {i + 1} following the replays')
+    if keep is None:
+        os.environ.pop('LP_OVERLAP', None)
+    else:
+        os.environ['LP_OVERLAP'] = keep
 dist.barrier()
 dist.destroy_process_group()
