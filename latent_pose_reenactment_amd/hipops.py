@@ -419,18 +419,27 @@ def sn_defer_end(discard: bool = False):
     jobs, _SN_DEFER['jobs'] = _SN_DEFER['jobs'], []
     if not jobs or discard:
         return
+    import ctypes
     import struct
     assert _lib.lib().lp_sn_apply_desc_bytes() == 64
-    blob = bytearray()
-    targets = set()
-    for dw, u, v, sig, dot, ndot, accum in jobs:
-        assert accum.data_ptr() not in targets, 'two deferred spectral-norm jobs accumulate into the same tensor'
-        targets.add(accum.data_ptr())
-        blob += struct.pack('<QQQQQQiiii', dw.data_ptr(), u.data_ptr(), v.data_ptr(), sig.data_ptr(), dot.data_ptr(), accum.data_ptr(), ndot,
-                            dw.shape[0], dw.numel() // dw.shape[0], 0)
-    import ctypes
-    buf = (ctypes.c_char * len(blob)).from_buffer(blob)
-    check(_lib.lib().lp_sn_grad_apply_batch(ctypes.addressof(buf), len(jobs), _stream()), 'lp_sn_grad_apply_batch')
+    # jobs that accumulate into the SAME tensor (two passes of the critic depositing on one parameter from one stream) must not share a launch:
+    # a job joins the first round that does not hold its target yet; the rounds run one after the other on this stream
+    rounds = []
+    for job in jobs:
+        key = job[6].data_ptr()
+        for targets, members in rounds:
+            if key not in targets:
+                targets.add(key); members.append(job)
+                break
+        else:
+            rounds.append(({key}, [job]))
+    for _, members in rounds:
+        blob = bytearray()
+        for dw, u, v, sig, dot, ndot, accum in members:
+            blob += struct.pack('<QQQQQQiiii', dw.data_ptr(), u.data_ptr(), v.data_ptr(), sig.data_ptr(), dot.data_ptr(), accum.data_ptr(), ndot,
+                                dw.shape[0], dw.numel() // dw.shape[0], 0)
+        buf = (ctypes.c_char * len(blob)).from_buffer(blob)
+        check(_lib.lib().lp_sn_grad_apply_batch(ctypes.addressof(buf), len(members), _stream()), 'lp_sn_grad_apply_batch')
     # (the temporaries in `jobs` are released here, AFTER the launch was enqueued on the stream that allocated them or was joined with it)
 
 

@@ -451,7 +451,10 @@ def generator_channels(num_channels: int, max_num_channels: int, image_size: int
 # ----------------------------------------------------------------------------------------------------------------------
 # the decoder as ONE autograd Function over HIP kernels
 # ----------------------------------------------------------------------------------------------------------------------
-G_Y16 = os.environ.get('LP_G_Y16', '1') != '0'      # fp16 mode: the decoder's conv outputs on >= 32 x 32 maps stay 16-bit resident (round 5)
+G_Y16 = os.environ.get('LP_G_Y16', '1') != '0'      # fp16 mode: the decoder's conv outputs on the large maps stay 16-bit resident (round 5)
+# smallest map (output height) that runs 16-bit resident: 64 -- at 32 x 32 the launches that do not cover the fused statistics would need a decode +
+# statistics pass (measured: two extra launch pairs per step), and 6 % of the decoder's activation bytes live there
+Y16_MIN_MAP = int(os.environ.get('LP_G_Y16_MIN', '64'))
 
 
 class _DecoderFunction(torch.autograd.Function):
@@ -483,7 +486,7 @@ class _DecoderFunction(torch.autograd.Function):
             off += 2 * c
             return gamma, beta, o
 
-        # 16-BIT-RESIDENT conv outputs (round 5, fp16 mode, maps of >= 32 x 32 -- where the conv epilogue also leaves the norm statistics): a
+        # 16-BIT-RESIDENT conv outputs (round 5, fp16 mode, maps of >= 64 x 64 -- Y16_MIN_MAP; the conv epilogue also leaves the norm statistics there): a
         # conv between two AdaIN blocks writes the UNSCALED fp16 plane of y (+ the {count, mean, M2} partials from its fp32 accumulators) and no
         # fp32 y.  The plane IS the raw operand of the next block's 1x1 skip conv (exactly what lp_act_pack pro 0 produced from fp32 y), the
         # AdaIN + ReLU prologue reads 2 B per element (lp_adain_act16), and the backward recomputes x-hat / the ReLU pattern from the same plane
@@ -507,7 +510,7 @@ class _DecoderFunction(torch.autograd.Function):
 
         def conv_out(a, pk, hout, **kw):
             """-> (y fp32 | the fp16 plane of y, statistics partials | None)"""
-            if y16 and hout >= 32 and pk.rows % 8 == 0:
+            if y16 and hout >= Y16_MIN_MAP and pk.rows % 8 == 0:
                 _, o16, cs = ops.conv16(a, pk, prec=prec, stats=True, want_y=False, out16=0, **kw)
                 return o16, cs
             return ops.conv16(a, pk, prec=prec, stats=True, **kw)
@@ -536,7 +539,7 @@ class _DecoderFunction(torch.autograd.Function):
                 s = ops.conv16(xs, ps, ksize=1, bias=bs.detach().contiguous(), alpha=sn[wi - 2][2][1:], prec=prec)   # 1x1 commutes with nearest upsampling
                 rs = 1 if up else 0
             else:
-                assert not isinstance(x, ops.Act16), 'an identity skip adds the fp32 block input (blocks without a skip conv sit on the < 32 x 32 maps)'
+                assert not isinstance(x, ops.Act16), 'an identity skip adds the fp32 block input (blocks without a skip conv sit on the smallest maps)'
                 s, rs = x, 0
             i2 = wi - (3 if has_skip else 1)
             p2 = fpack(i2, w2)
