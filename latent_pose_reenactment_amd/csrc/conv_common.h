@@ -23,11 +23,6 @@ struct Conv16Params {
                                   // extra pass over it).  Host-checked: every wave's rows lie in one image, tiles cover the images exactly.
     long long stats_cap;          // (host) capacity of `stats` in floats
     int stats_rows;               // (host, out) partial rows per image the launch wrote (0: none -- geometry not covered, caller runs the stats pass)
-    unsigned int* sk_count;       // split-K finish INSIDE the conv kernel (round 5): one zero-initialised, self-resetting counter per output tile
-                                  // (tile = blockIdx.x + blockIdx.y * gridDim.x).  Every slice writes its partial tile, then bumps the tile's
-                                  // counter; the workgroup that sees ksplit - 1 there is the last one: it sums the ksplit partial tiles in slice
-                                  // order (the order splitk_reduce_kernel used: bit-identical results) and runs the whole epilogue.  NULL: the
-                                  // caller launches splitk_reduce_kernel.
     int grouped;                  // block-diagonal (grouped) conv: the workgroup's 64 output channels only see input channels co0 .. co0+63;
                                   // the weight image then has 64 columns (CinP = 64) and the activation channel offset is co0
 };
@@ -81,43 +76,6 @@ __device__ __forceinline__ void conv16_epilogue(const Conv16Params& p, f32x4_t (
         if (p.bias && co < p.Cout) bv = *(const float4*)(p.bias + co);
         float am = 0.f;
         float st_n = 0.f, st_ref[4] = {0.f, 0.f, 0.f, 0.f}, st_d[4] = {0.f, 0.f, 0.f, 0.f}, st_q[4] = {0.f, 0.f, 0.f, 0.f};
-        // everything after the contraction for one float4 of one output pixel: scale, bias, residual, ReLU-backward mask, the optional outputs
-        auto emit = [&](float4 v, int n, int oyy, int oxx) {
-            v.x = fmaf(v.x, alpha, bv.x); v.y = fmaf(v.y, alpha, bv.y); v.z = fmaf(v.z, alpha, bv.z); v.w = fmaf(v.w, alpha, bv.w);
-            if (p.res) {
-                const float4 rv = *(const float4*)(p.res + ((size_t)(n * (p.H >> p.res_shift) + (oyy >> p.res_shift)) * (p.W >> p.res_shift)
-                                                            + (oxx >> p.res_shift)) * p.Cout + co);
-                v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-            }
-            const size_t pix = (size_t)(n * p.H + oyy) * p.W + oxx;
-            if (p.mask16) {
-                const ushort4 mv = *(const ushort4*)(p.mask16 + pix * p.Co8 + co);      // > 0  <=>  sign clear and magnitude non-zero
-                v.x = (mv.x - 1u) < 0x7fffu ? v.x : 0.f; v.y = (mv.y - 1u) < 0x7fffu ? v.y : 0.f;
-                v.z = (mv.z - 1u) < 0x7fffu ? v.z : 0.f; v.w = (mv.w - 1u) < 0x7fffu ? v.w : 0.f;
-            }
-            if (p.y) *(float4*)(p.y + pix * p.Cout + co) = v;
-            am = lp_amax4(am, v);
-            if (p.stats) {                     // shifted sums (reference = the lane's first value): no cancellation at large |mean| / std
-                const float o4[4] = {v.x, v.y, v.z, v.w};
-                if (st_n == 0.f) { st_ref[0] = v.x; st_ref[1] = v.y; st_ref[2] = v.z; st_ref[3] = v.w; }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { const float d = o4[j] - st_ref[j]; st_d[j] += d; st_q[j] = fmaf(d, d, st_q[j]); }
-                st_n += 1.f;
-            }
-            if (p.o_hi) {
-                float o[4] = {v.x, v.y, v.z, v.w};
-                ushort4 oh, ol;
-                uint16_t* ohp = (uint16_t*)&oh; uint16_t* olp = (uint16_t*)&ol;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float q = p.o_relu ? fmaxf(o[j], 0.f) : o[j];
-                    ohp[j] = lp_f32_to_op16<F16>(q);
-                    if (SPLIT) olp[j] = lp_f32_to_op16<false>(q - lp_op16_to_f32<false>(ohp[j]));
-                }
-                *(ushort4*)(p.o_hi + pix * p.Co8 + co) = oh;
-                if (SPLIT) *(ushort4*)(p.o_lo + pix * p.Co8 + co) = ol;
-            }
-        };
 #pragma unroll
         for (int mp = 0; mp < MR; mp += MRP) {
 #pragma unroll
@@ -137,52 +95,50 @@ __device__ __forceinline__ void conv16_epilogue(const Conv16Params& p, f32x4_t (
             const int n = n0 + nb, oyy = y0 + py, oxx = x0 + px;
             if (nb < NBv && n < p.N && oyy < p.H && oxx < p.W && co < p.Cout) {
                 float4 v = *(const float4*)(tile + (row - mp * 16) * LDW + c4 * 4);
-                if (p.ksplit > 1) {        // split-K: the raw partial tile; the last slice of the tile (below) or splitk_reduce_kernel finishes
+                if (p.ksplit > 1) {        // split-K: the raw partial tile; splitk_reduce_kernel sums the slices and applies the epilogue
                     const size_t pixs = (size_t)(n * p.H + oyy) * p.W + oxx;
                     *(float4*)(p.part + ((size_t)blockIdx.z * p.N * p.H * p.W + pixs) * p.Cout + co) = v;
                     continue;
                 }
-                emit(v, n, oyy, oxx);
-            }
-        }
-        }
-        if (p.ksplit > 1) {
-            if (!p.sk_count) return;                                       // finished by splitk_reduce_kernel
-            // ---- split-K finish in the LAST workgroup of the tile (device-scope release of the partial tile, counter bump, acquire).  The
-            // flag travels through the first word of the (now dead) LDS transpose scratch: no static LDS beside the kernels' 160 KB budgets.
-            volatile int* sk_last = (volatile int*)smem;
-            __threadfence();
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                unsigned int* cnt = p.sk_count + (blockIdx.x + blockIdx.y * gridDim.x);
-                const unsigned int old = atomicAdd(cnt, 1u);
-                const int last = (old == (unsigned)p.ksplit - 1u);
-                if (last) atomicExch(cnt, 0u);                              // self-reset: the next launch on this counter set starts from zero
-                *sk_last = last;
-            }
-            __syncthreads();
-            if (!*sk_last) return;
-            __threadfence();
-            const size_t slice = (size_t)p.N * p.H * p.W * p.Cout;
-#pragma unroll 2
-            for (int row = rsub; row < WR; row += RPP) {
-                const int m = wm * WR + row;
-                int nb, py, px;
-                tile_row_linear(m, p.lTH, p.lTW, nb, py, px);
-                const int n = n0 + nb, oyy = y0 + py, oxx = x0 + px;
-                if (nb < NBv && n < p.N && oyy < p.H && oxx < p.W && co < p.Cout) {
-                    const float* src = p.part + ((size_t)(n * p.H + oyy) * p.W + oxx) * p.Cout + co;
-                    float4 v = *(const float4*)src;
-                    for (int z = 1; z < p.ksplit; ++z) {
-                        const float4 q = *(const float4*)(src + z * slice);
-                        v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+                v.x = fmaf(v.x, alpha, bv.x); v.y = fmaf(v.y, alpha, bv.y); v.z = fmaf(v.z, alpha, bv.z); v.w = fmaf(v.w, alpha, bv.w);
+                if (p.res) {
+                    const float4 rv = *(const float4*)(p.res + ((size_t)(n * (p.H >> p.res_shift) + (oyy >> p.res_shift)) * (p.W >> p.res_shift)
+                                                                + (oxx >> p.res_shift)) * p.Cout + co);
+                    v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                }
+                const size_t pix = (size_t)(n * p.H + oyy) * p.W + oxx;
+                if (p.mask16) {
+                    const ushort4 mv = *(const ushort4*)(p.mask16 + pix * p.Co8 + co);      // > 0  <=>  sign clear and magnitude non-zero
+                    v.x = (mv.x - 1u) < 0x7fffu ? v.x : 0.f; v.y = (mv.y - 1u) < 0x7fffu ? v.y : 0.f;
+                    v.z = (mv.z - 1u) < 0x7fffu ? v.z : 0.f; v.w = (mv.w - 1u) < 0x7fffu ? v.w : 0.f;
+                }
+                if (p.y) *(float4*)(p.y + pix * p.Cout + co) = v;
+                am = lp_amax4(am, v);
+                if (p.stats) {                     // shifted sums (reference = the lane's first value): no cancellation at large |mean| / std
+                    const float o4[4] = {v.x, v.y, v.z, v.w};
+                    if (st_n == 0.f) { st_ref[0] = v.x; st_ref[1] = v.y; st_ref[2] = v.z; st_ref[3] = v.w; }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const float d = o4[j] - st_ref[j]; st_d[j] += d; st_q[j] = fmaf(d, d, st_q[j]); }
+                    st_n += 1.f;
+                }
+                if (p.o_hi) {
+                    float o[4] = {v.x, v.y, v.z, v.w};
+                    ushort4 oh, ol;
+                    uint16_t* ohp = (uint16_t*)&oh; uint16_t* olp = (uint16_t*)&ol;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float q = p.o_relu ? fmaxf(o[j], 0.f) : o[j];
+                        ohp[j] = lp_f32_to_op16<F16>(q);
+                        if (SPLIT) olp[j] = lp_f32_to_op16<false>(q - lp_op16_to_f32<false>(ohp[j]));
                     }
-                    emit(v, n, oyy, oxx);
+                    *(ushort4*)(p.o_hi + pix * p.Co8 + co) = oh;
+                    if (SPLIT) *(ushort4*)(p.o_lo + pix * p.Co8 + co) = ol;
                 }
             }
         }
-        if (p.amax) lp_amax_commit(am, p.amax, blockIdx.x + blockIdx.y * 7u);
-        if (p.stats) {
+        }
+        if (p.amax && p.ksplit == 1) lp_amax_commit(am, p.amax, blockIdx.x + blockIdx.y * 7u);
+        if (p.stats && p.ksplit == 1) {
             // lane -> (count, mean, M2) of its 4 channels over its rows; the RPP lanes that share the channel quad (lane bits above C4)
             // merge pairwise (Chan et al.); rsub == 0 writes the wave's partial: row block = tile * WM + wm
             float mean[4], m2[4];

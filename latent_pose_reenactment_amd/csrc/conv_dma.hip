@@ -34,31 +34,6 @@
 
 __device__ __attribute__((aligned(64))) unsigned int lp_zero_page[16];      // what out-of-image / out-of-channel DMA lanes read
 
-// Counter sets of the in-kernel split-K finish (conv_common.h: Conv16Params::sk_count): SK_SETS sets of SK_TILES zero-initialised, self-resetting
-// counters.  Every split-K launch takes the next set round-robin, so two launches can only share a set when SK_SETS other split-K launches were
-// issued between them -- never while both are in flight (a training step issues ~120; inside a hipGraph the set index is part of the captured
-// kernel arguments, i.e. every node of the graphs of a step has its own set).  LP_SPLITK_FUSED=0: finish by splitk_reduce_kernel (round 4).
-#define SK_SETS 1024
-#define SK_TILES 256
-__device__ unsigned int lp_sk_counters[SK_SETS * SK_TILES];
-
-static unsigned int* sk_counter_set(int tiles) {
-    static const bool on = !(getenv("LP_SPLITK_FUSED") && atoi(getenv("LP_SPLITK_FUSED")) == 0);
-    if (!on || tiles > SK_TILES) return nullptr;
-    static thread_local int dev_cached = -1;
-    static thread_local unsigned int* base = nullptr;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    if (dev != dev_cached) {
-        void* ptr = nullptr;
-        if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(lp_sk_counters)) != hipSuccess) return nullptr;
-        base = (unsigned int*)ptr; dev_cached = dev;
-    }
-    static unsigned int next = 0;
-    const unsigned int set = __atomic_fetch_add(&next, 1u, __ATOMIC_RELAXED) % SK_SETS;
-    return base + (size_t)set * SK_TILES;
-}
-
 
 // GH (grouped convs with groups of <= 32 channels): output channels [co0, co0 + 32) only contract with the chunk co0 .. co0 + 31 and
 // [co0 + 32, co0 + 64) only with the second chunk -- the other half of every stage's MFMAs multiplies the zeros of the block-diagonal weight
@@ -455,7 +430,6 @@ static int launch_conv16(Conv16Params& p, hipStream_t stream) {
         for (;;) { const int per = (nch + ks - 1) / ks, k2 = (nch + per - 1) / per; if (k2 == ks) break; ks = k2; }
         p.ksplit = ks;
         grid.z = ks;
-        p.sk_count = ks > 1 ? sk_counter_set((int)(grid.x * grid.y)) : nullptr;
     }
     p.stats_rows = 0;
     if (p.stats) {
@@ -587,7 +561,7 @@ extern "C" int lp_conv16_fwd_stats(const uint16_t* a_hi, const uint16_t* a_lo, c
     p.o_hi = (Cout & 7) ? nullptr : out_hi; p.o_lo = (Cout & 7) ? nullptr : out_lo;   // (pad channels: the pack pass writes them)
     p.N = N; p.H = H; p.W = W; p.Hin = upsample ? H / 2 : H; p.Win = upsample ? W / 2 : W;
     p.Cin = Cin; p.C8 = (Cin + 7) & ~7; p.Cout = Cout; p.Co8 = (Cout + 7) & ~7; p.CinP = CinP; p.CoutP = CoutP; p.res_shift = res_shift;
-    p.grouped = 0; p.stats = stats; p.stats_cap = stats ? stats_capacity_floats : 0; p.stats_rows = 0; p.sk_count = nullptr;
+    p.grouped = 0; p.stats = stats; p.stats_cap = stats ? stats_capacity_floats : 0; p.stats_rows = 0;
     hipStream_t s = (hipStream_t)stream;
     int rc;
     if (prec == LP_PREC_BF16) rc = dispatch_conv16<LP_PREC_BF16>(p, ksize, upsample, s);
@@ -595,7 +569,7 @@ extern "C" int lp_conv16_fwd_stats(const uint16_t* a_hi, const uint16_t* a_lo, c
     else if (prec == LP_PREC_F16) rc = dispatch_conv16<LP_PREC_F16>(p, ksize, upsample, s);
     else return lp_set_error(LP_ERR_ARG, "lp_conv16_fwd: unknown precision mode");
     if (rc) return rc;
-    if (p.ksplit > 1 && !p.sk_count) {
+    if (p.ksplit > 1) {
         const long long items = (long long)N * H * W * (Cout >> 2);
         long long blocks = (items + 255) / 256; if (blocks > 2048) blocks = 2048;
         if (prec == LP_PREC_BF16) hipLaunchKernelGGL(splitk_reduce_kernel<LP_PREC_BF16>, dim3((unsigned)blocks), dim3(256), 0, s, p);
@@ -649,7 +623,7 @@ extern "C" int lp_gconv16_fwd_planes(const uint16_t* a_hi, const uint16_t* a_lo,
     p.mask16 = nullptr; p.o_relu = 0; p.part = nullptr; p.part_bytes = 0; p.amax = amax_slots; p.o_hi = o_hi; p.o_lo = o_lo;
     p.N = N; p.H = H; p.W = W; p.Hin = H; p.Win = W;
     p.Cin = C; p.C8 = C; p.Cout = C; p.Co8 = C; p.CinP = 64; p.CoutP = CP; p.res_shift = 0; p.grouped = 1;
-    p.stats = stats; p.stats_cap = stats ? stats_capacity_floats : 0; p.stats_rows = 0; p.sk_count = nullptr;
+    p.stats = stats; p.stats_cap = stats ? stats_capacity_floats : 0; p.stats_rows = 0;
     hipStream_t s = (hipStream_t)stream;
     int rc;
     // group_size (0: unknown) in 1 .. 32: the two 32-channel halves of a 64-channel block do not interact -- the kernel variant that skips

@@ -28,6 +28,8 @@ from latent_pose_reenactment_amd.parallel import GradReducer  # noqa: E402
 tm.reducer = GradReducer(tm, finetune=False, optimizer_G=opt_G, optimizer_D=opt_D, max_batch=8)
 data, target = bench.synthetic_batch(args, 8, seed=123 + rank)
 named = [(f'{m}.{k}', p) for m in ('generator', 'embedder', 'discriminator') for k, p in getattr(tm, m).named_parameters()]
+# plus the spectral-norm power-iteration vectors of the critic (buffers: rank-local by design, but identical as long as the weights are)
+named += [(f'discriminator.{k} (buffer)', b) for k, b in tm.discriminator.named_buffers() if b.dtype == torch.float32]
 
 
 def checksums():
@@ -44,7 +46,16 @@ def compare(tag):
     dist.all_gather_object(allc, mine)
     if rank == 0:
         bad = [named[i][0] for i in range(len(named)) if any(c[i] != allc[0][i] for c in allc)]
-        print(f'[replicas] {tag}: {len(bad)} of {len(named)} parameters differ between ranks' + (': ' + ', '.join(bad[:12]) + (' ...' if len(bad) > 12 else '') if bad else ''), flush=True)
+        print(f'[replicas] {tag}: {len(bad)} of {len(named)} tensors differ between ranks' + (': ' + ', '.join(bad[:12]) + (' ...' if len(bad) > 12 else '') if bad else ''), flush=True)
+    # how far apart: max |delta| of the label embedding between rank 0 and the others (0 expected)
+    w = tm.discriminator.embed.weight_orig.detach()
+    ref = w.clone()
+    dist.broadcast(ref, 0)
+    d = (w - ref).abs()
+    stat = torch.stack([d.max(), (d > 0).sum().float(), (d > 0).any(dim=1).sum().float()])
+    dist.all_reduce(stat, op=dist.ReduceOp.MAX)
+    if rank == 0 and float(stat[0]) > 0:
+        print(f'[replicas]    label embedding vs rank 0: max |delta| {float(stat[0]):.3e}, {int(stat[1])} elements in {int(stat[2])} rows differ', flush=True)
 
 
 compare('after the start-up broadcast')
