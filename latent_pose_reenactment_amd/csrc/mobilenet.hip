@@ -13,6 +13,13 @@
 #include "lp_common.h"
 #include "lp_hip.h"
 #include "lp_internal.h"
+// No packed fp32 arithmetic in this file: on gfx950 the forms the compiler picks for "vector times broadcast scalar" with the scalar in the
+// HIGH dword of a register pair (v_pk_fma_f32 ... op_sel:[0,1,0], v_pk_mul_f32 / v_pk_add_f32 op_sel:[0,1]) returned a wrong LOW half in lanes
+// 48..63 whenever the LDS-DMA convolution kernels ran beside them on another stream (scripts/pk_forms_probe.py,
+// profiles/r05_pk_fp32_opsel_hazard.txt; alone they are exact).  tests/test_isa_lint.py keeps those forms out of the whole library.
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma clang attribute push(__attribute__((target("no-packed-fp32-ops"))), apply_to = function)
+#endif
 
 // x [N][3][H][W] fp32 (NCHW, as the dataloader hands frames over), w [Cout][3][3][3] (nn.Conv2d layout) -> y [N][H/2][W/2][Cout]
 __global__ __launch_bounds__(256) void stem_conv_s2_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
@@ -791,3 +798,7 @@ extern "C" int lp_dwconv3x3_wgrad(const float* x, const float* in_scale, const f
     hipLaunchKernelGGL(dwconv3x3_wgrad_reduce_kernel, dim3((9 * C + 255) / 256), dim3(256), 0, st, workspace, dw, blocks, C);
     return lp_check_launch("dwconv3x3_wgrad_reduce");
 }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma clang attribute pop
+#endif

@@ -7,6 +7,13 @@
 #include "lp_common.h"
 #include "lp_hip.h"
 #include "lp_internal.h"
+// No packed fp32 arithmetic in this file: on gfx950 the forms the compiler picks for "vector times broadcast scalar" with the scalar in the
+// HIGH dword of a register pair (v_pk_fma_f32 ... op_sel:[0,1,0], v_pk_mul_f32 / v_pk_add_f32 op_sel:[0,1]) returned a wrong LOW half in lanes
+// 48..63 whenever the LDS-DMA convolution kernels ran beside them on another stream (scripts/pk_forms_probe.py,
+// profiles/r05_pk_fp32_opsel_hazard.txt; alone they are exact).  tests/test_isa_lint.py keeps those forms out of the whole library.
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma clang attribute push(__attribute__((target("no-packed-fp32-ops"))), apply_to = function)
+#endif
 
 struct SnDesc {
     const float* w; float* u; float* v;          // W [rows][cols] row-major; persistent buffers weight_u [rows], weight_v [cols]
@@ -328,3 +335,7 @@ extern "C" int lp_sn_embed_grad(float* grad, const float* u, const float* v, con
     hipLaunchKernelGGL(sn_embed_rows_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, grad, label, rows, N, E, B);
     return lp_check_launch("sn_embed_grad");
 }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma clang attribute pop
+#endif

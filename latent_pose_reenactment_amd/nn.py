@@ -451,7 +451,10 @@ def generator_channels(num_channels: int, max_num_channels: int, image_size: int
 # ----------------------------------------------------------------------------------------------------------------------
 # the decoder as ONE autograd Function over HIP kernels
 # ----------------------------------------------------------------------------------------------------------------------
-G_Y16 = os.environ.get('LP_G_Y16', '1') != '0'      # fp16 mode: the decoder's conv outputs on the large maps stay 16-bit resident (round 5)
+# fp16 mode, OPT-IN (LP_G_Y16=1): the decoder's conv outputs on the large maps stay 16-bit resident (round 5).  Measured (profiles/r05_generator_y16.txt):
+# generator forward + backward 5.12 -> 5.00 ms, meta-training step -0.1 .. -0.3 ms; outputs 1.64e-4 -> 1.83e-4, tie-masked gradients 1.68e-3 ->
+# 1.86e-3 .. 2.16e-3 -- beyond the 2e-3 this package gates the fp16 generator gradients at, for < 1 % of the step: off by default.
+G_Y16 = os.environ.get('LP_G_Y16', '0') != '0'
 # smallest map (output height) that runs 16-bit resident: 64 -- at 32 x 32 the launches that do not cover the fused statistics would need a decode +
 # statistics pass (measured: two extra launch pairs per step), and 6 % of the decoder's activation bytes live there
 Y16_MIN_MAP = int(os.environ.get('LP_G_Y16_MIN', '64'))

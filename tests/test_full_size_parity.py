@@ -126,6 +126,44 @@ def test_generator_256_vs_oracle(prec, tol_out, tol_grad):
         assert untied64 <= 40 * floor32, (untied64, floor32)
 
 
+def test_generator_256_sixteen_bit_resident_conv_outputs(monkeypatch):
+    """LP_G_Y16=1 (opt-in, nn.G_Y16): the decoder's conv outputs on the >= 64 x 64 maps stay 16-bit resident -- lp_adain_act16, lp_adain_relu_bwd16,
+    lp_thin_wgrad16, planes-only conv epilogues with statistics -- against the SAME module with fp32-resident outputs: the two paths differ by
+    one fp16 rounding of every such conv output before its normalisation (outputs: 1e-3 of north_star with a wide margin; gradients compared
+    directly, untied, as vectors: the paths share their ReLU patterns except where that rounding flips a tie)."""
+    from latent_pose_reenactment_amd import nn as lpnn
+    from latent_pose_reenactment_amd.nn import Generator
+    torch.manual_seed(0)
+    G = Generator('zero', 3, 4, 64, 512, 512, 256, 'in', 4, 2, 256, prec=2)
+    with torch.no_grad():
+        G.constant.constant.normal_()
+    G = G.cuda().train()
+    e, p = torch.randn(2, 512).cuda(), torch.randn(2, 256).cuda()
+    with torch.no_grad():
+        for _ in range(5):
+            G({'embeds': e, 'pose_embedding': p})
+    sd = {k: v.clone() for k, v in G.state_dict().items()}
+    g = torch.Generator().manual_seed(1)
+    r1, r2 = torch.randn(2, 3, 256, 256, generator=g).cuda(), torch.randn(2, 1, 256, 256, generator=g).cuda()
+    res = {}
+    for y16 in (False, True):
+        monkeypatch.setattr(lpnn, 'G_Y16', y16)
+        G.load_state_dict(sd)                      # (the power iteration advances u, v: same start for both runs)
+        G.zero_grad(set_to_none=True)
+        ec, pc = e.clone().requires_grad_(True), p.clone().requires_grad_(True)
+        dd = {'embeds': ec, 'pose_embedding': pc}
+        G(dd)
+        ((dd['fake_rgbs'] * r1).sum() + (dd['fake_segm'] * r2).sum()).backward()
+        torch.cuda.synchronize()
+        res[y16] = (dd['fake_rgbs'].detach().clone(), dd['fake_segm'].detach().clone(),
+                    torch.cat([q.grad.reshape(-1) for q in G.parameters() if q.grad is not None] + [ec.grad.reshape(-1), pc.grad.reshape(-1)]).clone())
+    e_rgb, e_segm, e_grad = (rel(a, b) for a, b in zip(res[True], res[False]))
+    cos = float((res[True][2].double() * res[False][2].double()).sum() / (res[True][2].double().norm() * res[False][2].double().norm()))
+    print(f'[parity-256] generator f16, 16-bit-resident conv outputs vs fp32-resident: fake_rgbs {e_rgb:.2e}, fake_segm {e_segm:.2e}, all gradients {e_grad:.2e} (cosine {cos:.6f})')
+    assert e_rgb < 5e-4 and e_segm < 5e-4, (e_rgb, e_segm)
+    assert cos > 0.995, (e_grad, cos)
+
+
 def _with_tape(fn):
     """run ``fn`` (a forward through the HIP modules) while recording the activation pattern of every ReLU site -> (result, masks NCHW, CPU)"""
     from latent_pose_reenactment_amd import nn as lpnn
