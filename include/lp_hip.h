@@ -339,6 +339,24 @@ int lp_avgpool2_fwd16(const uint16_t* x_hi, uint16_t* out_hi, int N, int H, int 
 int lp_avgpool2_bwd(const float* dy, const float* x, float* dx, int N, int H, int W, int C, int relu_in, float* amax_slots, void* stream);
 /* the same with the ReLU mask read from the operand planes mask_hi [N][H][W][C] of relu(x) (ABI 7: planes-only chains keep no fp32 x) */
 int lp_avgpool2_bwd_m16(const float* dy, const uint16_t* mask_hi, float* dx, int N, int H, int W, int C, float* amax_slots, void* stream);
+/* Reflection padding of the 3x3 ResBlock convs (ABI 9) -- reference: generators/common/blocks.py:76-88 `padding(1)` = nn.ReflectionPad2d(1) in
+ * front of a conv with padding 0 (--gen_padding / --dis_padding 'reflection': generators/vector_pose_unsupervised_segmentation_noBottleneck.py:53-58,
+ * discriminators/no_landmarks.py:45-50).  conv(reflect_pad(x)) = conv_zero_pad(x) + B(x), where B adds, at the 2W + 2(H-2) border pixels, the taps that
+ * leave the image applied to the mirrored source pixel (-1 -> 1, H -> H-2).  The three calls add B, B^T and the border's share of the weight gradient
+ * to the results of lp_conv16_fwd / lp_conv16_fwd (data gradient) / lp_conv16_wgrad with zero padding.  H, W = the conv's resolution (>= 4); x planes
+ * [N][H >> upsample][W >> upsample][C8] in operand mode `prec` (x_lo: bf16x3 only) = what the conv consumed; w = W_orig [Cout][Cin][3][3] fp32;
+ * alpha = device scalar 1/sigma | NULL.
+ *   fwd:   y  [N][H][W][Cout] += alpha * sum_{taps t outside at p} W[:, :, t] . x[mirror(p + t)]
+ *   dgrad: dx [N][H][W][Cin]  += alpha * (the transposed sum; gathered per pixel of the ring one pixel inside the border, no atomics), multiplied by
+ *          [mask_hi > 0] when mask_hi (planes [N][H][W][mask_c8] of relu(x), the forward's prologue) is given
+ *   wgrad: gw [Cout][Cin][3][3] = sum_n sum_{p: p + t outside} dy[n][p][:] (x) x[n][mirror(p + t)][:]   (every element written, centre tap 0): the raw
+ *          gradient w.r.t. W/sigma -- lp_sn_grad_apply turns it into the W_orig gradient like the main term (the rule is linear in it). */
+int lp_reflect_border_fwd(const uint16_t* x_hi, const uint16_t* x_lo, int prec, int N, int H, int W, int Cin, int C8, int upsample,
+                          const float* w, int Cout, const float* alpha, float* y, void* stream);
+int lp_reflect_border_dgrad(const float* dy, int N, int H, int W, int Cout, const float* w, int Cin, const float* alpha,
+                            const uint16_t* mask_hi, int mask_c8, float* dx, void* stream);
+int lp_reflect_border_wgrad(const uint16_t* x_hi, const uint16_t* x_lo, int prec, int N, int H, int W, int Cin, int C8, int upsample,
+                            const float* dy, int Cout, float* gw, void* stream);
 /* L1 taps: partial[lp_l1_partial_blocks()] block sums of |relu?(a) - relu?(b)| (F.l1_loss numerator; featmat.py:17, perceptual_loss.py:107);
  * backward: da = coef * grad_out[0] * sign(relu?(a) - relu?(b)) * (relu_in ? [a>0] : 1)  (+ add [numel]|NULL: the gradient that
  * reaches `a` from its other consumer -- the next conv / pool of the VGG stack -- summed here instead of by an autograd add) */

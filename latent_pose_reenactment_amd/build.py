@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 INCLUDE = os.path.join(os.path.dirname(HERE), 'include')
 LIB = os.path.join(HERE, 'liblp_hip.so')
-SOURCES = ['lp_api.hip', 'elementwise.hip', 'spectral_norm.hip', 'act_pack.hip', 'conv_dma.hip', 'conv_pipe.hip', 'conv_wgrad.hip', 'conv_thin.hip', 'linear_crop.hip', 'mobilenet.hip', 'resnext.hip']
+SOURCES = ['lp_api.hip', 'elementwise.hip', 'spectral_norm.hip', 'act_pack.hip', 'conv_dma.hip', 'conv_pipe.hip', 'conv_wgrad.hip', 'conv_thin.hip', 'linear_crop.hip', 'mobilenet.hip', 'resnext.hip', 'reflect_border.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I', INCLUDE, '-I', CSRC]
 
 

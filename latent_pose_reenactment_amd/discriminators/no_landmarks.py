@@ -45,7 +45,7 @@ def gpass_prec():
 class Wrapper:
     @staticmethod
     def get_args(parser):
-        parser.add('--dis_padding', type=str, default='zero', help='zero (reflection is not implemented)')
+        parser.add('--dis_padding', type=str, default='zero', help='zero|reflection')
         parser.add('--dis_num_blocks', type=int, default=7)
         parser.add('--lr_dis', type=float, default=2e-4)
 
@@ -79,8 +79,9 @@ def _conv(x, layer, track, states, prec=None, **kw):
 class _DisBlock(nn.Module):
     """parameters of blocks.ResBlock(norm_layer='none'): block.2, block.5 (3x3 + bias) and optional skip.0 (1x1 + bias)"""
 
-    def __init__(self, cin, cout, downsample):
+    def __init__(self, cin, cout, downsample, reflect=False):
         super().__init__()
+        self.reflect = reflect          # dis_padding='reflection': nn.ReflectionPad2d(1) in front of the block's two 3x3 convs (blocks.py:76-88)
         self.block = _Indexed(_2=SNWeight((cout, cin, 3, 3), True, SN_EPS_CONV), _5=SNWeight((cout, cout, 3, 3), True, SN_EPS_CONV))
         self.has_skip = cin != cout or downsample
         if self.has_skip:
@@ -100,6 +101,13 @@ class _DisBlock(nn.Module):
         # relu(x) is packed to operand planes ONCE for its two consumers; conv1's epilogue emits the planes of relu(h) for conv2
         if xr16 is None:
             xr16 = ops.act_pack(x_relu, pro=0, prec=prec)
+        if self.reflect:          # (border terms are added after each conv launch: no epilogue-emitted planes; conv2 packs relu(h) itself)
+            h = _conv(x_relu, c1, track, states, prec, ksize=3, x16=xr16, reflect=True)
+            shortcut = _conv(x_relu, self.skip._modules['0'], track, states, prec, ksize=1, x16=xr16) if self.has_skip else x_relu
+            out = _conv(h, c2, track, states, prec, res=shortcut, ksize=3, pro=2, reflect=True)
+            if self.downsample and last:
+                return AvgPool2Fn.apply(out, False)
+            return pool_relu(out, next_prec) if self.downsample else out
         h, h16 = _conv(x_relu, c1, track, states, prec, ksize=3, x16=xr16, emit16=1, want_y=not PLANES_ONLY)      # (h itself is never read: conv2 takes the planes)
         shortcut = _conv(x_relu, self.skip._modules['0'], track, states, prec, ksize=1, x16=xr16) if self.has_skip else x_relu
         out = _conv(h, c2, track, states, prec, res=shortcut, ksize=3, pro=2, x16=h16)
@@ -124,8 +132,9 @@ class Discriminator(nn.Module):
     def __init__(self, padding, in_channels, out_channels, num_channels, max_num_channels, embed_channels, dis_num_blocks,
                  image_size, num_labels):
         super().__init__()
-        if padding != 'zero':
-            raise NotImplementedError("only dis_padding='zero' is implemented")
+        if padding not in ('zero', 'reflection'):
+            raise Exception('Incorrect `padding` argument, required `zero` or `reflection`')       # (no_landmarks.py:49-50)
+        reflect = padding == 'reflection'          # (the stem's convs keep their zero padding: no_landmarks.py:52-60 has `padding(1)` commented out)
         self.out_channels = embed_channels
         self.down_block = _Indexed(_0=SNWeight((num_channels, in_channels, 3, 3), True, SN_EPS_CONV),
                                    _2=SNWeight((num_channels, num_channels, 3, 3), True, SN_EPS_CONV))
@@ -138,12 +147,12 @@ class Discriminator(nn.Module):
             cout = min(cin * 2, max_num_channels)
             if i == dis_num_blocks - 1:
                 cout = self.out_channels
-            self.blocks.append(_DisBlock(cin, cout, True))
+            self.blocks.append(_DisBlock(cin, cout, True, reflect))
             cin = cout
         for i in range(num_down, dis_num_blocks):
             if i == dis_num_blocks - 1:
                 cout = self.out_channels
-            self.blocks.append(_DisBlock(cin, cout, False))
+            self.blocks.append(_DisBlock(cin, cout, False, reflect))
         self.linear = SNWeight((1, self.out_channels), True, SN_EPS_CONV)
         self.embed = SNWeight((num_labels, self.out_channels), False, SN_EPS_CONV)
         with torch.no_grad():

@@ -10,7 +10,7 @@ class Wrapper:
     def get_args(parser):
         parser.add('--gen_constant_input_size', type=int, default=4)
         parser.add('--gen_num_residual_blocks', type=int, default=2)
-        parser.add('--gen_padding', type=str, default='zero', help='zero (reflection is not implemented on the HIP path)')
+        parser.add('--gen_padding', type=str, default='zero', help='zero|reflection')
         parser.add('--norm_layer', type=str, default='in')
 
     @staticmethod

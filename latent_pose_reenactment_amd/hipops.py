@@ -461,6 +461,44 @@ def _sn_finish(dw, sn, accum, dot=None, ndot=0):
     return None if accum is not None else dw
 
 
+# ---- reflection padding of the 3x3 ResBlock convs as a border correction of the zero-padded conv (csrc/reflect_border.hip) -----------------------
+def reflect_border_fwd(a: Act16, w_orig: Tensor, alpha: Optional[Tensor], y: Tensor, *, prec: int, upsample: bool = False) -> Tensor:
+    """y [N,H,W,Cout] (the zero-padded conv of up2?(a) with W_orig * alpha) += the taps that leave the image, applied to the mirrored pixels:
+    afterwards y is the conv behind nn.ReflectionPad2d(1) (blocks.py:76-88 with --gen_padding / --dis_padding reflection).  In place."""
+    _chk(y, 'y'); _chk(w_orig, 'w_orig')
+    n, h, w, cout = y.shape
+    assert a.inv is None and a.nhw == ((n, h // 2, w // 2) if upsample else (n, h, w)), (a.hi.shape, y.shape, upsample)
+    assert tuple(w_orig.shape) == (cout, a.c, 3, 3), (w_orig.shape, cout, a.c)
+    check(_lib.lib().lp_reflect_border_fwd(a.hi.data_ptr(), _p(a.lo), prec, n, h, w, a.c, a.hi.shape[3], int(upsample), w_orig.data_ptr(), cout,
+                                           _p(alpha), y.data_ptr(), _stream()), 'lp_reflect_border_fwd')
+    return y
+
+
+def reflect_border_dgrad(dy: Tensor, w_orig: Tensor, alpha: Optional[Tensor], dx: Tensor, mask16: Optional[Act16] = None) -> Tensor:
+    """dx [N,H,W,Cin] (the zero-padded data gradient) += the transposed border terms; ``mask16`` = planes of relu(x) when the forward applied ReLU
+    in its prologue (the main launch masked its result by [x > 0] in its epilogue; the correction is masked the same way).  In place."""
+    _chk(dy, 'dy'); _chk(dx, 'dx'); _chk(w_orig, 'w_orig')
+    n, h, w, cout = dy.shape
+    cin = dx.shape[3]
+    assert tuple(dx.shape[:3]) == (n, h, w) and tuple(w_orig.shape) == (cout, cin, 3, 3), (dx.shape, dy.shape, w_orig.shape)
+    assert mask16 is None or mask16.nhw == (n, h, w)
+    check(_lib.lib().lp_reflect_border_dgrad(dy.data_ptr(), n, h, w, cout, w_orig.data_ptr(), cin, _p(alpha), None if mask16 is None else mask16.hi.data_ptr(),
+                                             0 if mask16 is None else mask16.hi.shape[3], dx.data_ptr(), _stream()), 'lp_reflect_border_dgrad')
+    return dx
+
+
+def reflect_border_wgrad(a: Act16, dy: Tensor, *, prec: int, upsample: bool = False, sn=None, accum: Optional[Tensor] = None) -> Optional[Tensor]:
+    """the border terms' share of the weight gradient, [Cout,Cin,3,3]; ``sn`` / ``accum`` as in ``conv_wgrad16`` (the spectral-norm gradient rule is
+    linear in the raw gradient, so the share is passed through it on its own and added to the same .grad): None when accumulated."""
+    _chk(dy, 'dy')
+    n, h, w, cout = dy.shape
+    assert a.inv is None and a.nhw == ((n, h // 2, w // 2) if upsample else (n, h, w)), (a.hi.shape, dy.shape, upsample)
+    gw = torch.empty((cout, a.c, 3, 3), dtype=torch.float32, device=dy.device)
+    check(_lib.lib().lp_reflect_border_wgrad(a.hi.data_ptr(), _p(a.lo), prec, n, h, w, a.c, a.hi.shape[3], int(upsample), dy.data_ptr(), cout,
+                                             gw.data_ptr(), _stream()), 'lp_reflect_border_wgrad')
+    return _sn_finish(gw, sn, accum)
+
+
 def thin_wgrad_supported(cin: int, cout: int, ksize: int, pro: int, w: int) -> bool:
     return _THIN and bool(_lib.lib().lp_thin_wgrad_supported(cin, cout, ksize, pro, w))
 

@@ -494,7 +494,11 @@ class _DecoderFunction(torch.autograd.Function):
         # fp32 y.  The plane IS the raw operand of the next block's 1x1 skip conv (exactly what lp_act_pack pro 0 produced from fp32 y), the
         # AdaIN + ReLU prologue reads 2 B per element (lp_adain_act16), and the backward recomputes x-hat / the ReLU pattern from the same plane
         # (lp_adain_relu_bwd16).  Per element over forward + backward: a conv1 output 16 B -> 8 B, a block output 22 B -> 8 B.  LP_G_Y16=0: fp32.
-        y16 = bool(cfg.get('y16')) and prec == PREC_F16
+        # gen_padding='reflection' (noBottleneck.py:53-58: nn.ReflectionPad2d(1) in front of the ResBlocks' 3x3 convs, blocks.py:76-88; the head conv
+        # keeps its zero padding, noBottleneck.py:80-88): the zero-padded conv + the border correction of csrc/reflect_border.hip; the statistics of a
+        # conv output are then taken after the correction (no epilogue partials, no 16-bit-resident outputs)
+        reflect = bool(cfg.get('reflect'))
+        y16 = bool(cfg.get('y16')) and prec == PREC_F16 and not reflect
 
         def dims(t):
             return tuple(t.hi.shape) if isinstance(t, ops.Act16) else tuple(t.shape)
@@ -511,8 +515,11 @@ class _DecoderFunction(torch.autograd.Function):
                 return ops.adain_act16(t, st[2], st[3])
             return ops.act_pack(t, pro=1, scale=st[2], shift=st[3], prec=prec)
 
-        def conv_out(a, pk, hout, **kw):
+        def conv_out(a, pk, hout, w_orig, **kw):
             """-> (y fp32 | the fp16 plane of y, statistics partials | None)"""
+            if reflect:
+                y = ops.conv16(a, pk, prec=prec, **kw)
+                return ops.reflect_border_fwd(a, w_orig.detach().contiguous(), kw.get('alpha'), y, prec=prec, upsample=bool(kw.get('upsample'))), None
             if y16 and hout >= Y16_MIN_MAP and pk.rows % 8 == 0:
                 _, o16, cs = ops.conv16(a, pk, prec=prec, stats=True, want_y=False, out16=0, **kw)
                 return o16, cs
@@ -530,7 +537,7 @@ class _DecoderFunction(torch.autograd.Function):
             st0 = in_stats(x, x_cs, g0, b0)
             a0 = norm_planes(x, st0)
             p1 = fpack(wi - 2, w1)
-            h1, cs1 = conv_out(a0, p1, hout, ksize=3, upsample=up, alpha=sn[wi - 2][2][1:])
+            h1, cs1 = conv_out(a0, p1, hout, w1, ksize=3, upsample=up, alpha=sn[wi - 2][2][1:])
             st1 = in_stats(h1, cs1, g1, b1)
             a1 = norm_planes(h1, st1)
             xs = None
@@ -546,7 +553,7 @@ class _DecoderFunction(torch.autograd.Function):
                 s, rs = x, 0
             i2 = wi - (3 if has_skip else 1)
             p2 = fpack(i2, w2)
-            out, x_cs = conv_out(a1, p2, hout, ksize=3, res=s, res_shift=rs, alpha=sn[i2][2][1:])
+            out, x_cs = conv_out(a1, p2, hout, w2, ksize=3, res=s, res_shift=rs, alpha=sn[i2][2][1:])
             if need_grad:
                 saved.append((x, h1, st0, st1, o0, o1, a0, a1, xs))
             if cfg.get('debug') is not None:      # activation patterns of the AdaIN+ReLU sites (tie-masked parity checks)
@@ -578,9 +585,18 @@ class _DecoderFunction(torch.autograd.Function):
         blocks, prec = cfg['blocks'], cfg['prec']
         f16 = prec == PREC_F16          # gradient tensors become fp16 operands: their producers fold max|.| in (no amax pass)
         sn = cfg['sn']
+        reflect = bool(cfg.get('reflect'))
         affine, wl = ctx.affine, ctx.weights
         params = ctx.params
         d_affine = torch.zeros_like(affine)
+
+        def border(i, a, dy, dA, up=False):
+            """gen_padding='reflection': the border terms of conv weight i -- their share of the weight gradient (through the same spectral-norm
+            rule, into the same .grad) and of the data gradient dA (in place); a = the conv's operand planes, dy = the fp32 gradient of its output"""
+            corr = ops.reflect_border_wgrad(a, dy, prec=prec, upsample=up, sn=snw(i), accum=_accum_target(params[i]))
+            if corr is not None:
+                grads[i] = grads[i] + corr
+            ops.reflect_border_dgrad(dy, wl[i].contiguous(), sn[i][2][1:], dA)
 
         def snw(i):          # (W_orig, u, v, sig) of conv weight i -> wgrad returns the gradient w.r.t. W_orig
             return (wl[i],) + tuple(sn[i])
@@ -622,6 +638,8 @@ class _DecoderFunction(torch.autograd.Function):
             # conv2 (+ AdaIN1/ReLU prologue)
             grads[wi + 1] = ops.conv_wgrad16(a1, d16, ksize=3, prec=prec, sn=snw(wi + 1), accum=_accum_target(params[wi + 1]))
             dA1 = ops.conv16(d16, tpack(wi + 1), ksize=3, alpha=sn[wi + 1][2][1:], prec=prec)
+            if reflect:
+                border(wi + 1, a1, d_out, dA1)
             g, dg, db = slices(o1, cout)
             dh1 = ops.adain_relu_bwd(dA1, h1, None, g, st1[0], st1[1], st1[2], st1[3], dg, db, False, amax=f16)
             # skip branch: out += up2(conv1x1(x) + b)
@@ -641,6 +659,8 @@ class _DecoderFunction(torch.autograd.Function):
             dh16 = ops.act_pack(dh1, prec=prec, grad=True)
             grads[wi] = ops.conv_wgrad16(a0, dh16, ksize=3, upsample=up, prec=prec, sn=snw(wi), accum=_accum_target(params[wi]))
             dA0 = ops.conv16(dh16, tpack(wi), ksize=3, alpha=sn[wi][2][1:], prec=prec)
+            if reflect:
+                border(wi, a0, dh1, dA0, up)
             g, dg, db = slices(o0, cin)
             dx = ops.adain_relu_bwd(dA0, x, dx_skip, g, st0[0], st0[1], st0[2], st0[3], dg, db, up, amax=f16 and bi > 0)
             if dbg is not None:
@@ -657,8 +677,9 @@ class Generator(nn.Module):
                  pose_embedding_size, norm_layer, gen_constant_input_size, gen_num_residual_blocks, output_image_size,
                  prec: Optional[int] = None):
         super().__init__()
-        if padding != 'zero':
-            raise NotImplementedError("only gen_padding='zero' (the shipped configs) is implemented on the HIP path")
+        if padding not in ('zero', 'reflection'):
+            raise Exception('Incorrect `padding` argument, required `zero` or `reflection`')       # (noBottleneck.py:57-58)
+        self.reflect = padding == 'reflection'
         if 'in' not in norm_layer:
             raise NotImplementedError("only norm_layer='in' is implemented on the HIP path")
         assert math.log2(output_image_size / gen_constant_input_size).is_integer(), \
@@ -825,7 +846,7 @@ class Generator(nn.Module):
                 self.__dict__['_pack_cache'] = cache
             packs = cache[1]
         cfg = dict(blocks=self.blocks_cfg, prec=self.prec, need_grad=need_grad, sn=sn, packs=packs, packsT=packsT,
-                   debug=getattr(self, '_debug', None), y16=G_Y16 and self.training and need_grad)
+                   debug=getattr(self, '_debug', None), y16=G_Y16 and self.training and need_grad, reflect=self.reflect)
         rgbs, segm = _DecoderFunction.apply(cfg, affine, self.constant.constant, *weights)
         data_dict['fake_rgbs'] = rgbs
         data_dict['fake_segm'] = segm
@@ -875,11 +896,14 @@ class ConvFn(torch.autograd.Function):
     thin-channel kernels.  ``packs`` = optional cached (forward, dgrad) WeightPacks of a frozen w."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, res, ksize, pro, prec, packs, sn=None, x16=None, emit=None):
+    def forward(ctx, x, w, bias, res, ksize, pro, prec, packs, sn=None, x16=None, emit=None, reflect=False):
         """``sn`` = (u_used, v_used, [sigma, 1/sigma]) from SNBatch when ``w`` is a spectrally normalised W_orig.
         ``x16``: operand planes of act(x) that already exist (emitted by the producer conv's epilogue, or packed once for several
         consumers) -- skips this call's lp_act_pack.  ``emit`` = (out_relu: 0|1, holder list): the conv epilogue also writes the
-        operand planes of (relu?)(y) for the consumer conv; they are appended to ``holder``."""
+        operand planes of (relu?)(y) for the consumer conv; they are appended to ``holder``.  ``reflect``: the 3x3 conv sits behind
+        nn.ReflectionPad2d(1) instead of zero padding (blocks.py:76-88, --dis_padding reflection): the zero-padded MFMA conv + the border terms of
+        csrc/reflect_border.hip, forward and backward; no emitted planes (they would be taken before the correction)."""
+        assert not reflect or (ksize == 3 and emit is None), 'reflection padding: 3x3 convs without epilogue-emitted planes'
         small_k = ksize == 3 and w.shape[1] <= 32
         wd = w.detach().contiguous()
         # planes-only output (emit = (relu, holder, emit_prec | None, False)): nothing reads the fp32 y of a conv whose only consumer takes the
@@ -896,9 +920,9 @@ class ConvFn(torch.autograd.Function):
         bd = None if bias is None else bias.detach().contiguous()
         alpha = None if sn is None else sn[2][1:]
         need_w = w.requires_grad
-        thin_w = need_w and ops.thin_wgrad_supported(cin, cout, ksize, pro, width)       # the weight gradient will want fp32 x
+        thin_w = need_w and not reflect and ops.thin_wgrad_supported(cin, cout, ksize, pro, width)       # the weight gradient will want fp32 x
         a16 = x16
-        if a16 is None and pro == 0 and res is None and ops.thin_conv_supported(cin, cout, ksize, width):
+        if a16 is None and pro == 0 and res is None and not reflect and ops.thin_conv_supported(cin, cout, ksize, width):
             y = ops.thin_conv(x, pack, ksize=ksize, bias=bd, alpha=alpha, prec=prec, out16=None if emit is None else emit[0],
                               out16_prec=None if emit is None or len(emit) < 3 else emit[2], want_y=want_y)
             if emit is not None:
@@ -915,6 +939,8 @@ class ConvFn(torch.autograd.Function):
             assert emit is None or len(emit) < 3 or emit[2] in (None, prec), 'emit_prec differs from the conv\'s operand mode on the MFMA path'
             y = ops.conv16(a16, pack, ksize=ksize, bias=bd, res=res, alpha=alpha, prec=prec, out16=None if emit is None else emit[0],
                            want_y=want_y or cout % 8 != 0)
+            if reflect:
+                ops.reflect_border_fwd(a16, wd, alpha, y, prec=prec)
             if emit is not None:
                 y, o16 = y
                 emit[1].append(o16)
@@ -924,6 +950,7 @@ class ConvFn(torch.autograd.Function):
             y = phantom((x.shape[0], x.shape[1], x.shape[2], cout), x.device)
         if need_w and not thin_w and a16 is None:
             a16 = ops.act_pack(x, pro=pro, prec=prec)
+        ctx.reflect = reflect
         ctx.x = x if thin_w else None                               # fp32 input only where a thin-channel weight gradient needs it
         ctx.a16 = a16 if ((need_w and not thin_w) or pro == 2) else None
         ctx.wd = wd
@@ -960,7 +987,9 @@ class ConvFn(torch.autograd.Function):
                 dx = ops.thin_conv(dy, packT, ksize=ksize, alpha=alpha, prec=prec)
             else:
                 # pro == 2: the forward applied ReLU to x first -> dx = dA * (x > 0), fused into the dgrad launch's epilogue
-                dx = ops.conv16(dy16(), packT, ksize=ksize, alpha=alpha, prec=prec, relu_mask=a16 if pro == 2 else None, amax=True)
+                dx = ops.conv16(dy16(), packT, ksize=ksize, alpha=alpha, prec=prec, relu_mask=a16 if pro == 2 else None, amax=not ctx.reflect)
+            if ctx.reflect:          # (the border terms change dx after the launch: its folded max|dx| would be stale -> the consumer takes its own)
+                ops.reflect_border_dgrad(dy, wd, alpha, dx, a16 if pro == 2 else None)
         want_db = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             kw = dict(ksize=ksize, sn=None if sn is None else (wd,) + tuple(sn),
@@ -972,22 +1001,26 @@ class ConvFn(torch.autograd.Function):
                                       **kw)
             if want_db:
                 dw, db = dw
+            if ctx.reflect:
+                corr = ops.reflect_border_wgrad(a16, dy, prec=prec, sn=kw['sn'], accum=kw['accum'])
+                if corr is not None:
+                    dw = dw + corr
         elif want_db:
             db = dy.sum(dim=(0, 1, 2))
         if has_res and ctx.needs_input_grad[3]:
             dres = dy
-        return dx, dw, db, dres, None, None, None, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None, None, None
 
 
-def hip_conv(x, w, bias=None, res=None, ksize=3, pro=0, prec=None, packs=None, sn=None, x16=None, emit16=None, emit_prec=None, want_y=True):
+def hip_conv(x, w, bias=None, res=None, ksize=3, pro=0, prec=None, packs=None, sn=None, x16=None, emit16=None, emit_prec=None, want_y=True, reflect=False):
     """``x16``: existing operand planes of act(x); ``emit16`` = 0 | 1: also return the operand planes of y (1: of relu(y)), written
     by the conv's epilogue -> ``(y, Act16)``; ``emit_prec``: their operand mode when the consumer's differs from this conv's ``prec``
     (thin-channel first layers only).  ``want_y=False`` (with ``emit16``): the returned y is a PHANTOM (shape and autograd edge only, no
-    storage) -- for convs whose fp32 output nobody reads."""
+    storage) -- for convs whose fp32 output nobody reads.  ``reflect``: reflection instead of zero padding (3x3, no ``emit16``)."""
     prec = default_prec() if prec is None else prec
     _TAPE_GRAD[0] = torch.is_grad_enabled()
     if emit16 is None:
-        return ConvFn.apply(x, w, bias, res, ksize, pro, prec, packs, sn, x16, None)
+        return ConvFn.apply(x, w, bias, res, ksize, pro, prec, packs, sn, x16, None, reflect)
     holder = []
     y = ConvFn.apply(x, w, bias, res, ksize, pro, prec, packs, sn, x16, (int(emit16), holder) + ((() if emit_prec is None else (emit_prec,)) if want_y else (emit_prec, False)))
     return y, holder[0]

@@ -136,17 +136,26 @@ def _relu_m(x: Tensor, mask: Optional[Tensor]) -> Tensor:
     return torch.relu(x) if mask is None else x * mask.to(x.dtype)
 
 
-def resblock_ada(x: Tensor, sd: State, prefix: str, aff0, aff1, upsample: bool, train: bool, masks=(None, None)) -> Tensor:
+def conv3x3(x: Tensor, w: Tensor, b: Optional[Tensor], padding: str = 'zero') -> Tensor:
+    """the 3x3 conv of a ResBlock behind its padding layer (blocks.py:76-88): `nn.Sequential()` + Conv2d(padding=1) for nn.ZeroPad2d,
+    nn.ReflectionPad2d(1) + Conv2d(padding=0) for --gen_padding / --dis_padding reflection"""
+    if padding == 'reflection':
+        return F.conv2d(F.pad(x, (1, 1, 1, 1), mode='reflect'), w, b, 1, 0)
+    assert padding == 'zero', padding
+    return F.conv2d(x, w, b, 1, 1)
+
+
+def resblock_ada(x: Tensor, sd: State, prefix: str, aff0, aff1, upsample: bool, train: bool, masks=(None, None), padding: str = 'zero') -> Tensor:
     """blocks.ResBlock with norm_layer='adain' (blocks.py:47-111): pre-activation, convs without bias, SN eps 1e-4."""
     i1, i2 = (4, 8) if upsample else (3, 7)
     h = _relu_m(adain(x, *aff0), masks[0])
     if upsample:
         h = upsample2(h)
     w1 = sn_effective_weight(sd, f'{prefix}.block.{i1}', SN_EPS_CONV, train)
-    h = F.conv2d(h, w1, None, 1, 1)
+    h = conv3x3(h, w1, None, padding)
     h = _relu_m(adain(h, *aff1), masks[1])
     w2 = sn_effective_weight(sd, f'{prefix}.block.{i2}', SN_EPS_CONV, train)
-    h = F.conv2d(h, w2, None, 1, 1)
+    h = conv3x3(h, w2, None, padding)
     if f'{prefix}.skip.1.weight_orig' in sd:   # in != out or upsample (blocks.py:92-103); Upsample is skip.0
         s = upsample2(x) if upsample else x
         ws = sn_effective_weight(sd, f'{prefix}.skip.1', SN_EPS_CONV, train)
@@ -160,7 +169,7 @@ def resblock_ada(x: Tensor, sd: State, prefix: str, aff0, aff1, upsample: bool, 
 
 def generator_forward(sd: State, identity: Tensor, pose: Tensor, *, num_channels: int, max_num_channels: int,
                       image_size: int, train: bool, const_size: int = 4, num_res_blocks: int = 2,
-                      relu_masks: Optional[List[Tensor]] = None, fsth_plus: bool = False) -> Tuple[Tensor, Tensor]:
+                      relu_masks: Optional[List[Tensor]] = None, fsth_plus: bool = False, padding: str = 'zero') -> Tuple[Tensor, Tensor]:
     """Generator.forward (noBottleneck.py:165-181).  ``identity`` is data_dict['embeds'] (B x E) or the finetuned
     ``identity_embedding`` (1 x E, expanded).  Returns (fake_rgbs, fake_segm).  SN buffers in ``sd`` are updated in
     place when ``train``.  ``relu_masks``: prescribed activation patterns of the 17 AdaIN+ReLU sites in execution order
@@ -188,7 +197,7 @@ def generator_forward(sd: State, identity: Tensor, pose: Tensor, *, num_channels
     # distinct layers are independent so the order does not matter numerically.
     for i, (cin, cout, up) in enumerate(blocks):
         mk = (None, None) if relu_masks is None else (relu_masks[2 * i], relu_masks[2 * i + 1])
-        x = resblock_ada(x, sd, f'decoder_blocks.{i}', affs[2 * i], affs[2 * i + 1], up, train, mk)
+        x = resblock_ada(x, sd, f'decoder_blocks.{i}', affs[2 * i], affs[2 * i + 1], up, train, mk, padding)     # (the head conv below keeps zero padding: noBottleneck.py:80-88)
     nb = len(blocks)
     x = _relu_m(adain(x, *affs[2 * nb]), None if relu_masks is None else relu_masks[2 * nb])
     wh = sn_effective_weight(sd, f'decoder_blocks.{nb + 2}', SN_EPS_CONV, train)
@@ -201,15 +210,15 @@ def generator_forward(sd: State, identity: Tensor, pose: Tensor, *, num_channels
 # ----------------------------------------------------------------------------------------------------------------
 # discriminator (discriminators/no_landmarks.py)
 # ----------------------------------------------------------------------------------------------------------------
-def resblock_none(x_relu: Tensor, sd: State, prefix: str, downsample: bool, train: bool) -> Tensor:
+def resblock_none(x_relu: Tensor, sd: State, prefix: str, downsample: bool, train: bool, padding: str = 'zero') -> Tensor:
     """blocks.ResBlock with norm_layer='none' as the reference actually behaves: its first layer is
     ReLU(inplace=True) on the block *input* (blocks.py:71-73), so block, skip and identity all see relu(x)
     (SURVEY Appendix B).  ``x_relu`` must already be relu(x)."""
     w1 = sn_effective_weight(sd, f'{prefix}.block.2', SN_EPS_CONV, train)
-    h = F.conv2d(x_relu, w1, sd[f'{prefix}.block.2.bias'], 1, 1)
+    h = conv3x3(x_relu, w1, sd[f'{prefix}.block.2.bias'], padding)
     h = _relu(h)
     w2 = sn_effective_weight(sd, f'{prefix}.block.5', SN_EPS_CONV, train)
-    h = F.conv2d(h, w2, sd[f'{prefix}.block.5.bias'], 1, 1)
+    h = conv3x3(h, w2, sd[f'{prefix}.block.5.bias'], padding)
     if downsample:
         h = F.avg_pool2d(h, 2)
     if f'{prefix}.skip.0.weight_orig' in sd:
@@ -228,7 +237,7 @@ def discriminator_layout(image_size: int, dis_num_blocks: int) -> List[bool]:
 
 
 def discriminator_pass(sd: State, x: Tensor, embed: Optional[Tensor], *, image_size: int, dis_num_blocks: int,
-                       train: bool) -> Tuple[Tensor, List[Tensor]]:
+                       train: bool, padding: str = 'zero') -> Tuple[Tensor, List[Tensor]]:
     """Discriminator.pass_inputs (no_landmarks.py:90-108).  Returned features are what the reference's list holds
     *after* the call: feats[0..n-2] post-ReLU (mutated in place by the next block), feats[n-1] pre-ReLU."""
     w = sn_effective_weight(sd, 'down_block.0', SN_EPS_CONV, train)
@@ -242,7 +251,7 @@ def discriminator_pass(sd: State, x: Tensor, embed: Optional[Tensor], *, image_s
     for i, down in enumerate(discriminator_layout(image_size, dis_num_blocks)):
         out_relu = _relu(out)
         feats.append(out_relu)
-        out = resblock_none(out_relu, sd, f'blocks.{i}', down, train)
+        out = resblock_none(out_relu, sd, f'blocks.{i}', down, train, padding)     # (the stem above keeps zero padding: no_landmarks.py:52-60)
     feats.append(out)
     h = _relu(out)
     h = h.reshape(h.shape[0], h.shape[1], -1).sum(2)
@@ -253,17 +262,17 @@ def discriminator_pass(sd: State, x: Tensor, embed: Optional[Tensor], *, image_s
 
 
 def discriminator_forward(sd: State, fake_rgbs: Tensor, target_rgbs: Tensor, label: Tensor, *, image_size: int,
-                          dis_num_blocks: int, train: bool, embed_eps: float = SN_EPS_CONV) -> Dict[str, object]:
+                          dis_num_blocks: int, train: bool, embed_eps: float = SN_EPS_CONV, padding: str = 'zero') -> Dict[str, object]:
     """Discriminator.forward (no_landmarks.py:138-166): embedding lookup through SN, then three passes
     (fake -> G, fake.detach -> D, real), each running its own power iteration in train mode."""
     w_embed = sn_effective_weight(sd, 'embed', embed_eps, train)
     embed = w_embed[label]
     fake_score_G, fake_features = discriminator_pass(sd, fake_rgbs, embed, image_size=image_size,
-                                                     dis_num_blocks=dis_num_blocks, train=train)
+                                                     dis_num_blocks=dis_num_blocks, train=train, padding=padding)
     fake_score_D, _ = discriminator_pass(sd, fake_rgbs.detach(), embed.detach(), image_size=image_size,
-                                         dis_num_blocks=dis_num_blocks, train=train)
+                                         dis_num_blocks=dis_num_blocks, train=train, padding=padding)
     real_score, real_features = discriminator_pass(sd, target_rgbs, embed, image_size=image_size,
-                                                   dis_num_blocks=dis_num_blocks, train=train)
+                                                   dis_num_blocks=dis_num_blocks, train=train, padding=padding)
     return dict(fake_features=fake_features, real_features=real_features, real_embedding=embed,
                 fake_score_G=fake_score_G, fake_score_D=fake_score_D, real_score=real_score)
 

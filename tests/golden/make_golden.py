@@ -80,10 +80,10 @@ SMALL = dict(image_size=32, num_channels=4, max_num_channels=16, embed_channels=
              in_channels=3, out_channels=3, num_labels=5, dis_num_blocks=5)
 
 
-def small_args():
+def small_args(padding='zero'):
     a = argparse.Namespace(**SMALL)
-    a.gen_padding = 'zero'; a.norm_layer = 'in'; a.gen_constant_input_size = 4; a.gen_num_residual_blocks = 2
-    a.dis_padding = 'zero'; a.device = 'cpu'
+    a.gen_padding = padding; a.norm_layer = 'in'; a.gen_constant_input_size = 4; a.gen_num_residual_blocks = 2
+    a.dis_padding = padding; a.device = 'cpu'
     return a
 
 
@@ -112,10 +112,16 @@ def make_ops():
     conv(xin)
     out['sn_weff_eval'] = npy(conv.weight)
 
+    _resblock_fixtures(out, nn.ZeroPad2d)
+    np.savez_compressed(os.path.join(OUT, 'ops_small.npz'), **out)
+    print('ops_small.npz', len(out), 'arrays')
+
+
+def _resblock_fixtures(out, pad_cls):
     # ResBlocks: ada (same res), ada up (6->4), none down (4->6), none same-channels no-down (6->6)
     for tag, cin, cout, up, down, norm in (('rb_ada', 6, 6, False, False, 'adain'), ('rb_up', 6, 4, True, False, 'adain'),
                                            ('rb_down', 4, 6, False, True, 'none'), ('rb_none', 6, 6, False, False, 'none')):
-        blk = ref_blocks.ResBlock(cin, cout, nn.ZeroPad2d, upsample=up, downsample=down, norm_layer=norm)
+        blk = ref_blocks.ResBlock(cin, cout, pad_cls, upsample=up, downsample=down, norm_layer=norm)
         blk.train()
         out.update(sd_np(blk, f'{tag}.'))   # state BEFORE the forward (u/v pre power iteration)
         x = (torch.randn(2, cin, 8, 8)).requires_grad_(True)
@@ -141,8 +147,18 @@ def make_ops():
         for k, v in blk.state_dict().items():
             if k.endswith('_u') or k.endswith('_v'):
                 out[f'{tag}.after.{k}'] = npy(v)
-    np.savez_compressed(os.path.join(OUT, 'ops_small.npz'), **out)
-    print('ops_small.npz', len(out), 'arrays')
+
+
+def make_reflection():
+    """--gen_padding / --dis_padding reflection (nn.ReflectionPad2d(1) in front of the ResBlocks' 3x3 convs, blocks.py:76-88): the four ResBlock
+    fixtures, the small generator and the small discriminator of the zero-padding fixtures, same keys"""
+    torch.manual_seed(11)
+    out = {}
+    _resblock_fixtures(out, nn.ReflectionPad2d)
+    np.savez_compressed(os.path.join(OUT, 'reflection_ops_small.npz'), **out)
+    print('reflection_ops_small.npz', len(out), 'arrays')
+    make_generator('reflection', 'generator_small_reflection.npz')
+    make_discriminator('reflection', 'discriminator_small_reflection.npz')
 
 
 # ---- B. generator ----------------------------------------------------------------------------------------------------
@@ -165,11 +181,11 @@ def _relu_tie_margin(G, embeds, pose):
     return min(margins)
 
 
-def make_generator():
+def make_generator(padding='zero', fname='generator_small.npz'):
     # ReLU gradients are discontinuous at 0: two correct fp32 implementations may disagree on the mask of an element whose
     # pre-activation is ~1e-7, which in this tiny net (4 channels x 1024 pixels in the last layer) is a several-% gradient
     # change.  Pick the first seed whose smallest |pre-ReLU| is comfortably above fp32/bf16x3 rounding.
-    args = small_args()
+    args = small_args(padding)
     for seed in range(2, 200):
         torch.manual_seed(seed)
         G = ref_gen.Wrapper.get_net(args)
@@ -239,14 +255,14 @@ def make_generator():
     loss.backward()
     out.update(ft_fake_rgbs=npy(dd['fake_rgbs']), ft_fake_segm=npy(dd['fake_segm']),
                ft_grad_identity=npy(Gf.identity_embedding.grad), ft_grad_pose=npy(pose2.grad))
-    np.savez_compressed(os.path.join(OUT, 'generator_small.npz'), **out)
-    print('generator_small.npz', len(out), 'arrays; G params', sum(p.numel() for p in G.parameters()))
+    np.savez_compressed(os.path.join(OUT, fname), **out)
+    print(fname, len(out), 'arrays; G params', sum(p.numel() for p in G.parameters()))
 
 
 # ---- C/D. discriminator + cheap criterions -------------------------------------------------------------------------
-def make_discriminator():
+def make_discriminator(padding='zero', fname='discriminator_small.npz'):
     torch.manual_seed(3)
-    args = small_args()
+    args = small_args(padding)
     D = ref_dis.Wrapper.get_net(args)
     D.train()
     out = dict(cfg=np.array([args.image_size, args.dis_num_blocks, args.num_labels]))
@@ -296,8 +312,8 @@ def make_discriminator():
     Df(dd2)
     out.update(ft_fake_score_G=npy(dd2['fake_score_G']), ft_real_score=npy(dd2['real_score']),
                ft_real_embedding=npy(dd2['real_embedding']))
-    np.savez_compressed(os.path.join(OUT, 'discriminator_small.npz'), **out)
-    print('discriminator_small.npz', len(out), 'arrays; D params', sum(p.numel() for p in D.parameters()))
+    np.savez_compressed(os.path.join(OUT, fname), **out)
+    print(fname, len(out), 'arrays; D params', sum(p.numel() for p in D.parameters()))
 
 
 # ---- E. perceptual (narrow VGG shim) + crop ------------------------------------------------------------------------
@@ -687,7 +703,7 @@ def make_fsth_plus():
 
 if __name__ == '__main__':
     torch.set_num_threads(1)
-    which = sys.argv[1:] or ['ops', 'generator', 'discriminator', 'perceptual', 'train_step', 'metatrain_step', 'metatrain_step_trainbn', 'metatrain_step_128', 'checkpoint', 'fsth_plus']
+    which = sys.argv[1:] or ['ops', 'generator', 'discriminator', 'perceptual', 'train_step', 'metatrain_step', 'metatrain_step_trainbn', 'metatrain_step_128', 'checkpoint', 'fsth_plus', 'reflection']
     for w in which:
         if w == 'metatrain_step_trainbn':
             make_metatrain_step(train_bn=True)

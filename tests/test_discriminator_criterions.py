@@ -23,10 +23,13 @@ def rel(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
 
 
-def make_dis(z):
+def make_dis(z, padding='zero'):
     from discriminators.no_landmarks import Discriminator
     image_size, nblocks, nlabels = (int(v) for v in z['cfg'])
-    return Discriminator('zero', 3, 3, 4, 16, 8, nblocks, image_size, nlabels)
+    return Discriminator(padding, 3, 3, 4, 16, 8, nblocks, image_size, nlabels)
+
+
+PADDINGS = [('zero', 'discriminator_small.npz'), ('reflection', 'discriminator_small_reflection.npz')]      # --dis_padding (no_landmarks.py:45-50)
 
 
 def test_discriminator_state_dict_matches_reference():
@@ -41,11 +44,12 @@ def test_discriminator_state_dict_matches_reference():
 
 
 @pytest.mark.gpu
-def test_discriminator_three_passes_and_losses_vs_reference_golden(monkeypatch):
+@pytest.mark.parametrize('padding,fixture', PADDINGS)
+def test_discriminator_three_passes_and_losses_vs_reference_golden(monkeypatch, padding, fixture):
     monkeypatch.setenv('LP_PREC', 'bf16x3')
     from criterions import adversarial, featmat, dice, dis_embed
-    z = load('discriminator_small.npz')
-    D = make_dis(z)
+    z = load(fixture)
+    D = make_dis(z, padding)
     D.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in z.items() if k.startswith('sd.')}, strict=True)
     D = D.cuda().train()
     D.keep_reference_waste = True      # this test also compares the (discarded) D-parameter gradients of loss_G
@@ -79,7 +83,7 @@ def test_discriminator_three_passes_and_losses_vs_reference_golden(monkeypatch):
         if k.endswith('_u') or k.endswith('_v'):
             errs['buf.' + k] = rel(v, z['sd_after.' + k])
     worst = sorted(errs.items(), key=lambda kv: -kv[1])[:8]
-    print('[parity] discriminator + cheap criterions (bf16x3): worst', [(k, f'{v:.2e}') for k, v in worst])
+    print(f'[parity] discriminator + cheap criterions (bf16x3, padding={padding}): worst', [(k, f'{v:.2e}') for k, v in worst])
     # ReLU sign ties in this 4..16-channel toy net can move single gradients by a few 1e-3 (see make_golden.py note)
     bad = {k: v for k, v in errs.items() if v >= (1e-5 if k.startswith('buf.') else 5e-3 if 'grad' in k or k.startswith('gG') else 2e-4)}
     assert not bad, bad

@@ -14,10 +14,13 @@ def load(name):
     return {k: z[k] for k in z.files}
 
 
-def make_gen(z, prec=None):
+def make_gen(z, prec=None, padding='zero'):
     from latent_pose_reenactment_amd.nn import Generator
     image_size, nc, mx, e, p = (int(v) for v in z['cfg'])
-    return Generator('zero', 3, 4, nc, mx, e, p, 'in', 4, 2, image_size, prec=prec)
+    return Generator(padding, 3, 4, nc, mx, e, p, 'in', 4, 2, image_size, prec=prec)
+
+
+PADDINGS = [('zero', 'generator_small.npz'), ('reflection', 'generator_small_reflection.npz')]      # --gen_padding (noBottleneck.py:53-58)
 
 
 def rel(a, b):
@@ -46,11 +49,18 @@ def test_cpu_forward_fails_loudly():
         G({'embeds': torch.zeros(2, int(z['cfg'][3])), 'pose_embedding': torch.zeros(2, int(z['cfg'][4]))})
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize('prec,tol', [(1, 1e-4), (0, 0.35)])
-def test_generator_train_forward_backward_vs_reference_golden(prec, tol):
+def test_unknown_padding_raises_like_the_reference():
     z = load('generator_small.npz')
-    G = make_gen(z, prec=prec)
+    with pytest.raises(Exception, match='Incorrect `padding` argument'):
+        make_gen(z, prec=1, padding='replicate')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('padding,fixture', PADDINGS)
+@pytest.mark.parametrize('prec,tol', [(1, 1e-4), (0, 0.35)])
+def test_generator_train_forward_backward_vs_reference_golden(prec, tol, padding, fixture):
+    z = load(fixture)
+    G = make_gen(z, prec=prec, padding=padding)
     G.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in z.items() if k.startswith('sd.')}, strict=True)
     G = G.cuda().train()
     e = torch.from_numpy(z['embeds']).cuda().requires_grad_(True)
@@ -70,7 +80,7 @@ def test_generator_train_forward_backward_vs_reference_golden(prec, tol):
         if k.endswith('_u') or k.endswith('_v'):
             errs['buf.' + k] = rel(v, z['sd_after.' + k])
     worst = sorted(errs.items(), key=lambda kv: -kv[1])[:6]
-    print(f'[parity] generator(train) prec={prec}: worst rel-L2 {worst}')
+    print(f'[parity] generator(train) prec={prec} padding={padding}: worst rel-L2 {worst}')
     # bf16 operands (prec=0): forward within 1e-2; gradients of this 4-channel toy net are dominated by ReLU sign flips of
     # near-zero pre-activations (|y| < bf16 rounding), so they only get a sanity bound.  bf16x3 (prec=1): everything 1e-4.
     def bound(k):
@@ -84,9 +94,10 @@ def test_generator_train_forward_backward_vs_reference_golden(prec, tol):
 
 
 @pytest.mark.gpu
-def test_generator_eval_and_finetuning_vs_reference_golden():
-    z = load('generator_small.npz')
-    G = make_gen(z, prec=1)
+@pytest.mark.parametrize('padding,fixture', PADDINGS)
+def test_generator_eval_and_finetuning_vs_reference_golden(padding, fixture):
+    z = load(fixture)
+    G = make_gen(z, prec=1, padding=padding)
     G.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in z.items() if k.startswith('sd.')}, strict=True)
     G = G.cuda().eval()
     with torch.no_grad():

@@ -60,14 +60,18 @@ def test_sn_power_iteration_sequence():
     close(sd['c.weight_u'], z['sn_u3'])
 
 
+PADDINGS = [('zero', ''), ('reflection', '_reflection')]      # (--gen_padding / --dis_padding, fixture suffix)
+
+
+@pytest.mark.parametrize('padding', ['zero', 'reflection'])
 @pytest.mark.parametrize('tag,up', [('rb_ada', False), ('rb_up', True)])
-def test_resblock_ada(tag, up):
-    z = load('ops_small.npz')
+def test_resblock_ada(tag, up, padding):
+    z = load('ops_small.npz' if padding == 'zero' else 'reflection_ops_small.npz')
     sd = sd_from(z, tag + '.')
     sd = {k: v for k, v in sd.items() if '.' in k and not k.startswith(('grad', 'after'))}
     x = T(z[f'{tag}.x'], True)
     g0, b0, g1, b1 = (T(z[f'{tag}.{n}'], True) for n in ('g0', 'b0', 'g1', 'b1'))
-    y = O.resblock_ada(x, {f'blk.{k}': v for k, v in sd.items()}, 'blk', (g0, b0), (g1, b1), up, train=True)
+    y = O.resblock_ada(x, {f'blk.{k}': v for k, v in sd.items()}, 'blk', (g0, b0), (g1, b1), up, train=True, padding=padding)
     close(y, z[f'{tag}.y'])
     y.backward(T(z[f'{tag}.gy']))
     close(x.grad, z[f'{tag}.gx'])
@@ -80,13 +84,14 @@ def test_resblock_ada(tag, up):
             close(v, z[f'{tag}.after.{k}'])
 
 
+@pytest.mark.parametrize('padding', ['zero', 'reflection'])
 @pytest.mark.parametrize('tag,down', [('rb_down', True), ('rb_none', False)])
-def test_resblock_none_inplace_relu_aliasing(tag, down):
-    z = load('ops_small.npz')
+def test_resblock_none_inplace_relu_aliasing(tag, down, padding):
+    z = load('ops_small.npz' if padding == 'zero' else 'reflection_ops_small.npz')
     sd = sd_from(z, tag + '.')
     sd = {f'blk.{k}': v for k, v in sd.items() if '.' in k and not k.startswith(('grad', 'after'))}
     x = T(z[f'{tag}.x'], True)
-    y = O.resblock_none(torch.relu(x), sd, 'blk', down, train=True)
+    y = O.resblock_none(torch.relu(x), sd, 'blk', down, train=True, padding=padding)
     close(y, z[f'{tag}.y'])
     close(torch.relu(x), z[f'{tag}.x_after'])       # the reference mutated its input to relu(x)
     y.backward(T(z[f'{tag}.gy']))
@@ -112,19 +117,21 @@ def test_generator_affine_slice_order():
     np.testing.assert_array_equal([float(g[0, 0]) for g, b in affs], z['affine_first_weight'])
 
 
-def test_generator_eval_forward():
-    z = load('generator_small.npz')
+@pytest.mark.parametrize('padding,suffix', PADDINGS)
+def test_generator_eval_forward(padding, suffix):
+    z = load(f'generator_small{suffix}.npz')
     sd = sd_from(z, 'sd.', grad=False)
-    rgb, segm = O.generator_forward(sd, T(z['embeds']), T(z['pose']), train=False, **_gen_cfg(z))
+    rgb, segm = O.generator_forward(sd, T(z['embeds']), T(z['pose']), train=False, padding=padding, **_gen_cfg(z))
     close(rgb, z['eval_fake_rgbs'])
     close(segm, z['eval_fake_segm'])
 
 
-def test_generator_train_forward_backward():
-    z = load('generator_small.npz')
+@pytest.mark.parametrize('padding,suffix', PADDINGS)
+def test_generator_train_forward_backward(padding, suffix):
+    z = load(f'generator_small{suffix}.npz')
     sd = sd_from(z, 'sd.')
     e, p = T(z['embeds'], True), T(z['pose'], True)
-    rgb, segm = O.generator_forward(sd, e, p, train=True, **_gen_cfg(z))
+    rgb, segm = O.generator_forward(sd, e, p, train=True, padding=padding, **_gen_cfg(z))
     close(rgb, z['train_fake_rgbs'])
     close(segm, z['train_fake_segm'])
     ((rgb * T(z['r1'])).sum() + (segm * T(z['r2'])).sum()).backward()
@@ -144,28 +151,30 @@ def test_generator_train_forward_backward():
     assert n == sum(1 for k in z if k.startswith('grad.'))
 
 
-def test_generator_finetuning_mode():
-    z = load('generator_small.npz')
+@pytest.mark.parametrize('padding,suffix', PADDINGS)
+def test_generator_finetuning_mode(padding, suffix):
+    z = load(f'generator_small{suffix}.npz')
     sd = sd_from(z, 'sd.')
     for k in list(sd):
         if k.endswith('_u') or k.endswith('_v'):
             sd[k] = T(z[f'sd_after.{k}'])
     ident = T(z['ft_identity'], True)
     p = T(z['pose'], True)
-    rgb, segm = O.generator_forward(sd, ident, p, train=True, **_gen_cfg(z))
+    rgb, segm = O.generator_forward(sd, ident, p, train=True, padding=padding, **_gen_cfg(z))
     close(rgb, z['ft_fake_rgbs'])
     ((rgb * T(z['r1'])).sum() + (segm * T(z['r2'])).sum()).backward()
     close(ident.grad, z['ft_grad_identity'], 1e-4)
     close(p.grad, z['ft_grad_pose'], 1e-4)
 
 
-def test_discriminator_and_cheap_criterions():
-    z = load('discriminator_small.npz')
+@pytest.mark.parametrize('padding,suffix', PADDINGS)
+def test_discriminator_and_cheap_criterions(padding, suffix):
+    z = load(f'discriminator_small{suffix}.npz')
     image_size, nblocks, _ = (int(v) for v in z['cfg'])
     sd = sd_from(z, 'sd.')
     fake = T(z['fake'], True)
     real = T(z['real'])[:, 0]
-    out = O.discriminator_forward(sd, fake, real, T(z['label']), image_size=image_size, dis_num_blocks=nblocks, train=True)
+    out = O.discriminator_forward(sd, fake, real, T(z['label']), image_size=image_size, dis_num_blocks=nblocks, train=True, padding=padding)
     for k in ('fake_score_G', 'fake_score_D', 'real_score', 'real_embedding'):
         close(out[k], z[k])
     assert len(out['fake_features']) == nblocks
@@ -195,13 +204,14 @@ def test_discriminator_and_cheap_criterions():
             close(v, z[f'sd_after.{k}'])
 
 
-def test_discriminator_finetuning_embedding():
-    z = load('discriminator_small.npz')
+@pytest.mark.parametrize('padding,suffix', PADDINGS)
+def test_discriminator_finetuning_embedding(padding, suffix):
+    z = load(f'discriminator_small{suffix}.npz')
     image_size, nblocks, _ = (int(v) for v in z['cfg'])
     sd = sd_from(z, 'ft_sd.', grad=False)
     out = O.discriminator_forward(sd, T(z['fake']), T(z['real'])[:, 0], torch.zeros(2, dtype=torch.long),
                                   image_size=image_size, dis_num_blocks=nblocks, train=True,
-                                  embed_eps=O.SN_EPS_DEFAULT)
+                                  embed_eps=O.SN_EPS_DEFAULT, padding=padding)
     close(out['fake_score_G'], z['ft_fake_score_G'])
     close(out['real_score'], z['ft_real_score'])
     close(out['real_embedding'], z['ft_real_embedding'])
