@@ -665,6 +665,7 @@ def main():
                     help='default: metatrain_step for EVERY --gpus value (configs[2], default.yaml: the configuration that is trained data-parallel; one '
                          'workload so that the 1/2/4/8-GPU values form a scaling curve).  finetune_step = BASELINE configs[1] (single GPU in the '
                          'reference); the default N = 1 run also reports it under "finetune_step"')
+    ap.add_argument('--padding', default='zero', choices=['zero', 'reflection'], help='--gen_padding / --dis_padding of the timed step (the shipped configs and the headline line: zero)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-only', action='store_true', help='only the CPU baseline leg (no GPU work): prints its JSON object')
     ap.add_argument('--no-also', action='store_true', help='skip the side measurements (strict bf16x3 mode, fine-tuning step)')
@@ -703,6 +704,7 @@ def main():
         a.workload = 'metatrain_step'
     finetune = a.workload != 'metatrain_step'
     args = make_args(a.image_size, a.batch, device, world, rank, a.prec, finetune=finetune)
+    args.gen_padding = args.dis_padding = a.padding
     args.generator = a.generator
     if a.generator == 'FSTH_plus':
         args.pose_embedding_size = 136          # 68 landmarks x 2 (generators/FSTH_plus.py:129-139)
@@ -912,7 +914,7 @@ def main():
                                                       'the 98000x512 label embedding, VGG19/VGGFace/featmat/adversarial/dis_embed/dice criterions, Adam, EMA',
                                     'generator': 'generator forward+backward only (HIP kernels)'}[a.workload],
                        'image_size': a.image_size, 'per_gpu_batch': a.batch, 'global_batch': a.batch * world,
-                       'parallelism': f'dp{world}', 'precision_mode': a.prec,
+                       'parallelism': f'dp{world}', 'precision_mode': a.prec, 'padding': a.padding,
                        'launch_mode': mode if a.workload != 'generator' else 'eager',
                        'streams': stream_config(a.workload)},
             'roofline': roof,

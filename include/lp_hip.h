@@ -350,13 +350,16 @@ int lp_avgpool2_bwd_m16(const float* dy, const uint16_t* mask_hi, float* dx, int
  *   dgrad: dx [N][H][W][Cin]  += alpha * (the transposed sum; gathered per pixel of the ring one pixel inside the border, no atomics), multiplied by
  *          [mask_hi > 0] when mask_hi (planes [N][H][W][mask_c8] of relu(x), the forward's prologue) is given
  *   wgrad: gw [Cout][Cin][3][3] = sum_n sum_{p: p + t outside} dy[n][p][:] (x) x[n][mirror(p + t)][:]   (every element written, centre tap 0): the raw
- *          gradient w.r.t. W/sigma -- lp_sn_grad_apply turns it into the W_orig gradient like the main term (the rule is linear in it). */
+ *          gradient w.r.t. W/sigma -- lp_sn_grad_apply turns it into the W_orig gradient like the main term (the rule is linear in it).  Thin layers cut
+ *          their border pixels into slices (partials in `workspace`, added in a fixed order: deterministic). */
 int lp_reflect_border_fwd(const uint16_t* x_hi, const uint16_t* x_lo, int prec, int N, int H, int W, int Cin, int C8, int upsample,
                           const float* w, int Cout, const float* alpha, float* y, void* stream);
 int lp_reflect_border_dgrad(const float* dy, int N, int H, int W, int Cout, const float* w, int Cin, const float* alpha,
                             const uint16_t* mask_hi, int mask_c8, float* dx, void* stream);
 int lp_reflect_border_wgrad(const uint16_t* x_hi, const uint16_t* x_lo, int prec, int N, int H, int W, int Cin, int C8, int upsample,
-                            const float* dy, int Cout, float* gw, void* stream);
+                            const float* dy, int Cout, float* gw, float* workspace, void* stream);
+/* bytes of `workspace` for that call (0: none needed -- the layer has enough output tiles to fill the chip without slicing its border pixels) */
+long long lp_reflect_border_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout);
 /* L1 taps: partial[lp_l1_partial_blocks()] block sums of |relu?(a) - relu?(b)| (F.l1_loss numerator; featmat.py:17, perceptual_loss.py:107);
  * backward: da = coef * grad_out[0] * sign(relu?(a) - relu?(b)) * (relu_in ? [a>0] : 1)  (+ add [numel]|NULL: the gradient that
  * reaches `a` from its other consumer -- the next conv / pool of the VGG stack -- summed here instead of by an autograd add) */

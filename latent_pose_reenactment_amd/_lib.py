@@ -107,7 +107,8 @@ SIGNATURES = {
     'lp_avgpool2_bwd_m16': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'lp_reflect_border_fwd': (_i, [_vp, _vp] + [_i] * 7 + [_vp, _i, _vp, _vp, _vp]),
     'lp_reflect_border_dgrad': (_i, [_vp] + [_i] * 4 + [_vp, _i, _vp, _vp, _i, _vp, _vp]),
-    'lp_reflect_border_wgrad': (_i, [_vp, _vp] + [_i] * 7 + [_vp, _i, _vp, _vp]),
+    'lp_reflect_border_wgrad': (_i, [_vp, _vp] + [_i] * 7 + [_vp, _i, _vp, _vp, _vp]),
+    'lp_reflect_border_wgrad_workspace_bytes': (_ll, [_i] * 5),
     'lp_l1_bwd': (_i, [_vp, _vp, _vp, _f, _vp, _vp, _ll, _i, _vp, _vp, _vp]),
     'lp_dice_partial_blocks': (_i, []),
     'lp_reduce_dice': (_i, [_vp] * 5 + [_i] * 4 + [_f, _vp]),

@@ -494,8 +494,10 @@ def reflect_border_wgrad(a: Act16, dy: Tensor, *, prec: int, upsample: bool = Fa
     n, h, w, cout = dy.shape
     assert a.inv is None and a.nhw == ((n, h // 2, w // 2) if upsample else (n, h, w)), (a.hi.shape, dy.shape, upsample)
     gw = torch.empty((cout, a.c, 3, 3), dtype=torch.float32, device=dy.device)
+    nws = _lib.lib().lp_reflect_border_wgrad_workspace_bytes(n, h, w, a.c, cout) // 4
+    ws = torch.empty(nws, dtype=torch.float32, device=dy.device) if nws else None
     check(_lib.lib().lp_reflect_border_wgrad(a.hi.data_ptr(), _p(a.lo), prec, n, h, w, a.c, a.hi.shape[3], int(upsample), dy.data_ptr(), cout,
-                                             gw.data_ptr(), _stream()), 'lp_reflect_border_wgrad')
+                                             gw.data_ptr(), _p(ws), _stream()), 'lp_reflect_border_wgrad')
     return _sn_finish(gw, sn, accum)
 
 
