@@ -70,13 +70,17 @@ def stamp_status(stamp):
     return bool(diff), ('' if not diff else 'source changed since the file was measured: ' + ', '.join(diff))
 
 
-def step_algorithmic_tflop(workload, batch, frames=8):
+def step_algorithmic_tflop(workload, batch, frames=8, image_size=256, generator='vector_pose_unsupervised_segmentation_noBottleneck'):
     """useful dense FLOPs of one training step as THIS path executes it (fwd = 1, data gradient = 1, weight gradient = 1 per layer):
     G fwd + both gradients; D: the fake pass of the G loss (fwd + dgrad, its weight gradients are never consumed), the detached fake and
     the real pass of the D loss (fwd + both gradients each); VGG19 / VGGFace: fake fwd + dgrad, real fwd; meta-training adds the encoders
     (fwd + both gradients).  The reference's step also computes D weight gradients in the G backward and discards them (holycow.py:247)."""
     per_img = 3 * GEN_FWD_GFLOP_PER_IMAGE
     if workload == 'generator':
+        if generator == 'FSTH_plus' and image_size == 512:
+            per_img = 3 * 242.5          # BASELINE.md section 2: FSTH_plus forward at 512 x 512 (one more up block: not the 256 x 256 count x 4)
+        else:
+            assert image_size == 256, 'FLOP table holds the 256 x 256 generator and the 512 x 512 FSTH_plus generator (BASELINE.md section 2)'
         return per_img * batch / 1e3
     per_img += (2 + 3 + 3) * DIS_GFLOP + 3 * VGG19_GFLOP + 3 * VGGFACE_GFLOP
     if workload == 'metatrain_step':
@@ -920,7 +924,7 @@ def main():
             'roofline': roof,
         }
         # whole-step MFMA utilisation: the number the 0.60 target of BASELINE.json is about (useful dense FLOPs of the step / time / peak)
-        tf = step_algorithmic_tflop(a.workload, a.batch, args.n_frames_for_encoder) * world
+        tf = step_algorithmic_tflop(a.workload, a.batch, args.n_frames_for_encoder, a.image_size, a.generator) * world
         out['step_mfma_utilisation'] = {'algorithmic_tflop_per_step': round(tf, 3), 'achieved_tflops': round(tf / (dt / a.steps), 1),
                                         'frac_of_bf16_peak': round(tf / (dt / a.steps) / (MFMA_BF16_PEAK_TFLOPS * world), 4),
                                         'note': 'useful dense 2*MAC of one step as executed (step_algorithmic_tflop) / ms_per_step / (2.5 PF x n_gpus)'}
