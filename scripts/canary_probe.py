@@ -13,7 +13,11 @@ import torch  # noqa: E402
 from latent_pose_reenactment_amd import hipops as ops  # noqa: E402
 
 runs = int(sys.argv[1]) if len(sys.argv) > 1 else 6
-lib = ctypes.CDLL(os.path.join(ROOT, 'scripts', 'diag', '_canary.so'))
+_so, _src = os.path.join(ROOT, 'scripts', 'diag', '_canary.so'), os.path.join(ROOT, 'scripts', 'diag', 'canary.hip')
+if not os.path.exists(_so) or os.path.getmtime(_so) < os.path.getmtime(_src):          # (diagnosis kernels: built on demand, not part of liblp_hip.so)
+    import subprocess
+    subprocess.run([os.environ.get('HIPCC', '/opt/rocm/bin/hipcc'), '--offload-arch=gfx950', '-O3', '-shared', '-fPIC', _src, '-o', _so], check=True)
+lib = ctypes.CDLL(_so)
 lib.canary_launch.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 torch.manual_seed(0)
 x = torch.randn(8, 64, 64, 256, device='cuda')
