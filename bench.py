@@ -478,9 +478,10 @@ def cpu_baseline(args, full=False, workload='metatrain_step'):
     extra = {}
     try:
         node0 = nodes[0]
-        g_ = result(spawn(len(node0[1]), 8, 1, 3 if full else 2, 120 if full else 30, node0[2], kind=2), 120 if full else 30)
-        d_ = result(spawn(len(node0[1]), 1, 1, 5 if full else 3, 60 if full else 20, node0[2], kind=3), 60 if full else 20)
-        d1 = result(spawn(1, 1, 1, 5 if full else 2, 60 if full else 20, kind=3), 60 if full else 20)
+        # (--cpu-baseline-full: the section-3 protocol for these two rows as well, 3 warm-up + 10 timed)
+        g_ = result(spawn(len(node0[1]), 8, 3 if full else 1, 10 if full else 2, 240 if full else 30, node0[2], kind=2), 240 if full else 30)
+        d_ = result(spawn(len(node0[1]), 1, 3 if full else 1, 10 if full else 3, 60 if full else 20, node0[2], kind=3), 60 if full else 20)
+        d1 = result(spawn(1, 1, 3 if full else 1, 10 if full else 2, 90 if full else 20, kind=3), 90 if full else 20)
         extra = {'generator_only': {'value': round(8 / g_['t'], 3), 'unit': 'images/s', 'cores': len(node0[1]), 's_per_step': round(g_['t'], 3),
                                     'sample': f"generator forward + backward, bs 8 at {args.image_size}x{args.image_size}, oracle/lp_oracle.py on the {len(node0[1])} physical cores "
                                               f"of NUMA node {node0[0]}; median of {g_['n']} step(s)"},
