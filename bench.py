@@ -31,6 +31,9 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0       # MI355X dense bf16 MFMA peak (MI355X_MICRO
 DIS_GFLOP, VGG19_GFLOP, VGGFACE_GFLOP, RESNEXT_GFLOP_PER_FRAME, MOBILENET_GFLOP_PER_FRAME = 30.97, 47.34, 40.09, 11.0, 0.8
 
 
+ROUND = 'r06'          # prefix of the profiles/ files this tree's tests and artifact script write and this file quotes
+
+
 def source_stamp():
     """what ties a measured file under profiles/ to the tree that produced it: sha256 over the kernel sources + C header (`csrc`) and over
     the package's Python files (`py`), 16 hex digits each -- computable on the GPU box (which has no .git) and here; `head` = git HEAD when
@@ -583,7 +586,7 @@ def measured_parity(mode, workload):
       gradients: tests/test_full_size_parity.py (G, D, VGG19, VGGFace at 256 x 256: tie-masked against the oracle) and
                  tests/test_e1_full_gpu.py (identity encoder, 64 frames: all-gradient rel-L2 / cosine vs fp64 with the stock-fp32 calibration).
     The files carry the source stamp of the tree that produced them; a file whose stamp differs from the running tree is reported STALE."""
-    res, stale, why = _load_profile(f'r05_parity_configs2_{mode}.json')
+    res, stale, why = _load_profile(f'{ROUND}_parity_configs2_{mode}.json')
     if res is None:
         return {'status': 'unmeasured', 'note': why + ': run tests/test_metatrain_full_gpu.py with LP_PARITY_OUT=profiles'}
     worst = max(res['errors'].items(), key=lambda kv: kv[1])
@@ -597,13 +600,13 @@ def measured_parity(mode, workload):
            'stock_fp32_encoders_vs_fp64': res.get('stock_fp32_encoders_vs_fp64')}
     if stale:
         out['stale_reason'] = why
-    g, gstale, gwhy = _load_profile(f"r05_parity_gradients_{'f16' if mode == 'default' else mode}.json")
+    g, gstale, gwhy = _load_profile(f"{ROUND}_parity_gradients_{'f16' if mode == 'default' else mode}.json")
     if g is None:
         out['gradients'] = {'status': 'unmeasured', 'note': gwhy}
     else:
         r3 = lambda v: float(f'{v:.3g}')
         grads = {'status': 'stale' if gstale else 'measured', 'stale': gstale,
-                 'source': 'tests/test_full_size_parity.py + tests/test_e1_full_gpu.py -> profiles/' + f"r05_parity_gradients_{'f16' if mode == 'default' else mode}.json"}
+                 'source': 'tests/test_full_size_parity.py + tests/test_e1_full_gpu.py -> profiles/' + f"{ROUND}_parity_gradients_{'f16' if mode == 'default' else mode}.json"}
         tie = {}
         if 'generator' in g:
             tie['generator'] = r3(g['generator']['tie_masked_worst'][1])
@@ -868,14 +871,14 @@ def main():
                 entry.pop(k_, None)
         if kind == 'conv_igemm':
             # HBM bytes per launch of this kernel family from the committed PMC passes: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs
-            # of THIS workload (the meta-training step), counter collection restricted to the 3x3 kernels (scripts/r05_artifacts.sh; FETCH_SIZE
+            # of THIS workload (the meta-training step), counter collection restricted to the 3x3 kernels (scripts/r06_artifacts.sh; FETCH_SIZE
             # doubled per MI355X_MICROARCH.md).  The file carries the source stamp of the tree it was measured on: a stale file is SAID to be stale.
-            pm, pstale, pwhy = _load_profile('r05_pmc_conv3x3_metatrain.json')
+            pm, pstale, pwhy = _load_profile(f'{ROUND}_pmc_conv3x3_metatrain.json')
             if pm is not None:
                 entry['traffic'] = pm.get('hbm_bytes_per_launch')
                 entry['traffic_stale'] = pstale
                 entry['traffic_note'] = ('mean HBM bytes per 3x3 conv launch (conv_pipe_kernel + conv_dma_kernel<3>) over the launch population of the '
-                                         'meta-training step (warm-up, capture and replays of `bench.py --steps 2 --warmup 1`): profiles/r05_pmc_conv3x3_metatrain.json, '
+                                         'meta-training step (warm-up, capture and replays of `bench.py --steps 2 --warmup 1`): profiles/' + ROUND + '_pmc_conv3x3_metatrain.json, '
                                          'separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per MI355X_MICROARCH.md; '
                                          f"MFMA busy fraction from SQ_VALU_MFMA_BUSY_CYCLES: {pm.get('mfma_busy_fraction')}" + (f' -- STALE: {pwhy}' if pstale else ''))
                 entry['mfma_busy_fraction_pmc'] = pm.get('mfma_busy_fraction')
@@ -886,7 +889,7 @@ def main():
             entry['frac_note'] = ('frac / achieved: LIVE -- HIP events on the launch stream around every launch of the family in two eager one-stream steps of this '
                                   'process (each event pair adds a few microseconds to a ~35 us launch); in_graph: the same family inside the captured step '
                                   '(rocprofv3 kernel trace of a graph replay x the shape list, scripts/in_graph_conv.py) -- the figure without eager launch gaps')
-            ig, istale, iwhy = _load_profile('r05_conv3x3_in_graph.json')
+            ig, istale, iwhy = _load_profile(f'{ROUND}_conv3x3_in_graph.json')
             if ig is not None:      # the same family INSIDE the graph replay (rocprofv3 kernel trace of the captured step: no eager launch gaps)
                 entry['in_graph'] = dict(ig, stale=istale, **({'stale_reason': iwhy} if istale else {}))
                 entry['frac_in_graph'] = ig.get('frac')

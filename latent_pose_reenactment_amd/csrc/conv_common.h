@@ -2,6 +2,7 @@
 // counted-vmcnt tap pipeline): the launch parameter block and the epilogue that turns a wave's accumulator block into the outputs.
 #pragma once
 #include "lp_common.h"
+#include <stdlib.h>
 
 struct Conv16Params {
     const uint16_t* a_hi; const uint16_t* a_lo; const uint16_t* w_hi; const uint16_t* w_lo;
@@ -23,11 +24,33 @@ struct Conv16Params {
                                   // extra pass over it).  Host-checked: every wave's rows lie in one image, tiles cover the images exactly.
     long long stats_cap;          // (host) capacity of `stats` in floats
     int stats_rows;               // (host, out) partial rows per image the launch wrote (0: none -- geometry not covered, caller runs the stats pass)
+    int xcd_map, ntiles, nco;     // xcd_map: 1-D grid of 8 * ceil(ntiles / 8) * nco workgroups; workgroup id -> XCD id & 7 (round-robin dispatch), and on
+                                  // that XCD the Cout blocks of ONE pixel tile run back to back, the XCD's tiles being a contiguous range: the halo
+                                  // a tile's nco workgroups share (and the rows neighbouring tiles share) is fetched from HBM once, into one L2
     int grouped;                  // block-diagonal (grouped) conv: the workgroup's 64 output channels only see input channels co0 .. co0+63;
                                   // the weight image then has 64 columns (CinP = 64) and the activation channel offset is co0
 };
 
 static inline int ilog2_floor(int v) { int l = 0; while ((1 << (l + 1)) <= v) ++l; return l; }
+
+// workgroup id -> (pixel tile | pair of tiles, Cout block); false: the workgroup lies in the padding of the XCD-ordered grid
+__device__ __forceinline__ bool conv16_block(const Conv16Params& p, int& tile, int& cob) {
+    if (!p.xcd_map) { tile = (int)blockIdx.x; cob = (int)blockIdx.y; return true; }
+    const int id = (int)blockIdx.x, x = id & 7, j = id >> 3;
+    const int per = (p.ntiles + 7) >> 3;          // tiles per XCD
+    cob = j % p.nco;
+    const int k = j / p.nco;
+    tile = x * per + k;
+    return k < per && tile < p.ntiles;
+}
+
+static inline dim3 conv16_grid(Conv16Params& p, int ntiles, int nco, int gz = 1) {
+    static const int on = getenv("LP_CONV_XCD") ? atoi(getenv("LP_CONV_XCD")) : 1;
+    p.ntiles = ntiles; p.nco = nco;
+    p.xcd_map = (on && nco > 1 && ntiles >= 16) ? 1 : 0;
+    if (!p.xcd_map) return dim3(ntiles, nco, gz);
+    return dim3(((ntiles + 7) / 8) * 8 * nco, 1, gz);
+}
 
 // choose NB x TH x TW = BM with TH<=H, TW<=W (powers of two), preferring wide patches (TW up to 16)
 static inline void choose_tile(int BM, int N, int H, int W, int* lTH, int* lTW, int* lNB) {

@@ -77,11 +77,14 @@ void conv_dma_kernel(Conv16Params p) {
     const int wm = wave / WN, wn = wave % WN;
     const int TH = 1 << p.lTH, TW = 1 << p.lTW, NBv = 1 << p.lNB;
 
-    int t = PP ? (int)blockIdx.x * 2 + grp : (int)blockIdx.x;
+    int tile_id, cob;
+    if (!conv16_block(p, tile_id, cob)) return;          // (uniform: padding of the XCD-ordered grid)
+    if (PP) tile_id = tile_id * 2 + grp;
+    int t = tile_id;
     const int tx = t % p.tiles_x; t /= p.tiles_x;
     const int ty = t % p.tiles_y; const int ng = t / p.tiles_y;
     const int n0 = ng << p.lNB, y0 = ty << p.lTH, x0 = tx << p.lTW;
-    const int co0 = blockIdx.y * BN;
+    const int co0 = cob * BN;
 
     int HH, HW, oy, ox;
     if (KS == 1) { HH = TH; HW = TW; oy = y0; ox = x0; }
@@ -296,8 +299,7 @@ void conv_dma_kernel(Conv16Params p) {
     }
 
     // ---- epilogue (conv_common.h).  1x1 layers transpose 16 rows (one MFMA row block) at a time, 3x3 kernels the whole block
-    conv16_epilogue<WM, WN, MR, NR, PREC, (KS == 1) ? 1 : MR>(p, acc, smem, wave_d, wm, wn, lane, n0, y0, x0, co0, NBv,
-                                                              PP ? (int)blockIdx.x * 2 + grp : (int)blockIdx.x);
+    conv16_epilogue<WM, WN, MR, NR, PREC, (KS == 1) ? 1 : MR>(p, acc, smem, wave_d, wm, wn, lane, n0, y0, x0, co0, NBv, tile_id);
 }
 
 // Split-K finish: y = alpha * sum_s part[s] + bias + res, ReLU mask, 16-bit planes of the consumer -- the whole epilogue of the conv,
@@ -414,6 +416,7 @@ static int launch_conv16(Conv16Params& p, hipStream_t stream) {
     if (lds < epi) lds = epi;
     if (lds > LDS_MAX) return lp_set_error(LP_ERR_UNSUPPORTED, "conv16 tile needs too much LDS");
     dim3 grid(pp ? (tiles + 1) / 2 : tiles, (p.Cout + BN - 1) / BN);
+    p.xcd_map = 0; p.ntiles = grid.x; p.nco = grid.y;
     {   // split-K when the output tiling alone cannot fill the 256 CUs (4x4 ... 16x16 layers with K = 9*512): grid.z slices of the
         // contraction write partial tiles into the caller's workspace, splitk_reduce_kernel (launched by lp_conv16_fwd) finishes.
         // 1x1 convs are not split: their whole contraction is 16 stages, less than the cost of a second launch.
@@ -431,6 +434,7 @@ static int launch_conv16(Conv16Params& p, hipStream_t stream) {
         p.ksplit = ks;
         grid.z = ks;
     }
+    if (KS == 3 && !p.grouped) grid = conv16_grid(p, (int)grid.x, (int)grid.y, (int)grid.z);      // XCD-aware order (dense 3x3: the halo is the shared operand)
     p.stats_rows = 0;
     if (p.stats) {
         // fused norm statistics need: full tiles (every wave's MR*16 rows inside ONE image, tiles covering the images exactly, image-major

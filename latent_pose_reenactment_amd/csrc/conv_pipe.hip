@@ -74,11 +74,13 @@ void conv_pipe_kernel(Conv16Params p) {
     const int wm = wave / WN, wn = wave % WN;
     const int TH = 1 << p.lTH;                           // (host: lTW == 4, lNB == 0)
 
-    int t = (int)blockIdx.x;
+    int tile_id, cob;
+    if (!conv16_block(p, tile_id, cob)) return;          // (uniform: padding of the XCD-ordered grid)
+    int t = tile_id;
     const int tx = t % p.tiles_x; t /= p.tiles_x;
     const int ty = t % p.tiles_y; const int n0 = t / p.tiles_y;
     const int y0 = ty << p.lTH, x0 = tx << 4;
-    const int co0 = blockIdx.y * BN;
+    const int co0 = cob * BN;
     const int HH = UPS ? (TH >> 1) + 2 : TH + 2;
     const int oy = UPS ? (y0 >> 1) - 1 : y0 - 1, ox = UPS ? (x0 >> 1) - 1 : x0 - 1;
     const int halo_px = HH * HW;
@@ -249,7 +251,7 @@ void conv_pipe_kernel(Conv16Params p) {
         }
     }
     // ---- epilogue (conv_common.h; 16 rows through LDS at a time: 4.3 KB of scratch per wave)
-    conv16_epilogue<WM, WN, MR, NR, PREC, 1>(p, acc, smem, wave, wm, wn, lane, n0, y0, x0, co0, 1, (int)blockIdx.x);
+    conv16_epilogue<WM, WN, MR, NR, PREC, 1>(p, acc, smem, wave, wm, wn, lane, n0, y0, x0, co0, 1, tile_id);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -404,6 +406,7 @@ static int launch_pipe1x1(Conv16Params& p, hipStream_t stream) {
             return lp_set_error(LP_ERR_HIP, "hipFuncSetAttribute failed");
         attr_dev = dev;
     }
+    p.xcd_map = 0; p.ntiles = tiles; p.nco = (p.Cout + BN - 1) / BN;
     hipLaunchKernelGGL(kern, dim3(tiles, (p.Cout + BN - 1) / BN), dim3(256), lds, stream, p);
     const int rc = lp_check_launch("conv1x1_pipe");
     return rc ? rc : 1;
@@ -472,7 +475,7 @@ static int launch_pipe(Conv16Params& p, hipStream_t stream) {
             return lp_set_error(LP_ERR_HIP, "hipFuncSetAttribute failed");
         attr_dev = dev;
     }
-    hipLaunchKernelGGL(kern, dim3(tiles, (p.Cout + BN - 1) / BN), dim3(NWAVE * 64), lds, stream, p);
+    hipLaunchKernelGGL(kern, conv16_grid(p, tiles, (p.Cout + BN - 1) / BN), dim3(NWAVE * 64), lds, stream, p);
     const int rc = lp_check_launch("conv_pipe");
     return rc ? rc : 1;
 }

@@ -42,6 +42,21 @@ def gpass_prec():
     return lpnn.PREC_NAMES[name], int(_os.environ.get('LP_D_GPASS_FROM', '0'))
 
 
+def dpass_prec():
+    """operand mode of the two discriminator-side passes (fake.detach -> D, real -> D: the passes behind loss_D.backward, i.e. behind every
+    parameter gradient the critic's optimizer sees).  The hinge loss puts -1/2 on the real and +1/2 on the fake sample, so the weight gradients
+    of the last blocks are DIFFERENCES of nearly equal terms and fp16 operand rounding shows up amplified in them (9.3e-3 tie-masked on
+    ``blocks.5.block.5`` at 256 x 256, round 5) -- outside SURVEY 8d's 1e-3 on every parameter gradient.  ``LP_D_DPASS_PREC`` (f16 | bf16x3)
+    and ``LP_D_DPASS_FROM`` (first strict unit: 0 = stem, 1.. = blocks) choose the assignment; -> (mode, first strict unit)"""
+    name = _os.environ.get('LP_D_DPASS_PREC', DPASS_DEFAULT[0])
+    if default_prec() != lpnn.PREC_F16 or name == 'f16':
+        return default_prec(), 0
+    return lpnn.PREC_NAMES[name], int(_os.environ.get('LP_D_DPASS_FROM', str(DPASS_DEFAULT[1])))
+
+
+DPASS_DEFAULT = ('f16', 0)
+
+
 class Wrapper:
     @staticmethod
     def get_args(parser):
@@ -167,11 +182,13 @@ class Discriminator(nn.Module):
         units = [[d0, d2, sk]] + [blk.sn_layers() for blk in self.blocks]          # unit 0 = stem, 1.. = blocks (gpass_prec's numbering)
         if not d0.weight_orig.is_cuda:
             return {}
-        gprec, gfrom = gpass_prec()
         training = self.training and torch.is_grad_enabled()
         out = {}
-        for prec, convs in ((default_prec(), [m for u in units for m in u]),
-                            (gprec, [m for u in units[gfrom:] for m in u] if (gprec != default_prec() and training) else [])):
+        strict_from = {}          # operand mode other than the default one -> first unit any pass runs in it
+        for sprec, sfrom in (gpass_prec(), dpass_prec()):
+            if sprec != default_prec() and training:
+                strict_from[sprec] = min(sfrom, strict_from.get(sprec, sfrom))
+        for prec, convs in [(default_prec(), [m for u in units for m in u])] + [(sp, [m for u in units[sf:] for m in u]) for sp, sf in strict_from.items()]:
             if not convs:
                 continue
             specs = []
@@ -293,8 +310,11 @@ class Discriminator(nn.Module):
         eu, ev, esig = prepared[1]
         embed = SNEmbeddingFn.apply(label, self.embed.weight_orig, eu, ev, esig, self.__dict__.setdefault('_embed_parts', {}))
         with streams.branch(real.device, 7) as b3:
-            real_score, real_features = self.pass_inputs(real, embed, sn_states=ahead[2])
+            real_score, real_features = self.pass_inputs(real, embed, sn_states=ahead[2], strict=self._dstrict())
         self.__dict__['_early_real'] = (embed, b3, real_score, real_features)
+
+    def _dstrict(self):
+        return dpass_prec() if (self.training and torch.is_grad_enabled() and dpass_prec()[0] != default_prec()) else None
 
     def forward(self, data_dict):
         fake, real, label = data_dict['fake_rgbs'], data_dict['target_rgbs'], data_dict['label']
@@ -322,6 +342,7 @@ class Discriminator(nn.Module):
         # are not computed unless ``keep_reference_waste`` asks for the reference's exact .grad side effects (parity tests).
         track1 = bool(getattr(self, 'keep_reference_waste', False))
         gstrict = gpass_prec() if (self.training and torch.is_grad_enabled() and gpass_prec()[0] != default_prec()) else None
+        dstrict = self._dstrict()
         from latent_pose_reenactment_amd import streams
         if self.training and torch.is_grad_enabled() and streams.enabled(fake, 'dpasses', finetuning=self.finetuning):
             # the three passes are independent given the images and the label embedding: the two discriminator-side passes run on side
@@ -336,17 +357,17 @@ class Discriminator(nn.Module):
             # (this pass and the real-image pass deposit gradients on the same parameters from two streams: this one accumulates into the
             #  parameters' SECOND buffers -- nn.alt_accumulation)
             with streams.branch(fake.device, 6, after=here) as b2, lpnn.alt_accumulation():
-                fake_score_D, _ = self.pass_inputs(fake.detach(), embed.detach(), sn_states=sts[1])
+                fake_score_D, _ = self.pass_inputs(fake.detach(), embed.detach(), sn_states=sts[1], strict=dstrict)
             if early_real is not None:
                 _, b3, real_score, real_features = early_real
             else:
                 with streams.branch(fake.device, 7, after=here) as b3:
-                    real_score, real_features = self.pass_inputs(real, embed, sn_states=sts[2])
+                    real_score, real_features = self.pass_inputs(real, embed, sn_states=sts[2], strict=dstrict)
             b2.join(fake_score_D)
             b3.join((real_score, real_features))
         else:
             fake_score_G, fake_features = self.pass_inputs(fake, embed if track1 else embed.detach(), track_weights=track1, strict=gstrict)
-            fake_score_D, _ = self.pass_inputs(fake.detach(), embed.detach())
-            real_score, real_features = self.pass_inputs(real, embed)
+            fake_score_D, _ = self.pass_inputs(fake.detach(), embed.detach(), strict=dstrict)
+            real_score, real_features = self.pass_inputs(real, embed, strict=dstrict)
         data_dict.update(fake_features=fake_features, real_features=real_features, real_embedding=embed,
                          fake_score_G=fake_score_G, fake_score_D=fake_score_D, real_score=real_score)

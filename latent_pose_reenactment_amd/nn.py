@@ -37,6 +37,18 @@ def default_prec() -> int:
     return PREC_NAMES[os.environ.get('LP_PREC', 'f16')]
 
 
+def generator_prec() -> int:
+    """operand mode of the generator's convs: ``LP_PREC_G`` if set, else the assignment default (GENERATOR_DEFAULT under the global fp16 mode,
+    the global mode otherwise)"""
+    name = os.environ.get('LP_PREC_G')
+    if name:
+        return PREC_NAMES[name]
+    return PREC_NAMES[GENERATOR_DEFAULT] if default_prec() == PREC_F16 else default_prec()
+
+
+GENERATOR_DEFAULT = 'f16'
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # spectral-norm parameter holder with the legacy-hook key names (weight_orig / weight_u / weight_v [+ bias])
 # ----------------------------------------------------------------------------------------------------------------------
@@ -703,7 +715,7 @@ class Generator(nn.Module):
         self.num_affine_params = sum(2 * (a + b) for a, b, _ in self.blocks_cfg) + 2 * self.blocks_cfg[-1][1]
         self.affine_params_projector = self._build_projector(joint)
         self.finetuning = False
-        self.prec = default_prec() if prec is None else prec
+        self.prec = generator_prec() if prec is None else prec
 
     # ---- the projector is the only part in which the generator plugins differ (noBottleneck.py:96-101 vs FSTH_plus.py:96-103)
     def _build_projector(self, joint):

@@ -79,7 +79,7 @@ def test_identity_encoder_full_geometry_forward_and_gradients(monkeypatch, mode,
     keep = os.environ.get('LP_PARITY_OUT')
     if keep:
         import bench
-        path = os.path.join(keep, f'r05_parity_gradients_{"f16" if mode == "default" else mode}.json')
+        path = os.path.join(keep, f'{bench.ROUND}_parity_gradients_{"f16" if mode == "default" else mode}.json')
         try:
             cur = json.load(open(path))
         except Exception:

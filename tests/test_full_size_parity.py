@@ -22,7 +22,7 @@ def rel(a, b):
 
 
 def export(mode, net, figures):
-    """LP_PARITY_OUT=<dir> (the artifact scripts): merge this test's measured figures into <dir>/r05_parity_gradients_<mode>.json -- bench.py's
+    """LP_PARITY_OUT=<dir> (the artifact scripts): merge this test's measured figures into <dir>/r06_parity_gradients_<mode>.json -- bench.py's
     ``parity.gradients`` reads them from profiles/ (with the source stamp of the tree that produced them)"""
     keep = os.environ.get('LP_PARITY_OUT')
     if not keep:
@@ -32,7 +32,7 @@ def export(mode, net, figures):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     import bench
-    path = os.path.join(keep, f'r05_parity_gradients_{mode}.json')
+    path = os.path.join(keep, f'{bench.ROUND}_parity_gradients_{mode}.json')
     try:
         cur = json.load(open(path))
     except Exception:
@@ -251,6 +251,7 @@ def test_discriminator_256_three_passes_vs_oracle(prec_name, tol_out, tol_grad, 
     export(prec_name, 'discriminator', {'forward_worst': [max(errs, key=errs.get), max(errs.values())],
                                         'tie_masked_worst_G_loss': max(((k, v) for k, v in gerr.items() if k.startswith('G.')), key=lambda kv: kv[1]),
                                         'tie_masked_worst_D_loss': max(((k, v) for k, v in gerr.items() if k.startswith('D.')), key=lambda kv: kv[1]),
+                                        'tie_masked_all': gerr, 'forward_all': errs,
                                         'gate_G_loss': tol_grad, 'gate_D_loss': 3 * tol_grad})
     assert all(v < tol_out for v in errs.values()), errs
     # D-loss weight gradients of the last blocks are DIFFERENCES of nearly equal fake / real terms (hinge: -1/2 on the real, +1/2 on the

@@ -124,7 +124,7 @@ def test_full_size_metatrain_forward_vs_reference_chain(tmp_path, mode, gate):
           f"| stock fp32 encoders vs fp64: {res['stock_fp32_encoders_vs_fp64']}")
     keep = os.environ.get('LP_PARITY_OUT')        # (scripts: copy the measured figures to profiles/)
     if keep:
-        json.dump(res, open(os.path.join(keep, f'r05_parity_configs2_{mode}.json'), 'w'), indent=1)
+        json.dump(res, open(os.path.join(keep, f'{bench.ROUND}_parity_configs2_{mode}.json'), 'w'), indent=1)
     bad = {k: v for k, v in res['errors'].items() if not v < gate}
     assert not bad, bad
 
