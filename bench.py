@@ -590,7 +590,7 @@ def measured_parity(mode, workload):
     if res is None:
         return {'status': 'unmeasured', 'note': why + ': run tests/test_metatrain_full_gpu.py with LP_PARITY_OUT=profiles'}
     worst = max(res['errors'].items(), key=lambda kv: kv[1])
-    out = {'status': 'stale' if stale else 'measured', 'stale': stale, 'source': f'tests/test_metatrain_full_gpu.py -> profiles/r05_parity_configs2_{mode}.json',
+    out = {'status': 'stale' if stale else 'measured', 'stale': stale, 'source': f'tests/test_metatrain_full_gpu.py -> profiles/{ROUND}_parity_configs2_{mode}.json',
            'geometry': res.get('geometry'),
            'identity_encoder_fp16_tail_blocks': res['identity_encoder_blocks'].count('f16') if res['identity_encoder_blocks'][0] != 'f16' else 'all',
            'critic_fake_to_G_pass': res.get('critic_fake_to_G_pass'),
@@ -617,6 +617,19 @@ def measured_parity(mode, workload):
             if k in g:
                 tie[k + '_d_image'] = r3(g[k]['tie_masked_d_fake'])
         grads['tie_masked_worst_rel_l2'] = tie
+        # the plain figures (against the true-ReLU / true-sign oracle) beside them: a pre-activation within rounding distance of 0 flips its ReLU
+        # between two correct implementations, which the tie-masked comparison removes and these keep (fp32 CPU oracle vs fp64: generator 2.7e-4)
+        untied = {}
+        if 'generator' in g:
+            untied['generator'] = r3(g['generator']['untied_worst'])
+            untied['generator_fp32_oracle_tie_floor_vs_fp64'] = r3(g['generator']['fp32_oracle_tie_floor_vs_fp64'])
+        if 'discriminator' in g and 'untied_worst_D_loss' in g['discriminator']:
+            untied['discriminator_G_loss'] = r3(g['discriminator']['untied_worst_G_loss'])
+            untied['discriminator_D_loss'] = r3(g['discriminator']['untied_worst_D_loss'])
+        for k in ('vgg19', 'vggface'):
+            if k in g:
+                untied[k + '_d_image'] = r3(g[k]['untied_d_fake'])
+        grads['untied_worst_rel_l2'] = untied
         grads['within_1e-3'] = bool(tie) and all(v < 1e-3 for v in tie.values())
         if 'identity_encoder' in g:
             e = g['identity_encoder']
@@ -803,6 +816,27 @@ def main():
                         'after_steps': a.warmup + a.steps + 2,
                         'note': 'checked after the warm-up, timed and instrumented steps, BEFORE the exchange-free single-GPU leg (which lets the ranks drift apart on purpose)'}
 
+    comm = None
+    if world > 1 and a.workload != 'generator' and getattr(tm, 'reducer', None) is not None:
+        # diagnosis of the gradient exchange: a few more steps of the SAME step function with events around every
+        # all-reduce issue and around the wait of its consumer -- per-bucket bytes, how long each collective had to finish behind other work,
+        # and how long the compute stream still stood in the wait (exposed_comm_ms_per_step).  Outside the timed region.
+        try:
+            nd = 5
+            tm.reducer.enable_diag()
+            for _ in range(nd):
+                step()
+            sync()
+            comm = tm.reducer.diag_summary(nd)
+            tm.reducer.diag = None
+            for b_ in [tm.reducer.g_bucket, tm.reducer.d_bucket] + list(tm.reducer.g_parts.values()):
+                b_.diag = None
+            if comm is not None:
+                comm['backend'] = a.backend
+                comm['reduce_op'] = 'AVG (inside the collective)' if a.backend == 'nccl' else 'SUM + div_'
+        except Exception as ex:
+            comm = {'error': repr(ex)}
+
     solo = None
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -841,7 +875,11 @@ def main():
     agg = {}
     shapes = {}
     agg_bytes = {}
-    for kind, flops, e0, e1, tag, nbytes in prof:
+    agg_rw = {}
+    for kind, flops, e0, e1, tag, nbytes, rw in prof:
+        if rw is not None:
+            q = agg_rw.setdefault(kind, [0.0, 0.0, 0])
+            q[0] += rw[0]; q[1] += rw[1]; q[2] += 1
         sd = shapes.setdefault((kind, tag), [0.0, 0.0, 0])
         sd[0] += flops; sd[1] += e0.elapsed_time(e1) * 1e-3; sd[2] += 1
         d = agg.setdefault(kind, [0.0, 0.0, 0])
@@ -877,7 +915,14 @@ def main():
             if pm is not None:
                 entry['traffic'] = pm.get('hbm_bytes_per_launch')
                 entry['traffic_stale'] = pstale
-                entry['traffic_note'] = ('mean HBM bytes per 3x3 conv launch (conv_pipe_kernel + conv_dma_kernel<3>) over the launch population of the '
+                # read and write separately, with the algorithmic bytes of the same family beside them (mean over this process's instrumented launches)
+                rw = agg_rw.get(kind)
+                entry['traffic_read_write'] = {'hbm_read_bytes_per_launch': pm.get('hbm_read_bytes_per_launch'), 'hbm_write_bytes_per_launch': pm.get('hbm_write_bytes_per_launch'),
+                                               'algorithmic_read_bytes_per_launch': None if not rw else int(rw[0] / rw[2]),
+                                               'algorithmic_write_bytes_per_launch': None if not rw else int(rw[1] / rw[2]),
+                                               'family': 'dense 3x3 forward / dgrad: conv_pipe_kernel + conv_dma_kernel<3> without the grouped (identity-encoder) instantiations',
+                                               'read_amplification': None if not (rw and pm.get('hbm_read_bytes_per_launch')) else round(pm['hbm_read_bytes_per_launch'] / (rw[0] / rw[2]), 2)}
+                entry['traffic_note'] = ('mean HBM bytes per DENSE 3x3 conv launch (conv_pipe_kernel + conv_dma_kernel<3>, grouped instantiations excluded) over the launch population of the '
                                          'meta-training step (warm-up, capture and replays of `bench.py --steps 2 --warmup 1`): profiles/' + ROUND + '_pmc_conv3x3_metatrain.json, '
                                          'separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per MI355X_MICROARCH.md; '
                                          f"MFMA busy fraction from SQ_VALU_MFMA_BUSY_CYCLES: {pm.get('mfma_busy_fraction')}" + (f' -- STALE: {pwhy}' if pstale else ''))
@@ -939,6 +984,8 @@ def main():
             out['single_gpu_same_workload'] = solo
         if replicas is not None:
             out['replicas'] = replicas
+        if comm is not None:
+            out['gradient_exchange'] = comm
         if world == 1 and not a.no_drive:
             try:
                 out['drive'] = drive_fps(args)

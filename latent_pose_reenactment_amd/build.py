@@ -3,6 +3,7 @@ the product is a plain C-ABI shared library (include/lp_hip.h) that travels with
 import os
 import subprocess
 import sys
+import time
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -31,12 +32,16 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     def compile_one(job):
         s, o = job
+        t_start = time.time()
         cmd = [hipcc] + FLAGS + ['-c', s, '-o', o]
         if verbose:
             print('[lp build]', ' '.join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f'hipcc failed for {s}:\n{r.stderr}')
+        # the object is as old as the sources hipcc READ: a source or header edited while the (minutes-long) compile ran must make it stale again
+        # (round 6: an object built from pre-edit sources passed the mtime check and was linked beside objects with the new struct layout)
+        os.utime(o, (t_start, t_start))
         return o
 
     with ThreadPoolExecutor(max_workers=4) as ex:

@@ -37,6 +37,7 @@ static inline int ilog2_floor(int v) { int l = 0; while ((1 << (l + 1)) <= v) ++
 __device__ __forceinline__ bool conv16_block(const Conv16Params& p, int& tile, int& cob) {
     if (!p.xcd_map) { tile = (int)blockIdx.x; cob = (int)blockIdx.y; return true; }
     const int id = (int)blockIdx.x, x = id & 7, j = id >> 3;
+    if (p.xcd_map == 2) { tile = id % p.ntiles; cob = id / p.ntiles; return cob < p.nco; }      // (debug: 1-D grid, plain order)
     const int per = (p.ntiles + 7) >> 3;          // tiles per XCD
     cob = j % p.nco;
     const int k = j / p.nco;
@@ -47,7 +48,7 @@ __device__ __forceinline__ bool conv16_block(const Conv16Params& p, int& tile, i
 static inline dim3 conv16_grid(Conv16Params& p, int ntiles, int nco, int gz = 1) {
     static const int on = getenv("LP_CONV_XCD") ? atoi(getenv("LP_CONV_XCD")) : 1;
     p.ntiles = ntiles; p.nco = nco;
-    p.xcd_map = (on && nco > 1 && ntiles >= 16) ? 1 : 0;
+    p.xcd_map = (on && nco > 1 && ntiles >= 16) ? on : 0;
     if (!p.xcd_map) return dim3(ntiles, nco, gz);
     return dim3(((ntiles + 7) / 8) * 8 * nco, 1, gz);
 }

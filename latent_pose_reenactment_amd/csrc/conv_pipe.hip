@@ -475,7 +475,8 @@ static int launch_pipe(Conv16Params& p, hipStream_t stream) {
             return lp_set_error(LP_ERR_HIP, "hipFuncSetAttribute failed");
         attr_dev = dev;
     }
-    hipLaunchKernelGGL(kern, conv16_grid(p, tiles, (p.Cout + BN - 1) / BN), dim3(NWAVE * 64), lds, stream, p);
+    const dim3 grid = conv16_grid(p, tiles, (p.Cout + BN - 1) / BN);          // (sets p.xcd_map / ntiles / nco: BEFORE p is copied into the launch)
+    hipLaunchKernelGGL(kern, grid, dim3(NWAVE * 64), lds, stream, p);
     const int rc = lp_check_launch("conv_pipe");
     return rc ? rc : 1;
 }

@@ -26,6 +26,21 @@ def _unsupported(name, rule, x):
                         '(tests evaluate such geometries through oracle/backbones_ref.py)')
 
 
+def _padded_batch(n, ok):
+    """smallest batch >= n the kernels cover (None: the image size itself is outside the path)"""
+    for m in range(n, n + 9):
+        if ok(m):
+            return m
+    return None
+
+
+def _pad_rows(fn, x, n_pad):
+    """fn on x with zero frames appended up to n_pad rows; -> the first len(x) rows (autograd flows through cat / narrow)"""
+    n = x.shape[0]
+    pad = x.new_zeros((n_pad - n,) + tuple(x.shape[1:]))
+    return fn(torch.cat([x, pad]))[:n]
+
+
 class _BatchNorm2d(nn.BatchNorm2d):
     """nn.BatchNorm2d as a container (same parameters, buffers and state_dict keys): the statistics, the normalisation and the running-
     statistics update happen inside the HIP encoders; ``num_batches_tracked`` of all layers advances by ONE multi-tensor add per forward."""
@@ -83,9 +98,21 @@ class ResNeXt(nn.Module):
 
     def forward(self, x):
         from . import resnext_hip
-        if not (x.is_cuda and x.dim() == 4 and x.shape[1] == 3 and resnext_hip.supported(x.shape[0], x.shape[2], x.shape[3])):
-            raise _unsupported('ResNeXt', 'resnext_hip.supported: N x 3 x H x W on the GPU, 32 | H, W >= 128, N >= 8, 4 | N', x)
-        return self._forward_hip(x)
+        if not (x.is_cuda and x.dim() == 4 and x.shape[1] == 3):
+            raise _unsupported('ResNeXt', 'N x 3 x H x W on the GPU', x)
+        n, h, w = x.shape[0], x.shape[2], x.shape[3]
+        if resnext_hip.supported(n, h, w):
+            return self._forward_hip(x)
+        # ANY batch in eval mode: the reference's fine-tuning bootstrap (train.py:241-256: training_module.eval(), no_grad,
+        # b*k frames per dataloader batch) and few-shot runs hand over 1 .. 7 frames or a count that is no multiple of 4.  With running
+        # statistics every frame is normalised on its own, so the batch is zero-padded to the next count the kernels cover and the extra
+        # rows are dropped: EXACT (the pad frames touch no statistic and no other frame's output).  Train-mode BatchNorm couples the frames
+        # of a batch -- padding would change the statistics -- so that case still raises.
+        n_pad = _padded_batch(n, lambda m: resnext_hip.supported(m, h, w))
+        if n_pad is None or self.training:
+            raise _unsupported('ResNeXt', 'resnext_hip.supported: 32 | H, W >= 128; train-mode BatchNorm also needs N >= 8, 4 | N '
+                               '(eval mode pads the batch)', x)
+        return _pad_rows(self._forward_hip, x, n_pad)
 
     # ---- HIP path (forward and backward): embedders/resnext_hip.py -----------------------------------------------------------------
     @property
@@ -257,13 +284,25 @@ class MobileNetV2(nn.Module):
     def forward(self, x):
         if not (x.is_cuda and x.dim() == 4 and x.shape[1] == 3):
             raise _unsupported('MobileNetV2', 'N x 3 x H x W on the GPU', x)
+        train_bn = self.features[0][1].training
         if not torch.is_grad_enabled():
-            if x.shape[2] % 2 or x.shape[3] % 2 or x.shape[0] > 64:
-                raise _unsupported('MobileNetV2 (no-grad forward)', 'even H, W and N <= 64', x)
+            if x.shape[2] % 2 or x.shape[3] % 2:
+                raise _unsupported('MobileNetV2 (no-grad forward)', 'even H, W', x)
+            if x.shape[0] > 64:
+                #  the fused forward takes <= 64 frames per launch sequence: larger eval batches run as chunks (exact: running
+                # statistics); train-mode batch statistics would differ per chunk, so that case raises
+                if train_bn:
+                    raise _unsupported('MobileNetV2 (no-grad forward, train-mode BatchNorm)', 'N <= 64', x)
+                return torch.cat([self._forward_hip(x[i:i + 64]) for i in range(0, x.shape[0], 64)])
             return self._forward_hip(x)                      # fused fp32 forward (fine-tuning step, drive.py)
         from . import mobilenet_hip
-        if not mobilenet_hip.supported(x.shape[0], x.shape[2], x.shape[3]):
-            raise _unsupported('MobileNetV2 (autograd on)', 'mobilenet_hip.supported: 32 | H, W; N * H/32 * W/32 >= 8 and a multiple of 4', x)
+        n, h, w = x.shape[0], x.shape[2], x.shape[3]
+        if not mobilenet_hip.supported(n, h, w):
+            n_pad = _padded_batch(n, lambda m: mobilenet_hip.supported(m, h, w))
+            if n_pad is None or train_bn:
+                raise _unsupported('MobileNetV2 (autograd on)', 'mobilenet_hip.supported: 32 | H, W; train-mode BatchNorm also needs '
+                                   'N * H/32 * W/32 >= 8 and a multiple of 4 (eval mode pads the batch)', x)
+            return _pad_rows(self._forward_hip_train, x, n_pad)          # (eval-mode BatchNorm: zero frames appended, their rows dropped -- exact)
         return self._forward_hip_train(x)                    # autograd on (meta-training): forward + backward on the HIP kernels
 
     # ---- HIP training path (forward + backward): embedders/mobilenet_hip.py --------------------------------------------------------

@@ -23,7 +23,9 @@ PROFILE = None
 
 class _Timed:
     def __init__(self, kind, flops, tag=None, nbytes=0.0):
-        self.kind, self.flops, self.tag, self.nbytes = kind, flops, tag, nbytes
+        """``nbytes``: algorithmic HBM bytes of the launch -- a total, or (read, write)"""
+        self.rw = tuple(nbytes) if isinstance(nbytes, tuple) else None
+        self.kind, self.flops, self.tag, self.nbytes = kind, flops, tag, (sum(nbytes) if isinstance(nbytes, tuple) else nbytes)
 
     def __enter__(self):
         if PROFILE is not None:
@@ -35,7 +37,7 @@ class _Timed:
     def __exit__(self, *exc):
         if PROFILE is not None:
             self.e1.record()
-            PROFILE.append((self.kind, self.flops, self.e0, self.e1, self.tag, self.nbytes))
+            PROFILE.append((self.kind, self.flops, self.e0, self.e1, self.tag, self.nbytes, self.rw))
 
 
 def _p(t: Optional[Tensor]):
@@ -279,8 +281,8 @@ def conv16(a: Act16, pack: WeightPack, *, ksize: int, upsample: bool = False, bi
         st_buf = torch.empty(st_cap, dtype=torch.float32, device=dev)
         st_rows = ctypes.c_int(0)
     pl = 4 if prec == PREC_BF16X3 else 2              # bytes per operand-plane element
-    nbytes = n * hin * win * a.hi.shape[3] * pl + pack.hi.numel() * pl + n * h * w * cout * ((4 if want_y else 0) + (pl if out16 is not None else 0)) \
-        + (n * (h >> res_shift) * (w >> res_shift) * cout * 4 if res is not None else 0)
+    nbytes = (n * hin * win * a.hi.shape[3] * pl + pack.hi.numel() * pl + (n * (h >> res_shift) * (w >> res_shift) * cout * 4 if res is not None else 0),
+              n * h * w * cout * ((4 if want_y else 0) + (pl if out16 is not None else 0)))          # (read: planes once + weights + residual, write)
     with _Timed(kind, 2.0 * n * h * w * cout * cin * ksize * ksize, (n, h, w, cin, cout, ksize, int(upsample), 0), nbytes):
         check(_lib.lib().lp_conv16_fwd_stats(a.hi.data_ptr(), _p(a.lo), pack.hi.data_ptr(), _p(pack.lo), _p(y), _p(bias), _p(res),
                                              _p(alpha), _p(a.inv), n, h, w, cin, cout, pack.cols_p, pack.rows_p, ksize, int(upsample),

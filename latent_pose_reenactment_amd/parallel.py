@@ -55,6 +55,28 @@ class _Bucket:
         self.optimizer = optimizer if hasattr(optimizer, 'ensure_flat') else None
         self.arena = None
         self.divide = False
+        self.diag = None          # GradReducer.enable_diag(): list of per-collective records (bytes, issue / wait events)
+        self.name = ''
+
+    def _diag_issue(self, parts, tag=None):
+        if self.diag is None or not parts or not parts[0].is_cuda:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        rec = {'bucket': tag or self.name, 'bytes': int(sum(t.numel() * t.element_size() for t in parts)), 'issue': ev}
+        self.diag.append(rec)
+        return rec
+
+    def _diag_wait(self, begin):
+        """brackets the wait of ``finish``: the span between the two events is the time the COMPUTE stream stood still for the exchange"""
+        if self.diag is None or not torch.cuda.is_available():
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        for rec in self.diag:
+            if rec['bucket'].split(':')[0] == self.name and ('done' if not begin else 'wait') not in rec:
+                rec['wait' if begin else 'done'] = ev
+        return ev
 
     def arena_slice_of(self, param):
         """(offset, numel) of ``param``'s gradient inside the optimizer's flat arena, or None"""
@@ -89,6 +111,7 @@ class _Bucket:
                 parts = [arena]
             parts = [t for t in parts if t.numel()]
             self.parts += parts
+            self._diag_issue(parts, None if only is None else f'{self.name}:{only[0]}+{only[1]}')
             self.handle += [dist.all_reduce(t, op=op, async_op=async_op) for t in parts]
             if not async_op:
                 self.finish(world_size)
@@ -101,15 +124,18 @@ class _Bucket:
         if self.flat is None or self.flat.numel() != n or self.flat.device != self.live[0].grad.device:
             self.flat = torch.empty(n, dtype=torch.float32, device=self.live[0].grad.device)
         torch.cat([p.grad.reshape(-1) for p in self.live], out=self.flat)      # one gather kernel instead of one copy per tensor
+        self._diag_issue([self.flat])
         self.handle = dist.all_reduce(self.flat, op=op, async_op=async_op)
         if not async_op:
             self.finish(world_size)
 
     def finish(self, world_size: int):
         if self.arena is not None:
+            self._diag_wait(True)
             for h in (self.handle or []):
                 if h is not None and hasattr(h, 'wait'):
                     h.wait()          # (RCCL: the current stream waits for the collective's stream; the host does not block)
+            self._diag_wait(False)
             self.handle = None
             if self.divide:
                 for t in self.parts:
@@ -119,7 +145,9 @@ class _Bucket:
         if not self.live:
             return
         if self.handle is not None:
+            self._diag_wait(True)
             self.handle.wait()
+            self._diag_wait(False)
             self.handle = None
         if self.divide:
             self.flat.div_(world_size)
@@ -141,12 +169,16 @@ class GradReducer:
         gen = [p for p in training_module.generator.parameters()]
         emb = [] if finetune else [p for p in training_module.embedder.parameters()]
         self.g_bucket = _Bucket(gen + emb, optimizer_G)
+        self.g_bucket.name = 'G-side arena (generator | encoders)'
+        self._arena_layout_checked = False
         # the generator-side arena is [generator | embedder] (runners/holycow.get_optimizer): two buckets of ONE buffer
         self.g_parts = {'generator': _Bucket(gen), 'embedder': _Bucket(emb)}           # (plain-parameter path: one flat buffer each)
         self.n_gen = sum(p.numel() for p in gen if p.requires_grad)
         self.n_emb = sum(p.numel() for p in emb if p.requires_grad)
         self._g_split_live = []
+        self.g_parts['generator'].name, self.g_parts['embedder'].name = 'generator', 'encoders'
         self.d_bucket = _Bucket(training_module.discriminator.parameters(), optimizer_D)
+        self.d_bucket.name = 'D-side arena (critic without the label embedding)'
         self.discriminator = training_module.discriminator
         self.max_batch = max_batch
         self.use_sparse = None          # agreed on by all ranks at the first discriminator-side exchange
@@ -171,10 +203,7 @@ class GradReducer:
             return
         assert part in ('generator', 'embedder'), part
         if self.g_bucket.optimizer is not None and len(self.g_bucket.optimizer.param_groups) == 1:
-            # the arena's layout must be the one get_optimizer gives it: generator parameters first
-            first = next((p for p in self.g_bucket.optimizer.param_groups[0]['params'] if p.requires_grad), None)
-            assert first is None or self.n_gen == 0 or any(first is q for q in self.g_parts['generator'].params), 'optimizer_G must list the generator first'
-            only = (0, self.n_gen) if part == 'generator' else (self.n_gen, self.n_emb)
+            only = self._g_arena_slices()[part]
             if only[1]:
                 self.g_bucket.start(self.world_size, async_op, only=only)
             return
@@ -182,6 +211,73 @@ class GradReducer:
         b.start(self.world_size, async_op)
         if async_op:
             self._g_split_live.append(b)
+
+    def _g_arena_slices(self):
+        """(offset, numel) of the generator's and of the encoders' gradients inside optimizer_G's flat arena, DERIVED from the optimizer's own
+        parameter list: each must be one contiguous run, the two must tile the arena -- a shared / tied parameter, another
+        get_optimizer ordering or an extra parameter would otherwise leave part of the arena un-averaged without any error"""
+        cached = self.__dict__.get('_g_slices')
+        if cached is not None:
+            return cached
+        gen_ids = {id(p) for p in self.g_parts['generator'].params}
+        emb_ids = {id(p) for p in self.g_parts['embedder'].params}
+        runs, off = [], 0
+        for p in self.g_bucket.optimizer.param_groups[0]['params']:
+            if not p.requires_grad:
+                continue
+            owner = 'generator' if id(p) in gen_ids else 'embedder' if id(p) in emb_ids else None
+            if owner is None:
+                raise RuntimeError('GradReducer: optimizer_G holds a parameter that belongs to neither the generator nor the embedder')
+            if runs and runs[-1][0] == owner:
+                runs[-1][2] += p.numel()
+            else:
+                runs.append([owner, off, p.numel()])
+            off += p.numel()
+        owners = [r[0] for r in runs]
+        if len(owners) != len(set(owners)):
+            raise RuntimeError(f'GradReducer: generator and encoder parameters interleave in optimizer_G ({owners}); the two-bucket exchange needs one contiguous run each')
+        out = {'generator': (0, 0), 'embedder': (0, 0)}
+        for owner, o, n in runs:
+            out[owner] = (o, n)
+        if out['generator'][1] != self.n_gen or out['embedder'][1] != self.n_emb or self.n_gen + self.n_emb != off:
+            raise RuntimeError(f'GradReducer: optimizer_G covers {off} gradient elements in runs {runs}, expected generator {self.n_gen} + encoders {self.n_emb}')
+        self.__dict__['_g_slices'] = out
+        return out
+
+    # ---- diagnosis of the exchange (bench.py --gpus N prints it: the first run on real xGMI then yields a diagnosis, not just a number) --------
+    def enable_diag(self):
+        """record, per collective issued from now on: bytes, an event at its issue and the events around the wait of its consumer"""
+        self.diag = []
+        for b in [self.g_bucket, self.d_bucket] + list(self.g_parts.values()):
+            b.diag = self.diag
+
+    def diag_summary(self, steps: int):
+        """-> per bucket: bytes per step, mean issue -> consumer-wait span and the EXPOSED time (what the compute stream actually stood still
+        in ``finish``), plus ``exposed_comm_ms`` per step.  Call after a device synchronize."""
+        if not getattr(self, 'diag', None):
+            return None
+        agg = {}
+        for rec in self.diag:
+            if 'wait' not in rec or 'done' not in rec:
+                continue
+            a = agg.setdefault(rec['bucket'], {'bytes': 0, 'n': 0, 'issue_to_wait_ms': 0.0, 'exposed_ms': 0.0})
+            a['bytes'] += rec['bytes']; a['n'] += 1
+            a['issue_to_wait_ms'] += rec['issue'].elapsed_time(rec['wait'])
+            a['exposed_ms'] += rec['wait'].elapsed_time(rec['done'])
+        out = {'buckets': {k: {'all_reduce_bytes_per_step': v['bytes'] // max(steps, 1), 'collectives_per_step': v['n'] / max(steps, 1),
+                               'issue_to_consumer_wait_ms': round(v['issue_to_wait_ms'] / max(v['n'], 1), 3),
+                               'exposed_wait_ms': round(v['exposed_ms'] / max(v['n'], 1), 3)} for k, v in agg.items()}}
+        # the wait events of the slices of one arena coincide (one ``finish``): count each arena's wait once per step
+        seen, total = set(), 0.0
+        for rec in self.diag:
+            if 'wait' in rec and 'done' in rec and id(rec['wait']) not in seen:
+                seen.add(id(rec['wait']))
+                total += rec['wait'].elapsed_time(rec['done'])
+        out['exposed_comm_ms_per_step'] = round(total / max(steps, 1), 3)
+        out['note'] = ('issue_to_consumer_wait: time the collective had to complete behind other work before its optimizer step asked for it; exposed_wait: '
+                       'how long the compute stream then still stood in the wait (0 = fully hidden); the label-embedding rows go through two small '
+                       'padded all-reduces that are not listed')
+        return out
 
     def wait_generator_side(self):
         self.g_bucket.finish(self.world_size)

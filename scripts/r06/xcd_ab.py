@@ -1,0 +1,59 @@
+"""A/B of the XCD-ordered conv grids (LP_CONV_XCD=0|1, read once per process): the mapping is a bijection of workgroup ids, so every output must be
+BIT-IDENTICAL.  usage: LP_CONV_XCD=0 python scripts/r06/xcd_ab.py save /tmp/a.pt ; LP_CONV_XCD=1 python scripts/r06/xcd_ab.py cmp /tmp/a.pt"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from latent_pose_reenactment_amd import hipops as ops  # noqa: E402
+
+SHAPES = [  # N, H, W, Cin, Cout, ups
+    (2, 32, 32, 256, 512, 0), (2, 32, 32, 512, 512, 0), (2, 64, 64, 128, 256, 0), (2, 16, 16, 512, 512, 0), (2, 8, 8, 512, 512, 0),
+    (8, 64, 64, 256, 256, 0), (8, 128, 128, 128, 128, 0), (8, 256, 256, 64, 64, 0), (8, 32, 32, 512, 512, 0), (8, 16, 16, 512, 512, 0),
+    (8, 64, 64, 512, 256, 1), (8, 32, 32, 512, 512, 1), (8, 8, 8, 512, 512, 1), (8, 4, 4, 512, 512, 0), (1, 64, 48, 96, 256, 0), (3, 40, 24, 64, 384, 0),
+]
+mode, path = sys.argv[1], sys.argv[2]
+out = {}
+for prec in (2, 1):
+    for (n, h, w, cin, cout, ups) in SHAPES:
+        g = torch.Generator().manual_seed(n + h + cin + cout + prec)
+        hin, win = (h // 2, w // 2) if ups else (h, w)
+        x = torch.randn(n, hin, win, cin, generator=g).cuda()
+        wt = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).cuda()
+        a = ops.act_pack(x, pro=2, prec=prec)
+        pack = ops.pack_weights(wt, 0, prec)
+        res = torch.randn(n, h, w, cout, generator=g).cuda()
+        print('[xcd-ab] running', prec, n, h, w, cin, cout, ups, flush=True)
+        y = ops.conv16(a, pack, ksize=3, upsample=bool(ups), res=res, prec=prec, stats=True)
+        y = y if isinstance(y, tuple) else (y,)
+        torch.cuda.synchronize()
+        out[(prec, n, h, w, cin, cout, ups)] = y[0].cpu()
+        # reference: fp64 conv of the decoded planes (coarse check that either mapping computes the conv at all)
+        if mode == 'cmp':
+            import torch.nn.functional as F
+            dt = torch.float16 if prec == 2 else torch.bfloat16
+            xs = a.hi.view(dt).double()[..., :cin]
+            if prec == 1:
+                xs = xs + a.lo.view(torch.bfloat16).double()[..., :cin]
+            xs = xs.permute(0, 3, 1, 2)
+            if ups:
+                xs = F.interpolate(xs, scale_factor=2, mode='nearest')
+            ref = F.conv2d(xs, wt.double(), None, 1, 1).permute(0, 2, 3, 1) + res.double()
+            e = ((y[0].double() - ref).norm() / ref.norm()).item()
+            out[(prec, n, h, w, cin, cout, ups, 'err')] = e
+if mode == 'save':
+    torch.save(out, path)
+else:
+    old = torch.load(path)
+    bad = 0
+    for k, v in out.items():
+        if k[-1] == 'err':
+            continue
+        same = torch.equal(v, old[k])
+        e = out[k + ('err',)]
+        if not same or e > 2e-3:
+            bad += 1
+        print(f'[xcd-ab] {k}: bit-identical {same}; vs fp64 conv of the planes {e:.2e}' + ('' if same else f'  max|diff| {(v - old[k]).abs().max().item():.3e}'))
+    print(f'[xcd-ab] {bad} mismatching cases of {len(old)}')

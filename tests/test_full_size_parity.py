@@ -231,7 +231,7 @@ def test_discriminator_256_three_passes_vs_oracle(prec_name, tol_out, tol_grad, 
         oG = torch.autograd.grad(olg, [f] + [st[k] for k in params], retain_graph=True, allow_unused=True)
         oD = torch.autograd.grad(old, [st[k] for k in params], allow_unused=True)
         return out, olg, old, oG, oD
-    out, olg, old, _, _ = oracle(None)
+    out, olg, old, oG_true, oD_true = oracle(None)
     _, _, _, oG, oD = oracle(masks)
     errs = {'loss_G': rel(lg, olg), 'loss_D': rel(ld, old)}
     for k in ('fake_score_G', 'fake_score_D', 'real_score'):
@@ -245,13 +245,23 @@ def test_discriminator_256_three_passes_vs_oracle(prec_name, tol_out, tol_grad, 
     for (k, _), a, b in zip(params.items(), gD, oD):
         if a is not None and b is not None and b.abs().max() > 0:
             gerr['D.' + k] = rel(a, b)
+    # the untied figures (against the true-ReLU oracle), printed beside the tie-masked ones
+    untied = {}
+    for (k, _), a, b in zip(params.items(), gG[1:], oG_true[1:]):
+        if a is not None and b is not None and b.abs().max() > 0:
+            untied['G.' + k] = rel(a, b)
+    for (k, _), a, b in zip(params.items(), gD, oD_true):
+        if a is not None and b is not None and b.abs().max() > 0:
+            untied['D.' + k] = rel(a, b)
     worst = sorted(gerr.items(), key=lambda kv: -kv[1])[:4]
     print(f'[parity-256] critic {prec_name}: forward worst {max(errs.values()):.2e} ({max(errs, key=errs.get)}); tie-masked grads worst '
-          f'{[(k, round(v, 6)) for k, v in worst]} over {len(gerr)} tensors')
+          f'{[(k, round(v, 6)) for k, v in worst]} over {len(gerr)} tensors; untied worst {max(untied.values()):.3e}')
     export(prec_name, 'discriminator', {'forward_worst': [max(errs, key=errs.get), max(errs.values())],
                                         'tie_masked_worst_G_loss': max(((k, v) for k, v in gerr.items() if k.startswith('G.')), key=lambda kv: kv[1]),
                                         'tie_masked_worst_D_loss': max(((k, v) for k, v in gerr.items() if k.startswith('D.')), key=lambda kv: kv[1]),
-                                        'tie_masked_all': gerr, 'forward_all': errs,
+                                        'tie_masked_all': gerr, 'forward_all': errs, 'untied_worst': max(untied.values()),
+                                        'untied_worst_G_loss': max(v for k, v in untied.items() if k.startswith('G.')),
+                                        'untied_worst_D_loss': max(v for k, v in untied.items() if k.startswith('D.')),
                                         'gate_G_loss': tol_grad, 'gate_D_loss': 3 * tol_grad})
     assert all(v < tol_out for v in errs.values()), errs
     # D-loss weight gradients of the last blocks are DIFFERENCES of nearly equal fake / real terms (hinge: -1/2 on the real, +1/2 on the

@@ -57,7 +57,7 @@ def test_unknown_padding_raises_like_the_reference():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('padding,fixture', PADDINGS)
-@pytest.mark.parametrize('prec,tol', [(1, 1e-4), (0, 0.35)])
+@pytest.mark.parametrize('prec,tol', [(1, 1e-4), (2, 0.1), (0, 0.35)])
 def test_generator_train_forward_backward_vs_reference_golden(prec, tol, padding, fixture):
     z = load(fixture)
     G = make_gen(z, prec=prec, padding=padding)
@@ -83,11 +83,13 @@ def test_generator_train_forward_backward_vs_reference_golden(prec, tol, padding
     print(f'[parity] generator(train) prec={prec} padding={padding}: worst rel-L2 {worst}')
     # bf16 operands (prec=0): forward within 1e-2; gradients of this 4-channel toy net are dominated by ReLU sign flips of
     # near-zero pre-activations (|y| < bf16 rounding), so they only get a sanity bound.  bf16x3 (prec=1): everything 1e-4.
+    # f16 (prec=2, round 6: the mode the bench's VGG / encoder-tail / fake -> G legs run): forward 1e-3, gradients UNTIED against the reference's
+    # own values (the tie-masked 256 x 256 figures are tests/test_full_size_parity.py's).
     def bound(k):
         if k.startswith('buf.'):
             return 1e-5
         if k.startswith('fake_'):
-            return 1e-4 if prec == 1 else 1e-2
+            return 1e-4 if prec == 1 else 1e-3 if prec == 2 else 1e-2
         return tol
     bad = {k: v for k, v in errs.items() if v >= bound(k)}
     assert not bad, bad

@@ -449,3 +449,38 @@ def test_embedder_plugin_uses_hip_identity_encoder(monkeypatch):
     d['embeds'].sum().backward()
     assert E.identity_encoder.__dict__.get('_hip_param_names') is not None
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in E.identity_encoder.parameters())
+
+
+@pytest.mark.parametrize('n', [1, 3, 6, 13])
+def test_eval_mode_takes_any_batch(monkeypatch, n):
+    """ the reference's fine-tuning bootstrap (train.py:241-256: eval(), no_grad, b*k frames per batch) and few-shot runs hand the
+    identity encoder 1 .. 7 frames or a count that is no multiple of 4; with running statistics the batch is zero-padded to the next count the
+    kernels cover and the pad rows are dropped -- every frame's logits against the stock layers in fp64, with and without autograd.  The pose
+    encoder likewise (autograd on: padded; no-grad: chunks of 64).  Train-mode BatchNorm keeps raising (the frames of a batch are coupled)."""
+    from oracle import backbones_ref as BR
+    monkeypatch.setenv('LP_PREC_E', 'bf16x3')
+    m, ref = _nets(32, 7, (2, 1, 1, 1))
+    m.eval(); ref.eval()
+    x = structured_frames(n, 128, 3).cuda()
+    with torch.no_grad():
+        y0 = m(x)
+    y = m(x)                      # autograd on (parameter gradients; the encoder does not differentiate w.r.t. its frames)
+    assert y.shape == (n, 32) and torch.equal(y.detach(), y0)
+    r = torch.randn(n, 32, device='cuda')
+    (y * r).sum().backward()
+    yr = BR.resnext_forward(ref, x.double())
+    (yr * r.double()).sum().backward()
+    e_out, e_g = rel(y, yr), _grad_err(list(m.parameters()), list(ref.parameters()))
+    print(f'[parity] eval-mode identity encoder, {n} frames (padded to a covered batch): logits {e_out:.2e}, all-gradients {e_g:.2e}')
+    assert e_out < 2e-5 and e_g < 1e-3, (e_out, e_g)
+    m.train()
+    with pytest.raises(RuntimeError, match='outside the HIP path'):
+        m(x)
+    from embedders import backbones
+    torch.manual_seed(3)
+    pe = backbones.mobilenet_v2(8).cuda().eval()
+    pr = copy.deepcopy(pe).double()
+    xp = structured_frames(n, 64, 5).cuda()
+    yp = pe(xp)
+    ypr = BR.mobilenet_forward(pr, xp.double())
+    assert yp.shape == (n, 8) and rel(yp, ypr) < 1e-4, rel(yp, ypr)
