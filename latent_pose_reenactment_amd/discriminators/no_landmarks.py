@@ -54,7 +54,7 @@ def dpass_prec():
     return lpnn.PREC_NAMES[name], int(_os.environ.get('LP_D_DPASS_FROM', str(DPASS_DEFAULT[1])))
 
 
-DPASS_DEFAULT = ('f16', 0)
+DPASS_DEFAULT = ('bf16x3', 3)
 
 
 class Wrapper:

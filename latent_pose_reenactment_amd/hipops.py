@@ -22,8 +22,9 @@ PROFILE = None
 
 
 class _Timed:
-    def __init__(self, kind, flops, tag=None, nbytes=0.0):
-        """``nbytes``: algorithmic HBM bytes of the launch -- a total, or (read, write)"""
+    def __init__(self, kind, flops, tag=None, nbytes=0.0, mm=1):
+        """``nbytes``: algorithmic HBM bytes of the launch -- a total, or (read, write); ``mm``: MFMAs per algorithmic MAC (bf16x3: 3)"""
+        self.mm = mm
         self.rw = tuple(nbytes) if isinstance(nbytes, tuple) else None
         self.kind, self.flops, self.tag, self.nbytes = kind, flops, tag, (sum(nbytes) if isinstance(nbytes, tuple) else nbytes)
 
@@ -37,7 +38,7 @@ class _Timed:
     def __exit__(self, *exc):
         if PROFILE is not None:
             self.e1.record()
-            PROFILE.append((self.kind, self.flops, self.e0, self.e1, self.tag, self.nbytes, self.rw))
+            PROFILE.append((self.kind, self.flops, self.e0, self.e1, self.tag, self.nbytes, self.rw, self.mm))
 
 
 def _p(t: Optional[Tensor]):
@@ -283,7 +284,7 @@ def conv16(a: Act16, pack: WeightPack, *, ksize: int, upsample: bool = False, bi
     pl = 4 if prec == PREC_BF16X3 else 2              # bytes per operand-plane element
     nbytes = (n * hin * win * a.hi.shape[3] * pl + pack.hi.numel() * pl + (n * (h >> res_shift) * (w >> res_shift) * cout * 4 if res is not None else 0),
               n * h * w * cout * ((4 if want_y else 0) + (pl if out16 is not None else 0)))          # (read: planes once + weights + residual, write)
-    with _Timed(kind, 2.0 * n * h * w * cout * cin * ksize * ksize, (n, h, w, cin, cout, ksize, int(upsample), 0), nbytes):
+    with _Timed(kind, 2.0 * n * h * w * cout * cin * ksize * ksize, (n, h, w, cin, cout, ksize, int(upsample), 0), nbytes, mm=3 if prec == PREC_BF16X3 else 1):
         check(_lib.lib().lp_conv16_fwd_stats(a.hi.data_ptr(), _p(a.lo), pack.hi.data_ptr(), _p(pack.lo), _p(y), _p(bias), _p(res),
                                              _p(alpha), _p(a.inv), n, h, w, cin, cout, pack.cols_p, pack.rows_p, ksize, int(upsample),
                                              res_shift, prec, None if relu_mask is None else relu_mask.hi.data_ptr(), _p(o_hi), _p(o_lo),
@@ -394,7 +395,7 @@ def conv_wgrad16(a: Act16, dy: Act16, *, ksize: int, upsample: bool = False, pre
         dot = torch.empty(ndot, dtype=torch.float32, device=dev)
     pl = 4 if prec == PREC_BF16X3 else 2
     nbytes = (a.hi.numel() + dy.hi.numel()) * pl + cout * cin * ksize * ksize * 4
-    with _Timed(kind, 2.0 * n * h * w * cout * cin * ksize * ksize, (n, h, w, cin, cout, ksize, int(upsample), 0), nbytes):
+    with _Timed(kind, 2.0 * n * h * w * cout * cin * ksize * ksize, (n, h, w, cin, cout, ksize, int(upsample), 0), nbytes, mm=3 if prec == PREC_BF16X3 else 1):
         check(_lib.lib().lp_conv16_wgrad(a.hi.data_ptr(), _p(a.lo), dy.hi.data_ptr(), _p(dy.lo), dw.data_ptr(), ws.data_ptr(), n, h, w, cin,
                                          cout, ksize, int(upsample), splits, prec, _p(db), int(bias_grad and bias_accum is not None), _p(dy.inv),
                                          None if sn is None else sn[0].data_ptr(), _p(dot), _stream()), 'lp_conv16_wgrad')
@@ -990,7 +991,7 @@ def gconv16(a: Act16, pack: WeightPack, *, prec: int, amax: bool = False, stats:
         st_rows = ctypes.c_int(0)
     pl = 4 if prec == PREC_BF16X3 else 2
     nbytes = n * h * w * c * (pl + (4 if want_y else 0) + (pl if out16 else 0)) + pack.hi.numel() * pl
-    with _Timed('gconv', 2.0 * n * h * w * c * pack.cols * 9, (n, h, w, pack.cols, c, 3, 0, 0), nbytes):
+    with _Timed('gconv', 2.0 * n * h * w * c * pack.cols * 9, (n, h, w, pack.cols, c, 3, 0, 0), nbytes, mm=3 if prec == PREC_BF16X3 else 1):
         check(_lib.lib().lp_gconv16_fwd_planes(a.hi.data_ptr(), _p(a.lo), pack.hi.data_ptr(), _p(pack.lo), _p(y), _p(o_hi), _p(o_lo), _p(a.inv),
                                                n, h, w, c, pack.rows_p, pack.cols, prec, _p(slots), _p(st_buf), st_cap,
                                                None if st_rows is None else ctypes.addressof(st_rows), _stream()), 'lp_gconv16_fwd')
@@ -1081,7 +1082,7 @@ def gconv_wgrad16(a: Act16, dy: Act16, group_size: int, *, prec: int, splits: Op
     ws = torch.empty(_lib.lib().lp_gconv_wgrad_workspace_bytes(c, splits) // 4, dtype=torch.float32, device=dy.hi.device)
     dw = torch.empty((c, group_size, 3, 3), dtype=torch.float32, device=dy.hi.device)
     pl = 4 if prec == PREC_BF16X3 else 2
-    with _Timed('gconv_wgrad', 2.0 * n * h * w * c * group_size * 9, (n, h, w, group_size, c, 3, 0, 0), 2 * n * h * w * c * pl):
+    with _Timed('gconv_wgrad', 2.0 * n * h * w * c * group_size * 9, (n, h, w, group_size, c, 3, 0, 0), 2 * n * h * w * c * pl, mm=3 if prec == PREC_BF16X3 else 1):
         check(_lib.lib().lp_gconv16_wgrad(a.hi.data_ptr(), _p(a.lo), dy.hi.data_ptr(), _p(dy.lo), dw.data_ptr(), ws.data_ptr(), n, h, w, c,
                                           group_size, splits, prec, _p(dy.inv), _stream()), 'lp_gconv16_wgrad')
     return dw

@@ -46,7 +46,8 @@ def generator_prec() -> int:
     return PREC_NAMES[GENERATOR_DEFAULT] if default_prec() == PREC_F16 else default_prec()
 
 
-GENERATOR_DEFAULT = 'f16'
+GENERATOR_DEFAULT = 'bf16x3'      # round 6: the 17-layer AdaIN decoder with fp16 operands (11 bits) sits at 1.0 - 1.7e-3 on 26 of its 27 gradient tensors and at
+                                  # ~6e-4 on its own pre-tanh activations -- SURVEY 8d gates every parameter gradient at 1e-3 (profiles/r05_parity_gradients_f16.json)
 
 
 # ----------------------------------------------------------------------------------------------------------------------

@@ -28,8 +28,14 @@ def rel(a, c):
 
 # (mode, gates: embeds, per-frame logits, all-gradient rel-L2, all-gradient cosine, worst per-stage cosine).  Measured in round 4
 # (profiles/r04_e1_parity.txt): default 2.1e-4 / 6.0e-4 / ~0.12 (cosine ~0.99); bf16x3 1.1e-4 / 3.2e-4 / 0.098 (0.995); stock fp32: 6e-6 / 2e-5 / 0.023
-@pytest.mark.parametrize('mode,gates', [('default', (5e-4, 1.5e-3, 0.2, 0.985, 0.95)), ('bf16x3', (3e-4, 8e-4, 0.16, 0.99, 0.95))])
-def test_identity_encoder_full_geometry_forward_and_gradients(monkeypatch, mode, gates):
+# bn = 'eval' (round 6): the WELL-CONDITIONED full-depth check.  The running statistics are first calibrated to this very batch
+# (one train-mode forward of the fp64 stock layers with momentum 1), then all three nets run in eval mode: the same 53 convolutions, BatchNorms,
+# ReLUs and the same activation scale as the training forward, but every BatchNorm is a constant per-channel affine map -- no batch coupling, no
+# chaos -- so an arithmetic error in ANY layer shows up undiminished and the gradient gate can be tight: all-parameter rel-L2 <= 1e-2
+# (gates: embeds, logits, all-gradient rel-L2, cosine, worst per-stage cosine).
+@pytest.mark.parametrize('mode,bn,gates', [('default', 'train', (5e-4, 1.5e-3, 0.2, 0.985, 0.95)), ('bf16x3', 'train', (3e-4, 8e-4, 0.16, 0.99, 0.95)),
+                                          ('default', 'eval', (5e-4, 1e-3, 1e-2, 0.9999, 0.9999)), ('bf16x3', 'eval', (1e-4, 1e-4, 2e-3, 0.99999, 0.99999))])
+def test_identity_encoder_full_geometry_forward_and_gradients(monkeypatch, mode, bn, gates):
     for k in ('LP_PREC', 'LP_PREC_E', 'LP_E_F16_TAIL', 'LP_E_HEAD_F16'):
         monkeypatch.delenv(k, raising=False)
     if mode != 'default':
@@ -40,9 +46,17 @@ def test_identity_encoder_full_geometry_forward_and_gradients(monkeypatch, mode,
     torch.manual_seed(123)
     net = backbones.resnext50_32x4d(num_classes=512).cuda().train()
     ref = copy.deepcopy(net).double()
-    m32 = copy.deepcopy(net)
     b, k, size = 8, 8, 256
     x = torch.stack([make_sample(i, size, k, 98000, False, 123)[0]['enc_rgbs'] for i in range(b)]).cuda().reshape(b * k, 3, size, size)
+    if bn == 'eval':
+        for mod in ref.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.momentum = 1.0                      # running statistics := the statistics of this batch
+        with torch.no_grad():
+            BR.resnext_forward(ref, x.double())
+        net.load_state_dict({k_: v.float() if v.dtype.is_floating_point else v for k_, v in ref.state_dict().items()})
+        net.eval(); ref.eval()
+    m32 = copy.deepcopy(net)
     r = torch.randn(b, 512, device='cuda')
     y = net(x)
     assert net.__dict__.get('_hip_param_names') is not None, 'the HIP path did not run'
@@ -70,12 +84,12 @@ def test_identity_encoder_full_geometry_forward_and_gradients(monkeypatch, mode,
         stages[st] = {'cosine': gcos([g[i] for i in idx], [gr[i] for i in idx]), 'rel': grel([g[i] for i in idx], [gr[i] for i in idx]),
                       'stock_fp32_rel': grel([g32[i] for i in idx], [gr[i] for i in idx])}
     modes = [{0: 'bf16', 1: 'bf16x3', 2: 'f16'}[m] for m in net.block_precs()]
-    res = {'geometry': '64 frames (8 samples x 8) of 256 x 256, train-mode BatchNorm, U[0,1) frames', 'blocks': modes,
+    res = {'geometry': f'64 frames (8 samples x 8) of 256 x 256, {bn}-mode BatchNorm' + (' (running statistics calibrated to the batch)' if bn == 'eval' else '') + ', U[0,1) frames', 'blocks': modes,
            'embeds': rel(emb, embr), 'per_frame_logits': rel(y, yr), 'all_gradients_rel': grel(g, gr), 'all_gradients_cosine': gcos(g, gr),
            'per_stage': stages,
            'stock_fp32_layers_vs_fp64': {'embeds': rel(e32, embr), 'per_frame_logits': rel(y32, yr), 'all_gradients_rel': grel(g32, gr),
                                          'all_gradients_cosine': gcos(g32, gr)}}
-    print(f'[e1-full] mode {mode} ({modes.count("f16")} fp16 blocks of {len(modes)}):', json.dumps(res))
+    print(f'[e1-full] mode {mode}, {bn}-mode BatchNorm ({modes.count("f16")} fp16 blocks of {len(modes)}):', json.dumps(res))
     keep = os.environ.get('LP_PARITY_OUT')
     if keep:
         import bench
@@ -84,7 +98,7 @@ def test_identity_encoder_full_geometry_forward_and_gradients(monkeypatch, mode,
             cur = json.load(open(path))
         except Exception:
             cur = {}
-        cur['identity_encoder'] = res
+        cur['identity_encoder' if bn == 'train' else 'identity_encoder_eval_bn'] = res
         cur['stamp'] = bench.source_stamp()
         json.dump(cur, open(path, 'w'), indent=1)
     assert all(torch.isfinite(t).all() for t in g)

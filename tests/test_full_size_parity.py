@@ -45,13 +45,22 @@ def export(mode, net, figures):
     json.dump(cur, open(path, 'w'), indent=1)
 
 
-# (mode, gate on outputs, gate on tie-masked gradients): bf16 operands miss the 1e-3 output gate (~1.3e-3) and are only bounded
-@pytest.mark.parametrize('prec,tol_out,tol_grad', [(1, 1e-4, 1e-4), (2, 1e-3, 2e-3), (0, 3e-3, 2e-2)])
-def test_generator_256_vs_oracle(prec, tol_out, tol_grad):
+# (mode, gate on outputs, gate on tie-masked gradients).  'default' = the generator as the DEFAULT precision assignment builds it (round 6: bf16x3
+# operands, nn.generator_prec) against SURVEY 8d's gate itself -- 1e-3 on the outputs AND on every parameter gradient; 1 / 2 / 0 = explicit operand
+# modes: bf16x3 at its own fp32-class bound, f16 (LP_PREC_G=f16: meets the output gate, 1.0 - 1.7e-3 on the gradients -- why it is not the default),
+# bf16 (misses the output gate, only bounded)
+@pytest.mark.parametrize('prec,tol_out,tol_grad', [('default', 1e-3, 1e-3), (1, 1e-4, 1e-4), (2, 1e-3, 2e-3), (0, 3e-3, 2e-2)])
+def test_generator_256_vs_oracle(prec, tol_out, tol_grad, monkeypatch):
     from latent_pose_reenactment_amd.nn import Generator
     from oracle import lp_oracle as O
     torch.manual_seed(0)
+    default = prec == 'default'
+    if default:
+        for k in ('LP_PREC', 'LP_PREC_G'):
+            monkeypatch.delenv(k, raising=False)
+        prec = None
     G = Generator('zero', 3, 4, 64, 512, 512, 256, 'in', 4, 2, 256, prec=prec)
+    prec = G.prec
     with torch.no_grad():
         G.constant.constant.normal_()
     G = G.cuda().train()
@@ -112,8 +121,9 @@ def test_generator_256_vs_oracle(prec, tol_out, tol_grad):
     worst = sorted(gerr.items(), key=lambda kv: -kv[1])[:4]
     print(f'[parity-256] prec={prec}: outputs {errs}; tie-masked grads worst {[(k, round(v, 6)) for k, v in worst]}; '
           f'untied worst {max(gerr_untied.values()):.3e} | calibration vs the fp64 oracle: HIP untied {untied64:.3e}, fp32 CPU oracle untied (the tie floor) {floor32:.3e}')
-    export({0: 'bf16', 1: 'bf16x3', 2: 'f16'}[prec], 'generator',
-           {'outputs': errs, 'tie_masked_worst': [worst[0][0], worst[0][1]], 'tie_masked_all': gerr, 'untied_worst': max(gerr_untied.values()),
+    # the default assignment's figures go into the file bench.py reads for its headline mode (LP_PREC=f16 -> "<round>_parity_gradients_f16.json")
+    export('f16' if default else {0: 'bf16', 1: 'bf16x3', 2: 'f16'}[prec], 'generator' if (default or prec != 2) else 'generator_f16_operands',
+           {'operands': {0: 'bf16', 1: 'bf16x3', 2: 'f16'}[prec], 'outputs': errs, 'tie_masked_worst': [worst[0][0], worst[0][1]], 'tie_masked_all': gerr, 'untied_worst': max(gerr_untied.values()),
             'fp32_oracle_tie_floor_vs_fp64': floor32, 'hip_untied_vs_fp64': untied64, 'gate': tol_grad})
     assert all(v < tol_out for v in errs.values()), errs
     assert all(v < tol_grad for v in gerr.values()), worst
@@ -176,11 +186,20 @@ def _with_tape(fn):
     return out, masks
 
 
-# (mode, gate on forward quantities, gate on tie-masked gradients)
-@pytest.mark.parametrize('prec_name,tol_out,tol_grad', [('bf16x3', 1e-4, 5e-4), ('f16', 1e-3, 5e-3)])
+# (mode, gate on forward quantities, gate on tie-masked gradients).  'f16' = the DEFAULT assignment under LP_PREC=f16 (round 6: the fake -> G pass and,
+# from block 3 on, the two discriminator-side passes run bf16x3 operands -- discriminators/no_landmarks.gpass_prec / dpass_prec): SURVEY 8d's 1e-3 on
+# every parameter gradient, no allowance for the D-loss tensors any more.  'f16_all' = LP_D_DPASS_PREC=f16 (round 5's assignment: every D-side conv
+# with fp16 operands): the hinge gradients of the last blocks are differences of nearly equal fake / real terms -- 9.3e-3 -- kept as a bounded option.
+@pytest.mark.parametrize('prec_name,tol_out,tol_grad', [('bf16x3', 1e-4, 5e-4), ('f16', 1e-3, 1e-3), ('f16_all', 1e-3, 5e-3)])
 def test_discriminator_256_three_passes_vs_oracle(prec_name, tol_out, tol_grad, monkeypatch):
     """The critic as the step runs it: 256x256, 64..512 channels, B = 2, three passes (fake -> G, fake.detach -> D, real) each with
     its own power iteration, adversarial + feature-matching losses, both backward passes (runners/holycow.py:239-250)."""
+    all_f16 = prec_name == 'f16_all'
+    for k in ('LP_D_DPASS_PREC', 'LP_D_DPASS_FROM', 'LP_D_GPASS_PREC', 'LP_D_GPASS_FROM'):
+        monkeypatch.delenv(k, raising=False)
+    if all_f16:
+        monkeypatch.setenv('LP_D_DPASS_PREC', 'f16')
+        prec_name = 'f16'
     monkeypatch.setenv('LP_PREC', prec_name)
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'latent_pose_reenactment_amd'))
@@ -256,20 +275,24 @@ def test_discriminator_256_three_passes_vs_oracle(prec_name, tol_out, tol_grad, 
     worst = sorted(gerr.items(), key=lambda kv: -kv[1])[:4]
     print(f'[parity-256] critic {prec_name}: forward worst {max(errs.values()):.2e} ({max(errs, key=errs.get)}); tie-masked grads worst '
           f'{[(k, round(v, 6)) for k, v in worst]} over {len(gerr)} tensors; untied worst {max(untied.values()):.3e}')
-    export(prec_name, 'discriminator', {'forward_worst': [max(errs, key=errs.get), max(errs.values())],
+    from discriminators.no_landmarks import dpass_prec, gpass_prec
+    export(prec_name, 'discriminator_f16_operands' if all_f16 else 'discriminator',
+                                       {'fake_to_G_pass': list(gpass_prec()), 'D_side_passes': list(dpass_prec()),
+                                        'forward_worst': [max(errs, key=errs.get), max(errs.values())],
                                         'tie_masked_worst_G_loss': max(((k, v) for k, v in gerr.items() if k.startswith('G.')), key=lambda kv: kv[1]),
                                         'tie_masked_worst_D_loss': max(((k, v) for k, v in gerr.items() if k.startswith('D.')), key=lambda kv: kv[1]),
                                         'tie_masked_all': gerr, 'forward_all': errs, 'untied_worst': max(untied.values()),
                                         'untied_worst_G_loss': max(v for k, v in untied.items() if k.startswith('G.')),
                                         'untied_worst_D_loss': max(v for k, v in untied.items() if k.startswith('D.')),
-                                        'gate_G_loss': tol_grad, 'gate_D_loss': 3 * tol_grad})
+                                        'gate_G_loss': tol_grad, 'gate_D_loss': (3 if all_f16 else 1) * tol_grad})
     assert all(v < tol_out for v in errs.values()), errs
     # D-loss weight gradients of the last blocks are DIFFERENCES of nearly equal fake / real terms (hinge: -1/2 on the real, +1/2 on the
-    # fake sample, both images uniform noise here): the cancellation amplifies any operand rounding ~20x, so they get 3x the gate
-    assert all(v < (3 * tol_grad if k.startswith('D.') else tol_grad) for k, v in gerr.items()), worst
+    # fake sample, both images uniform noise here): the cancellation amplifies any operand rounding ~20x.  The default assignment runs those
+    # blocks with bf16x3 operands and is held to the plain gate; only the all-fp16 option keeps the 3x allowance.
+    assert all(v < ((3 if all_f16 else 1) * tol_grad if k.startswith('D.') else tol_grad) for k, v in gerr.items()), worst
 
 
-@pytest.mark.parametrize('prec_name,tol_out,tol_grad', [('bf16x3', 1e-4, 2e-4), ('f16', 1e-3, 3e-3)])
+@pytest.mark.parametrize('prec_name,tol_out,tol_grad', [('bf16x3', 1e-4, 2e-4), ('f16', 1e-3, 1e-3)])          # (f16 measured: 3.6e-4 / 3.5e-4)
 @pytest.mark.parametrize('net', ['caffe', 'face'])
 def test_vgg_stacks_256_vs_oracle(net, prec_name, tol_out, tol_grad, monkeypatch):
     """VGG19 / VGGFace perceptual stacks at full width and 256x256 (thin-channel first conv at W = 256, 64..512-channel convs, fused

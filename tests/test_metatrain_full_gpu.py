@@ -96,10 +96,13 @@ def run(out_path):
     d_score = (all_data['fake_score_G'].detach().double().cpu() - out['fake_score_G'].double())
     conditioned = {'fake_score_G': float(d_score.norm() / scale.norm()), 'loss.adversarial_G': float(d_score.mean().abs() / scale.mean())}
     modes = [{0: 'bf16', 1: 'bf16x3', 2: 'f16'}[m] for m in tm.embedder.identity_encoder.block_precs()]
-    from discriminators.no_landmarks import gpass_prec
+    from discriminators.no_landmarks import dpass_prec, gpass_prec
     gp, gfrom = gpass_prec()
+    dp, dfrom = dpass_prec()
     res = {'LP_PREC': prec, 'identity_encoder_blocks': modes,
            'critic_fake_to_G_pass': {'operands': {0: 'bf16', 1: 'bf16x3', 2: 'f16'}[gp], 'from_unit': gfrom},
+           'critic_D_side_passes': {'operands': {0: 'bf16', 1: 'bf16x3', 2: 'f16'}[dp], 'from_unit': dfrom},
+           'generator_operands': {0: 'bf16', 1: 'bf16x3', 2: 'f16'}[tm.generator.prec],
            'errors': errs, 'conditioned': conditioned, 'stock_fp32_encoders_vs_fp64': calib,
            'loss_values': {k: float(v) for k, v in ref_losses.items()},
            'note': 'errors: PLAIN rel-L2 |a - b| / |b| of every quantity (all gated); conditioned: fake_score_G / loss.adversarial_G relative to '
@@ -111,7 +114,7 @@ def run(out_path):
 
 @pytest.mark.parametrize('mode,gate', [('default', 1e-3), ('bf16x3', 5e-4)])
 def test_full_size_metatrain_forward_vs_reference_chain(tmp_path, mode, gate):
-    env = {k: v for k, v in os.environ.items() if k not in ('LP_PREC', 'LP_PREC_E', 'LP_E_F16_TAIL', 'LP_D_GPASS_PREC', 'LP_D_GPASS_FROM')}
+    env = {k: v for k, v in os.environ.items() if k not in ('LP_PREC', 'LP_PREC_E', 'LP_PREC_G', 'LP_E_F16_TAIL', 'LP_D_GPASS_PREC', 'LP_D_GPASS_FROM', 'LP_D_DPASS_PREC', 'LP_D_DPASS_FROM')}
     if mode != 'default':
         env['LP_PREC'] = mode
     out = str(tmp_path / 'res.json')
@@ -120,7 +123,7 @@ def test_full_size_metatrain_forward_vs_reference_chain(tmp_path, mode, gate):
     res = json.load(open(out))
     worst = sorted(res['errors'].items(), key=lambda kv: -kv[1])
     print(f"[parity-configs2] mode {mode} (identity encoder blocks: {res['identity_encoder_blocks'].count('f16')} fp16 of {len(res['identity_encoder_blocks'])}; "
-          f"critic fake->G pass: {res['critic_fake_to_G_pass']}): PLAIN rel-L2 {[(k, f'{v:.2e}') for k, v in worst]} | conditioned {res['conditioned']} "
+          f"critic fake->G pass: {res['critic_fake_to_G_pass']}, D-side passes: {res['critic_D_side_passes']}; generator: {res['generator_operands']}): PLAIN rel-L2 {[(k, f'{v:.2e}') for k, v in worst]} | conditioned {res['conditioned']} "
           f"| stock fp32 encoders vs fp64: {res['stock_fp32_encoders_vs_fp64']}")
     keep = os.environ.get('LP_PARITY_OUT')        # (scripts: copy the measured figures to profiles/)
     if keep:
