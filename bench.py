@@ -652,14 +652,15 @@ def measured_parity(mode, workload):
                                          'stock_fp32_layers_all_gradients_rel_l2': r3(e['stock_fp32_layers_vs_fp64']['all_gradients_rel']),
                                          'note': 'train-mode BatchNorm at random initialisation is chaotic: the stock fp32 layers (the reference\'s own '
                                                  'arithmetic class) are this far from fp64 themselves; no 1e-3 claim is made for these gradients in any mode'}
-        if 'identity_encoder_eval_bn' in g:
-            e = g['identity_encoder_eval_bn']
-            grads['identity_encoder_eval_mode_batchnorm'] = {
+        if 'identity_encoder_tie_masked' in g:
+            e = g['identity_encoder_tie_masked']
+            grads['identity_encoder_tie_masked'] = {
                 'all_gradients_rel_l2': r3(e['all_gradients_rel']), 'all_gradients_cosine': float(f"{e['all_gradients_cosine']:.7g}"),
                 'embeds': r3(e['embeds']), 'per_frame_logits': r3(e['per_frame_logits']),
                 'stock_fp32_layers_all_gradients_rel_l2': r3(e['stock_fp32_layers_vs_fp64']['all_gradients_rel']),
-                'note': 'the well-conditioned full-depth check: same 64 frames, same layers, running statistics calibrated to the batch, eval mode (every '
-                        'BatchNorm a constant affine map); gate 1e-2 on the all-parameter gradient (tests/test_e1_full_gpu.py)'}
+                'note': 'the well-conditioned full-depth check: the same 64 frames and train-mode BatchNorm, the fp64 stock layers evaluated on the HIP '
+                        'path\'s own ReLU patterns and max-pool argmax (as the G / D / VGG figures are); gate 1e-2 on the all-parameter gradient '
+                        '(tests/test_e1_full_gpu.py)'}
         if gstale:
             grads['stale_reason'] = gwhy
         out['gradients'] = grads

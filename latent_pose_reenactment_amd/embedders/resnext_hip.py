@@ -44,6 +44,7 @@ def supported(n: int, h: int, w: int) -> bool:
 
 
 Y16 = os.environ.get('LP_E_Y16', '1') != '0'        # fp16 mode: conv outputs stay 16-bit resident
+MASK16 = os.environ.get('LP_E_MASK16', '1') != '0'  # block-output ReLU pattern from the operand planes in every mode (0: from the fp32 copy outside the fp16 mode)
 
 
 def _side_ok(t):
@@ -169,8 +170,9 @@ class ResNeXtFunction(torch.autograd.Function):
             else:
                 out, out16 = ops.bn_add_act(y3, st3.scale, st3.shift, xin, relu=True, prec=nprec)
             if need_grad:
-                # (the ReLU pattern of the block output: its operand planes in the 16-bit-resident mode, its fp32 copy otherwise)
-                saved_blocks.append((xin16, y1, st1, a1, y2, st2, a2, y3, st3, xd16, yd, std, out16 if y16 else out, (h, w, ho, wo), (p1, p2, p3)))
+                # (the ReLU pattern of the block output is read from the HI plane of its operand planes -- 2 B per element in every mode (round 6; the
+                #  16-bit-resident mode did so since round 3): relu(out) > 0 <=> its bf16 / fp16 rounding > 0, and the fp32 copy is not kept alive)
+                saved_blocks.append((xin16, y1, st1, a1, y2, st2, a2, y3, st3, xd16, yd, std, out16 if MASK16 else (out16 if y16 else out), (h, w, ho, wo), (p1, p2, p3)))
         # ---- head
         prec = base_prec
         _, hl, wl, cl = out.shape

@@ -414,6 +414,14 @@ def sn_defer_begin():
     _SN_DEFER['depth'] += 1
 
 
+def sn_defer_check(who: str):
+    """ a reader of ``.grad`` -- the gradient exchange, an optimizer step -- must not run while deferred spectral-norm jobs are
+    pending: the conv weights' gradients are incomplete until ``nn.fused_grad_accumulation`` is left.  Raises instead of reading them early."""
+    if _SN_DEFER['jobs']:
+        raise RuntimeError(f'{who}: {len(_SN_DEFER["jobs"])} deferred spectral-norm gradient jobs are pending -- .grad of the conv weights is '
+                           'incomplete inside nn.fused_grad_accumulation; leave the context (or set LP_SN_DEFER=0) before reading gradients')
+
+
 def sn_defer_end(discard: bool = False):
     """leave one level of deferral; the outermost level runs (or, after a failed backward, drops) the collected jobs"""
     _SN_DEFER['depth'] -= 1

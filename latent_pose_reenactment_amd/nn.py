@@ -475,7 +475,9 @@ Y16_MIN_MAP = int(os.environ.get('LP_G_Y16_MIN', '64'))
 
 class _DecoderFunction(torch.autograd.Function):
     """inputs: affine [B, n_aff] (projector output; per AdaIN: C biases then C weights, noBottleneck.py:108-125),
-    constant [1,C,s,s], then per block (w1, w2[, w_skip, b_skip]) and (w_head, b_head) -- effective (W/sigma) weights.
+    constant [1,C,s,s], then per block (w1, w2[, w_skip, b_skip]) and (w_head, b_head) -- the W_ORIG parameters themselves: 1/sigma of each
+    conv (``cfg['sn']``, from SNBatch) is the ``alpha`` of its launch's epilogue, W/sigma is never formed, and the weight-gradient launches
+    return the gradient w.r.t. W_orig through the legacy-hook rule (``snw``).
     outputs: fake_rgbs [B,3,S,S], fake_segm [B,1,S,S] (NCHW, noBottleneck.py:170-181)."""
 
     @staticmethod

@@ -98,6 +98,8 @@ class _FusedBase(Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        from . import hipops as _ops
+        _ops.sn_defer_check(type(self).__name__ + '.step')          #  .grad is incomplete while deferred spectral-norm jobs are pending
         for gi, group in enumerate(self.param_groups):
             _, table, max_n, step, n = self._prepare(gi, group)
             b1, b2 = group['betas']

@@ -96,6 +96,8 @@ class _Bucket:
         numel): all-reduce just that slice now -- further ``start`` calls add more slices, ``finish`` waits for all of them (the
         generator-side arena goes out as two buckets: the generator's slice before the encoders' backward, the encoders' slice after)"""
         op, self.divide = _mean_op()
+        from . import hipops as _ops
+        _ops.sn_defer_check('GradReducer')          # (ADVICE r05) no exchange of gradients that a deferred spectral-norm job has yet to complete
         if self.optimizer is not None and len(self.optimizer.param_groups) == 1:
             # fused optimizers keep every gradient in one flat arena: reduce it in place, no gather/scatter
             arena = self.optimizer.ensure_flat(0)

@@ -29,20 +29,47 @@ def _conv(m, x):
     return F.conv2d(x, m.weight, m.bias, m.stride, m.padding, m.dilation, m.groups)
 
 
+# Tie-masked evaluation of the ResNeXt oracle (round 6, tests/test_e1_full_gpu.py): a pre-activation within rounding distance of 0 flips its ReLU --
+# and a 3x3 max-pool window with two near-equal candidates its argmax -- between two correct implementations, and on a 50-layer network those
+# flips, not arithmetic error, dominate any plain gradient comparison (the stock fp32 layers are 2e-2 from fp64).  When REPLAY is a dict
+# {'relu': [bool NCHW masks in execution order], 'pool': int64 NCHW argmax (ky * 3 + kx) of the stem's max-pool}, the oracle takes the OTHER
+# implementation's branch decisions: relu(x) := x * mask, maxpool := gather at the recorded window position -- the same piecewise-linear map on
+# both sides, so what remains is arithmetic.
+REPLAY = None
+
+
+def _relu(x):
+    if REPLAY is None:
+        return F.relu(x)
+    m = REPLAY['relu'].pop(0)
+    assert m.shape == x.shape, (m.shape, x.shape)
+    return x * m.to(x.dtype)
+
+
+def _maxpool(x):
+    if REPLAY is None:
+        return F.max_pool2d(x, 3, 2, 1)
+    idx = REPLAY['pool']
+    n, c, h, w = x.shape
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    win = F.unfold(x, 3, padding=1, stride=2).view(n, c, 9, ho, wo)          # window position k = ky * 3 + kx
+    return win.gather(2, idx.view(n, c, 1, ho, wo)).squeeze(2)
+
+
 # ---------------------------------------------------------------- ResNeXt-50 32x4d (torchvision resnet.py: ResNet / Bottleneck)
 def _bottleneck(blk, x):
     idt = x
     if blk.downsample is not None:
         idt = _bn(blk.downsample[1], _conv(blk.downsample[0], x))
-    out = F.relu(_bn(blk.bn1, _conv(blk.conv1, x)))
-    out = F.relu(_bn(blk.bn2, _conv(blk.conv2, out)))
+    out = _relu(_bn(blk.bn1, _conv(blk.conv1, x)))
+    out = _relu(_bn(blk.bn2, _conv(blk.conv2, out)))
     out = _bn(blk.bn3, _conv(blk.conv3, out))
-    return F.relu(out + idt)
+    return _relu(out + idt)
 
 
 def resnext_forward(net, x):
     """frames [N,3,H,W] -> logits [N, num_classes]"""
-    x = F.max_pool2d(F.relu(_bn(net.bn1, _conv(net.conv1, x))), 3, 2, 1)
+    x = _maxpool(_relu(_bn(net.bn1, _conv(net.conv1, x))))
     for stage in (net.layer1, net.layer2, net.layer3, net.layer4):
         for blk in stage:
             x = _bottleneck(blk, x)
