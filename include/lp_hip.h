@@ -317,6 +317,16 @@ int lp_spatial_mean_bwd(const float* g, float* dx, int N, int HW, int C, void* s
 
 /* out[n,y,x,c] = sum of the 2x2 block of in[n,2y..2y+1,2x..2x+1,c]  (adjoint of nearest x2 upsampling, blocks.py:95). */
 int lp_sum2x2(const float* in, float* out, int N, int H, int W, int C, float* amax_slots, void* stream);
+/* (ABI 10, round 6) The two gradient producers of the decoder's backward (autograd of generators/common/blocks.py:70-111) writing the NEXT
+ * contraction's operand directly in the bf16 (out_lo == NULL) / bf16x3 (hi + lo) modes, where gradient operands carry no scale: out_hi / out_lo
+ * [N][H][W][C] (C % 8 == 0) hold exactly what lp_act_pack(prologue 0) would write for the fp32 result.
+ *   lp_adain_relu_bwd_planes: lp_adain_relu_bwd; keep_dx = 0: planes only (dx is scratch: it holds the masked gradient between the passes)
+ *   lp_sum2x2_planes:         lp_sum2x2; out = NULL: planes only */
+int lp_adain_relu_bwd_planes(const float* dA, const float* x, const float* add, const float* gamma, int ab_stride,
+                             const float* mean, const float* rstd, const float* scale, const float* shift,
+                             float* dx, float* dgamma, float* dbeta, float* workspace,
+                             int N, int H, int W, int C, int upsample, uint16_t* out_hi, uint16_t* out_lo, int keep_dx, void* stream);
+int lp_sum2x2_planes(const float* in, float* out, uint16_t* out_hi, uint16_t* out_lo, int N, int H, int W, int C, void* stream);
 
 /* Generator head (noBottleneck.py:86-88,170-181): t = tanh(z), rgb = t[:3]*0.75+0.5, segm = t[3]*0.5+0.5,
  * fake_rgbs = rgb*segm.  z/t NHWC [N][H][W][4]; fake_rgbs NCHW [N][3][H][W]; fake_segm NCHW [N][1][H][W]. */

@@ -302,6 +302,20 @@ template <bool X16> __device__ __forceinline__ float4 lp_ldx4(const void* x, siz
     return *(const float4*)((const float*)x + e);
 }
 
+// four consecutive channels of a gradient tensor as bf16 operand planes: hi = RNE bf16, lo = bf16(v - hi) (|NULL: plain bf16 mode)
+__device__ __forceinline__ void lp_store_bf16_planes4(const float4& o, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo, size_t e) {
+    const float v[4] = {o.x, o.y, o.z, o.w};
+    ushort4 h, l;
+    uint16_t* hp = (uint16_t*)&h; uint16_t* lp = (uint16_t*)&l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        hp[j] = lp_f32_to_op16<false>(v[j]);
+        lp[j] = lp_f32_to_op16<false>(v[j] - lp_op16_to_f32<false>(hp[j]));
+    }
+    *(ushort4*)(hi + e) = h;
+    if (lo) *(ushort4*)(lo + e) = l;
+}
+
 template <bool X16 = false>
 __global__ __launch_bounds__(256) void adain_bwd_partial_kernel(const float* __restrict__ dA, const void* __restrict__ x,
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -379,9 +393,13 @@ __global__ __launch_bounds__(256) void adain_bwd_finalize_kernel(const float* __
     coef[(size_t)idx * 3 + 0] = ca; coef[(size_t)idx * 3 + 1] = cb; coef[(size_t)idx * 3 + 2] = cc;
 }
 
+// o_hi (, o_lo) | NULL: the result ALSO goes out as bf16 (hi + lo) operand planes [N][HW][C] (C % 8 == 0) -- what lp_act_pack(grad) would write in
+// the bf16 / bf16x3 modes (no gradient scale there) -- and with keep_dx == 0 ONLY as planes (round 6: the generator's backward in its bf16x3 default;
+// a conv's gradient operand then costs no fp32 round trip and no pack launch)
 template <bool X16 = false>
 __global__ void adain_bwd_apply_kernel(float* __restrict__ dx /* holds g */, const void* __restrict__ x, const float* __restrict__ add,
-                                       const float* __restrict__ coef, long long total4, int HW, int C, float* __restrict__ amax) {
+                                       const float* __restrict__ coef, long long total4, int HW, int C, float* __restrict__ amax,
+                                       uint16_t* __restrict__ o_hi = nullptr, uint16_t* __restrict__ o_lo = nullptr, int keep_dx = 1) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long stride = (long long)gridDim.x * blockDim.x;
     const int C4 = C >> 2;
@@ -396,7 +414,8 @@ __global__ void adain_bwd_apply_kernel(float* __restrict__ dx /* holds g */, con
         o.z = fmaf(cf[6], g.z, fmaf(cf[7], xv.z, cf[8]));
         o.w = fmaf(cf[9], g.w, fmaf(cf[10], xv.w, cf[11]));
         if (add) { float4 a = ((const float4*)add)[i]; o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w; }
-        ((float4*)dx)[i] = o;
+        if (keep_dx) ((float4*)dx)[i] = o;
+        if (o_hi) lp_store_bf16_planes4(o, o_hi, o_lo, (size_t)i * 4);
         am = lp_amax4(am, o);
     }
     if (amax) lp_amax_commit(am, amax, blockIdx.x);
@@ -418,7 +437,21 @@ extern "C" int lp_adain_relu_bwd(const float* dA, const float* x, const float* a
 static int norm_act_bwd_impl(const float* dA, const void* x, int x16, const float* add, const float* gamma, int ab_stride, const float* mean,
                              const float* rstd, const float* scale, const float* shift, float* dx, float* dgamma, float* dbeta,
                              float* workspace, int N, int H, int W, int C, int upsample, int mask_mode, const float* mask_src,
-                             float* g_copy, float act_hi, int frozen_stats, float* amax_slots, void* stream);
+                             float* g_copy, float act_hi, int frozen_stats, float* amax_slots, void* stream,
+                             uint16_t* o_hi = nullptr, uint16_t* o_lo = nullptr, int keep_dx = 1);
+
+// lp_adain_relu_bwd whose result goes out as bf16 (out_lo == NULL) / bf16 hi + lo operand planes [N][H][W][C] (C % 8 == 0) -- the gradient operand
+// of the conv below, in the bf16 / bf16x3 modes (no gradient scale) -- and, with keep_dx != 0, also as fp32 dx.  dx must always be given: it holds
+// the masked gradient between the passes.
+extern "C" int lp_adain_relu_bwd_planes(const float* dA, const float* x, const float* add, const float* gamma, int ab_stride, const float* mean,
+                                        const float* rstd, const float* scale, const float* shift, float* dx, float* dgamma, float* dbeta,
+                                        float* workspace, int N, int H, int W, int C, int upsample, uint16_t* out_hi, uint16_t* out_lo,
+                                        int keep_dx, void* stream) {
+    if (!out_hi) return lp_set_error(LP_ERR_ARG, "lp_adain_relu_bwd_planes: null pointer");
+    if (C & 7) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_adain_relu_bwd_planes: C must be a multiple of 8");
+    return norm_act_bwd_impl(dA, x, 0, add, gamma, ab_stride, mean, rstd, scale, shift, dx, dgamma, dbeta, workspace, N, H, W, C, upsample, 0,
+                             nullptr, nullptr, 0.f, 0, nullptr, stream, out_hi, out_lo, keep_dx);
+}
 
 // lp_adain_relu_bwd with x held as a 16-bit-resident conv output (fp16 plane [N][H][W][C], C % 8 == 0): the generator's fp16 mode keeps
 // no fp32 copy of its conv outputs (round 5); x-hat and the ReLU pattern are recomputed from the SAME fp16 values the forward normalised
@@ -441,7 +474,8 @@ extern "C" int lp_norm_act_bwd(const float* dA, const float* x, const float* add
 static int norm_act_bwd_impl(const float* dA, const void* x, int x16, const float* add, const float* gamma, int ab_stride, const float* mean,
                              const float* rstd, const float* scale, const float* shift, float* dx, float* dgamma, float* dbeta,
                              float* workspace, int N, int H, int W, int C, int upsample, int mask_mode, const float* mask_src,
-                             float* g_copy, float act_hi, int frozen_stats, float* amax_slots, void* stream) {
+                             float* g_copy, float act_hi, int frozen_stats, float* amax_slots, void* stream,
+                             uint16_t* o_hi, uint16_t* o_lo, int keep_dx) {
     if (!dA || !x || !mean || !rstd || !scale || !shift || !dx || !workspace) return lp_set_error(LP_ERR_ARG, "lp_norm_act_bwd: null pointer");
     if (C & 3) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_norm_act_bwd: C must be a multiple of 4");
     if (mask_mode < 0 || mask_mode > 2 || (mask_mode == 2 && !mask_src)) return lp_set_error(LP_ERR_ARG, "lp_norm_act_bwd: bad mask mode");
@@ -464,8 +498,8 @@ static int norm_act_bwd_impl(const float* dA, const void* x, int x16, const floa
     if (rc) return rc;
     long long total4 = (long long)N * HW * C / 4;
     int blocks = (int)((total4 + 255) / 256); if (blocks > 4096) blocks = 4096;
-    if (x16) hipLaunchKernelGGL(adain_bwd_apply_kernel<true>, dim3(blocks), dim3(256), 0, st, dx, x, add, coef, total4, HW, C, amax_slots);
-    else hipLaunchKernelGGL(adain_bwd_apply_kernel<false>, dim3(blocks), dim3(256), 0, st, dx, x, add, coef, total4, HW, C, amax_slots);
+    if (x16) hipLaunchKernelGGL(adain_bwd_apply_kernel<true>, dim3(blocks), dim3(256), 0, st, dx, x, add, coef, total4, HW, C, amax_slots, o_hi, o_lo, keep_dx);
+    else hipLaunchKernelGGL(adain_bwd_apply_kernel<false>, dim3(blocks), dim3(256), 0, st, dx, x, add, coef, total4, HW, C, amax_slots, o_hi, o_lo, keep_dx);
     return lp_check_launch("adain_bwd_apply");
 }
 
@@ -473,7 +507,7 @@ static int norm_act_bwd_impl(const float* dA, const void* x, int x16, const floa
 // 2x2 block sum (adjoint of nearest x2 upsampling)
 // ------------------------------------------------------------------------------------------------------------------
 __global__ void sum2x2_kernel(const float* __restrict__ in, float* __restrict__ out, long long total4, int H, int W, int C,
-                              float* __restrict__ amax) {
+                              float* __restrict__ amax, uint16_t* __restrict__ o_hi = nullptr, uint16_t* __restrict__ o_lo = nullptr) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long stride = (long long)gridDim.x * blockDim.x;
     const int C4 = C >> 2;
@@ -488,10 +522,21 @@ __global__ void sum2x2_kernel(const float* __restrict__ in, float* __restrict__ 
                a3 = *(const float4*)(b + (size_t)2 * W * C + C), o;
         o.x = (a0.x + a1.x) + (a2.x + a3.x); o.y = (a0.y + a1.y) + (a2.y + a3.y);
         o.z = (a0.z + a1.z) + (a2.z + a3.z); o.w = (a0.w + a1.w) + (a2.w + a3.w);
-        ((float4*)out)[i] = o;
+        if (out) ((float4*)out)[i] = o;
+        if (o_hi) lp_store_bf16_planes4(o, o_hi, o_lo, (size_t)i * 4);
         am = lp_amax4(am, o);
     }
     if (amax) lp_amax_commit(am, amax, blockIdx.x);
+}
+
+// lp_sum2x2 straight to bf16 (out_lo == NULL) / bf16 hi + lo operand planes [N][H][W][C] (C % 8 == 0); out (fp32) | NULL
+extern "C" int lp_sum2x2_planes(const float* in, float* out, uint16_t* out_hi, uint16_t* out_lo, int N, int H, int W, int C, void* stream) {
+    if (!in || !out_hi) return lp_set_error(LP_ERR_ARG, "lp_sum2x2_planes: null pointer");
+    if (C & 7) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_sum2x2_planes: C must be a multiple of 8");
+    long long total4 = (long long)N * H * W * C / 4;
+    int blocks = (int)((total4 + 255) / 256); if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(sum2x2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, total4, H, W, C, (float*)nullptr, out_hi, out_lo);
+    return lp_check_launch("sum2x2");
 }
 
 extern "C" int lp_sum2x2(const float* in, float* out, int N, int H, int W, int C, float* amax_slots, void* stream) {

@@ -732,10 +732,27 @@ def instnorm_stats(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], e
 
 
 def adain_relu_bwd(dA: Tensor, x: Tensor, add: Optional[Tensor], gamma: Tensor, mean: Tensor, rstd: Tensor, scale: Tensor,
-                   shift: Tensor, dgamma: Tensor, dbeta: Tensor, upsample: bool, amax: bool = False) -> Tensor:
+                   shift: Tensor, dgamma: Tensor, dbeta: Tensor, upsample: bool, amax: bool = False, planes: Optional[int] = None,
+                   keep_dx: bool = True):
     """Backward of relu(AdaIN(x)) (+x2 upsample).  dgamma/dbeta: [N,C] views into the projector-output gradient (written).
-    ``amax`` (here and below): the result will be packed as an fp16 gradient operand -- fold its max|.| into the kernel."""
+    ``amax`` (here and below): the result will be packed as an fp16 gradient operand -- fold its max|.| into the kernel.
+    ``planes`` = PREC_BF16 | PREC_BF16X3 (round 6): the result ALSO leaves as that mode's gradient operand planes, written by the same launch
+    (lp_adain_relu_bwd_planes; no scale in those modes) -> (dx | None, Act16); ``keep_dx=False``: planes only."""
     _chk(dA, 'dA')
+    if planes is not None and planes_direct_ok(planes, x, x.shape[3] if not isinstance(x, Act16) else 0):
+        n, h, w, c = x.shape
+        assert dA.shape == (n, h << int(upsample), w << int(upsample), c), (dA.shape, (n, h, w, c))
+        assert gamma.stride(1) == 1 and dgamma.stride(1) == 1 and dbeta.stride(1) == 1 and gamma.stride(0) == dgamma.stride(0) == dbeta.stride(0)
+        dx = torch.empty((n, h, w, c), dtype=torch.float32, device=dA.device)          # (holds the masked gradient between the passes)
+        ws = torch.empty(_lib.lib().lp_adain_bwd_workspace_bytes(n, h * w, c) // 4, dtype=torch.float32, device=dA.device)
+        o_hi, o_lo = _alloc16(n, h, w, c, planes, dA.device)
+        check(_lib.lib().lp_adain_relu_bwd_planes(dA.data_ptr(), x.data_ptr(), _p(add), gamma.data_ptr(), gamma.stride(0), mean.data_ptr(), rstd.data_ptr(),
+                                                  scale.data_ptr(), shift.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(),
+                                                  n, h, w, c, int(upsample), o_hi.data_ptr(), _p(o_lo), int(keep_dx), _stream()), 'lp_adain_relu_bwd_planes')
+        return (dx if keep_dx else None), Act16(o_hi, o_lo, c, None)
+    if planes is not None:          # (geometry the fused form does not cover: the two-launch form)
+        dx = adain_relu_bwd(dA, x, add, gamma, mean, rstd, scale, shift, dgamma, dbeta, upsample, amax=amax)
+        return dx, act_pack(dx, prec=planes, grad=True)
     x16 = x if isinstance(x, Act16) else None          # 16-bit-resident conv output (the generator's fp16 mode: no fp32 copy of x exists)
     if x16 is not None:
         assert x16.lo is None and x16.inv is None and x16.hi.shape[3] == x16.c, 'a 16-bit-resident x is ONE unscaled fp16 plane with C % 8 == 0'
@@ -753,6 +770,24 @@ def adain_relu_bwd(dA: Tensor, x: Tensor, add: Optional[Tensor], gamma: Tensor, 
     check(fn(dA.data_ptr(), xp, _p(add), gamma.data_ptr(), gamma.stride(0), mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr(),
              dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), n, h, w, c, int(upsample), _p(_amax_attach(dx, amax)), _stream()), nm)
     return dx
+
+
+PLANES_DIRECT = os.environ.get('LP_PLANES_DIRECT', '1') != '0'      # 0: gradient operands of the bf16 / bf16x3 modes through lp_act_pack again (A/B knob)
+
+
+def planes_direct_ok(prec: int, x, c: int) -> bool:
+    return PLANES_DIRECT and prec in (PREC_BF16, PREC_BF16X3) and not isinstance(x, Act16) and c % 8 == 0
+
+
+def sum2x2_planes(x: Tensor, prec: int) -> 'Act16':
+    """sum2x2 straight to the bf16 / bf16x3 gradient operand planes (no fp32 result, no pack launch)"""
+    _chk(x, 'x')
+    n, h2, w2, c = x.shape
+    if not planes_direct_ok(prec, x, c):
+        return act_pack(sum2x2(x, amax=prec == PREC_F16), prec=prec, grad=True)
+    o_hi, o_lo = _alloc16(n, h2 // 2, w2 // 2, c, prec, x.device)
+    check(_lib.lib().lp_sum2x2_planes(x.data_ptr(), None, o_hi.data_ptr(), _p(o_lo), n, h2 // 2, w2 // 2, c, _stream()), 'lp_sum2x2_planes')
+    return Act16(o_hi, o_lo, c, None)
 
 
 def sum2x2(x: Tensor, amax: bool = False) -> Tensor:

@@ -471,6 +471,7 @@ G_Y16 = os.environ.get('LP_G_Y16', '0') != '0'
 # smallest map (output height) that runs 16-bit resident: 64 -- at 32 x 32 the launches that do not cover the fused statistics would need a decode +
 # statistics pass (measured: two extra launch pairs per step), and 6 % of the decoder's activation bytes live there
 Y16_MIN_MAP = int(os.environ.get('LP_G_Y16_MIN', '64'))
+RAW16_SKIP = os.environ.get('LP_G_RAW16', '1') != '0'      # conv2's epilogue also writes the raw planes of the block output for the next skip conv (0: a pack launch)
 
 
 class _DecoderFunction(torch.autograd.Function):
@@ -530,17 +531,22 @@ class _DecoderFunction(torch.autograd.Function):
                 return ops.adain_act16(t, st[2], st[3])
             return ops.act_pack(t, pro=1, scale=st[2], shift=st[3], prec=prec)
 
-        def conv_out(a, pk, hout, w_orig, **kw):
-            """-> (y fp32 | the fp16 plane of y, statistics partials | None)"""
+        def conv_out(a, pk, hout, w_orig, raw16=False, **kw):
+            """-> (y fp32 | the fp16 plane of y, statistics partials | None, raw operand planes of y | None).  ``raw16`` (round 6): the epilogue
+            also writes the operand planes of y itself -- the input of the NEXT block's 1x1 skip conv (lp_act_pack prologue 0 of y: one launch
+            and one read of y less per up block)"""
             if reflect:
                 y = ops.conv16(a, pk, prec=prec, **kw)
-                return ops.reflect_border_fwd(a, w_orig.detach().contiguous(), kw.get('alpha'), y, prec=prec, upsample=bool(kw.get('upsample'))), None
+                return ops.reflect_border_fwd(a, w_orig.detach().contiguous(), kw.get('alpha'), y, prec=prec, upsample=bool(kw.get('upsample'))), None, None
             if y16 and hout >= Y16_MIN_MAP and pk.rows % 8 == 0:
                 _, o16, cs = ops.conv16(a, pk, prec=prec, stats=True, want_y=False, out16=0, **kw)
-                return o16, cs
-            return ops.conv16(a, pk, prec=prec, stats=True, **kw)
-        x_cs = None
-        for (cin, cout, up) in blocks:
+                return o16, cs, None
+            if raw16 and pk.rows % 8 == 0:
+                y, o16, cs = ops.conv16(a, pk, prec=prec, stats=True, out16=0, **kw)
+                return y, cs, o16
+            return ops.conv16(a, pk, prec=prec, stats=True, **kw) + (None,)
+        x_cs = x_raw16 = None
+        for bi_, (cin, cout, up) in enumerate(blocks):
             w1, w2 = wl[wi], wl[wi + 1]
             wi += 2
             has_skip = (cin != cout) or up
@@ -552,7 +558,7 @@ class _DecoderFunction(torch.autograd.Function):
             st0 = in_stats(x, x_cs, g0, b0)
             a0 = norm_planes(x, st0)
             p1 = fpack(wi - 2, w1)
-            h1, cs1 = conv_out(a0, p1, hout, w1, ksize=3, upsample=up, alpha=sn[wi - 2][2][1:])
+            h1, cs1, _ = conv_out(a0, p1, hout, w1, ksize=3, upsample=up, alpha=sn[wi - 2][2][1:])
             st1 = in_stats(h1, cs1, g1, b1)
             a1 = norm_planes(h1, st1)
             xs = None
@@ -560,7 +566,7 @@ class _DecoderFunction(torch.autograd.Function):
                 ws, bs = wl[wi], wl[wi + 1]
                 wi += 2
                 ps = fpack(wi - 2, ws)
-                xs = x if isinstance(x, ops.Act16) else ops.act_pack(x, pro=0, prec=prec)
+                xs = x if isinstance(x, ops.Act16) else x_raw16 if x_raw16 is not None else ops.act_pack(x, pro=0, prec=prec)
                 s = ops.conv16(xs, ps, ksize=1, bias=bs.detach().contiguous(), alpha=sn[wi - 2][2][1:], prec=prec)   # 1x1 commutes with nearest upsampling
                 rs = 1 if up else 0
             else:
@@ -568,7 +574,9 @@ class _DecoderFunction(torch.autograd.Function):
                 s, rs = x, 0
             i2 = wi - (3 if has_skip else 1)
             p2 = fpack(i2, w2)
-            out, x_cs = conv_out(a1, p2, hout, w2, ksize=3, res=s, res_shift=rs, alpha=sn[i2][2][1:])
+            nxt = blocks[bi_ + 1] if bi_ + 1 < len(blocks) else None
+            out, x_cs, x_raw16 = conv_out(a1, p2, hout, w2, raw16=RAW16_SKIP and nxt is not None and (nxt[0] != nxt[1] or nxt[2]), ksize=3, res=s, res_shift=rs,
+                                          alpha=sn[i2][2][1:])
             if need_grad:
                 saved.append((x, h1, st0, st1, o0, o1, a0, a1, xs))
             if cfg.get('debug') is not None:      # activation patterns of the AdaIN+ReLU sites (tie-masked parity checks)
@@ -638,8 +646,16 @@ class _DecoderFunction(torch.autograd.Function):
         pT = tpack(wi, small_k=True)
         dA = ops.conv(dz, pT, ksize=3, alpha=sn[wi][2][1:], prec=prec, grad=True)
         g, dg, db = slices(oh, ch)
-        dx = ops.adain_relu_bwd(dA, x, None, g, sth[0], sth[1], sth[2], sth[3], dg, db, False, amax=f16)
+        # bf16 / bf16x3 (round 6): gradient operands carry no scale there, so the AdaIN backward (and the 2x2 sum of the skip branch) write the
+        # operand planes of their result themselves -- lp_adain_relu_bwd_planes / lp_sum2x2_planes: no pack launch, and the conv1-output gradient
+        # (dh1), whose only consumers are the two contractions, never exists in fp32
+        direct = prec in (PREC_BF16, PREC_BF16X3)
         dbg = cfg.get('debug')
+        dx16 = None
+        if direct:
+            dx, dx16 = ops.adain_relu_bwd(dA, x, None, g, sth[0], sth[1], sth[2], sth[3], dg, db, False, planes=prec)
+        else:
+            dx = ops.adain_relu_bwd(dA, x, None, g, sth[0], sth[1], sth[2], sth[3], dg, db, False, amax=f16)
         if dbg is not None:
             dbg['dz'] = dz; dbg['dA_head'] = dA; dbg[f'dx{len(blocks)}'] = dx
 
@@ -649,19 +665,22 @@ class _DecoderFunction(torch.autograd.Function):
             x, h1, st0, st1, o0, o1, a0, a1, xs = ctx.saved[bi]
             wi -= 4 if has_skip else 2
             d_out = dx
-            d16 = ops.act_pack(d_out, prec=prec, grad=True)       # packed once: operand of conv2's weight AND data gradient
+            d16 = dx16 if dx16 is not None else ops.act_pack(d_out, prec=prec, grad=True)       # packed once: operand of conv2's weight AND data gradient
             # conv2 (+ AdaIN1/ReLU prologue)
             grads[wi + 1] = ops.conv_wgrad16(a1, d16, ksize=3, prec=prec, sn=snw(wi + 1), accum=_accum_target(params[wi + 1]))
             dA1 = ops.conv16(d16, tpack(wi + 1), ksize=3, alpha=sn[wi + 1][2][1:], prec=prec)
             if reflect:
                 border(wi + 1, a1, d_out, dA1)
             g, dg, db = slices(o1, cout)
-            dh1 = ops.adain_relu_bwd(dA1, h1, None, g, st1[0], st1[1], st1[2], st1[3], dg, db, False, amax=f16)
+            if direct:
+                dh1, dh16 = ops.adain_relu_bwd(dA1, h1, None, g, st1[0], st1[1], st1[2], st1[3], dg, db, False, planes=prec, keep_dx=reflect or dbg is not None)
+            else:
+                dh1 = ops.adain_relu_bwd(dA1, h1, None, g, st1[0], st1[1], st1[2], st1[3], dg, db, False, amax=f16)
+                dh16 = None
             # skip branch: out += up2(conv1x1(x) + b)
             if has_skip:
                 if up:
-                    ds = ops.sum2x2(d_out, amax=f16)
-                    ds16 = ops.act_pack(ds, prec=prec, grad=True)
+                    ds16 = ops.sum2x2_planes(d_out, prec) if direct else ops.act_pack(ops.sum2x2(d_out, amax=f16), prec=prec, grad=True)
                 else:
                     ds16 = d16
                 grads[wi + 2], grads[wi + 3] = ops.conv_wgrad16(xs, ds16, ksize=1, prec=prec, sn=snw(wi + 2),
@@ -671,13 +690,18 @@ class _DecoderFunction(torch.autograd.Function):
             else:
                 dx_skip = d_out
             # conv1 (+ AdaIN0/ReLU/upsample prologue)
-            dh16 = ops.act_pack(dh1, prec=prec, grad=True)
+            if dh16 is None:
+                dh16 = ops.act_pack(dh1, prec=prec, grad=True)
             grads[wi] = ops.conv_wgrad16(a0, dh16, ksize=3, upsample=up, prec=prec, sn=snw(wi), accum=_accum_target(params[wi]))
             dA0 = ops.conv16(dh16, tpack(wi), ksize=3, alpha=sn[wi][2][1:], prec=prec)
             if reflect:
                 border(wi, a0, dh1, dA0, up)
             g, dg, db = slices(o0, cin)
-            dx = ops.adain_relu_bwd(dA0, x, dx_skip, g, st0[0], st0[1], st0[2], st0[3], dg, db, up, amax=f16 and bi > 0)
+            dx16 = None
+            if direct and bi > 0:          # (block 0's input gradient only feeds the learned constant: fp32)
+                dx, dx16 = ops.adain_relu_bwd(dA0, x, dx_skip, g, st0[0], st0[1], st0[2], st0[3], dg, db, up, planes=prec)
+            else:
+                dx = ops.adain_relu_bwd(dA0, x, dx_skip, g, st0[0], st0[1], st0[2], st0[3], dg, db, up, amax=f16 and bi > 0)
             if dbg is not None:
                 dbg[f'dx{bi}'] = dx; dbg[f'dh1_{bi}'] = dh1; dbg[f'dxskip{bi}'] = dx_skip
         d_const = dx.sum(dim=0, keepdim=True).permute(0, 3, 1, 2).contiguous()

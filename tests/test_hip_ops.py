@@ -190,6 +190,36 @@ def test_instnorm_stats(shape):
     report('scale', rel(sc, rstd * gamma), 2e-5); report('shift', rel(sh, beta - mean * rstd * gamma), 2e-4)
 
 
+@pytest.mark.parametrize('prec', [0, 1])
+@pytest.mark.parametrize('ups', [0, 1])
+@pytest.mark.parametrize('shape', [(2, 4, 4, 64), (2, 16, 16, 32), (1, 128, 128, 8), (2, 8, 8, 16)])
+def test_gradient_producers_write_operand_planes_directly(shape, ups, prec):
+    """(round 6) lp_adain_relu_bwd_planes / lp_sum2x2_planes: the bf16 / bf16x3 operand planes written by the producing launch are BIT-IDENTICAL to
+    lp_act_pack of the fp32 result of the two-launch form; keep_dx=False returns no fp32 tensor"""
+    ops = _ops()
+    n, h, w, c = shape
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(n, h, w, c, generator=g) * 2 + 1).cuda()
+    aff = torch.randn(n, 2 * c, generator=g).cuda()
+    dA = torch.randn(n, h << ups, w << ups, c, generator=g).cuda()
+    add = torch.randn(n, h, w, c, generator=g).cuda()
+    m, r, sc, sh = ops.instnorm_stats(x, aff[:, c:], aff[:, :c], 1e-4)
+    d0, d1, d2 = torch.zeros_like(aff), torch.zeros_like(aff), torch.zeros_like(aff)
+    ref = ops.adain_relu_bwd(dA, x, add, aff[:, c:], m, r, sc, sh, d0[:, c:], d0[:, :c], bool(ups))
+    ref16 = ops.act_pack(ref, prec=prec, grad=True)
+    dx, p16 = ops.adain_relu_bwd(dA, x, add, aff[:, c:], m, r, sc, sh, d1[:, c:], d1[:, :c], bool(ups), planes=prec)
+    none, q16 = ops.adain_relu_bwd(dA, x, add, aff[:, c:], m, r, sc, sh, d2[:, c:], d2[:, :c], bool(ups), planes=prec, keep_dx=False)
+    torch.cuda.synchronize()
+    assert none is None and torch.equal(dx, ref) and torch.equal(d0, d1) and torch.equal(d0, d2)
+    for got in (p16, q16):
+        assert got.inv is None and torch.equal(got.hi, ref16.hi) and (prec == 0 or torch.equal(got.lo, ref16.lo)) and (got.lo is None) == (prec == 0)
+    if ups:
+        s_ref = ops.act_pack(ops.sum2x2(dA), prec=prec, grad=True)
+        s16 = ops.sum2x2_planes(dA, prec)
+        torch.cuda.synchronize()
+        assert torch.equal(s16.hi, s_ref.hi) and (prec == 0 or torch.equal(s16.lo, s_ref.lo))
+
+
 @pytest.mark.parametrize('ups', [0, 1])
 @pytest.mark.parametrize('shape', [(2, 4, 4, 64), (2, 16, 16, 32), (1, 128, 128, 8), (2, 32, 32, 4), (2, 8, 8, 16)])
 def test_adain_relu_bwd(shape, ups):
