@@ -477,6 +477,13 @@ static int dispatch_conv16(Conv16Params& p, int ks, int ups, hipStream_t s) {
     static const int w8_env = getenv("LP_CONV_W8") ? atoi(getenv("LP_CONV_W8")) : -1;
     const bool w8 = w8_env >= 0 ? (w8_env != 0) : (p.H * p.W <= 256);
     if (w8 && p.Cout > 64) {
+        // bf16x3 small maps (round 6, LP_CONV_X3_BN64=0 restores the 128 x 128 tile): the 8-wave 128 x 128 tile's hi + lo weight stages (49 KB each) leave no room for the 3-deep
+        // ring, so every stage drains vmcnt(0); 128 x 64 tiles of four waves (24.5 KB stages) keep the ring and double the workgroups per slice
+        static const int x3bn64 = getenv("LP_CONV_X3_BN64") ? atoi(getenv("LP_CONV_X3_BN64")) : 1;      // measured (profiles/r06_x3_small_maps.txt): 4x4 23.2 -> 17.7 us, 8x8 25.4 -> 23.3, 8x8 upsampled 26.0 -> 21.9, 16x16 unchanged; step -0.35 ms
+        if (PREC == LP_PREC_BF16X3 && x3bn64 && ks == 3) {
+            if (!ups) return launch_conv16<3, false, 2, 2, 4, 2, PREC>(p, s);
+            return launch_conv16<3, true, 2, 2, 4, 2, PREC>(p, s);
+        }
         if (ks == 3 && !ups) return launch_conv16<3, false, 2, 4, 4, 2, PREC>(p, s);
         if (ks == 3 && ups) return launch_conv16<3, true, 2, 4, 4, 2, PREC>(p, s);
         if (ks == 1 && !ups) return launch_conv16<1, false, 2, 4, 4, 2, PREC>(p, s);
