@@ -690,7 +690,8 @@ static int launch_wgrad1x1(WgradParams& p, float* dw, const float* out_scale, co
 //     every tap shift (halo rows are 18 | 10 = 2 mod 8 pixels apart: the key of pixel (row, col) is (row + (col >> 1)) & 3);
 //   * the bias gradient (column sums of dy) comes from the matrix core as well: dy x ones, one extra MFMA per k-step and wave;
 //   * XCD-aware block order as wgrad1x1_kernel: the (co, ci) tiles of one pixel range run on one XCD.
-// Output: the [split][tap][CoP][CiP] slabs of the common reduction.  f16 / bf16 operands (the bf16x3 mode keeps conv_wgrad_kernel).
+// Output: the [split][tap][CoP][CiP] slabs of the common reduction.  f16 / bf16 operands; bf16x3 since round 6 (one workgroup per CU: the doubled
+// planes fill the LDS; 512 registers per lane, accumulators in AGPRs).
 struct W3Params {
     const uint16_t* a_hi; const uint16_t* a_lo; const uint16_t* d_hi; const uint16_t* d_lo; float* part; float* bpart;
     int N, H, W, Hin, Win, C8, Co8, CoP, CiP;
@@ -703,9 +704,10 @@ struct W3Params {
 //   -- the two row fragments of the wave's 32-channel half.  The bf16x3 mode (hi + lo planes, 3 MFMAs) is built for the diagonal forms only:
 //   their 9 / 18 accumulator tiles leave the registers for the second fragment set, and ONE workgroup per CU holds the doubled planes.
 template <bool UPS, int PREC, int DIAGB>
-__global__ __launch_bounds__(256, 2) void wgrad3_pipe_kernel(W3Params p) {
+__global__ __launch_bounds__(256, (PREC == LP_PREC_BF16X3 && DIAGB == 0) ? 1 : 2) void wgrad3_pipe_kernel(W3Params p) {
     constexpr bool SPLIT = (PREC == LP_PREC_BF16X3), F16 = (PREC == LP_PREC_F16);
-    static_assert(!SPLIT || DIAGB != 0, "bf16x3: diagonal forms only");
+    // (round 6) dense bf16x3: the doubled planes hold a CU to ONE workgroup anyway (156 KB of LDS), so the kernel is built for one wave per SIMD --
+    // 512 registers: the 36 accumulator tiles go to AGPRs and the second fragment set fits without scratch
     static_assert(!UPS || DIAGB == 0, "grouped convs are not upsampled");
     constexpr int NT = DIAGB == 16 ? 1 : DIAGB == 32 ? 2 : 4;     // row (co) fragments per wave
     constexpr int HH = UPS ? 6 : 10, HW = UPS ? 10 : 18;
@@ -838,6 +840,10 @@ __global__ __launch_bounds__(256, 2) void wgrad3_pipe_kernel(W3Params p) {
                 if (tap == 0 && do_bias) {                  // (scalar selects: no dynamic register indexing)
                     const s16x8_t fw = wave == 0 ? fa[ks & 1][0] : wave == 1 ? fa[ks & 1][1] : wave == 2 ? fa[ks & 1][2] : fa[ks & 1][3];
                     accb = mfma16t<F16>(fw, ones, accb);
+                    if (SPLIT) {          // (dense bf16x3: dy = hi + lo)
+                        const s16x8_t fwl = wave == 0 ? fal[ks & 1][0] : wave == 1 ? fal[ks & 1][1] : wave == 2 ? fal[ks & 1][2] : fal[ks & 1][3];
+                        accb = mfma16(fwl, ones, accb);
+                    }
                 }
             }
         }
@@ -912,7 +918,8 @@ static int launch_wgrad3_pipe(WgradParams& p, float* dw, float* dbias, const flo
 // tiles and W >= 16 | 2: for every 3x3 layer of a one-plane mode (tests)
 template <int PREC>
 static bool wgrad3_pipe_wanted(const WgradParams& p, bool diag_form = false) {
-    if (PREC == LP_PREC_BF16X3 && !diag_form) return false;          // (bf16x3: the diagonal forms of the grouped convs only)
+    static const int x3 = getenv("LP_WGRAD3_X3") ? atoi(getenv("LP_WGRAD3_X3")) : 1;          // dense bf16x3 layers on this kernel (round 6: -4 .. -9 % per layer, profiles/r06_wgrad3_x3.txt; 0: conv_wgrad_kernel)
+    if (PREC == LP_PREC_BF16X3 && !diag_form && !x3) return false;
     static const int mode = getenv("LP_WGRAD3_PIPE") ? atoi(getenv("LP_WGRAD3_PIPE")) : 1;
     static const int min_tiles = getenv("LP_WGRAD3_MIN_TILES") ? atoi(getenv("LP_WGRAD3_MIN_TILES")) : 32;
     if (mode == 0) return false;
@@ -935,10 +942,8 @@ static int dispatch_wgrad(WgradParams& p, float* dw, float* dbias, const float* 
     // 128 output channels per workgroup (8 waves) where the layer is wide enough; LP_WGRAD_COB = 64 | 128 overrides
     static const int cob_env = getenv("LP_WGRAD_COB") ? atoi(getenv("LP_WGRAD_COB")) : 0;
     const bool cob128 = cob_env ? (cob_env == 128) : true;      // measured: -9 % (bf16x3), -6 % (bf16) on the 64..512-channel layers
-    if constexpr (PREC != LP_PREC_BF16X3) {
-        if (ksize == 3 && wgrad3_pipe_wanted<PREC>(p))
-            return upsample ? launch_wgrad3_pipe<true, PREC>(p, dw, dbias, out_scale, sn_w, sn_dot, s) : launch_wgrad3_pipe<false, PREC>(p, dw, dbias, out_scale, sn_w, sn_dot, s);
-    }
+    if (ksize == 3 && wgrad3_pipe_wanted<PREC>(p))
+        return upsample ? launch_wgrad3_pipe<true, PREC>(p, dw, dbias, out_scale, sn_w, sn_dot, s) : launch_wgrad3_pipe<false, PREC>(p, dw, dbias, out_scale, sn_w, sn_dot, s);
     if (cob128 && p.Cout >= 128 && ksize == 3)
         return upsample ? launch_wgrad<3, true, PREC, 128>(p, dw, dbias, out_scale, sn_w, sn_dot, s) : launch_wgrad<3, false, PREC, 128>(p, dw, dbias, out_scale, sn_w, sn_dot, s);
     static const bool w1_old = getenv("LP_WGRAD1X1_OLD") != nullptr;                              // A/B knob: the generic kernel for 1x1 layers

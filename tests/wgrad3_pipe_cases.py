@@ -58,6 +58,8 @@ def run_case(case, prec):
     dw, db = ops.conv_wgrad16(a, d, ksize=3, upsample=bool(ups), prec=prec, splits=splits, bias_grad=True)
     torch.cuda.synchronize()
     A, D = dec(a.hi, prec, cin), dec(d.hi, prec, cout)
+    if prec == 1:          # bf16x3: operands = hi + lo (the kernel drops the lo x lo term: 2^-16 relative)
+        A, D = A + dec(a.lo, prec, cin), D + dec(d.lo, prec, cout)
     if ups:
         A = A.repeat_interleave(2, 2).repeat_interleave(2, 3)
     wgt = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, device=A.device, requires_grad=True)
@@ -95,7 +97,14 @@ def main():
             errs = run_grouped(case, prec)
             print(f'[wgrad3_pipe grouped] prec={prec} {case}: ' + ' '.join(f'{k}={v:.2e}' for k, v in errs.items()), flush=True)
             bad += [(prec, case, k, v) for k, v in errs.items() if not v < 2e-5]
-    for case in GROUPED:                     # bf16x3: the grouped (block-diagonal) forms are the only ones the DMA-staged kernel takes
+    if os.environ.get('LP_WGRAD3_X3', '1') != '0':          # (round 6) the dense bf16x3 layers on the DMA-staged kernel (one workgroup per CU, 512 registers)
+        for case in CASES:
+            if os.environ.get('LP_WGRAD3_PIPE') != '2' and (case[2] < 16 or case[1] < 8):
+                continue
+            errs = run_case(case, 1)
+            print(f'[wgrad3_pipe dense bf16x3 mode={os.environ.get("LP_WGRAD3_PIPE")}] {case}: ' + ' '.join(f'{k}={v:.2e}' for k, v in errs.items()), flush=True)
+            bad += [(1, case, k, v) for k, v in errs.items() if not v < 3e-5]
+    for case in GROUPED:                     # bf16x3 grouped (block-diagonal) forms
         errs = run_grouped(case, 1)
         print(f'[wgrad3_pipe grouped] prec=1 {case}: ' + ' '.join(f'{k}={v:.2e}' for k, v in errs.items()), flush=True)
         bad += [(1, case, k, v) for k, v in errs.items() if not v < 3e-5]
