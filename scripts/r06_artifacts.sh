@@ -33,7 +33,7 @@ for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI
   echo "pmc $tag rc=$?" >> $O/summary.txt
   rm -f $O/${R}_pmc_$tag/${R}_kernel_trace.csv
 done
-GROUPED='conv_dma_kernel<3, (true|false), 4, 1, 4, 4, [0-2], (true|false), [23], 32, true>'
+GROUPED='conv_dma_kernel<3,.* true>$'
 python scripts/pmc_summary.py --json "conv_pipe_kernel|conv_dma_kernel<3" --exclude "$GROUPED" $O/${R}_pmc_*/*counter_collection.csv > $O/${R}_pmc_conv3x3_metatrain.json 2> $O/${R}_pmc_summary.err
 python scripts/pmc_summary.py --json "conv_dma_kernel<1" $O/${R}_pmc_*/*counter_collection.csv > $O/${R}_pmc_conv1x1_metatrain.json 2>> $O/${R}_pmc_summary.err
 python scripts/pmc_summary.py --json "conv_wgrad_kernel|wgrad3_pipe_kernel" $O/${R}_pmc_*/*counter_collection.csv > $O/${R}_pmc_conv_wgrad_metatrain.json 2>> $O/${R}_pmc_summary.err
