@@ -945,7 +945,7 @@ def main():
                           'algorithmic_mb_per_launch': round(agg_bytes.get(kind, 0.0) / max(cnt, 1) / 1e6, 2), 'algorithmic_tflops': round(ach, 1),
                           'traffic_note': 'algorithmic bytes: operand planes read once + weights + the fp32 (and plane) outputs written once; '
                                           'priced against the 8 TB/s HBM3E peak (6.3 TB/s is what a streaming copy reaches on this chip)'})
-            for k_ in ('mfma_per_algorithmic_flop', 'mfma_work_tflops', 'algorithmic_gflop_per_launch'):
+            for k_ in ('mfma_per_algorithmic_flop', 'mfma_work_tflops', 'algorithmic_gflop_per_launch', 'frac_mfma_work', 'by_operand_mode'):
                 entry.pop(k_, None)
         if kind == 'conv_igemm':
             # HBM bytes per launch of this kernel family from the committed PMC passes: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs

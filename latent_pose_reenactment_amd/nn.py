@@ -743,6 +743,10 @@ class Generator(nn.Module):
         self.affine_params_projector = self._build_projector(joint)
         self.finetuning = False
         self.prec = generator_prec() if prec is None else prec
+        # forwards that keep NO autograd state (drive.py, the fine-tuning bootstrap, visualisation under no_grad): only the 1e-3 OUTPUT gate applies,
+        # which fp16 operands meet with a wide margin (fake_rgbs 1.6e-4 at 256 x 256) at a third of the matrix work -- the default assignment's
+        # bf16x3 is for the gradients.  An explicit ``prec`` / LP_PREC_G / a global mode other than f16 applies to every forward.
+        self.infer_prec = self.prec if (prec is not None or os.environ.get('LP_PREC_G') or default_prec() != PREC_F16) else PREC_F16
 
     # ---- the projector is the only part in which the generator plugins differ (noBottleneck.py:96-101 vs FSTH_plus.py:96-103)
     def _build_projector(self, joint):
@@ -866,6 +870,7 @@ class Generator(nn.Module):
         states = self._sn_states
         weights, sn = self._conv_weights(states)
         need_grad = torch.is_grad_enabled() and (affine.requires_grad or any(w.requires_grad for w in weights))
+        prec = self.prec if need_grad else self.infer_prec
         packs = packsT = None
         prepared = self.__dict__.pop('_prepared_packs', None)
         if not torch.is_grad_enabled():
@@ -877,14 +882,14 @@ class Generator(nn.Module):
             # generation counter of the fused optimizer / EMA kernels: those update weights through raw pointers without bumping
             # ``_version`` (a graph replay bumps neither: GraphedTrainStep.__call__ advances the counter itself).
             from .optim import WEIGHTS_GENERATION
-            key = (self.prec, WEIGHTS_GENERATION[0]) + tuple((w.data_ptr(), w._version) for w in weights)
+            key = (prec, WEIGHTS_GENERATION[0]) + tuple((w.data_ptr(), w._version) for w in weights)
             cache = self.__dict__.get('_pack_cache')
             if cache is None or cache[0] != key:
-                cache = (key, [ops.pack_weights(w.detach().contiguous(), 0, self.prec) if s_ is not None else None
+                cache = (key, [ops.pack_weights(w.detach().contiguous(), 0, prec) if s_ is not None else None
                                for w, s_ in zip(weights, sn)])
                 self.__dict__['_pack_cache'] = cache
             packs = cache[1]
-        cfg = dict(blocks=self.blocks_cfg, prec=self.prec, need_grad=need_grad, sn=sn, packs=packs, packsT=packsT,
+        cfg = dict(blocks=self.blocks_cfg, prec=prec, need_grad=need_grad, sn=sn, packs=packs, packsT=packsT,
                    debug=getattr(self, '_debug', None), y16=G_Y16 and self.training and need_grad, reflect=self.reflect)
         rgbs, segm = _DecoderFunction.apply(cfg, affine, self.constant.constant, *weights)
         data_dict['fake_rgbs'] = rgbs

@@ -127,6 +127,8 @@ def test_full_size_metatrain_forward_vs_reference_chain(tmp_path, mode, gate):
           f"| stock fp32 encoders vs fp64: {res['stock_fp32_encoders_vs_fp64']}")
     keep = os.environ.get('LP_PARITY_OUT')        # (scripts: copy the measured figures to profiles/)
     if keep:
+        sys.path.insert(0, ROOT)
+        import bench
         json.dump(res, open(os.path.join(keep, f'{bench.ROUND}_parity_configs2_{mode}.json'), 'w'), indent=1)
     bad = {k: v for k, v in res['errors'].items() if not v < gate}
     assert not bad, bad
