@@ -18,6 +18,7 @@ from latent_pose_reenactment_amd import streams as _streams
 from latent_pose_reenactment_amd.nn import fused_grad_accumulation
 from latent_pose_reenactment_amd.utils import radam as _radam
 from latent_pose_reenactment_amd.utils.utils import Meter, dict_to_device
+from latent_pose_reenactment_amd.utils.tracing import rng
 
 torch.optim.RAdam = _radam.RAdam
 logger = logging.getLogger('runner')
@@ -160,7 +161,7 @@ class TrainingModule(nn.Module):
                 self.discriminator.prepare_step()
         # In fine-tuning the optimizer holds generator parameters only (get_optimizer above, holycow.py:34-41), so the pose
         # encoder's weight gradients are never consumed: run it without autograd (bit-identical parameters afterwards).
-        with torch.set_grad_enabled(torch.is_grad_enabled() and not getattr(generator, 'finetuning', False)):
+        with torch.set_grad_enabled(torch.is_grad_enabled() and not getattr(generator, 'finetuning', False)), rng('forward.embedder'):
             embedder(data_dict)
         # ``_ebwd_cut`` (set by train_step / GraphedTrainStep, one GPU, meta-training): the autograd graph is CUT behind the embedder -- the
         # generator, discriminator and criterions see leaf copies of its outputs, loss_G.backward stops there, and ``embedder_backward()``
@@ -182,7 +183,8 @@ class TrainingModule(nn.Module):
             start_targets()
         if prep is not None and streams.enabled(tgt, 'real', finetuning=ft) and hasattr(self.discriminator, 'start_real_pass'):
             self.discriminator.start_real_pass({**data_dict, **target_dict})
-        generator(data_dict)
+        with rng('forward.generator'):
+            generator(data_dict)
         data_dict.update(target_dict)
         # criterions that touch neither the discriminator nor each other (the two VGG stacks: ``independent_branch``) are issued on side
         # streams BEFORE the discriminator pass, so that their small-map layers fill the gaps of its launches (streams.py)
@@ -191,10 +193,11 @@ class TrainingModule(nn.Module):
         if crit_side and streams.enabled(fake, 'criterions', finetuning=ft):
             for i, criterion in enumerate(self.criterion_list):
                 if getattr(criterion, 'independent_branch', False):
-                    with streams.branch(fake.device, crit_stream.get(i, 1 + len(early))) as b:
+                    with streams.branch(fake.device, crit_stream.get(i, 1 + len(early))) as b, rng('forward.criterion.' + type(criterion).__module__.split('.')[-1]):
                         early[i] = (b, criterion(data_dict))
         if self.compute_losses:
-            self.discriminator(data_dict)
+            with rng('forward.discriminator'):
+                self.discriminator(data_dict)
         losses_G, losses_D = {}, {}
         for i, criterion in enumerate(self.criterion_list):
             try:
@@ -204,7 +207,8 @@ class TrainingModule(nn.Module):
                 else:
                     if ahead and i in crit_stream:          # target features were computed on a side stream, the criterion itself runs here
                         torch.cuda.current_stream(tgt.device).wait_stream(streams.side_stream(tgt.device, crit_stream[i]))
-                    out = criterion(data_dict)
+                    with rng('forward.criterion.' + type(criterion).__module__.split('.')[-1]):
+                        out = criterion(data_dict)
             except Exception:
                 if self.compute_losses:
                     raise
@@ -259,7 +263,7 @@ def train_step(training_module, data_dict, target_dict, optimizer_G, optimizer_D
     loss_G = sum(v for v in losses_G.values() if isinstance(v, torch.Tensor))
     loss_D = sum(v for v in losses_D.values() if isinstance(v, torch.Tensor))
     optimizer_G.zero_grad()
-    with fused_grad_accumulation():
+    with fused_grad_accumulation(), rng('backward.loss_G'):
         loss_G.backward(retain_graph=True)
     _streams.join_all()
     if ebwd and losses_D:
@@ -269,46 +273,58 @@ def train_step(training_module, data_dict, target_dict, optimizer_G, optimizer_D
         dev = next(training_module.generator.parameters()).device
         with _streams.branch(dev, 8) as b:
             optimizer_D.zero_grad()
-            with fused_grad_accumulation():
+            with fused_grad_accumulation(), rng('backward.loss_D'):
                 loss_D.backward()
             _streams.join_all()
-        with fused_grad_accumulation():
+        with fused_grad_accumulation(), rng('backward.embedder'):
             training_module.embedder_backward()
         _streams.join_all()
         b.join()
-        optimizer_G.step()
-        optimizer_D.step()
-        training_module.update_running_average(0.972 if args.finetune else 0.999)
+        with rng('optimizer_G.step'):
+            optimizer_G.step()
+        with rng('optimizer_D.step'):
+            optimizer_D.step()
+        with rng('ema'):
+            training_module.update_running_average(0.972 if args.finetune else 0.999)
         return all_data, losses_G, losses_D
     if split:
         # data parallel, meta-training: the backward pass was cut behind the embedder -- the generator's gradients (the first 150 MB of the
         # generator-side arena) are final NOW and go out as their own bucket; the encoders' backward (>= 10 ms of kernels) runs while that
         # all-reduce is on the links, then the encoders' bucket follows; both hide behind zero_grad(D) + loss_D.backward
-        reducer.reduce_generator_side(async_op=True, part='generator')
-        with fused_grad_accumulation():
+        with rng('all_reduce.generator_bucket.issue'):
+            reducer.reduce_generator_side(async_op=True, part='generator')
+        with fused_grad_accumulation(), rng('backward.embedder'):
             training_module.embedder_backward()
         _streams.join_all()
-        reducer.reduce_generator_side(async_op=True, part='embedder')
+        with rng('all_reduce.encoder_bucket.issue'):
+            reducer.reduce_generator_side(async_op=True, part='embedder')
     else:
-        with fused_grad_accumulation():
+        with fused_grad_accumulation(), rng('backward.embedder'):
             training_module.embedder_backward()          # (cut without a discriminator-side loss: finish the backward pass here)
         if multi:
-            reducer.reduce_generator_side(async_op=True)
+            with rng('all_reduce.generator_side.issue'):
+                reducer.reduce_generator_side(async_op=True)
         else:
-            optimizer_G.step()
+            with rng('optimizer_G.step'):
+                optimizer_G.step()
     if losses_D:
         optimizer_D.zero_grad()
-        with fused_grad_accumulation():
+        with fused_grad_accumulation(), rng('backward.loss_D'):
             loss_D.backward()
         _streams.join_all()
     if multi:
-        reducer.wait_generator_side()
-        optimizer_G.step()
+        with rng('all_reduce.generator_side.wait'):
+            reducer.wait_generator_side()
+        with rng('optimizer_G.step'):
+            optimizer_G.step()
     if losses_D:
         if multi:
-            reducer.reduce_discriminator_side()
-        optimizer_D.step()
-    training_module.update_running_average(0.972 if args.finetune else 0.999)
+            with rng('all_reduce.discriminator_side'):
+                reducer.reduce_discriminator_side()
+        with rng('optimizer_D.step'):
+            optimizer_D.step()
+    with rng('ema'):
+        training_module.update_running_average(0.972 if args.finetune else 0.999)
     return all_data, losses_G, losses_D
 
 

@@ -34,12 +34,14 @@ def enabled(t, what: str, finetuning: bool = False) -> bool:
     autograd graph behind the embedder)"""
     if not (torch.is_tensor(t) and t.is_cuda) or os.environ.get('LP_OVERLAP', '1') == '0':
         return False
-    # 'ebwd': measured null on the captured full-size step (42.9 / 43.5 ms on vs 43.4 / 43.5 ms off, profiles/r04_stream_overlap.txt): the
-    # encoders' backward and the discriminator's backward are both bound by HBM traffic -- off
+    # 'ebwd': measured null in round 4 (42.9 / 43.5 ms on vs 43.4 / 43.5 ms off, profiles/r04_stream_overlap.txt: both backward passes bound by HBM
+    # traffic with an all-fp16 critic)
     # 'real' (round 4): the critic's pass over the REAL image issued beside the generator's forward (whose 4x4 .. 32x32 layers leave most of the
     # chip idle) instead of beside the other two passes: 42.2 -> 41.75 ms; the VGG target halves at the same place ('targets' = 2): 42.2 -> 42.0,
     # not additive (profiles/r04_stream_overlap.txt)
-    default = '0' if (what in ('optimizer', 'wgrad', 'targets', 'ebwd') or (what in ('criterions', 'prepare', 'dpasses', 'real') and finetuning)) else '1'
+    # round 6: with the generator and the critic's D-side tail on bf16x3 operands the discriminator-side backward is matrix-bound enough to run
+    # beside the encoders' bandwidth-bound backward: 43.11 / 43.09 / 43.24 ms off vs 42.71 / 42.06 / 42.62 ms on (profiles/r06_stream_overlap.txt) -- ON
+    default = '0' if (what in ('optimizer', 'wgrad', 'targets') or (what in ('criterions', 'prepare', 'dpasses', 'real', 'ebwd') and finetuning)) else '1'
     return os.environ.get('LP_OVERLAP_' + what.upper(), default) != '0'
 
 

@@ -289,3 +289,15 @@ def test_resnext_operand_modes_per_block_and_per_contraction(monkeypatch):
     assert lp[(last, 'conv1')] == lp[(last, 'conv2')] == f16
     monkeypatch.setenv('LP_E_F16_TAIL', '0')
     assert net.block_precs() == [x3] * 16
+
+
+def test_roctx_ranges_are_a_noop_when_off_and_bind_libroctx_when_on():
+    """utils/tracing.py (SURVEY 5 tracing row): LP_ROCTX=1 brackets the step's phases with roctxRangePushA / roctxRangePop of the ROCm installation
+    (ctypes; no GPU needed to push a range), and without the variable ``rng`` costs one generator frame"""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\nfrom latent_pose_reenactment_amd.utils import tracing\n"
+            "with tracing.rng('probe'):\n    pass\nprint('enabled', tracing.enabled())") % ROOT
+    for flag, want in (('0', 'enabled False'), ('1', 'enabled True')):
+        r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, LP_ROCTX=flag), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and want in r.stdout, (flag, r.stdout, r.stderr[-500:])

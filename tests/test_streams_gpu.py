@@ -96,7 +96,7 @@ def _train_step_grads(monkeypatch, env):
 
 
 def test_embedder_backward_beside_the_discriminator_backward_reproduces_the_step(monkeypatch):
-    """LP_OVERLAP_EBWD=1 (off by default: measured null): train_step cuts the autograd graph behind the embedder and runs the encoders' backward
+    """LP_OVERLAP_EBWD (default ON since round 6: -0.7 ms, profiles/r06_stream_overlap.txt): train_step cuts the autograd graph behind the embedder and runs the encoders' backward
     on a side stream beside loss_D.backward -- same gradients as the uncut step"""
     plain = _train_step_grads(monkeypatch, {'LP_OVERLAP_EBWD': '0'})
     again = _train_step_grads(monkeypatch, {'LP_OVERLAP_EBWD': '0'})
