@@ -488,6 +488,17 @@ static int dispatch_conv16(Conv16Params& p, int ks, int ups, hipStream_t s) {
         if (ks == 3 && ups) return launch_conv16<3, true, 2, 4, 4, 2, PREC>(p, s);
         if (ks == 1 && !ups) return launch_conv16<1, false, 2, 4, 4, 2, PREC>(p, s);
     }
+    if (PREC == LP_PREC_BF16X3 && ks == 3 && p.Cout > 64) {
+        // bf16x3 layers whose paired (ping-pong) grid would not cover the chip (e.g. 32 x 32 x 512 at N = 8: 256 workgroups of 128 x 128) fall to the
+        // single-group kernel, whose doubled weight stages do not fit a 3-deep ring either: the same 128 x 64 four-wave tile as the small maps
+        // (LP_CONV_X3_BN64=2 enables it; measured in profiles/r06_x3_small_maps.txt)
+        static const int x3mid = getenv("LP_CONV_X3_BN64") ? atoi(getenv("LP_CONV_X3_BN64")) : 1;
+        const long long tiles128 = ((long long)p.N * p.H * p.W + 127) / 128;
+        if (x3mid >= 2 && ((tiles128 + 1) / 2) * ((p.Cout + 127) / 128) < 200) {
+            if (!ups) return launch_conv16<3, false, 2, 2, 4, 2, PREC>(p, s);
+            return launch_conv16<3, true, 2, 2, 4, 2, PREC>(p, s);
+        }
+    }
     if (ks == 3 && !ups) {
         if (p.Cout <= 16 && big_img) return launch_conv16<3, false, 4, 1, 4, 1, PREC>(p, s);
         if (p.Cout <= 64 && big_img) return launch_conv16<3, false, 4, 1, 4, 4, PREC>(p, s);
