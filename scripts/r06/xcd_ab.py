@@ -25,7 +25,6 @@ for prec in (2, 1):
         a = ops.act_pack(x, pro=2, prec=prec)
         pack = ops.pack_weights(wt, 0, prec)
         res = torch.randn(n, h, w, cout, generator=g).cuda()
-        print('[xcd-ab] running', prec, n, h, w, cin, cout, ups, flush=True)
         y = ops.conv16(a, pack, ksize=3, upsample=bool(ups), res=res, prec=prec, stats=True)
         y = y if isinstance(y, tuple) else (y,)
         torch.cuda.synchronize()
