@@ -960,7 +960,7 @@ def main():
                 entry['traffic_read_write'] = {'hbm_read_bytes_per_launch': pm.get('hbm_read_bytes_per_launch'), 'hbm_write_bytes_per_launch': pm.get('hbm_write_bytes_per_launch'),
                                                'algorithmic_read_bytes_per_launch': None if not rw else int(rw[0] / rw[2]),
                                                'algorithmic_write_bytes_per_launch': None if not rw else int(rw[1] / rw[2]),
-                                               'family': 'dense 3x3 forward / dgrad: conv_pipe_kernel + conv_dma_kernel<3> without the grouped (identity-encoder) instantiations',
+                                               'family': 'dense 3x3 forward / dgrad: conv_pipe_kernel + conv_dma_kernel<3> (+ <2>: the phase forms of the x2-upsampled convs) without the grouped (identity-encoder) instantiations',
                                                'read_amplification': None if not (rw and pm.get('hbm_read_bytes_per_launch')) else round(pm['hbm_read_bytes_per_launch'] / (rw[0] / rw[2]), 2)}
                 entry['traffic_note'] = ('mean HBM bytes per DENSE 3x3 conv launch (conv_pipe_kernel + conv_dma_kernel<3>, grouped instantiations excluded) over the launch population of the '
                                          'meta-training step (warm-up, capture and replays of `bench.py --steps 2 --warmup 1`): profiles/' + ROUND + '_pmc_conv3x3_metatrain.json, '

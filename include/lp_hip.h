@@ -32,13 +32,18 @@ int lp_abi_version(void);
 /* Re-layout + 16-bit conversion of a conv/linear weight.  w: fp32 [Cout][Cin][T] (reference nn.Conv2d layout, T = k*k).
  * mode 0 (forward):  out[t][co][ci] = w[co][ci][t]            rows padded to CoutP (x128), cols to CinP (x32)
  * mode 1 (dgrad):    out[T-1-t][ci][co] = w[co][ci][t]        rows = Cin padded to RowsP, cols = Cout padded to ColsP
+ * modes 2 / 3 (ABI 10; T = 9 in, SIXTEEN taps out, t = phase * 4 + i * 2 + j): the phase form of nn.Upsample(scale_factor=2) + 3x3 conv
+ *   (generators/common/blocks.py:74-88).  Output pixel (2y + a, 2x + b), phase = 2a + b, only meets the low-resolution pixels
+ *   (y + a - 1 + i, x + b - 1 + j); the taps that meet the same pixel are summed in fp32 before the 16-bit split.
+ *   mode 2 (forward): out[t][co][ci];  mode 3 (data gradient): out[t][ci][co] = the (phase, 1 - i, 1 - j) sums.
+ *   Consumed by lp_conv16_fwd(_stats) with upsample = 2 (forward) / 3 (data gradient): 4/9 of the matrix work of the fused-upsample conv.
  * f16 = 0: hi = bf16(w), lo = bf16(w - hi) (may be NULL);  f16 = 1: hi = fp16(w) (saturating), lo unused.
  * Replaces nothing in the reference (cuDNN does this internally). */
 int lp_pack_weights(const float* w, uint16_t* hi, uint16_t* lo, int Cout, int Cin, int T, int RowsP, int ColsP, int mode, int f16,
                     void* stream);
 /* batched: table = DEVICE array of {const float* w; uint16_t* hi; uint16_t* lo; int Cout, Cin, T, RowsP, ColsP, mode, chunk0, f16;}
  * (lp_pack_desc_bytes() each); one launch packs every (weight, orientation) entry -- all convs of a module after an optimizer step.
- * The grid is flat over 1024-element chunks: chunk0 = sum of ceil(T*RowsP*ColsP/1024) of the preceding entries (ascending),
+ * The grid is flat over 1024-element chunks: chunk0 = sum of ceil(T'*RowsP*ColsP/1024) of the preceding entries (ascending; T' = 16 for modes 2 / 3),
  * total_chunks = that sum over all entries. */
 int lp_pack_desc_bytes(void);
 int lp_pack_weights_batch(const void* table, int num_entries, long long total_chunks, void* stream);
@@ -78,7 +83,12 @@ int lp_amax_partial(const float* x, long long numel, float* part, void* stream);
  *   the operand of the conv whose data gradient this launch computes (replaces a dx = dA * (x > 0) pass; blocks.py:71-73,84).
  *   out_hi/out_lo [N][H][W][Co8]|NULL: also emit the operand planes of (out_relu ? relu(y) : y) for the consumer conv.
  *   workspace (lp_conv16_fwd_workspace_bytes(); 0 = never needed) | NULL: split-K partial tiles for the layers whose output tiling
- *   cannot fill the chip (4x4 .. 16x16 maps); without it those layers run unsplit. */
+ *   cannot fill the chip (4x4 .. 16x16 maps); without it those layers run unsplit.
+ *   upsample (ABI 10): 0 | 1 (fused nearest x2 in front of the 3x3 conv) | 2: the same conv in its PHASE form -- w = an lp_pack_weights mode-2
+ *   image (16 taps), per output phase a 2 x 2 conv on the low-resolution planes: identical result up to the fp32 summation of coinciding taps,
+ *   4/9 of the matrix work | 3: the phase form of its DATA GRADIENT -- a = dy planes [N][2H][2W][C8], w = a mode-3 image, y = the gradient
+ *   w.r.t. the LOW-resolution input [N][H][W][Cout] (the 2 x 2 sum of the upsample's adjoint included): replaces the 3x3 data-gradient conv on
+ *   the 2H x 2W grid + lp_sum2x2 / the upsample flag of lp_adain_relu_bwd. */
 int lp_conv16_fwd(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* w_hi, const uint16_t* w_lo, float* y,
                   const float* bias, const float* res, const float* alpha, const float* alpha2,
                   int N, int H, int W, int Cin, int Cout, int CinP, int CoutP,

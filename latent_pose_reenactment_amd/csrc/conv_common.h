@@ -27,6 +27,11 @@ struct Conv16Params {
     int xcd_map, ntiles, nco;     // xcd_map: 1-D grid of 8 * ceil(ntiles / 8) * nco workgroups; workgroup id -> XCD id & 7 (round-robin dispatch), and on
                                   // that XCD the Cout blocks of ONE pixel tile run back to back, the XCD's tiles being a contiguous range: the halo
                                   // a tile's nco workgroups share (and the rows neighbouring tiles share) is fetched from HBM once, into one L2
+    int phase;                    // 1: PHASE-DECOMPOSED x2-upsampled 3x3 conv (round 6; KS = 2 kernels): output pixel (2y + a, 2x + b) of the conv over the
+                                  // nearest-upsampled input only meets the 2 x 2 low-resolution pixels (y + a - 1 + i, x + b - 1 + j), with the
+                                  // 3 x 3 taps that fall on the same pixel pre-summed -- 4/9 of the matrix work, exact algebra.  Tiles cover the
+                                  // LOW-resolution grid (Hin x Win) once per phase (tile index: x, y, phase, image); the weight image holds
+                                  // [4 phases][2 x 2 taps][CoutP][CinP]; the epilogue writes to the phase's position of the H x W output
     int grouped;                  // block-diagonal (grouped) conv: the workgroup's 64 output channels only see input channels co0 .. co0+63;
                                   // the weight image then has 64 columns (CinP = 64) and the activation channel offset is co0
 };
@@ -78,7 +83,7 @@ int lp_conv1x1_pipe_launch(Conv16Params& p, int prec, hipStream_t s);      // th
 // {count, mean, M2} partials, or the raw split-K partial tile.  Must be called by every wave of the workgroup.
 template <int WM, int WN, int MR, int NR, int PREC, int MRP>
 __device__ __forceinline__ void conv16_epilogue(const Conv16Params& p, f32x4_t (&acc)[MR][NR], unsigned char* smem, int wave_d, int wm, int wn,
-                                                int lane, int n0, int y0, int x0, int co0, int NBv, int tile_index) {
+                                                int lane, int n0, int y0, int x0, int co0, int NBv, int tile_index, int ph = -1) {
     constexpr bool SPLIT = (PREC == LP_PREC_BF16X3), F16 = (PREC == LP_PREC_F16);
     float alpha = p.alpha ? *p.alpha : 1.f;
     if (p.alpha2) alpha *= *p.alpha2;
@@ -116,8 +121,12 @@ __device__ __forceinline__ void conv16_epilogue(const Conv16Params& p, f32x4_t (
             const int m = wm * WR + row;
             int nb, py, px;
             tile_row_linear(m, p.lTH, p.lTW, nb, py, px);
-            const int n = n0 + nb, oyy = y0 + py, oxx = x0 + px;
-            if (nb < NBv && n < p.N && oyy < p.H && oxx < p.W && co < p.Cout) {
+            const int n = n0 + nb;
+            int oyy = y0 + py, oxx = x0 + px;
+            bool inside = nb < NBv && n < p.N && co < p.Cout;
+            if (ph >= 0) { inside = inside && oyy < p.Hin && oxx < p.Win; oyy = 2 * oyy + (ph >> 1); oxx = 2 * oxx + (ph & 1); }      // (phase mode: tile rows are low-resolution positions)
+            else inside = inside && oyy < p.H && oxx < p.W;
+            if (inside) {
                 float4 v = *(const float4*)(tile + (row - mp * 16) * LDW + c4 * 4);
                 if (p.ksplit > 1) {        // split-K: the raw partial tile; splitk_reduce_kernel sums the slices and applies the epilogue
                     const size_t pixs = (size_t)(n * p.H + oyy) * p.W + oxx;

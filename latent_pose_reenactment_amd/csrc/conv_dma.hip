@@ -65,8 +65,9 @@ void conv_dma_kernel(Conv16Params p) {
     constexpr int NBW = ((NQ + NWD - 1) / NWD) * (SPLIT ? 2 : 1);     // weight DMA instructions one wave issues per stage
     static_assert(B_STAGE % 1024 == 0, "stage must be a whole number of 1 KiB DMA pieces");
     static_assert(NBUF == 2 || (NBUF == 3 && !PP && NQ % NWD == 0), "3-deep weight ring: single group, uniform DMA count per wave");
-    static_assert(!PP || (KS == 3 && NWAVE == 4), "ping-pong: two 4-wave groups, 3x3");
-    static_assert(!(UPS && KS == 1), "1x1 convs commute with nearest upsampling: run them at low resolution");
+    static_assert(!PP || ((KS == 3 || KS == 2) && NWAVE == 4), "ping-pong: two 4-wave groups, 3x3 (or the 2x2 phase form)");
+    static_assert(!(UPS && KS != 3), "1x1 convs commute with nearest upsampling: run them at low resolution; KS = 2 IS the phase form of an upsampled 3x3 conv");
+    static_assert(KS == 1 || KS == 2 || KS == 3, "kernel sizes");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -82,12 +83,18 @@ void conv_dma_kernel(Conv16Params p) {
     if (PP) tile_id = tile_id * 2 + grp;
     int t = tile_id;
     const int tx = t % p.tiles_x; t /= p.tiles_x;
-    const int ty = t % p.tiles_y; const int ng = t / p.tiles_y;
+    const int ty = t % p.tiles_y; t /= p.tiles_y;
+    int ph = -1;                                         // KS == 2: phase (a, b) = (ph >> 1, ph & 1) of the x2-upsampled output this tile writes
+    const bool pdg = (KS == 2) && (p.phase == 2);       // phase form of the DATA GRADIENT: the K loop runs over (phase, channel chunk), output = low-res dx
+    if (KS == 2 && !pdg) { ph = t & 3; t >>= 2; }
+    const int ng = t;
     const int n0 = ng << p.lNB, y0 = ty << p.lTH, x0 = tx << p.lTW;
     const int co0 = cob * BN;
 
     int HH, HW, oy, ox;
     if (KS == 1) { HH = TH; HW = TW; oy = y0; ox = x0; }
+    else if (KS == 2) { HH = TH + 1; HW = TW + 1; oy = y0 + (ph >> 1) - 1; ox = x0 + (ph & 1) - 1; }      // (tiles and halo on the LOW-resolution grid;
+                                                                                                             //  data gradient: origin per phase, issue_a_pd)
     else if (UPS) { HH = (TH >> 1) + 2; HW = (TW >> 1) + 2; oy = (y0 >> 1) - 1; ox = (x0 >> 1) - 1; }
     else { HH = TH + 2; HW = TW + 2; oy = y0 - 1; ox = x0 - 1; }
     const int halo_px = NBv * HH * HW;
@@ -150,9 +157,38 @@ void conv_dma_kernel(Conv16Params p) {
             }
         }
     };
+    // phase form of the data gradient (KS == 2, p.phase == 2): chunk = (phase, channel chunk of dy); the halo of phase (a, b) is the (TH + 1) x
+    // (TW + 1) patch of the PHASE-SUBSAMPLED dy with origin (y0 - a, x0 - b): halo pixel (hy, hx) = dy pixel (2 (y0 - a + hy) + a, 2 (x0 - b + hx) + b)
+    // of the [N][Hin = 2H][Win = 2W] planes -- a stride-2 gather by the DMA lanes; the per-lane geometry is re-derived per chunk (a few integer
+    // operations per 1 KiB piece) instead of being held in registers for four phases
+    const int nch1 = p.CinP / CC;                          // channel chunks (per phase)
+    auto issue_a_pd = [&](int chunk, unsigned char* Hbuf) {
+        const int phq = chunk / nch1, c0 = (chunk - phq * nch1) * CC;
+        const int pa = phq >> 1, pb = phq & 1;
+        const bool cok = (c0 + a_g8) < p.C8;
+        const unsigned dst = (unsigned)(uintptr_t)Hbuf;
+#pragma unroll
+        for (int k = 0; k < AIT; ++k) {
+            if (k < p.hit) {
+                const int hp = (k * NWAVE + wave) * RPI + lane / SL;
+                const int hx = hp % HW, t2 = hp / HW;
+                const int hy = t2 % HH, nb = t2 / HH;
+                const int n = n0 + nb, iy = y0 - pa + hy, ix = x0 - pb + hx;          // low-resolution position inside phase (pa, pb)
+                const bool ok = cok && (hp < halo_px) && (n < p.N) && (iy >= 0) && (iy < p.H) && (ix >= 0) && (ix < p.W);
+                const size_t off = ok ? ((size_t)((n * p.Hin + 2 * iy + pa) * p.Win + 2 * ix + pb) * p.C8 + a_g8 + c0) : 0;
+                const unsigned d = dst + (unsigned)((k * NWAVE + wave) * 1024);
+                lp_glds16(ok ? (p.a_hi + off) : zero16, d);
+                if (SPLIT) lp_glds16(ok ? (p.a_lo + off) : zero16, d + a_bytes);
+            }
+        }
+    };
+    auto issue_halo = [&](int chunk, unsigned char* Hbuf) {
+        if (KS == 2 && pdg) issue_a_pd(chunk, Hbuf); else issue_a(chunk, Hbuf);
+    };
     // LDS-DMA of the weight tile of stage (chunk, ky) into stage buffer `buf`: piece q covers rows 16q .. 16q+15 of [KS*BN][32]
     auto issue_b = [&](int chunk, int ky, int buf) {
-        const int c0 = chunk * CC;
+        const int phw = (KS == 2) ? (pdg ? chunk / nch1 : ph) : 0;          // phase whose 2 x 2 tap images this stage reads
+        const int c0 = (KS == 2 && pdg ? chunk - phw * nch1 : chunk) * CC;
         const unsigned dst_lds = (unsigned)(uintptr_t)(B_base + buf * B_BUF);
         const int rr = lane / SL, slot = lane % SL;
         const int g8 = (slot ^ rkey(rr)) * 8;
@@ -162,7 +198,7 @@ void conv_dma_kernel(Conv16Params p) {
             if (NQ % NWD == 0 || q < NQ) {
                 const int r = q * RPI + rr;                                          // row inside the stage: kx * BN + n
                 const int kx = r / BN, n = r % BN;
-                const size_t off = ((size_t)((ky * KS + kx) * p.CoutP + co0 + n) * p.CinP + c0 + g8);
+                const size_t off = ((size_t)(((KS == 2 ? phw * 4 : 0) + ky * KS + kx) * p.CoutP + co0 + n) * p.CinP + c0 + g8);
                 lp_glds16(p.w_hi + off, dst_lds + q * 1024);
                 if (SPLIT) lp_glds16(p.w_lo + off, dst_lds + B_STAGE + q * 1024);
             }
@@ -180,7 +216,7 @@ void conv_dma_kernel(Conv16Params p) {
         constexpr int STEPS = KS * KK;
         auto fetch = [&](int st, int set) {
             const int kx = st / KK, kk = st % KK;
-            const int dy = (KS == 3) ? ky : 0, dx = (KS == 3) ? kx : 0;
+            const int dy = (KS >= 2) ? ky : 0, dx = (KS >= 2) ? kx : 0;
             const unsigned char* Bk = Bc + kx * (BN * ROWB);
             const int grp8 = kk * 4 + kb;                                  // 8-channel group of this lane's fragment slice
 #pragma unroll
@@ -229,14 +265,14 @@ void conv_dma_kernel(Conv16Params p) {
         else compute_h(ky, Hbuf, bbuf, std::integral_constant<int, 0>{});
     };
 
-    const int nch_total = p.CinP / CC;
+    const int nch_total = (p.CinP / CC) * ((KS == 2 && pdg) ? 4 : 1);
     const int per = (nch_total + p.ksplit - 1) / p.ksplit;
     const int cbeg = blockIdx.z * per;
     const int nch = min(nch_total, cbeg + per) - cbeg;        // chunks of this workgroup: [cbeg, cbeg + nch)
     if (nch <= 0) return;                                       // (uniform) nothing to contribute
     const int S = nch * KS;
     issue_b(cbeg, 0, 0);
-    issue_a(cbeg, H_base);
+    issue_halo(cbeg, H_base);
 
     if constexpr (PP) {
         // slot k = stage k of both groups.  Phase A(k): group 0 multiplies stage k, group 1 stages; phase B(k): swapped.  Staging
@@ -255,7 +291,7 @@ void conv_dma_kernel(Conv16Params p) {
                 if (grp == 0) {
                     compute(ky, H_base, bbuf, cbeg + chunk);
                 } else {
-                    if (ky == 0 && chunk > 0) issue_a(cbeg + chunk, H_base);
+                    if (ky == 0 && chunk > 0) issue_halo(cbeg + chunk, H_base);
                     if (k + 1 < S) issue_b(cbeg + (k + 1) / KS, (k + 1) % KS, bbuf ^ 1);
                 }
                 lp_wait_vm0();
@@ -263,7 +299,7 @@ void conv_dma_kernel(Conv16Params p) {
                 if (grp == 1) {
                     compute(ky, H_base, bbuf, cbeg + chunk);
                 } else {
-                    if (ky == KS - 1 && has_next) issue_a(cbeg + chunk + 1, H_base);
+                    if (ky == KS - 1 && has_next) issue_halo(cbeg + chunk + 1, H_base);
                     if (k + 1 < S) issue_b(cbeg + (k + 1) / KS, (k + 1) % KS, bbuf ^ 1);
                 }
             }
@@ -285,13 +321,13 @@ void conv_dma_kernel(Conv16Params p) {
                 if (NBUF == 3 && s + 1 < S && p.a_dbuf) lp_wait_vm<NBW>(); else lp_wait_vm0();
                 __syncthreads();
                 // (halo first: it is older than the weights issued below, so the counted wait of the next stage covers it)
-                if (p.a_dbuf && ky == 0 && has_next) issue_a(cbeg + chunk + 1, H_base + (abuf ^ 1) * a_buf);
+                if (p.a_dbuf && ky == 0 && has_next) issue_halo(cbeg + chunk + 1, H_base + (abuf ^ 1) * a_buf);
                 const int sp = s + NBUF - 1;
                 if (sp < S) issue_b(cbeg + sp / KS, sp % KS, sp % NBUF);
                 compute(ky, H_base + abuf * a_buf, s % NBUF, cbeg + chunk);
                 if (!p.a_dbuf && ky == KS - 1 && has_next) {      // (LDS-tight tiles) one halo buffer: restage it once everyone has read it
                     __syncthreads();
-                    issue_a(cbeg + chunk + 1, H_base);
+                    issue_halo(cbeg + chunk + 1, H_base);
                 }
             }
             if (p.a_dbuf) abuf ^= 1;
@@ -299,7 +335,7 @@ void conv_dma_kernel(Conv16Params p) {
     }
 
     // ---- epilogue (conv_common.h).  1x1 layers transpose 16 rows (one MFMA row block) at a time, 3x3 kernels the whole block
-    conv16_epilogue<WM, WN, MR, NR, PREC, (KS == 1) ? 1 : MR>(p, acc, smem, wave_d, wm, wn, lane, n0, y0, x0, co0, NBv, tile_id);
+    conv16_epilogue<WM, WN, MR, NR, PREC, (KS == 1) ? 1 : MR>(p, acc, smem, wave_d, wm, wn, lane, n0, y0, x0, co0, NBv, tile_id, ph);
 }
 
 // Split-K finish: y = alpha * sum_s part[s] + bias + res, ReLU mask, 16-bit planes of the consumer -- the whole epilogue of the conv,
@@ -382,17 +418,20 @@ static int launch_conv16(Conv16Params& p, hipStream_t stream) {
     constexpr size_t LDS_MAX = 160 * 1024;
     constexpr int AIT = ((BM == 128) ? (NWAVE == 8 ? 3 : 5) : 6) * (CC / 32) - (CC == 64 ? 1 : 0);
     if (p.CinP % CC) return lp_set_error(LP_ERR_ARG, "conv16: padded input channels must be a multiple of the chunk size");
-    choose_tile(BM, p.N, p.H, p.W, &p.lTH, &p.lTW, &p.lNB);
+    const bool phf = (KS == 2) && p.phase == 1, phd = (KS == 2) && p.phase == 2;          // phase forms: forward | data gradient
+    const int GHt = phf ? p.Hin : p.H, GWt = phf ? p.Win : p.W;          // the grid the tiles cover (forward phase form: the low-resolution INPUT grid;
+                                                                         //  data gradient: its low-resolution OUTPUT, p.H x p.W as always)
+    choose_tile(BM, p.N, GHt, GWt, &p.lTH, &p.lTW, &p.lNB);
     int HH, HW, halo_px;
     for (;;) {       // fewer images per tile until the halo fits the per-wave descriptor budget (tiny feature maps)
         const int TH = 1 << p.lTH, TW = 1 << p.lTW, NBv = 1 << p.lNB;
-        if (KS == 1) { HH = TH; HW = TW; } else if (UPS) { HH = TH / 2 + 2; HW = TW / 2 + 2; } else { HH = TH + 2; HW = TW + 2; }
+        if (KS == 1) { HH = TH; HW = TW; } else if (KS == 2) { HH = TH + 1; HW = TW + 1; } else if (UPS) { HH = TH / 2 + 2; HW = TW / 2 + 2; } else { HH = TH + 2; HW = TW + 2; }
         halo_px = NBv * HH * HW;
         if ((halo_px + RPI - 1) / RPI <= AIT * NWAVE || p.lNB == 0) break;
         --p.lNB;
     }
     const int TH = 1 << p.lTH, TW = 1 << p.lTW, NBv = 1 << p.lNB;
-    p.tiles_x = (p.W + TW - 1) / TW; p.tiles_y = (p.H + TH - 1) / TH;
+    p.tiles_x = (GWt + TW - 1) / TW; p.tiles_y = (GHt + TH - 1) / TH;
     const int NH = (halo_px + RPI - 1) / RPI;
     p.hit = (NH + NWAVE - 1) / NWAVE;
     if (p.hit > AIT) return lp_set_error(LP_ERR_UNSUPPORTED, "conv16: halo exceeds the DMA descriptor budget");
@@ -406,12 +445,13 @@ static int launch_conv16(Conv16Params& p, hipStream_t stream) {
     const size_t lds_halo = (p.a_dbuf ? 2 : 1) * a_buf;
     size_t lds = lds_halo + 2 * B_BUF;
     size_t epi = (size_t)NWAVE * ((KS == 1) ? 16 : MR * 16) * (NR * 16 + 4) * sizeof(float);      // LDS transpose of the coalesced epilogue (1x1: 16 rows per wave at a time)
-    const int tiles = p.tiles_x * p.tiles_y * ((p.N + NBv - 1) / NBv);
+    const int tiles = p.tiles_x * p.tiles_y * ((p.N + NBv - 1) / NBv) * (phf ? 4 : 1);          // (forward phase form: every tile position once per phase)
     // ping-pong: two adjacent M tiles per workgroup, when the paired grid still covers the CUs.  LP_CONV_PP = 0 | 1 overrides.
-    constexpr bool pp_ok = (KS == 3) && (NWAVE == 4);
+    constexpr bool pp_ok = (KS == 3 || KS == 2) && (NWAVE == 4);
     static const int pp_env = getenv("LP_CONV_PP") ? atoi(getenv("LP_CONV_PP")) : -1;
     const long long pp_wgs = (long long)((tiles + 1) / 2) * ((p.Cout + BN - 1) / BN);
-    const bool pp = pp_ok && (pp_env >= 0 ? pp_env != 0 : pp_wgs >= 200) && tiles >= 2 && p.a_dbuf;
+    // (the two groups of a ping-pong workgroup share their weight stages: in the phase form a pair of tiles must not straddle two phases)
+    const bool pp = pp_ok && (pp_env >= 0 ? pp_env != 0 : pp_wgs >= 200) && tiles >= 2 && p.a_dbuf && (!phf || ((p.tiles_x * p.tiles_y) & 1) == 0);
     if (pp) epi *= 2;
     if (lds < epi) lds = epi;
     if (lds > LDS_MAX) return lp_set_error(LP_ERR_UNSUPPORTED, "conv16 tile needs too much LDS");
@@ -422,9 +462,9 @@ static int launch_conv16(Conv16Params& p, hipStream_t stream) {
         // 1x1 convs are not split: their whole contraction is 16 stages, less than the cost of a second launch.
         static const int max_split = getenv("LP_CONV_KSPLIT") ? atoi(getenv("LP_CONV_KSPLIT")) : 8;
         static const int split_wgs = getenv("LP_CONV_SPLIT_WGS") ? atoi(getenv("LP_CONV_SPLIT_WGS")) : 256;   // split while <= this many workgroups result
-        const int wgs = grid.x * grid.y, nch = p.CinP / CC;
+        const int wgs = grid.x * grid.y, nch = (p.CinP / CC) * (phd ? 4 : 1);
         int ks = 1;
-        if (KS == 3 && (p.Cout & 3) == 0 && p.part)
+        if ((KS == 3 || KS == 2) && (p.Cout & 3) == 0 && p.part)
             while (ks < max_split && wgs * ks * 2 <= split_wgs && nch / (ks * 2) >= 2 &&
                    (long long)(ks * 2) * p.N * p.H * p.W * p.Cout * (long long)sizeof(float) <= p.part_bytes) ks *= 2;
         // every slice must own at least one chunk: the kernel gives slice z the chunks [z*per, (z+1)*per) with per = ceil(nch/ks), and
@@ -434,15 +474,17 @@ static int launch_conv16(Conv16Params& p, hipStream_t stream) {
         p.ksplit = ks;
         grid.z = ks;
     }
-    if (KS == 3 && !p.grouped) grid = conv16_grid(p, (int)grid.x, (int)grid.y, (int)grid.z);      // XCD-aware order (dense 3x3: the halo is the shared operand)
+    if ((KS == 3 || KS == 2) && !p.grouped) grid = conv16_grid(p, (int)grid.x, (int)grid.y, (int)grid.z);      // XCD-aware order (dense 3x3: the halo is the shared operand)
     p.stats_rows = 0;
     if (p.stats) {
         // fused norm statistics need: full tiles (every wave's MR*16 rows inside ONE image, tiles covering the images exactly, image-major
         // row-block order), the coalesced epilogue (Cout % 4 == 0), no split-K (its finish kernel has no statistics), room in the buffer
         constexpr int WR = MR * 16;
         const long long rows = (long long)(pp ? 2 * ((tiles + 1) / 2) : tiles) * WM;
-        const bool ok = (NBv * TH * TW == BM) && (TH * TW >= WR) && (p.H % TH == 0) && (p.W % TW == 0) && ((p.Cout & 3) == 0) && p.ksplit == 1 &&
-                        rows * p.Cout * 3 <= p.stats_cap;
+        // (forward phase form: a tile's row blocks are ordered (image group, phase, tile): with several images per tile the rows of ONE image would
+        //  not be contiguous -- the partials are only offered for one image per tile, small maps take the statistics pass)
+        const bool ok = (NBv * TH * TW == BM) && (TH * TW >= WR) && (GHt % TH == 0) && (GWt % TW == 0) && ((p.Cout & 3) == 0) && p.ksplit == 1 &&
+                        rows * p.Cout * 3 <= p.stats_cap && (!phf || NBv == 1);
         if (ok) p.stats_rows = (p.H * p.W) / WR; else p.stats = nullptr;
     }
     // (64-channel chunks -- CC = 64, twice the MFMAs between two barriers -- were measured 7-15 % SLOWER on the 64^2..256^2 layers: their
@@ -463,6 +505,12 @@ static int launch_conv16(Conv16Params& p, hipStream_t stream) {
 
 template <int PREC>
 static int dispatch_conv16(Conv16Params& p, int ks, int ups, hipStream_t s) {
+    if (ks == 3 && ups >= 2) {      // phase-decomposed x2-upsampled conv (Conv16Params::phase): 2 x 2 taps per phase on the low-resolution grid
+        const int gh = ups == 2 ? p.Hin : p.H, gw = ups == 2 ? p.Win : p.W;
+        if ((p.Cout & 3) || gh < 2 || gw < 2) return lp_set_error(LP_ERR_UNSUPPORTED, "phase-decomposed conv: Cout % 4 == 0, low-resolution grid >= 2 x 2");
+        if (p.Cout <= 64 && gh * gw >= 256) return launch_conv16<2, false, 4, 1, 4, 4, PREC>(p, s);
+        return launch_conv16<2, false, 2, 2, 4, 4, PREC>(p, s);
+    }
     if (ks == 3) {      // the tap-pipelined kernel (conv_pipe.hip) takes the layers it covers: maps whose tiling fills the chip
         const int r = lp_conv_pipe_launch(p, ups, PREC, s);
         if (r) return r < 0 ? r : LP_OK;
@@ -574,7 +622,8 @@ extern "C" int lp_conv16_fwd_stats(const uint16_t* a_hi, const uint16_t* a_lo, c
     if (stats && !stats_rows) return lp_set_error(LP_ERR_ARG, "lp_conv16_fwd: stats needs stats_rows");
     if (prec == LP_PREC_BF16X3 && (!w_lo || !a_lo)) return lp_set_error(LP_ERR_ARG, "lp_conv16_fwd: bf16x3 needs the lo planes");
     if (prec == LP_PREC_BF16X3 && out_hi && !out_lo) return lp_set_error(LP_ERR_ARG, "lp_conv16_fwd: bf16x3 needs out_lo");
-    if (upsample && ((H | W) & 1)) return lp_set_error(LP_ERR_ARG, "lp_conv16_fwd: upsampled output dims must be even");
+    if ((upsample == 1 || upsample == 2) && ((H | W) & 1)) return lp_set_error(LP_ERR_ARG, "lp_conv16_fwd: upsampled output dims must be even");
+    if (upsample < 0 || upsample > 3) return lp_set_error(LP_ERR_ARG, "lp_conv16_fwd: upsample = 0 | 1 | 2 (phase form) | 3 (phase form of the data gradient)");
     if (CinP % 32 || CinP < Cin || CoutP % 128 || CoutP < Cout) return lp_set_error(LP_ERR_ARG, "lp_conv16_fwd: bad padded dims");
     if (H < 2 || W < 2) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_conv16_fwd: H,W must be >= 2");
     Conv16Params p;
@@ -584,6 +633,9 @@ extern "C" int lp_conv16_fwd_stats(const uint16_t* a_hi, const uint16_t* a_lo, c
     p.N = N; p.H = H; p.W = W; p.Hin = upsample ? H / 2 : H; p.Win = upsample ? W / 2 : W;
     p.Cin = Cin; p.C8 = (Cin + 7) & ~7; p.Cout = Cout; p.Co8 = (Cout + 7) & ~7; p.CinP = CinP; p.CoutP = CoutP; p.res_shift = res_shift;
     p.grouped = 0; p.stats = stats; p.stats_cap = stats ? stats_capacity_floats : 0; p.stats_rows = 0;
+    p.phase = (upsample == 2) ? 1 : (upsample == 3) ? 2 : 0;
+    if (upsample >= 2 && ksize != 3) return lp_set_error(LP_ERR_ARG, "lp_conv16_fwd: upsample = 2 | 3 (phase-decomposed forms) are 3x3 forms");
+    if (upsample == 3) { p.Hin = 2 * H; p.Win = 2 * W; }          // data gradient: a = dy planes [N][2H][2W][C8], output = the low-resolution dx [N][H][W][Cout]
     hipStream_t s = (hipStream_t)stream;
     int rc;
     if (prec == LP_PREC_BF16) rc = dispatch_conv16<LP_PREC_BF16>(p, ksize, upsample, s);
@@ -644,7 +696,7 @@ extern "C" int lp_gconv16_fwd_planes(const uint16_t* a_hi, const uint16_t* a_lo,
     p.a_hi = a_hi; p.a_lo = a_lo; p.w_hi = w_hi; p.w_lo = w_lo; p.y = y; p.bias = nullptr; p.res = nullptr; p.alpha = nullptr; p.alpha2 = alpha2;
     p.mask16 = nullptr; p.o_relu = 0; p.part = nullptr; p.part_bytes = 0; p.amax = amax_slots; p.o_hi = o_hi; p.o_lo = o_lo;
     p.N = N; p.H = H; p.W = W; p.Hin = H; p.Win = W;
-    p.Cin = C; p.C8 = C; p.Cout = C; p.Co8 = C; p.CinP = 64; p.CoutP = CP; p.res_shift = 0; p.grouped = 1;
+    p.Cin = C; p.C8 = C; p.Cout = C; p.Co8 = C; p.CinP = 64; p.CoutP = CP; p.res_shift = 0; p.grouped = 1; p.phase = 0;
     p.stats = stats; p.stats_cap = stats ? stats_capacity_floats : 0; p.stats_rows = 0;
     hipStream_t s = (hipStream_t)stream;
     int rc;

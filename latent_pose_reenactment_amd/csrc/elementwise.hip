@@ -9,17 +9,40 @@ static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b)
 // ------------------------------------------------------------------------------------------------------------------
 // weight packing
 // ------------------------------------------------------------------------------------------------------------------
+// modes 2 / 3 (round 6): the PHASE form of a x2-upsampled 3x3 conv (T = 9 in, 16 taps out: t = phase * 4 + i * 2 + j, phase = 2a + b).  Output pixel
+// (2y + a, 2x + b) of conv3x3(nearest_up2(x)) reads the low-resolution pixels (y + a - 1 + i, x + b - 1 + j); the 3x3 taps that meet the same
+// pixel are summed here, in fp32, before the 16-bit split: rows {0} | {1, 2} for a = 0, {0, 1} | {2} for a = 1 (columns alike).
+//   mode 2 (forward):        out[t][co][ci] = sum of w[co][ci][dy][dx] over the taps of (phase, i, j)
+//   mode 3 (data gradient):  out[t][ci][co] = the (phase, 1 - i, 1 - j) sum  (dx_lo[y] = sum_a sum_i Wp[a][i]^T dy_a[y - (a - 1 + i)]: a 2 x 2
+//                            conv per phase over the phase-subsampled dy with origin y - a and flipped taps)
+__device__ __forceinline__ float lp_phase_tap_sum(const float* __restrict__ w9, int t16, bool flip) {
+    const int ph = t16 >> 2, a = ph >> 1, b = ph & 1;
+    int i = (t16 >> 1) & 1, j = t16 & 1;
+    if (flip) { i = 1 - i; j = 1 - j; }
+    const int r0 = (a == 0) ? (i == 0 ? 0 : 1) : (i == 0 ? 0 : 2), r1 = (a == 0) ? (i == 0 ? 0 : 2) : (i == 0 ? 1 : 2);
+    const int c0 = (b == 0) ? (j == 0 ? 0 : 1) : (j == 0 ? 0 : 2), c1 = (b == 0) ? (j == 0 ? 0 : 2) : (j == 0 ? 1 : 2);
+    float v = 0.f;
+    for (int r = r0; r <= r1; ++r)
+        for (int c = c0; c <= c1; ++c) v += w9[r * 3 + c];
+    return v;
+}
+
+__device__ __forceinline__ float lp_pack_value(const float* __restrict__ w, int Cout, int Cin, int T, int mode, int t, int row, int col) {
+    if (mode == 0) return (row < Cout && col < Cin) ? w[((size_t)row * Cin + col) * T + t] : 0.f;                 // [t][co][ci]
+    if (mode == 1) return (row < Cin && col < Cout) ? w[((size_t)col * Cin + row) * T + (T - 1 - t)] : 0.f;     // [T-1-t][ci][co]
+    if (mode == 2) return (row < Cout && col < Cin) ? lp_phase_tap_sum(w + ((size_t)row * Cin + col) * 9, t, false) : 0.f;
+    return (row < Cin && col < Cout) ? lp_phase_tap_sum(w + ((size_t)col * Cin + row) * 9, t, true) : 0.f;
+}
+
 __global__ void pack_weights_kernel(const float* __restrict__ w, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo,
                                     int Cout, int Cin, int T, int RowsP, int ColsP, int mode, int f16) {
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    long long total = (long long)T * RowsP * ColsP;
+    long long total = (long long)(mode >= 2 ? 16 : T) * RowsP * ColsP;
     if (idx >= total) return;
     int col = (int)(idx % ColsP);
     int row = (int)((idx / ColsP) % RowsP);
     int t = (int)(idx / ((long long)ColsP * RowsP));
-    float v = 0.f;
-    if (mode == 0) { if (row < Cout && col < Cin) v = w[((size_t)row * Cin + col) * T + t]; }                 // [t][co][ci]
-    else { if (row < Cin && col < Cout) v = w[((size_t)col * Cin + row) * T + (T - 1 - t)]; }                  // [T-1-t][ci][co]
+    const float v = lp_pack_value(w, Cout, Cin, T, mode, t, row, col);
     if (f16) { hi[idx] = lp_f32_to_op16<true>(v); return; }
     __bf16 h = (__bf16)v;
     hi[idx] = __builtin_bit_cast(uint16_t, h);
@@ -39,7 +62,7 @@ __global__ __launch_bounds__(256) void pack_weights_batch_kernel(const PackDesc*
         if (table[mid].chunk0 <= (int)blockIdx.x) lo_e = mid; else hi_e = mid - 1;
     }
     const PackDesc d = table[lo_e];
-    const long long total = (long long)d.T * d.RowsP * d.ColsP;
+    const long long total = (long long)(d.mode >= 2 ? 16 : d.T) * d.RowsP * d.ColsP;
     const long long base = (long long)((int)blockIdx.x - d.chunk0) * 1024;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -48,9 +71,7 @@ __global__ __launch_bounds__(256) void pack_weights_batch_kernel(const PackDesc*
         int col = (int)(idx % d.ColsP);
         int row = (int)((idx / d.ColsP) % d.RowsP);
         int t = (int)(idx / ((long long)d.ColsP * d.RowsP));
-        float v = 0.f;
-        if (d.mode == 0) { if (row < d.Cout && col < d.Cin) v = d.w[((size_t)row * d.Cin + col) * d.T + t]; }
-        else { if (row < d.Cin && col < d.Cout) v = d.w[((size_t)col * d.Cin + row) * d.T + (d.T - 1 - t)]; }
+        const float v = lp_pack_value(d.w, d.Cout, d.Cin, d.T, d.mode, t, row, col);
         if (d.f16) { d.hi[idx] = lp_f32_to_op16<true>(v); continue; }
         __bf16 h = (__bf16)v;
         d.hi[idx] = __builtin_bit_cast(uint16_t, h);
@@ -125,9 +146,10 @@ extern "C" int lp_pack_weights_batch(const void* table, int num_entries, long lo
 extern "C" int lp_pack_weights(const float* w, uint16_t* hi, uint16_t* lo, int Cout, int Cin, int T, int RowsP, int ColsP, int mode,
                                int f16, void* stream) {
     if (!w || !hi) return lp_set_error(LP_ERR_ARG, "lp_pack_weights: null pointer");
-    int rows = mode == 0 ? Cout : Cin, cols = mode == 0 ? Cin : Cout;
+    if (mode < 0 || mode > 3 || (mode >= 2 && T != 9)) return lp_set_error(LP_ERR_ARG, "lp_pack_weights: mode 0 | 1, or 2 | 3 (phase forms of a 3x3 weight: T = 9)");
+    int rows = (mode == 0 || mode == 2) ? Cout : Cin, cols = (mode == 0 || mode == 2) ? Cin : Cout;
     if (RowsP < rows || ColsP < cols || (ColsP & 7)) return lp_set_error(LP_ERR_ARG, "lp_pack_weights: bad padded dims");
-    long long total = (long long)T * RowsP * ColsP;
+    long long total = (long long)(mode >= 2 ? 16 : T) * RowsP * ColsP;
     hipLaunchKernelGGL(pack_weights_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, hi, lo, Cout, Cin, T,
                        RowsP, ColsP, mode, f16);
     return lp_check_launch("pack_weights");

@@ -68,20 +68,53 @@ class WeightPack(NamedTuple):
     taps: int
 
 
-def pack_weights(w: Tensor, mode: int, prec: int, small_k: bool = False) -> WeightPack:
-    """w: [Cout, Cin, k, k] (or [Cout, Cin]) fp32.  mode 0 = forward pack, mode 1 = dgrad pack (flipped + transposed).
-    small_k pads the contraction dim to 32 instead of 64 (only valid for 3x3 non-upsampled convs)."""
-    _chk(w, 'w')
+def _pack_geometry(w: Tensor, mode: int, small_k: bool):
+    """(cout, cin, taps in, taps out, rows, cols, rows_p, cols_p) of a pack: modes 0 / 2 are [taps][Cout][Cin] images, 1 / 3 [taps][Cin][Cout];
+    2 / 3 = the phase forms of a x2-upsampled 3x3 conv (16 taps: lp_pack_weights)"""
     cout, cin = w.shape[0], w.shape[1]
     taps = w.numel() // (cout * cin)
-    rows, cols = (cout, cin) if mode == 0 else (cin, cout)
+    assert mode in (0, 1) or taps == 9, 'the phase forms (modes 2 / 3) pack a 3x3 weight'
+    rows, cols = (cout, cin) if mode in (0, 2) else (cin, cout)
     rows_p = _round_up(rows, 128)
     cols_p = _round_up(cols, 32 if (small_k and cols <= 32) else 64)
-    hi = torch.empty((taps, rows_p, cols_p), dtype=torch.int16, device=w.device)
+    return cout, cin, taps, (16 if mode >= 2 else taps), rows, cols, rows_p, cols_p
+
+
+def pack_weights(w: Tensor, mode: int, prec: int, small_k: bool = False) -> WeightPack:
+    """w: [Cout, Cin, k, k] (or [Cout, Cin]) fp32.  mode 0 = forward pack, mode 1 = dgrad pack (flipped + transposed); 2 / 3 = the phase forms
+    (forward / data gradient) of a x2-upsampled 3x3 conv.  small_k pads the contraction dim to 32 instead of 64 (only valid for 3x3
+    non-upsampled convs)."""
+    _chk(w, 'w')
+    cout, cin, taps, taps_out, rows, cols, rows_p, cols_p = _pack_geometry(w, mode, small_k)
+    hi = torch.empty((taps_out, rows_p, cols_p), dtype=torch.int16, device=w.device)
     lo = torch.empty_like(hi) if prec == PREC_BF16X3 else None
     check(_lib.lib().lp_pack_weights(w.data_ptr(), hi.data_ptr(), _p(lo), cout, cin, taps, rows_p, cols_p, mode, _f16(prec), _stream()),
           'lp_pack_weights')
-    return WeightPack(hi, lo, rows, cols, rows_p, cols_p, taps)
+    return WeightPack(hi, lo, rows, cols, rows_p, cols_p, taps_out)
+
+
+def phase_weights(w: Tensor) -> Tensor:
+    """w [Cout, Cin, 3, 3] -> [Cout, Cin, 4, 2, 2]: the phase form of conv3x3(nearest_up2(x)).  Output pixel (2y + a, 2x + b) reads the upsampled rows
+    2y + a + dy - 1, i.e. the low-resolution rows y - 1, y, y (a = 0) / y, y, y + 1 (a = 1) for dy = 0, 1, 2: taps that meet the same low-resolution
+    pixel are summed -- rows {0}, {1, 2} for a = 0 and {0, 1}, {2} for a = 1 (columns alike); tap (i, j) of phase (a, b) reads pixel
+    (y + a - 1 + i, x + b - 1 + j).  Plain fp32 sums of the reference's taps (generators/common/blocks.py:74-88)."""
+    r = [[w[:, :, 0], w[:, :, 1] + w[:, :, 2]], [w[:, :, 0] + w[:, :, 1], w[:, :, 2]]]          # [a][i] -> [Cout, Cin, 3 (dx)]
+    out = []
+    for a in range(2):
+        for b in range(2):
+            taps = []
+            for i in range(2):
+                row = r[a][i]
+                cols = [[row[..., 0], row[..., 1] + row[..., 2]], [row[..., 0] + row[..., 1], row[..., 2]]][b]
+                taps.append(torch.stack(cols, dim=-1))
+            out.append(torch.stack(taps, dim=-2))          # [Cout, Cin, 2 (i), 2 (j)]
+    return torch.stack(out, dim=2).contiguous()           # [Cout, Cin, 4 (phase = 2a + b), 2, 2]
+
+
+def pack_phase_weights(w: Tensor, prec: int, dgrad: bool = False) -> WeightPack:
+    """[4 phases x 4 taps] pack of the phase-decomposed x2-upsampled 3x3 conv: forward [CoutP][CinP] (``conv16(..., upsample=True, phase=True)``) or
+    data gradient [CinP][CoutP] -- lp_pack_weights modes 2 / 3 (the tap sums happen inside the pack launch; ``phase_weights`` is their torch form)"""
+    return pack_weights(w, 3 if dgrad else 2, prec)
 
 
 class PackBatch:
@@ -100,14 +133,10 @@ class PackBatch:
         geo = []
         for w, mode, small_k in specs:
             _chk(w, 'w')
-            cout, cin = w.shape[0], w.shape[1]
-            taps = w.numel() // (cout * cin)
-            rows, cols = (cout, cin) if mode == 0 else (cin, cout)
-            rows_p = _round_up(rows, 128)
-            cols_p = _round_up(cols, 32 if (small_k and cols <= 32) else 64)
-            hi = torch.empty((taps, rows_p, cols_p), dtype=torch.int16, device=w.device)
+            cout, cin, taps, taps_out, rows, cols, rows_p, cols_p = _pack_geometry(w, mode, small_k)
+            hi = torch.empty((taps_out, rows_p, cols_p), dtype=torch.int16, device=w.device)
             lo = torch.empty_like(hi) if prec == PREC_BF16X3 else None
-            self.packs.append(WeightPack(hi, lo, rows, cols, rows_p, cols_p, taps))
+            self.packs.append(WeightPack(hi, lo, rows, cols, rows_p, cols_p, taps_out))
             geo.append((w, mode, cout, cin, taps))
         by_w = {}
         for i, (w, mode, *_rest) in enumerate(geo):
@@ -133,7 +162,7 @@ class PackBatch:
             elif i not in in_pair:
                 blob += struct.pack('<QQQiiiiiiii', w.data_ptr(), pk.hi.data_ptr(), lop(pk), cout, cin, taps, pk.rows_p, pk.cols_p, mode,
                                     self.chunks, _f16(prec))
-                self.chunks += (taps * pk.rows_p * pk.cols_p + 1023) // 1024
+                self.chunks += (pk.taps * pk.rows_p * pk.cols_p + 1023) // 1024
                 self.nsingle += 1
         dev = specs[0][0].device
         self.table = torch.frombuffer(blob, dtype=torch.uint8).clone().to(dev) if self.nsingle else None
@@ -246,17 +275,22 @@ class ConvStats(NamedTuple):
 def conv16(a: Act16, pack: WeightPack, *, ksize: int, upsample: bool = False, bias: Optional[Tensor] = None,
            res: Optional[Tensor] = None, res_shift: int = 0, alpha: Optional[Tensor] = None, prec: int = PREC_BF16,
            relu_mask: Optional[Act16] = None, out16: Optional[int] = None, amax: bool = False, stats: bool = False, want_y: bool = True,
-           kind: str = 'conv_igemm'):
+           kind: str = 'conv_igemm', phase: bool = False, phase_dgrad: bool = False):
     """y = alpha * conv(up2?(a), pack) + bias + res on operand planes; a [N,Hin,Win,C8] -> y [N,H,W,Cout] fp32.
     ``relu_mask``: operand planes [N,H,W,Co8] of the forward conv's input; y is zeroed where they are <= 0 (fused ReLU backward
     when this launch is a data gradient).  ``out16`` = 0 | 1: also return the operand planes of y (1: of relu(y)) -> (y, Act16).
     ``stats``: the epilogue also leaves the norm-statistics partials of y -> (..., ConvStats | None) appended (None: geometry not covered
     by the fused path -- run ``instnorm_stats`` / ``bn_train_stats`` on y).  ``want_y=False`` (with ``out16`` and Cout % 8 == 0): no fp32 y
-    is written, y is returned as None."""
+    is written, y is returned as None.  ``phase`` (with ``upsample``, 3x3; round 6): ``pack`` is a ``pack_phase_weights`` image and the conv runs in
+    its phase-decomposed form -- per output phase (a, b) a 2 x 2 conv on the low-resolution planes with the coinciding taps pre-summed: the same
+    result with 4/9 of the matrix work.  ``phase_dgrad``: ``a`` = the planes of dy [N, 2H, 2W, C8] of such a conv, ``pack`` =
+    ``pack_phase_weights(w, prec, dgrad=True)`` -> the gradient w.r.t. the LOW-resolution input [N, H, W, Cout] (the upsample's 2x2 sum included)."""
     n, hin, win = a.nhw
     cin = a.c
-    assert cin == pack.cols and pack.taps == ksize * ksize, (a.hi.shape, a.c, pack.rows, pack.cols, pack.taps)
-    h, w = (hin * 2, win * 2) if upsample else (hin, win)
+    assert not phase or (upsample and ksize == 3)
+    assert not phase_dgrad or (ksize == 3 and not upsample and not phase and hin % 2 == 0 and win % 2 == 0)
+    assert cin == pack.cols and pack.taps == (16 if (phase or phase_dgrad) else ksize * ksize), (a.hi.shape, a.c, pack.rows, pack.cols, pack.taps)
+    h, w = (hin * 2, win * 2) if upsample else (hin // 2, win // 2) if phase_dgrad else (hin, win)
     cout = pack.rows
     dev = a.hi.device
     if not want_y:
@@ -284,9 +318,13 @@ def conv16(a: Act16, pack: WeightPack, *, ksize: int, upsample: bool = False, bi
     pl = 4 if prec == PREC_BF16X3 else 2              # bytes per operand-plane element
     nbytes = (n * hin * win * a.hi.shape[3] * pl + pack.hi.numel() * pl + (n * (h >> res_shift) * (w >> res_shift) * cout * 4 if res is not None else 0),
               n * h * w * cout * ((4 if want_y else 0) + (pl if out16 is not None else 0)))          # (read: planes once + weights + residual, write)
-    with _Timed(kind, 2.0 * n * h * w * cout * cin * ksize * ksize, (n, h, w, cin, cout, ksize, int(upsample), 0), nbytes, mm=3 if prec == PREC_BF16X3 else 1):
+    # (roofline accounting: the DENSE count of the conv as the reference executes it -- the phase forms do 4/9 of it; the data-gradient form's dense
+    #  conv lives on the 2h x 2w grid)
+    dh, dw_ = (2 * h, 2 * w) if phase_dgrad else (h, w)
+    with _Timed(kind, 2.0 * n * dh * dw_ * cout * cin * ksize * ksize, (n, dh, dw_, cin, cout, ksize, 3 if phase_dgrad else 2 if phase else int(upsample), 0), nbytes,
+                mm=3 if prec == PREC_BF16X3 else 1):
         check(_lib.lib().lp_conv16_fwd_stats(a.hi.data_ptr(), _p(a.lo), pack.hi.data_ptr(), _p(pack.lo), _p(y), _p(bias), _p(res),
-                                             _p(alpha), _p(a.inv), n, h, w, cin, cout, pack.cols_p, pack.rows_p, ksize, int(upsample),
+                                             _p(alpha), _p(a.inv), n, h, w, cin, cout, pack.cols_p, pack.rows_p, ksize, 3 if phase_dgrad else 2 if phase else int(upsample),
                                              res_shift, prec, None if relu_mask is None else relu_mask.hi.data_ptr(), _p(o_hi), _p(o_lo),
                                              int(bool(out16)), _p(ws), ws_bytes, _p(slots), _p(st_buf), st_cap,
                                              None if st_rows is None else ctypes.addressof(st_rows), _stream()), 'lp_conv16_fwd')

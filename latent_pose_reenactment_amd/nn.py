@@ -471,6 +471,19 @@ G_Y16 = os.environ.get('LP_G_Y16', '0') != '0'
 # smallest map (output height) that runs 16-bit resident: 64 -- at 32 x 32 the launches that do not cover the fused statistics would need a decode +
 # statistics pass (measured: two extra launch pairs per step), and 6 % of the decoder's activation bytes live there
 Y16_MIN_MAP = int(os.environ.get('LP_G_Y16_MIN', '64'))
+# x2-upsampled 3x3 convs (conv1 of every up block) in their PHASE-DECOMPOSED forms (round 6; csrc/conv_dma.hip KS = 2): forward per output phase a
+# 2 x 2 conv on the low-resolution planes, data gradient ONE launch on the low-resolution grid (no 2H x 2W dA, no 2 x 2 sum in the AdaIN
+# backward) -- 4/9 of the matrix work each, exact algebra (the coinciding taps are summed in fp32 inside the weight pack).  bf16x3, N = 8
+# (profiles/r06_phase_conv.txt): forward 114 / 160 / 161 / 176 us -> 64 / 83 / 89 / 108 us, data gradient 113 / 184 / 210 / 295 us -> 71 / 112 / 86 / 98 us
+# at 32^2 .. 256^2.  LP_G_PHASE=0: the fused-upsample kernels; maps below PHASE_MIN_OUT keep them as well.
+PHASE_UP = os.environ.get('LP_G_PHASE', '1') != '0'
+PHASE_MIN_OUT = int(os.environ.get('LP_G_PHASE_MIN', '16'))
+
+
+def phase_conv(up: bool, hout: int, reflect: bool) -> bool:
+    return bool(up) and PHASE_UP and hout >= PHASE_MIN_OUT and not reflect
+
+
 RAW16_SKIP = os.environ.get('LP_G_RAW16', '1') != '0'      # conv2's epilogue also writes the raw planes of the block output for the next skip conv (0: a pack launch)
 
 
@@ -488,8 +501,8 @@ class _DecoderFunction(torch.autograd.Function):
         sn = cfg['sn']                    # per entry of `weights`: (u_used, v_used, [sigma, 1/sigma]) for conv weights, None for biases
         packs = cfg.get('packs')          # forward packs prepared by the module (inference: cached; training: one batched launch)
 
-        def fpack(i, w):
-            return packs[i] if packs is not None else ops.pack_weights(w.detach().contiguous(), 0, prec)
+        def fpack(i, w, phase=False):
+            return packs[i] if packs is not None else ops.pack_weights(w.detach().contiguous(), 2 if phase else 0, prec)
         B = affine.shape[0]
         affine = affine.contiguous()
         wl = list(weights)
@@ -557,8 +570,9 @@ class _DecoderFunction(torch.autograd.Function):
             # the weight gradient in backward); the convs themselves stage their operands by LDS-DMA only
             st0 = in_stats(x, x_cs, g0, b0)
             a0 = norm_planes(x, st0)
-            p1 = fpack(wi - 2, w1)
-            h1, cs1, _ = conv_out(a0, p1, hout, w1, ksize=3, upsample=up, alpha=sn[wi - 2][2][1:])
+            ph1 = phase_conv(up, hout, reflect)
+            p1 = fpack(wi - 2, w1, ph1)
+            h1, cs1, _ = conv_out(a0, p1, hout, w1, ksize=3, upsample=up, alpha=sn[wi - 2][2][1:], **({'phase': True} if ph1 else {}))
             st1 = in_stats(h1, cs1, g1, b1)
             a1 = norm_planes(h1, st1)
             xs = None
@@ -641,8 +655,8 @@ class _DecoderFunction(torch.autograd.Function):
                                                         accum=_accum_target(params[wi]), bias_grad=True)
         packsT = cfg.get('packsT')        # dgrad packs from the same batched launch (training), else packed on demand
 
-        def tpack(i, small_k=False):
-            return packsT[i] if packsT is not None else ops.pack_weights(wl[i].contiguous(), 1, prec, small_k=small_k)
+        def tpack(i, small_k=False, phase=False):
+            return packsT[i] if packsT is not None else ops.pack_weights(wl[i].contiguous(), 3 if phase else 1, prec, small_k=small_k)
         pT = tpack(wi, small_k=True)
         dA = ops.conv(dz, pT, ksize=3, alpha=sn[wi][2][1:], prec=prec, grad=True)
         g, dg, db = slices(oh, ch)
@@ -693,15 +707,20 @@ class _DecoderFunction(torch.autograd.Function):
             if dh16 is None:
                 dh16 = ops.act_pack(dh1, prec=prec, grad=True)
             grads[wi] = ops.conv_wgrad16(a0, dh16, ksize=3, upsample=up, prec=prec, sn=snw(wi), accum=_accum_target(params[wi]))
-            dA0 = ops.conv16(dh16, tpack(wi), ksize=3, alpha=sn[wi][2][1:], prec=prec)
+            ph1 = phase_conv(up, dh16.hi.shape[1], reflect)
+            if ph1:      # phase form of the data gradient: the gradient w.r.t. the LOW-resolution AdaIN output from one launch (2 x 2 sum included)
+                dA0 = ops.conv16(dh16, tpack(wi, phase=True), ksize=3, alpha=sn[wi][2][1:], prec=prec, phase_dgrad=True)
+            else:
+                dA0 = ops.conv16(dh16, tpack(wi), ksize=3, alpha=sn[wi][2][1:], prec=prec)
             if reflect:
                 border(wi, a0, dh1, dA0, up)
+            up_bwd = up and not ph1          # (the fused-upsample form hands the AdaIN backward a 2H x 2W gradient to sum)
             g, dg, db = slices(o0, cin)
             dx16 = None
             if direct and bi > 0:          # (block 0's input gradient only feeds the learned constant: fp32)
-                dx, dx16 = ops.adain_relu_bwd(dA0, x, dx_skip, g, st0[0], st0[1], st0[2], st0[3], dg, db, up, planes=prec)
+                dx, dx16 = ops.adain_relu_bwd(dA0, x, dx_skip, g, st0[0], st0[1], st0[2], st0[3], dg, db, up_bwd, planes=prec)
             else:
-                dx = ops.adain_relu_bwd(dA0, x, dx_skip, g, st0[0], st0[1], st0[2], st0[3], dg, db, up, amax=f16 and bi > 0)
+                dx = ops.adain_relu_bwd(dA0, x, dx_skip, g, st0[0], st0[1], st0[2], st0[3], dg, db, up_bwd, amax=f16 and bi > 0)
             if dbg is not None:
                 dbg[f'dx{bi}'] = dx; dbg[f'dh1_{bi}'] = dh1; dbg[f'dxskip{bi}'] = dx_skip
         d_const = dx.sum(dim=0, keepdim=True).permute(0, 3, 1, 2).contiguous()
@@ -827,7 +846,8 @@ class Generator(nn.Module):
     def _train_packs_update(self, weights, sn):
         """training: every conv weight changed in the last optimizer step -> ONE launch re-packs all of them, both orientations"""
         conv_idx = [i for i, s_ in enumerate(sn) if s_ is not None]
-        specs = [(weights[i], 0, False) for i in conv_idx] + [(weights[i], 1, i == len(weights) - 2) for i in conv_idx]
+        ph = self._phase_weight_indices()          # conv1 of the up blocks that run in their phase forms: pack modes 2 / 3 instead of 0 / 1
+        specs = [(weights[i], 2 if i in ph else 0, False) for i in conv_idx] + [(weights[i], 3 if i in ph else 1, i == len(weights) - 2) for i in conv_idx]
         pb = self.__dict__.get('_train_packs')
         if pb is None or pb.prec != self.prec or pb.key != tuple((w.data_ptr(), m, bool(k_)) for w, m, k_ in specs):
             pb = ops.PackBatch(specs, self.prec)
@@ -837,6 +857,19 @@ class Generator(nn.Module):
         for j, i in enumerate(conv_idx):
             packs[i], packsT[i] = allp[j], allp[len(conv_idx) + j]
         return packs, packsT
+
+    def _phase_weight_indices(self):
+        """indices (into ``_conv_weights``' list) of the conv1 weights whose up block runs the phase-decomposed forms (``phase_conv``)"""
+        cached = self.__dict__.get('_phase_idx')
+        if cached is None:
+            cached, wi, size = set(), 0, self.constant.constant.shape[-1]
+            for cin, cout, up in self.blocks_cfg:
+                size *= 2 if up else 1
+                if phase_conv(up, size, self.reflect):
+                    cached.add(wi)
+                wi += 4 if (cin != cout or up) else 2
+            self.__dict__['_phase_idx'] = cached
+        return cached
 
     def prepare_step(self):
         """The parts of a TRAINING forward that depend on the weights only -- the spectral-norm power iteration and the 16-bit weight packs
@@ -885,8 +918,9 @@ class Generator(nn.Module):
             key = (prec, WEIGHTS_GENERATION[0]) + tuple((w.data_ptr(), w._version) for w in weights)
             cache = self.__dict__.get('_pack_cache')
             if cache is None or cache[0] != key:
-                cache = (key, [ops.pack_weights(w.detach().contiguous(), 0, prec) if s_ is not None else None
-                               for w, s_ in zip(weights, sn)])
+                ph = self._phase_weight_indices()
+                cache = (key, [ops.pack_weights(w.detach().contiguous(), 2 if i in ph else 0, prec) if s_ is not None else None
+                               for i, (w, s_) in enumerate(zip(weights, sn))])
                 self.__dict__['_pack_cache'] = cache
             packs = cache[1]
         cfg = dict(blocks=self.blocks_cfg, prec=prec, need_grad=need_grad, sn=sn, packs=packs, packsT=packsT,

@@ -9,6 +9,9 @@ SHAPES = [  # N, H, W, Cin, Cout, ks, ups
     (8, 4, 4, 512, 512, 3, 0), (8, 16, 16, 512, 512, 3, 0), (8, 32, 32, 512, 512, 3, 0), (8, 64, 64, 256, 256, 3, 0),
     (8, 128, 128, 128, 128, 3, 0), (8, 256, 256, 64, 64, 3, 0), (8, 256, 256, 128, 64, 3, 1), (8, 256, 256, 64, 128, 3, 0),
     (8, 64, 64, 512, 256, 3, 1), (8, 64, 64, 256, 128, 1, 0), (16, 128, 128, 128, 128, 3, 0), (16, 64, 64, 256, 256, 3, 0)]
+if os.environ.get('SHAPES') == 'ups':        # the generator's x2-upsampled 3x3 convs (up1 .. up5); PHASE=1: their phase-decomposed form (round 6)
+    SHAPES = [(8, 16, 16, 512, 512, 3, 1), (8, 32, 32, 512, 512, 3, 1), (8, 64, 64, 512, 256, 3, 1), (8, 128, 128, 256, 128, 3, 1), (8, 256, 256, 128, 64, 3, 1)]
+PHASE = os.environ.get('PHASE', '0') != '0'
 if os.environ.get('SHAPES') == 'small':      # the latency-bound layer classes (4x4 .. 16x16 maps, 1x1 skips)
     SHAPES = [(8, 4, 4, 512, 512, 3, 0), (8, 8, 8, 512, 512, 3, 0), (8, 16, 16, 512, 512, 3, 0), (8, 8, 8, 512, 512, 1, 0),
               (8, 16, 16, 512, 512, 1, 0), (8, 8, 8, 512, 512, 3, 1), (8, 32, 32, 512, 512, 3, 0)]
@@ -44,13 +47,13 @@ for (n, h, w, cin, cout, ks, ups) in SHAPES:
     dy = torch.randn(n, h, w, cout, device='cuda')
     wgt = torch.randn(cout, cin, ks, ks, device='cuda') * 0.02
     sc = torch.randn(n, cin, device='cuda'); sh = torch.randn(n, cin, device='cuda')
-    pack = ops.pack_weights(wgt, 0, prec)
+    pack = ops.pack_phase_weights(wgt, prec) if (PHASE and ups and ks == 3) else ops.pack_weights(wgt, 0, prec)
     a = ops.act_pack(x, pro=1, scale=sc, shift=sh, prec=prec)
     d = ops.act_pack(dy, prec=prec, grad=True)
     fl = 2.0 * n * h * w * cin * cout * ks * ks
     out = [f'prec={prec} {str((n, h, w, cin, cout, ks, ups)):40s}']
     if 'conv' in WHAT:
-        us = timeit(lambda: ops.conv16(a, pack, ksize=ks, upsample=bool(ups), prec=prec))
+        us = timeit(lambda: ops.conv16(a, pack, ksize=ks, upsample=bool(ups), prec=prec, phase=bool(PHASE and ups and ks == 3)))
         out.append(f'conv {us:7.1f} us {fl / us / 1e6:7.1f} TF/s')
     if 'pack' in WHAT:
         us = timeit(lambda: ops.act_pack(x, pro=1, scale=sc, shift=sh, prec=prec))

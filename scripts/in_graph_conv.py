@@ -2,7 +2,7 @@
 algorithmic FLOPs of the same launches (bench.py --shapes table, kind conv_igemm, two instrumented steps) -> the in-graph roofline figure
 that bench.py prints beside its live eager-event one.
 usage: python scripts/in_graph_conv.py <step_breakdown.csv> <conv_shapes.csv> > profiles/r06_conv3x3_in_graph.json
-Family = conv_pipe_kernel (all variants) + conv_dma_kernel<3, ...> except the instantiations whose last template flag (GH) is true -- the identity
+Family = conv_pipe_kernel (all variants) + conv_dma_kernel<3, ...> and <2, ...> (the phase forms of the x2-upsampled convs, round 6) except the instantiations whose last template flag (GH) is true -- the identity
 encoder's GROUPED 3x3 convs (round 6: the dense bf16x3 <= 64-channel layers of the default assignment run conv_dma_kernel<3, false, 4, 1, 4, 4, ..,
 false> and belong to the family) -- + the split-K finishes (splitk_reduce_kernel).  The figure prices ALGORITHMIC flops; bf16x3 launches execute three
 MFMAs per MAC (bench.py prints the matrix-pipe work beside it)."""
@@ -24,8 +24,8 @@ for line in open(bd):
     fam = None
     if name.startswith('conv_pipe_kernel'):
         fam = 'conv_pipe_kernel'
-    elif name.startswith('conv_dma_kernel<3,') and not name.rstrip().endswith('true>'):          # (last template flag GH: the grouped instantiations)
-        fam = 'conv_dma_kernel<3> (small maps, <= 16-channel outputs, leftovers)'
+    elif (name.startswith('conv_dma_kernel<3,') or name.startswith('conv_dma_kernel<2,')) and not name.rstrip().endswith('true>'):          # (last template flag GH: the grouped instantiations)
+        fam = 'conv_dma_kernel<3> / <2> (bf16x3 layers, phase forms of the x2-upsampled convs, small maps, leftovers)'
     elif name.startswith('splitk_reduce_kernel'):
         fam = 'splitk_reduce_kernel'
     if fam:

@@ -33,8 +33,8 @@ for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI
   echo "pmc $tag rc=$?" >> $O/summary.txt
   rm -f $O/${R}_pmc_$tag/${R}_kernel_trace.csv
 done
-GROUPED='conv_dma_kernel<3,.* true>$'
-python scripts/pmc_summary.py --json "conv_pipe_kernel|conv_dma_kernel<3" --exclude "$GROUPED" $O/${R}_pmc_*/*counter_collection.csv > $O/${R}_pmc_conv3x3_metatrain.json 2> $O/${R}_pmc_summary.err
+GROUPED='conv_dma_kernel<3,.* true>\$'
+python scripts/pmc_summary.py --json "conv_pipe_kernel|conv_dma_kernel<3|conv_dma_kernel<2" --exclude "$GROUPED" $O/${R}_pmc_*/*counter_collection.csv > $O/${R}_pmc_conv3x3_metatrain.json 2> $O/${R}_pmc_summary.err
 python scripts/pmc_summary.py --json "conv_dma_kernel<1" $O/${R}_pmc_*/*counter_collection.csv > $O/${R}_pmc_conv1x1_metatrain.json 2>> $O/${R}_pmc_summary.err
 python scripts/pmc_summary.py --json "conv_wgrad_kernel|wgrad3_pipe_kernel" $O/${R}_pmc_*/*counter_collection.csv > $O/${R}_pmc_conv_wgrad_metatrain.json 2>> $O/${R}_pmc_summary.err
 python scripts/pmc_summary.py --json "wgrad1x1_kernel" $O/${R}_pmc_*/*counter_collection.csv > $O/${R}_pmc_wgrad1x1_metatrain.json 2>> $O/${R}_pmc_summary.err
@@ -54,6 +54,7 @@ LP_OVERLAP=0 timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline
 env -u WORLD_SIZE -u RANK -u LOCAL_RANK timeout 600 python bench.py --gpus 2 --steps 6 --warmup 2 --backend gloo --no-cpu-baseline --no-also --no-drive > $O/${R}_bench_dp2_gloo_one_gpu_functional.json 2> $O/${R}_bench_dp2.err
 PREC=1 WHAT=conv timeout 200 python scripts/conv_micro.py 2>&1 | grep prec > $O/${R}_conv_micro_bf16x3.txt
 PREC=2 WHAT=conv timeout 200 python scripts/conv_micro.py 2>&1 | grep prec > $O/${R}_conv_micro_f16.txt
+(for pr in 1 2; do PREC=\$pr timeout 200 python scripts/r06/phase_micro.py 2>&1 | grep prec; done) > $O/${R}_phase_conv.txt
 SHAPES=wgrad PREC=1 WHAT=wgrad timeout 300 python scripts/conv_micro.py 2>&1 | grep prec > $O/${R}_wgrad_micro_bf16x3.txt
 rm -f $O/*.err.empty
 cut -c1-2500 $O/${R}_bench.json; echo
