@@ -10,7 +10,7 @@ struct Conv16Params {
     const float* bias; const float* res; const float* alpha; const float* alpha2;
     const uint16_t* mask16;       // epilogue: y = 0 where this 16-bit activation plane [N][H][W][Co8] is <= 0 (fused ReLU backward)
     uint16_t* o_hi; uint16_t* o_lo;   // optional: 16-bit planes [N][H][W][Co8] of (o_relu ? relu(y) : y) for the consumer conv
-    int o_relu;
+    int o_relu;                   // bit 0: the emitted planes hold relu(y); bit 1 (round 6): y itself is stored as relu(y) (conv + pool + the next block's in-place ReLU)
     float* amax;                            // LP_AMAX_SLOTS pre-zeroed floats | NULL: fold max|y| in (y will become an fp16 gradient operand)
     float* part; long long part_bytes;      // split-K partial sums [ksplit][N*H*W][Cout] (caller's workspace)
     int N, H, W, Hin, Win, Cin, C8, Cout, Co8, CinP, CoutP;
@@ -145,6 +145,7 @@ __device__ __forceinline__ void conv16_epilogue(const Conv16Params& p, f32x4_t (
                     v.x = (mv.x - 1u) < 0x7fffu ? v.x : 0.f; v.y = (mv.y - 1u) < 0x7fffu ? v.y : 0.f;
                     v.z = (mv.z - 1u) < 0x7fffu ? v.z : 0.f; v.w = (mv.w - 1u) < 0x7fffu ? v.w : 0.f;
                 }
+                if (p.o_relu & 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 if (p.y) *(float4*)(p.y + pix * p.Cout + co) = v;
                 am = lp_amax4(am, v);
                 if (p.stats) {                     // shifted sums (reference = the lane's first value): no cancellation at large |mean| / std
@@ -160,7 +161,7 @@ __device__ __forceinline__ void conv16_epilogue(const Conv16Params& p, f32x4_t (
                     uint16_t* ohp = (uint16_t*)&oh; uint16_t* olp = (uint16_t*)&ol;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float q = p.o_relu ? fmaxf(o[j], 0.f) : o[j];
+                        const float q = (p.o_relu & 1) ? fmaxf(o[j], 0.f) : o[j];
                         ohp[j] = lp_f32_to_op16<F16>(q);
                         if (SPLIT) olp[j] = lp_f32_to_op16<false>(q - lp_op16_to_f32<false>(ohp[j]));
                     }
@@ -227,7 +228,7 @@ __device__ __forceinline__ void conv16_epilogue(const Conv16Params& p, f32x4_t (
                     if (p.y) p.y[pix + co] = v;
                     am_s = fmaxf(am_s, fabsf(v));
                     if (p.o_hi) {
-                        const float q = p.o_relu ? fmaxf(v, 0.f) : v;
+                        const float q = (p.o_relu & 1) ? fmaxf(v, 0.f) : v;
                         const uint16_t h = lp_f32_to_op16<F16>(q);
                         p.o_hi[pixi * p.Co8 + co] = h;
                         if (SPLIT) p.o_lo[pixi * p.Co8 + co] = lp_f32_to_op16<false>(q - lp_op16_to_f32<false>(h));

@@ -372,6 +372,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(Conv16Params p) {
             v.x = (mv.x - 1u) < 0x7fffu ? v.x : 0.f; v.y = (mv.y - 1u) < 0x7fffu ? v.y : 0.f;
             v.z = (mv.z - 1u) < 0x7fffu ? v.z : 0.f; v.w = (mv.w - 1u) < 0x7fffu ? v.w : 0.f;
         }
+        if (p.o_relu & 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         if (p.y) *(float4*)(p.y + pix * p.Cout + co) = v;
         am = lp_amax4(am, v);
         if (p.o_hi) {
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(Conv16Params p) {
             uint16_t* ohp = (uint16_t*)&oh; uint16_t* olp = (uint16_t*)&ol;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float q = p.o_relu ? fmaxf(o[j], 0.f) : o[j];
+                const float q = (p.o_relu & 1) ? fmaxf(o[j], 0.f) : o[j];
                 ohp[j] = lp_f32_to_op16<F16>(q);
                 if (SPLIT) olp[j] = lp_f32_to_op16<false>(q - lp_op16_to_f32<false>(ohp[j]));
             }
@@ -656,7 +657,7 @@ extern "C" int lp_conv16_fwd_stats(const uint16_t* a_hi, const uint16_t* a_lo, c
     // channel counts the epilogue writes element-wise (Cout % 8 != 0: padding channels) get their 16-bit planes from a
     // bandwidth-bound pass over the finished y instead (same stream)
     if (out_hi && !p.o_hi)
-        return lp_act_pack(y, nullptr, nullptr, out_relu ? 2 : 0, out_hi, out_lo, N, H * W, Cout, prec, nullptr, nullptr, 0, 1, nullptr, stream);
+        return lp_act_pack(y, nullptr, nullptr, (out_relu & 1) ? 2 : 0, out_hi, out_lo, N, H * W, Cout, prec, nullptr, nullptr, 0, 1, nullptr, stream);
     return LP_OK;
 }
 

@@ -27,11 +27,32 @@ __device__ __forceinline__ float lp_phase_tap_sum(const float* __restrict__ w9, 
     return v;
 }
 
+// modes 4 / 5 (round 6): a 3x3 conv FOLLOWED BY AvgPool2d(2) (the critic's down blocks, discriminators/no_landmarks.py:52-81 via blocks.py:76-90) is a
+// 4x4 stride-2 conv: pooled[y] = 1/4 sum_{a in {0,1}} conv[2y + a] = sum_{u = -1..2} W4[u] in[2y + u],  W4[u] = 1/4 sum of w[dy] over dy = u - a + 1 in [0, 2]
+// (rows; columns alike) -- 16 taps per pooled output instead of 4 x 9: 4/9 of the matrix work, and the un-pooled conv output never exists.
+// It runs on the phase kernels: hi-res offset u = 2 ky - pa of (phase pa, tap ky) in the gather form (lp_conv16_fwd upsample = 3), and its
+// data gradient on the scatter-free phase-forward form (upsample = 2): hi-res pixel 2y + a collects W4[u_a(i)]^T d_pooled[y + a - 1 + i],
+// u_0 = (2, 0), u_1 = (1, -1).
+//   mode 4 (forward):        out[t = (pa, pb, ky, kx)][co][ci] = W4[2 ky - pa][2 kx - pb]
+//   mode 5 (data gradient):  out[t = (a, b, i, j)][ci][co]     = W4[u_a(i)][u_b(j)]
+__device__ __forceinline__ float lp_pool_tap_sum(const float* __restrict__ w9, int u, int v) {
+    float s = 0.f;
+    for (int dy = (u > 0 ? u : 0); dy <= (u + 1 < 2 ? u + 1 : 2); ++dy)
+        for (int dx = (v > 0 ? v : 0); dx <= (v + 1 < 2 ? v + 1 : 2); ++dx) s += w9[dy * 3 + dx];
+    return 0.25f * s;
+}
+
 __device__ __forceinline__ float lp_pack_value(const float* __restrict__ w, int Cout, int Cin, int T, int mode, int t, int row, int col) {
     if (mode == 0) return (row < Cout && col < Cin) ? w[((size_t)row * Cin + col) * T + t] : 0.f;                 // [t][co][ci]
     if (mode == 1) return (row < Cin && col < Cout) ? w[((size_t)col * Cin + row) * T + (T - 1 - t)] : 0.f;     // [T-1-t][ci][co]
     if (mode == 2) return (row < Cout && col < Cin) ? lp_phase_tap_sum(w + ((size_t)row * Cin + col) * 9, t, false) : 0.f;
-    return (row < Cin && col < Cout) ? lp_phase_tap_sum(w + ((size_t)col * Cin + row) * 9, t, true) : 0.f;
+    if (mode == 3) return (row < Cin && col < Cout) ? lp_phase_tap_sum(w + ((size_t)col * Cin + row) * 9, t, true) : 0.f;
+    if (mode == 4) {
+        const int pa = (t >> 3) & 1, pb = (t >> 2) & 1, ky = (t >> 1) & 1, kx = t & 1;
+        return (row < Cout && col < Cin) ? lp_pool_tap_sum(w + ((size_t)row * Cin + col) * 9, 2 * ky - pa, 2 * kx - pb) : 0.f;
+    }
+    const int a = (t >> 3) & 1, b = (t >> 2) & 1, i = (t >> 1) & 1, j = t & 1;
+    return (row < Cin && col < Cout) ? lp_pool_tap_sum(w + ((size_t)col * Cin + row) * 9, (a ? 1 : 2) - 2 * i, (b ? 1 : 2) - 2 * j) : 0.f;
 }
 
 __global__ void pack_weights_kernel(const float* __restrict__ w, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo,
@@ -146,8 +167,8 @@ extern "C" int lp_pack_weights_batch(const void* table, int num_entries, long lo
 extern "C" int lp_pack_weights(const float* w, uint16_t* hi, uint16_t* lo, int Cout, int Cin, int T, int RowsP, int ColsP, int mode,
                                int f16, void* stream) {
     if (!w || !hi) return lp_set_error(LP_ERR_ARG, "lp_pack_weights: null pointer");
-    if (mode < 0 || mode > 3 || (mode >= 2 && T != 9)) return lp_set_error(LP_ERR_ARG, "lp_pack_weights: mode 0 | 1, or 2 | 3 (phase forms of a 3x3 weight: T = 9)");
-    int rows = (mode == 0 || mode == 2) ? Cout : Cin, cols = (mode == 0 || mode == 2) ? Cin : Cout;
+    if (mode < 0 || mode > 5 || (mode >= 2 && T != 9)) return lp_set_error(LP_ERR_ARG, "lp_pack_weights: mode 0 | 1, or 2 .. 5 (phase / conv + pool forms of a 3x3 weight: T = 9)");
+    int rows = (mode == 0 || mode == 2 || mode == 4) ? Cout : Cin, cols = (mode == 0 || mode == 2 || mode == 4) ? Cin : Cout;
     if (RowsP < rows || ColsP < cols || (ColsP & 7)) return lp_set_error(LP_ERR_ARG, "lp_pack_weights: bad padded dims");
     long long total = (long long)(mode >= 2 ? 16 : T) * RowsP * ColsP;
     hipLaunchKernelGGL(pack_weights_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, hi, lo, Cout, Cin, T,

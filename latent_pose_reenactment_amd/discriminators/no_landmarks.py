@@ -26,6 +26,9 @@ import os as _os
 PLANES_ONLY = _os.environ.get('LP_D_PLANES_ONLY', '1') != '0'
 # pool -> (next block's in-place) ReLU -> operand planes in ONE launch (round 5; 0: three launches)
 FUSE_POOL_RELU = _os.environ.get('LP_D_POOL_RELU', '1') != '0'
+# conv2 + skip + AvgPool2d(2) + the next block's ReLU of every down block / the stem as ONE 4x4 stride-2 conv launch (round 6, nn.ConvPoolFn: 4/9 of the
+# matrix work, no full-resolution block output); 0: conv, then the pool launch
+CONV_POOL = _os.environ.get('LP_D_CONVPOOL', '1') != '0'
 
 
 def gpass_prec():
@@ -83,6 +86,13 @@ def _wb(layer, track, states):
     return w, b, states[id(layer)]
 
 
+def _conv_pool(h, layer, track, states, prec, res, x16, relu_out, emit):
+    """conv3x3(relu(h)) + bias, AvgPool2d(2), + res, [ReLU] in one launch (nn.ConvPoolFn); packs shared through the per-step cache like ``_conv``"""
+    w, b, st = _wb(layer, track, states)
+    prec = default_prec() if prec is None else prec
+    return lpnn.ConvPoolFn.apply(h, w, b, res, prec, states['packs'].setdefault(prec, {}), st, x16, relu_out, emit)
+
+
 def _conv(x, layer, track, states, prec=None, **kw):
     """SN conv through the HIP kernels; the 16-bit packs of W_orig are shared by the three passes of a step and their backward
     passes (only 1/sigma differs between passes) through the per-step cache ``states['packs']`` (one dict per operand mode)"""
@@ -124,6 +134,14 @@ class _DisBlock(nn.Module):
                 return AvgPool2Fn.apply(out, False)
             return pool_relu(out, next_prec) if self.downsample else out
         h, h16 = _conv(x_relu, c1, track, states, prec, ksize=3, x16=xr16, emit16=1, want_y=not PLANES_ONLY)      # (h itself is never read: conv2 takes the planes)
+        if self.downsample and CONV_POOL:
+            # pool(conv2(relu(h)) + skip(x)) = conv4x4/2(relu(h)) + skip(pool(x)): the 1x1 skip conv commutes with the average
+            xp = AvgPool2Fn.apply(x_relu, False)
+            shortcut_lo = _conv(xp, self.skip._modules['0'], track, states, prec, ksize=1) if self.has_skip else xp
+            nprec = default_prec() if next_prec is None else next_prec
+            holder = [] if (not last and nprec == prec) else None          # (the epilogue emits planes in its own operand mode only)
+            y = _conv_pool(h, c2, track, states, prec, shortcut_lo, h16, not last, holder)
+            return y if last else (y, holder[0] if holder else None)
         shortcut = _conv(x_relu, self.skip._modules['0'], track, states, prec, ksize=1, x16=xr16) if self.has_skip else x_relu
         out = _conv(h, c2, track, states, prec, res=shortcut, ksize=3, pro=2, x16=h16)
         if self.downsample and last:          # the final feature map is handed out BEFORE any ReLU (the reference appends it un-mutated)
@@ -191,10 +209,15 @@ class Discriminator(nn.Module):
         for prec, convs in [(default_prec(), [m for u in units for m in u])] + [(sp, [m for u in units[sf:] for m in u]) for sp, sf in strict_from.items()]:
             if not convs:
                 continue
+            # conv + pool launches (nn.ConvPoolFn: the stem's second conv, conv2 of every down block) take the 16-tap images of modes 4 / 5
+            pooled = {id(d2)} | {id(blk.block._modules['5']) for blk in self.blocks if blk.downsample and not blk.reflect} if CONV_POOL else set()
             specs = []
             for m in convs:
                 w = m.weight_orig
                 ks = w.shape[-1]
+                if id(m) in pooled:
+                    specs += [(w, 4, False), (w, 5, False)]
+                    continue
                 specs.append((w, 0, ks == 3 and w.shape[1] <= 32))
                 specs.append((w, 1, ks == 3 and w.shape[0] <= 32))
             key = tuple((w.data_ptr(), mode, bool(k_)) for w, mode, k_ in specs)
@@ -252,9 +275,18 @@ class Discriminator(nn.Module):
         unit_prec = lambda u: sprec if (sprec is not None and u >= sfrom) else None          # None = the default mode
         p0 = unit_prec(0)
         h, h16 = _conv(xn, d0, track_weights, states, p0, ksize=3, emit16=1, want_y=not PLANES_ONLY)
-        shortcut = _conv(xn, sk, track_weights, states, p0, ksize=1)
         nb = len(self.blocks)
-        out_relu, xr16 = pool_relu(_conv(h, d2, track_weights, states, p0, res=shortcut, ksize=3, pro=2, x16=h16), unit_prec(1) if nb else None)
+        if CONV_POOL:
+            # stem: pool(conv2(relu(h)) + skip(image)) as one launch; the skip conv (3 -> 64, 1x1) runs on the pooled image
+            shortcut_lo = _conv(to_nhwc(F.avg_pool2d(x, 2)), sk, track_weights, states, p0, ksize=1)
+            pp0 = default_prec() if p0 is None else p0
+            np1 = unit_prec(1) if nb else None
+            holder = [] if (default_prec() if np1 is None else np1) == pp0 else None
+            out_relu = _conv_pool(h, d2, track_weights, states, p0, shortcut_lo, h16, True, holder)
+            xr16 = holder[0] if holder else None
+        else:
+            shortcut = _conv(xn, sk, track_weights, states, p0, ksize=1)
+            out_relu, xr16 = pool_relu(_conv(h, d2, track_weights, states, p0, res=shortcut, ksize=3, pro=2, x16=h16), unit_prec(1) if nb else None)
         feats = []
         out = out_relu
         for bi, block in enumerate(self.blocks):

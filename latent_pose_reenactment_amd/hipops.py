@@ -70,11 +70,12 @@ class WeightPack(NamedTuple):
 
 def _pack_geometry(w: Tensor, mode: int, small_k: bool):
     """(cout, cin, taps in, taps out, rows, cols, rows_p, cols_p) of a pack: modes 0 / 2 are [taps][Cout][Cin] images, 1 / 3 [taps][Cin][Cout];
-    2 / 3 = the phase forms of a x2-upsampled 3x3 conv (16 taps: lp_pack_weights)"""
+    2 / 3 = the phase forms of a x2-upsampled 3x3 conv, 4 / 5 = forward / data gradient of a 3x3 conv followed by AvgPool2d(2) (16 taps:
+    lp_pack_weights)"""
     cout, cin = w.shape[0], w.shape[1]
     taps = w.numel() // (cout * cin)
     assert mode in (0, 1) or taps == 9, 'the phase forms (modes 2 / 3) pack a 3x3 weight'
-    rows, cols = (cout, cin) if mode in (0, 2) else (cin, cout)
+    rows, cols = (cout, cin) if mode in (0, 2, 4) else (cin, cout)
     rows_p = _round_up(rows, 128)
     cols_p = _round_up(cols, 32 if (small_k and cols <= 32) else 64)
     return cout, cin, taps, (16 if mode >= 2 else taps), rows, cols, rows_p, cols_p
@@ -275,7 +276,7 @@ class ConvStats(NamedTuple):
 def conv16(a: Act16, pack: WeightPack, *, ksize: int, upsample: bool = False, bias: Optional[Tensor] = None,
            res: Optional[Tensor] = None, res_shift: int = 0, alpha: Optional[Tensor] = None, prec: int = PREC_BF16,
            relu_mask: Optional[Act16] = None, out16: Optional[int] = None, amax: bool = False, stats: bool = False, want_y: bool = True,
-           kind: str = 'conv_igemm', phase: bool = False, phase_dgrad: bool = False):
+           kind: str = 'conv_igemm', phase: bool = False, phase_dgrad: bool = False, y_relu: bool = False):
     """y = alpha * conv(up2?(a), pack) + bias + res on operand planes; a [N,Hin,Win,C8] -> y [N,H,W,Cout] fp32.
     ``relu_mask``: operand planes [N,H,W,Co8] of the forward conv's input; y is zeroed where they are <= 0 (fused ReLU backward
     when this launch is a data gradient).  ``out16`` = 0 | 1: also return the operand planes of y (1: of relu(y)) -> (y, Act16).
@@ -284,7 +285,10 @@ def conv16(a: Act16, pack: WeightPack, *, ksize: int, upsample: bool = False, bi
     is written, y is returned as None.  ``phase`` (with ``upsample``, 3x3; round 6): ``pack`` is a ``pack_phase_weights`` image and the conv runs in
     its phase-decomposed form -- per output phase (a, b) a 2 x 2 conv on the low-resolution planes with the coinciding taps pre-summed: the same
     result with 4/9 of the matrix work.  ``phase_dgrad``: ``a`` = the planes of dy [N, 2H, 2W, C8] of such a conv, ``pack`` =
-    ``pack_phase_weights(w, prec, dgrad=True)`` -> the gradient w.r.t. the LOW-resolution input [N, H, W, Cout] (the upsample's 2x2 sum included)."""
+    ``pack_phase_weights(w, prec, dgrad=True)`` -> the gradient w.r.t. the LOW-resolution input [N, H, W, Cout] (the upsample's 2x2 sum included).
+    The same two kernel forms run a 3x3 conv FOLLOWED BY AvgPool2d(2) as one 4x4 stride-2 conv (``pack_weights`` modes 4 / 5; nn.ConvPoolFn):
+    ``phase_dgrad`` with a mode-4 pack = pooled conv output from the full-resolution planes, ``phase`` with a mode-5 pack = its data gradient.
+    ``y_relu``: y is stored as relu(y) (the next block's in-place ReLU)."""
     n, hin, win = a.nhw
     cin = a.c
     assert not phase or (upsample and ksize == 3)
@@ -326,7 +330,7 @@ def conv16(a: Act16, pack: WeightPack, *, ksize: int, upsample: bool = False, bi
         check(_lib.lib().lp_conv16_fwd_stats(a.hi.data_ptr(), _p(a.lo), pack.hi.data_ptr(), _p(pack.lo), _p(y), _p(bias), _p(res),
                                              _p(alpha), _p(a.inv), n, h, w, cin, cout, pack.cols_p, pack.rows_p, ksize, 3 if phase_dgrad else 2 if phase else int(upsample),
                                              res_shift, prec, None if relu_mask is None else relu_mask.hi.data_ptr(), _p(o_hi), _p(o_lo),
-                                             int(bool(out16)), _p(ws), ws_bytes, _p(slots), _p(st_buf), st_cap,
+                                             int(bool(out16)) | (2 if y_relu else 0), _p(ws), ws_bytes, _p(slots), _p(st_buf), st_cap,
                                              None if st_rows is None else ctypes.addressof(st_rows), _stream()), 'lp_conv16_fwd')
     out = (y,) if out16 is None else (y, Act16(o_hi, o_lo, cout, None))
     if stats:

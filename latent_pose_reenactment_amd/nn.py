@@ -1104,6 +1104,72 @@ def hip_conv(x, w, bias=None, res=None, ksize=3, pro=0, prec=None, packs=None, s
     return y, holder[0]
 
 
+class ConvPoolFn(torch.autograd.Function):
+    """y = [relu] AvgPool2d(2)( conv3x3(relu(h), W) + bias ) + res  as ONE launch (round 6): conv followed by the 2 x 2 average is a 4x4 stride-2
+    conv -- 16 taps per pooled output instead of 4 x 9 (4/9 of the matrix work), and the full-resolution conv output is never written or read.
+    The critic's down blocks and stem (discriminators/no_landmarks.py:52-81 of the reference; blocks.py:76-90): out = conv2(relu(h)) + skip(x),
+    AvgPool2d(2), then the next block's in-place ReLU -- the pooled skip branch comes in as ``res`` (a 1x1 conv commutes with the pool: it runs on
+    the pooled block input, a quarter of its work).  ``x16`` = the operand planes of relu(h) (conv1's epilogue wrote them; ``h`` itself may be
+    a phantom); ``relu_out``: the result is relu(pooled) -- what every consumer of a block output sees (blocks.py:71-73) -- and ``emit`` (a list)
+    receives its operand planes for the next conv.  Forward: lp_conv16_fwd upsample = 3 with an lp_pack_weights mode-4 image.  Backward: the data
+    gradient (with the ReLU mask of relu(h)) is the scatter-free phase-forward form (upsample = 2, mode-5 image) on the planes of the masked
+    pooled gradient; the weight / bias gradient takes the 0.25-upsampled gradient through lp_conv16_wgrad as the unfused chain does."""
+
+    @staticmethod
+    def forward(ctx, h, w, bias, res, prec, packs, sn, x16, relu_out, emit):
+        wd = w.detach().contiguous()
+
+        def pk(mode):
+            if isinstance(packs, dict):
+                key = (wd.data_ptr(), mode)
+                if key not in packs:
+                    packs[key] = ops.pack_weights(wd, mode, prec)
+                return packs[key]
+            return ops.pack_weights(wd, mode, prec)
+        bd = None if bias is None else bias.detach().contiguous()
+        alpha = None if sn is None else sn[2][1:]
+        out = ops.conv16(x16, pk(4), ksize=3, bias=bd, res=res, alpha=alpha, prec=prec, phase_dgrad=True,
+                         out16=(1 if relu_out else 0) if emit is not None else None, y_relu=bool(relu_out))
+        if emit is not None:
+            y, o16 = out
+            emit.append(o16)
+        else:
+            y = out
+        ctx.x16, ctx.wd, ctx.pk = x16, wd, pk
+        ctx.save_for_backward(y if relu_out else None)          # (an OUTPUT kept on ctx as a plain attribute would be a reference cycle: the graph -- and every
+                                                                 #  spectral-norm state set it reserves -- would only be freed by the garbage collector)
+        ctx.w_param = w if (sn is not None and w.requires_grad and w.is_leaf) else None
+        ctx.b_param = bias if (bias is not None and bias.requires_grad and bias.is_leaf) else None
+        ctx.accum_alt = _ALT['on']
+        ctx.cfg = (prec, bias is not None, res is not None, sn)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        prec, has_bias, has_res, sn = ctx.cfg
+        x16, wd = ctx.x16, ctx.wd
+        (y_out,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        f16 = prec == PREC_F16
+        dm = dy if y_out is None else torch.where(y_out > 0, dy, torch.zeros((), dtype=dy.dtype, device=dy.device))      # the ReLU behind the pool
+        dx = dw = db = None
+        alpha = None if sn is None else sn[2][1:]
+        if ctx.needs_input_grad[0]:
+            d16 = ops.act_pack(dm, prec=prec, grad=True)
+            dx = ops.conv16(d16, ctx.pk(5), ksize=3, upsample=True, phase=True, alpha=alpha, prec=prec, relu_mask=x16, amax=f16)
+        want_db = has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1]:
+            dhi = ops.avgpool2_bwd(dy, None, False, amax=f16, y_relu=y_out)          # 0.25 * nearest-upsampled (masked) gradient: the conv output's
+            dw = ops.conv_wgrad16(x16, ops.act_pack(dhi, prec=prec, grad=True), ksize=3, prec=prec, sn=None if sn is None else (wd,) + tuple(sn),
+                                  accum=None if ctx.w_param is None else _accum_target(ctx.w_param, ctx.accum_alt), bias_grad=want_db,
+                                  bias_accum=_accum_target(ctx.b_param, ctx.accum_alt) if (want_db and ctx.b_param is not None) else None)
+            if want_db:
+                dw, db = dw
+        elif want_db:
+            db = dm.sum(dim=(0, 1, 2))
+        return dx, dw, db, (dm if (has_res and ctx.needs_input_grad[3]) else None), None, None, None, None, None, None
+
+
 class AvgPool2Fn(torch.autograd.Function):
     """AvgPool2d(2) of relu?(x), NHWC (blocks.py:89-90 / perceptual_loss.py:77 with the preceding ReLU fused); ``relu_out``: relu(pool(x)) -- the
     in-place ReLU of the critic's NEXT block (blocks.py:71-73) fused into the pool launch (round 5: one launch instead of pool + relu + pack)."""
