@@ -54,7 +54,7 @@ LP_OVERLAP=0 timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline
 env -u WORLD_SIZE -u RANK -u LOCAL_RANK timeout 600 python bench.py --gpus 2 --steps 6 --warmup 2 --backend gloo --no-cpu-baseline --no-also --no-drive > $O/${R}_bench_dp2_gloo_one_gpu_functional.json 2> $O/${R}_bench_dp2.err
 PREC=1 WHAT=conv timeout 200 python scripts/conv_micro.py 2>&1 | grep prec > $O/${R}_conv_micro_bf16x3.txt
 PREC=2 WHAT=conv timeout 200 python scripts/conv_micro.py 2>&1 | grep prec > $O/${R}_conv_micro_f16.txt
-(for pr in 1 2; do PREC=\$pr timeout 200 python scripts/r06/phase_micro.py 2>&1 | grep prec; done) > $O/${R}_phase_conv.txt
+(for pr in 1 2; do PREC=$pr timeout 200 python scripts/r06/phase_micro.py 2>&1 | grep prec; done) > $O/${R}_phase_conv.txt
 SHAPES=wgrad PREC=1 WHAT=wgrad timeout 300 python scripts/conv_micro.py 2>&1 | grep prec > $O/${R}_wgrad_micro_bf16x3.txt
 rm -f $O/*.err.empty
 cut -c1-2500 $O/${R}_bench.json; echo
