@@ -338,6 +338,17 @@ int lp_adain_relu_bwd_planes(const float* dA, const float* x, const float* add, 
                              int N, int H, int W, int C, int upsample, uint16_t* out_hi, uint16_t* out_lo, int keep_dx, void* stream);
 int lp_sum2x2_planes(const float* in, float* out, uint16_t* out_hi, uint16_t* out_lo, int N, int H, int W, int C, void* stream);
 
+/* (ABI 11, round 6) Backward of conv3x3 + nn.AvgPool2d(2) [+ the next block's in-place ReLU] (the critic's down blocks, generators/common/blocks.py:76-90,
+ * discriminators/no_landmarks.py:52-81) as ONE pass over the pooled gradient dy [N][h][w][C] (C % 8 == 0):
+ *   dm = dy * [ymask > 0] (ymask [N][h][w][C] fp32 = the stored relu(pooled) output | NULL: no ReLU behind the pool); dm (fp32) | NULL;
+ *   lo_hi / lo_lo [N][h][w][C] | NULL: operand planes of dm (what lp_act_pack of dm writes; operand of the data-gradient launch);
+ *   up_hi / up_lo [N][2h][2w][C] | NULL: operand planes of 0.25 * nearest_up2(dm) -- the pool's adjoint, operand of lp_conv16_wgrad -- the same 16-bit values
+ *   replicated over each 2 x 2 window.  Replaces torch.where(y > 0, dy, 0), lp_act_pack, lp_avgpool2_bwd (a full-resolution fp32 round trip) and a second
+ *   lp_act_pack.  fp16 mode: amax_part / amax_count / amax_stride as in lp_act_pack (partials of dy: lp_amax_partial), scale_out[4] (device) =
+ *   {s, 1/s, 4 s, 1/(4 s)}: the lo planes carry scale s, the up planes 4 s (0.25 dm * 4 s = dm * s).  bf16 / bf16x3: no scale, scale_out untouched. */
+int lp_pool_grad_pack(const float* dy, const float* ymask, float* dm, uint16_t* lo_hi, uint16_t* lo_lo, uint16_t* up_hi, uint16_t* up_lo,
+                      int N, int h, int w, int C, int prec, const float* amax_part, int amax_count, int amax_stride, float* scale_out, void* stream);
+
 /* Generator head (noBottleneck.py:86-88,170-181): t = tanh(z), rgb = t[:3]*0.75+0.5, segm = t[3]*0.5+0.5,
  * fake_rgbs = rgb*segm.  z/t NHWC [N][H][W][4]; fake_rgbs NCHW [N][3][H][W]; fake_segm NCHW [N][1][H][W]. */
 int lp_head_fwd(const float* z, float* t, float* fake_rgbs, float* fake_segm, int N, int H, int W, void* stream);

@@ -139,6 +139,97 @@ extern "C" int lp_act_pack(const float* x, const float* scale, const float* shif
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------------------------
+// Backward of conv + AvgPool2d(2) [+ the next block's ReLU] as ONE pass over the pooled gradient (round 6, nn.ConvPoolFn.backward):
+//   dm = dy * [ymask > 0]                      the ReLU behind the pool (ymask = the stored relu(pooled) output | NULL: no ReLU)
+//   lo planes [N][h][w][C]   = split(dm * s)   operand of the data-gradient launch (and of the skip conv's backward)
+//   up planes [N][2h][2w][C] = the same 16-bit values at the four positions of every 2 x 2 window: the operand planes of 0.25 * nearest_up2(dm) --
+//                              the pool's adjoint, operand of the weight-gradient launch -- under the scale 4 s (fp16) / as split(0.25 dm) (bf16 modes:
+//                              a power-of-two factor commutes with the hi / lo split)
+// It replaces gt + where (2 ATen launches), lp_act_pack(dm), lp_avgpool2_bwd (a full-resolution fp32 tensor written and read back) and
+// lp_act_pack of that tensor.  fp16: s = the power of two lp_act_pack would take from amax(dy) (>= amax(dm): no overflow);
+// scale_out = {s, 1/s, 4 s, 1/(4 s)}.  Every thread owns 8 channels of one pooled pixel.
+// ------------------------------------------------------------------------------------------------------------------
+template <int PREC>
+__global__ __launch_bounds__(256) void pool_grad_pack_kernel(const float* __restrict__ dy, const float* __restrict__ ymask, float* __restrict__ dm,
+                                                             uint16_t* __restrict__ lo_hi, uint16_t* __restrict__ lo_lo,
+                                                             uint16_t* __restrict__ up_hi, uint16_t* __restrict__ up_lo, long long items, int h, int w, int C,
+                                                             const float* __restrict__ amax_part, int amax_count, int amax_stride, float* __restrict__ scale_out) {
+    constexpr bool SPLIT = (PREC == LP_PREC_BF16X3), F16 = (PREC == LP_PREC_F16);
+    float isc = 1.f;
+    if (F16 && amax_part) {
+        __shared__ float sh[4];
+        float m = 0.f;
+        for (int j = threadIdx.x; j < amax_count; j += 256) m = fmaxf(m, amax_part[(size_t)j * amax_stride]);
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+        float inv;
+        amax_to_scale(m, isc, inv);
+        if (scale_out && blockIdx.x == 0 && threadIdx.x == 0) { scale_out[0] = isc; scale_out[1] = inv; scale_out[2] = 4.f * isc; scale_out[3] = 0.25f * inv; }
+    }
+    const int G = C >> 3;
+    const float upf = F16 ? 1.f : 0.25f;          // fp16: the factor lives in the planes' scale; bf16 modes: in the values
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < items; i += (long long)gridDim.x * 256) {
+        const int g = (int)(i % G);
+        const long long pix = i / G;
+        const size_t e = (size_t)pix * C + (size_t)g * 8;
+        float4 a = *(const float4*)(dy + e), b = *(const float4*)(dy + e + 4);
+        if (ymask) {
+            const float4 ma = *(const float4*)(ymask + e), mb = *(const float4*)(ymask + e + 4);
+            a.x = ma.x > 0.f ? a.x : 0.f; a.y = ma.y > 0.f ? a.y : 0.f; a.z = ma.z > 0.f ? a.z : 0.f; a.w = ma.w > 0.f ? a.w : 0.f;
+            b.x = mb.x > 0.f ? b.x : 0.f; b.y = mb.y > 0.f ? b.y : 0.f; b.z = mb.z > 0.f ? b.z : 0.f; b.w = mb.w > 0.f ? b.w : 0.f;
+        }
+        if (dm) { *(float4*)(dm + e) = a; *(float4*)(dm + e + 4) = b; }
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        s16x8_t hl, ll, hu, lu;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float q = v[j] * isc;
+            const uint16_t hb = lp_f32_to_op16<F16>(q);
+            hl[j] = (short)hb;
+            if (SPLIT) ll[j] = (short)lp_f32_to_op16<false>(q - lp_op16_to_f32<false>(hb));
+            if (F16) { hu[j] = hl[j]; }
+            else {
+                const float qu = q * upf;
+                const uint16_t hbu = lp_f32_to_op16<false>(qu);
+                hu[j] = (short)hbu;
+                if (SPLIT) lu[j] = (short)lp_f32_to_op16<false>(qu - lp_op16_to_f32<false>(hbu));
+            }
+        }
+        if (lo_hi) { *(s16x8_t*)(lo_hi + e) = hl; if (SPLIT) *(s16x8_t*)(lo_lo + e) = ll; }
+        if (up_hi) {
+            const int x = (int)(pix % w); const long long t = pix / w; const int y = (int)(t % h); const long long n = t / h;
+            const size_t row = ((size_t)(n * 2 * h + 2 * y) * (2 * w) + 2 * x) * C + (size_t)g * 8;
+            const size_t dn = (size_t)2 * w * C;
+            *(s16x8_t*)(up_hi + row) = hu; *(s16x8_t*)(up_hi + row + C) = hu; *(s16x8_t*)(up_hi + row + dn) = hu; *(s16x8_t*)(up_hi + row + dn + C) = hu;
+            if (SPLIT) { *(s16x8_t*)(up_lo + row) = lu; *(s16x8_t*)(up_lo + row + C) = lu; *(s16x8_t*)(up_lo + row + dn) = lu; *(s16x8_t*)(up_lo + row + dn + C) = lu; }
+        }
+    }
+}
+
+extern "C" int lp_pool_grad_pack(const float* dy, const float* ymask, float* dm, uint16_t* lo_hi, uint16_t* lo_lo, uint16_t* up_hi, uint16_t* up_lo,
+                                 int N, int h, int w, int C, int prec, const float* amax_part, int amax_count, int amax_stride, float* scale_out,
+                                 void* stream) {
+    if (!dy || (!lo_hi && !up_hi && !dm)) return lp_set_error(LP_ERR_ARG, "lp_pool_grad_pack: null pointer");
+    if (C & 7) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_pool_grad_pack: C must be a multiple of 8");
+    if (prec == LP_PREC_BF16X3 && ((lo_hi && !lo_lo) || (up_hi && !up_lo))) return lp_set_error(LP_ERR_ARG, "lp_pool_grad_pack: bf16x3 needs the lo planes");
+    if (prec == LP_PREC_F16 && (!amax_part || amax_count < 1 || amax_stride < 1 || !scale_out))
+        return lp_set_error(LP_ERR_ARG, "lp_pool_grad_pack: the fp16 mode needs the amax partials of dy (lp_amax_partial) and scale_out[4]");
+    const long long items = (long long)N * h * w * (C >> 3);
+    if (items == 0) return LP_OK;
+    long long blocks = (items + 255) / 256; if (blocks > 4096) blocks = 4096;
+    hipStream_t st = (hipStream_t)stream;
+#define LP_PG(P) hipLaunchKernelGGL(pool_grad_pack_kernel<P>, dim3((unsigned)blocks), dim3(256), 0, st, dy, ymask, dm, lo_hi, lo_lo, up_hi, up_lo, items, h, w, C, amax_part, amax_count, amax_stride, scale_out)
+    if (prec == LP_PREC_BF16) LP_PG(LP_PREC_BF16);
+    else if (prec == LP_PREC_BF16X3) LP_PG(LP_PREC_BF16X3);
+    else if (prec == LP_PREC_F16) LP_PG(LP_PREC_F16);
+    else return lp_set_error(LP_ERR_ARG, "lp_pool_grad_pack: unknown precision mode");
+#undef LP_PG
+    return lp_check_launch("pool_grad_pack");
+}
+
 // amax partials of a gradient tensor: part[AMAX_BLOCKS] block maxima of |x| (every entry written); lp_act_pack finishes the
 // reduction (amax_part argument), so a gradient operand costs one extra streaming read and no extra finalize launch
 // ------------------------------------------------------------------------------------------------------------------

@@ -64,7 +64,8 @@ void conv_dma_kernel(Conv16Params p) {
     constexpr int AIT = ((BM == 128) ? (NWAVE == 8 ? 3 : 5) : 6) * (CC / 32) - (CC == 64 ? 1 : 0);     // max halo DMA instructions per wave (host checks p.hit <= AIT)
     constexpr int NBW = ((NQ + NWD - 1) / NWD) * (SPLIT ? 2 : 1);     // weight DMA instructions one wave issues per stage
     static_assert(B_STAGE % 1024 == 0, "stage must be a whole number of 1 KiB DMA pieces");
-    static_assert(NBUF == 2 || (NBUF == 3 && !PP && NQ % NWD == 0), "3-deep weight ring: single group, uniform DMA count per wave");
+    static_assert(NBUF == 2 || (NBUF == 3 && !PP && NQ % NWD == 0) || (NBUF == 1 && !PP && KS == 1),
+                  "3-deep weight ring: single group, uniform DMA count per wave; NBUF = 1: pointwise layers, ONE weight stage + double-buffered activations");
     static_assert(!PP || ((KS == 3 || KS == 2) && NWAVE == 4), "ping-pong: two 4-wave groups, 3x3 (or the 2x2 phase form)");
     static_assert(!(UPS && KS != 3), "1x1 convs commute with nearest upsampling: run them at low resolution; KS = 2 IS the phase form of an upsampled 3x3 conv");
     static_assert(KS == 1 || KS == 2 || KS == 3, "kernel sizes");
@@ -145,7 +146,7 @@ void conv_dma_kernel(Conv16Params p) {
     auto issue_a = [&](int chunk, unsigned char* Hbuf) {
         const int c0 = chunk * CC + (p.grouped ? co0 : 0);
         const bool cok = (c0 + a_g8) < p.C8;
-        const unsigned dst = (unsigned)(uintptr_t)Hbuf;
+        const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)Hbuf);          // (m0 operand: an SGPR)
 #pragma unroll
         for (int k = 0; k < AIT; ++k) {
             if (k < p.hit) {
@@ -166,7 +167,7 @@ void conv_dma_kernel(Conv16Params p) {
         const int phq = chunk / nch1, c0 = (chunk - phq * nch1) * CC;
         const int pa = phq >> 1, pb = phq & 1;
         const bool cok = (c0 + a_g8) < p.C8;
-        const unsigned dst = (unsigned)(uintptr_t)Hbuf;
+        const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)Hbuf);          // (m0 operand: an SGPR)
 #pragma unroll
         for (int k = 0; k < AIT; ++k) {
             if (k < p.hit) {
@@ -189,7 +190,7 @@ void conv_dma_kernel(Conv16Params p) {
     auto issue_b = [&](int chunk, int ky, int buf) {
         const int phw = (KS == 2) ? (pdg ? chunk / nch1 : ph) : 0;          // phase whose 2 x 2 tap images this stage reads
         const int c0 = (KS == 2 && pdg ? chunk - phw * nch1 : chunk) * CC;
-        const unsigned dst_lds = (unsigned)(uintptr_t)(B_base + buf * B_BUF);
+        const unsigned dst_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(B_base + buf * B_BUF));
         const int rr = lane / SL, slot = lane % SL;
         const int g8 = (slot ^ rkey(rr)) * 8;
 #pragma unroll
@@ -310,6 +311,21 @@ void conv_dma_kernel(Conv16Params p) {
         // NBUF == 3 (grids of <= 1 workgroup per CU, where nothing else hides the L2/HBM latency of a stage's weights): the DMA of
         // stage s+1 stays in flight across the barrier -- only what stage s needs (everything older, in issue order) is waited for.
         int abuf = 0;
+        if constexpr (NBUF == 1) {
+            // pointwise layers bound by their activation traffic (round 6): the ACTIVATION chunk -- the operand that comes from HBM -- is double
+            // buffered and prefetched one chunk ahead; the weight stage -- L2 resident, a third of the latency -- has ONE buffer and is restaged
+            // after the chunk's MFMAs.  Same LDS as one activation buffer + two weight stages (three workgroups per CU), but what a chunk now
+            // waits for is an L2 hit instead of an HBM round trip.
+            for (int chunk = 0; chunk < nch; ++chunk) {
+                const bool has_next = chunk + 1 < nch;
+                lp_wait_vm0();
+                __syncthreads();
+                if (has_next) issue_halo(cbeg + chunk + 1, H_base + __builtin_amdgcn_readfirstlane((abuf ^ 1) * a_buf));      // (the DMA's LDS base travels in m0: an SGPR)
+                compute(0, H_base + abuf * a_buf, 0, cbeg + chunk);
+                if (has_next) { __syncthreads(); issue_b(cbeg + chunk + 1, 0, 0); }
+                abuf ^= 1;
+            }
+        } else {
         if (NBUF == 3 && S > 1) issue_b(cbeg + 1 / KS, 1 % KS, 1);
         for (int chunk = 0; chunk < nch; ++chunk) {
             const bool has_next = chunk + 1 < nch;
@@ -331,6 +347,7 @@ void conv_dma_kernel(Conv16Params p) {
                 }
             }
             if (p.a_dbuf) abuf ^= 1;
+        }
         }
     }
 
@@ -443,8 +460,16 @@ static int launch_conv16(Conv16Params& p, hipStream_t stream) {
     // bf16x3 pointwise layers with short contractions (<= 8 chunks: the layers bound by their traffic): one activation buffer, i.e. a
     // third resident workgroup per CU, beats the double buffer (longer contractions lose 5 - 10 % with it and keep two)
     if (adbuf_env < 0 && KS == 1 && SPLIT && CC == 32 && p.CinP <= 256) p.a_dbuf = 0;
+    // LP_CONV1X1_B1=1 (round 6 experiment, OFF): those layers with TWO activation buffers and ONE weight stage instead (NBUF = 1 schedule of the kernel):
+    // the HBM round trip of every activation chunk is hidden behind the previous chunk's MFMAs -- and NOTHING moves (119.8 -> 117.4 us at 262 k pixels x
+    // 128 -> 256, 107.2 -> 105.2 us at 256 -> 128; = 2: also the longer contractions, 5 - 20 % slower: profiles/r06_conv1x1_schedules.txt).  The layers'
+    // times fit  bytes / 8.7 TB/s + MFMA work / 0.7 PF/s: what bounds them is the matrix pipe's stage loop (16 fragment reads per 48 MFMAs and a barrier
+    // per 32-channel stage), not the exposed latency of their activation traffic.
+    static const int b1_env = getenv("LP_CONV1X1_B1") ? atoi(getenv("LP_CONV1X1_B1")) : 0;
+    const bool b1 = KS == 1 && CC == 32 && ((b1_env && !p.a_dbuf) || (b1_env >= 2 && SPLIT && BN == 128));          // 2: also the longer bf16x3 contractions
+    if (b1) p.a_dbuf = 1;
     const size_t lds_halo = (p.a_dbuf ? 2 : 1) * a_buf;
-    size_t lds = lds_halo + 2 * B_BUF;
+    size_t lds = lds_halo + (b1 ? 1 : 2) * B_BUF;
     size_t epi = (size_t)NWAVE * ((KS == 1) ? 16 : MR * 16) * (NR * 16 + 4) * sizeof(float);      // LDS transpose of the coalesced epilogue (1x1: 16 rows per wave at a time)
     const int tiles = p.tiles_x * p.tiles_y * ((p.N + NBv - 1) / NBv) * (phf ? 4 : 1);          // (forward phase form: every tile position once per phase)
     // ping-pong: two adjacent M tiles per workgroup, when the paired grid still covers the CUs.  LP_CONV_PP = 0 | 1 overrides.
@@ -491,6 +516,7 @@ static int launch_conv16(Conv16Params& p, hipStream_t stream) {
     // (64-channel chunks -- CC = 64, twice the MFMAs between two barriers -- were measured 7-15 % SLOWER on the 64^2..256^2 layers: their
     //  146 KB of LDS leave one workgroup per CU, while the 72 KB of the 32-channel kernel let two ping-pong workgroups share a CU)
     if constexpr (pp_ok) { if (pp) return launch_v<KS, UPS, WM, WN, MR, NR, PREC, true, 2, CC, GH>(p, lds, grid, stream); }
+    if constexpr (KS == 1 && CC == 32 && !GH) { if (b1) return launch_v<KS, UPS, WM, WN, MR, NR, PREC, false, 1, CC, GH>(p, lds, grid, stream); }
     // 3-deep weight ring when the grid gives each CU at most ~one workgroup (its LDS would exclude a second one anyway) and it fits
     constexpr int NQ = KS * BN * ROWB / 1024;
     constexpr bool ring_ok = (NQ % NWAVE == 0);
@@ -579,6 +605,8 @@ static int dispatch_conv16(Conv16Params& p, int ks, int ups, hipStream_t s) {
         }
         if (p.Cout <= 64 && big_img) return launch_conv16<1, false, 4, 1, 4, 4, PREC>(p, s);
         if (tall) return launch_conv16<1, false, 4, 2, 4, 4, PREC>(p, s);
+        // (round 6, measured and removed: 128 x 64 tiles for the bf16x3 layers with short contractions -- 41.6 -> 54.8 us, 119.8 -> 154.7 us,
+        //  profiles/r06_conv1x1_schedules.txt)
         return launch_conv16<1, false, 2, 2, 4, 4, PREC>(p, s);
     }
     return lp_set_error(LP_ERR_UNSUPPORTED, "unsupported conv configuration");

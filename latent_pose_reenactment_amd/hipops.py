@@ -832,6 +832,41 @@ def sum2x2_planes(x: Tensor, prec: int) -> 'Act16':
     return Act16(o_hi, o_lo, c, None)
 
 
+# backward of nn.ConvPoolFn in one pass over the pooled gradient (round 6, lp_pool_grad_pack; 0: where + act_pack + avgpool2_bwd + act_pack)
+POOL_GRAD_FUSED = os.environ.get('LP_POOL_GRAD_FUSED', '1') != '0'
+
+
+def pool_grad_pack(dy: Tensor, y_mask: Optional[Tensor], prec: int, want_dm: bool, want_lo: bool, want_up: bool):
+    """dm = dy * [y_mask > 0] -> (dm fp32 | None, operand planes of dm | None, operand planes of 0.25 * nearest_up2(dm) at twice the resolution | None),
+    one launch (fp16 mode: + the amax partials of dy when its producer did not leave them)"""
+    _chk(dy, 'dy')
+    n, h, w, c = dy.shape
+    assert c % 8 == 0 and (y_mask is None or tuple(y_mask.shape) == tuple(dy.shape))
+    if y_mask is not None:
+        _chk(y_mask, 'y_mask')
+    dev = dy.device
+    dm = torch.empty_like(dy) if want_dm else None
+    lo_hi, lo_lo = _alloc16(n, h, w, c, prec, dev) if want_lo else (None, None)
+    up_hi, up_lo = _alloc16(n, 2 * h, 2 * w, c, prec, dev) if want_up else (None, None)
+    part = sc = None
+    npart, pstride = 0, 1
+    if prec == PREC_F16:
+        rec = getattr(dy, '_lp_amax', None)
+        if rec is not None and rec[1] == dy._version and FUSE_AMAX:
+            part, npart, pstride = rec[0], _lib.lib().lp_amax_slots(), _lib.lib().lp_amax_slot_stride()
+            sc = torch.empty(4, dtype=torch.float32, device=dev)
+        else:
+            npart = _lib.lib().lp_amax_blocks()
+            buf = torch.empty(npart + 4, dtype=torch.float32, device=dev)
+            part, sc = buf[:npart], buf[npart:]
+            check(_lib.lib().lp_amax_partial(dy.data_ptr(), dy.numel(), part.data_ptr(), _stream()), 'lp_amax_partial')
+    check(_lib.lib().lp_pool_grad_pack(dy.data_ptr(), _p(y_mask), _p(dm), _p(lo_hi), _p(lo_lo), _p(up_hi), _p(up_lo), n, h, w, c, prec,
+                                       _p(part), npart, pstride, _p(sc), _stream()), 'lp_pool_grad_pack')
+    lo16 = Act16(lo_hi, lo_lo, c, None if sc is None else sc[1:2]) if want_lo else None
+    up16 = Act16(up_hi, up_lo, c, None if sc is None else sc[3:4]) if want_up else None
+    return dm, lo16, up16
+
+
 def sum2x2(x: Tensor, amax: bool = False) -> Tensor:
     _chk(x, 'x')
     n, h2, w2, c = x.shape

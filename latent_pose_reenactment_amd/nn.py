@@ -1049,7 +1049,11 @@ class ConvFn(torch.autograd.Function):
         def dy16():
             nonlocal d16
             if d16 is None:
-                d16 = ops.act_pack(dy, prec=prec, grad=True)
+                rec = getattr(dy, '_lp_planes', None)          # the producer of dy already wrote its operand planes (nn.ConvPoolFn.backward -> the skip conv)
+                if rec is not None and rec[1] == prec and rec[2] == dy._version:
+                    d16 = rec[0]
+                else:
+                    d16 = ops.act_pack(dy, prec=prec, grad=True)
             return d16
         cout, cin, width = dy.shape[3], wd.shape[1], dy.shape[2]
         if ctx.needs_input_grad[0]:
@@ -1151,23 +1155,39 @@ class ConvPoolFn(torch.autograd.Function):
         (y_out,) = ctx.saved_tensors
         dy = dy.contiguous()
         f16 = prec == PREC_F16
-        dm = dy if y_out is None else torch.where(y_out > 0, dy, torch.zeros((), dtype=dy.dtype, device=dy.device))      # the ReLU behind the pool
         dx = dw = db = None
         alpha = None if sn is None else sn[2][1:]
-        if ctx.needs_input_grad[0]:
-            d16 = ops.act_pack(dm, prec=prec, grad=True)
-            dx = ops.conv16(d16, ctx.pk(5), ksize=3, upsample=True, phase=True, alpha=alpha, prec=prec, relu_mask=x16, amax=f16)
         want_db = has_bias and ctx.needs_input_grad[2]
+        want_res = has_res and ctx.needs_input_grad[3]
+        if ops.POOL_GRAD_FUSED and dy.shape[3] % 8 == 0:
+            # ONE pass over the pooled gradient: the ReLU behind the pool, the planes of the masked gradient (data-gradient operand; the skip conv's
+            # backward picks them up through ``_lp_planes``) and the planes of the pool's adjoint 0.25 * up2(dm) (weight-gradient operand) -- no
+            # full-resolution fp32 gradient is written or read
+            need_dm = want_res or (want_db and not ctx.needs_input_grad[1])
+            dm, d16, up16 = ops.pool_grad_pack(dy, y_out, prec, want_dm=need_dm and y_out is not None, want_lo=ctx.needs_input_grad[0] or want_res,
+                                               want_up=ctx.needs_input_grad[1])
+            if y_out is None:
+                dm = dy          # (no ReLU behind the pool: the masked gradient IS dy)
+            if dm is not None and d16 is not None:
+                dm._lp_planes = (d16, prec, dm._version)
+        else:
+            dm = dy if y_out is None else torch.where(y_out > 0, dy, torch.zeros((), dtype=dy.dtype, device=dy.device))      # the ReLU behind the pool
+            d16 = ops.act_pack(dm, prec=prec, grad=True) if ctx.needs_input_grad[0] else None
+            up16 = None
+            if ctx.needs_input_grad[1]:
+                dhi = ops.avgpool2_bwd(dy, None, False, amax=f16, y_relu=y_out)          # 0.25 * nearest-upsampled (masked) gradient: the conv output's
+                up16 = ops.act_pack(dhi, prec=prec, grad=True)
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv16(d16, ctx.pk(5), ksize=3, upsample=True, phase=True, alpha=alpha, prec=prec, relu_mask=x16, amax=f16)
         if ctx.needs_input_grad[1]:
-            dhi = ops.avgpool2_bwd(dy, None, False, amax=f16, y_relu=y_out)          # 0.25 * nearest-upsampled (masked) gradient: the conv output's
-            dw = ops.conv_wgrad16(x16, ops.act_pack(dhi, prec=prec, grad=True), ksize=3, prec=prec, sn=None if sn is None else (wd,) + tuple(sn),
+            dw = ops.conv_wgrad16(x16, up16, ksize=3, prec=prec, sn=None if sn is None else (wd,) + tuple(sn),
                                   accum=None if ctx.w_param is None else _accum_target(ctx.w_param, ctx.accum_alt), bias_grad=want_db,
                                   bias_accum=_accum_target(ctx.b_param, ctx.accum_alt) if (want_db and ctx.b_param is not None) else None)
             if want_db:
                 dw, db = dw
         elif want_db:
             db = dm.sum(dim=(0, 1, 2))
-        return dx, dw, db, (dm if (has_res and ctx.needs_input_grad[3]) else None), None, None, None, None, None, None
+        return dx, dw, db, (dm if want_res else None), None, None, None, None, None, None
 
 
 class AvgPool2Fn(torch.autograd.Function):

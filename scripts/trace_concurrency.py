@@ -13,9 +13,9 @@ with open(sys.argv[1]) as f:
 top = int(sys.argv[2]) if len(sys.argv) > 2 else 45
 rows.sort()
 marks = [i for i, r in enumerate(rows) if 'mt_step_inc' in r[2]]
-if len(marks) < 8:
+if len(marks) < 14:
     sys.exit('not enough optimizer steps in the trace')
-a, b = marks[-5], marks[-3]
+a, b = marks[-9], marks[-7]          # the step scripts/step_breakdown.py cuts (the last two steps of a bench.py trace are its eager one-stream instrumented steps)
 seg = rows[a:b]
 t0, t1 = seg[0][0], max(e for _, e, *_ in seg)
 ev = []

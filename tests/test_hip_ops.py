@@ -220,6 +220,41 @@ def test_gradient_producers_write_operand_planes_directly(shape, ups, prec):
         assert torch.equal(s16.hi, s_ref.hi) and (prec == 0 or torch.equal(s16.lo, s_ref.lo))
 
 
+@pytest.mark.parametrize('prec', [0, 1, 2])
+@pytest.mark.parametrize('masked', [True, False])
+@pytest.mark.parametrize('shape', [(2, 4, 4, 64), (3, 5, 7, 8), (1, 64, 64, 128)])
+def test_pool_grad_pack_matches_the_unfused_chain(shape, masked, prec):
+    """(round 6) lp_pool_grad_pack: dm = dy * [y > 0], its operand planes and the operand planes of the pool's adjoint 0.25 * up2(dm) in ONE launch
+    against where + lp_act_pack + lp_avgpool2_bwd + lp_act_pack -- bit-identical planes in the bf16 modes; fp16: identical DECODED values
+    (planes * 1/scale), the scale being taken from amax(dy) instead of amax(dm)"""
+    ops = _ops()
+    n, h, w, c = shape
+    g = torch.Generator().manual_seed(5)
+    dy = (torch.randn(n, h, w, c, generator=g) * 3e-3).cuda()
+    y = torch.relu(torch.randn(n, h, w, c, generator=g)).cuda() if masked else None
+    dm_ref = dy if y is None else torch.where(y > 0, dy, torch.zeros((), device='cuda'))
+    lo_ref = ops.act_pack(dm_ref, prec=prec, grad=True)
+    up_ref = ops.act_pack(ops.avgpool2_bwd(dy, None, False, y_relu=y), prec=prec, grad=True)
+    dm, lo, up = ops.pool_grad_pack(dy, y, prec, want_dm=True, want_lo=True, want_up=True)
+    torch.cuda.synchronize()
+    assert torch.equal(dm, dm_ref)
+    if prec != 2:
+        assert lo.inv is None and up.inv is None
+        assert torch.equal(lo.hi, lo_ref.hi) and torch.equal(up.hi, up_ref.hi)
+        if prec == 1:
+            assert torch.equal(lo.lo, lo_ref.lo) and torch.equal(up.lo, up_ref.lo)
+    else:
+        dec = lambda a: a.hi.view(torch.float16).double() * a.inv.double()
+        # fp16 operands carry 11 significant bits; the two scales differ by a power of two at most (amax(dy) >= amax(dm)): same values unless a
+        # tiny entry falls into the subnormal range of the coarser scale
+        assert (dec(lo) - dec(lo_ref)).abs().max() <= 2.0 ** -11 * dm_ref.abs().max().double() * 2 ** -10
+        assert (dec(up) - dec(up_ref)).abs().max() <= 2.0 ** -11 * dm_ref.abs().max().double() * 2 ** -10
+        assert torch.equal(up.hi[:, ::2, ::2], lo.hi) and torch.equal(up.hi[:, 1::2, 1::2], lo.hi)
+    none, lo2, none2 = ops.pool_grad_pack(dy, y, prec, want_dm=False, want_lo=True, want_up=False)
+    torch.cuda.synchronize()
+    assert none is None and none2 is None and torch.equal(lo2.hi, lo.hi)
+
+
 @pytest.mark.parametrize('ups', [0, 1])
 @pytest.mark.parametrize('shape', [(2, 4, 4, 64), (2, 16, 16, 32), (1, 128, 128, 8), (2, 32, 32, 4), (2, 8, 8, 16)])
 def test_adain_relu_bwd(shape, ups):
