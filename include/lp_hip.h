@@ -425,6 +425,19 @@ int lp_reduce_hinge(const float* real, const float* fake_d, const float* fake_g,
 int lp_reduce_hinge_bwd(const float* real, const float* fake_d, const float* grad_G, const float* grad_D, float* d_real,
                         float* d_fake_d, float* d_fake_g, int B, void* stream);
 
+/* (ABI 11, round 6) Projection head of the critic (discriminators/no_landmarks.py:100-108): out = relu(out) [N][HW][C] NHWC; pooled = sum over HW;
+ * score = linear(pooled) + <pooled, embed>.  lp_proj_score_fwd: pooled [N][C] and dot [N] (|NULL with embed NULL) in one launch -- the linear layer
+ * stays lp_linear_fwd on pooled.  lp_proj_score_bwd: d_out[n,p,c] = (g_pooled[n,c] + g_dot[n] embed[n,c]) [out > 0] (|NULL), d_embed[n,c] = g_dot[n]
+ * pooled[n,c] (|NULL); g_pooled / g_dot | NULL = zero. */
+int lp_proj_score_fwd(const float* out, const float* embed, float* pooled, float* dot, int N, int HW, int C, void* stream);
+int lp_proj_score_bwd(const float* out, const float* embed, const float* pooled, const float* g_pooled, const float* g_dot, float* d_out,
+                      float* d_embed, int N, int HW, int C, void* stream);
+/* (ABI 11, round 6) Input side of the VGG criterions (criterions/common/perceptual_loss.py:72-80,86-93): x NCHW [N][3][HW] in [-1, 1] ->
+ * out NHWC [N][HW][3] = ((x + 1) / 2 - mean[c]) / std[c] (mean, std: 3 device floats), the reference's operations in the reference's order;
+ * lp_image_prep_bwd: dx NCHW = g NHWC / std[c] / 2. */
+int lp_image_prep_fwd(const float* x, const float* mean, const float* stdv, float* out, int N, int HW, void* stream);
+int lp_image_prep_bwd(const float* g, const float* stdv, float* dx, int N, int HW, void* stream);
+
 /* ---- fused multi-tensor optimizers + EMA (runners/holycow.py:34-41,99-109; utils/radam.py:29-95; torch.optim.Adam) ----
  * table: DEVICE array of {float* p; const float* g; float* m; float* v; long long n;} (lp_mt_desc_bytes() each), one per
  * parameter tensor; step: DEVICE int64 counter, incremented by the call (graph-replay safe).  kind 0 = RAdam, 1 = Adam.

@@ -95,6 +95,10 @@ SIGNATURES = {
     'lp_dwconv3x3_wgrad': (_i, [_vp] * 6 + [_i] * 5 + [_vp]),
     'lp_sum2x2': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'lp_sum2x2_planes': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'lp_proj_score_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'lp_proj_score_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'lp_image_prep_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
+    'lp_image_prep_bwd': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     'lp_pool_grad_pack': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
     'lp_adain_relu_bwd_planes': (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     'lp_head_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),

@@ -75,6 +75,15 @@ class PerceptualLoss(nn.Module):
     def normalize_inputs(self, x):
         return (x - self.mean) / self.std
 
+    def prep(self, x):
+        """normalize_inputs((x + 1) / 2) of an image in [-1, 1] (perceptual_loss.py:86-93) as ONE launch that also leaves the NHWC layout the convs
+        read (round 6; same fp32 operations in the same order) -> logical NCHW view of NHWC storage"""
+        mean, std = self.__dict__.get('_ms', (None, None))
+        if mean is None or mean.device != x.device:
+            mean, std = self.mean.reshape(3).contiguous(), self.std.reshape(3).contiguous()
+            self.__dict__['_ms'] = (mean, std)
+        return lpnn.ImagePrepFn.apply(x, mean, std).permute(0, 3, 1, 2)
+
     def _packs(self, prec):
         """frozen weights: (forward, dgrad) bf16 packs per conv, built once per precision mode"""
         cache = self.__dict__.setdefault('_pack_cache', {})
@@ -176,7 +185,7 @@ class PerceptualLoss(nn.Module):
             raise RuntimeError('PerceptualLoss runs on the MI355X HIP path only (no CPU fallback)')
         prec = default_prec()
         with torch.no_grad():
-            ft = self.normalize_inputs((target.detach() + 1) / 2)
+            ft = self.prep(target.detach())
             if prec == lpnn.PREC_F16 and TAPS16 and lpnn.RELU_TAPE is None and all(m.weight.shape[0] % 8 == 0 for m in self.model if isinstance(m, nn.Conv2d)):
                 return self._features16(ft, self._packs(prec), prec)
             return self._features(ft, self._packs(prec), prec, [])
@@ -187,7 +196,7 @@ class PerceptualLoss(nn.Module):
             raise RuntimeError('PerceptualLoss runs on the MI355X HIP path only (no CPU fallback)')
         prec = default_prec()
         packs = self._packs(prec)
-        fi = self.normalize_inputs((input + 1) / 2)
+        fi = self.prep(input)
         if taps_t is None:
             taps_t = self.target_features(target)
         terms = self._features(fi, packs, prec, [], targets=taps_t)

@@ -1202,3 +1202,95 @@ extern "C" int lp_reduce_hinge_bwd(const float* real, const float* fake_d, const
     hipLaunchKernelGGL(hinge_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, real, fake_d, grad_G, grad_D, d_real, d_fake_d, d_fake_g, B);
     return lp_check_launch("hinge_bwd");
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Projection head of the critic (discriminators/no_landmarks.py:100-108 of the reference): out = relu(out); pooled = out.sum(dim = (2, 3));
+// score = linear(pooled) + (pooled * embed).sum(1).  Forward: pooled [N][C] and dot[n] = <pooled[n], embed[n]> in one launch (one workgroup per
+// sample; the linear layer stays lp_linear_fwd on pooled).  Backward: d_out[n,p,c] = (g_pooled[n,c] + g_dot[n] embed[n,c]) [out > 0] and
+// d_embed[n,c] = g_dot[n] pooled[n,c] in one launch.  (round 6: replaces relu + sum + mul + sum and their five autograd launches per pass)
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void proj_score_fwd_kernel(const float* __restrict__ out, const float* __restrict__ embed, float* __restrict__ pooled,
+                                                             float* __restrict__ dot, int HW, int C) {
+    __shared__ float red[4];
+    const int n = blockIdx.x;
+    float acc = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (int p = 0; p < HW; ++p) s += fmaxf(out[((size_t)n * HW + p) * C + c], 0.f);
+        pooled[(size_t)n * C + c] = s;
+        if (embed) acc = fmaf(s, embed[(size_t)n * C + c], acc);
+    }
+    if (!dot) return;
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) dot[n] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void proj_score_bwd_kernel(const float* __restrict__ out, const float* __restrict__ embed, const float* __restrict__ pooled,
+                                                             const float* __restrict__ g_pooled, const float* __restrict__ g_dot, float* __restrict__ d_out,
+                                                             float* __restrict__ d_embed, int HW, int C) {
+    const int n = blockIdx.x;
+    const float gd = g_dot ? g_dot[n] : 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const size_t nc = (size_t)n * C + c;
+        float g = g_pooled ? g_pooled[nc] : 0.f;
+        if (embed) g = fmaf(gd, embed[nc], g);
+        if (d_embed) d_embed[nc] = gd * pooled[nc];
+        if (d_out) for (int p = 0; p < HW; ++p) { const size_t i = ((size_t)n * HW + p) * C + c; d_out[i] = out[i] > 0.f ? g : 0.f; }
+    }
+}
+extern "C" int lp_proj_score_fwd(const float* out, const float* embed, float* pooled, float* dot, int N, int HW, int C, void* stream) {
+    if (!out || !pooled || (dot && !embed)) return lp_set_error(LP_ERR_ARG, "lp_proj_score_fwd: null pointer");
+    if (N < 1) return LP_OK;
+    hipLaunchKernelGGL(proj_score_fwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, out, embed, pooled, dot, HW, C);
+    return lp_check_launch("proj_score_fwd");
+}
+extern "C" int lp_proj_score_bwd(const float* out, const float* embed, const float* pooled, const float* g_pooled, const float* g_dot, float* d_out,
+                                 float* d_embed, int N, int HW, int C, void* stream) {
+    if (!out || (!d_out && !d_embed) || (d_embed && (!pooled || !g_dot)) || (g_dot && !embed)) return lp_set_error(LP_ERR_ARG, "lp_proj_score_bwd: null pointer");
+    if (N < 1) return LP_OK;
+    hipLaunchKernelGGL(proj_score_bwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, out, embed, pooled, g_pooled, g_dot, d_out, d_embed, HW, C);
+    return lp_check_launch("proj_score_bwd");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Input side of the VGG criterions (criterions/common/perceptual_loss.py:72-80,86-93 of the reference): x in [-1, 1], NCHW [N][3][HW] ->
+// ((x + 1) / 2 - mean[c]) / std[c] as NHWC [N][HW][3] -- the same fp32 operations in the same order, and the layout change, in one launch
+// (round 6: add + div + sub + div + the NCHW -> NHWC copy were five launches per image batch); backward dx[n,c,p] = g[n,p,c] / std[c] / 2.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void image_prep_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ stdv,
+                                                             float* __restrict__ out, long long total, int HW) {
+    const float m0 = mean[0], m1 = mean[1], m2 = mean[2], s0 = stdv[0], s1 = stdv[1], s2 = stdv[2];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long n = i / HW; const int p = (int)(i - n * HW);
+        const float* xn = x + (size_t)n * 3 * HW + p;
+        float* o = out + (size_t)i * 3;
+        o[0] = ((xn[0] + 1.f) / 2.f - m0) / s0; o[1] = ((xn[HW] + 1.f) / 2.f - m1) / s1; o[2] = ((xn[2 * (size_t)HW] + 1.f) / 2.f - m2) / s2;
+    }
+}
+__global__ __launch_bounds__(256) void image_prep_bwd_kernel(const float* __restrict__ g, const float* __restrict__ stdv, float* __restrict__ dx,
+                                                             long long total, int HW) {
+    const float s0 = stdv[0], s1 = stdv[1], s2 = stdv[2];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long n = i / HW; const int p = (int)(i - n * HW);
+        const float* gi = g + (size_t)i * 3;
+        float* d = dx + (size_t)n * 3 * HW + p;
+        d[0] = gi[0] / s0 / 2.f; d[HW] = gi[1] / s1 / 2.f; d[2 * (size_t)HW] = gi[2] / s2 / 2.f;
+    }
+}
+extern "C" int lp_image_prep_fwd(const float* x, const float* mean, const float* stdv, float* out, int N, int HW, void* stream) {
+    if (!x || !mean || !stdv || !out) return lp_set_error(LP_ERR_ARG, "lp_image_prep_fwd: null pointer");
+    const long long total = (long long)N * HW;
+    if (total == 0) return LP_OK;
+    long long blocks = (total + 255) / 256; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(image_prep_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, mean, stdv, out, total, HW);
+    return lp_check_launch("image_prep_fwd");
+}
+extern "C" int lp_image_prep_bwd(const float* g, const float* stdv, float* dx, int N, int HW, void* stream) {
+    if (!g || !stdv || !dx) return lp_set_error(LP_ERR_ARG, "lp_image_prep_bwd: null pointer");
+    const long long total = (long long)N * HW;
+    if (total == 0) return LP_OK;
+    long long blocks = (total + 255) / 256; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(image_prep_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, stdv, dx, total, HW);
+    return lp_check_launch("image_prep_bwd");
+}

@@ -304,11 +304,11 @@ class Discriminator(nn.Module):
                     out_relu, xr16 = torch.relu(out), None
         feats.append(as_nchw_view(out))
         lpnn.tape_relu(lambda: out > 0)
-        pooled = torch.relu(out).sum(dim=(1, 2))
+        pooled, dot = lpnn.ProjScoreFn.apply(out, embed)          # sum_hw relu(out) and <pooled, embed> in one launch
         wl, bl, sl = _wb(self.linear, track_weights, states)
         score = SNLinearFn.apply(pooled, wl, bl, *sl)[:, 0]
         if embed is not None:
-            score = (pooled * embed).sum(1) + score
+            score = dot + score
         return score, feats
 
     def enable_finetuning(self, data_dict=None):

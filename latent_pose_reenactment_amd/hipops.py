@@ -1304,6 +1304,49 @@ def add_strided2(d: Tensor, s: Tensor) -> Tensor:
     return d
 
 
+def proj_score_fwd(out: Tensor, embed: Optional[Tensor]):
+    """critic head: out [N,H,W,C] -> (pooled = sum_hw relu(out) [N,C], dot = <pooled, embed> [N] | None), one launch"""
+    _chk(out, 'out')
+    n, h, w, c = out.shape
+    if embed is not None:
+        _chk(embed, 'embed'); assert tuple(embed.shape) == (n, c)
+    pooled = torch.empty((n, c), dtype=torch.float32, device=out.device)
+    dot = torch.empty((n,), dtype=torch.float32, device=out.device) if embed is not None else None
+    check(_lib.lib().lp_proj_score_fwd(out.data_ptr(), _p(embed), pooled.data_ptr(), _p(dot), n, h * w, c, _stream()), 'lp_proj_score_fwd')
+    return pooled, dot
+
+
+def proj_score_bwd(out: Tensor, embed: Optional[Tensor], pooled: Tensor, g_pooled: Optional[Tensor], g_dot: Optional[Tensor], want_out: bool, want_embed: bool):
+    n, h, w, c = out.shape
+    for t, nm in ((g_pooled, 'g_pooled'), (g_dot, 'g_dot')):
+        if t is not None:
+            _chk(t, nm)
+    d_out = torch.empty_like(out) if want_out else None
+    d_embed = torch.empty_like(pooled) if (want_embed and g_dot is not None) else None
+    check(_lib.lib().lp_proj_score_bwd(out.data_ptr(), _p(embed), pooled.data_ptr(), _p(g_pooled), _p(g_dot if embed is not None else None), _p(d_out),
+                                       _p(d_embed), n, h * w, c, _stream()), 'lp_proj_score_bwd')
+    return d_out, d_embed
+
+
+def image_prep_fwd(x: Tensor, mean: Tensor, std: Tensor) -> Tensor:
+    """x NCHW [N,3,H,W] in [-1, 1] -> ((x + 1) / 2 - mean) / std as NHWC [N,H,W,3] (one launch)"""
+    _chk(x, 'x'); _chk(mean, 'mean'); _chk(std, 'std')
+    n, c, h, w = x.shape
+    assert c == 3 and mean.numel() == 3 and std.numel() == 3
+    out = torch.empty((n, h, w, 3), dtype=torch.float32, device=x.device)
+    check(_lib.lib().lp_image_prep_fwd(x.data_ptr(), mean.data_ptr(), std.data_ptr(), out.data_ptr(), n, h * w, _stream()), 'lp_image_prep_fwd')
+    return out
+
+
+def image_prep_bwd(g: Tensor, std: Tensor) -> Tensor:
+    _chk(g, 'g')
+    n, h, w, c = g.shape
+    assert c == 3
+    dx = torch.empty((n, 3, h, w), dtype=torch.float32, device=g.device)
+    check(_lib.lib().lp_image_prep_bwd(g.data_ptr(), std.data_ptr(), dx.data_ptr(), n, h * w, _stream()), 'lp_image_prep_bwd')
+    return dx
+
+
 def spatial_mean(x: Tensor) -> Tensor:
     _chk(x, 'x')
     n, h, w, c = x.shape

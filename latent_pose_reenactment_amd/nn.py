@@ -318,6 +318,44 @@ def _pad4(t):
 _LINEAR_ROWS = 64          # rows per lp_linear_* launch (the kernels keep one accumulator row set per wave): larger batches go in chunks
 
 
+class ProjScoreFn(torch.autograd.Function):
+    """critic head (discriminators/no_landmarks.py:100-108): (pooled, dot) = (sum_hw relu(out), <pooled, embed>) -- one launch forward, one backward
+    (round 6; relu + sum + mul + sum and their autograd were ~11 launches per pass).  ``embed`` None: pooled only."""
+
+    @staticmethod
+    def forward(ctx, out, embed):
+        o = out.detach().contiguous()
+        e = None if embed is None else embed.detach().contiguous()
+        pooled, dot = ops.proj_score_fwd(o, e)
+        ctx.save_for_backward(o, e, pooled)
+        if dot is None:
+            dot = pooled.new_zeros(())
+            ctx.mark_non_differentiable(dot)
+        return pooled, dot
+
+    @staticmethod
+    def backward(ctx, g_pooled, g_dot):
+        o, e, pooled = ctx.saved_tensors
+        gp = None if g_pooled is None else g_pooled.contiguous()
+        gd = None if (g_dot is None or e is None) else g_dot.contiguous()
+        d_out, d_embed = ops.proj_score_bwd(o, e, pooled, gp, gd, ctx.needs_input_grad[0], e is not None and ctx.needs_input_grad[1])
+        return d_out, d_embed
+
+
+class ImagePrepFn(torch.autograd.Function):
+    """input side of the VGG criterions (criterions/common/perceptual_loss.py:72-80): NCHW image in [-1, 1] -> ((x + 1) / 2 - mean) / std as an NHWC
+    tensor, the reference's fp32 operations in the reference's order, one launch each way (round 6: five ATen launches per image batch)"""
+
+    @staticmethod
+    def forward(ctx, x, mean, std):
+        ctx.std = std
+        return ops.image_prep_fwd(x.detach().contiguous(), mean, std)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.image_prep_bwd(g.contiguous(), ctx.std), None, None
+
+
 class SNLinearFn(torch.autograd.Function):
     """y = (x W_orig^T) / sigma + b for a spectrally normalised nn.Linear whose sigma comes from SNBatch -- or, with ``sig`` None, a plain
     nn.Linear (FSTH_plus's projector).  Both passes are lp_linear_fwd / lp_linear_bwd (small-batch weight streams with 1/sigma and the

@@ -220,6 +220,49 @@ def test_gradient_producers_write_operand_planes_directly(shape, ups, prec):
         assert torch.equal(s16.hi, s_ref.hi) and (prec == 0 or torch.equal(s16.lo, s_ref.lo))
 
 
+@pytest.mark.parametrize('with_embed', [True, False])
+@pytest.mark.parametrize('shape', [(8, 4, 4, 512), (3, 2, 5, 40), (1, 1, 1, 300)])
+def test_projection_head_of_the_critic(shape, with_embed):
+    """(round 6) nn.ProjScoreFn = relu -> sum over (H, W) -> <pooled, embed> (no_landmarks.py:100-108) against torch autograd in fp64"""
+    from latent_pose_reenactment_amd import nn as lpnn
+    n, h, w, c = shape
+    g = torch.Generator().manual_seed(9)
+    out = torch.randn(n, h, w, c, generator=g).cuda().requires_grad_(True)
+    emb = torch.randn(n, c, generator=g).cuda().requires_grad_(True) if with_embed else None
+    r1, r2 = torch.randn(n, c, generator=g).cuda(), torch.randn(n, generator=g).cuda()
+    pooled, dot = lpnn.ProjScoreFn.apply(out, emb)
+    loss = (pooled * r1).sum() + ((dot * r2).sum() if with_embed else 0)
+    loss.backward()
+    o64 = out.detach().double().requires_grad_(True)
+    e64 = emb.detach().double().requires_grad_(True) if with_embed else None
+    p64 = torch.relu(o64).sum(dim=(1, 2))
+    l64 = (p64 * r1.double()).sum() + (((p64 * e64).sum(1) * r2.double()).sum() if with_embed else 0)
+    l64.backward()
+    torch.cuda.synchronize()
+    rel = lambda a, b: ((a.double() - b).norm() / b.norm().clamp_min(1e-30)).item()
+    assert rel(pooled, p64) < 1e-6 and rel(out.grad, o64.grad) < 1e-6
+    if with_embed:
+        assert rel(dot, (p64 * e64).sum(1)) < 1e-5 and rel(emb.grad, e64.grad) < 1e-6
+
+
+def test_vgg_input_preparation_matches_the_reference_expression_bit_for_bit():
+    """(round 6) nn.ImagePrepFn: ((x + 1) / 2 - mean) / std + NCHW -> NHWC in one launch == the torch expression of perceptual_loss.py:72-93, and its
+    backward == autograd of that expression"""
+    from latent_pose_reenactment_amd import nn as lpnn
+    g = torch.Generator().manual_seed(2)
+    x = (torch.rand(3, 3, 20, 36, generator=g) * 2 - 1).cuda().requires_grad_(True)
+    mean = (torch.tensor([103.939, 116.779, 123.680]) / 255.).cuda()
+    std = (torch.tensor([1., 1., 1.]) / 255.).cuda()
+    y = lpnn.ImagePrepFn.apply(x, mean, std)
+    r = torch.randn(y.shape, generator=g).cuda()
+    (y * r).sum().backward()
+    x2 = x.detach().clone().requires_grad_(True)
+    y2 = (((x2 + 1) / 2) - mean[None, :, None, None]) / std[None, :, None, None]
+    (y2.permute(0, 2, 3, 1) * r).sum().backward()
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2.permute(0, 2, 3, 1)) and torch.equal(x.grad, x2.grad)
+
+
 @pytest.mark.parametrize('prec', [0, 1, 2])
 @pytest.mark.parametrize('masked', [True, False])
 @pytest.mark.parametrize('shape', [(2, 4, 4, 64), (3, 5, 7, 8), (1, 64, 64, 128)])
