@@ -41,7 +41,10 @@ def enabled(t, what: str, finetuning: bool = False) -> bool:
     # not additive (profiles/r04_stream_overlap.txt)
     # round 6: with the generator and the critic's D-side tail on bf16x3 operands the discriminator-side backward is matrix-bound enough to run
     # beside the encoders' bandwidth-bound backward: 43.11 / 43.09 / 43.24 ms off vs 42.71 / 42.06 / 42.62 ms on (profiles/r06_stream_overlap.txt) -- ON
-    default = '0' if (what in ('optimizer', 'wgrad', 'targets') or (what in ('criterions', 'prepare', 'dpasses', 'real', 'ebwd') and finetuning)) else '1'
+    # round 6: the FINE-TUNING step takes the same branches (it stayed a single-stream graph through round 5: -1.6 % / +1.1 % for single branches with
+    # fp16 operands).  With the bf16x3 generator / critic tail: 22.47 ms one stream, 22.16 dpasses, 21.35 + prepare, 21.39 + real, 19.63 ms + criterions
+    # (profiles/r06_stream_overlap.txt) -- on.  'ebwd' has no meaning there (no encoder is trained).
+    default = '0' if (what in ('optimizer', 'wgrad', 'targets') or (what == 'ebwd' and finetuning)) else '1'
     return os.environ.get('LP_OVERLAP_' + what.upper(), default) != '0'
 
 

@@ -17,14 +17,14 @@ pytestmark = pytest.mark.gpu
 KNOBS = ('LP_OVERLAP', 'LP_OVERLAP_ENCODERS', 'LP_OVERLAP_CRITERIONS', 'LP_OVERLAP_OPTIMIZER', 'LP_OVERLAP_WGRAD', 'LP_OVERLAP_TARGETS', 'LP_OVERLAP_PREPARE', 'LP_OVERLAP_DPASSES', 'LP_OVERLAP_REAL', 'LP_OVERLAP_EBWD')
 
 
-def _iteration(monkeypatch, env):
+def _iteration(monkeypatch, env, finetune=False):
     import bench
     from latent_pose_reenactment_amd.nn import fused_grad_accumulation
     for k in KNOBS:
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
-    args = bench.make_args(128, 8, 'cuda:0', 1, 0, 'f16', finetune=False)
+    args = bench.make_args(128, 8, 'cuda:0', 1, 0, 'f16', finetune=finetune)
     args.num_labels = 100
     tm, opt_G, opt_D, holycow = bench.build(args)
     data, target = bench.synthetic_batch(args, 8, seed=500)
@@ -75,6 +75,21 @@ def test_concurrent_branches_reproduce_the_one_stream_iteration(monkeypatch):
         for g, d in sp.items():
             # (E, G: the run-to-run spread is itself random -- 1.7e-3 / 2.6e-4 typically; a missing dependency shows up as 0.1 .. 1)
             assert d <= max(20 * floor[g], 1e-2 if g in ('E', 'G') else 1e-5), (name, g, d, floor[g])
+
+
+def test_fine_tuning_iteration_with_its_default_branches_reproduces_one_stream(monkeypatch):
+    """(round 6) the fine-tuning step takes the criterions / prepare / dpasses / real branches by default: same losses, generator and critic
+    gradients as on one stream"""
+    one = _iteration(monkeypatch, {'LP_OVERLAP': '0'}, finetune=True)
+    again = _iteration(monkeypatch, {'LP_OVERLAP': '0'}, finetune=True)
+    floor = _spread(again, one)
+    default = _iteration(monkeypatch, {}, finetune=True)
+    assert one.keys() == default.keys()
+    sp = _spread(default, one)
+    fmt = lambda d: ', '.join(f'{g} {v:.1e}' for g, v in sorted(d.items()))
+    print(f'[streams] fine-tuning, one stream run to run: {fmt(floor)}; default branches vs one stream: {fmt(sp)}')
+    for g, d in sp.items():
+        assert d <= max(20 * floor[g], 1e-2 if g in ('E', 'G') else 1e-5), (g, d, floor[g])
 
 
 def _train_step_grads(monkeypatch, env):
