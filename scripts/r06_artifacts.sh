@@ -51,10 +51,11 @@ timeout 300 python bench.py --workload generator --generator FSTH_plus --image_s
 timeout 300 python bench.py --workload generator --steps 20 --warmup 5 --no-cpu-baseline > $O/${R}_bench_generator.json 2> $O/${R}_bench_generator.err
 LP_PREC_G=f16 timeout 300 python bench.py --workload generator --steps 20 --warmup 5 --no-cpu-baseline > $O/${R}_bench_generator_f16.json 2> $O/${R}_bench_generator_f16.err
 LP_OVERLAP=0 timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-also --no-drive > $O/${R}_bench_one_stream.json 2> $O/${R}_bench_one_stream.err
+LP_OVERLAP=0 timeout 300 python bench.py --workload finetune_step --steps 30 --warmup 5 --no-cpu-baseline --no-also --no-drive > $O/${R}_bench_finetune_one_stream.json 2> $O/${R}_bench_finetune_one_stream.err
 env -u WORLD_SIZE -u RANK -u LOCAL_RANK timeout 600 python bench.py --gpus 2 --steps 6 --warmup 2 --backend gloo --no-cpu-baseline --no-also --no-drive > $O/${R}_bench_dp2_gloo_one_gpu_functional.json 2> $O/${R}_bench_dp2.err
 PREC=1 WHAT=conv timeout 200 python scripts/conv_micro.py 2>&1 | grep prec > $O/${R}_conv_micro_bf16x3.txt
 PREC=2 WHAT=conv timeout 200 python scripts/conv_micro.py 2>&1 | grep prec > $O/${R}_conv_micro_f16.txt
-(for pr in 1 2; do PREC=$pr timeout 200 python scripts/r06/phase_micro.py 2>&1 | grep prec; done) > $O/${R}_phase_conv.txt
+(echo "# round 6: the generator's x2-upsampled 3x3 convs (N = 8), fused-upsample kernels vs the phase-decomposed forms (scripts/r06/phase_micro.py; prec 1 = bf16x3, 2 = f16; dense count = the conv as the reference executes it)"; for pr in 1 2; do PREC=$pr timeout 200 python scripts/r06/phase_micro.py 2>&1 | grep prec; done) > $O/${R}_phase_conv.txt
 SHAPES=wgrad PREC=1 WHAT=wgrad timeout 300 python scripts/conv_micro.py 2>&1 | grep prec > $O/${R}_wgrad_micro_bf16x3.txt
 rm -f $O/*.err.empty
 cut -c1-2500 $O/${R}_bench.json; echo
