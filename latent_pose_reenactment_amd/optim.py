@@ -41,6 +41,31 @@ class _FusedBase(Optimizer):
             raise NotImplementedError('weight decay is not used by the reference configs and is not fused')
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._tables = {}
+        self._parts = None          # set_partitions(): [(name, {id(param)})] + the implicit partition 'rest'
+        self._stepped = set()
+
+    def set_partitions(self, named):
+        """Step named SUBSETS of the parameters with their own launches (round 6): ``step(part=name)`` updates that subset only -- e.g. the generator's
+        parameters as soon as loss_G.backward has produced their gradients, on a side stream beside the encoders' backward -- and the next plain
+        ``step()`` updates whatever has not been stepped since the previous plain ``step()``.  Every subset of a group keeps its own device step counter,
+        advanced once per iteration like the group's single one: the update of every element is unchanged, bit for bit.  ``named``: {name: params}."""
+        self._publish_steps()
+        self._parts = [(name, {id(p) for p in ps}) for name, ps in named.items()]
+        self._stepped = set()
+        self._tables = {}
+
+    def _part_names(self):
+        return [None] if self._parts is None else [n for n, _ in self._parts] + ['rest']
+
+    def _part_params(self, group, part):
+        params = [p for p in group['params'] if p.requires_grad]
+        if self._parts is None or part is None:
+            return params
+        if part == 'rest':
+            taken = set().union(*[ids for _, ids in self._parts]) if self._parts else set()
+            return [p for p in params if id(p) not in taken]
+        ids = dict(self._parts)[part]
+        return [p for p in params if id(p) in ids]
 
     def ensure_flat(self, gi=0):
         """Gradient arena: all gradients of a parameter group are views into ONE flat fp32 buffer (created once).  zero_grad is a
@@ -66,8 +91,10 @@ class _FusedBase(Optimizer):
             flats[gi] = cur
         return cur[1]
 
-    def _prepare(self, gi, group):
-        params = [p for p in group['params'] if p.requires_grad]
+    def _prepare(self, gi, group, part=None):
+        params = self._part_params(group, part)
+        if not params:
+            return None
         dev = params[0].device
         self.ensure_flat(gi)
         for p in params:
@@ -77,13 +104,14 @@ class _FusedBase(Optimizer):
                 st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 st['step'] = 0
         key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in params)
-        cached = self._tables.get(gi)
+        tk = gi if part is None else (gi, part)
+        cached = self._tables.get(tk)
         if cached is None or cached[0] != key:
             table, max_n = _build_table([(p.data, p.grad, self.state[p]['exp_avg'], self.state[p]['exp_avg_sq']) for p in params], dev)
             step0 = max((int(self.state[p]['step']) for p in params), default=0)
             step = cached[3] if cached is not None else torch.tensor([step0], dtype=torch.int64, device=dev)
             cached = (key, table, max_n, step, len(params))
-            self._tables[gi] = cached
+            self._tables[tk] = cached
         return cached
 
     def zero_grad(self, set_to_none: bool = False):
@@ -93,28 +121,48 @@ class _FusedBase(Optimizer):
                 self.ensure_flat(gi).zero_()
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, part=None):
+        """``part`` (after ``set_partitions``): update that subset only; a plain call updates every subset not stepped since the last plain call"""
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
         from . import hipops as _ops
         _ops.sn_defer_check(type(self).__name__ + '.step')          # (ADVICE r05) .grad is incomplete while deferred spectral-norm jobs are pending
+        if part is not None:
+            assert self._parts is not None and part in self._part_names() and part not in self._stepped, (part, self._stepped)
+            todo = [part]
+        else:
+            todo = [n for n in self._part_names() if n not in self._stepped]
         for gi, group in enumerate(self.param_groups):
-            _, table, max_n, step, n = self._prepare(gi, group)
-            b1, b2 = group['betas']
-            check(_lib.lib().lp_mt_optimizer_step(table.data_ptr(), n, max_n, step.data_ptr(), self.KIND, group['lr'], b1, b2,
-                                                  group['eps'], torch.cuda.current_stream().cuda_stream), 'lp_mt_optimizer_step')
+            for name in todo:
+                prep = self._prepare(gi, group, name)
+                if prep is None:
+                    continue
+                _, table, max_n, step, n = prep
+                b1, b2 = group['betas']
+                check(_lib.lib().lp_mt_optimizer_step(table.data_ptr(), n, max_n, step.data_ptr(), self.KIND, group['lr'], b1, b2,
+                                                      group['eps'], torch.cuda.current_stream().cuda_stream), 'lp_mt_optimizer_step')
+        if part is not None:
+            self._stepped.add(part)
+        else:
+            self._stepped = set()
         WEIGHTS_GENERATION[0] += 1
         return loss
 
+    def _publish_steps(self):
+        """device step counters -> the reference's per-parameter ``state[p]['step']``"""
+        if torch.cuda.is_current_stream_capturing():
+            return
+        for tk, cached in self._tables.items():
+            gi, part = (tk, None) if not isinstance(tk, tuple) else tk
+            s = int(cached[3].item())
+            for p in self._part_params(self.param_groups[gi], part):
+                if p in self.state:
+                    self.state[p]['step'] = s
+
     def state_dict(self):
-        for gi, group in enumerate(self.param_groups):      # publish the device step counter in the reference's per-param layout
-            if gi in self._tables and not torch.cuda.is_current_stream_capturing():
-                s = int(self._tables[gi][3].item())
-                for p in group['params']:
-                    if p in self.state:
-                        self.state[p]['step'] = s
+        self._publish_steps()
         return super().state_dict()
 
     def load_state_dict(self, state_dict):

@@ -96,9 +96,13 @@ class TrainingModule(nn.Module):
             module.eval()
             module.requires_grad_(False)
 
-    def update_running_average(self, alpha=0.999):
+    def update_running_average(self, alpha=0.999, only=None, skip=()):
+        """``only`` / ``skip``: names of the averaged modules to update / to leave out (round 6: the generator's average is updated beside the encoders'
+        backward, the rest at the end of the step)"""
         with torch.no_grad():
             for name, avg in self.running_averages.items():
+                if (only is not None and name not in only) or name in skip:
+                    continue
                 cur = getattr(self, name)
                 first = next(iter(cur.parameters()), None)
                 if first is not None and first.is_cuda:
@@ -271,21 +275,34 @@ def train_step(training_module, data_dict, target_dict, optimizer_G, optimizer_D
         # (``TrainingModule.forward`` cut the graph behind the embedder).  loss_D.backward is CALLED from a side stream: autograd orders
         # every node behind the stream the root gradient lives on, which must not be the stream the encoders' backward is queued on.
         dev = next(training_module.generator.parameters()).device
+        early = _early_updates(training_module, optimizer_G)
+        alpha = 0.972 if args.finetune else 0.999
         with _streams.branch(dev, 8) as b:
             optimizer_D.zero_grad()
             with fused_grad_accumulation(), rng('backward.loss_D'):
                 loss_D.backward()
             _streams.join_all()
+            if early:
+                # (round 6) everything that does not wait for the encoders' backward runs HERE, beside it: the critic's update, the generator's
+                # slice of optimizer_G (its gradients are final since loss_G.backward) and the generator's running average -- none of them reads
+                # or writes anything the encoders' backward touches.  What is left behind the join: the encoders' slice and their average.
+                with rng('optimizer_D.step'):
+                    optimizer_D.step()
+                with rng('optimizer_G.step.generator'):
+                    optimizer_G.step(part='generator')
+                with rng('ema.generator'):
+                    training_module.update_running_average(alpha, only=('generator',))
         with fused_grad_accumulation(), rng('backward.embedder'):
             training_module.embedder_backward()
         _streams.join_all()
         b.join()
         with rng('optimizer_G.step'):
             optimizer_G.step()
-        with rng('optimizer_D.step'):
-            optimizer_D.step()
+        if not early:
+            with rng('optimizer_D.step'):
+                optimizer_D.step()
         with rng('ema'):
-            training_module.update_running_average(0.972 if args.finetune else 0.999)
+            training_module.update_running_average(alpha, skip=('generator',) if early else ())
         return all_data, losses_G, losses_D
     if split:
         # data parallel, meta-training: the backward pass was cut behind the embedder -- the generator's gradients (the first 150 MB of the
@@ -326,6 +343,18 @@ def train_step(training_module, data_dict, target_dict, optimizer_G, optimizer_D
     with rng('ema'):
         training_module.update_running_average(0.972 if args.finetune else 0.999)
     return all_data, losses_G, losses_D
+
+
+def _early_updates(training_module, optimizer_G):
+    """one GPU, encoders' backward beside loss_D.backward: may optimizer_D.step, the generator's slice of optimizer_G and the generator's running
+    average run beside the encoders' backward too?  Needs the fused optimizers (``set_partitions``); LP_OVERLAP_EARLY=0 keeps them behind the join."""
+    if os.environ.get('LP_OVERLAP_EARLY', '1') == '0' or not hasattr(optimizer_G, 'set_partitions'):
+        return False
+    gen = list(training_module.generator.parameters())
+    if optimizer_G.__dict__.get('_lp_gen_key') != tuple(id(p) for p in gen):
+        optimizer_G.set_partitions({'generator': gen})
+        optimizer_G.__dict__['_lp_gen_key'] = tuple(id(p) for p in gen)
+    return True
 
 
 def _ebwd_enabled(training_module, args, multi):
@@ -477,11 +506,13 @@ class GraphedTrainStep:
         first = next(iter(self.tm.generator.parameters()))
         # one GPU: optimizer_G.step and the EMA of embedder + generator touch nothing the discriminator backward reads or writes
         # (train_step's docstring), so they run on a side stream beside it; g3 is then optimizer_D.step alone
-        self.ema_in_g2 = self.reducer is None and streams.enabled(first, 'optimizer')
+        self.ema_in_g2 = self.reducer is None and streams.enabled(first, 'optimizer', finetuning=bool(getattr(args, 'finetune', False)))
+        self.early = False
         if self.reducer is None and self.ebwd and self.losses_D:
             # g2: the encoders' backward (main path) beside zero_grad(D) + loss_D.backward (side path, called from its own stream: see
             # train_step), then optimizer_G.step
             self.ema_in_g2 = False
+            self.early = _early_updates(self.tm, self.opt_G)          # (see train_step)
             self.g2 = G()
             with torch.cuda.graph(self.g2, pool=pool, **kw):
                 with streams.branch(first.device, 8) as b:
@@ -489,11 +520,17 @@ class GraphedTrainStep:
                     with fused_grad_accumulation():
                         loss_D.backward()
                     _streams.join_all()
+                    if self.early:
+                        self.opt_D.step()
+                        self.opt_G.step(part='generator')
+                        self.tm.update_running_average(self.alpha, only=('generator',))
                 with fused_grad_accumulation():
                     self.tm.embedder_backward()
                 _streams.join_all()
                 b.join()
                 self.opt_G.step()
+                if self.early:
+                    self.tm.update_running_average(self.alpha, skip=('generator',))
         elif self.reducer is None:
             self.g2 = G()
             with torch.cuda.graph(self.g2, pool=pool, **kw):
@@ -531,11 +568,13 @@ class GraphedTrainStep:
             with torch.cuda.graph(self.g2b, pool=pool, **kw):
                 self.opt_G.step()
             self.reducer.reduce_discriminator_side()
-        self.g3 = G()
-        with torch.cuda.graph(self.g3, pool=pool, **kw):
-            self.opt_D.step()
-            if not self.ema_in_g2:
-                self.tm.update_running_average(self.alpha)
+        self.g3 = None
+        if not getattr(self, 'early', False):
+            self.g3 = G()
+            with torch.cuda.graph(self.g3, pool=pool, **kw):
+                self.opt_D.step()
+                if not self.ema_in_g2:
+                    self.tm.update_running_average(self.alpha)
         del loss_G, loss_D
         torch.cuda.synchronize()
 
@@ -562,4 +601,5 @@ class GraphedTrainStep:
             self.reducer.wait_generator_side()
             self.g2b.replay()
             self.reducer.reduce_discriminator_side()
-        self.g3.replay()
+        if self.g3 is not None:
+            self.g3.replay()

@@ -62,3 +62,36 @@ def test_fused_ema():
     for a, e in zip(avg.parameters(), expect):
         assert torch.allclose(a, e, rtol=1e-6, atol=1e-7)
     assert torch.equal(avg[1].running_mean, cur[1].running_mean) and int(avg[1].num_batches_tracked) == 5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind', ['RAdam', 'Adam'])
+def test_partitioned_steps_are_bit_identical_to_the_single_launch(kind):
+    """(round 6) set_partitions(): a named subset stepped early (step(part=...)) and the rest by the closing plain step() -- or everything by a
+    plain step() -- give exactly the parameters, moments and step counts of the unpartitioned optimizer"""
+    from latent_pose_reenactment_amd.optim import FusedAdam, FusedRAdam
+    torch.manual_seed(3)
+    shapes = [(64, 32, 3, 3), (17,), (5, 7), (1, 512), (33, 9)]
+    ps_a = [torch.nn.Parameter(torch.randn(s, device='cuda')) for s in shapes]
+    ps_b = [torch.nn.Parameter(p.detach().clone()) for p in ps_a]
+    kw = dict(lr=5e-4, betas=(0.0 if kind == 'RAdam' else 0.5, 0.999), eps=1e-5)
+    cls = FusedRAdam if kind == 'RAdam' else FusedAdam
+    one, two = cls(ps_a, **kw), cls(ps_b, **kw)
+    for step in range(10):
+        if step == 2:
+            two.set_partitions({'generator': [ps_b[1], ps_b[3]]})          # (mid-run: the step counters carry over)
+        gs = [torch.randn(p.shape, device='cuda') for p in ps_a]
+        for opt, ps in ((one, ps_a), (two, ps_b)):
+            opt.zero_grad()
+            for p, g in zip(ps, gs):
+                p.grad.copy_(g)
+        one.step()
+        if step >= 2 and step % 2 == 0:
+            two.step(part='generator')
+            assert torch.equal(ps_b[1], ps_a[1]) and not torch.equal(ps_b[0], ps_a[0])          # only the subset has moved
+        two.step()
+        for a, b in zip(ps_a, ps_b):
+            assert torch.equal(a, b), step
+    sa, sb = one.state_dict()['state'], two.state_dict()['state']
+    for k in sa:
+        assert sa[k]['step'] == sb[k]['step'] == 10 and torch.equal(sa[k]['exp_avg'], sb[k]['exp_avg']) and torch.equal(sa[k]['exp_avg_sq'], sb[k]['exp_avg_sq'])
