@@ -152,7 +152,7 @@ class _FusedBase(Optimizer):
 
     def _publish_steps(self):
         """device step counters -> the reference's per-parameter ``state[p]['step']``"""
-        if torch.cuda.is_current_stream_capturing():
+        if not self._tables or torch.cuda.is_current_stream_capturing():      # (no table: nothing was stepped -- also the no-GPU case)
             return
         for tk, cached in self._tables.items():
             gi, part = (tk, None) if not isinstance(tk, tuple) else tk
