@@ -123,16 +123,19 @@ class PackBatch:
     the device descriptor tables are allocated once (static addresses: hipGraph friendly); ``update()`` re-packs all entries from
     the current weight values and returns the list of WeightPacks (same order as ``specs``).  A weight that appears in both
     orientations (training: forward + data-gradient pack) is handled by lp_pack_weights_pairs -- one coalesced read of W through an
-    LDS tile for both packs; the rest by lp_pack_weights_batch."""
+    LDS tile for both packs; the rest by lp_pack_weights_batch.  ``precs``: operand mode per entry (a net whose blocks run in different
+    modes: nn.Generator's fp16 tail); default: ``prec`` for all."""
 
-    def __init__(self, specs, prec: int):
+    def __init__(self, specs, prec: int, precs=None):
         import struct
         assert _lib.lib().lp_pack_desc_bytes() == 56 and _lib.lib().lp_pack_pair_desc_bytes() == 80
         self.prec = prec
+        self.precs = tuple(precs) if precs is not None else (prec,) * len(specs)
+        assert len(self.precs) == len(specs)
         self.key = tuple((w.data_ptr(), mode, bool(sk)) for w, mode, sk in specs)
         self.packs = []
         geo = []
-        for w, mode, small_k in specs:
+        for (w, mode, small_k), prec in zip(specs, self.precs):
             _chk(w, 'w')
             cout, cin, taps, taps_out, rows, cols, rows_p, cols_p = _pack_geometry(w, mode, small_k)
             hi = torch.empty((taps_out, rows_p, cols_p), dtype=torch.int16, device=w.device)
@@ -152,8 +155,10 @@ class PackBatch:
         lop = lambda pk: 0 if pk.lo is None else pk.lo.data_ptr()
         for i, (w, mode, cout, cin, taps) in enumerate(geo):
             pk = self.packs[i]
+            prec = self.precs[i]
             if i in paired:
                 pk1 = self.packs[paired[i]]
+                assert self.precs[paired[i]] == prec, 'both orientations of one weight are packed in one operand mode'
                 tco = (max(pk.rows_p, pk1.cols_p) + 31) // 32
                 tci = (max(pk.cols_p, pk1.rows_p) + 31) // 32
                 pblob += struct.pack('<QQQQQiiiiiiiiii', w.data_ptr(), pk.hi.data_ptr(), lop(pk), pk1.hi.data_ptr(), lop(pk1), cout, cin, taps,

@@ -522,6 +522,7 @@ def phase_conv(up: bool, hout: int, reflect: bool) -> bool:
     return bool(up) and PHASE_UP and hout >= PHASE_MIN_OUT and not reflect
 
 
+G_F16_TAIL_DEFAULT = 0      # decoder blocks (from the output end) that run fp16 operands in the default (bf16x3) generator assignment
 RAW16_SKIP = os.environ.get('LP_G_RAW16', '1') != '0'      # conv2's epilogue also writes the raw planes of the block output for the next skip conv (0: a pack launch)
 
 
@@ -535,11 +536,12 @@ class _DecoderFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cfg, affine, constant, *weights):
         blocks, prec = cfg['blocks'], cfg['prec']
+        precs = cfg.get('precs') or [prec] * len(blocks)      # operand mode per block (``prec``: the head conv's and the default)
         need_grad = cfg['need_grad']
         sn = cfg['sn']                    # per entry of `weights`: (u_used, v_used, [sigma, 1/sigma]) for conv weights, None for biases
         packs = cfg.get('packs')          # forward packs prepared by the module (inference: cached; training: one batched launch)
 
-        def fpack(i, w, phase=False):
+        def fpack(i, w, phase=False, prec=prec):
             return packs[i] if packs is not None else ops.pack_weights(w.detach().contiguous(), 2 if phase else 0, prec)
         B = affine.shape[0]
         affine = affine.contiguous()
@@ -565,7 +567,7 @@ class _DecoderFunction(torch.autograd.Function):
         # keeps its zero padding, noBottleneck.py:80-88): the zero-padded conv + the border correction of csrc/reflect_border.hip; the statistics of a
         # conv output are then taken after the correction (no epilogue partials, no 16-bit-resident outputs)
         reflect = bool(cfg.get('reflect'))
-        y16 = bool(cfg.get('y16')) and prec == PREC_F16 and not reflect
+        y16 = bool(cfg.get('y16')) and prec == PREC_F16 and all(p_ == PREC_F16 for p_ in precs) and not reflect
 
         def dims(t):
             return tuple(t.hi.shape) if isinstance(t, ops.Act16) else tuple(t.shape)
@@ -577,12 +579,12 @@ class _DecoderFunction(torch.autograd.Function):
                 return ops.norm_stats_finalize(cs, dims(t)[0], dims(t)[3], gamma, beta, ADAIN_EPS)
             return ops.instnorm_stats(ops.y16_to_f32(t) if isinstance(t, ops.Act16) else t, gamma, beta, ADAIN_EPS)
 
-        def norm_planes(t, st):          # operand planes of relu(AdaIN(t))
+        def norm_planes(t, st, prec=prec):          # operand planes of relu(AdaIN(t))
             if isinstance(t, ops.Act16):
                 return ops.adain_act16(t, st[2], st[3])
             return ops.act_pack(t, pro=1, scale=st[2], shift=st[3], prec=prec)
 
-        def conv_out(a, pk, hout, w_orig, raw16=False, **kw):
+        def conv_out(a, pk, hout, w_orig, prec, raw16=False, **kw):
             """-> (y fp32 | the fp16 plane of y, statistics partials | None, raw operand planes of y | None).  ``raw16`` (round 6): the epilogue
             also writes the operand planes of y itself -- the input of the NEXT block's 1x1 skip conv (lp_act_pack prologue 0 of y: one launch
             and one read of y less per up block)"""
@@ -598,6 +600,7 @@ class _DecoderFunction(torch.autograd.Function):
             return ops.conv16(a, pk, prec=prec, stats=True, **kw) + (None,)
         x_cs = x_raw16 = None
         for bi_, (cin, cout, up) in enumerate(blocks):
+            pb = precs[bi_]
             w1, w2 = wl[wi], wl[wi + 1]
             wi += 2
             has_skip = (cin != cout) or up
@@ -607,28 +610,28 @@ class _DecoderFunction(torch.autograd.Function):
             # AdaIN + ReLU are applied ONCE per tensor while it is packed to the conv's 16-bit operand planes (the same planes feed
             # the weight gradient in backward); the convs themselves stage their operands by LDS-DMA only
             st0 = in_stats(x, x_cs, g0, b0)
-            a0 = norm_planes(x, st0)
+            a0 = norm_planes(x, st0, pb)
             ph1 = phase_conv(up, hout, reflect)
-            p1 = fpack(wi - 2, w1, ph1)
-            h1, cs1, _ = conv_out(a0, p1, hout, w1, ksize=3, upsample=up, alpha=sn[wi - 2][2][1:], **({'phase': True} if ph1 else {}))
+            p1 = fpack(wi - 2, w1, ph1, pb)
+            h1, cs1, _ = conv_out(a0, p1, hout, w1, pb, ksize=3, upsample=up, alpha=sn[wi - 2][2][1:], **({'phase': True} if ph1 else {}))
             st1 = in_stats(h1, cs1, g1, b1)
-            a1 = norm_planes(h1, st1)
+            a1 = norm_planes(h1, st1, pb)
             xs = None
             if has_skip:
                 ws, bs = wl[wi], wl[wi + 1]
                 wi += 2
-                ps = fpack(wi - 2, ws)
-                xs = x if isinstance(x, ops.Act16) else x_raw16 if x_raw16 is not None else ops.act_pack(x, pro=0, prec=prec)
-                s = ops.conv16(xs, ps, ksize=1, bias=bs.detach().contiguous(), alpha=sn[wi - 2][2][1:], prec=prec)   # 1x1 commutes with nearest upsampling
+                ps = fpack(wi - 2, ws, False, pb)
+                xs = x if isinstance(x, ops.Act16) else x_raw16 if x_raw16 is not None else ops.act_pack(x, pro=0, prec=pb)
+                s = ops.conv16(xs, ps, ksize=1, bias=bs.detach().contiguous(), alpha=sn[wi - 2][2][1:], prec=pb)   # 1x1 commutes with nearest upsampling
                 rs = 1 if up else 0
             else:
                 assert not isinstance(x, ops.Act16), 'an identity skip adds the fp32 block input (blocks without a skip conv sit on the smallest maps)'
                 s, rs = x, 0
             i2 = wi - (3 if has_skip else 1)
-            p2 = fpack(i2, w2)
+            p2 = fpack(i2, w2, False, pb)
             nxt = blocks[bi_ + 1] if bi_ + 1 < len(blocks) else None
-            out, x_cs, x_raw16 = conv_out(a1, p2, hout, w2, raw16=RAW16_SKIP and nxt is not None and (nxt[0] != nxt[1] or nxt[2]), ksize=3, res=s, res_shift=rs,
-                                          alpha=sn[i2][2][1:])
+            out, x_cs, x_raw16 = conv_out(a1, p2, hout, w2, pb, raw16=RAW16_SKIP and nxt is not None and (nxt[0] != nxt[1] or nxt[2]) and precs[bi_ + 1] == pb,
+                                          ksize=3, res=s, res_shift=rs, alpha=sn[i2][2][1:])
             if need_grad:
                 saved.append((x, h1, st0, st1, o0, o1, a0, a1, xs))
             if cfg.get('debug') is not None:      # activation patterns of the AdaIN+ReLU sites (tie-masked parity checks)
@@ -658,6 +661,7 @@ class _DecoderFunction(torch.autograd.Function):
     def backward(ctx, d_rgbs, d_segm):
         cfg = ctx.cfg
         blocks, prec = cfg['blocks'], cfg['prec']
+        precs = cfg.get('precs') or [prec] * len(blocks)      # operand mode per block; ``prec``: the head conv
         f16 = prec == PREC_F16          # gradient tensors become fp16 operands: their producers fold max|.| in (no amax pass)
         sn = cfg['sn']
         reflect = bool(cfg.get('reflect'))
@@ -665,7 +669,7 @@ class _DecoderFunction(torch.autograd.Function):
         params = ctx.params
         d_affine = torch.zeros_like(affine)
 
-        def border(i, a, dy, dA, up=False):
+        def border(i, a, dy, dA, up=False, prec=prec):
             """gen_padding='reflection': the border terms of conv weight i -- their share of the weight gradient (through the same spectral-norm
             rule, into the same .grad) and of the data gradient dA (in place); a = the conv's operand planes, dy = the fp32 gradient of its output"""
             corr = ops.reflect_border_wgrad(a, dy, prec=prec, upsample=up, sn=snw(i), accum=_accum_target(params[i]))
@@ -693,7 +697,7 @@ class _DecoderFunction(torch.autograd.Function):
                                                         accum=_accum_target(params[wi]), bias_grad=True)
         packsT = cfg.get('packsT')        # dgrad packs from the same batched launch (training), else packed on demand
 
-        def tpack(i, small_k=False, phase=False):
+        def tpack(i, small_k=False, phase=False, prec=prec):
             return packsT[i] if packsT is not None else ops.pack_weights(wl[i].contiguous(), 3 if phase else 1, prec, small_k=small_k)
         pT = tpack(wi, small_k=True)
         dA = ops.conv(dz, pT, ksize=3, alpha=sn[wi][2][1:], prec=prec, grad=True)
@@ -701,13 +705,15 @@ class _DecoderFunction(torch.autograd.Function):
         # bf16 / bf16x3 (round 6): gradient operands carry no scale there, so the AdaIN backward (and the 2x2 sum of the skip branch) write the
         # operand planes of their result themselves -- lp_adain_relu_bwd_planes / lp_sum2x2_planes: no pack launch, and the conv1-output gradient
         # (dh1), whose only consumers are the two contractions, never exists in fp32
-        direct = prec in (PREC_BF16, PREC_BF16X3)
+        # A gradient's operand planes are written in the mode of the block that CONSUMES them (``precs``: the blocks of one decoder may differ).
+        def is_direct(p_):
+            return p_ in (PREC_BF16, PREC_BF16X3)
         dbg = cfg.get('debug')
         dx16 = None
-        if direct:
-            dx, dx16 = ops.adain_relu_bwd(dA, x, None, g, sth[0], sth[1], sth[2], sth[3], dg, db, False, planes=prec)
+        if is_direct(precs[-1]):
+            dx, dx16 = ops.adain_relu_bwd(dA, x, None, g, sth[0], sth[1], sth[2], sth[3], dg, db, False, planes=precs[-1])
         else:
-            dx = ops.adain_relu_bwd(dA, x, None, g, sth[0], sth[1], sth[2], sth[3], dg, db, False, amax=f16)
+            dx = ops.adain_relu_bwd(dA, x, None, g, sth[0], sth[1], sth[2], sth[3], dg, db, False, amax=precs[-1] == PREC_F16)
         if dbg is not None:
             dbg['dz'] = dz; dbg['dA_head'] = dA; dbg[f'dx{len(blocks)}'] = dx
 
@@ -716,13 +722,16 @@ class _DecoderFunction(torch.autograd.Function):
             has_skip = (cin != cout) or up
             x, h1, st0, st1, o0, o1, a0, a1, xs = ctx.saved[bi]
             wi -= 4 if has_skip else 2
+            prec = precs[bi]                 # this block's operand mode; the gradient it hands on is packed for block bi - 1
+            pnext = precs[bi - 1] if bi > 0 else prec
+            direct, f16 = is_direct(prec), prec == PREC_F16
             d_out = dx
             d16 = dx16 if dx16 is not None else ops.act_pack(d_out, prec=prec, grad=True)       # packed once: operand of conv2's weight AND data gradient
             # conv2 (+ AdaIN1/ReLU prologue)
             grads[wi + 1] = ops.conv_wgrad16(a1, d16, ksize=3, prec=prec, sn=snw(wi + 1), accum=_accum_target(params[wi + 1]))
-            dA1 = ops.conv16(d16, tpack(wi + 1), ksize=3, alpha=sn[wi + 1][2][1:], prec=prec)
+            dA1 = ops.conv16(d16, tpack(wi + 1, prec=prec), ksize=3, alpha=sn[wi + 1][2][1:], prec=prec)
             if reflect:
-                border(wi + 1, a1, d_out, dA1)
+                border(wi + 1, a1, d_out, dA1, prec=prec)
             g, dg, db = slices(o1, cout)
             if direct:
                 dh1, dh16 = ops.adain_relu_bwd(dA1, h1, None, g, st1[0], st1[1], st1[2], st1[3], dg, db, False, planes=prec, keep_dx=reflect or dbg is not None)
@@ -738,7 +747,7 @@ class _DecoderFunction(torch.autograd.Function):
                 grads[wi + 2], grads[wi + 3] = ops.conv_wgrad16(xs, ds16, ksize=1, prec=prec, sn=snw(wi + 2),
                                                                 accum=_accum_target(params[wi + 2]), bias_grad=True,
                                                                 bias_accum=_accum_target(params[wi + 3]))
-                dx_skip = ops.conv16(ds16, tpack(wi + 2), ksize=1, alpha=sn[wi + 2][2][1:], prec=prec)
+                dx_skip = ops.conv16(ds16, tpack(wi + 2, prec=prec), ksize=1, alpha=sn[wi + 2][2][1:], prec=prec)
             else:
                 dx_skip = d_out
             # conv1 (+ AdaIN0/ReLU/upsample prologue)
@@ -747,18 +756,18 @@ class _DecoderFunction(torch.autograd.Function):
             grads[wi] = ops.conv_wgrad16(a0, dh16, ksize=3, upsample=up, prec=prec, sn=snw(wi), accum=_accum_target(params[wi]))
             ph1 = phase_conv(up, dh16.hi.shape[1], reflect)
             if ph1:      # phase form of the data gradient: the gradient w.r.t. the LOW-resolution AdaIN output from one launch (2 x 2 sum included)
-                dA0 = ops.conv16(dh16, tpack(wi, phase=True), ksize=3, alpha=sn[wi][2][1:], prec=prec, phase_dgrad=True)
+                dA0 = ops.conv16(dh16, tpack(wi, phase=True, prec=prec), ksize=3, alpha=sn[wi][2][1:], prec=prec, phase_dgrad=True)
             else:
-                dA0 = ops.conv16(dh16, tpack(wi), ksize=3, alpha=sn[wi][2][1:], prec=prec)
+                dA0 = ops.conv16(dh16, tpack(wi, prec=prec), ksize=3, alpha=sn[wi][2][1:], prec=prec)
             if reflect:
-                border(wi, a0, dh1, dA0, up)
+                border(wi, a0, dh1, dA0, up, prec=prec)
             up_bwd = up and not ph1          # (the fused-upsample form hands the AdaIN backward a 2H x 2W gradient to sum)
             g, dg, db = slices(o0, cin)
             dx16 = None
-            if direct and bi > 0:          # (block 0's input gradient only feeds the learned constant: fp32)
-                dx, dx16 = ops.adain_relu_bwd(dA0, x, dx_skip, g, st0[0], st0[1], st0[2], st0[3], dg, db, up_bwd, planes=prec)
+            if is_direct(pnext) and bi > 0:          # (block 0's input gradient only feeds the learned constant: fp32)
+                dx, dx16 = ops.adain_relu_bwd(dA0, x, dx_skip, g, st0[0], st0[1], st0[2], st0[3], dg, db, up_bwd, planes=pnext)
             else:
-                dx = ops.adain_relu_bwd(dA0, x, dx_skip, g, st0[0], st0[1], st0[2], st0[3], dg, db, up_bwd, amax=f16 and bi > 0)
+                dx = ops.adain_relu_bwd(dA0, x, dx_skip, g, st0[0], st0[1], st0[2], st0[3], dg, db, up_bwd, amax=pnext == PREC_F16 and bi > 0)
             if dbg is not None:
                 dbg[f'dx{bi}'] = dx; dbg[f'dh1_{bi}'] = dh1; dbg[f'dxskip{bi}'] = dx_skip
         d_const = dx.sum(dim=0, keepdim=True).permute(0, 3, 1, 2).contiguous()
@@ -804,6 +813,22 @@ class Generator(nn.Module):
         # which fp16 operands meet with a wide margin (fake_rgbs 1.6e-4 at 256 x 256) at a third of the matrix work -- the default assignment's
         # bf16x3 is for the gradients.  An explicit ``prec`` / LP_PREC_G / a global mode other than f16 applies to every forward.
         self.infer_prec = self.prec if (prec is not None or os.environ.get('LP_PREC_G') or default_prec() != PREC_F16) else PREC_F16
+        # the LAST ``f16_tail`` blocks of the decoder (the widest maps: most of its matrix work) may run fp16 operands inside a bf16x3 generator:
+        # rounding injected there passes through few layers (LP_G_F16_TAIL; DESIGN section 2 has the measured gradient figures per setting)
+        self.f16_tail = int(os.environ.get('LP_G_F16_TAIL', str(G_F16_TAIL_DEFAULT))) if prec is None else 0
+
+    def block_precs(self, prec):
+        """operand mode per decoder block for a pass whose base mode is ``prec``"""
+        nb = len(self.blocks_cfg)
+        k = min(self.f16_tail, nb) if prec == PREC_BF16X3 else 0
+        return [prec] * (nb - k) + [PREC_F16] * k
+
+    def _weight_precs(self, precs, prec):
+        """operand mode per entry of ``_conv_weights``' list (biases: their conv's), the head conv in the base mode"""
+        out = []
+        for (cin, cout, up), p_ in zip(self.blocks_cfg, precs):
+            out += [p_] * (4 if (cin != cout or up) else 2)
+        return out + [prec, prec]
 
     # ---- the projector is the only part in which the generator plugins differ (noBottleneck.py:96-101 vs FSTH_plus.py:96-103)
     def _build_projector(self, joint):
@@ -886,9 +911,11 @@ class Generator(nn.Module):
         conv_idx = [i for i, s_ in enumerate(sn) if s_ is not None]
         ph = self._phase_weight_indices()          # conv1 of the up blocks that run in their phase forms: pack modes 2 / 3 instead of 0 / 1
         specs = [(weights[i], 2 if i in ph else 0, False) for i in conv_idx] + [(weights[i], 3 if i in ph else 1, i == len(weights) - 2) for i in conv_idx]
+        wp = self._weight_precs(self.block_precs(self.prec), self.prec)
+        sp = tuple(wp[i] for i in conv_idx) * 2
         pb = self.__dict__.get('_train_packs')
-        if pb is None or pb.prec != self.prec or pb.key != tuple((w.data_ptr(), m, bool(k_)) for w, m, k_ in specs):
-            pb = ops.PackBatch(specs, self.prec)
+        if pb is None or pb.prec != self.prec or pb.precs != sp or pb.key != tuple((w.data_ptr(), m, bool(k_)) for w, m, k_ in specs):
+            pb = ops.PackBatch(specs, self.prec, sp)
             self.__dict__['_train_packs'] = pb
         allp = pb.update()
         packs, packsT = [None] * len(weights), [None] * len(weights)
@@ -942,6 +969,7 @@ class Generator(nn.Module):
         weights, sn = self._conv_weights(states)
         need_grad = torch.is_grad_enabled() and (affine.requires_grad or any(w.requires_grad for w in weights))
         prec = self.prec if need_grad else self.infer_prec
+        precs = self.block_precs(prec)
         packs = packsT = None
         prepared = self.__dict__.pop('_prepared_packs', None)
         if not torch.is_grad_enabled():
@@ -953,15 +981,16 @@ class Generator(nn.Module):
             # generation counter of the fused optimizer / EMA kernels: those update weights through raw pointers without bumping
             # ``_version`` (a graph replay bumps neither: GraphedTrainStep.__call__ advances the counter itself).
             from .optim import WEIGHTS_GENERATION
-            key = (prec, WEIGHTS_GENERATION[0]) + tuple((w.data_ptr(), w._version) for w in weights)
+            key = (prec, tuple(precs), WEIGHTS_GENERATION[0]) + tuple((w.data_ptr(), w._version) for w in weights)
             cache = self.__dict__.get('_pack_cache')
             if cache is None or cache[0] != key:
                 ph = self._phase_weight_indices()
-                cache = (key, [ops.pack_weights(w.detach().contiguous(), 2 if i in ph else 0, prec) if s_ is not None else None
+                wp = self._weight_precs(precs, prec)
+                cache = (key, [ops.pack_weights(w.detach().contiguous(), 2 if i in ph else 0, wp[i]) if s_ is not None else None
                                for i, (w, s_) in enumerate(zip(weights, sn))])
                 self.__dict__['_pack_cache'] = cache
             packs = cache[1]
-        cfg = dict(blocks=self.blocks_cfg, prec=prec, need_grad=need_grad, sn=sn, packs=packs, packsT=packsT,
+        cfg = dict(blocks=self.blocks_cfg, prec=prec, precs=precs, need_grad=need_grad, sn=sn, packs=packs, packsT=packsT,
                    debug=getattr(self, '_debug', None), y16=G_Y16 and self.training and need_grad, reflect=self.reflect)
         rgbs, segm = _DecoderFunction.apply(cfg, affine, self.constant.constant, *weights)
         data_dict['fake_rgbs'] = rgbs
