@@ -284,6 +284,13 @@ int lp_bn_relu_maxpool_fwd(const float* y, const float* scale, const float* shif
 int lp_maxpool_bwd(const float* dout, const unsigned char* idx, float* dA, int N, int H, int W, int C, void* stream);
 int lp_bn_add_act(const float* y, const float* scale, const float* shift, const float* res, const float* res_scale, const float* res_shift,
                   float* out, uint16_t* hi, uint16_t* lo, long long P, int C, int relu, int prec, void* stream);
+/*   lp_bn_add_act_planes (ABI 12, round 6; bf16 / bf16x3): the identity-shortcut form of lp_bn_add_act (torchvision Bottleneck.forward's
+ *                     ``out += identity; out = relu(out)``, reached through embedders/unsupervised_pose_separate_embResNeXt_segmentation.py:26,37-54)
+ *                     with the residual read from the OPERAND PLANES of the block input (res_hi [+ res_lo]: hi + lo = 16 significant bits, the
+ *                     values the block's first conv multiplied) and fp32 ``out`` OPTIONAL (NULL: planes only -- nothing downstream of an
+ *                     identity bottleneck of a bf16x3 network reads an fp32 copy of its output) */
+int lp_bn_add_act_planes(const float* y, const float* scale, const float* shift, const uint16_t* res_hi, const uint16_t* res_lo, float* out,
+                         uint16_t* hi, uint16_t* lo, long long P, int C, int relu, int prec, void* stream);
 /*   16-bit-resident conv outputs (fp16 mode; y16 = the fp16 plane [P][C] a conv epilogue wrote instead of fp32 y, C % 8 == 0):
  *   lp_bn_add_act16:  lp_bn_add_act reading y16 (out fp32 + its fp16 operand plane hi|NULL)
  *   lp_bn_act16:      out_hi = fp16((relu?)(y16*scale[c]+shift[c])): the BatchNorm (+ ReLU) prologue of the next conv (lp_act_pack pro 4 / 5

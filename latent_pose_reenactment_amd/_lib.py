@@ -77,6 +77,7 @@ SIGNATURES = {
     'lp_bn_relu_maxpool_fwd': (_i, [_vp] * 7 + [_i] * 5 + [_vp]),
     'lp_maxpool_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'lp_bn_add_act': (_i, [_vp] * 9 + [_ll, _i, _i, _i, _vp]),
+    'lp_bn_add_act_planes': (_i, [_vp] * 8 + [_ll, _i, _i, _i, _vp]),
     'lp_bn_add_act16': (_i, [_vp] * 8 + [_ll, _i, _i, _vp]),
     'lp_bn_act16': (_i, [_vp] * 4 + [_ll, _i, _i, _vp]),
     'lp_adain_act16': (_i, [_vp] * 4 + [_i, _ll, _i, _i, _vp]),

@@ -21,4 +21,4 @@ int lp_check_launch(const char* what) {
 }
 
 extern "C" const char* lp_last_error(void) { return g_err; }
-extern "C" int lp_abi_version(void) { return 11; }
+extern "C" int lp_abi_version(void) { return 12; }

@@ -214,11 +214,15 @@ extern "C" int lp_maxpool_bwd(const float* dout, const unsigned char* idx, float
 }
 
 // ---- block output: out = act( y*scale[c]+shift[c] + r ),  r = res | res*rscale[c]+rshift[c] | 0;  act = ReLU | identity -------------
-template <int PREC, bool Y16>
+// RES16 (round 6, bf16 / bf16x3): r is read from the OPERAND PLANES of the block input (rhi [+ rlo]: hi + lo carries 16 significant bits -- the
+// same values the block's first conv multiplies) and ``out`` may be NULL: an identity bottleneck of a bf16x3 network then neither reads nor
+// writes an fp32 copy of a block output (16 -> 12 B per element here)
+template <int PREC, bool Y16, bool RES16 = false>
 __global__ __launch_bounds__(256) void bn_add_act_kernel(const void* __restrict__ y, const float* __restrict__ sc, const float* __restrict__ sh,
                                                          const float* __restrict__ res, const float* __restrict__ rsc, const float* __restrict__ rsh,
                                                          float* __restrict__ out, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo,
-                                                         long long items, int C, int relu) {
+                                                         long long items, int C, int relu,
+                                                         const uint16_t* __restrict__ rhi = nullptr, const uint16_t* __restrict__ rlo = nullptr) {
     constexpr bool SPLIT = (PREC == LP_PREC_BF16X3), F16 = (PREC == LP_PREC_F16);
     const int G = C >> 3;
     const float floor_v = relu ? 0.f : -3.0e38f;
@@ -228,7 +232,17 @@ __global__ __launch_bounds__(256) void bn_add_act_kernel(const void* __restrict_
         load8<Y16>(y, (size_t)i * 8, v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], sc[c + j], sh[c + j]);
-        if (res) {
+        if (RES16) {
+            const s16x8_t qh = *(const s16x8_t*)(rhi + i * 8);
+            s16x8_t ql = qh;
+            if (SPLIT) ql = *(const s16x8_t*)(rlo + i * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float r = lp_op16_to_f32<false>((uint16_t)qh[j]);
+                if (SPLIT) r += lp_op16_to_f32<false>((uint16_t)ql[j]);
+                v[j] += r;
+            }
+        } else if (res) {
             const float4 r0 = *(const float4*)(res + i * 8), r1 = *(const float4*)(res + i * 8 + 4);
             float r[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
             if (rsc) {
@@ -240,8 +254,10 @@ __global__ __launch_bounds__(256) void bn_add_act_kernel(const void* __restrict_
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], floor_v);
-        *(float4*)(out + i * 8) = make_float4(v[0], v[1], v[2], v[3]);
-        *(float4*)(out + i * 8 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        if (!RES16 || out) {
+            *(float4*)(out + i * 8) = make_float4(v[0], v[1], v[2], v[3]);
+            *(float4*)(out + i * 8 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
         if (hi) store_op8<F16, SPLIT>(v, hi, lo, (size_t)i * 8);
     }
 }
@@ -270,6 +286,26 @@ extern "C" int lp_bn_add_act(const float* y, const float* scale, const float* sh
                              void* stream) {
     if (!y) return lp_set_error(LP_ERR_ARG, "lp_bn_add_act: null pointer");
     return bn_add_act_impl(y, nullptr, scale, shift, res, res_scale, res_shift, out, hi, lo, P, C, relu, prec, (hipStream_t)stream);
+}
+
+// identity bottleneck of a bf16 / bf16x3 network: the residual from the operand planes of the block input, fp32 ``out`` optional (ABI 12)
+extern "C" int lp_bn_add_act_planes(const float* y, const float* scale, const float* shift, const uint16_t* res_hi, const uint16_t* res_lo,
+                                    float* out, uint16_t* hi, uint16_t* lo, long long P, int C, int relu, int prec, void* stream) {
+    if (!y || !scale || !shift || !res_hi || !hi) return lp_set_error(LP_ERR_ARG, "lp_bn_add_act_planes: null pointer");
+    if (prec != LP_PREC_BF16 && prec != LP_PREC_BF16X3)
+        return lp_set_error(LP_ERR_UNSUPPORTED, "lp_bn_add_act_planes: bf16 / bf16x3 planes only (an fp16 plane has 11 bits: not a residual stream)");
+    if (prec == LP_PREC_BF16X3 && (!res_lo || !lo)) return lp_set_error(LP_ERR_ARG, "lp_bn_add_act_planes: bf16x3 planes need lo");
+    if (C & 7) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_bn_add_act_planes: C must be a multiple of 8");
+    const long long items = P * (C >> 3);
+    if (items == 0) return LP_OK;
+    const float* nof = nullptr;
+    if (prec == LP_PREC_BF16X3)
+        hipLaunchKernelGGL((bn_add_act_kernel<LP_PREC_BF16X3, false, true>), dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, (const void*)y, scale, shift,
+                           nof, nof, nof, out, hi, lo, items, C, relu, res_hi, res_lo);
+    else
+        hipLaunchKernelGGL((bn_add_act_kernel<LP_PREC_BF16, false, true>), dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, (const void*)y, scale, shift,
+                           nof, nof, nof, out, hi, lo, items, C, relu, res_hi, res_lo);
+    return lp_check_launch("bn_add_act_planes");
 }
 
 // y as the fp16 plane a conv epilogue wrote instead of fp32 (fp16 mode)

@@ -25,7 +25,7 @@ import torch
 
 from latent_pose_reenactment_amd import hipops as ops
 from latent_pose_reenactment_amd import streams as _streams
-from latent_pose_reenactment_amd._lib import PREC_F16
+from latent_pose_reenactment_amd._lib import PREC_BF16, PREC_BF16X3, PREC_F16
 
 
 class _BN:
@@ -44,6 +44,7 @@ def supported(n: int, h: int, w: int) -> bool:
 
 
 Y16 = os.environ.get('LP_E_Y16', '1') != '0'        # fp16 mode: conv outputs stay 16-bit resident
+RES16 = os.environ.get('LP_E_RES16', '1') != '0'    # identity shortcuts of bf16 / bf16x3 blocks read the block input from its operand planes; no fp32 block output there
 MASK16 = os.environ.get('LP_E_MASK16', '1') != '0'  # block-output ReLU pattern from the operand planes in every mode (0: from the fp32 copy outside the fp16 mode)
 
 
@@ -134,6 +135,13 @@ class ResNeXtFunction(torch.autograd.Function):
         # ---- bottleneck blocks.  Inside the loop ``prec`` is the block's own mode; the block output's operand planes are written in the
         # mode of the block that consumes them.
         base_prec = prec
+        nblk = len(net._hip_blocks)
+
+        def next_prec(b):          # mode of the planes block b writes for its consumer
+            return lprecs[(net._hip_blocks[b + 1][0], 'conv1')] if b + 1 < nblk else bprecs[b]
+        # identity shortcuts read from the operand planes of the block input (RES16): blocks whose input and output planes share a bf16-class mode
+        planes_res = [RES16 and MASK16 and not blk[5] and lprecs[(blk[0], 'conv1')] in (PREC_BF16, PREC_BF16X3) and next_prec(b) == lprecs[(blk[0], 'conv1')]
+                      for b, blk in enumerate(net._hip_blocks)]
         for bi, (bname, cin, width, cout, stride, down) in enumerate(net._hip_blocks):
             prec = bprecs[bi]
             p1, p2, p3 = lprecs[(bname, 'conv1')], lprecs[(bname, 'conv2')], lprecs[(bname, 'conv3')]
@@ -141,7 +149,7 @@ class ResNeXtFunction(torch.autograd.Function):
             y16 = Y16 and p1 == p2 == p3 == PREC_F16
             assert not (y16 and nprec != PREC_F16), 'an fp16 block must be followed by fp16 blocks (lp_bn_add_act16 writes fp16 planes)'
             xin, xin16 = out, out16
-            _, h, w, _ = xin.shape
+            _, h, w, _ = xin16.hi.shape
             y1, cs = _conv1x1(xin16, packs[bname + '.conv1.weight'][0], p1, stats=True, y16=y16)
             y1 = _yview(y1, (n, h, w, width))
             st1 = bn(y1, bname + '.bn1', cs)
@@ -167,6 +175,11 @@ class ResNeXtFunction(torch.autograd.Function):
                 yd = yd.view(n, ho, wo, cout)
                 std = bn(yd, bname + '.downsample.1', cs)
                 out, out16 = ops.bn_add_act(y3, st3.scale, st3.shift, yd, std.scale, std.shift, relu=True, prec=nprec)
+            elif planes_res[bi]:
+                # identity shortcut from the operand planes of the block input (hi + lo: the values conv1 multiplied); the fp32 copy of the block
+                # output is only written when something reads it: an identity block that takes the fp32 route, or the pooling head behind the last block
+                need_f32 = bi + 1 >= nblk or not (net._hip_blocks[bi + 1][5] or planes_res[bi + 1])
+                out, out16 = ops.bn_add_act(y3, st3.scale, st3.shift, xin16, relu=True, prec=nprec, want_out=need_f32)
             else:
                 out, out16 = ops.bn_add_act(y3, st3.scale, st3.shift, xin, relu=True, prec=nprec)
             if need_grad:

@@ -1246,8 +1246,21 @@ def maxpool_bwd(dout: Tensor, idx: Tensor, h: int, w: int) -> Tensor:
 
 
 def bn_add_act(y: Tensor, scale: Tensor, shift: Tensor, res: Optional[Tensor] = None, res_scale: Optional[Tensor] = None,
-               res_shift: Optional[Tensor] = None, relu: bool = True, prec: Optional[int] = None):
-    """out = relu?(y*scale[c]+shift[c] + (res | res*res_scale[c]+res_shift[c])) over [..., C]; with ``prec`` -> (out, Act16)"""
+               res_shift: Optional[Tensor] = None, relu: bool = True, prec: Optional[int] = None, want_out: bool = True):
+    """out = relu?(y*scale[c]+shift[c] + (res | res*res_scale[c]+res_shift[c])) over [..., C]; with ``prec`` -> (out, Act16).
+    ``res`` as ``Act16`` (bf16 / bf16x3 planes of the same mode as ``prec``): the residual is read from the operand planes (lp_bn_add_act_planes);
+    ``want_out=False`` then skips the fp32 copy -> (None, Act16)."""
+    if isinstance(res, Act16):
+        _chk(y, 'y')
+        assert prec in (PREC_BF16, PREC_BF16X3) and res_scale is None and res.inv is None and (res.lo is not None) == (prec == PREC_BF16X3)
+        assert tuple(res.hi.shape) == tuple(y.shape), (res.hi.shape, y.shape)
+        c = y.shape[-1]
+        out = torch.empty_like(y) if want_out else None
+        hi = torch.empty(y.shape, dtype=torch.int16, device=y.device)
+        lo = torch.empty_like(hi) if prec == PREC_BF16X3 else None
+        check(_lib.lib().lp_bn_add_act_planes(y.data_ptr(), scale.data_ptr(), shift.data_ptr(), res.hi.data_ptr(), _p(res.lo), _p(out), hi.data_ptr(), _p(lo),
+                                              y.numel() // c, c, int(relu), prec, _stream()), 'lp_bn_add_act_planes')
+        return out, Act16(hi, lo, c, None)
     y16 = y if isinstance(y, Act16) else None
     if y16 is not None:          # 16-bit-resident conv output (fp16 mode)
         assert prec in (None, PREC_F16) and y16.lo is None and y16.inv is None

@@ -192,9 +192,15 @@ def maxpool_bwd(dout, idx, h, w):
     return dA.view(n, c, h, w).permute(0, 2, 3, 1).contiguous()
 
 
-def bn_add_act(y, scale, shift, res=None, res_scale=None, res_shift=None, relu=True, prec=None):
+def bn_add_act(y, scale, shift, res=None, res_scale=None, res_shift=None, relu=True, prec=None, want_out=True):
     if isinstance(y, Act16):
         y = y.hi
+    if isinstance(res, Act16):          # lp_bn_add_act_planes: the residual from the operand planes of the block input, fp32 out optional
+        assert res_scale is None and prec is not None
+        v = y * scale + shift + res.hi
+        if relu:
+            v = torch.relu(v)
+        return (v if want_out else None), Act16(v, None, v.shape[-1], None)
     v = y * scale + shift
     if res is not None:
         v = v + (res * res_scale + res_shift if res_scale is not None else res)

@@ -50,7 +50,7 @@ def test_ctypes_signatures_match_header():
 def test_abi_version_and_error_string():
     from latent_pose_reenactment_amd import _lib
     l = _lib.lib()
-    assert l.lp_abi_version() == 11
+    assert l.lp_abi_version() == 12
     # argument validation happens before any device work, so it is callable without a GPU
     rc = l.lp_pack_weights(None, None, None, 1, 1, 1, 128, 64, 0, 0, None)
     assert rc == -1 and b'null' in l.lp_last_error()

@@ -227,6 +227,27 @@ def test_bn_add_act(variant, prec):
     report(f'bn_add_act[{variant}] planes', rel(decode(o16, prec), rout), 3e-6 if prec == 1 else 3e-4)
 
 
+@pytest.mark.parametrize('prec', [0, 1])
+def test_bn_add_act_with_the_residual_from_operand_planes(prec):
+    """lp_bn_add_act_planes (ABI 12): the identity shortcut read from the operand planes of the block input equals lp_bn_add_act fed with the planes'
+    decoded values BIT FOR BIT (fp32 out and planes), the planes-only form (no fp32 out) writes the same planes, and against the fp32 residual the
+    result moves by the planes' own resolution (bf16x3: 2^-17 of the residual)"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    shp = (2, 9, 7, 256)
+    y, res = torch.randn(shp, generator=g).cuda(), torch.randn(shp, generator=g).cuda().relu()
+    sc, sh = (torch.rand(256, generator=g) + 0.5).cuda(), torch.randn(256, generator=g).cuda()
+    r16 = ops.act_pack(res, pro=0, prec=prec)
+    rdec = decode(r16, prec).float().contiguous()
+    out_a, p_a = ops.bn_add_act(y, sc, sh, r16, relu=True, prec=prec)
+    out_b, p_b = ops.bn_add_act(y, sc, sh, rdec, relu=True, prec=prec)
+    assert torch.equal(out_a, out_b) and torch.equal(p_a.hi, p_b.hi) and (prec == 0 or torch.equal(p_a.lo, p_b.lo))
+    none, p_c = ops.bn_add_act(y, sc, sh, r16, relu=True, prec=prec, want_out=False)
+    assert none is None and torch.equal(p_c.hi, p_a.hi) and (prec == 0 or torch.equal(p_c.lo, p_a.lo))
+    out_f, _ = ops.bn_add_act(y, sc, sh, res, relu=True, prec=prec)
+    report(f'bn_add_act_planes[{prec}] vs the fp32 residual', rel(out_a, out_f), 1e-5 if prec == 1 else 4e-3)
+
+
 @pytest.mark.parametrize('mode', ['relu', 'src'])
 def test_sixteen_bit_resident_conv_output_forms(mode):
     """fp16 mode, conv outputs 16-bit resident: (1) the conv / grouped-conv epilogue writes the fp16 plane of y (no fp32 y) and the SAME
