@@ -259,6 +259,7 @@ int lp_bn_train_stats(const float* y, const float* gamma, const float* beta, flo
  *   lp_bn_relu_maxpool_fwd: out [N][Ho][Wo][C] = MaxPool2d(3,2,1)(relu(y*scale[c]+shift[c])), hi/lo|NULL its operand planes,
  *                     idx|NULL [N][Ho][Wo][C] bytes = window position of the maximum;  lp_maxpool_bwd: dA [N][H][W][C] from d_out + idx
  *   lp_bn_add_act:    out = (relu?)(y*scale[c]+shift[c] + (res | res*res_scale[c]+res_shift[c] | 0)) over [P][C], + operand planes
+ *                     (ABI 12: out may be NULL when hi is given -- planes only)
  *   lp_subsample2 / lp_zero_stuff2: out[n,i,j] = in[n,2i,2j] / its adjoint on [N][H][W][row_bytes] tensors (H, W = FULL-resolution dims;
  *                     fp32 NHWC or operand planes: row_bytes % 16 == 0);  lp_add_strided2: d[n,2i,2j,:] += s[n,i,j,:] (fp32)
  *   lp_spatial_mean_fwd/bwd: AdaptiveAvgPool2d(1) */

@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void bn_add_act_kernel(const void* __restrict_
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], floor_v);
-        if (!RES16 || out) {
+        if (out) {
             *(float4*)(out + i * 8) = make_float4(v[0], v[1], v[2], v[3]);
             *(float4*)(out + i * 8 + 4) = make_float4(v[4], v[5], v[6], v[7]);
         }
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void bn_add_act_kernel(const void* __restrict_
 
 static int bn_add_act_impl(const float* y, const uint16_t* y16, const float* scale, const float* shift, const float* res, const float* res_scale,
                            const float* res_shift, float* out, uint16_t* hi, uint16_t* lo, long long P, int C, int relu, int prec, hipStream_t st) {
-    if ((!y && !y16) || !scale || !shift || !out) return lp_set_error(LP_ERR_ARG, "lp_bn_add_act: null pointer");
+    if ((!y && !y16) || !scale || !shift || (!out && !hi)) return lp_set_error(LP_ERR_ARG, "lp_bn_add_act: null pointer");      // (out NULL: planes only, ABI 12)
     if (!res_scale != !res_shift || (res_scale && !res)) return lp_set_error(LP_ERR_ARG, "lp_bn_add_act: res_scale/res_shift go together and need res");
     if (C & 7) return lp_set_error(LP_ERR_UNSUPPORTED, "lp_bn_add_act: C must be a multiple of 8");
     if (hi && prec == LP_PREC_BF16X3 && !lo) return lp_set_error(LP_ERR_ARG, "lp_bn_add_act: bf16x3 planes need lo");

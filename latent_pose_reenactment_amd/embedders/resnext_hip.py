@@ -174,7 +174,8 @@ class ResNeXtFunction(torch.autograd.Function):
                 yd, cs = _conv1x1(xd16, packs[bname + '.downsample.0.weight'][0], p1, stats=True)
                 yd = yd.view(n, ho, wo, cout)
                 std = bn(yd, bname + '.downsample.1', cs)
-                out, out16 = ops.bn_add_act(y3, st3.scale, st3.shift, yd, std.scale, std.shift, relu=True, prec=nprec)
+                need_f32 = bi + 1 >= nblk or not (net._hip_blocks[bi + 1][5] or planes_res[bi + 1])          # (as below: who reads an fp32 block output)
+                out, out16 = ops.bn_add_act(y3, st3.scale, st3.shift, yd, std.scale, std.shift, relu=True, prec=nprec, want_out=need_f32 or not MASK16)
             elif planes_res[bi]:
                 # identity shortcut from the operand planes of the block input (hi + lo: the values conv1 multiplied); the fp32 copy of the block
                 # output is only written when something reads it: an identity block that takes the fp32 route, or the pooling head behind the last block

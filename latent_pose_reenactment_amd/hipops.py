@@ -1272,7 +1272,8 @@ def bn_add_act(y: Tensor, scale: Tensor, shift: Tensor, res: Optional[Tensor] = 
     p = 1
     for d in shape[:-1]:
         p *= d
-    out = torch.empty(shape, dtype=torch.float32, device=dev)
+    assert want_out or prec is not None
+    out = torch.empty(shape, dtype=torch.float32, device=dev) if want_out else None
     hi = lo = None
     if prec is not None:
         hi = torch.empty(shape, dtype=torch.int16, device=dev)
@@ -1281,9 +1282,9 @@ def bn_add_act(y: Tensor, scale: Tensor, shift: Tensor, res: Optional[Tensor] = 
         _chk(res, 'res'); assert res.shape == shape, (res.shape, shape)
     if y16 is not None:
         check(_lib.lib().lp_bn_add_act16(y16.hi.data_ptr(), scale.data_ptr(), shift.data_ptr(), _p(res), _p(res_scale), _p(res_shift),
-                                         out.data_ptr(), _p(hi), p, c, int(relu), _stream()), 'lp_bn_add_act16')
+                                         _p(out), _p(hi), p, c, int(relu), _stream()), 'lp_bn_add_act16')
     else:
-        check(_lib.lib().lp_bn_add_act(y.data_ptr(), scale.data_ptr(), shift.data_ptr(), _p(res), _p(res_scale), _p(res_shift), out.data_ptr(),
+        check(_lib.lib().lp_bn_add_act(y.data_ptr(), scale.data_ptr(), shift.data_ptr(), _p(res), _p(res_scale), _p(res_shift), _p(out),
                                        _p(hi), _p(lo), p, c, int(relu), prec if prec is not None else 0, _stream()), 'lp_bn_add_act')
     return out if prec is None else (out, Act16(hi, lo, c, None))
 

@@ -206,7 +206,7 @@ def bn_add_act(y, scale, shift, res=None, res_scale=None, res_shift=None, relu=T
         v = v + (res * res_scale + res_shift if res_scale is not None else res)
     if relu:
         v = torch.relu(v)
-    return v if prec is None else (v, Act16(v, None, v.shape[-1], None))
+    return v if prec is None else ((v if want_out else None), Act16(v, None, v.shape[-1], None))
 
 
 def subsample2(x):

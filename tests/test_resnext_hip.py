@@ -225,6 +225,8 @@ def test_bn_add_act(variant, prec):
     rout = emu_ops.bn_add_act(y.double(), v[0].double(), v[1].double(), *[None if t is None else t.double() for t in args], relu=variant != 'plain')
     report(f'bn_add_act[{variant}]', rel(out, rout), 1e-6)
     report(f'bn_add_act[{variant}] planes', rel(decode(o16, prec), rout), 3e-6 if prec == 1 else 3e-4)
+    none, p16 = ops.bn_add_act(y, v[0], v[1], *args, relu=variant != 'plain', prec=prec, want_out=False)      # planes only (ABI 12): same planes, no fp32 out
+    assert none is None and torch.equal(p16.hi, o16.hi) and (prec != 1 or torch.equal(p16.lo, o16.lo))
 
 
 @pytest.mark.parametrize('prec', [0, 1])
