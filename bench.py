@@ -97,10 +97,12 @@ def stream_config(workload):
     probe = torch.empty(1, device='cuda') if torch.cuda.is_available() else None
     ft = workload != 'metatrain_step'
     on = [k for k in ('encoders', 'criterions', 'prepare', 'dpasses', 'real', 'optimizer') if probe is not None and streams.enabled(probe, k, finetuning=ft) and not (ft and k == 'encoders')]
+    on += [k for k in ('ebwd', 'gwgrad') if probe is not None and not ft and streams.enabled(probe, k, finetuning=False) and int(os.environ.get('WORLD_SIZE', '1')) == 1]
     return {'concurrent_branches': on if workload != 'generator' else [],
             'note': 'encoders: pose encoder beside the identity encoder; criterions: VGG-19 / VGGFace stacks beside the discriminator pass; '
                     'prepare: spectral-norm power iterations + weight packs of G and D beside the encoders; dpasses: the discriminator\'s three '
-                    'passes beside each other; real: its real-image pass already beside the generator forward; autograd runs each backward on its forward stream; captured as parallel '
+                    'passes beside each other; real: its real-image pass already beside the generator forward; ebwd (one GPU): the encoders\' backward beside loss_D.backward; '
+                    'gwgrad (with ebwd): the generator\'s weight-gradient launches issued on the critic-backward stream; autograd runs each backward on its forward stream; captured as parallel '
                     'paths of the hipGraphs'}
 
 

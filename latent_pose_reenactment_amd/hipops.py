@@ -412,6 +412,39 @@ def default_splits(n, h, w, cin, cout, ksize=3, prec=None, bias=False):
     return max(1, min(512 // blocks, tiles))
 
 
+# Deferred weight gradients (round 6, one-GPU meta-training step): a weight gradient whose result is ADDED to the parameter's .grad (spectral-norm rule
+# included) has no consumer inside the backward pass, so its launch need not sit in the data-gradient chain.  Inside ``wgrad_defer()`` such launches
+# are recorded instead of issued; ``wgrad_flush()`` issues them -- on whatever stream is current THEN (runners/holycow.py: the critic-backward
+# stream, beside the encoders' backward).  The operand planes stay alive in the job list, which the caller keeps until the flushing stream has been
+# joined (the planes were allocated on the backward pass's stream).  Same kernels, same operands, one contribution per parameter: bit-identical sums.
+_WG_DEFER = {'active': False, 'jobs': []}
+
+
+class wgrad_defer:
+    def __enter__(self):
+        self.prev = _WG_DEFER['active']
+        _WG_DEFER['active'] = True
+
+    def __exit__(self, *exc):
+        _WG_DEFER['active'] = self.prev
+        if exc[0] is not None:
+            _WG_DEFER['jobs'] = []
+
+
+def wgrad_flush():
+    """issue the recorded weight-gradient launches on the current stream (inside nn.fused_grad_accumulation: their spectral-norm rules join its
+    batched launch) -> the job list (operands): keep it until this stream has been joined"""
+    jobs, _WG_DEFER['jobs'] = _WG_DEFER['jobs'], []
+    prev, _WG_DEFER['active'] = _WG_DEFER['active'], False
+    try:
+        for args, kw in jobs:
+            out = conv_wgrad16(*args, **kw)
+            assert out is None or all(o is None for o in out), 'a deferred weight gradient accumulates: nothing is returned'
+    finally:
+        _WG_DEFER['active'] = prev
+    return jobs
+
+
 def conv_wgrad16(a: Act16, dy: Act16, *, ksize: int, upsample: bool = False, prec: int = PREC_BF16, splits: Optional[int] = None,
                  sn=None, accum: Optional[Tensor] = None, bias_grad: bool = False, bias_accum: Optional[Tensor] = None, kind: str = 'conv_wgrad'):
     """dw [Cout,Cin,k,k] = sum_pixels dy (x) up2?(a) (shifted by tap) on operand planes (a = what the forward conv consumed).
@@ -423,6 +456,11 @@ def conv_wgrad16(a: Act16, dy: Act16, *, ksize: int, upsample: bool = False, pre
     n, h, w = dy.nhw
     cout, cin = dy.c, a.c
     assert a.nhw == ((n, h // 2, w // 2) if upsample else (n, h, w)), (a.hi.shape, dy.hi.shape, upsample)
+    if (_WG_DEFER['active'] and sn is not None and accum is not None and (not bias_grad or bias_accum is not None)
+            and SN_DEFER and _SN_DEFER['depth'] > 0):
+        _WG_DEFER['jobs'].append(((a, dy), dict(ksize=ksize, upsample=upsample, prec=prec, splits=splits, sn=sn, accum=accum, bias_grad=bias_grad,
+                                                bias_accum=bias_accum, kind=kind)))
+        return (None, None) if bias_grad else None
     dev = dy.hi.device
     if splits is None:
         splits = default_splits(n, h, w, cin, cout, ksize, prec, bias_grad)
@@ -464,6 +502,8 @@ def sn_defer_begin():
 def sn_defer_check(who: str):
     """ a reader of ``.grad`` -- the gradient exchange, an optimizer step -- must not run while deferred spectral-norm jobs are
     pending: the conv weights' gradients are incomplete until ``nn.fused_grad_accumulation`` is left.  Raises instead of reading them early."""
+    if _WG_DEFER['jobs']:
+        raise RuntimeError(f'{who}: {len(_WG_DEFER["jobs"])} deferred weight-gradient launches are pending (hipops.wgrad_defer without wgrad_flush)')
     if _SN_DEFER['jobs']:
         raise RuntimeError(f'{who}: {len(_SN_DEFER["jobs"])} deferred spectral-norm gradient jobs are pending -- .grad of the conv weights is '
                            'incomplete inside nn.fused_grad_accumulation; leave the context (or set LP_SN_DEFER=0) before reading gradients')

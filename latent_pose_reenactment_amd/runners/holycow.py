@@ -5,6 +5,7 @@
 The reference's apex ``Reducer`` is replaced by ``parallel.GradReducer`` (RCCL all-reduce over xGMI of exactly the
 gradients each optimizer is about to consume).  TensorBoard / image-grid logging branches (holycow.py:266-400) are
 observability and out of scope; scalar losses go to ``Meter`` as in the reference."""
+import contextlib
 import copy
 import os
 import itertools
@@ -14,6 +15,7 @@ import time
 import torch
 from torch import nn
 
+from latent_pose_reenactment_amd import hipops as ops
 from latent_pose_reenactment_amd import streams as _streams
 from latent_pose_reenactment_amd.nn import fused_grad_accumulation
 from latent_pose_reenactment_amd.utils import radam as _radam
@@ -267,7 +269,8 @@ def train_step(training_module, data_dict, target_dict, optimizer_G, optimizer_D
     loss_G = sum(v for v in losses_G.values() if isinstance(v, torch.Tensor))
     loss_D = sum(v for v in losses_D.values() if isinstance(v, torch.Tensor))
     optimizer_G.zero_grad()
-    with fused_grad_accumulation(), rng('backward.loss_G'):
+    gwg = ebwd and bool(losses_D) and _gwgrad_enabled(training_module)
+    with fused_grad_accumulation(), rng('backward.loss_G'), (ops.wgrad_defer() if gwg else contextlib.nullcontext()):
         loss_G.backward(retain_graph=True)
     _streams.join_all()
     if ebwd and losses_D:
@@ -280,6 +283,9 @@ def train_step(training_module, data_dict, target_dict, optimizer_G, optimizer_D
         with _streams.branch(dev, 8) as b:
             optimizer_D.zero_grad()
             with fused_grad_accumulation(), rng('backward.loss_D'):
+                # (round 6) the generator's weight gradients, recorded during loss_G.backward (hipops.wgrad_defer), are issued HERE: matrix-bound
+                # launches beside the encoders' bandwidth-bound backward instead of inside the chain that the encoders' backward waits for
+                held = ops.wgrad_flush() if gwg else None
                 loss_D.backward()
             _streams.join_all()
             if early:
@@ -296,6 +302,7 @@ def train_step(training_module, data_dict, target_dict, optimizer_G, optimizer_D
             training_module.embedder_backward()
         _streams.join_all()
         b.join()
+        held = None          # (the deferred launches' operand planes: alive until their stream was joined)
         with rng('optimizer_G.step'):
             optimizer_G.step()
         if not early:
@@ -355,6 +362,12 @@ def _early_updates(training_module, optimizer_G):
         optimizer_G.set_partitions({'generator': gen})
         optimizer_G.__dict__['_lp_gen_key'] = tuple(id(p) for p in gen)
     return True
+
+
+def _gwgrad_enabled(training_module):
+    """the generator's weight gradients deferred to the critic-backward stream (with 'ebwd'; LP_OVERLAP_GWGRAD)"""
+    p = next(iter(training_module.generator.parameters()), None)
+    return p is not None and _streams.enabled(p, 'gwgrad', finetuning=False)
 
 
 def _ebwd_enabled(training_module, args, multi):
@@ -498,7 +511,8 @@ class GraphedTrainStep:
             loss_G = sum(v for v in self.losses_G.values() if isinstance(v, torch.Tensor))
             loss_D = sum(v for v in self.losses_D.values() if isinstance(v, torch.Tensor))
             self.opt_G.zero_grad()
-            with fused_grad_accumulation():
+            self.gwg = self.reducer is None and self.ebwd and bool(self.losses_D) and _gwgrad_enabled(self.tm)
+            with fused_grad_accumulation(), (ops.wgrad_defer() if self.gwg else contextlib.nullcontext()):
                 loss_G.backward(retain_graph=True)
             _streams.join_all()
         pool = self.g1.pool()
@@ -518,6 +532,7 @@ class GraphedTrainStep:
                 with streams.branch(first.device, 8) as b:
                     self.opt_D.zero_grad()
                     with fused_grad_accumulation():
+                        self._held = ops.wgrad_flush() if self.gwg else None          # (see train_step; the operand planes live as long as the graphs)
                         loss_D.backward()
                     _streams.join_all()
                     if self.early:

@@ -45,7 +45,7 @@ def enabled(t, what: str, finetuning: bool = False) -> bool:
     # fp16 operands).  With the bf16x3 generator / critic tail: 22.47 ms one stream, 22.16 dpasses, 21.35 + prepare, 21.39 + real, 19.63 ms + criterions
     # (profiles/r06_stream_overlap.txt) -- on.  'ebwd' has no meaning there (no encoder is trained).
     # 'optimizer' (optimizer_G.step + EMA beside loss_D.backward, graphed step): meta-training +-0 (42.51 vs 42.52 ms), fine-tuning 19.75 -> 19.51 ms -- on there
-    default = '0' if (what in ('wgrad', 'targets') or (what == 'optimizer' and not finetuning) or (what == 'ebwd' and finetuning)) else '1'
+    default = '0' if (what in ('wgrad', 'targets', 'gwgrad') or (what == 'optimizer' and not finetuning) or (what == 'ebwd' and finetuning)) else '1'
     return os.environ.get('LP_OVERLAP_' + what.upper(), default) != '0'
 
 

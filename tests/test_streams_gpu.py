@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'latent_pose_reenactment_amd'))
 pytestmark = pytest.mark.gpu
-KNOBS = ('LP_OVERLAP', 'LP_OVERLAP_ENCODERS', 'LP_OVERLAP_CRITERIONS', 'LP_OVERLAP_OPTIMIZER', 'LP_OVERLAP_WGRAD', 'LP_OVERLAP_TARGETS', 'LP_OVERLAP_PREPARE', 'LP_OVERLAP_DPASSES', 'LP_OVERLAP_REAL', 'LP_OVERLAP_EBWD')
+KNOBS = ('LP_OVERLAP', 'LP_OVERLAP_GWGRAD', 'LP_OVERLAP_EARLY', 'LP_OVERLAP_ENCODERS', 'LP_OVERLAP_CRITERIONS', 'LP_OVERLAP_OPTIMIZER', 'LP_OVERLAP_WGRAD', 'LP_OVERLAP_TARGETS', 'LP_OVERLAP_PREPARE', 'LP_OVERLAP_DPASSES', 'LP_OVERLAP_REAL', 'LP_OVERLAP_EBWD')
 
 
 def _iteration(monkeypatch, env, finetune=False):
@@ -119,5 +119,19 @@ def test_embedder_backward_beside_the_discriminator_backward_reproduces_the_step
     assert plain.keys() == cut.keys()
     floor, sp = _spread(again, plain), _spread(cut, plain)
     print('[streams] EBWD: run to run', {g: f'{v:.1e}' for g, v in floor.items()}, '| cut vs plain', {g: f'{v:.1e}' for g, v in sp.items()})
+    for g, d in sp.items():
+        assert d <= max(20 * floor[g], 1e-2 if g in ('E', 'G') else 1e-5), (g, d, floor[g])
+
+
+def test_generator_weight_gradients_deferred_to_the_critic_backward_stream_reproduce_the_step(monkeypatch):
+    """LP_OVERLAP_GWGRAD: the generator's weight-gradient launches are recorded during loss_G.backward (hipops.wgrad_defer) and issued on the critic-backward
+    stream beside the encoders' backward (runners/holycow.py) -- the same kernels on the same operands, one contribution per parameter: same gradients"""
+    plain = _train_step_grads(monkeypatch, {'LP_OVERLAP_GWGRAD': '0'})
+    again = _train_step_grads(monkeypatch, {'LP_OVERLAP_GWGRAD': '0'})
+    late = _train_step_grads(monkeypatch, {'LP_OVERLAP_GWGRAD': '1'})
+    assert plain.keys() == late.keys()
+    floor, sp = _spread(again, plain), _spread(late, plain)
+    same = all(torch.equal(late[k], plain[k]) for k in plain if k.startswith('G.'))
+    print('[streams] GWGRAD: run to run', {g: f'{v:.1e}' for g, v in floor.items()}, '| deferred vs plain', {g: f'{v:.1e}' for g, v in sp.items()}, '| generator gradients bit-identical:', same)
     for g, d in sp.items():
         assert d <= max(20 * floor[g], 1e-2 if g in ('E', 'G') else 1e-5), (g, d, floor[g])
