@@ -785,6 +785,10 @@ class Generator(nn.Module):
         if padding not in ('zero', 'reflection'):
             raise Exception('Incorrect `padding` argument, required `zero` or `reflection`')       # (noBottleneck.py:57-58)
         self.reflect = padding == 'reflection'
+        if self.reflect and gen_constant_input_size < 4:
+            #  nn.ReflectionPad2d(1) accepts maps of >= 2 x 2; the border-correction kernels (csrc/reflect_border.hip) cover >= 4 x 4 --
+            # the shipped 4 x 4 constant input.  Say so here instead of failing with LP_ERR_ARG in the first forward.
+            raise NotImplementedError('gen_padding=\'reflection\' on the HIP path needs gen_constant_input_size >= 4 (the reflection border kernels cover maps of >= 4 x 4)')
         if 'in' not in norm_layer:
             raise NotImplementedError("only norm_layer='in' is implemented on the HIP path")
         assert math.log2(output_image_size / gen_constant_input_size).is_integer(), \

@@ -12,10 +12,14 @@ with open(sys.argv[1]) as f:
         rows.append((int(x['Start_Timestamp']), int(x['End_Timestamp']), x['Kernel_Name']))
 rows.sort()
 marks = [i for i, r in enumerate(rows) if 'mt_step_inc' in r[2]]
-if len(marks) < 14:
+if len(marks) < 26:
     sys.exit('not enough optimizer steps in the trace')
-# marks come in (G, D) pairs; a step = from one D-step marker to the next; take the 4th-from-last full step (inside the timed replays)
-a, b = marks[-9], marks[-7]
+# a step holds 2 markers (G, D) -- 3 when the generator's slice of optimizer_G is stepped on its own (round 6: the early updates beside the
+# encoders' backward) -- so the period is read off the trace: the smallest p for which the kernel counts between consecutive markers repeat
+# with period p over the last replays.  A step = from one marker to the p-th next; take the 4th-from-last full step (inside the timed replays)
+gaps = [marks[i + 1] - marks[i] for i in range(len(marks) - 1)]
+per = next((p for p in (1, 2, 3, 4, 5, 6) if len(gaps) >= 4 * p and all(gaps[-1 - i] == gaps[-1 - i - p] for i in range(3 * p))), 2)
+a, b = marks[-1 - 4 * per], marks[-1 - 3 * per]
 seg = rows[a:b]
 span = (seg[-1][0] - seg[0][0]) / 1e6
 busy = sum(e - s for s, e, _ in seg[:-1]) / 1e6
