@@ -663,6 +663,15 @@ def measured_parity(mode, workload):
                 'note': 'the well-conditioned full-depth check: the same 64 frames and train-mode BatchNorm, the fp64 stock layers evaluated on the HIP '
                         'path\'s own ReLU patterns and max-pool argmax (as the G / D / VGG figures are); gate 1e-2 on the all-parameter gradient '
                         '(tests/test_e1_full_gpu.py)'}
+        if 'pose_encoder_tie_masked' in g:
+            e = g['pose_encoder_tie_masked']
+            grads['pose_encoder_tie_masked'] = {
+                'all_gradients_rel_l2': r3(e['all_gradients_rel']), 'all_gradients_cosine': float(f"{e['all_gradients_cosine']:.9g}"),
+                'worst_parameter_tensor': [e['worst_parameter_tensor'][0], r3(e['worst_parameter_tensor'][1])], 'pose_vector': r3(e['pose_vector']),
+                'plain_all_gradients_rel_l2': r3(g['pose_encoder']['all_gradients_rel']) if 'pose_encoder' in g else None,
+                'stock_fp32_layers_all_gradients_rel_l2': r3(e['stock_fp32_layers_vs_fp64']['all_gradients_rel']),
+                'note': 'MobileNetV2 pose encoder, 8 frames of 256 x 256, train-mode BatchNorm, bf16x3 contractions; the fp64 stock layers evaluated on the '
+                        'HIP path\'s own 35 ReLU6 branch patterns; gate 1e-3 on the all-parameter gradient (tests/test_e2_full_gpu.py)'}
         if gstale:
             grads['stale_reason'] = gwhy
         out['gradients'] = grads

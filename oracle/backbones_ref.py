@@ -77,8 +77,18 @@ def resnext_forward(net, x):
 
 
 # ---------------------------------------------------------------- MobileNetV2 (torchvision mobilenet.py: ConvBNReLU / InvertedResidual)
+def _relu6(x):
+    """ReLU6, or -- tie-masked evaluation (REPLAY['relu6'] = [(linear, saturated) bool NCHW masks in execution order], tests/test_e2_full_gpu.py) --
+    the other implementation's branch decisions: x where it took the linear branch, 6 where it saturated, 0 elsewhere"""
+    if REPLAY is None or 'relu6' not in REPLAY:
+        return F.relu6(x)
+    lin, sat = REPLAY['relu6'].pop(0)
+    assert lin.shape == x.shape, (lin.shape, x.shape)
+    return x * lin.to(x.dtype) + 6.0 * sat.to(x.dtype)
+
+
 def _conv_bn_relu6(seq, x):
-    return F.relu6(_bn(seq[1], _conv(seq[0], x)))
+    return _relu6(_bn(seq[1], _conv(seq[0], x)))
 
 
 def _inverted_residual(blk, x):
