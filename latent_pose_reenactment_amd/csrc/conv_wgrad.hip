@@ -987,22 +987,36 @@ extern "C" int lp_conv16_wgrad(const uint16_t* a_hi, const uint16_t* a_lo, const
 // ---- grouped 3x3 conv (ResNeXt conv2): weight gradient of the block-diagonal formulation (see lp_gconv16_fwd) --------------------
 // conv_wgrad_kernel with diag = 1 leaves slabs [split][9][C][64] (row = output channel, column = input channel inside the row's aligned
 // 64-channel block); the reduction keeps the group's own columns: dw[co][j][t] = osc * sum_s slab[s][t][co][(co % 64) / cg * cg + j].
+// (round 6) 32 columns x 8 split lanes per workgroup: lane r sums splits r, r + 8, ... on four accumulators, the lanes are folded in a fixed order
+// through LDS -- one thread per column walked all S slabs (18 workgroups of dependent L2 loads for the layer-1 shapes: 20 us per layer)
 __global__ __launch_bounds__(256) void gconv_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int S, int C, int cg,
                                                                   const float* __restrict__ out_scale) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;                 // (co, t, j), j fastest: neighbouring lanes read neighbouring columns
-    if (idx >= C * 9 * cg) return;
-    const int j = idx % cg, r = idx / cg;
-    const int t = r % 9, co = r / 9;
-    const size_t slab = (size_t)9 * C * 64;
-    const float* p = part + ((size_t)t * C + co) * 64 + ((co & 63) / cg) * cg + j;
+    __shared__ float red[8][32];
+    const int col = threadIdx.x & 31, lr = threadIdx.x >> 5;
+    const int idx = blockIdx.x * 32 + col;                          // (co, t, j), j fastest: neighbouring lanes read neighbouring columns
+    const bool live = idx < C * 9 * cg;
     float a[4] = {0.f, 0.f, 0.f, 0.f};
-    int k = 0;
-    for (; k + 4 <= S; k += 4) {
+    int j = 0, t = 0, co = 0;
+    if (live) {
+        j = idx % cg; const int r = idx / cg;
+        t = r % 9; co = r / 9;
+        const size_t slab = (size_t)9 * C * 64;
+        const float* p = part + ((size_t)t * C + co) * 64 + ((co & 63) / cg) * cg + j;
+        int k = lr;
+        for (; k + 24 < S; k += 32) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) a[q] += p[(size_t)(k + q) * slab];
+            for (int q = 0; q < 4; ++q) a[q] += p[(size_t)(k + 8 * q) * slab];
+        }
+        for (; k < S; k += 8) a[0] += p[(size_t)k * slab];
     }
-    for (; k < S; ++k) a[0] += p[(size_t)k * slab];
-    dw[((size_t)co * cg + j) * 9 + t] = ((a[0] + a[1]) + (a[2] + a[3])) * (out_scale ? out_scale[0] : 1.f);
+    red[lr][col] = (a[0] + a[1]) + (a[2] + a[3]);
+    __syncthreads();
+    if (lr == 0 && live) {
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) sum += red[r][col];
+        dw[((size_t)co * cg + j) * 9 + t] = sum * (out_scale ? out_scale[0] : 1.f);
+    }
 }
 
 extern "C" long long lp_gconv_wgrad_workspace_bytes(int C, int splits) { return (long long)splits * 9 * C * 64 * 4; }
@@ -1037,6 +1051,6 @@ extern "C" int lp_gconv16_wgrad(const uint16_t* a_hi, const uint16_t* a_lo, cons
     else return lp_set_error(LP_ERR_ARG, "lp_gconv16_wgrad: unknown precision");
     if (rc) return rc;
     const int total = C * 9 * group_size;
-    hipLaunchKernelGGL(gconv_wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, workspace, dw, p.splits, C, group_size, out_scale);
+    hipLaunchKernelGGL(gconv_wgrad_reduce_kernel, dim3((total + 31) / 32), dim3(256), 0, s, workspace, dw, p.splits, C, group_size, out_scale);
     return lp_check_launch("gconv_wgrad_reduce");
 }

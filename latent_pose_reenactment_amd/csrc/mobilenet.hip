@@ -709,13 +709,19 @@ extern "C" int lp_dwconv3x3_dgrad(const float* dy, const float* w, float* da, in
 // (recomputed from the raw input while it is loaded, as in the forward).  Pass 1: the grid's thread count per block is trimmed to a
 // multiple of the C/4 channel quads (C/4 <= 256), so a thread meets the same 4 channels on every step and keeps 9 x 4 partial sums in
 // registers; the block folds its threads per quad through LDS -> part[block][9][C].  Pass 2: fixed-order sum over the blocks.
+// Round 6: a work item is a SEGMENT of DWW_SEG consecutive output pixels of one row (not one pixel): the 3 x 3 window of activated inputs slides
+// along the row in registers, so a stride-1 layer loads 3 new input values per output pixel instead of 9 (the re-reads went through L1 / L2 and
+// bounded the large layers: 160 B of cache traffic per channel quad and pixel for 32 B of tensor), and the activation is applied once per
+// loaded value.  Stride 2: the window advances by two columns, 6 loads per pixel.
 #define DWW_MAXB 512
+#define DWW_SEG 16
 __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ sh,
                                                               const float* __restrict__ dy, float* __restrict__ part, int N, int H, int W, int C,
                                                               int stride, int BT) {
     __shared__ float red[36][256];
     const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride, C4 = C >> 2;
-    const long long total = (long long)N * Ho * Wo * C4;
+    const int nseg = (Wo + DWW_SEG - 1) / DWW_SEG;
+    const long long total = (long long)N * Ho * nseg * C4;
     float acc[9][4];
 #pragma unroll
     for (int k = 0; k < 9; ++k)
@@ -725,28 +731,56 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __res
     if (active) {
         const int c = ((int)threadIdx.x % C4) * 4;                      // BT % C4 == 0 and the grid stride is a multiple of C4: fixed quad
         float4 s = make_float4(1.f, 1.f, 1.f, 1.f), t = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (sc) { s = *(const float4*)(sc + c); t = *(const float4*)(sh + c); }
+        const bool aff = sc != nullptr;
+        if (aff) { s = *(const float4*)(sc + c); t = *(const float4*)(sh + c); }
+        auto load = [&](const float* row, int ix) -> float4 {           // act(x) at column ix of an in-image row (row == nullptr: padding row)
+            if (row == nullptr || ix < 0 || ix >= W) return make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 v = *(const float4*)(row + (size_t)ix * C);
+            if (aff) {
+                v.x = fminf(fmaxf(fmaf(v.x, s.x, t.x), 0.f), 6.f); v.y = fminf(fmaxf(fmaf(v.y, s.y, t.y), 0.f), 6.f);
+                v.z = fminf(fmaxf(fmaf(v.z, s.z, t.z), 0.f), 6.f); v.w = fminf(fmaxf(fmaf(v.w, s.w, t.w), 0.f), 6.f);
+            }
+            return v;
+        };
         for (long long i = (long long)blockIdx.x * BT + threadIdx.x; i < total; i += (long long)gridDim.x * BT) {
-            long long pix = i / C4;
-            const int xo = (int)(pix % Wo); pix /= Wo;
-            const int yo = (int)(pix % Ho); const int n = (int)(pix / Ho);
-            const float4 d = *(const float4*)(dy + (size_t)i * 4);
+            long long r = i / C4;
+            const int sg = (int)(r % nseg); r /= nseg;
+            const int yo = (int)(r % Ho); const int n = (int)(r / Ho);
+            const int x0 = sg * DWW_SEG, x1 = min(x0 + DWW_SEG, Wo);
+            const float* rows[3];
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
+            for (int ky = 0; ky < 3; ++ky) {
+                const int iy = yo * stride + ky - 1;
+                rows[ky] = (iy >= 0 && iy < H) ? x + ((size_t)n * H + iy) * W * C + c : nullptr;
+            }
+            const float* drow = dy + (((size_t)n * Ho + yo) * Wo) * C + c;
+            float4 win[3][3];                                           // win[ky][kx] = act(x)[yo*s + ky - 1][xo*s + kx - 1]
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int iy = yo * stride + ky - 1, ix = xo * stride + kx - 1;
-                    if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
-                        float4 v = *(const float4*)(x + (((size_t)n * H + iy) * W + ix) * C + c);
-                        if (sc) {
-                            v.x = fminf(fmaxf(fmaf(v.x, s.x, t.x), 0.f), 6.f); v.y = fminf(fmaxf(fmaf(v.y, s.y, t.y), 0.f), 6.f);
-                            v.z = fminf(fmaxf(fmaf(v.z, s.z, t.z), 0.f), 6.f); v.w = fminf(fmaxf(fmaf(v.w, s.w, t.w), 0.f), 6.f);
-                        }
+            for (int ky = 0; ky < 3; ++ky) {
+                win[ky][1] = load(rows[ky], x0 * stride - 1);           // (shifted into place by the first step of the loop)
+                win[ky][2] = load(rows[ky], x0 * stride);
+            }
+            for (int xo = x0; xo < x1; ++xo) {
+                const float4 d = *(const float4*)(drow + (size_t)xo * C);
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    if (stride == 1) {
+                        win[ky][0] = win[ky][1]; win[ky][1] = win[ky][2];
+                        win[ky][2] = load(rows[ky], xo + 1);
+                    } else {
+                        win[ky][0] = (xo == x0) ? win[ky][1] : win[ky][2];      // column 2*xo - 1 = the previous pixel's column 2*(xo-1) + 1
+                        win[ky][1] = (xo == x0) ? win[ky][2] : load(rows[ky], xo * 2);
+                        win[ky][2] = load(rows[ky], xo * 2 + 1);
+                    }
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
                         const int k = ky * 3 + kx;
+                        const float4 v = win[ky][kx];
                         acc[k][0] = fmaf(d.x, v.x, acc[k][0]); acc[k][1] = fmaf(d.y, v.y, acc[k][1]);
                         acc[k][2] = fmaf(d.z, v.z, acc[k][2]); acc[k][3] = fmaf(d.w, v.w, acc[k][3]);
                     }
                 }
+            }
         }
     }
 #pragma unroll
@@ -765,19 +799,35 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __res
     }
 }
 
+// Pass 2: dw[c][k] = sum over the blocks' partials in a FIXED order.  32 (k, c) columns x 8 row lanes per workgroup: lane r sums blocks r, r + 8, ...
+// on four independent accumulators, the eight lanes are folded in order through LDS (round 6: one thread per column walked all <= 512 partials
+// through two accumulators -- 4 .. 34 workgroups of dependent L2 loads, 30 us per layer).
 __global__ __launch_bounds__(256) void dwconv3x3_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int blocks, int C) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;                    // (k, c), c fastest: coalesced reads of the partials
-    if (idx >= 9 * C) return;
-    const int c = idx % C, k = idx / C;
-    float a0 = 0.f, a1 = 0.f;
-    int b = 0;
-    for (; b + 1 < blocks; b += 2) { a0 += part[((size_t)b * 9 + k) * C + c]; a1 += part[((size_t)(b + 1) * 9 + k) * C + c]; }
-    if (b < blocks) a0 += part[((size_t)b * 9 + k) * C + c];
-    dw[(size_t)c * 9 + k] = a0 + a1;
+    __shared__ float red[8][32];
+    const int col = threadIdx.x & 31, lr = threadIdx.x >> 5;
+    const int n = 9 * C;
+    const int idx = blockIdx.x * 32 + col;                              // (k, c), c fastest: part[b][k][c] = part[b * 9C + idx]
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (idx < n) {
+        const float* p = part + idx;
+        int b = lr;
+        for (; b + 24 < blocks; b += 32) {
+            a0 += p[(size_t)b * n]; a1 += p[(size_t)(b + 8) * n]; a2 += p[(size_t)(b + 16) * n]; a3 += p[(size_t)(b + 24) * n];
+        }
+        for (; b < blocks; b += 8) a0 += p[(size_t)b * n];
+    }
+    red[lr][col] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (lr == 0 && idx < n) {
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) sum += red[r][col];
+        dw[(size_t)(idx % C) * 9 + idx / C] = sum;
+    }
 }
 
 static int dww_blocks(long long total, int BT) {
-    long long nb = (total + 8ll * BT - 1) / (8ll * BT);
+    long long nb = (total + BT - 1) / BT;                                // (items are DWW_SEG-pixel row segments: one per thread where there are enough)
     return (int)(nb > DWW_MAXB ? DWW_MAXB : (nb < 1 ? 1 : nb));
 }
 
@@ -789,13 +839,14 @@ extern "C" int lp_dwconv3x3_wgrad(const float* x, const float* in_scale, const f
     if ((C & 3) || C > 1024 || (stride != 1 && stride != 2) || (!in_scale != !in_shift))
         return lp_set_error(LP_ERR_UNSUPPORTED, "lp_dwconv3x3_wgrad: needs C % 4 == 0, C <= 1024, stride 1|2");
     const int C4 = C >> 2, BT = 256 - 256 % C4;
-    const long long total = (long long)N * ((H + stride - 1) / stride) * ((W + stride - 1) / stride) * C4;
+    const int Wo_ = (W + stride - 1) / stride;
+    const long long total = (long long)N * ((H + stride - 1) / stride) * ((Wo_ + DWW_SEG - 1) / DWW_SEG) * C4;
     const int blocks = dww_blocks(total, BT);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(dwconv3x3_wgrad_kernel, dim3(blocks), dim3(256), 0, st, x, in_scale, in_shift, dy, workspace, N, H, W, C, stride, BT);
     int rc = lp_check_launch("dwconv3x3_wgrad");
     if (rc) return rc;
-    hipLaunchKernelGGL(dwconv3x3_wgrad_reduce_kernel, dim3((9 * C + 255) / 256), dim3(256), 0, st, workspace, dw, blocks, C);
+    hipLaunchKernelGGL(dwconv3x3_wgrad_reduce_kernel, dim3((9 * C + 31) / 32), dim3(256), 0, st, workspace, dw, blocks, C);
     return lp_check_launch("dwconv3x3_wgrad_reduce");
 }
 
