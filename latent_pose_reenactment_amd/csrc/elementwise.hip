@@ -232,12 +232,17 @@ __global__ __launch_bounds__(256) void instnorm_partial_kernel(const float* __re
     }
 }
 
-// one WAVE per (n, c): the lanes split the S partials (a BatchNorm over 10^6 positions has 1024 of them), merge pairwise in fp64
+// one WAVE per (n, c): the lanes split the S partials (a BatchNorm over 10^6 positions has 1024 of them), merge pairwise in fp64.
+// WPC = 4 (round 6, S >= 256: the train-mode BatchNorms of the identity encoder's stem / first two stages leave 512 .. 8192 partials per channel
+// and have 64 .. 512 channels): one WORKGROUP per (n, c), its four waves' sums folded in order through LDS -- these launches sit between every
+// conv and its consumer and were a few dozen waves walking 32 .. 128 rounds of strided loads each (8 us mean, 90 us for the stem).
+template <int WPC = 1>
 __global__ __launch_bounds__(256) void instnorm_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma, const float* __restrict__ beta,
                                          int ab_stride, float eps, float* __restrict__ mean, float* __restrict__ rstd,
                                          float* __restrict__ scale, float* __restrict__ shift, int N, int C, int S,
                                          float* __restrict__ run_mean = nullptr, float* __restrict__ run_var = nullptr, float momentum = 0.f) {
-    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int idx = WPC == 4 ? (int)blockIdx.x : blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = WPC == 4 ? (int)threadIdx.x : (threadIdx.x & 63), LANES = 64 * WPC;
     if (idx >= N * C) return;
     int n = idx / C, c = idx % C;
     // {count, mean, M2} partials -> shifted sums about ONE reference (the first partial's mean, the same for all lanes):
@@ -248,12 +253,20 @@ __global__ __launch_bounds__(256) void instnorm_finalize_kernel(const float* __r
     const double ref = part[((size_t)n * S * C + c) * 3 + 1];
     double na = 0, s1 = 0, s2 = 0;
 #pragma unroll 4
-    for (int s = lane; s < S; s += 64) {
+    for (int s = lane; s < S; s += LANES) {
         const float* q = part + (((size_t)n * S + s) * C + c) * 3;
         const double nb = q[0], d = (double)q[1] - ref;
         na += nb; s1 = fma(nb, d, s1); s2 += (double)q[2] + nb * d * d;
     }
     for (int o = 32; o > 0; o >>= 1) { na += __shfl_down(na, o, 64); s1 += __shfl_down(s1, o, 64); s2 += __shfl_down(s2, o, 64); }
+    if (WPC == 4) {          // the four waves' sums, in wave order
+        __shared__ double wsum[4][3];
+        if ((threadIdx.x & 63) == 0) { wsum[threadIdx.x >> 6][0] = na; wsum[threadIdx.x >> 6][1] = s1; wsum[threadIdx.x >> 6][2] = s2; }
+        __syncthreads();
+        na = ((wsum[0][0] + wsum[1][0]) + wsum[2][0]) + wsum[3][0];
+        s1 = ((wsum[0][1] + wsum[1][1]) + wsum[2][1]) + wsum[3][1];
+        s2 = ((wsum[0][2] + wsum[1][2]) + wsum[2][2]) + wsum[3][2];
+    }
     const double ma = ref + s1 / na;
     double qa = s2 - s1 * s1 / na;
     if (qa < 0) qa = 0;
@@ -288,8 +301,8 @@ extern "C" int lp_instnorm_stats(const float* x, const float* gamma, const float
     hipLaunchKernelGGL(instnorm_partial_kernel, dim3(S, (C + 63) / 64, N), dim3(256), 0, st, x, workspace, HW, C, S, PB);
     int rc = lp_check_launch("instnorm_partial");
     if (rc) return rc;
-    hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(cdiv((long long)N * C, 4)), dim3(256), 0, st, workspace, gamma, beta, ab_stride,
-                       eps, mean, rstd, scale, shift, N, C, S);
+    hipLaunchKernelGGL(instnorm_finalize_kernel<1>, dim3(cdiv((long long)N * C, 4)), dim3(256), 0, st, workspace, gamma, beta, ab_stride,
+                       eps, mean, rstd, scale, shift, N, C, S, nullptr, nullptr, 0.f);
     return lp_check_launch("instnorm_finalize");
 }
 
@@ -301,8 +314,12 @@ extern "C" int lp_norm_stats_finalize(const float* part, int S, const float* gam
                                       int N, int C, void* stream) {
     if (!part || !mean || !rstd || S < 1) return lp_set_error(LP_ERR_ARG, "lp_norm_stats_finalize: null pointer");
     if (!running_mean != !running_var || (running_mean && N != 1)) return lp_set_error(LP_ERR_ARG, "lp_norm_stats_finalize: running statistics need N == 1");
-    hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(cdiv((long long)N * C, 4)), dim3(256), 0, (hipStream_t)stream, part, gamma, beta, ab_stride,
-                       eps, mean, rstd, scale, shift, N, C, S, running_mean, running_var, momentum);
+    if (S >= 256 && (long long)N * C <= 65535)
+        hipLaunchKernelGGL(instnorm_finalize_kernel<4>, dim3(N * C), dim3(256), 0, (hipStream_t)stream, part, gamma, beta, ab_stride,
+                           eps, mean, rstd, scale, shift, N, C, S, running_mean, running_var, momentum);
+    else
+        hipLaunchKernelGGL(instnorm_finalize_kernel<1>, dim3(cdiv((long long)N * C, 4)), dim3(256), 0, (hipStream_t)stream, part, gamma, beta, ab_stride,
+                           eps, mean, rstd, scale, shift, N, C, S, running_mean, running_var, momentum);
     return lp_check_launch("norm_stats_finalize");
 }
 
@@ -323,7 +340,7 @@ extern "C" int lp_bn_train_stats(const float* y, const float* gamma, const float
     hipLaunchKernelGGL(instnorm_partial_kernel, dim3(S, (C + 63) / 64, 1), dim3(256), 0, st, y, workspace, HW, C, S, PB);
     int rc = lp_check_launch("bn_stats_partial");
     if (rc) return rc;
-    hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, workspace, gamma, beta, C, eps, mean, rstd, scale, shift,
+    hipLaunchKernelGGL(instnorm_finalize_kernel<1>, dim3(cdiv(C, 4)), dim3(256), 0, st, workspace, gamma, beta, C, eps, mean, rstd, scale, shift,
                        1, C, S, running_mean, running_var, momentum);
     return lp_check_launch("bn_stats_finalize");
 }
