@@ -301,3 +301,36 @@ def test_roctx_ranges_are_a_noop_when_off_and_bind_libroctx_when_on():
     for flag, want in (('0', 'enabled False'), ('1', 'enabled True')):
         r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, LP_ROCTX=flag), capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and want in r.stdout, (flag, r.stdout, r.stderr[-500:])
+
+
+def test_step_breakdown_reads_the_marker_period_off_the_trace(tmp_path):
+    """scripts/step_breakdown.py segments a rocprofv3 kernel trace into steps by the optimizer-step markers; a step holds 2 markers (G, D) or 3 (the
+    generator's slice of optimizer_G stepped on its own since round 6), the kernels of concurrent streams interleave a little differently from replay to
+    replay, and bench.py ends with two eager instrumented steps whose kernel counts differ: the script must still cut out ONE full graph replay"""
+    import csv
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for marks_per_step, segs in ((3, (50, 30, 20)), (2, (70, 30))):
+        rows, t = [], 0
+
+        def k(name, d=10):
+            nonlocal t
+            rows.append((t, t + d, name)); t += d + 2
+        for step in range(16):
+            eager_tail = step >= 14          # the last two steps: other kernel counts (the instrumented eager steps)
+            for si, n in enumerate(segs):
+                for i in range(n + (step % 2 if si == 0 and not eager_tail else 0) + (7 if eager_tail else 0)):      # +-1 kernel of interleaving jitter
+                    k(f'conv_{si}(float*)')
+                k('mt_step_inc_kernel(int*)')
+        path = tmp_path / f'trace{marks_per_step}.csv'
+        with open(path, 'w') as f:
+            w = csv.writer(f)
+            w.writerow(['Start_Timestamp', 'End_Timestamp', 'Kernel_Name'])
+            w.writerows(rows)
+        r = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'step_breakdown.py'), str(path)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        head = r.stdout.splitlines()[0]
+        kernels = int(head.rsplit('kernels', 1)[1])
+        assert f'period {marks_per_step}' in r.stderr, r.stderr
+        assert abs(kernels - (sum(segs) + marks_per_step - 1)) <= 2, (head, r.stderr)
